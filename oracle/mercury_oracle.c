@@ -1,0 +1,737 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.  See mercury_oracle.h for the parity statement.
+ *
+ * CPU restatement of Rhizomatica/mercury's physical-layer RX hot path, written to perform the
+ * SAME floating-point operations in the SAME order as the reference so that results are
+ * bit-identical to the compiled reference (checked by tests/test_oracle_vs_ref.py and the
+ * fixtures under tests/golden/).  Every function cites the reference lines it follows
+ * (paths relative to /root/reference).
+ */
+#define _GNU_SOURCE
+#include "mercury_oracle.h"
+
+#include <complex.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define N_MAX 1600
+#define PILOT 1
+#define DATA 0
+#define ST_UNKNOWN 0
+#define ST_MEASURED 1
+#define ST_INTERP 2
+#define EST_ZF 0
+#define EST_LS 1
+
+typedef double complex cd;
+
+/* ------------------------------------------------------------------------------------ */
+/* glibc TYPE_3 additive feedback generator — source/common/os_interop.cc:157-283,379-415 */
+typedef struct { int32_t st[31]; int f, r; } prng_t;
+
+static int32_t prng_next(prng_t* p) {
+    uint32_t val = (uint32_t)p->st[p->f] + (uint32_t)p->st[p->r];
+    p->st[p->f] = (int32_t)val;
+    int32_t result = (int32_t)(val >> 1);
+    p->f++;
+    if (p->f >= 31) { p->f = 0; p->r++; }
+    else { p->r++; if (p->r >= 31) p->r = 0; }
+    return result;
+}
+static void prng_seed(prng_t* p, unsigned seed) {
+    if (seed == 0) seed = 1;                      /* os_interop.cc:251-252 */
+    p->st[0] = (int32_t)seed;
+    int32_t word = (int32_t)seed;
+    for (int i = 1; i < 31; i++) {                /* os_interop.cc:260-271 */
+        long hi = word / 127773, lo = word % 127773;
+        word = (int32_t)(16807 * lo - 2836 * hi);
+        if (word < 0) word += 2147483647;
+        p->st[i] = word;
+    }
+    p->f = 3; p->r = 0;                           /* SEP_3 = 3 */
+    for (int k = 0; k < 310; k++) (void)prng_next(p);
+}
+
+void morc_prng(unsigned seed, int n, int* out) {
+    prng_t p; prng_seed(&p, seed);
+    for (int i = 0; i < n; i++) out[i] = prng_next(&p);
+}
+
+/* CRC16 — source/physical_layer/crc16_modbus_rtu.cc:25-45 */
+unsigned morc_crc16(const int* b, int n) {
+    uint16_t crc = 0xffff;
+    for (int j = 0; j < n; j++) {
+        crc ^= (b[j] & 0xFF);
+        for (int i = 0; i < 8; i++) {
+            if (crc & 1) { crc >>= 1; crc ^= 0xA001; } else crc >>= 1;
+        }
+    }
+    return crc;
+}
+
+/* ------------------------------------------------------------------------------------ */
+struct morc {
+    int cfg, M, bps, K, P, N, max_iters;
+    int Nsymb, Nc, Nfft, Ngi, Nofdm, nData, nBits, nPilots, nVirtual, nReal;
+    int bit_blk, tf_blk, preamble, estimator, amp_restore, lsw;
+    int Cwidth, Vwidth;
+    int* type;          /* [Nsymb*Nc] */
+    cd* pilot_seq;      /* [nPilots] */
+    cd* pilot_grid;     /* [Nsymb*Nc] pilot value at pilot cells */
+    cd constellation[64];
+    int scrambler[N_MAX];
+    cd tw[128];
+    int bitrev[256];
+    /* LDPC graph, reference layout (padded with -1) */
+    int *C, *V, *Vdeg, *Cdeg;
+    double *R, *Q;
+    int* Vpos;
+    /* work */
+    cd *grid, *eq, *eq_noamp, *H, *Hna, *deframed, *tfd, *framed, *tfi, *modulated;
+    int* Hst;
+};
+
+static const signed char QAM32[32][2] = {  /* psk.cc:124-157 */
+    {-3,5},{-1,5},{-3,-5},{-1,-5},{-5,3},{-5,1},{-5,-3},{-5,-1},{-1,3},{-1,1},{-1,-3},{-1,-1},
+    {-3,3},{-3,1},{-3,-3},{-3,-1},{3,5},{1,5},{3,-5},{1,-5},{5,3},{5,1},{5,-3},{5,-1},
+    {1,3},{1,1},{1,-3},{1,-1},{3,3},{3,1},{3,-3},{3,-1}};
+
+/* psk.cc:65-227 (predefined tables) + :229-256 (normalisation through a FLOAT accumulator) */
+static void build_constellation(morc* o) {
+    int M = o->M;
+    cd* c = o->constellation;
+    if (M == 2) { c[0] = 1; c[1] = -1; }
+    else if (M == 4) { c[0] = -1 + 1*I; c[1] = -1 - 1*I; c[2] = 1 + 1*I; c[3] = 1 - 1*I; }
+    else if (M == 8) {
+        double s2 = sqrt(2.0);
+        /* complex(-1,-1) * sqrt(2.0) / 2.0 : component-wise, multiply then divide */
+        c[0] = (-1 * s2) / 2.0 + ((-1 * s2) / 2.0) * I;
+        c[1] = -1; c[2] = CMPLX(0.0, 1.0);
+        c[3] = (-1 * s2) / 2.0 + ((1 * s2) / 2.0) * I;
+        c[4] = CMPLX(0.0, -1.0);
+        c[5] = (1 * s2) / 2.0 + ((-1 * s2) / 2.0) * I;
+        c[6] = (1 * s2) / 2.0 + ((1 * s2) / 2.0) * I;
+        c[7] = 1;
+    } else if (M == 16) {  /* psk.cc:105-121: idx=b3b2b1b0, I=(b3?+:-)(b2?1:3), Q=(b1?-:+)(b0?1:3) */
+        for (int s = 0; s < 16; s++) {
+            double re = ((s & 8) ? 1.0 : -1.0) * ((s & 4) ? 1.0 : 3.0);
+            double im = ((s & 2) ? -1.0 : 1.0) * ((s & 1) ? 1.0 : 3.0);
+            c[s] = re + im * I;
+        }
+    } else if (M == 32) {
+        for (int s = 0; s < 32; s++) c[s] = (double)QAM32[s][0] + (double)QAM32[s][1] * I;
+    }
+    float pnv = 0;
+    for (int i = 0; i < M; i++) pnv += creal(c[i]) * creal(c[i]) + cimag(c[i]) * cimag(c[i]);
+    pnv = 1 / (sqrt(pnv / M));   /* float/int -> float; ::sqrt(double); 1/double -> float */
+    for (int i = 0; i < M; i++) c[i] = (creal(c[i]) * (double)pnv) + (cimag(c[i]) * (double)pnv) * I;
+}
+
+/* cl_pilot_configurator::configure + init — ofdm.cc:904-952, :976-1064 */
+static void build_pilots(morc* o) {
+    int Nc = o->Nc, Ns = o->Nsymb, Dx = 1, Dy = 3;
+    int Ncm = Nc > Ns ? Nc : Ns;
+    int* vc = calloc((size_t)Ncm * Ncm, sizeof(int));
+    int x = 0, y = 0;
+    while (x < Ncm && y < Ncm) {
+        vc[y * Ncm + x] = PILOT;
+        for (int j = y; j < Ncm; j += Dy) vc[j * Ncm + x] = PILOT;
+        for (int j = y; j >= 0; j -= Dy) vc[j * Ncm + x] = PILOT;
+        y++; x += Dx;
+    }
+    int pc = 0;
+    for (int j = 0; j < Ns; j++) if (vc[j * Ncm + Nc - 1] == PILOT) pc++;
+    if (pc < 2)  /* last_col AUTO_SELLECT -> COPY_FIRST_COL (never triggers for the 17 modes) */
+        for (int j = 0; j < Ncm; j++) vc[j * Ncm + Nc - 1] = vc[j * Ncm + 0];
+    o->type = malloc(sizeof(int) * Ns * Nc);
+    o->nPilots = 0;
+    for (int j = 0; j < Ns; j++)
+        for (int i = 0; i < Nc; i++) {
+            o->type[j * Nc + i] = vc[j * Ncm + i];
+            if (vc[j * Ncm + i] == PILOT) o->nPilots++;
+        }
+    o->nData = Ns * Nc - o->nPilots;
+    free(vc);
+    /* DBPSK pilot sequence — ofdm.cc:940-951; boost is float 1.33 widened (physical_config.h:53) */
+    float boostf = 1.33;
+    double boost = boostf;
+    o->pilot_seq = malloc(sizeof(cd) * o->nPilots);
+    prng_t p; prng_seed(&p, 0);
+    int last = 0;
+    for (int i = 0; i < o->nPilots; i++) {
+        int pv = (prng_next(&p) % 2) ^ last;
+        o->pilot_seq[i] = ((double)(2 * pv - 1) * boost) + (0.0 * boost) * I;
+        last = pv;
+    }
+    o->pilot_grid = calloc((size_t)Ns * Nc, sizeof(cd));
+    int pi = 0;
+    for (int c = 0; c < Ns * Nc; c++) if (o->type[c] == PILOT) o->pilot_grid[c] = o->pilot_seq[pi++];
+}
+
+static int load_tables(morc* o, const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    uint32_t hdr[3];
+    if (fread(hdr, 4, 3, f) != 3 || memcmp(hdr, "MLDP", 4) != 0) { fclose(f); return -2; }
+    for (uint32_t r = 0; r < hdr[2]; r++) {
+        uint32_t h[6];
+        if (fread(h, 4, 6, f) != 6) break;
+        uint32_t K = h[0], P = h[1], N = h[2], E = h[3], cw = h[4], vw = h[5];
+        uint8_t* cdeg = malloc(P); uint16_t* Cf = malloc(2 * E);
+        uint8_t* vdeg = malloc(N); uint16_t* Vf = malloc(2 * E);
+        if (fread(cdeg, 1, P, f) != P || fread(Cf, 2, E, f) != E || fread(vdeg, 1, N, f) != N || fread(Vf, 2, E, f) != E) {
+            fclose(f); return -3;
+        }
+        if ((int)K == o->K) {
+            o->Cwidth = cw; o->Vwidth = vw;
+            o->C = malloc(sizeof(int) * P * cw); o->V = malloc(sizeof(int) * N * vw);
+            o->Cdeg = malloc(sizeof(int) * P); o->Vdeg = malloc(sizeof(int) * N);
+            size_t e = 0;
+            for (uint32_t c = 0; c < P; c++) {
+                o->Cdeg[c] = cdeg[c];
+                for (uint32_t j = 0; j < cw; j++) o->C[c * cw + j] = j < cdeg[c] ? Cf[e++] : -1;
+            }
+            e = 0;
+            for (uint32_t v = 0; v < N; v++) {
+                o->Vdeg[v] = vdeg[v];
+                for (uint32_t j = 0; j < vw; j++) o->V[v * vw + j] = j < vdeg[v] ? Vf[e++] : -1;
+            }
+            o->R = malloc(sizeof(double) * N * vw); o->Q = malloc(sizeof(double) * N * vw);
+            o->Vpos = malloc(sizeof(int) * P * cw);
+        }
+        free(cdeg); free(Cf); free(vdeg); free(Vf);
+    }
+    fclose(f);
+    return o->C ? 0 : -4;
+}
+
+/* mode table telecom_system.cc:2506-2624; sizes :1806-1869, data_container.cc:90-99 */
+static const struct { int M, rate16, preamble, est; } MODES[17] = {
+    {2,1,4,EST_LS},{2,2,4,EST_LS},{2,3,4,EST_LS},{2,4,4,EST_LS},{2,5,4,EST_LS},{2,6,4,EST_LS},{2,8,4,EST_LS},
+    {4,5,4,EST_LS},{4,6,4,EST_LS},{4,8,4,EST_LS},{8,6,3,EST_LS},{8,8,3,EST_LS},{4,14,3,EST_LS},
+    {16,8,2,EST_LS},{8,14,2,EST_LS},{16,14,2,EST_ZF},{32,14,1,EST_ZF}};
+
+morc* morc_create(int cfg, int max_iters, const char* tables_path) {
+    if (cfg < 0 || cfg > 16) return NULL;
+    morc* o = calloc(1, sizeof(morc));
+    o->cfg = cfg; o->M = MODES[cfg].M; o->preamble = MODES[cfg].preamble; o->estimator = MODES[cfg].est;
+    o->max_iters = max_iters;
+    o->amp_restore = (o->M == 2 || o->M == 4 || o->M == 8);   /* telecom_system.cc:2647-2654 */
+    o->N = 1600;
+    o->K = (int)((float)o->N * (MODES[cfg].rate16 / 16.0f));    /* ldpc.cc:65 */
+    o->P = o->N - o->K;
+    o->Nc = 50; o->Nfft = 256; o->Ngi = 16; o->Nofdm = 272;
+    o->Nsymb = o->M == 2 ? 48 : o->M == 4 ? 24 : o->M == 8 ? 16 : o->M == 16 ? 12 : 9;
+    o->bps = o->M == 2 ? 1 : o->M == 4 ? 2 : o->M == 8 ? 3 : o->M == 16 ? 4 : 5;
+    o->lsw = 21;
+    build_pilots(o);
+    build_constellation(o);
+    o->nBits = o->nData * o->bps;
+    o->nVirtual = o->N - o->nBits;
+    o->nReal = o->nBits - o->P;
+    o->bit_blk = o->nBits / 10; o->tf_blk = o->nData / 10;       /* telecom_system.cc:2910-2911 */
+    prng_t p; prng_seed(&p, 0);                                  /* telecom_system.cc:1961-1966 */
+    for (int i = 0; i < o->N; i++) o->scrambler[i] = prng_next(&p) % 2;
+    for (int k = 0; k < 128; k++) {                              /* ofdm.cc:266-271 */
+        double angle = -2.0 * M_PI * k / 256;
+        o->tw[k] = cos(angle) + sin(angle) * I;
+    }
+    for (int i = 0; i < 256; i++) {                              /* ofdm.cc:277-289 */
+        int rev = 0;
+        for (int j = 0; j < 8; j++) if (i & (1 << j)) rev |= 1 << (7 - j);
+        o->bitrev[i] = rev;
+    }
+    if (load_tables(o, tables_path) != 0) { free(o); return NULL; }
+    int g = o->Nsymb * o->Nc;
+    o->grid = malloc(sizeof(cd) * g); o->eq = malloc(sizeof(cd) * g); o->eq_noamp = malloc(sizeof(cd) * g);
+    o->H = malloc(sizeof(cd) * g); o->Hna = malloc(sizeof(cd) * g); o->Hst = malloc(sizeof(int) * g);
+    o->deframed = malloc(sizeof(cd) * g); o->tfd = malloc(sizeof(cd) * g);
+    o->framed = malloc(sizeof(cd) * g); o->tfi = malloc(sizeof(cd) * g); o->modulated = malloc(sizeof(cd) * g);
+    return o;
+}
+
+void morc_destroy(morc* o) {
+    if (!o) return;
+    free(o->type); free(o->pilot_seq); free(o->pilot_grid); free(o->C); free(o->V); free(o->Cdeg); free(o->Vdeg);
+    free(o->R); free(o->Q); free(o->Vpos); free(o->grid); free(o->eq); free(o->eq_noamp); free(o->H); free(o->Hna);
+    free(o->Hst); free(o->deframed); free(o->tfd); free(o->framed); free(o->tfi); free(o->modulated);
+    free(o);
+}
+
+void morc_get_info(morc* o, morc_info* i) {
+    i->cfg = o->cfg; i->M = o->M; i->bits_per_symbol = o->bps; i->K = o->K; i->P = o->P; i->N = o->N;
+    i->Nsymb = o->Nsymb; i->Nc = o->Nc; i->Nfft = o->Nfft; i->Ngi = o->Ngi; i->Nofdm = o->Nofdm;
+    i->nData = o->nData; i->nBits = o->nBits; i->nPilots = o->nPilots; i->nVirtual = o->nVirtual; i->nReal = o->nReal;
+    i->bit_blk = o->bit_blk; i->tf_blk = o->tf_blk; i->preamble_nsymb = o->preamble;
+    i->estimator = o->estimator; i->amp_restore = o->amp_restore; i->ls_window = o->lsw;
+    i->Cwidth = o->Cwidth; i->Vwidth = o->Vwidth; i->dwidth = 0;
+    i->payload_bytes = (o->nReal - 16) / 8;
+}
+void morc_get_frame_types(morc* o, int* t) { memcpy(t, o->type, sizeof(int) * o->Nsymb * o->Nc); }
+void morc_get_pilot_seq(morc* o, double* s) { memcpy(s, o->pilot_seq, sizeof(cd) * o->nPilots); }
+void morc_get_scrambler(morc* o, int* s) { memcpy(s, o->scrambler, sizeof(int) * N_MAX); }
+void morc_get_constellation(morc* o, double* c) { memcpy(c, o->constellation, sizeof(cd) * o->M); }
+
+/* ------------------------------------------------------------------------------------ */
+/* complex multiply exactly as libgcc's __muldc3 does for finite operands */
+static inline cd cmul(cd a, cd b) {
+    double ar = creal(a), ai = cimag(a), br = creal(b), bi = cimag(b);
+    return (ar * br - ai * bi) + (ar * bi + ai * br) * I;
+}
+
+/* _fft_fast / _ifft_fast — ofdm.cc:310-340, :343-377 */
+static void fft256(const morc* o, cd* v, int inverse) {
+    for (int i = 0; i < 256; i++) if (i < o->bitrev[i]) { cd t = v[i]; v[i] = v[o->bitrev[i]]; v[o->bitrev[i]] = t; }
+    for (int size = 2; size <= 256; size *= 2) {
+        int half = size / 2, step = 256 / size;
+        for (int i = 0; i < 256; i += size)
+            for (int j = 0; j < half; j++) {
+                cd w = o->tw[j * step];
+                if (inverse) w = conj(w);
+                cd t = cmul(w, v[i + j + half]);
+                v[i + j + half] = v[i + j] - t;
+                v[i + j] = v[i + j] + t;
+            }
+    }
+}
+
+/* interleaver.cc:25-75 / :77-109 — the same index rule for every element type */
+#define DEF_INTERLEAVE(name, T)                                                      \
+    static void name(const T* in, T* out, int n, int bs, int de) {                   \
+        int nb = n / bs;                                                             \
+        for (int i = 0; i < nb; i++)                                                 \
+            for (int j = 0; j < bs; j++) {                                           \
+                if (de) out[i * bs + j] = in[j * nb + i];                            \
+                else out[j * nb + i] = in[i * bs + j];                               \
+            }                                                                        \
+        for (int i = nb * bs; i < n; i++) out[i] = in[i];                            \
+    }
+DEF_INTERLEAVE(il_int, int)
+DEF_INTERLEAVE(il_float, float)
+DEF_INTERLEAVE(il_cd, cd)
+
+/* cl_ldpc::encode — ldpc.cc:111-132, with QCmatrixEnc[i] == C[i] minus the own parity bit */
+static void ldpc_encode(const morc* o, const int* data, int* enc) {
+    for (int i = 0; i < o->K; i++) enc[i] = data[i];
+    for (int i = 0; i < o->P; i++) {
+        int b = 0;
+        for (int j = 0; j < o->Cdeg[i]; j++) {
+            int v = o->C[i * o->Cwidth + j];
+            if (v != o->K + i) b ^= enc[v];
+        }
+        enc[i + o->K] = b;
+    }
+}
+
+/* TX: telecom_system.cc:114-139 (scramble=0) / :428-470 (scramble=1) */
+void morc_tx(morc* o, const int* bits, int scramble, double* out_c128) {
+    int db[N_MAX], enc[N_MAX], bi[N_MAX];
+    for (int i = 0; i < o->nReal; i++) db[i] = scramble ? (bits[i] ^ o->scrambler[i]) : bits[i];
+    for (int i = 0; i < o->nVirtual; i++) db[o->nReal + i] = db[i];
+    ldpc_encode(o, db, enc);
+    for (int i = 0; i < o->P; i++) enc[o->nReal + i] = enc[i + o->K];
+    il_int(enc, bi, o->nBits, o->bit_blk, 0);
+    for (int i = 0; i < o->nBits; i += o->bps) {                 /* psk.cc:259-272 */
+        unsigned loc = 0;
+        for (int j = 0; j < o->bps; j++) { loc += bi[i + j]; loc <<= 1; }
+        loc >>= 1;
+        o->modulated[i / o->bps] = o->constellation[loc];
+    }
+    il_cd(o->modulated, o->tfi, o->nData, o->tf_blk, 0);
+    int di = 0, pi = 0;                                          /* framer ofdm.cc:814-835 */
+    for (int c = 0; c < o->Nsymb * o->Nc; c++) {
+        if (o->type[c] == DATA) o->framed[c] = o->tfi[di++];
+        else o->framed[c] = o->pilot_seq[pi++];
+    }
+    cd* out = (cd*)out_c128;
+    for (int s = 0; s < o->Nsymb; s++) {                         /* symbol_mod ofdm.cc:855-860 */
+        cd z[256];
+        memset(z, 0, sizeof z);
+        const cd* in = &o->framed[s * o->Nc];
+        for (int j = 0; j < 25; j++) z[j + 256 - 25] = in[j];    /* zero_padder ofdm.cc:379-400 */
+        for (int j = 25; j < 50; j++) z[j - 25 + 1] = in[j];
+        fft256(o, z, 1);
+        cd* y = &out[s * o->Nofdm];
+        for (int j = 0; j < 256; j++) y[j + 16] = z[j];          /* gi_adder ofdm.cc:412-422 */
+        for (int j = 0; j < 16; j++) y[j] = z[j + 256 - 16];
+    }
+}
+
+/* transmit_byte's bit layout — telecom_system.cc:343-382; byte_to_bit misc.cc:93-105 */
+void morc_payload_to_bits(morc* o, const int* payload, int nBytes, int* bits) {
+    int fs = (o->nReal - 16) / 8;
+    int data[N_MAX];
+    for (int i = 0; i < fs; i++) data[i] = i < nBytes ? (payload[i] & 0xff) : 0;
+    for (int i = 0; i < fs; i++) for (int j = 0; j < 8; j++) bits[i * 8 + j] = (data[i] >> j) & 1;
+    unsigned crc = morc_crc16(data, fs);
+    int lsB = crc & 0xff, msB = (crc >> 8) & 0xff;
+    for (int j = 0; j < 8; j++) { bits[fs * 8 + j] = (lsB >> j) & 1; bits[(fs + 1) * 8 + j] = (msB >> j) & 1; }
+    for (int i = fs * 8 + 16; i < o->nReal; i++) bits[i] = 0;
+}
+
+/* interpolate_linear (complex) — interpolator.cc:43-50: a+(b-a)*(x-a_x)/(b_x-a_x) */
+static inline cd lerp(cd a, double ax, cd b, double bx, double x) {
+    cd d = b - a;
+    double m = x - ax, q = bx - ax;
+    cd t = (creal(d) * m) + (cimag(d) * m) * I;
+    t = (creal(t) / q) + (cimag(t) / q) * I;
+    return a + t;
+}
+
+/* interpolate_linear_col — interpolator.cc:163-254 */
+static void interp_col(cd* H, int* st, int maxc, int maxr, int col) {
+    int ls = 0, le = maxr - 1, nl = maxr - 1;
+    while (nl > 0) {
+        for (int i = ls; i < maxr; i++) if (st[i * maxc + col] == ST_MEASURED) { ls = i; break; }
+        for (int i = ls + 1; i < maxr; i++) if (st[i * maxc + col] == ST_MEASURED) { le = i; break; }
+        nl = le - ls;
+        for (int i = ls + 1; i < le; i++) { H[i * maxc + col] = lerp(H[ls * maxc + col], ls, H[le * maxc + col], le, i); st[i * maxc + col] = ST_INTERP; }
+        ls = le;
+    }
+    ls = 0; le = maxr - 1;
+    for (int i = 0; i < maxr; i++) if (st[i * maxc + col] == ST_MEASURED) { ls = i; break; }
+    for (int i = ls + 1; i < maxr; i++) if (st[i * maxc + col] == ST_MEASURED) { le = i; break; }
+    if (ls != 0)
+        for (int i = 0; i < ls; i++) { H[i * maxc + col] = lerp(H[ls * maxc + col], ls, H[le * maxc + col], le, i); st[i * maxc + col] = ST_INTERP; }
+    le = 0; ls = maxr - 1;
+    for (int i = maxr - 1; i >= 0; i--) if (st[i * maxc + col] == ST_MEASURED) { le = i; break; }
+    for (int i = le - 1; i >= 0; i--) if (st[i * maxc + col] == ST_MEASURED) { ls = i; break; }
+    if (le != maxr - 1)
+        for (int i = maxr - 1; i > le; i--) { H[i * maxc + col] = lerp(H[ls * maxc + col], ls, H[le * maxc + col], le, i); st[i * maxc + col] = ST_INTERP; }
+}
+
+/* ZF_channel_estimator — ofdm.cc:1266-1313 */
+static void est_zf(morc* o, const cd* in) {
+    int pi = 0;
+    for (int c = 0; c < o->Nsymb * o->Nc; c++) {
+        if (o->type[c] == PILOT) { o->Hst[c] = ST_MEASURED; o->H[c] = in[c] / o->pilot_seq[pi++]; }
+        else { o->Hst[c] = ST_UNKNOWN; o->H[c] = 0; }
+    }
+    for (int j = 0; j < o->Nc; j++) interp_col(o->H, o->Hst, o->Nc, o->Nsymb, j);
+    /* interpolate_bilinear_matrix over [j, j+Dx] with Dx=1 has no interior columns: no-op */
+}
+
+/* LS_channel_estimator — ofdm.cc:1315-1451; matrix_multiplication misc.cc:73-91 (no conjugate) */
+static void est_ls(morc* o, const cd* in) {
+    int Nc = o->Nc, Ns = o->Nsymb, hw = o->lsw / 2;
+    for (int c = 0; c < Ns * Nc; c++) if (o->type[c] != PILOT) { o->Hst[c] = ST_UNKNOWN; o->H[c] = 0; }
+    cd x[512], y[512];
+    for (int j = 0; j < Nc; j++)
+        for (int i = 0; i < Ns; i++) {
+            if (o->type[i * Nc + j] != PILOT) continue;
+            int n = 0;
+            for (int k = i - hw; k <= i + hw; k++) {
+                if (k < 0 || k >= Ns) continue;
+                for (int l = j - hw; l <= j + hw; l++) {
+                    if (l < 0 || l >= Nc) continue;
+                    if (o->type[k * Nc + l] == PILOT) { x[n] = o->pilot_grid[k * Nc + l]; y[n] = in[k * Nc + l]; n++; }
+                }
+            }
+            cd ch = 0;
+            for (int m = 0; m < n; m++) ch += cmul(x[m], x[m]);
+            ch = (1.0 + 0.0 * I) / ch;
+            for (int m = 0; m < n; m++) x[m] = cmul(x[m], ch);
+            ch = 0;
+            for (int m = 0; m < n; m++) ch += cmul(x[m], y[m]);
+            o->Hst[i * Nc + j] = ST_MEASURED;
+            o->H[i * Nc + j] = ch;
+        }
+    for (int j = 0; j < Nc; j++) interp_col(o->H, o->Hst, Nc, Ns, j);
+}
+
+/* get_angle — misc.cc:34-56 */
+static double get_angle(cd v) {
+    double theta = 0, re = creal(v), im = cimag(v);
+    if (re == 0) theta = M_PI / 2;
+    else if (re > 0) theta = atan(im / re);
+    else if (re < 0 && im >= 0) theta = atan(im / re) + M_PI;
+    else if (re < 0 && im < 0) theta = atan(im / re) - M_PI;
+    return theta;
+}
+
+/* cl_psk::demod — psk.cc:278-326 */
+static void psk_demod(const morc* o, const cd* in, int nItems, float* out, float variance) {
+    float D[64], LLR[8];
+    for (int i = 0; i < nItems; i += o->bps) {
+        cd s = in[i / o->bps];
+        for (int j = 0; j < o->M; j++) {
+            double dr = creal(s) - creal(o->constellation[j]), di = cimag(s) - cimag(o->constellation[j]);
+            D[j] = dr * dr + di * di;
+        }
+        unsigned mask = 1;
+        for (int k = 0; k < o->bps; k++) {
+            float d0 = D[0], d1 = D[mask];
+            for (int j = 0; j < o->M; j++) {
+                if ((j & mask) == 0) { if (D[j] < d0) d0 = D[j]; }
+                if ((j & mask) == mask) { if (D[j] < d1) d1 = D[j]; }
+            }
+            LLR[k] = ((1 / variance) * (d1 - d0));
+            mask <<= 1;
+        }
+        for (int j = 0; j < o->bps; j++) out[i + j] = LLR[o->bps - j - 1];
+    }
+}
+
+/* decode_SPA — ldpc_decoder_SPA.cc:25-218 */
+static int decode_spa(morc* o, const float* LLRi, int* LLRo) {
+    int N = o->N, P = o->P, K = o->K, CW = o->Cwidth, VW = o->Vwidth;
+    int *C = o->C, *V = o->V;
+    double *R = o->R, *Q = o->Q;
+    int Cout[N_MAX], LLRbin[N_MAX];
+    double LLRtmp[N_MAX];
+    int iteration = 0, nOnes;
+    for (int i = 0; i < N; i++) {
+        for (int j = 0; j < VW; j++) { R[i * VW + j] = 0; Q[i * VW + j] = 0; }
+        LLRbin[i] = (LLRi[i] < 0);
+        LLRtmp[i] = LLRi[i];
+    }
+    nOnes = 0;
+    for (int i = 0; i < P; i++) {
+        Cout[i] = LLRbin[C[i * CW]];
+        for (int j = 1; j < CW; j++) if (C[i * CW + j] != -1) Cout[i] ^= LLRbin[C[i * CW + j]];
+        nOnes += Cout[i];
+    }
+    if (nOnes != 0) {
+        for (int ci = 0; ci < P; ci++)
+            for (int cj = 0; cj < CW; cj++) {
+                int v = C[ci * CW + cj];
+                int pos = -1;
+                if (v != -1) for (int vk = 0; vk < VW; vk++) if (V[v * VW + vk] == ci) { pos = vk; break; }
+                o->Vpos[ci * CW + cj] = pos;
+            }
+        for (int i = 0; i < N; i++) for (int j = 0; j < o->Vdeg[i]; j++) Q[i * VW + j] = LLRi[i];
+        for (iteration = 1; iteration <= o->max_iters; iteration++) {
+            for (int ii = 0; ii < P; ii++)
+                for (int ci = 0; ci < CW; ci++) {
+                    int j = C[ii * CW + ci];
+                    if (j == -1) continue;
+                    double temp = 1;
+                    for (int i1i = 0; i1i < CW; i1i++) {
+                        int i1 = C[ii * CW + i1i];
+                        if (i1 != j && i1 != -1) temp *= tanh(0.5 * Q[i1 * VW + o->Vpos[ii * CW + i1i]]);
+                    }
+                    if (temp == 1) temp = 0.9999999;
+                    if (temp == -1) temp = -0.9999999;
+                    R[j * VW + o->Vpos[ii * CW + ci]] = 2 * atanh(temp);
+                }
+            for (int i = 0; i < N; i++) {
+                LLRtmp[i] = LLRi[i];
+                for (int j = 0; j < VW; j++) LLRtmp[i] += R[i * VW + j];
+                LLRbin[i] = (LLRtmp[i] < 0);
+            }
+            nOnes = 0;
+            for (int i = 0; i < P; i++) {
+                Cout[i] = LLRbin[C[i * CW]];
+                for (int j = 1; j < CW; j++) if (C[i * CW + j] != -1) Cout[i] ^= LLRbin[C[i * CW + j]];
+                nOnes += Cout[i];
+            }
+            if (nOnes == 0) break;
+            for (int i = 0; i < N; i++) for (int j = 0; j < o->Vdeg[i]; j++) Q[i * VW + j] = LLRtmp[i] - R[i * VW + j];
+        }
+    }
+    for (int i = 0; i < K; i++) LLRo[i] = (LLRtmp[i] < 0);
+    return iteration;
+}
+
+/* decode_GBF — ldpc_decoder_GBF.cc:25-117, eta = 0.5 (physical_config.cc:73) */
+static int decode_gbf(morc* o, const float* LLRi, int* LLRo) {
+    int N = o->N, P = o->P, K = o->K, CW = o->Cwidth;
+    int* C = o->C;
+    int Cout[N_MAX], LLRbin[N_MAX], delta[N_MAX] = {0};
+    float LLRtmp[N_MAX];
+    float eta = 0.5;
+    int iteration = 0, nOnes = 0;
+    for (int i = 0; i < N; i++) { LLRtmp[i] = LLRi[i]; LLRbin[i] = (LLRtmp[i] < 0); }
+    for (int i = 0; i < P; i++) {
+        Cout[i] = LLRbin[C[i * CW]];
+        for (int j = 1; j < CW; j++) if (C[i * CW + j] != -1) Cout[i] ^= LLRbin[C[i * CW + j]];
+        nOnes += Cout[i];
+    }
+    if (nOnes != 0) {
+        for (iteration = 1; iteration <= o->max_iters; iteration++) {
+            nOnes = 0;
+            for (int i = 0; i < N; i++) LLRbin[i] = (LLRtmp[i] < 0);
+            for (int i = 0; i < P; i++) {
+                Cout[i] = LLRbin[C[i * CW]];
+                for (int j = 1; j < CW; j++) if (C[i * CW + j] != -1) Cout[i] ^= LLRbin[C[i * CW + j]];
+                nOnes += Cout[i];
+                for (int j = 0; j < CW; j++) if (C[i * CW + j] != -1) delta[C[i * CW + j]] += 2 * Cout[i] - 1;
+            }
+            if (nOnes == 0) break;
+            for (int i = 0; i < N; i++) {
+                LLRtmp[i] += (delta[i] > 0) * (2 * (LLRtmp[i] < 0) - 1) * delta[i] * eta;
+                delta[i] = 0;
+            }
+        }
+    }
+    for (int i = 0; i < K; i++) LLRo[i] = (LLRtmp[i] < 0);
+    return iteration;
+}
+
+int morc_ldpc_decode(morc* o, const float* llr, int* bits, int alg) {
+    return alg == MORC_DEC_GBF ? decode_gbf(o, llr, bits) : decode_spa(o, llr, bits);
+}
+
+/* The hot path: telecom_system.cc:155-198 (flags=0) and :1132-1345 (flags = AGC|VAR_EQ) */
+void morc_rx(morc* o, const double* baseband_c128, int flags, morc_rx_out* out) {
+    const cd* bb = (const cd*)baseband_c128;
+    int Nc = o->Nc, Ns = o->Nsymb, G = Ns * Nc;
+    /* symbol_demod ofdm.cc:862-867 = gi_remover :423-429 + fft :431-444 + zero_depadder :401-411 */
+    for (int s = 0; s < Ns; s++) {
+        cd v[256];
+        for (int j = 0; j < 256; j++) v[j] = bb[s * o->Nofdm + j + 16];
+        fft256(o, v, 0);
+        for (int j = 0; j < 256; j++) v[j] = (creal(v[j]) / 256.0) + (cimag(v[j]) / 256.0) * I;
+        cd* g = &o->grid[s * Nc];
+        for (int j = 0; j < 25; j++) g[j] = v[j + 256 - 25];
+        for (int j = 25; j < 50; j++) g[j] = v[j - 25 + 1];
+    }
+    out->agc_gain = 0;
+    if (flags & MORC_FLAG_AGC) {   /* automatic_gain_control ofdm.cc:1467-1498 */
+        double amp = 0; int n = 0;
+        for (int c = 0; c < G; c++) if (o->type[c] == PILOT) {
+            amp += sqrt(creal(o->grid[c]) * creal(o->grid[c]) + cimag(o->grid[c]) * cimag(o->grid[c])); n++;
+        }
+        amp /= n;
+        float boostf = 1.33; double boost = boostf;
+        double agc = boost / amp;
+        for (int c = 0; c < G; c++) o->grid[c] = (creal(o->grid[c]) * agc) + (cimag(o->grid[c]) * agc) * I;
+        out->agc_gain = agc;
+    }
+    if (out->grid) memcpy(out->grid, o->grid, sizeof(cd) * G);
+    if (o->estimator == EST_ZF) est_zf(o, o->grid); else est_ls(o, o->grid);
+    {   /* telecom_system.cc:1224-1243 */
+        double hs = 0; int n = 0;
+        for (int c = 0; c < G; c++) if (o->Hst[c] == ST_MEASURED) { hs += cabs(o->H[c]); n++; }
+        out->mean_H = n ? hs / n : -1.0;
+    }
+    if (o->amp_restore) {  /* restore_channel_amplitude ofdm.cc:1453-1466; set_complex misc.cc:65-71 */
+        for (int c = 0; c < G; c++) {
+            o->Hna[c] = o->H[c];
+            double th = get_angle(o->H[c]);
+            o->H[c] = (1 * cos(th)) + (1 * sin(th)) * I;
+        }
+        for (int c = 0; c < G; c++) o->eq_noamp[c] = o->grid[c] / o->Hna[c];   /* ofdm.cc:1648-1657 */
+        if (out->H_noamp) memcpy(out->H_noamp, o->Hna, sizeof(cd) * G);
+    }
+    if (out->H) memcpy(out->H, o->H, sizeof(cd) * G);
+    for (int c = 0; c < G; c++) o->eq[c] = o->grid[c] / o->H[c];               /* ofdm.cc:1637-1647 */
+    if (out->eq) memcpy(out->eq, o->eq, sizeof(cd) * G);
+    /* measure_variance ofdm.cc:1500-1521 */
+    const cd* vin = (flags & MORC_FLAG_VAR_EQ) ? o->eq : o->grid;
+    double var = 0; int np = 0;
+    for (int c = 0; c < G; c++) if (o->type[c] == PILOT) {
+        cd d = vin[c] - o->pilot_grid[c];
+        var += creal(d) * creal(d) + cimag(d) * cimag(d); np++;
+    }
+    var /= (double)np;
+    float variance = var;
+    out->variance = var; out->variance_f = variance;
+    /* deframer ofdm.cc:837-852, deinterleaver interleaver.cc:94-109 */
+    int di = 0;
+    for (int c = 0; c < G; c++) if (o->type[c] == DATA) o->deframed[di++] = o->eq[c];
+    il_cd(o->deframed, o->tfd, o->nData, o->tf_blk, 1);
+    if (out->syms) memcpy(out->syms, o->tfd, sizeof(cd) * o->nData);
+    float dem[N_MAX], dei[N_MAX];
+    psk_demod(o, o->tfd, o->nBits, dem, variance);
+    if (out->llr_demod) memcpy(out->llr_demod, dem, sizeof(float) * o->nBits);
+    il_float(dem, dei, o->nBits, o->bit_blk, 1);
+    /* shortening re-pack telecom_system.cc:187-195 / :1300-1308 */
+    for (int i = o->P - 1; i >= 0; i--) dei[i + o->nReal + o->nVirtual] = dei[i + o->nReal];
+    for (int i = 0; i < o->nVirtual; i++) dei[o->nReal + i] = dei[i];
+    if (out->llr_ldpc) memcpy(out->llr_ldpc, dei, sizeof(float) * N_MAX);
+    out->iterations = -1; out->crc = -1; out->all_zeros = -1;
+    if (flags & MORC_FLAG_NO_LDPC) return;
+    int hd[N_MAX], bytes[N_MAX];
+    out->iterations = decode_spa(o, dei, hd);
+    if (out->bits) memcpy(out->bits, hd, sizeof(int) * o->K);
+    /* bit_energy_dispersal interleaver.cc:111-117; bit_to_byte misc.cc:107-130 */
+    for (int i = 0; i < o->nReal; i++) hd[i] ^= o->scrambler[i];
+    int nb = o->nReal;
+    for (int i = 0; i < nb / 8; i++) { bytes[i] = 0; for (int j = 0; j < 8; j++) bytes[i] |= hd[i * 8 + j] << j; }
+    if (nb % 8) { bytes[nb / 8] = 0; for (int j = 0; j < nb % 8; j++) bytes[nb / 8] |= hd[nb - (nb % 8) + j] << j; }
+    /* telecom_system.cc:1319-1341 */
+    out->all_zeros = 1;
+    for (int i = 0; i < nb / 8; i++) if (bytes[i] != 0) { out->all_zeros = 0; break; }
+    out->crc = 0;
+    if (!out->all_zeros) out->crc = morc_crc16(bytes, nb / 8);
+    if (out->bytes) memcpy(out->bytes, bytes, sizeof(int) * ((nb + 7) / 8));
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Synthetic workload generator (the repo's own definition; DESIGN.md §"Synthetic inputs") */
+static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+void morc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void morc_gen_payload(morc* o, uint64_t seed, uint64_t frame, int* payload) {
+    int fs = (o->nReal - 16) / 8;
+    for (int j = 0; j < fs; j++) {
+        uint32_t w[4];
+        morc_philox(seed, (uint32_t)(j >> 4), 0u, (uint32_t)frame, (uint32_t)(frame >> 32), w);
+        payload[j] = (w[(j >> 2) & 3] >> (8 * (j & 3))) & 0xff;
+    }
+}
+
+static inline double gauss_bm(uint32_t a, uint32_t b) {
+    double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0);
+    double u2 = (double)b * (1.0 / 4294967296.0);
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+}
+
+void morc_channel(morc* o, uint64_t seed, uint64_t frame, double noise_amp, int channel, double* frame_c128) {
+    cd* x = (cd*)frame_c128;
+    int n = o->Nsymb * o->Nofdm;
+    if (channel == 1) {
+        uint32_t w[4];
+        morc_philox(seed, 0u, 2u, (uint32_t)frame, (uint32_t)(frame >> 32), w);
+        double phi = 2.0 * M_PI * ((double)w[0] * (1.0 / 4294967296.0));
+        cd h1 = (0.5 * cos(phi)) + (0.5 * sin(phi)) * I;
+        for (int i = n - 1; i >= 6; i--) x[i] = x[i] + cmul(h1, x[i - 6]);
+    }
+    for (int i = 0; i < n; i++) {
+        uint32_t w[4];
+        morc_philox(seed, (uint32_t)i, 1u, (uint32_t)frame, (uint32_t)(frame >> 32), w);
+        double nr = noise_amp * gauss_bm(w[0], w[1]), ni = noise_amp * gauss_bm(w[2], w[3]);
+        /* telecom_system.cc:141-153: scale by 1/sqrt(Nfft), add noise, scale back (exact powers of two) */
+        double re = creal(x[i]) / 16.0 + nr, im = cimag(x[i]) / 16.0 + ni;
+        x[i] = (re * 16.0) + (im * 16.0) * I;
+    }
+}
+
+void morc_gen_frame(morc* o, uint64_t seed, uint64_t frame, double noise_amp, int channel,
+                    double* baseband_c128, int* payload_out) {
+    int payload[N_MAX], bits[N_MAX];
+    morc_gen_payload(o, seed, frame, payload);
+    if (payload_out) memcpy(payload_out, payload, sizeof(int) * ((o->nReal - 16) / 8));
+    morc_payload_to_bits(o, payload, (o->nReal - 16) / 8, bits);
+    morc_tx(o, bits, 1, baseband_c128);
+    morc_channel(o, seed, frame, noise_amp, channel, baseband_c128);
+}
+
+long morc_rx_many(morc* o, const double* bb, int n, int flags, int* iters_out, int* crc_out, unsigned char* payload_out) {
+    long total = 0;
+    int bytes[N_MAX];
+    size_t stride = (size_t)o->Nsymb * o->Nofdm * 2;
+    int pb = (o->nReal - 16) / 8;
+    for (int f = 0; f < n; f++) {
+        morc_rx_out r; memset(&r, 0, sizeof r);
+        r.bytes = bytes;
+        morc_rx(o, bb + stride * f, flags, &r);
+        total += r.iterations > o->max_iters ? o->max_iters : r.iterations;
+        if (iters_out) iters_out[f] = r.iterations;
+        if (crc_out) crc_out[f] = r.crc;
+        if (payload_out) for (int i = 0; i < pb; i++) payload_out[(size_t)f * pb + i] = (unsigned char)bytes[i];
+    }
+    return total;
+}

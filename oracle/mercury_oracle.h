@@ -1,0 +1,99 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+ *
+ * Plain-C, CPU restatement of the Mercury physical-layer RX hot path (and of the TX chain
+ * that is only needed to make synthetic inputs).  It exists to CHECK the HIP implementation:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Parity status: PINNED.  The reference ships no golden vectors for this path,
+ * so the restatement is pinned against the reference itself: oracle/_ref/libmercury_ref.so is
+ * the reference's own DSP objects compiled from /root/reference (oracle/Makefile), and
+ * tests/test_oracle_vs_ref.py + the committed fixtures in tests/golden/ (generated from that
+ * build by tests/golden/make_golden.py) require bit-identical outputs for every stage.
+ *
+ * The struct layouts deliberately match oracle/ref_harness.cc (mref_*) so one test body can
+ * drive either library.
+ */
+#ifndef MERCURY_ORACLE_H
+#define MERCURY_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct morc morc;
+
+typedef struct morc_info {
+    int cfg, M, bits_per_symbol, K, P, N;
+    int Nsymb, Nc, Nfft, Ngi, Nofdm;
+    int nData, nBits, nPilots, nVirtual, nReal;
+    int bit_blk, tf_blk, preamble_nsymb;
+    int estimator, amp_restore, ls_window;
+    int Cwidth, Vwidth, dwidth;
+    int payload_bytes;
+} morc_info;
+
+typedef struct morc_rx_out {
+    double* grid;     /* [Nsymb*Nc*2] */
+    double* H;        /* [Nsymb*Nc*2] */
+    double* H_noamp;  /* [Nsymb*Nc*2] */
+    double* eq;       /* [Nsymb*Nc*2] */
+    double* syms;     /* [nData*2]    */
+    float* llr_demod; /* [nBits]      */
+    float* llr_ldpc;  /* [1600]       */
+    int* bits;        /* [K]          */
+    int* bytes;       /* [ceil(nReal/8)] */
+    double variance;
+    float variance_f;
+    double agc_gain;
+    double mean_H;
+    int iterations;
+    int crc;
+    int all_zeros;
+} morc_rx_out;
+
+#define MORC_FLAG_AGC 1        /* receive_byte variant: automatic_gain_control first */
+#define MORC_FLAG_VAR_EQ 2     /* variance from the equalised grid (receive_byte) */
+#define MORC_FLAG_NO_LDPC 4    /* stop after the LDPC input is formed */
+
+#define MORC_DEC_GBF 0
+#define MORC_DEC_SPA 1
+
+/* tables_path: mercury_ldpc_tables.bin (derived data, see tools/gen_ldpc_tables.py) */
+morc* morc_create(int cfg, int max_iters, const char* tables_path);
+void morc_destroy(morc*);
+void morc_get_info(morc*, morc_info*);
+
+void morc_get_frame_types(morc*, int* types);       /* [Nsymb*Nc] 0=DATA 1=PILOT */
+void morc_get_pilot_seq(morc*, double* seq);        /* [nPilots*2] */
+void morc_get_scrambler(morc*, int* seq);           /* [1600] */
+void morc_get_constellation(morc*, double* c);      /* [M*2] */
+void morc_prng(unsigned seed, int n, int* out);
+unsigned morc_crc16(const int* bytes, int n);
+
+void morc_tx(morc*, const int* bits, int scramble, double* out_c128);
+void morc_payload_to_bits(morc*, const int* payload, int nBytes, int* bits);
+void morc_rx(morc*, const double* baseband_c128, int flags, morc_rx_out* out);
+int morc_ldpc_decode(morc*, const float* llr, int* bits_K, int alg);
+
+/* ---- synthetic workload generator (the repo's own) ---------------------
+ * Philox4x32-10 keyed by seed, counter = (index, stream, frame_lo, frame_hi).
+ * channel: 0 = AWGN, 1 = static 2-path h=[1, 0.5 e^{j phi_f}] at delay 6 + AWGN.
+ * noise_amp = per-component noise amplitude applied at the reference's 1/sqrt(Nfft) scale
+ * (telecom_system.cc:141-153), i.e. 10^(-EsN0/20)/sqrt(2). */
+void morc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
+void morc_gen_payload(morc*, uint64_t seed, uint64_t frame, int* payload_bytes);
+void morc_gen_frame(morc*, uint64_t seed, uint64_t frame, double noise_amp, int channel,
+                    double* baseband_c128, int* payload_bytes_out);
+/* apply the channel of morc_gen_frame to an already modulated frame (in place) */
+void morc_channel(morc*, uint64_t seed, uint64_t frame, double noise_amp, int channel, double* frame_c128);
+
+/* cpu_baseline helper: run morc_rx on n frames laid out back to back; returns sum of iterations */
+long morc_rx_many(morc*, const double* baseband_c128, int n, int flags, int* iters_out, int* crc_out,
+                  unsigned char* payload_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

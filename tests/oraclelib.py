@@ -1,0 +1,207 @@
+"""ctypes bindings for the two CHECKERS (test infrastructure only):
+
+* ``Oracle``  -> oracle/libmercury_oracle.so  (plain-C restatement, builds anywhere)
+* ``RefLib``  -> oracle/_ref/libmercury_ref.so (the reference's own DSP objects; only built where
+                 /root/reference exists, travels to the GPU box as a prebuilt .so)
+
+Both expose the same Python surface so one test body can drive either.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TABLES = os.path.join(ROOT, "mercury_amd", "data", "mercury_ldpc_tables.bin")
+ORACLE_SO = os.path.join(ROOT, "oracle", "libmercury_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libmercury_ref.so")
+
+FLAG_AGC, FLAG_VAR_EQ, FLAG_NO_LDPC = 1, 2, 4
+FLAGS_BASEBAND_TEST = 0                    # telecom_system.cc:155-198
+FLAGS_RECEIVE_BYTE = FLAG_AGC | FLAG_VAR_EQ  # telecom_system.cc:1132-1345
+
+INFO_FIELDS = ("cfg M bits_per_symbol K P N Nsymb Nc Nfft Ngi Nofdm nData nBits nPilots nVirtual nReal "
+               "bit_blk tf_blk preamble_nsymb estimator amp_restore ls_window Cwidth Vwidth dwidth payload_bytes").split()
+
+
+class Info(C.Structure):
+    _fields_ = [(n, C.c_int) for n in INFO_FIELDS]
+
+
+class RxOut(C.Structure):
+    _fields_ = [("grid", C.c_void_p), ("H", C.c_void_p), ("H_noamp", C.c_void_p), ("eq", C.c_void_p),
+                ("syms", C.c_void_p), ("llr_demod", C.c_void_p), ("llr_ldpc", C.c_void_p),
+                ("bits", C.c_void_p), ("bytes", C.c_void_p),
+                ("variance", C.c_double), ("variance_f", C.c_float), ("agc_gain", C.c_double),
+                ("mean_H", C.c_double), ("iterations", C.c_int), ("crc", C.c_int), ("all_zeros", C.c_int)]
+
+
+def build_oracle():
+    """Compile the checkers (never the product). Safe to call repeatedly."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"], check=True)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _Base:
+    prefix = None
+
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _init_info(self):
+        i = Info()
+        self._fn("get_info")(self.h, C.byref(i))
+        self.info = i
+        for n in INFO_FIELDS:
+            setattr(self, n, getattr(i, n))
+        self.frame_samples = self.Nsymb * self.Nofdm
+
+    # ---- tables
+    def frame_types(self):
+        t = np.zeros(self.Nsymb * self.Nc, np.int32)
+        self._fn("get_frame_types")(self.h, _p(t))
+        return t
+
+    def pilot_seq(self):
+        s = np.zeros(self.nPilots, np.complex128)
+        self._fn("get_pilot_seq")(self.h, _p(s))
+        return s
+
+    def scrambler(self):
+        s = np.zeros(1600, np.int32)
+        self._fn("get_scrambler")(self.h, _p(s))
+        return s
+
+    def constellation(self):
+        c = np.zeros(self.M, np.complex128)
+        self._fn("get_constellation")(self.h, _p(c))
+        return c
+
+    def prng(self, seed, n):
+        o = np.zeros(n, np.int32)
+        self._fn("prng")(C.c_uint(seed), C.c_int(n), _p(o))
+        return o
+
+    def crc16(self, data):
+        d = np.ascontiguousarray(data, np.int32)
+        f = self._fn("crc16")
+        f.restype = C.c_uint
+        return int(f(_p(d), C.c_int(len(d))))
+
+    # ---- TX
+    def payload_to_bits(self, payload):
+        pl = np.ascontiguousarray(payload, np.int32)
+        bits = np.zeros(1600, np.int32)
+        self._fn("payload_to_bits")(self.h, _p(pl), C.c_int(len(pl)), _p(bits))
+        return bits[: self.nReal].copy()
+
+    def tx(self, bits, scramble=1):
+        b = np.zeros(1600, np.int32)
+        b[: self.nReal] = bits[: self.nReal]
+        out = np.zeros(self.frame_samples, np.complex128)
+        self._fn("tx")(self.h, _p(b), C.c_int(scramble), _p(out))
+        return out
+
+    # ---- RX
+    def rx(self, baseband, flags=FLAGS_RECEIVE_BYTE):
+        bb = np.ascontiguousarray(baseband, np.complex128)
+        assert bb.size == self.frame_samples
+        G = self.Nsymb * self.Nc
+        bufs = dict(grid=np.zeros(G, np.complex128), H=np.zeros(G, np.complex128),
+                    H_noamp=np.zeros(G, np.complex128), eq=np.zeros(G, np.complex128),
+                    syms=np.zeros(self.nData, np.complex128), llr_demod=np.zeros(self.nBits, np.float32),
+                    llr_ldpc=np.zeros(1600, np.float32), bits=np.zeros(self.K, np.int32),
+                    bytes=np.zeros((self.nReal + 7) // 8, np.int32))
+        o = RxOut()
+        for k, v in bufs.items():
+            setattr(o, k, v.ctypes.data)
+        self._fn("rx")(self.h, _p(bb), C.c_int(flags), C.byref(o))
+        res = dict(bufs)
+        for k in ("variance", "variance_f", "agc_gain", "mean_H", "iterations", "crc", "all_zeros"):
+            res[k] = getattr(o, k)
+        return res
+
+
+class Oracle(_Base):
+    prefix = "morc_"
+
+    def __init__(self, cfg, max_iters=50):
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        self.lib = C.CDLL(ORACLE_SO)
+        self.lib.morc_create.restype = C.c_void_p
+        h = self.lib.morc_create(C.c_int(cfg), C.c_int(max_iters), TABLES.encode())
+        if not h:
+            raise RuntimeError("morc_create failed")
+        self.h = C.c_void_p(h)
+        self.max_iters = max_iters
+        self._init_info()
+
+    def ldpc_decode(self, llr, alg=1):
+        l = np.ascontiguousarray(llr, np.float32)
+        bits = np.zeros(self.K, np.int32)
+        it = self.lib.morc_ldpc_decode(self.h, _p(l), _p(bits), C.c_int(alg))
+        return bits, int(it)
+
+    def philox(self, seed, c0, c1, c2, c3):
+        out = np.zeros(4, np.uint32)
+        self.lib.morc_philox(C.c_uint64(seed), C.c_uint32(c0), C.c_uint32(c1), C.c_uint32(c2), C.c_uint32(c3), _p(out))
+        return out
+
+    def gen_payload(self, seed, frame):
+        pl = np.zeros(1600, np.int32)
+        self.lib.morc_gen_payload(self.h, C.c_uint64(seed), C.c_uint64(frame), _p(pl))
+        return pl[: self.payload_bytes].copy()
+
+    def gen_frame(self, seed, frame, noise_amp, channel=0):
+        bb = np.zeros(self.frame_samples, np.complex128)
+        pl = np.zeros(1600, np.int32)
+        self.lib.morc_gen_frame(self.h, C.c_uint64(seed), C.c_uint64(frame), C.c_double(noise_amp),
+                                C.c_int(channel), _p(bb), _p(pl))
+        return bb, pl[: self.payload_bytes].copy()
+
+    def channel(self, frame_c128, seed, frame, noise_amp, channel=0):
+        x = np.array(frame_c128, np.complex128, copy=True)
+        self.lib.morc_channel(self.h, C.c_uint64(seed), C.c_uint64(frame), C.c_double(noise_amp), C.c_int(channel), _p(x))
+        return x
+
+    def rx_many(self, baseband, flags=FLAGS_RECEIVE_BYTE):
+        bb = np.ascontiguousarray(baseband, np.complex128).reshape(-1, self.frame_samples)
+        n = bb.shape[0]
+        iters = np.zeros(n, np.int32)
+        crc = np.zeros(n, np.int32)
+        pl = np.zeros((n, self.payload_bytes), np.uint8)
+        f = self.lib.morc_rx_many
+        f.restype = C.c_long
+        tot = f(self.h, _p(bb), C.c_int(n), C.c_int(flags), _p(iters), _p(crc), _p(pl))
+        return int(tot), iters, crc, pl
+
+
+class RefLib(_Base):
+    prefix = "mref_"
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self, cfg, max_iters=50):
+        self.lib = C.CDLL(REF_SO)
+        self.lib.mref_create.restype = C.c_void_p
+        self.h = C.c_void_p(self.lib.mref_create(C.c_int(cfg), C.c_int(max_iters)))
+        self.max_iters = max_iters
+        self._init_info()
+
+    def ldpc_decode(self, llr, alg=1):
+        l = np.ascontiguousarray(llr, np.float32)
+        bits = np.zeros(self.K, np.int32)
+        it = self.lib.mref_ldpc_decode(self.h, _p(l), _p(bits))
+        return bits, int(it)
+
+
+def noise_amp_for(esn0_db):
+    """Per-component AWGN amplitude at the reference's 1/sqrt(Nfft) scale (telecom_system.cc:100,147)."""
+    return float(10.0 ** (-esn0_db / 20.0) / np.sqrt(2.0))
