@@ -1,0 +1,141 @@
+/* mercury_gpu.h — C-ABI of the MI355X-native Mercury RX physical layer.
+ *
+ * This is the drop-in boundary for the reference's physical-layer receive path: batches of
+ * independent OFDM frames go in, decoded payload bytes + per-frame receive statistics come
+ * out. Plain C types only, no exceptions cross the ABI, every entry point returns an int
+ * status (MGPU_OK == 0) and never calls exit() (the reference does: ldpc.cc:246-256).
+ *
+ * Reference interfaces each entry point replaces (paths relative to Rhizomatica/mercury):
+ *
+ *   mgpu_rx_batch*      the span of cl_telecom_system::receive_byte that runs per synchronised
+ *                       frame — source/physical_layer/telecom_system.cc:1132-1345 (agc=1,
+ *                       variance_source=1) — and the RX half of baseband_test_EsN0 —
+ *                       telecom_system.cc:155-198 (agc=0, variance_source=0). I.e. the calls
+ *                       cl_ofdm::symbol_demod / automatic_gain_control / LS_|ZF_channel_estimator /
+ *                       restore_channel_amplitude / channel_equalizer / measure_variance / deframer
+ *                       (include/physical_layer/ofdm.h:133-146), deinterleaver
+ *                       (include/physical_layer/interleaver.h:28-34), cl_psk::demod
+ *                       (include/physical_layer/psk.h:55), cl_ldpc::decode
+ *                       (include/physical_layer/ldpc.h:90), bit_energy_dispersal, bit_to_byte,
+ *                       CRC16_MODBUS_RTU_calc.
+ *   mgpu_ldpc_batch*    int cl_ldpc::decode(const float* data, int* decoded_data)
+ *                       (include/physical_layer/ldpc.h:90 -> source/physical_layer/ldpc.cc:266-278)
+ *   mgpu_frame_stats    st_receive_stats fields iterations_done, crc, all_zeros, SNR,
+ *                       message_decoded (include/physical_layer/telecom_system.h:63-82)
+ *   mgpu_config.cfg     cl_telecom_system::load_configuration(int) (telecom_system.cc:2487)
+ *   mgpu_txgen_dev      not part of the RX path: the synthetic-workload generator (TX chain of
+ *                       telecom_system.cc:384-470 + AWGN at the scale of :141-153) used by bench.py
+ *
+ * Threading: one context per (device, host thread); calls on one context must be serialised by
+ * the caller (the reference DSP objects are non-reentrant as well). *_dev entry points enqueue
+ * on the given HIP stream and return without synchronising.
+ */
+#ifndef MERCURY_GPU_H
+#define MERCURY_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGPU_OK 0
+#define MGPU_ERR_ARG 1        /* bad argument (cfg out of range, null pointer, F > max_batch ...) */
+#define MGPU_ERR_DEVICE 2     /* HIP runtime error; text in mgpu_last_error() */
+#define MGPU_ERR_TABLES 3     /* LDPC table blob missing / corrupt */
+#define MGPU_ERR_UNSUPPORTED 4
+
+/* decoder selection — reference: cl_ldpc::decoding_algorithm (physical_defines.h:44-45) */
+#define MGPU_DEC_GBF 0        /* gradient bit flipping, ldpc_decoder_GBF.cc:25-117 */
+#define MGPU_DEC_SPA 1        /* sum-product, double messages, ldpc_decoder_SPA.cc:25-218 (reference default) */
+#define MGPU_DEC_MINSUM 2     /* normalised min-sum, fp32 (not in the reference; fast variant) */
+
+#define MGPU_EST_ZF 0
+#define MGPU_EST_LS 1
+
+typedef struct mgpu_ctx mgpu_ctx;
+
+typedef struct mgpu_config {
+    int cfg;              /* Mercury CONFIG_0..CONFIG_16 */
+    int max_iters;        /* nIteration_max, reference default 50 (physical_config.cc:74), CLI 5..50 */
+    int decoder;          /* MGPU_DEC_* */
+    int agc;              /* 1 = automatic_gain_control before the estimator (receive_byte) */
+    int variance_source;  /* 0 = un-equalised grid (baseband_test_EsN0:178), 1 = equalised grid (receive_byte:1291) */
+    int device;           /* HIP device ordinal */
+    int max_batch;        /* largest F any call will pass; sizes the device workspaces */
+    float minsum_alpha;   /* normalisation factor for MGPU_DEC_MINSUM (0 -> 0.8) */
+} mgpu_config;
+
+typedef struct mgpu_info {
+    int cfg, M, bits_per_symbol, K, P, N;
+    int Nsymb, Nc, Nfft, Ngi, Nofdm;
+    int nData, nBits, nPilots, nVirtual, nReal;
+    int bit_blk, tf_blk, preamble_nsymb;
+    int estimator, amp_restore, ls_window;
+    int Cwidth, Vwidth, E;
+    int payload_bytes;    /* (nReal-16)/8, telecom_system.cc:332-335 */
+    int payload_stride;   /* bytes between consecutive frames in payload arrays = ceil(nReal/8) */
+    int frame_samples;    /* complex samples per frame = Nsymb*Nofdm */
+} mgpu_info;
+
+/* mirrors st_receive_stats (telecom_system.h:63-82) for the fields this path produces */
+typedef struct mgpu_frame_stats {
+    int iterations_done;  /* 0 = input already a codeword; max_iters+1 = never converged */
+    int crc;              /* CRC16 over nReal/8 bytes; 0 = pass (only computed when !all_zeros) */
+    int all_zeros;
+    int message_decoded;  /* !(all_zeros || crc != 0), telecom_system.cc:1343-1345 */
+    float variance;       /* measure_variance narrowed to float as the callers hold it */
+    float snr_db;         /* 10 log10(1/variance) when decoded, else -99.9 (telecom_system.cc:1347,1430) */
+} mgpu_frame_stats;
+
+/* optional per-stage taps (host pointers, any may be NULL) for parity testing */
+typedef struct mgpu_stage_taps {
+    double* grid;       /* [F][Nsymb*Nc][2]  after symbol_demod (+AGC) */
+    double* H;          /* [F][Nsymb*Nc][2]  channel after estimate/interp/amp-restore */
+    double* eq;         /* [F][Nsymb*Nc][2]  equalised grid */
+    double* syms;       /* [F][nData][2]     de-framed, time/freq de-interleaved */
+    float* llr_demod;   /* [F][nBits]        after cl_psk::demod */
+    float* llr_ldpc;    /* [F][1600]         decoder input (bit de-interleaved, re-packed) */
+    double* variance;   /* [F]               measure_variance as double */
+    double* agc_gain;   /* [F] */
+} mgpu_stage_taps;
+
+int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out);
+void mgpu_destroy(mgpu_ctx* ctx);
+const char* mgpu_last_error(mgpu_ctx* ctx);   /* ctx may be NULL: error of the last failed mgpu_create */
+int mgpu_get_info(mgpu_ctx* ctx, mgpu_info* info);
+
+/* ---- host-buffer entry points (blocking; copy in, run, copy out) -------------------- */
+/* baseband_c128: [F][Nsymb*Nofdm] complex<double>, data symbols only (preamble already
+ * stripped, i.e. the pointer receive_byte passes to symbol_demod at telecom_system.cc:1137).
+ * payload: [F][payload_stride] bytes (first payload_bytes are the user payload, then CRC lo/hi).
+ * stats: [F]. llr_opt: NULL or [F][1600] decoder-input LLRs. */
+int mgpu_rx_batch(mgpu_ctx* ctx, const double* baseband_c128, int F, uint8_t* payload,
+                  mgpu_frame_stats* stats, float* llr_opt);
+/* same, additionally copying out per-stage intermediates */
+int mgpu_rx_batch_taps(mgpu_ctx* ctx, const double* baseband_c128, int F, uint8_t* payload,
+                       mgpu_frame_stats* stats, const mgpu_stage_taps* taps);
+/* llr: [F][1600] float. bits: [F][K] one byte per hard decision (0/1). iters: [F]. */
+int mgpu_ldpc_batch(mgpu_ctx* ctx, const float* llr, int F, uint8_t* bits, int* iters);
+
+/* ---- device-buffer entry points (asynchronous on `stream`, a hipStream_t) ------------ */
+int mgpu_rx_batch_dev(mgpu_ctx* ctx, const void* d_baseband_c128, int F, void* d_payload,
+                      void* d_stats, void* d_llr_opt, void* stream);
+int mgpu_frontend_dev(mgpu_ctx* ctx, const void* d_baseband_c128, int F, void* d_llr, void* d_variance_f,
+                      void* stream);
+int mgpu_ldpc_batch_dev(mgpu_ctx* ctx, const void* d_llr, int F, void* d_bits_opt, void* d_iters,
+                        void* d_payload_opt, void* d_stats_opt, const void* d_variance_f_opt, void* stream);
+/* synthetic workload: frames frame0..frame0+F-1 of the Philox-keyed generator */
+int mgpu_txgen_dev(mgpu_ctx* ctx, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel,
+                   void* d_baseband_c128, void* d_payload_opt, void* stream);
+
+/* time (ms) spent by the kernels of the most recent *_dev / host call, measured with HIP events
+ * on the launch stream: [0]=front-end, [1]=LDPC(+tail). Synchronises the stream. */
+int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
+int mgpu_enable_timing(mgpu_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERCURY_GPU_H */

@@ -1,0 +1,399 @@
+// C-ABI of the MI355X-native Mercury RX physical layer (declared in include/mercury_gpu.h).
+// Host side only: context, constant-table upload, workspace management, kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mercury_gpu.h"
+#include "device_tables.h"
+#include "tables.hpp"
+
+extern "C" const unsigned char mgpu_ldpc_blob[];
+extern "C" const unsigned long mgpu_ldpc_blob_size;
+
+extern "C" size_t mgpu_frontend_lds_bytes(int G);
+extern "C" size_t mgpu_spa_lds_bytes(int E, int N);
+extern "C" size_t mgpu_gbf_lds_bytes(int N);
+extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
+extern "C" size_t mgpu_txgen_lds_bytes(int G);
+
+extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, MgpuTapsDev);
+extern "C" __global__ void mgpu_ldpc_spa_kernel(MgpuDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+extern "C" __global__ void mgpu_ldpc_gbf_kernel(MgpuDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+extern "C" __global__ void mgpu_ldpc_minsum_kernel(MgpuDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*);
+
+static_assert(sizeof(MgpuStatsDev) == sizeof(mgpu_frame_stats), "stats layout");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIPCK(expr)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+T* upload(const std::vector<T>& v) {
+    T* d = nullptr;
+    HIPCK(hipMalloc(&d, v.size() * sizeof(T) + 16));
+    HIPCK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+}  // namespace
+
+struct mgpu_ctx {
+    mgpu_config cfg{};
+    mgpu::ModeTables tab;
+    MgpuDev dev{};
+    std::vector<void*> owned;       // device allocations freed in destroy
+    std::string err;
+    int max_batch = 0;
+    // workspaces (device)
+    double* d_baseband = nullptr;   // lazily sized for the host-buffer entry points
+    size_t baseband_cap = 0;
+    float* d_llr = nullptr;
+    float* d_variance = nullptr;
+    float* d_snrvar = nullptr;
+    uint8_t* d_payload = nullptr;
+    MgpuStatsDev* d_stats = nullptr;
+    uint8_t* d_bits = nullptr;
+    int* d_iters = nullptr;
+    hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
+    hipEvent_t ev[4]{};
+    bool timing = false;
+    hipStream_t last_stream = nullptr;
+    bool ev_valid = false;
+    size_t lds_fe = 0, lds_dec = 0, lds_tx = 0;
+
+    template <typename T>
+    T* keep(T* p) { owned.push_back(p); return p; }
+};
+
+namespace {
+
+void ctx_alloc(mgpu_ctx* c) {
+    const auto& t = c->tab;
+    MgpuDev& d = c->dev;
+    std::vector<uint16_t> pilot_cell;
+    for (int i = 0; i < t.Nsymb * t.Nc; ++i) if (t.cell_type[i]) pilot_cell.push_back(uint16_t(i));
+    std::vector<double> cons, tw;
+    for (auto& z : t.constellation) { cons.push_back(z.re); cons.push_back(z.im); }
+    for (auto& z : t.twiddle) { tw.push_back(z.re); tw.push_back(z.im); }
+    d.cell_type = c->keep(upload(t.cell_type));
+    d.pilot_val = c->keep(upload(t.pilot_val));
+    d.pilot_cell = c->keep(upload(pilot_cell));
+    d.constellation = c->keep(upload(cons));
+    d.twiddle = c->keep(upload(tw));
+    d.sym_src = c->keep(upload(t.sym_src));
+    d.llr_src = c->keep(upload(t.llr_src));
+    d.ls_weight = c->keep(upload(t.ls_weight));
+    d.scrambler = c->keep(upload(t.scrambler));
+    d.bit_il = c->keep(upload(t.bit_il));
+    d.cptr = c->keep(upload(t.graph.cptr));
+    d.cvar = c->keep(upload(t.graph.cvar));
+    d.epack = c->keep(upload(t.graph.epack));
+    d.vptr = c->keep(upload(t.graph.vptr));
+    d.vedge = c->keep(upload(t.graph.vedge));
+    d.echk = c->keep(upload(t.graph.echk));
+    d.M = t.M; d.bps = t.bps; d.K = t.K; d.P = t.P; d.N = t.N; d.E = t.graph.E;
+    d.Nsymb = t.Nsymb; d.G = t.Nsymb * t.Nc; d.nData = t.nData; d.nBits = t.nBits; d.nPilots = t.nPilots;
+    d.nVirtual = t.nVirtual; d.nReal = t.nReal;
+    d.estimator = t.estimator; d.amp_restore = t.amp_restore; d.lsw = t.lsw;
+    d.payload_bytes = t.payload_bytes; d.payload_stride = t.payload_stride; d.frame_samples = t.frame_samples;
+    d.agc = c->cfg.agc; d.var_eq = c->cfg.variance_source; d.max_iters = c->cfg.max_iters;
+    d.pilot_boost = t.pilot_boost;
+    d.minsum_alpha = c->cfg.minsum_alpha > 0 ? c->cfg.minsum_alpha : 0.8f;
+
+    const size_t B = size_t(c->max_batch);
+    HIPCK(hipMalloc(&c->d_llr, B * t.N * sizeof(float)));
+    HIPCK(hipMalloc(&c->d_variance, B * sizeof(float)));
+    HIPCK(hipMalloc(&c->d_snrvar, B * sizeof(float)));
+    HIPCK(hipMalloc(&c->d_payload, B * t.payload_stride));
+    HIPCK(hipMalloc(&c->d_stats, B * sizeof(MgpuStatsDev)));
+    HIPCK(hipMalloc(&c->d_bits, B * t.K));
+    HIPCK(hipMalloc(&c->d_iters, B * sizeof(int)));
+    HIPCK(hipStreamCreate(&c->stream));
+    for (auto& e : c->ev) HIPCK(hipEventCreate(&e));
+
+    c->lds_fe = mgpu_frontend_lds_bytes(d.G);
+    c->lds_tx = mgpu_txgen_lds_bytes(d.G);
+    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_frontend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_fe)));
+    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_txgen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_tx)));
+    switch (c->cfg.decoder) {
+        case MGPU_DEC_SPA:
+            c->lds_dec = mgpu_spa_lds_bytes(d.E, d.N);
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
+            break;
+        case MGPU_DEC_GBF:
+            c->lds_dec = mgpu_gbf_lds_bytes(d.N);
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_gbf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
+            break;
+        case MGPU_DEC_MINSUM:
+            c->lds_dec = mgpu_minsum_lds_bytes(d.E, d.N);
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_minsum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
+            break;
+        default: throw std::runtime_error("unknown decoder");
+    }
+}
+
+void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float* d_var, float* d_snrvar,
+                     const MgpuTapsDev& taps, hipStream_t s) {
+    if (c->timing) HIPCK(hipEventRecord(c->ev[0], s));
+    hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(F), dim3(256), c->lds_fe, s, c->dev, d_bb, F, d_llr, d_var, d_snrvar, taps);
+    HIPCK(hipGetLastError());
+    if (c->timing) HIPCK(hipEventRecord(c->ev[1], s));
+}
+
+void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int* d_iters, uint8_t* d_payload,
+                    MgpuStatsDev* d_stats, const float* d_var, const float* d_snrvar, hipStream_t s) {
+    if (c->timing) HIPCK(hipEventRecord(c->ev[2], s));
+    switch (c->cfg.decoder) {
+        case MGPU_DEC_SPA:
+            hipLaunchKernelGGL(mgpu_ldpc_spa_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->dev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
+            break;
+        case MGPU_DEC_GBF:
+            hipLaunchKernelGGL(mgpu_ldpc_gbf_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->dev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
+            break;
+        default:
+            hipLaunchKernelGGL(mgpu_ldpc_minsum_kernel, dim3(F), dim3(512), c->lds_dec, s, c->dev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
+            break;
+    }
+    HIPCK(hipGetLastError());
+    if (c->timing) { HIPCK(hipEventRecord(c->ev[3], s)); c->last_stream = s; c->ev_valid = true; }
+}
+
+}  // namespace
+
+namespace {
+int guard(mgpu_ctx* c, const std::function<void()>& fn) {
+    try {
+        fn();
+        return MGPU_OK;
+    } catch (const HipError& e) {
+        if (c) c->err = e.what();
+        return MGPU_ERR_DEVICE;
+    } catch (const std::invalid_argument& e) {
+        if (c) c->err = e.what();
+        return MGPU_ERR_ARG;
+    } catch (const std::exception& e) {
+        if (c) c->err = e.what();
+        return MGPU_ERR_DEVICE;
+    }
+}
+void need(bool ok, const char* what) { if (!ok) throw std::invalid_argument(what); }
+}  // namespace
+
+extern "C" {
+
+int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return MGPU_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->cfg < 0 || cfg->cfg > 16) { g_create_error = "cfg must be 0..16"; return MGPU_ERR_ARG; }
+    if (cfg->max_iters < 1 || cfg->max_iters > 1000) { g_create_error = "max_iters out of range"; return MGPU_ERR_ARG; }
+    if (cfg->decoder < 0 || cfg->decoder > 2) { g_create_error = "unknown decoder"; return MGPU_ERR_ARG; }
+    if (cfg->max_batch < 1) { g_create_error = "max_batch must be >= 1"; return MGPU_ERR_ARG; }
+    mgpu_ctx* c = new mgpu_ctx();
+    c->cfg = *cfg;
+    c->max_batch = cfg->max_batch;
+    try {
+        std::vector<uint8_t> file_blob;
+        const uint8_t* blob = mgpu_ldpc_blob;
+        size_t blob_size = mgpu_ldpc_blob_size;
+        if (const char* p = std::getenv("MERCURY_LDPC_TABLES")) {
+            std::ifstream f(p, std::ios::binary);
+            if (!f) throw std::runtime_error(std::string("cannot open ") + p);
+            file_blob.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            blob = file_blob.data();
+            blob_size = file_blob.size();
+        }
+        try {
+            c->tab = mgpu::build_mode_tables(cfg->cfg, blob, blob_size);
+        } catch (const std::exception& e) {
+            g_create_error = e.what();
+            delete c;
+            return MGPU_ERR_TABLES;
+        }
+        int ndev = 0;
+        HIPCK(hipGetDeviceCount(&ndev));
+        if (ndev < 1) throw HipError("no HIP device visible (the MI355X path has no CPU fallback)");
+        HIPCK(hipSetDevice(cfg->device));
+        ctx_alloc(c);
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        mgpu_destroy(c);
+        return MGPU_ERR_DEVICE;
+    }
+    *out = c;
+    return MGPU_OK;
+}
+
+void mgpu_destroy(mgpu_ctx* c) {
+    if (!c) return;
+    for (void* p : c->owned) (void)hipFree(p);
+    (void)hipFree(c->d_baseband); (void)hipFree(c->d_llr); (void)hipFree(c->d_variance); (void)hipFree(c->d_snrvar);
+    (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+const char* mgpu_last_error(mgpu_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int mgpu_get_info(mgpu_ctx* c, mgpu_info* i) {
+    if (!c || !i) return MGPU_ERR_ARG;
+    const auto& t = c->tab;
+    i->cfg = t.cfg; i->M = t.M; i->bits_per_symbol = t.bps; i->K = t.K; i->P = t.P; i->N = t.N;
+    i->Nsymb = t.Nsymb; i->Nc = t.Nc; i->Nfft = t.Nfft; i->Ngi = t.Ngi; i->Nofdm = t.Nofdm;
+    i->nData = t.nData; i->nBits = t.nBits; i->nPilots = t.nPilots; i->nVirtual = t.nVirtual; i->nReal = t.nReal;
+    i->bit_blk = t.bit_blk; i->tf_blk = t.tf_blk; i->preamble_nsymb = t.preamble;
+    i->estimator = t.estimator; i->amp_restore = t.amp_restore; i->ls_window = t.lsw;
+    i->Cwidth = t.graph.Cwidth; i->Vwidth = t.graph.Vwidth; i->E = t.graph.E;
+    i->payload_bytes = t.payload_bytes; i->payload_stride = t.payload_stride; i->frame_samples = t.frame_samples;
+    return MGPU_OK;
+}
+
+int mgpu_enable_timing(mgpu_ctx* c, int on) {
+    if (!c) return MGPU_ERR_ARG;
+    c->timing = on != 0;
+    c->ev_valid = false;
+    return MGPU_OK;
+}
+
+int mgpu_last_kernel_ms(mgpu_ctx* c, float ms[2]) {
+    if (!c || !ms) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(c->timing && c->ev_valid, "timing not enabled or nothing launched");
+        HIPCK(hipEventSynchronize(c->ev[3]));
+        ms[0] = 0.f;
+        if (hipEventQuery(c->ev[1]) == hipSuccess) (void)hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
+        HIPCK(hipEventElapsedTime(&ms[1], c->ev[2], c->ev[3]));
+    });
+}
+
+int mgpu_frontend_dev(mgpu_ctx* c, const void* d_bb, int F, void* d_llr, void* d_variance_f, void* stream) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(d_bb && d_llr && F >= 0 && F <= c->max_batch, "bad argument (F must be <= max_batch)");
+        if (F == 0) return;
+        MgpuTapsDev taps{};
+        launch_frontend(c, static_cast<const double*>(d_bb), F, static_cast<float*>(d_llr),
+                        d_variance_f ? static_cast<float*>(d_variance_f) : c->d_variance, c->d_snrvar, taps, static_cast<hipStream_t>(stream));
+    });
+}
+
+int mgpu_ldpc_batch_dev(mgpu_ctx* c, const void* d_llr, int F, void* d_bits, void* d_iters, void* d_payload,
+                        void* d_stats, const void* d_variance_f, void* stream) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(d_llr && F >= 0 && F <= c->max_batch, "bad argument (F must be <= max_batch)");
+        if (F == 0) return;
+        launch_decoder(c, static_cast<const float*>(d_llr), F, static_cast<uint8_t*>(d_bits), static_cast<int*>(d_iters),
+                       static_cast<uint8_t*>(d_payload), static_cast<MgpuStatsDev*>(d_stats),
+                       static_cast<const float*>(d_variance_f), nullptr, static_cast<hipStream_t>(stream));
+    });
+}
+
+int mgpu_rx_batch_dev(mgpu_ctx* c, const void* d_bb, int F, void* d_payload, void* d_stats, void* d_llr_opt, void* stream) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(d_bb && d_payload && d_stats && F >= 0 && F <= c->max_batch, "bad argument (F must be <= max_batch)");
+        if (F == 0) return;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        float* llr = d_llr_opt ? static_cast<float*>(d_llr_opt) : c->d_llr;
+        MgpuTapsDev taps{};
+        launch_frontend(c, static_cast<const double*>(d_bb), F, llr, c->d_variance, c->d_snrvar, taps, s);
+        launch_decoder(c, llr, F, nullptr, nullptr, static_cast<uint8_t*>(d_payload), static_cast<MgpuStatsDev*>(d_stats),
+                       c->d_variance, c->d_snrvar, s);
+    });
+}
+
+int mgpu_txgen_dev(mgpu_ctx* c, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel, void* d_bb,
+                   void* d_payload_opt, void* stream) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(d_bb && F >= 0 && (channel == 0 || channel == 1), "bad argument");
+        if (F == 0) return;
+        hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(F), dim3(256), c->lds_tx, static_cast<hipStream_t>(stream), c->dev, seed,
+                           frame0, F, noise_amp, channel, static_cast<double*>(d_bb), static_cast<uint8_t*>(d_payload_opt));
+        HIPCK(hipGetLastError());
+    });
+}
+
+int mgpu_rx_batch_taps(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, mgpu_frame_stats* stats, const mgpu_stage_taps* taps) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(bb && F >= 0 && F <= c->max_batch, "bad argument (F must be <= max_batch)");
+        if (F == 0) return;
+        const auto& t = c->tab;
+        const size_t in_bytes = size_t(F) * t.frame_samples * 16;
+        if (c->baseband_cap < in_bytes) {
+            (void)hipFree(c->d_baseband);
+            c->d_baseband = nullptr; c->baseband_cap = 0;
+            HIPCK(hipMalloc(&c->d_baseband, in_bytes));
+            c->baseband_cap = in_bytes;
+        }
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(c->d_baseband, bb, in_bytes, hipMemcpyHostToDevice, s));
+        MgpuTapsDev dt{};
+        std::vector<void*> tmp;
+        const size_t G = size_t(t.Nsymb) * t.Nc;
+        auto dalloc = [&](size_t bytes) { void* p = nullptr; HIPCK(hipMalloc(&p, bytes)); tmp.push_back(p); return p; };
+        if (taps) {
+            if (taps->grid) dt.grid = static_cast<double*>(dalloc(F * G * 16));
+            if (taps->H) dt.H = static_cast<double*>(dalloc(F * G * 16));
+            if (taps->eq) dt.eq = static_cast<double*>(dalloc(F * G * 16));
+            if (taps->syms) dt.syms = static_cast<double*>(dalloc(size_t(F) * t.nData * 16));
+            if (taps->llr_demod) dt.llr_demod = static_cast<float*>(dalloc(size_t(F) * t.nBits * 4));
+            if (taps->variance) dt.variance = static_cast<double*>(dalloc(size_t(F) * 8));
+            if (taps->agc_gain) { dt.agc_gain = static_cast<double*>(dalloc(size_t(F) * 8)); HIPCK(hipMemsetAsync(dt.agc_gain, 0, size_t(F) * 8, s)); }
+        }
+        launch_frontend(c, c->d_baseband, F, c->d_llr, c->d_variance, c->d_snrvar, dt, s);
+        launch_decoder(c, c->d_llr, F, nullptr, nullptr, c->d_payload, c->d_stats, c->d_variance, c->d_snrvar, s);
+        if (payload) HIPCK(hipMemcpyAsync(payload, c->d_payload, size_t(F) * t.payload_stride, hipMemcpyDeviceToHost, s));
+        if (stats) HIPCK(hipMemcpyAsync(stats, c->d_stats, size_t(F) * sizeof(MgpuStatsDev), hipMemcpyDeviceToHost, s));
+        if (taps) {
+            auto back = [&](void* h, void* d, size_t bytes) { if (h) HIPCK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s)); };
+            back(taps->grid, dt.grid, F * G * 16); back(taps->H, dt.H, F * G * 16); back(taps->eq, dt.eq, F * G * 16);
+            back(taps->syms, dt.syms, size_t(F) * t.nData * 16); back(taps->llr_demod, dt.llr_demod, size_t(F) * t.nBits * 4);
+            back(taps->variance, dt.variance, size_t(F) * 8); back(taps->agc_gain, dt.agc_gain, size_t(F) * 8);
+            back(taps->llr_ldpc, c->d_llr, size_t(F) * t.N * 4);
+        }
+        HIPCK(hipStreamSynchronize(s));
+        for (void* p : tmp) (void)hipFree(p);
+    });
+}
+
+int mgpu_rx_batch(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, mgpu_frame_stats* stats, float* llr_opt) {
+    mgpu_stage_taps taps{};
+    taps.llr_ldpc = llr_opt;
+    return mgpu_rx_batch_taps(c, bb, F, payload, stats, llr_opt ? &taps : nullptr);
+}
+
+int mgpu_ldpc_batch(mgpu_ctx* c, const float* llr, int F, uint8_t* bits, int* iters) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(llr && F >= 0 && F <= c->max_batch, "bad argument (F must be <= max_batch)");
+        if (F == 0) return;
+        const auto& t = c->tab;
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(c->d_llr, llr, size_t(F) * t.N * 4, hipMemcpyHostToDevice, s));
+        launch_decoder(c, c->d_llr, F, c->d_bits, c->d_iters, nullptr, nullptr, nullptr, nullptr, s);
+        if (bits) HIPCK(hipMemcpyAsync(bits, c->d_bits, size_t(F) * t.K, hipMemcpyDeviceToHost, s));
+        if (iters) HIPCK(hipMemcpyAsync(iters, c->d_iters, size_t(F) * 4, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+}  // extern "C"

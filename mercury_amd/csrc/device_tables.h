@@ -1,0 +1,42 @@
+// Device-side view of the constant tables (pointers into HBM; all tiny and L2-resident) plus the
+// scalar mode parameters. Passed by value as a kernel argument.
+#pragma once
+#include <stdint.h>
+
+struct MgpuDev {
+    // front-end
+    const uint8_t* cell_type;      // [G]
+    const double* pilot_val;       // [G]
+    const uint16_t* pilot_cell;    // [nPilots] row-major list of pilot cells
+    const double* constellation;   // [M][2]
+    const double* twiddle;         // [128][2]
+    const uint16_t* sym_src;       // [nData]
+    const uint16_t* llr_src;       // [1600]
+    const double* ls_weight;       // [lsw*lsw+1]
+    const uint8_t* scrambler;      // [1600]
+    // generator
+    const uint16_t* bit_il;        // [nBits]
+    // LDPC graph
+    const uint32_t* cptr;          // [P+1]
+    const uint16_t* cvar;          // [E]
+    const uint32_t* epack;         // [E]
+    const uint32_t* vptr;          // [N+1]
+    const uint16_t* vedge;         // [E]   edge of (variable, slot)
+    const uint16_t* echk;          // [E]   check of edge e
+    int M, bps, K, P, N, E;
+    int Nsymb, G, nData, nBits, nPilots, nVirtual, nReal;
+    int estimator, amp_restore, lsw;
+    int payload_bytes, payload_stride, frame_samples;
+    int agc, var_eq, max_iters;
+    double pilot_boost;
+    float minsum_alpha;
+};
+
+struct MgpuTapsDev {
+    double* grid; double* H; double* eq; double* syms; float* llr_demod; double* variance; double* agc_gain;
+};
+
+struct MgpuStatsDev {  // must match mgpu_frame_stats
+    int iterations_done, crc, all_zeros, message_decoded;
+    float variance, snr_db;
+};

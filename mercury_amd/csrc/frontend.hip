@@ -1,0 +1,286 @@
+// RX front-end for gfx950: one workgroup per OFDM frame, everything between the baseband
+// samples and the LDPC input stays in LDS; HBM sees the samples once (16 B/sample, coalesced)
+// and 1600 floats out.
+//
+// Stages and the reference code they reproduce (same operations, same order, FP64, no FMA
+// contraction — this TU is built with -ffp-contract=off):
+//   symbol_demod ............. ofdm.cc:862-867 (gi_remover :423-429, radix-2 DIT fft :310-340 with
+//                              1/Nfft scaling :431-444, zero_depadder :401-411)
+//   automatic_gain_control ... ofdm.cc:1467-1498
+//   LS_/ZF_channel_estimator . ofdm.cc:1315-1451 / :1266-1313 ; matrix_multiplication misc.cc:73-91
+//   interpolate_linear_col ... interpolator.cc:163-254
+//   restore_channel_amplitude  ofdm.cc:1453-1466 ; get_angle/set_complex misc.cc:34-71
+//   channel_equalizer ........ ofdm.cc:1637-1647 (complex divide = libgcc __divdc3, Smith)
+//   measure_variance ......... ofdm.cc:1500-1521 (sequential sum, narrowed to float by the callers)
+//   deframer + deinterleaver . ofdm.cc:837-852, interleaver.cc:94-109   (one gather table)
+//   cl_psk::demod ............ psk.cc:278-326 (double distances narrowed to float, float LLR math)
+//   deinterleaver + re-pack .. interleaver.cc:77-92, telecom_system.cc:1300-1308 (one gather table)
+//
+// Sequential reductions (AGC mean, variance) are kept sequential on purpose: the terms are
+// produced in parallel, one lane adds them in the reference's order, so the float `variance`
+// that scales every LLR is bit-identical to the CPU path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_tables.h"
+
+namespace {
+
+struct c2 { double re, im; };
+
+__device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+
+// libgcc (GCC 11) __divdc3 main path
+__device__ __forceinline__ c2 cdiv(c2 n, c2 d) {
+    const double a = n.re, b = n.im, c = d.re, dd = d.im;
+    double x, y;
+    if (fabs(c) < fabs(dd)) {
+        const double ratio = c / dd, denom = (c * ratio) + dd;
+        x = ((a * ratio) + b) / denom;
+        y = ((b * ratio) - a) / denom;
+    } else {
+        const double ratio = dd / c, denom = (dd * ratio) + c;
+        x = ((b * ratio) + a) / denom;
+        y = (b - (a * ratio)) / denom;
+    }
+    return {x, y};
+}
+
+// interpolate_linear (complex): a + (b-a)*(x-a_x)/(b_x-a_x), component-wise scalings
+__device__ __forceinline__ c2 lerp(c2 a, double ax, c2 b, double bx, double x) {
+    const double m = x - ax, q = bx - ax;
+    c2 t = {(b.re - a.re) * m, (b.im - a.im) * m};
+    t.re = t.re / q;
+    t.im = t.im / q;
+    return {a.re + t.re, a.im + t.im};
+}
+
+__device__ __forceinline__ double get_angle(c2 v) {
+    double theta = 0;
+    if (v.re == 0) theta = M_PI / 2;
+    else if (v.re > 0) theta = atan(v.im / v.re);
+    else if (v.re < 0 && v.im >= 0) theta = atan(v.im / v.re) + M_PI;
+    else if (v.re < 0 && v.im < 0) theta = atan(v.im / v.re) - M_PI;
+    return theta;
+}
+
+}  // namespace
+
+#define FE_THREADS 256
+
+// LDS carve (bytes): grid 16G | H 16G | fft 4*256*16 | tw 128*16 | llr 4*nBits(<=1600) | type G | scal 64
+extern "C" size_t mgpu_frontend_lds_bytes(int G) {
+    return size_t(16) * G * 2 + 4 * 256 * 16 + 128 * 16 + 1600 * 4 + ((G + 15) & ~15) + 64;
+}
+
+extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
+    MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
+    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, MgpuTapsDev taps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int G = T.G, Nc = 50, Ns = T.Nsymb;
+    c2* grid = reinterpret_cast<c2*>(smem);
+    c2* H = grid + G;
+    c2* fftb = H + G;                       // 4 x 256
+    c2* tw = fftb + 4 * 256;                // 128
+    float* llr = reinterpret_cast<float*>(tw + 128);
+    uint8_t* type = reinterpret_cast<uint8_t*>(llr + 1600);
+    double* scal = reinterpret_cast<double*>(type + ((G + 15) & ~15));
+    double* red = reinterpret_cast<double*>(fftb);  // reduction scratch (<= 800 doubles), reuses the FFT area
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.x;
+    if (f >= F) return;
+    const c2* bb = reinterpret_cast<const c2*>(baseband) + size_t(f) * T.frame_samples;
+
+    for (int i = tid; i < 128; i += FE_THREADS) tw[i] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
+    for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i];
+    __syncthreads();
+
+    // ---- symbol_demod: one wave per symbol, 4 symbols per pass --------------------------------
+    const int passes = (Ns + 3) / 4;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int s = pass * 4 + wave;
+        const bool act = s < Ns;
+        c2* v = fftb + wave * 256;
+        if (act) {
+            const c2* in = bb + size_t(s) * 272 + 16;            // gi_remover
+            for (int i = lane; i < 256; i += 64) v[__brev(unsigned(i)) >> 24] = in[i];  // bit-reversal permutation
+        }
+        __syncthreads();
+        for (int size = 2; size <= 256; size <<= 1) {
+            const int half = size >> 1, step = 256 / size;
+            if (act) {
+                for (int b = lane; b < 128; b += 64) {
+                    const int j = b & (half - 1);
+                    const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
+                    const c2 t = cmul(tw[j * step], v[i1]);
+                    const c2 u = v[i0];
+                    v[i1] = {u.re - t.re, u.im - t.im};
+                    v[i0] = {u.re + t.re, u.im + t.im};
+                }
+            }
+            __syncthreads();
+        }
+        if (act && lane < 50) {                                   // 1/Nfft scale + zero_depadder
+            const int bin = lane < 25 ? lane + 256 - 25 : lane - 25 + 1;
+            grid[s * Nc + lane] = {v[bin].re / 256.0, v[bin].im / 256.0};
+        }
+        __syncthreads();
+    }
+
+    // ---- automatic_gain_control ---------------------------------------------------------------
+    if (T.agc) {
+        for (int p = tid; p < T.nPilots; p += FE_THREADS) {
+            const c2 y = grid[T.pilot_cell[p]];
+            red[p] = sqrt(y.re * y.re + y.im * y.im);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double amp = 0;
+            for (int p = 0; p < T.nPilots; ++p) amp += red[p];
+            amp /= T.nPilots;
+            scal[0] = T.pilot_boost / amp;
+        }
+        __syncthreads();
+        const double agc = scal[0];
+        for (int c = tid; c < G; c += FE_THREADS) grid[c] = {grid[c].re * agc, grid[c].im * agc};
+        __syncthreads();
+        if (taps.agc_gain && tid == 0) taps.agc_gain[f] = agc;
+    }
+    if (taps.grid) for (int c = tid; c < G; c += FE_THREADS) { taps.grid[(size_t(f) * G + c) * 2] = grid[c].re; taps.grid[(size_t(f) * G + c) * 2 + 1] = grid[c].im; }
+
+    // ---- channel estimate at the pilots -------------------------------------------------------
+    const int hw = T.lsw / 2;
+    for (int p = tid; p < T.nPilots; p += FE_THREADS) {
+        const int c = T.pilot_cell[p], i = c / Nc, j = c - i * Nc;
+        if (T.estimator == 0) {            // ZF: Y / (x + 0i) reduces to two real divisions in __divdc3
+            const double x = T.pilot_val[c];
+            H[c] = {grid[c].re / x, grid[c].im / x};
+        } else {                           // LS over the (clipped) 21x21 window, row-major order
+            const int k0 = max(i - hw, 0), k1 = min(i + hw, Ns - 1), l0 = max(j - hw, 0), l1 = min(j + hw, Nc - 1);
+            int n = 0;
+            for (int k = k0; k <= k1; ++k)
+                for (int l = l0; l <= l1; ++l) n += type[k * Nc + l];
+            const double w = T.ls_weight[n];
+            double hr = 0, hi = 0;
+            for (int k = k0; k <= k1; ++k)
+                for (int l = l0; l <= l1; ++l) {
+                    const int q = k * Nc + l;
+                    if (!type[q]) continue;
+                    const double xw = T.pilot_val[q] < 0 ? -w : w;   // x' = x * (1/sum x^2)
+                    hr += xw * grid[q].re;
+                    hi += xw * grid[q].im;
+                }
+            H[c] = {hr, hi};
+        }
+    }
+    __syncthreads();
+    // ---- interpolate_linear_col for the data cells --------------------------------------------
+    for (int c = tid; c < G; c += FE_THREADS) {
+        if (type[c]) continue;
+        const int i = c / Nc, j = c - i * Nc;
+        int prev = -1, next = -1;
+        for (int r = i - 1; r >= 0; --r) if (type[r * Nc + j]) { prev = r; break; }
+        for (int r = i + 1; r < Ns; ++r) if (type[r * Nc + j]) { next = r; break; }
+        int a, b;
+        if (prev >= 0 && next >= 0) { a = prev; b = next; }
+        else if (prev < 0) {               // above the first pilot: extrapolate from the first two
+            a = next; b = -1;
+            for (int r = next + 1; r < Ns; ++r) if (type[r * Nc + j]) { b = r; break; }
+        } else {                           // below the last pilot: extrapolate from the last two
+            b = prev; a = -1;
+            for (int r = prev - 1; r >= 0; --r) if (type[r * Nc + j]) { a = r; break; }
+        }
+        H[c] = lerp(H[a * Nc + j], double(a), H[b * Nc + j], double(b), double(i));
+    }
+    __syncthreads();
+
+    // ---- amplitude restoration (PSK modes) + SNR variance on the non-restored equalisation ----
+    if (T.amp_restore) {
+        for (int p = tid; p < T.nPilots; p += FE_THREADS) {      // measure_variance(equalized_data_without_amplitude_restoration)
+            const int c = T.pilot_cell[p];
+            const c2 e = cdiv(grid[c], H[c]);
+            const double dr = e.re - T.pilot_val[c], di = e.im - 0.0;
+            red[p] = dr * dr + di * di;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double var = 0;
+            for (int p = 0; p < T.nPilots; ++p) var += red[p];
+            var /= double(T.nPilots);
+            scal[2] = var;
+        }
+        __syncthreads();
+        for (int c = tid; c < G; c += FE_THREADS) {
+            const double th = get_angle(H[c]);
+            H[c] = {cos(th), sin(th)};
+        }
+        __syncthreads();
+    }
+    if (taps.H) for (int c = tid; c < G; c += FE_THREADS) { taps.H[(size_t(f) * G + c) * 2] = H[c].re; taps.H[(size_t(f) * G + c) * 2 + 1] = H[c].im; }
+
+    // ---- variance terms from the un-equalised grid (baseband_test_EsN0 variant) ----------------
+    if (!T.var_eq) {
+        for (int p = tid; p < T.nPilots; p += FE_THREADS) {
+            const int c = T.pilot_cell[p];
+            const double dr = grid[c].re - T.pilot_val[c], di = grid[c].im - 0.0;
+            red[p] = dr * dr + di * di;
+        }
+    }
+    __syncthreads();
+    // ---- channel_equalizer (in place over H) ---------------------------------------------------
+    for (int c = tid; c < G; c += FE_THREADS) H[c] = cdiv(grid[c], H[c]);
+    __syncthreads();
+    c2* eq = H;
+    if (taps.eq) for (int c = tid; c < G; c += FE_THREADS) { taps.eq[(size_t(f) * G + c) * 2] = eq[c].re; taps.eq[(size_t(f) * G + c) * 2 + 1] = eq[c].im; }
+    if (T.var_eq) {
+        for (int p = tid; p < T.nPilots; p += FE_THREADS) {
+            const int c = T.pilot_cell[p];
+            const double dr = eq[c].re - T.pilot_val[c], di = eq[c].im - 0.0;
+            red[p] = dr * dr + di * di;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double var = 0;
+        for (int p = 0; p < T.nPilots; ++p) var += red[p];
+        var /= double(T.nPilots);
+        scal[1] = var;
+    }
+    __syncthreads();
+    const float variance = float(scal[1]);
+    if (tid == 0) {
+        variance_out[f] = variance;
+        if (snr_variance_out) snr_variance_out[f] = T.amp_restore ? float(scal[2]) : variance;
+        if (taps.variance) taps.variance[f] = scal[1];
+    }
+
+    // ---- deframe + time/freq de-interleave + max-log demap -------------------------------------
+    const float inv_var = 1 / variance;
+    const int M = T.M, bps = T.bps;
+    for (int k = tid; k < T.nData; k += FE_THREADS) {
+        const c2 s = eq[T.sym_src[k]];
+        if (taps.syms) { taps.syms[(size_t(f) * T.nData + k) * 2] = s.re; taps.syms[(size_t(f) * T.nData + k) * 2 + 1] = s.im; }
+        float d0[5], d1[5];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) { d0[b] = __builtin_inff(); d1[b] = __builtin_inff(); }
+        for (int j = 0; j < M; ++j) {
+            const double dr = s.re - T.constellation[2 * j], di = s.im - T.constellation[2 * j + 1];
+            const float D = float(dr * dr + di * di);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                if (b < bps) {
+                    if ((j >> b) & 1) { if (D < d1[b]) d1[b] = D; }
+                    else { if (D < d0[b]) d0[b] = D; }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 5; ++b)
+            if (b < bps) llr[k * bps + (bps - 1 - b)] = inv_var * (d1[b] - d0[b]);
+    }
+    __syncthreads();
+    if (taps.llr_demod) for (int i = tid; i < T.nBits; i += FE_THREADS) taps.llr_demod[size_t(f) * T.nBits + i] = llr[i];
+    // ---- bit de-interleave + shortening re-pack -------------------------------------------------
+    for (int p = tid; p < T.N; p += FE_THREADS) llr_out[size_t(f) * T.N + p] = llr[T.llr_src[p]];
+}

@@ -1,0 +1,310 @@
+// LDPC belief-propagation decoders for Mercury's N=1600 IRA codes on gfx950.
+//
+// Layout decision: ONE WORKGROUP PER CODEWORD, all messages resident in LDS.
+// A codeword's whole Tanner graph state (E <= 6604 edges) is 53 KB in fp64 / 26 KB in fp32, so it
+// never needs to round-trip through HBM: HBM sees 1600 LLR floats in and ~200 B out per frame.
+// Early termination is per workgroup, so converged frames cost nothing further and there is no
+// divergence between frames. Graph index tables (<60 KB per rate) are shared by every frame and
+// stay L2-resident.
+//
+// Decoders:
+//   spa    — the reference's flooding sum-product decoder in double precision
+//            (ldpc_decoder_SPA.cc:25-218), restructured edge-parallel but performing the same
+//            arithmetic per message: tanh(0.5*Q) once per edge, the check product over the other
+//            edges in ascending row order starting from 1.0, the +-1 clamp to +-0.9999999,
+//            2*atanh, and the variable sum llr + R[slot 0] + R[slot 1] + ... in slot order.
+//   minsum — normalised min-sum in fp32 (not in the reference; BASELINE.json north_star variant).
+//   gbf    — gradient bit flipping (ldpc_decoder_GBF.cc:25-117), float, bit-exact.
+//
+// The tail (bit_energy_dispersal interleaver.cc:111-117, bit_to_byte misc.cc:107-130, all-zeros
+// test and CRC16 telecom_system.cc:1319-1345, crc16_modbus_rtu.cc:25-45) is fused into the
+// decoder's epilogue.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_tables.h"
+#include "spa_math.h"
+
+#define LDPC_THREADS 1024
+
+namespace {
+
+// Epilogue shared by all decoders: hard[] (N bytes in LDS) -> bits / payload / stats.
+__device__ void decode_tail(const MgpuDev& T, int f, const uint8_t* hard, uint8_t* bytes_lds, int iterations,
+                            uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
+                            uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+                            const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    const int tid = threadIdx.x;
+    if (bits_out) for (int i = tid; i < T.K; i += blockDim.x) bits_out[size_t(f) * T.K + i] = hard[i];
+    if (iters_out && tid == 0) iters_out[f] = iterations;
+    if (!payload_out && !stats_out) return;
+    const int nb = T.nReal, nbytes = (nb + 7) / 8;
+    for (int b = tid; b < nbytes; b += blockDim.x) {
+        unsigned v = 0;
+        for (int j = 0; j < 8; ++j) {
+            const int i = b * 8 + j;
+            if (i < nb) v |= unsigned(hard[i] ^ T.scrambler[i]) << j;
+        }
+        bytes_lds[b] = uint8_t(v);
+        if (payload_out) payload_out[size_t(f) * T.payload_stride + b] = uint8_t(v);
+    }
+    __syncthreads();
+    if (stats_out && tid == 0) {
+        const int full = nb / 8;
+        int all_zeros = 1;
+        for (int i = 0; i < full; ++i) if (bytes_lds[i]) { all_zeros = 0; break; }
+        unsigned crc = 0;
+        if (!all_zeros) {
+            crc = 0xffff;
+            for (int j = 0; j < full; ++j) {
+                crc ^= bytes_lds[j];
+                for (int i = 0; i < 8; ++i) crc = (crc & 1) ? ((crc >> 1) ^ 0xA001) : (crc >> 1);
+            }
+        }
+        MgpuStatsDev s;
+        s.iterations_done = iterations;
+        s.crc = int(crc);
+        s.all_zeros = all_zeros;
+        s.message_decoded = !(all_zeros || crc != 0);
+        s.variance = variance_in ? variance_in[f] : 0.0f;
+        // telecom_system.cc:1347 / :1366-1372: 10*log10(1/variance) with the float variance widened
+        const float sv = snr_variance_in ? snr_variance_in[f] : s.variance;
+        s.snr_db = s.message_decoded ? float(10.0 * log10(1.0 / double(sv))) : -99.9f;
+        stats_out[f] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mgpu_spa_lds_bytes(int E, int N) {
+    return size_t(8) * E * 2 + size_t(8) * N + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sum-product, double precision, reference arithmetic.
+extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_spa_kernel(
+    MgpuDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
+    int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+    const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int E = T.E, N = T.N, P = T.P;
+    double* Tt = reinterpret_cast<double*>(smem);     // tanh(0.5*Q) per edge, check-major
+    double* Rc = Tt + E;                              // R per edge, check-major
+    double* Lt = Rc + E;                              // LLRtmp per variable
+    float* Li = reinterpret_cast<float*>(Lt + N);     // channel LLR
+    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
+    uint8_t* bytes = hard + ((N + 15) & ~15);
+    int* flag = reinterpret_cast<int*>(bytes + 256);
+
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (f >= F) return;
+    const float* lin = llr_in + size_t(f) * N;
+    for (int v = tid; v < N; v += LDPC_THREADS) {
+        const float l = lin[v];
+        Li[v] = l;
+        Lt[v] = l;
+        hard[v] = l < 0;
+    }
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    // initial syndrome (ldpc_decoder_SPA.cc:62-76)
+    {
+        int bad = 0;
+        for (int c = tid; c < P; c += LDPC_THREADS) {
+            int x = 0;
+            for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) x ^= hard[T.cvar[e]];
+            bad |= x;
+        }
+        if (bad) flag[0] = 1;
+    }
+    __syncthreads();
+    int iteration = 0;
+    if (flag[0]) {
+        // Q = llr on every edge (:106-122) -> T = tanh(0.5*Q)
+        for (int e = tid; e < E; e += LDPC_THREADS) Tt[e] = spa_tanh(0.5 * double(Li[T.cvar[e]]));
+        __syncthreads();
+        for (iteration = 1; iteration <= T.max_iters; ++iteration) {
+            // check update (:129-160)
+            for (int e = tid; e < E; e += LDPC_THREADS) {
+                const uint32_t pk = T.epack[e];
+                const int cs = pk & 0xffff, deg = (pk >> 16) & 0xff, pos = pk >> 24;
+                double temp = 1;
+                for (int k = 0; k < deg; ++k)
+                    if (k != pos) temp *= Tt[cs + k];
+                if (temp == 1) temp = 0.9999999;
+                if (temp == -1) temp = -0.9999999;
+                Rc[e] = 2 * spa_atanh(temp);
+            }
+            if (tid == 0) flag[0] = 0;
+            __syncthreads();
+            // variable update (:162-170)
+            for (int v = tid; v < N; v += LDPC_THREADS) {
+                double s = Li[v];
+                for (uint32_t q = T.vptr[v]; q < T.vptr[v + 1]; ++q) s += Rc[T.vedge[q]];
+                Lt[v] = s;
+                hard[v] = s < 0;
+            }
+            __syncthreads();
+            // syndrome (:173-190)
+            {
+                int bad = 0;
+                for (int c = tid; c < P; c += LDPC_THREADS) {
+                    int x = 0;
+                    for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) x ^= hard[T.cvar[e]];
+                    bad |= x;
+                }
+                if (bad) flag[0] = 1;
+            }
+            __syncthreads();
+            if (!flag[0]) break;
+            // Q = LLRtmp - R (:193-209), then the tanh the next check update needs
+            if (iteration < T.max_iters)
+                for (int e = tid; e < E; e += LDPC_THREADS) Tt[e] = spa_tanh(0.5 * (Lt[T.cvar[e]] - Rc[e]));
+            __syncthreads();
+        }
+    }
+    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient bit flipping (ldpc_decoder_GBF.cc:25-117), eta = 0.5 (physical_config.cc:73).
+extern "C" size_t mgpu_gbf_lds_bytes(int N) { return size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64; }
+
+extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_gbf_kernel(
+    MgpuDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
+    int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+    const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = T.N, P = T.P;
+    float* Lt = reinterpret_cast<float*>(smem);
+    int* delta = reinterpret_cast<int*>(Lt + N);
+    uint8_t* hard = reinterpret_cast<uint8_t*>(delta + N);
+    uint8_t* bytes = hard + ((N + 15) & ~15);
+    int* flag = reinterpret_cast<int*>(bytes + 256);
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (f >= F) return;
+    const float eta = 0.5f;
+    for (int v = tid; v < N; v += LDPC_THREADS) { const float l = llr_in[size_t(f) * N + v]; Lt[v] = l; hard[v] = l < 0; delta[v] = 0; }
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    {
+        int bad = 0;
+        for (int c = tid; c < P; c += LDPC_THREADS) {
+            int x = 0;
+            for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) x ^= hard[T.cvar[e]];
+            bad |= x;
+        }
+        if (bad) flag[0] = 1;
+    }
+    __syncthreads();
+    int iteration = 0;
+    if (flag[0]) {
+        for (iteration = 1; iteration <= T.max_iters; ++iteration) {
+            __syncthreads();
+            if (tid == 0) flag[0] = 0;
+            __syncthreads();
+            int bad = 0;
+            for (int c = tid; c < P; c += LDPC_THREADS) {
+                int x = 0;
+                for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) x ^= hard[T.cvar[e]];
+                bad |= x;
+                for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) atomicAdd(&delta[T.cvar[e]], 2 * x - 1);
+            }
+            if (bad) flag[0] = 1;
+            __syncthreads();
+            if (!flag[0]) break;
+            for (int v = tid; v < N; v += LDPC_THREADS) {
+                const int d = delta[v];
+                const int k = (d > 0) * (2 * (Lt[v] < 0) - 1) * d;
+                Lt[v] += float(k) * eta;
+                delta[v] = 0;
+                hard[v] = Lt[v] < 0;
+            }
+        }
+    }
+    __syncthreads();
+    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Normalised min-sum, fp32, flooding schedule (BASELINE.json north_star variant; not in the
+// reference). Per iteration: (1) one lane per check reduces its edges' Q to {min1, min2, argmin,
+// sign product} and, from the posteriors' hard bits, the syndrome of the PREVIOUS iteration;
+// (2) one lane per variable rebuilds its R messages from the check summaries, forms the posterior
+// and writes the new extrinsic Q in place. Two barriers per iteration, all state in LDS.
+#define MS_THREADS 512
+
+extern "C" size_t mgpu_minsum_lds_bytes(int E, int N) {
+    return size_t(4) * E + size_t(16) * 1600 + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
+}
+
+extern "C" __global__ __launch_bounds__(MS_THREADS) void mgpu_ldpc_minsum_kernel(
+    MgpuDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
+    int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+    const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int E = T.E, N = T.N, P = T.P;
+    float* Qc = reinterpret_cast<float*>(smem);                 // extrinsic var->check message per edge (check-major)
+    float4* summ = reinterpret_cast<float4*>(Qc + ((E + 3) & ~3));  // per check: min1, min2, argmin (bits), sign product (bits)
+    float* Li = reinterpret_cast<float*>(summ + 1600);
+    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
+    uint8_t* bytes = hard + ((N + 15) & ~15);
+    int* flag = reinterpret_cast<int*>(bytes + 256);
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (f >= F) return;
+    const float alpha = T.minsum_alpha;
+    for (int v = tid; v < N; v += MS_THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; hard[v] = l < 0; }
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    __syncthreads();
+    for (int e = tid; e < E; e += MS_THREADS) Qc[e] = Li[T.cvar[e]];
+    __syncthreads();
+    int iteration = 0;
+    // iteration counts follow the reference's convention: 0 = input already a codeword,
+    // k = converged after k iterations, max+1 = never converged.
+    for (int it = 0; it <= T.max_iters; ++it) {
+        int bad = 0;
+        for (int c = tid; c < P; c += MS_THREADS) {
+            const uint32_t e0 = T.cptr[c], e1 = T.cptr[c + 1];
+            float m1 = __builtin_inff(), m2 = __builtin_inff();
+            uint32_t arg = 0, sgn = 0, syn = 0;
+            for (uint32_t e = e0; e < e1; ++e) {
+                const float q = Qc[e];
+                const float a = fabsf(q);
+                sgn ^= __float_as_uint(q) >> 31;
+                syn ^= hard[T.cvar[e]];
+                if (a < m1) { m2 = m1; m1 = a; arg = e; } else if (a < m2) { m2 = a; }
+            }
+            bad |= syn;
+            summ[c] = make_float4(m1 * alpha, m2 * alpha, __uint_as_float(arg), __uint_as_float(sgn));
+        }
+        if (bad) flag[it & 1] = 1;
+        __syncthreads();
+        const int unsat = flag[it & 1];   // the other flag word is reset below, so no lane can see a stale value
+        if (!unsat) { iteration = it; break; }
+        if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
+        for (int v = tid; v < N; v += MS_THREADS) {
+            const uint32_t q0 = T.vptr[v], q1 = T.vptr[v + 1];
+            float s = Li[v];
+            float r[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                if (q0 + k < q1) {
+                    const uint32_t e = T.vedge[q0 + k];
+                    const float4 sm = summ[T.echk[e]];
+                    const float q = Qc[e];
+                    const float mag = (__float_as_uint(sm.z) == e) ? sm.y : sm.x;
+                    const uint32_t sg = (__float_as_uint(sm.w) ^ (__float_as_uint(q) >> 31)) << 31;
+                    r[k] = __uint_as_float(__float_as_uint(mag) ^ sg);
+                    s += r[k];
+                }
+            }
+            hard[v] = s < 0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                if (q0 + k < q1) Qc[T.vedge[q0 + k]] = s - r[k];
+        }
+        if (tid == 0) flag[(it + 1) & 1] = 0;
+        __syncthreads();
+    }
+    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}

@@ -1,0 +1,257 @@
+// Host-side table construction for the Mercury RX kernels — see tables.hpp for the reference map.
+#include "tables.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace mgpu {
+
+// ---- glibc random() TYPE_3 (os_interop.cc:192-283) -------------------------------------------
+void GlibcRandom::reseed(unsigned seed) {
+    if (seed == 0) seed = 1;
+    st_[0] = static_cast<int32_t>(seed);
+    int32_t word = st_[0];
+    for (int i = 1; i < 31; ++i) {
+        // state[i] = (16807 * state[i-1]) % 2147483647 without overflowing 31 bits
+        const long hi = word / 127773, lo = word % 127773;
+        word = static_cast<int32_t>(16807 * lo - 2836 * hi);
+        if (word < 0) word += 2147483647;
+        st_[i] = word;
+    }
+    f_ = 3;
+    r_ = 0;
+    for (int k = 0; k < 310; ++k) (void)next();
+}
+
+int32_t GlibcRandom::next() {
+    const uint32_t val = static_cast<uint32_t>(st_[f_]) + static_cast<uint32_t>(st_[r_]);
+    st_[f_] = static_cast<int32_t>(val);
+    if (++f_ >= 31) { f_ = 0; ++r_; }
+    else if (++r_ >= 31) r_ = 0;
+    return static_cast<int32_t>(val >> 1);
+}
+
+uint16_t crc16_modbus(const uint8_t* bytes, int n) {
+    uint16_t crc = 0xffff;
+    for (int j = 0; j < n; ++j) {
+        crc ^= bytes[j];
+        for (int i = 0; i < 8; ++i) crc = (crc & 1) ? static_cast<uint16_t>((crc >> 1) ^ 0xA001) : static_cast<uint16_t>(crc >> 1);
+    }
+    return crc;
+}
+
+namespace {
+
+struct ModeRow { int M, rate16, preamble, estimator; };
+// telecom_system.cc:2506-2624
+constexpr ModeRow kModeTable[17] = {
+    {2, 1, 4, 1},  {2, 2, 4, 1},  {2, 3, 4, 1},  {2, 4, 4, 1},  {2, 5, 4, 1},  {2, 6, 4, 1},
+    {2, 8, 4, 1},  {4, 5, 4, 1},  {4, 6, 4, 1},  {4, 8, 4, 1},  {8, 6, 3, 1},  {8, 8, 3, 1},
+    {4, 14, 3, 1}, {16, 8, 2, 1}, {8, 14, 2, 1}, {16, 14, 2, 0}, {32, 14, 1, 0},
+};
+
+// psk.cc:124-157 — the 32-point cross constellation has no closed form
+constexpr int8_t kQam32[32][2] = {
+    {-3, 5}, {-1, 5}, {-3, -5}, {-1, -5}, {-5, 3}, {-5, 1}, {-5, -3}, {-5, -1},
+    {-1, 3}, {-1, 1}, {-1, -3}, {-1, -1}, {-3, 3}, {-3, 1}, {-3, -3}, {-3, -1},
+    {3, 5},  {1, 5},  {3, -5},  {1, -5},  {5, 3},  {5, 1},  {5, -3},  {5, -1},
+    {1, 3},  {1, 1},  {1, -3},  {1, -1},  {3, 3},  {3, 1},  {3, -3},  {3, -1}};
+
+std::vector<Cplx> make_constellation(int M) {
+    std::vector<Cplx> c(M);
+    switch (M) {
+        case 2: c = {{1, 0}, {-1, 0}}; break;
+        case 4: c = {{-1, 1}, {-1, -1}, {1, 1}, {1, -1}}; break;
+        case 8: {
+            const double h = std::sqrt(2.0);  // complex * sqrt(2.0) / 2.0, component-wise (psk.cc:83-90)
+            const double p = (1 * h) / 2.0, n = (-1 * h) / 2.0;
+            c = {{n, n}, {-1, 0}, {0, 1}, {n, p}, {0, -1}, {p, n}, {p, p}, {1, 0}};
+            break;
+        }
+        case 16:  // psk.cc:105-121: index b3b2b1b0 -> I = (b3 ? + : -)(b2 ? 1 : 3), Q = (b1 ? - : +)(b0 ? 1 : 3)
+            for (int s = 0; s < 16; ++s)
+                c[s] = {((s & 8) ? 1.0 : -1.0) * ((s & 4) ? 1.0 : 3.0), ((s & 2) ? -1.0 : 1.0) * ((s & 1) ? 1.0 : 3.0)};
+            break;
+        case 32:
+            for (int s = 0; s < 32; ++s) c[s] = {double(kQam32[s][0]), double(kQam32[s][1])};
+            break;
+        default: throw std::runtime_error("unsupported constellation size");
+    }
+    // psk.cc:229-256: the normaliser is accumulated and stored in a FLOAT
+    float pnv = 0;
+    for (const Cplx& z : c) pnv = static_cast<float>(static_cast<double>(pnv) + (z.re * z.re + z.im * z.im));
+    const float mean = pnv / static_cast<float>(M);
+    pnv = static_cast<float>(1.0 / std::sqrt(static_cast<double>(mean)));
+    for (Cplx& z : c) { z.re *= static_cast<double>(pnv); z.im *= static_cast<double>(pnv); }
+    return c;
+}
+
+// cl_pilot_configurator::configure (ofdm.cc:976-1064) for Dx=1, Dy=3, all edge rows/cols DATA,
+// last_col AUTO_SELLECT with the COPY_FIRST_COL fallback.
+std::vector<uint8_t> make_pilot_lattice(int Nsymb, int Nc) {
+    const int Dx = 1, Dy = 3;
+    const int S = Nc > Nsymb ? Nc : Nsymb;
+    std::vector<uint8_t> v(size_t(S) * S, 0);
+    for (int x = 0, y = 0; x < S && y < S; x += Dx, ++y) {
+        for (int j = y; j < S; j += Dy) v[size_t(j) * S + x] = 1;
+        for (int j = y; j >= 0; j -= Dy) v[size_t(j) * S + x] = 1;
+    }
+    int in_last = 0;
+    for (int j = 0; j < Nsymb; ++j) in_last += v[size_t(j) * S + Nc - 1];
+    if (in_last < 2)
+        for (int j = 0; j < S; ++j) v[size_t(j) * S + Nc - 1] = v[size_t(j) * S];
+    std::vector<uint8_t> t(size_t(Nsymb) * Nc);
+    for (int j = 0; j < Nsymb; ++j)
+        for (int i = 0; i < Nc; ++i) t[size_t(j) * Nc + i] = v[size_t(j) * S + i];
+    return t;
+}
+
+LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
+    auto rd32 = [&](size_t off) { uint32_t x; if (off + 4 > size) throw std::runtime_error("LDPC table blob truncated"); std::memcpy(&x, blob + off, 4); return x; };
+    if (size < 12 || std::memcmp(blob, "MLDP", 4) != 0 || rd32(4) != 1) throw std::runtime_error("LDPC table blob: bad magic/version");
+    const uint32_t nrates = rd32(8);
+    size_t off = 12;
+    for (uint32_t r = 0; r < nrates; ++r) {
+        const uint32_t k = rd32(off), P = rd32(off + 4), N = rd32(off + 8), E = rd32(off + 12), cw = rd32(off + 16), vw = rd32(off + 20);
+        off += 24;
+        const size_t need = size_t(P) + 2 * size_t(E) + N + 2 * size_t(E);
+        if (off + need > size) throw std::runtime_error("LDPC table blob truncated");
+        if (int(k) != K) { off += need; continue; }
+        LdpcGraph g;
+        g.K = K; g.P = P; g.N = N; g.E = E; g.Cwidth = cw; g.Vwidth = vw;
+        const uint8_t* cdeg = blob + off;
+        const uint8_t* cflat = cdeg + P;
+        const uint8_t* vdeg = cflat + 2 * size_t(E);
+        const uint8_t* vflat = vdeg + N;
+        g.cptr.resize(P + 1); g.cvar.resize(E); g.epack.resize(E); g.vptr.resize(N + 1); g.vedge.resize(E); g.eslot.resize(E); g.echk.resize(E);
+        uint32_t e = 0;
+        for (uint32_t c = 0; c < P; ++c) {
+            g.cptr[c] = e;
+            for (uint32_t j = 0; j < cdeg[c]; ++j, ++e) {
+                uint16_t v; std::memcpy(&v, cflat + 2 * size_t(e), 2);
+                g.cvar[e] = v;
+                g.echk[e] = uint16_t(c);
+                g.epack[e] = g.cptr[c] | (uint32_t(cdeg[c]) << 16) | (j << 24);
+            }
+        }
+        g.cptr[P] = e;
+        uint32_t s = 0;
+        for (uint32_t v = 0; v < N; ++v) {
+            g.vptr[v] = s;
+            for (uint32_t j = 0; j < vdeg[v]; ++j, ++s) {
+                uint16_t c; std::memcpy(&c, vflat + 2 * size_t(s), 2);
+                // slot j of variable v talks to check c: find v's edge inside check c (V_pos, ldpc_decoder_SPA.cc:81-104)
+                uint32_t found = UINT32_MAX;
+                for (uint32_t q = g.cptr[c]; q < g.cptr[c] + cdeg[c]; ++q)
+                    if (g.cvar[q] == v) { found = q; break; }
+                if (found == UINT32_MAX) throw std::runtime_error("LDPC table blob: C/V adjacency mismatch");
+                g.vedge[s] = uint16_t(found);
+                g.eslot[found] = uint16_t(s);
+            }
+        }
+        g.vptr[N] = s;
+        if (s != E) throw std::runtime_error("LDPC table blob: edge count mismatch");
+        return g;
+    }
+    throw std::runtime_error("LDPC table blob has no graph for this rate");
+}
+
+}  // namespace
+
+ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
+    if (cfg < 0 || cfg > 16) throw std::runtime_error("cfg must be 0..16");
+    const ModeRow& row = kModeTable[cfg];
+    ModeTables t;
+    t.cfg = cfg;
+    t.M = row.M;
+    t.preamble = row.preamble;
+    t.estimator = row.estimator;
+    t.amp_restore = (row.M == 2 || row.M == 4 || row.M == 8) ? 1 : 0;       // telecom_system.cc:2647-2654
+    t.K = static_cast<int>(static_cast<float>(t.N) * (row.rate16 / 16.0f));  // ldpc.cc:65
+    t.P = t.N - t.K;
+    switch (row.M) {                                                         // telecom_system.cc:1818-1826
+        case 2: t.Nsymb = 48; t.bps = 1; break;
+        case 4: t.Nsymb = 24; t.bps = 2; break;
+        case 8: t.Nsymb = 16; t.bps = 3; break;
+        case 16: t.Nsymb = 12; t.bps = 4; break;
+        default: t.Nsymb = 9; t.bps = 5; break;
+    }
+    const int G = t.Nsymb * t.Nc;
+    t.cell_type = make_pilot_lattice(t.Nsymb, t.Nc);
+    t.pilot_boost = static_cast<double>(1.33f);                               // physical_config.h:53 (float)
+    t.pilot_val.assign(G, 0.0);
+    {   // DBPSK pilot sequence, ofdm.cc:940-951
+        GlibcRandom rng(0);
+        int last = 0;
+        for (int c = 0; c < G; ++c) {
+            if (!t.cell_type[c]) continue;
+            const int pv = (rng.next() % 2) ^ last;
+            t.pilot_val[c] = double(2 * pv - 1) * t.pilot_boost;
+            last = pv;
+            ++t.nPilots;
+        }
+    }
+    t.nData = G - t.nPilots;
+    t.nBits = t.nData * t.bps;                                               // data_container.cc:93
+    t.nVirtual = t.N - t.nBits;
+    t.nReal = t.nBits - t.P;
+    t.bit_blk = t.nBits / 10;                                                // telecom_system.cc:2910-2911
+    t.tf_blk = t.nData / 10;
+    t.payload_bytes = (t.nReal - 16) / 8;                                    // telecom_system.cc:332-335
+    t.payload_stride = (t.nReal + 7) / 8;
+    t.frame_samples = t.Nsymb * t.Nofdm;
+    t.constellation = make_constellation(t.M);
+    {   // telecom_system.cc:1961-1966
+        GlibcRandom rng(0);
+        t.scrambler.resize(t.N);
+        for (int i = 0; i < t.N; ++i) t.scrambler[i] = uint8_t(rng.next() % 2);
+    }
+    t.twiddle.resize(128);
+    for (int k = 0; k < 128; ++k) {                                          // ofdm.cc:266-271
+        const double angle = -2.0 * M_PI * k / 256;
+        t.twiddle[k] = {std::cos(angle), std::sin(angle)};
+    }
+    // ---- RX gathers ---------------------------------------------------------------------
+    std::vector<uint16_t> data_cell;                                         // deframer ofdm.cc:837-852
+    for (int c = 0; c < G; ++c) if (!t.cell_type[c]) data_cell.push_back(uint16_t(c));
+    auto deint_src = [](int n, int bs) {                                     // interleaver.cc:94-109
+        std::vector<int> src(n);
+        const int nb = n / bs;
+        for (int i = 0; i < nb; ++i) for (int j = 0; j < bs; ++j) src[i * bs + j] = j * nb + i;
+        for (int i = nb * bs; i < n; ++i) src[i] = i;
+        return src;
+    };
+    const std::vector<int> tf = deint_src(t.nData, t.tf_blk);
+    t.sym_src.resize(t.nData);
+    for (int k = 0; k < t.nData; ++k) t.sym_src[k] = data_cell[tf[k]];
+    const std::vector<int> bd = deint_src(t.nBits, t.bit_blk);
+    // decoder input p <- de-interleaved index: telecom_system.cc:1300-1308
+    t.llr_src.resize(t.N);
+    for (int p = 0; p < t.N; ++p) {
+        int d;                       // index into the bit-de-interleaved vector
+        if (p < t.nReal) d = p;
+        else if (p < t.nReal + t.nVirtual) d = p - t.nReal;       // virtual bits copy LLRs of bits [0,nVirtual)
+        else d = p - t.nVirtual;                                  // parity shifted up by nVirtual
+        t.llr_src[p] = uint16_t(bd[d]);
+    }
+    // LS weights: x' = x / sum(x*x) with x = +-boost, sums accumulated sequentially (misc.cc:73-91)
+    t.ls_weight.assign(size_t(t.lsw) * t.lsw + 1, 0.0);
+    {
+        double s = 0;
+        for (size_t n = 1; n < t.ls_weight.size(); ++n) {
+            s += t.pilot_boost * t.pilot_boost;
+            t.ls_weight[n] = t.pilot_boost * (1.0 / s);
+        }
+    }
+    // ---- TX permutations (synthetic generator only) ----------------------------------------
+    t.bit_il.resize(t.nBits);
+    for (int i = 0; i < t.nBits; ++i) t.bit_il[bd[i]] = uint16_t(i);  // interleaver is the inverse gather: out[bd[i]] = in[i]
+    t.sym_cell.resize(t.nData);
+    for (int k = 0; k < t.nData; ++k) t.sym_cell[k] = t.sym_src[k];   // symbol k lands where the RX reads it back
+    t.graph = load_graph(t.K, blob, blob_size);
+    if (t.graph.P != t.P) throw std::runtime_error("LDPC graph does not match the mode");
+    return t;
+}
+
+}  // namespace mgpu

@@ -1,0 +1,71 @@
+// Host-side construction of every constant table the RX kernels consume.
+//
+// These are the init-time computations of the reference (done once per load_configuration),
+// restated so that the device sees bit-identical constants:
+//   mode table ............ telecom_system.cc:2506-2654, :1806-1869, data_container.cc:90-99
+//   PRNG .................. source/common/os_interop.cc:192-283 (glibc TYPE_3 random())
+//   pilot lattice/values .. ofdm.cc:904-952, :976-1064
+//   constellation ......... psk.cc:65-256
+//   FFT twiddles .......... ofdm.cc:256-290
+//   interleavers .......... interleaver.cc:77-109 ; re-pack telecom_system.cc:1300-1308
+//   scrambler ............. telecom_system.cc:1961-1966
+//   LDPC graph ............ mercury_normal_*_16.cc via mercury_ldpc_tables.bin (derived data)
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mgpu {
+
+struct Cplx { double re, im; };
+
+// glibc TYPE_3 additive-feedback generator; reference carries its own copy so pilots and the
+// scrambler are identical on every libc (os_interop.cc:157-170 holds the default state).
+class GlibcRandom {
+public:
+    explicit GlibcRandom(unsigned seed) { reseed(seed); }
+    void reseed(unsigned seed);
+    int32_t next();
+private:
+    int32_t st_[31];
+    int f_, r_;
+};
+
+struct LdpcGraph {
+    int K = 0, P = 0, N = 1600, E = 0, Cwidth = 0, Vwidth = 0;
+    std::vector<uint32_t> cptr;    // [P+1] first edge of each check (edges are check-major, reference row order)
+    std::vector<uint16_t> cvar;    // [E]   variable of edge e
+    std::vector<uint32_t> epack;   // [E]   check_start | deg<<16 | pos<<24
+    std::vector<uint32_t> vptr;    // [N+1] first slot of each variable
+    std::vector<uint16_t> vedge;   // [E]   edge index of (variable, slot) in the reference's slot order
+    std::vector<uint16_t> echk;    // [E]   check of edge e
+    std::vector<uint16_t> eslot;   // [E]   vptr[v]+slot for edge e (inverse of vedge)
+};
+
+struct ModeTables {
+    int cfg = 0, M = 0, bps = 0, K = 0, P = 0, N = 1600;
+    int Nsymb = 0, Nc = 50, Nfft = 256, Ngi = 16, Nofdm = 272;
+    int nData = 0, nBits = 0, nPilots = 0, nVirtual = 0, nReal = 0;
+    int bit_blk = 0, tf_blk = 0, preamble = 0, estimator = 1, amp_restore = 0, lsw = 21;
+    int payload_bytes = 0, payload_stride = 0, frame_samples = 0;
+    double pilot_boost = 0;                 // (double)(float)1.33
+    std::vector<uint8_t> cell_type;         // [G] 0 DATA / 1 PILOT
+    std::vector<double> pilot_val;          // [G] real pilot value (0 at data cells)
+    std::vector<Cplx> constellation;        // [M]
+    std::vector<uint8_t> scrambler;         // [1600]
+    std::vector<Cplx> twiddle;              // [128] exp(-2 pi i k/256)
+    std::vector<uint16_t> sym_src;          // [nData] grid cell feeding de-interleaved symbol k
+    std::vector<uint16_t> llr_src;          // [1600] index into the demod LLR vector feeding decoder input p
+    std::vector<double> ls_weight;          // [lsw*lsw+1] boost/sum_n(boost^2) per window population n
+    // TX-side permutations for the synthetic generator
+    std::vector<uint16_t> bit_il;           // [nBits] interleaved position <- encoded index: out[bit_il[i]] = in[i]
+    std::vector<uint16_t> sym_cell;         // [nData] grid cell of modulated symbol k (tf-interleave + framer)
+    LdpcGraph graph;
+};
+
+// Throws std::runtime_error on a bad cfg or unreadable/corrupt table blob.
+ModeTables build_mode_tables(int cfg, const uint8_t* ldpc_blob, size_t ldpc_blob_size);
+
+uint16_t crc16_modbus(const uint8_t* bytes, int n);
+
+}  // namespace mgpu

@@ -1,0 +1,187 @@
+// Synthetic-workload generator (NOT part of the RX path; bench.py and the scale tests use it so
+// that inputs are born in HBM): Philox-keyed payload -> CRC16 -> scrambler -> IRA LDPC encode ->
+// bit interleave -> constellation map -> time/freq interleave -> framer (pilots) -> IFFT + GI ->
+// channel (AWGN, optional static 2-path). It mirrors the reference TX chain
+// (telecom_system.cc:343-382 transmit_byte, :384-470 transmit_bit; ldpc.cc:111-132 encode;
+// psk.cc:259-272 mod; ofdm.cc:814-835 framer, :855-860 symbol_mod) and the AWGN scaling of
+// baseband_test_EsN0 (telecom_system.cc:141-153). Generator definition: DESIGN.md §Synthetic inputs;
+// the CPU twin used to validate it is oracle/mercury_oracle.c:morc_gen_frame.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_tables.h"
+
+#define TX_THREADS 256
+
+namespace {
+
+struct c2 { double re, im; };
+__device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+
+__device__ void philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2_, uint32_t c3, uint32_t out[4]) {
+    uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2_), l1 = 0xCD9E8D57u * c2_;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2_ = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2_; out[3] = c3;
+}
+
+__device__ __forceinline__ double gauss_bm(uint32_t a, uint32_t b) {
+    const double u1 = (double(a) + 1.0) * (1.0 / 4294967296.0);
+    const double u2 = double(b) * (1.0 / 4294967296.0);
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+}
+
+}  // namespace
+
+// LDS: bits 1600 | enc 1600 | inter 1600 | par 1600 (bytes) | grid 16*G | fft 4*256*16 | tw 128*16 | pay 256
+extern "C" size_t mgpu_txgen_lds_bytes(int G) { return 4 * 1600 + size_t(16) * G + 4 * 256 * 16 + 128 * 16 + 256 + 64; }
+
+extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
+    MgpuDev T, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel,
+    double* __restrict__ baseband, uint8_t* __restrict__ payload_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint8_t* bits = smem;               // data bits (scrambled, with virtual copy): K entries
+    uint8_t* enc = bits + 1600;         // encoded word N
+    uint8_t* inter = enc + 1600;        // interleaved nBits
+    uint8_t* par = inter + 1600;        // info-part parity per check
+    c2* grid = reinterpret_cast<c2*>(par + 1600);
+    c2* fftb = grid + T.G;
+    c2* tw = fftb + 4 * 256;
+    uint8_t* pay = reinterpret_cast<uint8_t*>(tw + 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (int(blockIdx.x) >= F) return;
+    const uint64_t frame = frame0 + blockIdx.x;
+    const uint32_t flo = uint32_t(frame), fhi = uint32_t(frame >> 32);
+    const int K = T.K, P = T.P, nReal = T.nReal, fs = T.payload_bytes;
+    c2* out = reinterpret_cast<c2*>(baseband) + size_t(blockIdx.x) * T.frame_samples;
+
+    for (int i = tid; i < 128; i += TX_THREADS) tw[i] = {T.twiddle[2 * i], -T.twiddle[2 * i + 1]};  // conj (ofdm.cc:365)
+    for (int j = tid; j < fs; j += TX_THREADS) {
+        uint32_t w[4];
+        philox4x32(seed, uint32_t(j >> 4), 0u, flo, fhi, w);
+        pay[j] = uint8_t(w[(j >> 2) & 3] >> (8 * (j & 3)));
+    }
+    __syncthreads();
+    if (tid == 0) {                     // CRC16 over the payload (telecom_system.cc:365-372)
+        unsigned crc = 0xffff;
+        for (int j = 0; j < fs; ++j) {
+            crc ^= pay[j];
+            for (int i = 0; i < 8; ++i) crc = (crc & 1) ? ((crc >> 1) ^ 0xA001) : (crc >> 1);
+        }
+        pay[fs] = uint8_t(crc & 0xff);
+        pay[fs + 1] = uint8_t(crc >> 8);
+    }
+    __syncthreads();
+    for (int i = tid; i < nReal; i += TX_THREADS) {
+        const int byte = i >> 3;
+        const uint8_t b = byte < fs + 2 ? uint8_t((pay[byte] >> (i & 7)) & 1) : uint8_t(0);
+        bits[i] = b ^ T.scrambler[i];   // bit_energy_dispersal
+    }
+    if (payload_out)
+        for (int b = tid; b < T.payload_stride; b += TX_THREADS) {
+            // expected RX bytes: the nReal (un-scrambled) data bits packed LSB first
+            uint8_t v = b < fs + 2 ? pay[b] : uint8_t(0);
+            if ((b + 1) * 8 > nReal) v &= uint8_t((1u << (nReal - b * 8)) - 1);
+            payload_out[size_t(blockIdx.x) * T.payload_stride + b] = v;
+        }
+    __syncthreads();
+    for (int i = tid; i < T.nVirtual; i += TX_THREADS) bits[nReal + i] = bits[i];
+    __syncthreads();
+    // IRA encode (ldpc.cc:111-132): parity i = XOR of the other entries of check row i
+    for (int i = tid; i < K; i += TX_THREADS) enc[i] = bits[i];
+    for (int c = tid; c < P; c += TX_THREADS) {
+        uint8_t x = 0;
+        for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) { const int v = T.cvar[e]; if (v < K) x ^= bits[v]; }
+        par[c] = x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int c = 0; c < P; ++c) {
+            uint8_t x = par[c];
+            for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) { const int v = T.cvar[e]; if (v >= K && v != K + c) x ^= enc[v]; }
+            enc[K + c] = x;
+        }
+    }
+    __syncthreads();
+    // parity moved down over the virtual bits, then bit interleaver (gather form)
+    for (int pos = tid; pos < T.nBits; pos += TX_THREADS) {
+        const int src = T.bit_il[pos];
+        inter[pos] = src < nReal ? enc[src] : enc[src + T.nVirtual];
+    }
+    __syncthreads();
+    // pilots + mapped data into the frame grid
+    for (int c = tid; c < T.G; c += TX_THREADS) if (T.cell_type[c]) grid[c] = {T.pilot_val[c], 0.0};
+    for (int k = tid; k < T.nData; k += TX_THREADS) {
+        unsigned loc = 0;
+        for (int j = 0; j < T.bps; ++j) loc = (loc << 1) | inter[k * T.bps + j];
+        grid[T.sym_src[k]] = {T.constellation[2 * loc], T.constellation[2 * loc + 1]};
+    }
+    __syncthreads();
+    // symbol_mod: zero_padder + unnormalised IFFT + gi_adder, one wave per symbol
+    const int passes = (T.Nsymb + 3) / 4;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int s = pass * 4 + wave;
+        const bool act = s < T.Nsymb;
+        c2* v = fftb + wave * 256;
+        if (act) {
+            for (int i = lane; i < 256; i += 64) {
+                c2 z = {0.0, 0.0};
+                if (i >= 256 - 25) z = grid[s * 50 + (i - (256 - 25))];
+                else if (i >= 1 && i <= 25) z = grid[s * 50 + 25 + (i - 1)];
+                v[__brev(unsigned(i)) >> 24] = z;
+            }
+        }
+        __syncthreads();
+        for (int size = 2; size <= 256; size <<= 1) {
+            const int half = size >> 1, step = 256 / size;
+            if (act) {
+                for (int b = lane; b < 128; b += 64) {
+                    const int j = b & (half - 1);
+                    const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
+                    const c2 t = cmul(tw[j * step], v[i1]);
+                    const c2 u = v[i0];
+                    v[i1] = {u.re - t.re, u.im - t.im};
+                    v[i0] = {u.re + t.re, u.im + t.im};
+                }
+            }
+            __syncthreads();
+        }
+        if (act) {
+            c2* y = out + size_t(s) * 272;
+            for (int j = lane; j < 256; j += 64) y[j + 16] = v[j];
+            if (lane < 16) y[lane] = v[lane + 240];
+        }
+        __syncthreads();
+    }
+    // channel, back to front in chunks so the 6-sample echo always reads clean samples
+    const int n = T.frame_samples;
+    c2 h1 = {0.0, 0.0};
+    if (channel == 1) {
+        uint32_t w[4];
+        philox4x32(seed, 0u, 2u, flo, fhi, w);
+        const double phi = 2.0 * M_PI * (double(w[0]) * (1.0 / 4294967296.0));
+        h1 = {0.5 * cos(phi), 0.5 * sin(phi)};
+    }
+    for (int base = ((n - 1) / TX_THREADS) * TX_THREADS; base >= 0; base -= TX_THREADS) {
+        const int i = base + tid;
+        c2 x = {0.0, 0.0};
+        if (i < n) {
+            x = out[i];
+            if (channel == 1 && i >= 6) { const c2 e = cmul(h1, out[i - 6]); x = {x.re + e.re, x.im + e.im}; }
+            uint32_t w[4];
+            philox4x32(seed, uint32_t(i), 1u, flo, fhi, w);
+            const double nr = noise_amp * gauss_bm(w[0], w[1]), ni = noise_amp * gauss_bm(w[2], w[3]);
+            x = {(x.re / 16.0 + nr) * 16.0, (x.im / 16.0 + ni) * 16.0};
+        }
+        __syncthreads();
+        if (i < n) out[i] = x;
+        __syncthreads();
+    }
+}

@@ -1,0 +1,174 @@
+"""ctypes binding of the C-ABI in include/mercury_gpu.h.
+
+This is only a thin loader: every computation happens in the HIP library
+(``mercury_amd/libmercury_gpu.so``). There is NO CPU fallback — if the library is missing or no
+GPU is visible, constructing :class:`RxPhy` raises.
+
+Naming follows the reference's physical layer (source/physical_layer/telecom_system.cc): a
+*frame* is one LDPC codeword worth of OFDM symbols for one ``CONFIG_n`` mode, ``receive`` runs
+the span of ``receive_byte`` after synchronisation (telecom_system.cc:1132-1345) on a batch of
+frames, ``ldpc_decode`` is ``cl_ldpc::decode`` (ldpc.h:90) on a batch of LLR vectors.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmercury_gpu.so")
+
+DEC_GBF, DEC_SPA, DEC_MINSUM = 0, 1, 2
+EST_ZF, EST_LS = 0, 1
+
+
+class Config(C.Structure):
+    _fields_ = [("cfg", C.c_int), ("max_iters", C.c_int), ("decoder", C.c_int), ("agc", C.c_int),
+                ("variance_source", C.c_int), ("device", C.c_int), ("max_batch", C.c_int),
+                ("minsum_alpha", C.c_float)]
+
+
+INFO_FIELDS = ("cfg M bits_per_symbol K P N Nsymb Nc Nfft Ngi Nofdm nData nBits nPilots nVirtual nReal "
+               "bit_blk tf_blk preamble_nsymb estimator amp_restore ls_window Cwidth Vwidth E "
+               "payload_bytes payload_stride frame_samples").split()
+
+
+class Info(C.Structure):
+    _fields_ = [(n, C.c_int) for n in INFO_FIELDS]
+
+
+class Taps(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in "grid H eq syms llr_demod llr_ldpc variance agc_gain".split()]
+
+
+STATS_DTYPE = np.dtype([("iterations_done", "<i4"), ("crc", "<i4"), ("all_zeros", "<i4"),
+                        ("message_decoded", "<i4"), ("variance", "<f4"), ("snr_db", "<f4")])
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library; raise (never fall back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the Mercury RX path has no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.mgpu_last_error.restype = C.c_char_p
+        lib.mgpu_last_error.argtypes = [C.c_void_p]
+        lib.mgpu_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        lib.mgpu_txgen_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.mgpu_rx_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.mgpu_frontend_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.mgpu_ldpc_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.mgpu_destroy.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
+    "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
+    "mgpu_last_kernel_ms", "mgpu_enable_timing",
+]
+
+
+class MgpuError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class RxPhy:
+    """One GPU receive context for one Mercury mode (``load_configuration(cfg)`` equivalent)."""
+
+    def __init__(self, cfg, max_iters=50, decoder=DEC_SPA, agc=1, variance_source=1, device=0,
+                 max_batch=4096, minsum_alpha=0.0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        c = Config(cfg, max_iters, decoder, agc, variance_source, device, max_batch, minsum_alpha)
+        rc = self.lib.mgpu_create(C.byref(c), C.byref(self.h))
+        if rc != 0:
+            raise MgpuError("mgpu_create failed (%d): %s" % (rc, self.lib.mgpu_last_error(None).decode()))
+        self.config = c
+        self.max_iters = max_iters
+        self.max_batch = max_batch
+        i = Info()
+        self._ck(self.lib.mgpu_get_info(self.h, C.byref(i)))
+        self.info = i
+        for n in INFO_FIELDS:
+            setattr(self, n, getattr(i, n))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MgpuError("mgpu error %d: %s" % (rc, self.lib.mgpu_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.mgpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer entry points -------------------------------------------------------------
+    def receive(self, baseband, taps=False, want_llr=False):
+        """baseband: complex128 [F, Nsymb*Nofdm]. Returns dict(payload, stats[, taps...])."""
+        bb = np.ascontiguousarray(baseband, np.complex128).reshape(-1, self.frame_samples)
+        F = bb.shape[0]
+        payload = np.zeros((F, self.payload_stride), np.uint8)
+        stats = np.zeros(F, STATS_DTYPE)
+        out = {"payload": payload, "stats": stats}
+        if taps:
+            G = self.Nsymb * self.Nc
+            t = dict(grid=np.zeros((F, G), np.complex128), H=np.zeros((F, G), np.complex128),
+                     eq=np.zeros((F, G), np.complex128), syms=np.zeros((F, self.nData), np.complex128),
+                     llr_demod=np.zeros((F, self.nBits), np.float32), llr_ldpc=np.zeros((F, 1600), np.float32),
+                     variance=np.zeros(F, np.float64), agc_gain=np.zeros(F, np.float64))
+            ts = Taps(**{k: v.ctypes.data for k, v in t.items()})
+            self._ck(self.lib.mgpu_rx_batch_taps(self.h, _ptr(bb), C.c_int(F), _ptr(payload), _ptr(stats), C.byref(ts)))
+            out.update(t)
+        else:
+            llr = np.zeros((F, 1600), np.float32) if want_llr else None
+            self._ck(self.lib.mgpu_rx_batch(self.h, _ptr(bb), C.c_int(F), _ptr(payload), _ptr(stats), _ptr(llr)))
+            if want_llr:
+                out["llr_ldpc"] = llr
+        return out
+
+    def ldpc_decode(self, llr):
+        """llr: float32 [F,1600] -> (bits uint8 [F,K], iterations int32 [F])  (cl_ldpc::decode)."""
+        l = np.ascontiguousarray(llr, np.float32).reshape(-1, 1600)
+        F = l.shape[0]
+        bits = np.zeros((F, self.K), np.uint8)
+        iters = np.zeros(F, np.int32)
+        self._ck(self.lib.mgpu_ldpc_batch(self.h, _ptr(l), C.c_int(F), _ptr(bits), _ptr(iters)))
+        return bits, iters
+
+    # ---- device-buffer entry points (raw device pointers, e.g. torch tensor.data_ptr()) --------
+    def receive_dev(self, d_baseband, F, d_payload, d_stats, d_llr=None, stream=None):
+        self._ck(self.lib.mgpu_rx_batch_dev(self.h, d_baseband, F, d_payload, d_stats, d_llr, stream))
+
+    def frontend_dev(self, d_baseband, F, d_llr, d_variance=None, stream=None):
+        self._ck(self.lib.mgpu_frontend_dev(self.h, d_baseband, F, d_llr, d_variance, stream))
+
+    def ldpc_decode_dev(self, d_llr, F, d_bits=None, d_iters=None, d_payload=None, d_stats=None, d_variance=None, stream=None):
+        self._ck(self.lib.mgpu_ldpc_batch_dev(self.h, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_variance, stream))
+
+    def txgen_dev(self, seed, frame0, F, noise_amp, d_baseband, d_payload=None, channel=0, stream=None):
+        self._ck(self.lib.mgpu_txgen_dev(self.h, seed, frame0, F, noise_amp, channel, d_baseband, d_payload, stream))
+
+    def enable_timing(self, on=True):
+        self._ck(self.lib.mgpu_enable_timing(self.h, C.c_int(1 if on else 0)))
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 2)()
+        self._ck(self.lib.mgpu_last_kernel_ms(self.h, ms))
+        return float(ms[0]), float(ms[1])

@@ -1,0 +1,219 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): bit-exact interleaver indexing / hard decisions / CRC / payload;
+soft LLRs within 1e-5 (absolute, scaled by max(1,|LLR|) as SURVEY.md §7.3-2 specifies).
+"""
+import numpy as np
+import pytest
+
+import oraclelib
+from conftest import OPERATING_ESN0, SEED
+from oraclelib import FLAGS_BASEBAND_TEST, FLAGS_RECEIVE_BYTE, Oracle, noise_amp_for
+
+pytestmark = pytest.mark.gpu
+
+LLR_TOL = 1e-5
+
+
+def _rx(cfg, **kw):
+    from mercury_amd import RxPhy
+    return RxPhy(cfg, **kw)
+
+
+def _frames(orc, snrs, seed=SEED, channel=0, start=0):
+    bb, pl = [], []
+    for i, snr in enumerate(snrs):
+        b, p = orc.gen_frame(seed, start + i, noise_amp_for(snr), channel)
+        bb.append(b)
+        pl.append(p)
+    return np.stack(bb), pl
+
+
+def _llr_close(got, ref):
+    tol = LLR_TOL * np.maximum(1.0, np.abs(ref.astype(np.float64)))
+    return np.abs(got.astype(np.float64) - ref.astype(np.float64)) <= tol
+
+
+def _variants(cfg):
+    # the reference's receive_byte variant divides by a ~1e-33 variance for the ZF modes (the
+    # equalised pilots equal the pilots exactly), which turns every LLR into rounding noise; the
+    # ZF modes are therefore exercised the way the reference's own BER loop runs them.
+    if cfg in (15, 16):
+        return [(0, 0, FLAGS_BASEBAND_TEST)]
+    return [(1, 1, FLAGS_RECEIVE_BYTE), (0, 0, FLAGS_BASEBAND_TEST)]
+
+
+@pytest.mark.parametrize("cfg", list(range(17)))
+def test_all_stages_match_oracle(cfg):
+    orc = Oracle(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    snrs = [op, op, op + 1.0, -15.0, 60.0]
+    bb, payloads = _frames(orc, snrs)
+    for agc, vs, flags in _variants(cfg):
+        rx = _rx(cfg, max_iters=50, agc=agc, variance_source=vs, max_batch=len(snrs))
+        out = rx.receive(bb, taps=True)
+        for f in range(len(snrs)):
+            ref = orc.rx(bb[f], flags)
+            # FP64 front-end: the reference's operation order is reproduced, so demand (near) equality
+            for key, rtol in (("grid", 0.0), ("eq", 1e-12), ("syms", 1e-12)):
+                d = np.abs(out[key][f] - ref[key]).max()
+                scale = np.abs(ref[key]).max()
+                assert d <= rtol * scale, (cfg, flags, f, key, d, scale)
+            assert abs(out["variance"][f] - ref["variance"]) <= 1e-12 * abs(ref["variance"]), (cfg, f)
+            assert np.float32(out["stats"]["variance"][f]) == np.float32(ref["variance_f"]) or \
+                abs(out["stats"]["variance"][f] - ref["variance_f"]) <= 2e-7 * ref["variance_f"]
+            assert _llr_close(out["llr_demod"][f], ref["llr_demod"]).all(), (cfg, flags, f, "llr_demod")
+            assert _llr_close(out["llr_ldpc"][f], ref["llr_ldpc"]).all(), (cfg, flags, f, "llr_ldpc")
+            # integer / byte outputs: bit exact
+            assert out["stats"]["iterations_done"][f] == ref["iterations"], (cfg, flags, f, "iterations")
+            assert np.array_equal(out["payload"][f], ref["bytes"].astype(np.uint8)), (cfg, flags, f, "payload")
+            assert out["stats"]["crc"][f] == ref["crc"], (cfg, flags, f)
+            assert out["stats"]["all_zeros"][f] == ref["all_zeros"], (cfg, flags, f)
+            if ref["iterations"] <= 50 and snrs[f] > 0 or snrs[f] == 60.0:
+                assert np.array_equal(out["payload"][f][: orc.payload_bytes], payloads[f].astype(np.uint8))
+        rx.close()
+
+
+@pytest.mark.parametrize("cfg", [0, 3, 5, 8, 9, 12])
+def test_ldpc_spa_bit_exact_on_identical_llrs(cfg):
+    """cl_ldpc::decode parity: same float LLRs in -> same hard bits and iteration count out, including
+    frames that never converge (the GPU evaluates tanh/atanh with the reference libm's algorithm)."""
+    orc = Oracle(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    snrs = [op - 1.0] * 6 + [op + 0.5] * 6 + [-15.0] * 3 + [op - 2.5] * 5
+    bb, _ = _frames(orc, snrs, seed=77)
+    llr = np.stack([orc.rx(b, FLAGS_BASEBAND_TEST | oraclelib.FLAG_NO_LDPC)["llr_ldpc"] for b in bb])
+    rx = _rx(cfg, max_iters=50, max_batch=len(snrs))
+    bits, iters = rx.ldpc_decode(llr)
+    for f in range(len(snrs)):
+        rb, ri = orc.ldpc_decode(llr[f])
+        assert iters[f] == ri, (cfg, f, iters[f], ri)
+        assert np.array_equal(bits[f], rb.astype(np.uint8)), (cfg, f, "bits differ", ri)
+
+
+@pytest.mark.parametrize("max_iters", [5, 20])
+def test_ldpc_iteration_cap(max_iters):
+    orc = Oracle(8, max_iters)
+    bb, _ = _frames(orc, [0.0, 1.0, -15.0, 2.5], seed=5)
+    llr = np.stack([orc.rx(b, oraclelib.FLAG_NO_LDPC)["llr_ldpc"] for b in bb])
+    rx = _rx(8, max_iters=max_iters, max_batch=4)
+    bits, iters = rx.ldpc_decode(llr)
+    for f in range(4):
+        rb, ri = orc.ldpc_decode(llr[f])
+        assert iters[f] == ri and np.array_equal(bits[f], rb.astype(np.uint8))
+    assert iters[2] == max_iters + 1
+
+
+@pytest.mark.parametrize("cfg", [2, 8, 13, 16])
+def test_gbf_decoder_bit_exact(cfg):
+    from mercury_amd import DEC_GBF
+    orc = Oracle(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    bb, _ = _frames(orc, [op + 3, op + 4, op + 6, -15.0, 60.0], seed=9)
+    llr = np.stack([orc.rx(b, FLAGS_BASEBAND_TEST | oraclelib.FLAG_NO_LDPC)["llr_ldpc"] for b in bb])
+    rx = _rx(cfg, decoder=DEC_GBF, max_batch=8)
+    bits, iters = rx.ldpc_decode(llr)
+    for f in range(len(bb)):
+        rb, ri = orc.ldpc_decode(llr[f], alg=0)
+        assert iters[f] == ri, (cfg, f, iters[f], ri)
+        assert np.array_equal(bits[f], rb.astype(np.uint8)), (cfg, f)
+
+
+@pytest.mark.parametrize("cfg", [5, 8, 9, 13, 16])
+def test_minsum_agrees_where_both_converge(cfg):
+    """Min-sum is not the reference's algorithm: parity is defined on frames both decoders converge on
+    (a converged word is a codeword)."""
+    from mercury_amd import DEC_MINSUM
+    orc = Oracle(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    snrs = [op + 1.0] * 16
+    bb, payloads = _frames(orc, snrs, seed=21)
+    variant = _variants(cfg)[0]
+    rx = _rx(cfg, decoder=DEC_MINSUM, agc=variant[0], variance_source=variant[1], max_batch=len(snrs))
+    out = rx.receive(bb)
+    both = 0
+    for f in range(len(snrs)):
+        ref = orc.rx(bb[f], variant[2])
+        if ref["iterations"] <= 50 and out["stats"]["iterations_done"][f] <= 50:
+            both += 1
+            assert np.array_equal(out["payload"][f], ref["bytes"].astype(np.uint8)), (cfg, f)
+            assert out["stats"]["crc"][f] == 0
+    assert both >= len(snrs) // 2
+
+
+def test_txgen_matches_cpu_generator_and_round_trips():
+    """The on-device generator follows the same Philox streams as the oracle's: identical payload bytes,
+    time-domain samples equal up to libm ulps in the Box-Muller noise; and everything it makes decodes."""
+    import torch
+    cfg, F = 8, 64
+    orc = Oracle(cfg, 50)
+    rx = _rx(cfg, max_batch=F)
+    amp = noise_amp_for(4.0)
+    bb = torch.empty((F, rx.frame_samples, 2), dtype=torch.float64, device="cuda")
+    pl = torch.empty((F, rx.payload_stride), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rx.txgen_dev(SEED, 1000, F, amp, bb.data_ptr(), pl.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    bbh = bb.cpu().numpy().view(np.complex128).reshape(F, -1)
+    plh = pl.cpu().numpy()
+    for f in (0, 1, 63):
+        ref_bb, ref_pl = orc.gen_frame(SEED, 1000 + f, amp)
+        assert np.array_equal(plh[f][: orc.payload_bytes], ref_pl.astype(np.uint8))
+        assert np.abs(bbh[f] - ref_bb).max() <= 1e-9 * np.abs(ref_bb).max()
+    out = rx.receive(bbh)
+    assert (out["stats"]["message_decoded"] == 1).all()
+    assert np.array_equal(out["payload"], plh)
+
+
+def test_full_batch_round_trip_mode8():
+    """BASELINE.json config[1] size (4096 mode-8 frames) through size-independent properties:
+    every frame generated on the device at +2.5 dB must come back with CRC==0 and the sent payload,
+    and a sample of frames is re-checked against the oracle bit for bit."""
+    import torch
+    cfg, F = 8, 4096
+    rx = _rx(cfg, max_batch=F)
+    amp = noise_amp_for(2.5)
+    bb = torch.empty((F, rx.frame_samples, 2), dtype=torch.float64, device="cuda")
+    sent = torch.empty((F, rx.payload_stride), dtype=torch.uint8, device="cuda")
+    got = torch.empty((F, rx.payload_stride), dtype=torch.uint8, device="cuda")
+    stats = torch.empty((F, 6), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rx.txgen_dev(SEED, 0, F, amp, bb.data_ptr(), sent.data_ptr(), stream=st)
+    rx.receive_dev(bb.data_ptr(), F, got.data_ptr(), stats.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    s = stats.cpu().numpy()
+    decoded = s[:, 3] == 1
+    assert decoded.mean() > 0.97, decoded.mean()
+    assert torch.equal(got[torch.from_numpy(decoded).cuda()], sent[torch.from_numpy(decoded).cuda()])
+    orc = Oracle(cfg, 50)
+    bbh = bb[:12].cpu().numpy().view(np.complex128).reshape(12, -1)
+    for f in range(12):
+        ref = orc.rx(bbh[f], FLAGS_RECEIVE_BYTE)
+        assert s[f, 0] == ref["iterations"] and s[f, 1] == ref["crc"]
+        assert np.array_equal(got[f].cpu().numpy(), ref["bytes"].astype(np.uint8))
+
+
+def test_empty_and_oversize_batches():
+    from mercury_amd import MgpuError
+    rx = _rx(8, max_batch=4)
+    out = rx.receive(np.zeros((0, rx.frame_samples), np.complex128))
+    assert out["payload"].shape[0] == 0
+    with pytest.raises(MgpuError):
+        rx.receive(np.zeros((5, rx.frame_samples), np.complex128))
+    # all-zero input: pilots vanish, variance/LLRs are NaN/inf in the reference too; must not hang
+    out = rx.receive(np.zeros((2, rx.frame_samples), np.complex128))
+    assert out["stats"]["message_decoded"].sum() == 0
+
+
+def test_multipath_channel_mode16():
+    """BASELINE.json config[3] shape at test size: 2-path channel, mode 16 (ZF estimator)."""
+    cfg = 16
+    orc = Oracle(cfg, 50)
+    bb, payloads = _frames(orc, [30.0] * 6, seed=3, channel=1)
+    rx = _rx(cfg, agc=0, variance_source=0, max_batch=8)
+    out = rx.receive(bb, taps=True)
+    for f in range(6):
+        ref = orc.rx(bb[f], FLAGS_BASEBAND_TEST)
+        assert _llr_close(out["llr_ldpc"][f], ref["llr_ldpc"]).all()
+        assert out["stats"]["iterations_done"][f] == ref["iterations"]
+        assert np.array_equal(out["payload"][f], ref["bytes"].astype(np.uint8))
