@@ -54,6 +54,13 @@ def load_library():
             raise RuntimeError(
                 "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(the Mercury RX path has no CPU fallback)" % LIB_PATH)
+        # torch (used by bench/tests for device buffers, streams and torch.distributed) bundles its own
+        # HIP runtime under the same SONAME; it has to be the first one in the process or the process ends
+        # up with two HSA runtimes and the second one sees no GPU.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing, not a dependency of the library itself
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.mgpu_last_error.restype = C.c_char_p
         lib.mgpu_last_error.argtypes = [C.c_void_p]
