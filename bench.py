@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — RX frames/s + LDPC iterations/s for Mercury's physical-layer RX hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+  (one rank per GPU). A *step* is one pass of the whole hot path (OFDM demod -> estimate/equalise ->
+  de-interleave -> demap -> LDPC -> de-scramble/CRC) over one batch of synthetic frames that is already
+  resident in HBM. Frames are sharded by frame index across ranks (weak scaling: every rank owns
+  --frames frames per step); there is no data-path collective, only the barrier + MAX-time reduction
+  the contract asks for.
+
+Workload (BASELINE.json configs[1]): 4096 mode-8 frames (QPSK, LDPC 6/16, N=1600), max 50 iterations,
+AWGN. Default Es/N0 = -15 dB so that every frame executes all 50 iterations ("mode 8 @ 50 iters");
+--esn0 2.5 gives the operating point with early termination. Decoder = sum-product in double (the
+reference's algorithm, results identical to the CPU path); --decoder minsum selects the fp32 variant.
+
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (the LDPC decoder) with SURVEY.md
+§8d's algorithmic bytes (16*E + 4*N per codeword-iteration + LLRs in + payload out) against 8 TB/s;
+`cpu_baseline` times the CPU checker (the plain-C port of the reference, bit-identical to it) on a
+bounded sample of the very same frames on the host cores, and cross-checks the GPU results on them.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from mercury_amd import DEC_GBF, DEC_MINSUM, DEC_SPA, RxPhy
+from mercury_amd.sharding import frame_range
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 0x4D455243
+
+
+def algorithmic_bytes(rx, iters_exec_sum, frames):
+    """B_frame = 16*Nsymb*Nofdm + 4*N + I_exec*(16*E + 4*N) + ceil(nReal/8) + 16."""
+    b_in = 16 * rx.Nsymb * rx.Nofdm
+    b_iter = 16 * rx.E + 4 * rx.N
+    b_out = rx.payload_stride + 16
+    ldpc = frames * (4 * rx.N + b_out) + iters_exec_sum * b_iter       # what the decoder kernel itself moves
+    total = frames * (b_in + 4 * rx.N + b_out) + iters_exec_sum * b_iter
+    return ldpc, total, b_iter
+
+
+def cpu_baseline(cfg, max_iters, bb_sample, flags, gpu_payload, gpu_stats):
+    """Time the CPU checker on a bounded sample of the same frames; also cross-check the GPU output."""
+    import oraclelib
+    cores = os.cpu_count() or 1
+    n = bb_sample.shape[0]
+    per = max(1, n // cores)
+    used = min(cores, n)
+    chunks = [(i * per, min(n, (i + 1) * per)) for i in range(used)]
+    chunks = [c for c in chunks if c[1] > c[0]]
+    ctxs = [oraclelib.Oracle(cfg, max_iters) for _ in chunks]
+    results = [None] * len(chunks)
+
+    def work(i):
+        a, b = chunks[i]
+        results[i] = ctxs[i].rx_many(bb_sample[a:b], flags)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(chunks))]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    frames = sum(b - a for a, b in chunks)
+    iters_exec = sum(r[0] for r in results)
+    mism = 0
+    for (a, b), r in zip(chunks, results):
+        _, iters, crc, pl = r
+        mism += int((gpu_stats[a:b, 0] != iters).sum()) + int((gpu_stats[a:b, 1] != crc).sum())
+        mism += int((gpu_payload[a:b, : pl.shape[1]] != pl).any(axis=1).sum())
+    out = {"value": frames / dt, "unit": "frames/s", "cores": len(chunks), "kind": "port",
+           "ldpc_iters_per_s": iters_exec / dt,
+           "sample": "%d of the benchmarked frames (same samples, same flags), %d threads x %d frames, %.1f s wall"
+                     % (frames, len(chunks), per, dt),
+           "gpu_vs_cpu_mismatches": mism}
+    # the real reference objects (oracle/_ref), one thread, for the record
+    if oraclelib.RefLib.available():
+        try:
+            ref = oraclelib.RefLib(cfg, max_iters)
+            k = min(8, n)
+            t0 = time.perf_counter()
+            for f in range(k):
+                ref.rx(bb_sample[f], flags)
+            out["reference_1core_frames_per_s"] = k / (time.perf_counter() - t0)
+        except Exception as e:  # pragma: no cover
+            out["reference_1core_error"] = str(e)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cfg", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per step per GPU")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--esn0", type=float, default=-15.0)
+    ap.add_argument("--decoder", choices=["spa", "minsum", "gbf"], default="spa")
+    ap.add_argument("--variant", choices=["receive_byte", "baseband_test"], default="receive_byte")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-per-core", type=int, default=96)
+    ap.add_argument("--nbuf", type=int, default=2, help="distinct input batches cycled through")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    decoder = {"spa": DEC_SPA, "minsum": DEC_MINSUM, "gbf": DEC_GBF}[args.decoder]
+    agc, vs = (1, 1) if args.variant == "receive_byte" else (0, 0)
+    F = args.frames
+    rx = RxPhy(args.cfg, max_iters=args.iters, decoder=decoder, agc=agc, variance_source=vs,
+               device=local_rank, max_batch=F)
+    noise_amp = float(10.0 ** (-args.esn0 / 20.0) / np.sqrt(2.0))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # synthetic inputs, born in HBM; frame indices are global so ranks hold disjoint frames
+    nbuf = max(1, args.nbuf)
+    bufs, sent = [], []
+    for b in range(nbuf):
+        lo, _ = frame_range(rank, world, F * world)
+        frame0 = b * F * world + lo
+        bb = torch.empty((F, rx.frame_samples, 2), dtype=torch.float64, device=dev)
+        pl = torch.empty((F, rx.payload_stride), dtype=torch.uint8, device=dev)
+        rx.txgen_dev(SEED, frame0, F, noise_amp, bb.data_ptr(), pl.data_ptr(), stream=stream)
+        bufs.append(bb)
+        sent.append(pl)
+    payload = torch.empty((F, rx.payload_stride), dtype=torch.uint8, device=dev)
+    stats = torch.empty((F, 6), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step(i):
+        rx.receive_dev(bufs[i % nbuf].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    rx.enable_timing(True)
+    torch.cuda.synchronize()
+    iters_acc = torch.zeros((), dtype=torch.int64, device=dev)
+    decoded_acc = torch.zeros((), dtype=torch.int64, device=dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        # iterations actually executed (max+1 means "never converged" after max iterations)
+        iters_acc += stats[:, 0].clamp(max=args.iters).sum()
+        decoded_acc += stats[:, 3].sum()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fe_ms, dec_ms, nl = rx.kernel_ms_avg()
+    rx.enable_timing(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    sums = torch.stack([iters_acc, decoded_acc]).to(torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    iters_total = float(sums[0].item())
+    decoded_total = float(sums[1].item())
+    frames_total = F * args.steps * world
+
+    if rank == 0:
+        iters_per_launch = float(iters_acc.item()) / args.steps
+        ldpc_bytes, _, b_iter = algorithmic_bytes(rx, iters_per_launch, F)
+        achieved = ldpc_bytes / (dec_ms * 1e-3)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("%s_cfg%d" % (args.decoder, args.cfg))
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters),
+            "value": frames_total / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.decoder == "spa" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: %d mode-%d OFDM frames per GPU per step through AWGN at Es/N0 %+.1f dB, "
+                                   "%s variant, decoder=%s, max %d iterations" % (F, args.cfg, args.esn0, args.variant, args.decoder, args.iters),
+                       "frames_per_step_per_gpu": F, "cfg": args.cfg, "esn0_db": args.esn0, "decoder": args.decoder,
+                       "parallelism": "frame-sharded x%d, no collectives" % world},
+            "ldpc_iters_per_s": iters_total / dt,
+            "avg_iters_per_frame": iters_total / frames_total,
+            "decoded_fraction": decoded_total / frames_total,
+            "kernel_ms": {"frontend": fe_ms, "ldpc": dec_ms, "launches_averaged": nl},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
+                         "bytes_per_codeword_iteration": b_iter,
+                         "note": "algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are LDS-resident so real HBM traffic is far lower"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            S = min(F, args.cpu_sample_per_core * cores)
+            last = (args.steps - 1) % nbuf
+            bb_h = bufs[last][:S].cpu().numpy().view(np.complex128).reshape(S, -1)
+            import oraclelib
+            flags = oraclelib.FLAGS_RECEIVE_BYTE if args.variant == "receive_byte" else oraclelib.FLAGS_BASEBAND_TEST
+            if args.decoder == "spa":
+                line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload[:S].cpu().numpy(), stats[:S].cpu().numpy())
+            else:
+                line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload[:S].cpu().numpy(), stats[:S].cpu().numpy())
+                line["cpu_baseline"]["note"] = "CPU runs the reference's sum-product decoder; mismatches vs %s are expected on non-converged frames" % args.decoder
+            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,10 +130,13 @@ int mgpu_ldpc_batch_dev(mgpu_ctx* ctx, const void* d_llr, int F, void* d_bits_op
 int mgpu_txgen_dev(mgpu_ctx* ctx, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel,
                    void* d_baseband_c128, void* d_payload_opt, void* stream);
 
-/* time (ms) spent by the kernels of the most recent *_dev / host call, measured with HIP events
- * on the launch stream: [0]=front-end, [1]=LDPC(+tail). Synchronises the stream. */
-int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
+/* Kernel timing with HIP events recorded on the launch stream around each kernel.
+ * mgpu_enable_timing(ctx,1) resets the counters; mgpu_kernel_ms_avg returns the average launch
+ * duration in ms over the launches since then (at most the last 64): [0]=front-end kernel,
+ * [1]=LDPC decoder kernel (incl. fused tail). Synchronises on the recorded events. */
 int mgpu_enable_timing(mgpu_ctx* ctx, int on);
+int mgpu_kernel_ms_avg(mgpu_ctx* ctx, float ms[2], int* n_launches);
+int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
 
 #ifdef __cplusplus
 }

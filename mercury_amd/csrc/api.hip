@@ -71,10 +71,11 @@ struct mgpu_ctx {
     uint8_t* d_bits = nullptr;
     int* d_iters = nullptr;
     hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
-    hipEvent_t ev[4]{};
+    static constexpr int kEvRing = 64;
+    hipEvent_t ev[kEvRing][4]{};    // per launch: front-end start/stop, decoder start/stop
     bool timing = false;
-    hipStream_t last_stream = nullptr;
-    bool ev_valid = false;
+    int ev_count = 0;               // launches recorded since timing was enabled (ring of kEvRing)
+    bool ev_fe[kEvRing]{};          // whether the front-end ran in that slot
     size_t lds_fe = 0, lds_dec = 0, lds_tx = 0;
 
     template <typename T>
@@ -125,7 +126,7 @@ void ctx_alloc(mgpu_ctx* c) {
     HIPCK(hipMalloc(&c->d_bits, B * t.K));
     HIPCK(hipMalloc(&c->d_iters, B * sizeof(int)));
     HIPCK(hipStreamCreate(&c->stream));
-    for (auto& e : c->ev) HIPCK(hipEventCreate(&e));
+    for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));
 
     c->lds_fe = mgpu_frontend_lds_bytes(d.G);
     c->lds_tx = mgpu_txgen_lds_bytes(d.G);
@@ -150,15 +151,17 @@ void ctx_alloc(mgpu_ctx* c) {
 
 void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float* d_var, float* d_snrvar,
                      const MgpuTapsDev& taps, hipStream_t s) {
-    if (c->timing) HIPCK(hipEventRecord(c->ev[0], s));
+    const int slot = c->ev_count % mgpu_ctx::kEvRing;
+    if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][0], s)); c->ev_fe[slot] = true; }
     hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(F), dim3(256), c->lds_fe, s, c->dev, d_bb, F, d_llr, d_var, d_snrvar, taps);
     HIPCK(hipGetLastError());
-    if (c->timing) HIPCK(hipEventRecord(c->ev[1], s));
+    if (c->timing) HIPCK(hipEventRecord(c->ev[slot][1], s));
 }
 
 void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int* d_iters, uint8_t* d_payload,
                     MgpuStatsDev* d_stats, const float* d_var, const float* d_snrvar, hipStream_t s) {
-    if (c->timing) HIPCK(hipEventRecord(c->ev[2], s));
+    const int slot = c->ev_count % mgpu_ctx::kEvRing;
+    if (c->timing) HIPCK(hipEventRecord(c->ev[slot][2], s));
     switch (c->cfg.decoder) {
         case MGPU_DEC_SPA:
             hipLaunchKernelGGL(mgpu_ldpc_spa_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->dev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
@@ -171,7 +174,7 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
             break;
     }
     HIPCK(hipGetLastError());
-    if (c->timing) { HIPCK(hipEventRecord(c->ev[3], s)); c->last_stream = s; c->ev_valid = true; }
+    if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][3], s)); ++c->ev_count; c->ev_fe[c->ev_count % mgpu_ctx::kEvRing] = false; }
 }
 
 }  // namespace
@@ -245,7 +248,7 @@ void mgpu_destroy(mgpu_ctx* c) {
     (void)hipFree(c->d_baseband); (void)hipFree(c->d_llr); (void)hipFree(c->d_variance); (void)hipFree(c->d_snrvar);
     (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& q : c->ev) for (auto& e : q) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -267,18 +270,33 @@ int mgpu_get_info(mgpu_ctx* c, mgpu_info* i) {
 int mgpu_enable_timing(mgpu_ctx* c, int on) {
     if (!c) return MGPU_ERR_ARG;
     c->timing = on != 0;
-    c->ev_valid = false;
+    c->ev_count = 0;
+    for (auto& b : c->ev_fe) b = false;
     return MGPU_OK;
 }
 
 int mgpu_last_kernel_ms(mgpu_ctx* c, float ms[2]) {
+    int n = 0;
+    return mgpu_kernel_ms_avg(c, ms, &n);
+}
+
+int mgpu_kernel_ms_avg(mgpu_ctx* c, float ms[2], int* n_launches) {
     if (!c || !ms) return MGPU_ERR_ARG;
     return guard(c, [&] {
-        need(c->timing && c->ev_valid, "timing not enabled or nothing launched");
-        HIPCK(hipEventSynchronize(c->ev[3]));
-        ms[0] = 0.f;
-        if (hipEventQuery(c->ev[1]) == hipSuccess) (void)hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
-        HIPCK(hipEventElapsedTime(&ms[1], c->ev[2], c->ev[3]));
+        need(c->timing && c->ev_count > 0, "timing not enabled or nothing launched");
+        const int n = c->ev_count < mgpu_ctx::kEvRing ? c->ev_count : mgpu_ctx::kEvRing;
+        double fe = 0, dec = 0;
+        int nfe = 0;
+        for (int i = 0; i < n; ++i) {
+            HIPCK(hipEventSynchronize(c->ev[i][3]));
+            float t = 0;
+            HIPCK(hipEventElapsedTime(&t, c->ev[i][2], c->ev[i][3]));
+            dec += t;
+            if (c->ev_fe[i]) { HIPCK(hipEventElapsedTime(&t, c->ev[i][0], c->ev[i][1])); fe += t; ++nfe; }
+        }
+        ms[0] = nfe ? float(fe / nfe) : 0.f;
+        ms[1] = float(dec / n);
+        if (n_launches) *n_launches = n;
     });
 }
 

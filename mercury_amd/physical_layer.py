@@ -79,7 +79,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
-    "mgpu_last_kernel_ms", "mgpu_enable_timing",
+    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing",
 ]
 
 
@@ -175,7 +175,9 @@ class RxPhy:
     def enable_timing(self, on=True):
         self._ck(self.lib.mgpu_enable_timing(self.h, C.c_int(1 if on else 0)))
 
-    def last_kernel_ms(self):
+    def kernel_ms_avg(self):
+        """(front-end ms, decoder ms, launches) averaged over the launches since enable_timing()."""
         ms = (C.c_float * 2)()
-        self._ck(self.lib.mgpu_last_kernel_ms(self.h, ms))
-        return float(ms[0]), float(ms[1])
+        n = C.c_int(0)
+        self._ck(self.lib.mgpu_kernel_ms_avg(self.h, ms, C.byref(n)))
+        return float(ms[0]), float(ms[1]), int(n.value)
