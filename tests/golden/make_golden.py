@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container: it needs oracle/_ref/libmercury_ref.so, i.e. the reference's own
+DSP objects compiled from /root/reference by oracle/Makefile. For every Mercury mode 0..16 a few
+frames are synthesised (the repo's Philox generator: seed, frame index, Es/N0, channel), pushed
+through the reference RX chain in both orchestration variants (baseband_test_EsN0,
+telecom_system.cc:155-198, and receive_byte, :1132-1345), and the reference's outputs are stored:
+
+  * small outputs verbatim: decoder-input LLRs (float32[1600]), hard bits, de-scrambled bytes,
+    iteration count, CRC, all-zeros flag, variance (double + float), AGC gain;
+  * large FP64 intermediates (carrier grid, channel estimate, equalised grid, de-interleaved
+    symbols, demapper LLRs) as SHA-256 digests — the CPU oracle is required to match them bit for bit;
+  * static tables per mode (pilot lattice + signs, scrambler, constellation) and KATs (PRNG, CRC).
+
+Fixtures are DATA (inputs are regenerated from the recorded seeds; a digest of the input guards
+against generator drift). No reference source text is stored.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oraclelib  # noqa: E402
+from conftest import OPERATING_ESN0, SEED  # noqa: E402
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
+    arrays = {}
+    meta = {"seed": SEED, "modes": {}, "kat": {}}
+    ref0 = oraclelib.RefLib(0)
+    meta["kat"]["prng_seed1_first3"] = [int(x) for x in ref0.prng(1, 3)]
+    meta["kat"]["prng_seed0_first8"] = [int(x) for x in ref0.prng(0, 8)]
+    meta["kat"]["crc16_123456789"] = ref0.crc16([ord(c) for c in "123456789"])
+    for cfg in range(17):
+        ref = oraclelib.RefLib(cfg, 50)
+        orc = oraclelib.Oracle(cfg, 50)   # only used as the input generator here
+        m = {n: getattr(ref, n) for n in oraclelib.INFO_FIELDS if n != "dwidth"}
+        arrays["cfg%d_frame_types" % cfg] = ref.frame_types().astype(np.uint8)
+        arrays["cfg%d_pilot_seq" % cfg] = ref.pilot_seq()
+        arrays["cfg%d_constellation" % cfg] = ref.constellation()
+        if cfg == 0:
+            arrays["scrambler"] = ref.scrambler().astype(np.uint8)
+        op = OPERATING_ESN0[cfg]
+        cases = [(op, 0), (op + 1.0, 0), (-15.0, 0), (60.0, 0)]
+        if cfg in (8, 16):
+            cases.append((30.0, 1))       # static 2-path channel
+        frames = []
+        for idx, (snr, ch) in enumerate(cases):
+            bb, pl = orc.gen_frame(SEED, 100 * cfg + idx, oraclelib.noise_amp_for(snr), ch)
+            rec = {"frame": 100 * cfg + idx, "esn0_db": snr, "channel": ch, "input_sha256": digest(bb),
+                   "payload_sha256": digest(pl.astype(np.uint8)), "variants": {}}
+            for vname, flags in (("baseband_test", oraclelib.FLAGS_BASEBAND_TEST), ("receive_byte", oraclelib.FLAGS_RECEIVE_BYTE)):
+                r = ref.rx(bb, flags)
+                key = "cfg%d_f%d_%s" % (cfg, idx, vname)
+                arrays[key + "_llr_ldpc"] = r["llr_ldpc"]
+                arrays[key + "_bits"] = np.packbits(r["bits"].astype(np.uint8))
+                arrays[key + "_bytes"] = r["bytes"].astype(np.uint8)
+                rec["variants"][vname] = {
+                    "iterations": int(r["iterations"]), "crc": int(r["crc"]), "all_zeros": int(r["all_zeros"]),
+                    "variance": float(r["variance"]).hex(), "variance_f": float(r["variance_f"]).hex(),
+                    "agc_gain": float(r["agc_gain"]).hex(), "mean_H": float(r["mean_H"]).hex(),
+                    "sha256": {k: digest(r[k]) for k in ("grid", "H", "eq", "syms", "llr_demod", "llr_ldpc")},
+                }
+            frames.append(rec)
+        m["frames"] = frames
+        meta["modes"][str(cfg)] = m
+        print("cfg", cfg, "done")
+    np.savez_compressed(os.path.join(HERE, "golden_rx.npz"), **arrays)
+    with open(os.path.join(HERE, "golden_rx.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote golden_rx.npz (%d arrays), golden_rx.json" % len(arrays))
+
+
+if __name__ == "__main__":
+    main()

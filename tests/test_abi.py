@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports exactly what include/mercury_gpu.h
+declares, and refuses loudly (error code + message, no crash, no CPU fallback) when it cannot run."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "mercury_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mgpu_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mercury_amd import EXPORTED_SYMBOLS, load_library
+    lib = load_library()
+    declared = _header_functions()
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "declared in mercury_gpu.h but not exported: " + name
+    assert sorted(EXPORTED_SYMBOLS) == declared
+
+
+def test_struct_layouts_match_header():
+    from mercury_amd import STATS_DTYPE
+    from mercury_amd.physical_layer import Config, Info
+    assert STATS_DTYPE.itemsize == 24           # 4 ints + 2 floats
+    assert C.sizeof(Config) == 32
+    assert C.sizeof(Info) == 4 * 28
+
+
+def test_bad_arguments_return_error_codes():
+    from mercury_amd import load_library
+    from mercury_amd.physical_layer import Config
+    lib = load_library()
+    h = C.c_void_p()
+    for bad in (Config(17, 50, 1, 1, 1, 0, 16, 0.0), Config(-1, 50, 1, 1, 1, 0, 16, 0.0),
+                Config(8, 0, 1, 1, 1, 0, 16, 0.0), Config(8, 50, 7, 1, 1, 0, 16, 0.0), Config(8, 50, 1, 1, 1, 0, 0, 0.0)):
+        rc = lib.mgpu_create(C.byref(bad), C.byref(h))
+        assert rc == 1 and not h.value
+        assert lib.mgpu_last_error(None)
+    assert lib.mgpu_create(None, C.byref(h)) == 1
+    assert lib.mgpu_get_info(None, None) == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """On the CPU-only build container mgpu_create must fail with MGPU_ERR_DEVICE; on a GPU box it succeeds."""
+    from mercury_amd import MgpuError, RxPhy
+    import torch
+    if torch.cuda.is_available():
+        rx = RxPhy(8, max_batch=2)
+        assert rx.K == 600 and rx.E == 5616 and rx.payload_bytes == 73 and rx.frame_samples == 24 * 272
+        rx.close()
+    else:
+        with pytest.raises(MgpuError) as e:
+            RxPhy(8, max_batch=2)
+        assert "mgpu_create failed (2)" in str(e.value)
+
+
+def test_corrupt_table_blob_is_reported(tmp_path, monkeypatch):
+    from mercury_amd import load_library
+    from mercury_amd.physical_layer import Config
+    lib = load_library()
+    p = tmp_path / "bad.bin"
+    p.write_bytes(b"MLDP" + b"\x00" * 40)
+    monkeypatch.setenv("MERCURY_LDPC_TABLES", str(p))
+    h = C.c_void_p()
+    rc = lib.mgpu_create(C.byref(Config(8, 50, 1, 1, 1, 0, 4, 0.0)), C.byref(h))
+    assert rc == 3 and not h.value
+    assert b"LDPC" in lib.mgpu_last_error(None)

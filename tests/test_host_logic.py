@@ -1,0 +1,97 @@
+"""CPU tests of the host logic around the kernels: frame sharding (single process and a 2-rank gloo
+world), the byte model used by bench.py, and the build recipe."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_frame_ranges_partition_the_index_space():
+    from mercury_amd.sharding import frame_range, owner_of
+    for total in (0, 1, 7, 4096, 1048576, 12345):
+        for world in (1, 2, 3, 8):
+            ranges = [frame_range(r, world, total) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            for (a, b), (c, d) in zip(ranges, ranges[1:]):
+                assert b == c and a <= b
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+            for f in (0, total // 3, total - 1):
+                if 0 <= f < total:
+                    r = owner_of(f, world, total)
+                    assert ranges[r][0] <= f < ranges[r][1]
+    with pytest.raises(ValueError):
+        frame_range(2, 2, 10)
+
+
+def _rank_main(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from mercury_amd.sharding import frame_range, merge_counters
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = frame_range(rank, world, 1001)
+    # every rank "decodes" its own frames: the stand-in work is a checksum of the frame indices it owns
+    local = {"frames": hi - lo, "iterations": 50 * (hi - lo), "checksum": float(sum(range(lo, hi))), "seconds": 0.5 + rank}
+    merged = merge_counters(local, dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, lo, hi, merged))
+
+
+def test_two_rank_gloo_world_shards_and_merges():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, m0), (r1, lo1, hi1, m1) = out
+    assert (lo0, hi1) == (0, 1001) and hi0 == lo1
+    assert m0 == m1
+    assert m0["frames"] == 1001 and m0["iterations"] == 50 * 1001
+    assert m0["checksum"] == float(sum(range(1001)))      # a checksum of checksums: nothing lost, nothing doubled
+    assert m0["seconds"] == 1.5                            # MAX over ranks
+
+
+def test_algorithmic_byte_model_matches_survey():
+    sys.path.insert(0, ROOT)
+    import types
+    import bench
+    rx = types.SimpleNamespace(Nsymb=24, Nofdm=272, E=5616, N=1600, payload_stride=75)
+    ldpc, total, b_iter = bench.algorithmic_bytes(rx, 50, 1)
+    assert b_iter == 96256                                   # SURVEY.md §8d, rate 6/16
+    assert abs(total - 4.92e6) < 0.02e6                      # 4.92 MB / frame at 50 iterations
+    rx8 = types.SimpleNamespace(Nsymb=24, Nofdm=272, E=6049, N=1600, payload_stride=100)
+    assert bench.algorithmic_bytes(rx8, 50, 1)[2] == 103184  # rate 8/16
+    assert bench.usable_cores() >= 1
+
+
+def test_table_blob_is_wellformed():
+    import struct
+    blob = open(os.path.join(ROOT, "mercury_amd", "data", "mercury_ldpc_tables.bin"), "rb").read()
+    magic, ver, n = struct.unpack_from("<4sII", blob, 0)
+    assert magic == b"MLDP" and ver == 1 and n == 8
+    off, seen = 12, {}
+    for _ in range(n):
+        K, P, N, E, cw, vw = struct.unpack_from("<6I", blob, off)
+        off += 24
+        cdeg = np.frombuffer(blob, "u1", P, off); off += P
+        C = np.frombuffer(blob, "<u2", E, off); off += 2 * E
+        vdeg = np.frombuffer(blob, "u1", N, off); off += N
+        V = np.frombuffer(blob, "<u2", E, off); off += 2 * E
+        assert K + P == N == 1600 and cdeg.sum() == E == vdeg.sum() and cdeg.max() == cw and vdeg.max() == vw
+        assert C.max() < N and V.max() < P
+        seen[K] = E
+    assert off == len(blob)
+    # SURVEY.md §0 graph statistics
+    assert seen == {100: 3574, 200: 3859, 300: 4439, 400: 4651, 500: 5409, 600: 5616, 800: 6049, 1400: 6604}

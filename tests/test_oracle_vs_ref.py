@@ -1,0 +1,43 @@
+"""CPU tests: the C restatement against the reference's own compiled objects (oracle/_ref), when the
+prebuilt library is present (it is built from /root/reference in the build container and travels as a
+.so). Fresh random frames, every stage bit-identical."""
+import numpy as np
+import pytest
+
+import oraclelib
+from conftest import OPERATING_ESN0
+
+pytestmark = pytest.mark.skipif(not oraclelib.RefLib.available(), reason="oracle/_ref not built (no /root/reference here)")
+
+
+@pytest.mark.parametrize("cfg", [0, 4, 8, 10, 13, 16])
+def test_stage_by_stage_identical(cfg):
+    orc, ref = oraclelib.Oracle(cfg, 50), oraclelib.RefLib(cfg, 50)
+    for n in oraclelib.INFO_FIELDS:
+        if n != "dwidth":
+            assert getattr(orc, n) == getattr(ref, n)
+    op = OPERATING_ESN0[cfg]
+    for i, snr in enumerate((op, op - 1.5, 40.0)):
+        bb, pl = orc.gen_frame(991, 7 * cfg + i, oraclelib.noise_amp_for(snr), channel=i % 2)
+        bits = orc.payload_to_bits(pl)
+        assert np.array_equal(bits, ref.payload_to_bits(pl))
+        assert orc.tx(bits, 1).tobytes() == ref.tx(bits, 1).tobytes()
+        assert orc.tx(bits, 0).tobytes() == ref.tx(bits, 0).tobytes()
+        for flags in (oraclelib.FLAGS_BASEBAND_TEST, oraclelib.FLAGS_RECEIVE_BYTE):
+            a, b = orc.rx(bb, flags), ref.rx(bb, flags)
+            for k in a:
+                if isinstance(a[k], np.ndarray):
+                    assert a[k].tobytes() == b[k].tobytes(), (cfg, snr, flags, k)
+                elif k != "agc_gain":
+                    assert a[k] == b[k] or (np.isnan(a[k]) and np.isnan(b[k])), (cfg, snr, flags, k)
+
+
+@pytest.mark.parametrize("cfg", [1, 6, 12])
+def test_ldpc_decode_identical(cfg):
+    orc, ref = oraclelib.Oracle(cfg, 50), oraclelib.RefLib(cfg, 50)
+    rng = np.random.default_rng(cfg)
+    for sigma in (0.7, 1.0):
+        llr = (2.0 * (1.0 + sigma * rng.standard_normal(1600)) / sigma ** 2).astype(np.float32)  # all-zero codeword
+        b1, i1 = orc.ldpc_decode(llr)
+        b2, i2 = ref.ldpc_decode(llr)
+        assert i1 == i2 and np.array_equal(b1, b2)
