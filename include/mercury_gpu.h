@@ -138,6 +138,11 @@ int mgpu_enable_timing(mgpu_ctx* ctx, int on);
 int mgpu_kernel_ms_avg(mgpu_ctx* ctx, float ms[2], int* n_launches);
 int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
 
+/* test hook: evaluates the decoder's device tanh/atanh (csrc/spa_math.h) on n host doubles so the tests
+ * can compare them bit for bit with the libm the reference calls (ldpc_decoder_SPA.cc:145,156).
+ * atanh_out[i] is 0 where |in[i]| >= 1. */
+int mgpu_debug_spa_math(mgpu_ctx* ctx, const double* in, int n, double* tanh_out, double* atanh_out);
+
 #ifdef __cplusplus
 }
 #endif

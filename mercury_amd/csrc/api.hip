@@ -25,9 +25,12 @@ extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
 extern "C" size_t mgpu_txgen_lds_bytes(int G);
 
 extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, MgpuTapsDev);
-extern "C" __global__ void mgpu_ldpc_spa_kernel(MgpuDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-extern "C" __global__ void mgpu_ldpc_gbf_kernel(MgpuDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-extern "C" __global__ void mgpu_ldpc_minsum_kernel(MgpuDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+#define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
+extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
+using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+extern "C" __global__ void mgpu_ldpc_minsum_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*);
 
 static_assert(sizeof(MgpuStatsDev) == sizeof(mgpu_frame_stats), "stats layout");
@@ -57,6 +60,7 @@ struct mgpu_ctx {
     mgpu_config cfg{};
     mgpu::ModeTables tab;
     MgpuDev dev{};
+    LdpcDev ldev{};
     std::vector<void*> owned;       // device allocations freed in destroy
     std::string err;
     int max_batch = 0;
@@ -77,6 +81,7 @@ struct mgpu_ctx {
     int ev_count = 0;               // launches recorded since timing was enabled (ring of kEvRing)
     bool ev_fe[kEvRing]{};          // whether the front-end ran in that slot
     size_t lds_fe = 0, lds_dec = 0, lds_tx = 0;
+    DecoderKernel spa_kernel = nullptr;
 
     template <typename T>
     T* keep(T* p) { owned.push_back(p); return p; }
@@ -108,6 +113,12 @@ void ctx_alloc(mgpu_ctx* c) {
     d.vptr = c->keep(upload(t.graph.vptr));
     d.vedge = c->keep(upload(t.graph.vedge));
     d.echk = c->keep(upload(t.graph.echk));
+    d.spack = c->keep(upload(t.graph.spack));
+    d.svar = c->keep(upload(t.graph.svar));
+    d.vslot = c->keep(upload(t.graph.vslot));
+    d.cinfo = c->keep(upload(t.graph.cinfo));
+    d.vinfo = c->keep(upload(t.graph.vinfo));
+    d.S = t.graph.S;
     d.M = t.M; d.bps = t.bps; d.K = t.K; d.P = t.P; d.N = t.N; d.E = t.graph.E;
     d.Nsymb = t.Nsymb; d.G = t.Nsymb * t.Nc; d.nData = t.nData; d.nBits = t.nBits; d.nPilots = t.nPilots;
     d.nVirtual = t.nVirtual; d.nReal = t.nReal;
@@ -116,6 +127,11 @@ void ctx_alloc(mgpu_ctx* c) {
     d.agc = c->cfg.agc; d.var_eq = c->cfg.variance_source; d.max_iters = c->cfg.max_iters;
     d.pilot_boost = t.pilot_boost;
     d.minsum_alpha = c->cfg.minsum_alpha > 0 ? c->cfg.minsum_alpha : 0.8f;
+    LdpcDev& l = c->ldev;
+    l.spack = d.spack; l.svar = d.svar; l.vptr = d.vptr; l.vslot = d.vslot; l.cinfo = d.cinfo; l.vinfo = d.vinfo; l.scrambler = d.scrambler;
+    l.cptr = d.cptr; l.cvar = d.cvar; l.vedge = d.vedge; l.echk = d.echk;
+    l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
+    l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
 
     const size_t B = size_t(c->max_batch);
     HIPCK(hipMalloc(&c->d_llr, B * t.N * sizeof(float)));
@@ -134,8 +150,16 @@ void ctx_alloc(mgpu_ctx* c) {
     HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_txgen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_tx)));
     switch (c->cfg.decoder) {
         case MGPU_DEC_SPA:
-            c->lds_dec = mgpu_spa_lds_bytes(d.E, d.N);
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
+            c->lds_dec = mgpu_spa_lds_bytes(d.S, d.N);
+            switch ((d.S + 1023) / 1024) {
+                case 1: case 2: case 3: case 4: c->spa_kernel = mgpu_ldpc_spa_kernel_ne4; break;
+                case 5: c->spa_kernel = mgpu_ldpc_spa_kernel_ne5; break;
+                case 6: c->spa_kernel = mgpu_ldpc_spa_kernel_ne6; break;
+                case 7: c->spa_kernel = mgpu_ldpc_spa_kernel_ne7; break;
+                case 8: c->spa_kernel = mgpu_ldpc_spa_kernel_ne8; break;
+                default: throw std::runtime_error("graph too large for the sum-product kernel");
+            }
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
         case MGPU_DEC_GBF:
             c->lds_dec = mgpu_gbf_lds_bytes(d.N);
@@ -164,13 +188,13 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
     if (c->timing) HIPCK(hipEventRecord(c->ev[slot][2], s));
     switch (c->cfg.decoder) {
         case MGPU_DEC_SPA:
-            hipLaunchKernelGGL(mgpu_ldpc_spa_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->dev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
+            hipLaunchKernelGGL(c->spa_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
             break;
         case MGPU_DEC_GBF:
-            hipLaunchKernelGGL(mgpu_ldpc_gbf_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->dev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
+            hipLaunchKernelGGL(mgpu_ldpc_gbf_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
             break;
         default:
-            hipLaunchKernelGGL(mgpu_ldpc_minsum_kernel, dim3(F), dim3(512), c->lds_dec, s, c->dev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
+            hipLaunchKernelGGL(mgpu_ldpc_minsum_kernel, dim3(F), dim3(512), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
             break;
     }
     HIPCK(hipGetLastError());
@@ -346,6 +370,22 @@ int mgpu_txgen_dev(mgpu_ctx* c, uint64_t seed, uint64_t frame0, int F, double no
         hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(F), dim3(256), c->lds_tx, static_cast<hipStream_t>(stream), c->dev, seed,
                            frame0, F, noise_amp, channel, static_cast<double*>(d_bb), static_cast<uint8_t*>(d_payload_opt));
         HIPCK(hipGetLastError());
+    });
+}
+
+int mgpu_debug_spa_math(mgpu_ctx* c, const double* in, int n, double* tanh_out, double* atanh_out) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(in && tanh_out && atanh_out && n > 0, "bad argument");
+        double *d_in = nullptr, *d_t = nullptr, *d_a = nullptr;
+        HIPCK(hipMalloc(&d_in, size_t(n) * 8)); HIPCK(hipMalloc(&d_t, size_t(n) * 8)); HIPCK(hipMalloc(&d_a, size_t(n) * 8));
+        HIPCK(hipMemcpy(d_in, in, size_t(n) * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(mgpu_spa_math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_in, d_t, d_a, n);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(c->stream));
+        HIPCK(hipMemcpy(tanh_out, d_t, size_t(n) * 8, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(atanh_out, d_a, size_t(n) * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_in); (void)hipFree(d_t); (void)hipFree(d_a);
     });
 }
 

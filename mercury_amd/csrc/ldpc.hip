@@ -30,7 +30,7 @@
 namespace {
 
 // Epilogue shared by all decoders: hard[] (N bytes in LDS) -> bits / payload / stats.
-__device__ void decode_tail(const MgpuDev& T, int f, const uint8_t* hard, uint8_t* bytes_lds, int iterations,
+__device__ void decode_tail(const LdpcDev& T, int f, const uint8_t* hard, uint8_t* bytes_lds, int iterations,
                             uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
                             uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
                             const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
@@ -76,21 +76,44 @@ __device__ void decode_tail(const MgpuDev& T, int f, const uint8_t* hard, uint8_
 
 }  // namespace
 
-extern "C" size_t mgpu_spa_lds_bytes(int E, int N) {
-    return size_t(8) * E * 2 + size_t(8) * N + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
+extern "C" size_t mgpu_spa_lds_bytes(int S, int N) {
+    return size_t(8) * S + size_t(8) * N + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Sum-product, double precision, reference arithmetic.
-extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_spa_kernel(
-    MgpuDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
-    int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
-    const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+//
+// One message array M[] in LDS holds, alternately, T = tanh(0.5*Q) and R for every edge. Edges
+// live in a padded, wave-private layout: whole checks are bin-packed into 64-slot bins, and a bin
+// is always processed by one wavefront in one instruction stream. All lanes of a wave finish
+// reading the T values of their checks before the (later) instruction that overwrites them with R
+// issues, so the check update runs in place without a workgroup barrier and without staging.
+// Each lane keeps the (constant) descriptors of its NE slots in registers for the whole decode, so
+// the two edge-parallel phases touch no index memory at all. The syndrome costs nothing extra: in
+// the Q/tanh phase every lane already holds the posterior of its edge's variable, one 64-bit ballot
+// of the sign bits gives every check its parity.
+// Per iteration: check update | barrier | variable update | barrier | syndrome + Q/tanh | barrier.
+// Up to eight slot descriptors per lane held in named registers (an indexed array would be demoted
+// to scratch memory); get(r) selects by the wave-uniform round number.
+struct SlotRegs {
+    uint32_t k0, k1, k2, k3, k4, k5, k6, k7;
+    __device__ __forceinline__ uint32_t get(int r) const {
+        uint32_t v = k0;
+        v = (r == 1) ? k1 : v; v = (r == 2) ? k2 : v; v = (r == 3) ? k3 : v; v = (r == 4) ? k4 : v;
+        v = (r == 5) ? k5 : v; v = (r == 6) ? k6 : v; v = (r == 7) ? k7 : v;
+        return v;
+    }
+};
+
+template <int NE>
+__device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
+                                           uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
+                                           uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+                                           const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int E = T.E, N = T.N, P = T.P;
-    double* Tt = reinterpret_cast<double*>(smem);     // tanh(0.5*Q) per edge, check-major
-    double* Rc = Tt + E;                              // R per edge, check-major
-    double* Lt = Rc + E;                              // LLRtmp per variable
+    const int S = T.S, N = T.N;
+    double* M = reinterpret_cast<double*>(smem);      // T or R per padded edge slot
+    double* Lt = M + S;                               // LLRtmp per variable
     float* Li = reinterpret_cast<float*>(Lt + N);     // channel LLR
     uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
     uint8_t* bytes = hard + ((N + 15) & ~15);
@@ -103,67 +126,132 @@ extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_spa_kernel(
         const float l = lin[v];
         Li[v] = l;
         Lt[v] = l;
-        hard[v] = l < 0;
     }
+    // slot descriptors, one register each: check_start(13) | deg(6)<<13 | variable(11)<<19 ; deg == 0 marks padding.
+    // The slot's position inside its check is p - check_start.
+    auto load_slot = [&](int r) -> uint32_t {
+        const int p = tid + r * LDPC_THREADS;
+        uint32_t k = 0;
+        if (r < NE && p < S) {
+            const uint32_t sp = T.spack[p];
+            if (sp >> 31) k = (sp & 0x7ffffu) | (uint32_t(T.svar[p]) << 19);
+        }
+        return k;
+    };
+    const SlotRegs pk = {load_slot(0), load_slot(1), load_slot(2), load_slot(3), load_slot(4), load_slot(5), load_slot(6), load_slot(7)};
     if (tid == 0) flag[0] = 0;
     __syncthreads();
-    // initial syndrome (ldpc_decoder_SPA.cc:62-76)
+
+    // parity of every check of this wave's bin from the sign bits of its edges' variables
+    auto check_parity = [&](uint32_t k, bool neg) -> bool {
+        const unsigned long long m = __ballot(neg);
+        const uint32_t deg = (k >> 13) & 0x3f, l0 = k & 63u;
+        const unsigned long long cm = ((deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << l0);
+        return (__popcll(m & cm) & 1) != 0;
+    };
+
+    // initial syndrome (ldpc_decoder_SPA.cc:62-76) and Q = llr on every edge (:106-122) -> T
     {
-        int bad = 0;
-        for (int c = tid; c < P; c += LDPC_THREADS) {
-            int x = 0;
-            for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) x ^= hard[T.cvar[e]];
-            bad |= x;
+        bool unsat = false;
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t k = pk.get(r);
+            const bool valid = ((k >> 13) & 0x3f) != 0;
+            const float l = valid ? Li[k >> 19] : 0.0f;
+            unsat |= check_parity(k, valid && l < 0) && valid;
+            if (valid) M[tid + r * LDPC_THREADS] = spa_tanh(0.5 * double(l));
         }
-        if (bad) flag[0] = 1;
+        if (unsat) flag[0] = 1;
     }
     __syncthreads();
     int iteration = 0;
     if (flag[0]) {
-        // Q = llr on every edge (:106-122) -> T = tanh(0.5*Q)
-        for (int e = tid; e < E; e += LDPC_THREADS) Tt[e] = spa_tanh(0.5 * double(Li[T.cvar[e]]));
-        __syncthreads();
         for (iteration = 1; iteration <= T.max_iters; ++iteration) {
-            // check update (:129-160)
-            for (int e = tid; e < E; e += LDPC_THREADS) {
-                const uint32_t pk = T.epack[e];
-                const int cs = pk & 0xffff, deg = (pk >> 16) & 0xff, pos = pk >> 24;
-                double temp = 1;
-                for (int k = 0; k < deg; ++k)
-                    if (k != pos) temp *= Tt[cs + k];
-                if (temp == 1) temp = 0.9999999;
-                if (temp == -1) temp = -0.9999999;
-                Rc[e] = 2 * spa_atanh(temp);
+            // check update (:129-160), in place
+#pragma unroll 1
+            for (int r = 0; r < NE; ++r) {
+                const uint32_t k = pk.get(r);
+                const int deg = (k >> 13) & 0x3f;
+                const bool valid = deg != 0;
+                double rr = 0.0;
+                if (valid) {
+                    const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
+                    double temp = 1;
+                    for (int j = 0; j < deg; ++j) {
+                        const double m = M[cs + j];
+                        temp *= (j == pos) ? 1.0 : m;      // x * 1.0 == x exactly: same product as skipping j == pos
+                    }
+                    if (temp == 1) temp = 0.9999999;
+                    if (temp == -1) temp = -0.9999999;
+                    rr = 2 * spa_atanh(temp);
+                }
+                __builtin_amdgcn_wave_barrier();   // every lane of this wave has read its check's T values
+                if (valid) M[tid + r * LDPC_THREADS] = rr;
             }
             if (tid == 0) flag[0] = 0;
             __syncthreads();
-            // variable update (:162-170)
-            for (int v = tid; v < N; v += LDPC_THREADS) {
+            // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count
+            for (int i = tid; i < N; i += LDPC_THREADS) {
+                // record: variable | deg<<11, then 10 u16 slot indices (reference slot order, zero padded)
+                const uint32_t* rec = T.vinfo + size_t(i) * 6;
+                const uint32_t vi = rec[0], w0 = rec[1], w1 = rec[2], w2 = rec[3], w3 = rec[4], w4 = rec[5];
+                const int v = vi & 0x7ff, deg = vi >> 11;
                 double s = Li[v];
-                for (uint32_t q = T.vptr[v]; q < T.vptr[v + 1]; ++q) s += Rc[T.vedge[q]];
+                const double m0 = M[w0 & 0xffff], m1 = M[w0 >> 16], m2 = M[w1 & 0xffff], m3 = M[w1 >> 16], m4 = M[w2 & 0xffff];
+                s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
+                s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+                if (deg > 5) {
+                    const double m5 = M[w2 >> 16], m6 = M[w3 & 0xffff], m7 = M[w3 >> 16], m8 = M[w4 & 0xffff];
+                    s += m5;
+                    s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
+                }
                 Lt[v] = s;
-                hard[v] = s < 0;
             }
             __syncthreads();
-            // syndrome (:173-190)
-            {
-                int bad = 0;
-                for (int c = tid; c < P; c += LDPC_THREADS) {
-                    int x = 0;
-                    for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) x ^= hard[T.cvar[e]];
-                    bad |= x;
+            // syndrome (:173-190) and Q = LLRtmp - R (:193-209) -> T for the next check update
+            bool unsat = false;
+#pragma unroll 1
+            for (int r = 0; r < NE; ++r) {
+                const uint32_t k = pk.get(r);
+                const bool valid = ((k >> 13) & 0x3f) != 0;
+                const double lt = valid ? Lt[k >> 19] : 0.0;
+                unsat |= check_parity(k, valid && lt < 0) && valid;
+                if (valid) {
+                    const int p = tid + r * LDPC_THREADS;
+                    M[p] = spa_tanh(0.5 * (lt - M[p]));
                 }
-                if (bad) flag[0] = 1;
             }
+            if (unsat) flag[0] = 1;
             __syncthreads();
             if (!flag[0]) break;
-            // Q = LLRtmp - R (:193-209), then the tanh the next check update needs
-            if (iteration < T.max_iters)
-                for (int e = tid; e < E; e += LDPC_THREADS) Tt[e] = spa_tanh(0.5 * (Lt[T.cvar[e]] - Rc[e]));
-            __syncthreads();
         }
     }
+    for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
+    __syncthreads();
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}
+
+#define SPA_KERNEL(NE)                                                                                          \
+    extern "C" __global__ __launch_bounds__(LDPC_THREADS, 8) void mgpu_ldpc_spa_kernel_ne##NE(                \
+        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                     \
+        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,   \
+        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                     \
+        spa_decode<NE>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
+    }
+SPA_KERNEL(4)
+SPA_KERNEL(5)
+SPA_KERNEL(6)
+SPA_KERNEL(7)
+SPA_KERNEL(8)
+
+// device probe of spa_math.h for tests: out_t[i] = tanh(in[i]); out_a[i] = atanh(in[i]) for |in[i]| < 1 else 0
+extern "C" __global__ void mgpu_spa_math_probe_kernel(const double* __restrict__ in, double* __restrict__ out_t,
+                                                      double* __restrict__ out_a, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    out_t[i] = spa_tanh(x);
+    out_a[i] = (spa_fabs(x) < 1.0) ? spa_atanh(x) : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -171,7 +259,7 @@ extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_spa_kernel(
 extern "C" size_t mgpu_gbf_lds_bytes(int N) { return size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64; }
 
 extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_gbf_kernel(
-    MgpuDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
+    LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
     int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
     const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -239,7 +327,7 @@ extern "C" size_t mgpu_minsum_lds_bytes(int E, int N) {
 }
 
 extern "C" __global__ __launch_bounds__(MS_THREADS) void mgpu_ldpc_minsum_kernel(
-    MgpuDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
+    LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
     int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
     const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

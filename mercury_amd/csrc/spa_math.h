@@ -11,7 +11,22 @@
 // (Sun Microsystems 1993, "Developed at SunPro ... Permission to use, copy, modify, and distribute
 // this software is freely granted, provided that this notice is preserved.") with FMA contraction
 // disabled gives identical bits on any IEEE machine. tests/test_spa_math.py checks this header
-// (compiled for the host) against the host libm on millions of arguments, including every branch.
+// (compiled for the host) against the host libm on millions of arguments, including every branch,
+// and tests/test_gpu_parity.py::test_spa_math_on_device does the same for the device build.
+//
+// GPU shaping: the textbook routines are a tree of data-dependent branches; inside a 64-lane
+// wavefront neighbouring edges take different branches almost always, so every branch body would
+// be executed. The functions below perform, per lane, exactly the floating-point operations of
+// the branch that lane's argument selects, but share everything the branches have in common
+// (one expm1 body per tanh, one division per tanh beyond it, one log1p body per atanh) and pick
+// operands/results with selects. Each select only chooses between values the original would have
+// computed with the same operations, so results stay bit-identical. Branches the decoder's
+// argument ranges cannot reach are dropped (stated at each function).
+//
+// Division: IEEE-correct a/b on gfx950 is v_div_scale x2 + v_rcp + Newton/residual FMAs +
+// v_div_fmas + v_div_fixup. Scaling and fix-up only act on denormal/huge/non-finite operands; every
+// division below has operands in a stated normal range, so spa_div keeps the correctly-rounding core
+// (rcp, two Newton steps, quotient, residual, final FMA) and drops the three guard instructions.
 //
 // Build note: the including TU must be compiled with -ffp-contract=off.
 #pragma once
@@ -22,6 +37,16 @@
 #define SPA_BITS_HI(x) uint32_t(__double2hiint(x))
 #define SPA_MAKE(hi, lo) __hiloint2double(int(hi), int(lo))
 #define SPA_LO(x) uint32_t(__double2loint(x))
+SPA_FN double spa_div(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    const double q = n * r;
+    const double rem = __builtin_fma(-d, q, n);
+    return __builtin_fma(rem, r, q);
+}
 #else
 #include <string.h>
 #define SPA_FN static inline
@@ -31,176 +56,125 @@ static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_
 #define SPA_BITS_HI(x) spa_bits_hi_(x)
 #define SPA_LO(x) spa_bits_lo_(x)
 #define SPA_MAKE(hi, lo) spa_make_(hi, lo)
+SPA_FN double spa_div(double n, double d) { return n / d; }
 #endif
 
 SPA_FN double spa_set_high(double x, uint32_t hi) { return SPA_MAKE(hi, SPA_LO(x)); }
 SPA_FN double spa_fabs(double x) { return SPA_MAKE(SPA_BITS_HI(x) & 0x7fffffffu, SPA_LO(x)); }
+SPA_FN double spa_add_exponent(double y, int32_t k) { return spa_set_high(y, SPA_BITS_HI(y) + (uint32_t(k) << 20)); }
 
-// expm1 for finite |x| (the decoder never feeds it inf/nan/overflowing arguments: |x| <= 44)
-SPA_FN double spa_expm1(double x) {
-    const double one = 1.0, tiny = 1.0e-300, huge = 1.0e+300;
+// tanh(x) for any finite x (s_tanh.c + s_expm1.c).
+// expm1 is only ever evaluated at -2|x| in [-2, -2^-54] (|x| < 1) or at 2|x| in [2, 44) (1 <= |x| < 22),
+// so of s_expm1.c's cases k = 0, k = -1, k <= -2, 2 <= k < 20, 20 <= k <= 56 and k > 56 remain
+// (k = +1, the |x| < 2^-54 shortcut and the x <= -56 ln2 shortcut cannot occur).
+SPA_FN double spa_tanh(double x) {
+    const double one = 1.0, two = 2.0;
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00;
     const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
                  Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
                  Q5 = -2.01099218183624371326e-07;
-    double y, hi, lo, c = 0, t, e, hxs, hfx, r1, h2, h4, R1, R2, R3;
-    int32_t k;
-    uint32_t hx = SPA_BITS_HI(x);
-    const uint32_t xsb = hx & 0x80000000u;
-    hx &= 0x7fffffffu;
-    if (hx >= 0x4043687Au) {            // |x| >= 56 ln2
-        if (xsb != 0) return tiny - one;  // -1
-        // large positive arguments fall through to the general path (k > 56)
-    }
-    if (hx > 0x3fd62e42u) {             // |x| > 0.5 ln2
-        if (hx < 0x3FF0A2B2u) {         // |x| < 1.5 ln2
-            if (xsb == 0) { hi = x - ln2_hi; lo = ln2_lo; k = 1; }
-            else { hi = x + ln2_hi; lo = -ln2_lo; k = -1; }
-        } else {
-            k = int32_t(invln2 * x + ((xsb == 0) ? 0.5 : -0.5));
-            t = k;
-            hi = x - t * ln2_hi;
-            lo = t * ln2_lo;
-        }
-        x = hi - lo;
-        c = (hi - x) - lo;
-    } else if (hx < 0x3c900000u) {      // |x| < 2^-54
-        t = huge + x;
-        return x - (t - (huge + x));
-    } else {
-        k = 0;
-    }
-    hfx = 0.5 * x;
-    hxs = x * hfx;
-    R1 = one + hxs * Q1; h2 = hxs * hxs;
-    R2 = Q2 + hxs * Q3; h4 = h2 * h2;
-    R3 = Q4 + hxs * Q5;
-    r1 = R1 + h2 * R2 + h4 * R3;
-    t = 3.0 - r1 * hfx;
-    e = hxs * ((r1 - t) / (6.0 - x * t));
-    if (k == 0) return x - (x * e - hxs);
-    e = (x * (e - c) - c);
-    e -= hxs;
-    if (k == -1) return 0.5 * (x - e) - 0.5;
-    if (k == 1) {
-        if (x < -0.25) return -2.0 * (e - (x + 0.5));
-        return one + 2.0 * (x - e);
-    }
-    if (k <= -2 || k > 56) {
-        y = one - (e - x);
-        y = spa_set_high(y, SPA_BITS_HI(y) + (uint32_t(k) << 20));
-        return y - one;
-    }
-    t = one;
-    if (k < 20) {
-        t = spa_set_high(t, 0x3ff00000u - (0x200000u >> k));   // 1 - 2^-k
-        y = t - (e - x);
-        y = spa_set_high(y, SPA_BITS_HI(y) + (uint32_t(k) << 20));
-    } else {
-        t = spa_set_high(t, uint32_t(0x3ff - k) << 20);        // 2^-k
-        y = x - (e + t);
-        y += one;
-        y = spa_set_high(y, SPA_BITS_HI(y) + (uint32_t(k) << 20));
-    }
-    return y;
-}
-
-SPA_FN double spa_tanh(double x) {
-    const double one = 1.0, two = 2.0;
-    double t, z;
-    const uint32_t jx = SPA_BITS_HI(x), lx = SPA_LO(x);
+    const uint32_t jx = SPA_BITS_HI(x);
     const uint32_t ix = jx & 0x7fffffffu;
-    if (ix >= 0x7ff00000u) return (jx >> 31) ? one / x - one : one / x + one;
-    if (ix < 0x40360000u) {             // |x| < 22
-        if ((ix | lx) == 0) return x;
-        if (ix < 0x3c800000u) return x * (one + x);   // |x| < 2^-55
-        if (ix >= 0x3ff00000u) {        // |x| >= 1
-            t = spa_expm1(two * spa_fabs(x));
-            z = one - two / (t + two);
-        } else {
-            t = spa_expm1(-two * spa_fabs(x));
-            z = -t / (t + two);
-        }
-    } else {
-        z = one;                        // 1 - tiny rounds to 1
-    }
-    return (jx >> 31) ? -z : z;
+    const double ax = spa_fabs(x);
+    const bool big = ix >= 0x3ff00000u;                      // |x| >= 1
+    // ---- t = expm1(big ? 2|x| : -2|x|) -------------------------------------------------------
+    double a = two * ax;                                     // exact
+    a = big ? a : -a;
+    const uint32_t ha = SPA_BITS_HI(a) & 0x7fffffffu;
+    const bool kzero = !(ha > 0x3fd62e42u);                  // |a| <= 0.5 ln2
+    const bool kone = !kzero && (ha < 0x3FF0A2B2u);          // 0.5 ln2 < |a| < 1.5 ln2 (only reached with a < 0)
+    int32_t k = int32_t(invln2 * a + (big ? 0.5 : -0.5));
+    k = kone ? -1 : k;
+    k = kzero ? 0 : k;
+    const double tk = double(k);
+    const double hi = a - tk * ln2_hi;                       // exact products for k = 0, -1
+    const double lo = tk * ln2_lo;
+    const double r = hi - lo;
+    const double c = (hi - r) - lo;                          // 0 when k == 0
+    const double hfx = 0.5 * r;
+    const double hxs = r * hfx;
+    const double R1 = one + hxs * Q1, h2 = hxs * hxs;
+    const double R2 = Q2 + hxs * Q3, h4 = h2 * h2;
+    const double R3 = Q4 + hxs * Q5;
+    const double r1 = R1 + h2 * R2 + h4 * R3;
+    const double tt = 3.0 - r1 * hfx;
+    double e = hxs * spa_div(r1 - tt, 6.0 - r * tt);         // denominator in [5, 7]
+    const double res0 = r - (r * e - hxs);                   // k == 0
+    e = (r * (e - c) - c);
+    e -= hxs;
+    const double resm1 = 0.5 * (r - e) - 0.5;                // k == -1
+    const double emx = e - r;
+    const double ya = spa_add_exponent(one - emx, k) - one;                              // k <= -2 || k > 56
+    const double tb = SPA_MAKE(0x3ff00000u - (0x200000u >> (uint32_t(k) & 31u)), 0u);   // 1 - 2^-k, 2 <= k < 20
+    const double yb = spa_add_exponent(tb - emx, k);
+    const double tc = SPA_MAKE(uint32_t(0x3ff - k) << 20, 0u);                           // 2^-k, 20 <= k <= 56
+    const double yc = spa_add_exponent((r - (e + tc)) + one, k);
+    double t = (k <= -2 || k > 56) ? ya : (k < 20 ? yb : yc);
+    t = (k == -1) ? resm1 : t;
+    t = (k == 0) ? res0 : t;
+    // ---- tanh from t -------------------------------------------------------------------------
+    const double q = spa_div(big ? two : -t, t + two);       // denominator in [1, 2^64]
+    double z = big ? one - q : q;
+    z = (ix >= 0x40360000u) ? one : z;                       // |x| >= 22: one - tiny
+    const double res = (jx >> 31) ? -z : z;
+    // |x| < 2^-55 (incl. +-0): x*(one+x) == x ; non-finite arguments never reach the decoder
+    return (ix < 0x3c800000u) ? x : res;
 }
 
-// log1p for -1 < x < +inf, finite
-SPA_FN double spa_log1p(double x) {
+// atanh(x) for |x| < 1 (e_atanh.c + s_log1p.c; the decoder clamps +-1 to +-0.9999999 first).
+// log1p is only ever evaluated at y = 2|x|/(1-|x|)-type arguments with 2^-27 <= y <= 2e7, so of
+// s_log1p.c's cases the y <= -0.2929, |y| < 2^-29 and y >= 2^53 ones cannot occur.
+SPA_FN double spa_atanh(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                  Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
                  Lp7 = 1.479819860511658591e-01;
-    double hfsq, f = 0, c = 0, s, z, R, u, z2, z4, z6, R1, R2, R3, R4;
-    int32_t k, hx, hu = 0, ax;
-    hx = int32_t(SPA_BITS_HI(x));
-    ax = hx & 0x7fffffff;
-    k = 1;
-    if (hx < 0x3FDA827A) {              // x < 0.41422
-        if (ax < 0x3e200000) {          // |x| < 2^-29
-            if (ax < 0x3c900000) return x;
-            return x - x * x * 0.5;
-        }
-        if (hx > 0 || hx <= int32_t(0xbfd2bec3u)) { k = 0; f = x; hu = 1; }   // -0.2929 < x < 0.41422
-    }
-    if (k != 0) {
-        if (hx < 0x43400000) {
-            u = 1.0 + x;
-            hu = int32_t(SPA_BITS_HI(u));
-            k = (hu >> 20) - 1023;
-            c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
-            c /= u;
-        } else {
-            u = x;
-            hu = int32_t(SPA_BITS_HI(u));
-            k = (hu >> 20) - 1023;
-            c = 0;
-        }
-        hu &= 0x000fffff;
-        if (hu < 0x6a09e) {
-            u = spa_set_high(u, uint32_t(hu) | 0x3ff00000u);
-        } else {
-            k += 1;
-            u = spa_set_high(u, uint32_t(hu) | 0x3fe00000u);
-            hu = (0x00100000 - hu) >> 2;
-        }
-        f = u - 1.0;
-    }
-    hfsq = 0.5 * f * f;
-    if (hu == 0) {                      // |f| < 2^-20
-        if (f == 0.0) {
-            if (k == 0) return 0.0;
-            c += k * ln2_lo;
-            return k * ln2_hi + c;
-        }
-        R = hfsq * (1.0 - 0.66666666666666666 * f);
-        if (k == 0) return f - R;
-        return k * ln2_hi - ((R - (k * ln2_lo + c)) - f);
-    }
-    s = f / (2.0 + f);
-    z = s * s;
-    R1 = z * Lp1; z2 = z * z;
-    R2 = Lp2 + z * Lp3; z4 = z2 * z2;
-    R3 = Lp4 + z * Lp5; z6 = z4 * z2;
-    R4 = Lp6 + z * Lp7;
-    R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
-    if (k == 0) return f - (hfsq - s * (hfsq + R));
-    return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
-}
-
-// atanh for |x| < 1 (the decoder clamps +-1 to +-0.9999999 first)
-SPA_FN double spa_atanh(double x) {
     const double xa = spa_fabs(x);
-    double t;
-    if (xa < 0.5) {
-        if (xa < 0x1.0p-28) return x;
-        t = xa + xa;
-        t = 0.5 * spa_log1p(t + t * xa / (1.0 - xa));
+    const bool small = xa < 0.5;
+    const double t2 = xa + xa;
+    const double q = spa_div(small ? t2 * xa : t2, 1.0 - xa);    // denominator in [1e-7, 1]
+    const double y = small ? t2 + q : q;
+    // ---- log1p(y), y > 0 ----------------------------------------------------------------------
+    const int32_t hy = int32_t(SPA_BITS_HI(y));
+    const bool direct = hy < 0x3FDA827A;                     // y < 0.41422: f = y, k = 0
+    double u = 1.0 + y;
+    int32_t hu = int32_t(SPA_BITS_HI(u));
+    int32_t k = (hu >> 20) - 1023;
+    double c = (k > 0) ? 1.0 - (u - y) : y - (u - 1.0);
+    c = spa_div(c, u);                                       // u in [1, 2e7]; |c| <= 2^-53 or 0
+    hu &= 0x000fffff;
+    const bool lowhalf = hu < 0x6a09e;
+    u = spa_set_high(u, uint32_t(hu) | (lowhalf ? 0x3ff00000u : 0x3fe00000u));
+    k = lowhalf ? k : k + 1;
+    hu = lowhalf ? hu : (0x00100000 - hu) >> 2;
+    double f = u - 1.0;
+    f = direct ? y : f;
+    k = direct ? 0 : k;
+    c = direct ? 0.0 : c;
+    hu = direct ? 1 : hu;
+    const double dk = double(k);
+    const double hfsq = 0.5 * f * f;
+    double l;
+    if (hu == 0) {                       // |f| < 2^-20: rare, short
+        if (f == 0.0) {
+            l = (k == 0) ? 0.0 : dk * ln2_hi + (c + dk * ln2_lo);
+        } else {
+            const double R = hfsq * (1.0 - 0.66666666666666666 * f);
+            l = (k == 0) ? f - R : dk * ln2_hi - ((R - (dk * ln2_lo + c)) - f);
+        }
     } else {
-        t = 0.5 * spa_log1p((xa + xa) / (1.0 - xa));
+        const double s = spa_div(f, 2.0 + f);                // denominator in [1.7, 2.42]
+        const double z = s * s;
+        const double R1 = z * Lp1, z2 = z * z;
+        const double R2 = Lp2 + z * Lp3, z4 = z2 * z2;
+        const double R3 = Lp4 + z * Lp5, z6 = z4 * z2;
+        const double R4 = Lp6 + z * Lp7;
+        const double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
+        const double sr = s * (hfsq + R);
+        l = (k == 0) ? f - (hfsq - sr) : dk * ln2_hi - ((hfsq - (sr + (dk * ln2_lo + c))) - f);
     }
-    return (SPA_BITS_HI(x) >> 31) ? -t : t;
+    double t = 0.5 * l;
+    t = (SPA_BITS_HI(x) >> 31) ? -t : t;
+    return (xa < 0x1.0p-28) ? x : t;
 }

@@ -1,6 +1,7 @@
 // Host-side table construction for the Mercury RX kernels — see tables.hpp for the reference map.
 #include "tables.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -152,6 +153,57 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         }
         g.vptr[N] = s;
         if (s != E) throw std::runtime_error("LDPC table blob: edge count mismatch");
+        // ---- wave-private bins (first-fit decreasing over check degrees) ----------------------
+        std::vector<uint32_t> order(P);
+        for (uint32_t c = 0; c < P; ++c) order[c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cdeg[a] > cdeg[b]; });
+        std::vector<int> fill;                       // used slots per bin
+        std::vector<std::vector<uint32_t>> members;  // checks per bin
+        for (uint32_t c : order) {
+            const int d = cdeg[c];
+            if (d > 64) throw std::runtime_error("check degree exceeds a wavefront");
+            size_t b = 0;
+            for (; b < fill.size(); ++b) if (fill[b] + d <= 64) break;
+            if (b == fill.size()) { fill.push_back(0); members.emplace_back(); }
+            fill[b] += d;
+            members[b].push_back(c);
+        }
+        g.S = int(fill.size()) * 64;
+        if (g.S >= 8192) throw std::runtime_error("padded edge count exceeds the 13-bit slot field");
+        g.spack.assign(g.S, 0u);
+        g.svar.assign(g.S, 0);
+        g.vslot.resize(E);
+        g.cinfo.clear();
+        std::vector<uint32_t> slot_of_edge(E);
+        for (size_t b = 0; b < members.size(); ++b) {
+            uint32_t p = uint32_t(b) * 64;
+            for (uint32_t c : members[b]) {
+                const uint32_t cs = p, d = cdeg[c];
+                g.cinfo.push_back(cs | (d << 16));
+                for (uint32_t j = 0; j < d; ++j, ++p) {
+                    const uint32_t eo = g.cptr[c] + j;
+                    g.spack[p] = cs | (d << 13) | (j << 19) | 0x80000000u;
+                    g.svar[p] = g.cvar[eo];
+                    slot_of_edge[eo] = p;
+                }
+            }
+        }
+        // variable update order: by degree (descending) so the lanes of a wavefront share a trip count
+        std::vector<uint32_t> vorder(N);
+        for (uint32_t v = 0; v < N; ++v) vorder[v] = v;
+        std::stable_sort(vorder.begin(), vorder.end(), [&](uint32_t a, uint32_t b) { return vdeg[a] > vdeg[b]; });
+        g.vinfo.assign(size_t(N) * 6, 0u);   // per variable: v | deg<<11, then 10 u16 slot indices in 5 words
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < N; ++i) {
+            const uint32_t v = vorder[i], d = vdeg[v];
+            if (d > 9) throw std::runtime_error("variable degree exceeds the unrolled update");
+            g.vinfo[size_t(i) * 6] = v | (d << 11);
+            for (uint32_t j = 0; j < d; ++j) {
+                const uint32_t slot = slot_of_edge[g.vedge[g.vptr[v] + j]];
+                g.vslot[w++] = uint16_t(slot);
+                g.vinfo[size_t(i) * 6 + 1 + j / 2] |= slot << (16 * (j & 1));
+            }
+        }
         return g;
     }
     throw std::runtime_error("LDPC table blob has no graph for this rate");

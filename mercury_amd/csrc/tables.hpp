@@ -40,6 +40,14 @@ struct LdpcGraph {
     std::vector<uint16_t> vedge;   // [E]   edge index of (variable, slot) in the reference's slot order
     std::vector<uint16_t> echk;    // [E]   check of edge e
     std::vector<uint16_t> eslot;   // [E]   vptr[v]+slot for edge e (inverse of vedge)
+    // wave-private layout for the sum-product kernel: whole checks bin-packed (first-fit decreasing)
+    // into 64-slot bins so that one wavefront owns every edge of the checks it updates
+    int S = 0;                     // padded slot count = 64 * bins
+    std::vector<uint32_t> spack;   // [S] check_start_slot | deg<<13 | pos<<19 | valid<<31 (0 for padding)
+    std::vector<uint16_t> svar;    // [S] variable of the slot's edge (0 for padding)
+    std::vector<uint16_t> vslot;   // [E] padded slot of (variable, slot j), variables in vinfo order, j in the reference's slot order
+    std::vector<uint32_t> vinfo;   // [N][6] variable | deg<<11, then 10 u16 padded-slot indices; rows sorted by degree (descending)
+    std::vector<uint32_t> cinfo;   // [P] check_start_slot | deg<<16, in bin order
 };
 
 struct ModeTables {

@@ -79,7 +79,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
-    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing",
+    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math",
 ]
 
 
@@ -171,6 +171,14 @@ class RxPhy:
 
     def txgen_dev(self, seed, frame0, F, noise_amp, d_baseband, d_payload=None, channel=0, stream=None):
         self._ck(self.lib.mgpu_txgen_dev(self.h, seed, frame0, F, noise_amp, channel, d_baseband, d_payload, stream))
+
+    def debug_spa_math(self, x):
+        """Device tanh / atanh (csrc/spa_math.h) of a float64 array -> (tanh, atanh[0 where |x|>=1])."""
+        xin = np.ascontiguousarray(x, np.float64).ravel()
+        t = np.zeros_like(xin)
+        a = np.zeros_like(xin)
+        self._ck(self.lib.mgpu_debug_spa_math(self.h, _ptr(xin), C.c_int(xin.size), _ptr(t), _ptr(a)))
+        return t, a
 
     def enable_timing(self, on=True):
         self._ck(self.lib.mgpu_enable_timing(self.h, C.c_int(1 if on else 0)))

@@ -659,6 +659,14 @@ void morc_rx(morc* o, const double* baseband_c128, int flags, morc_rx_out* out) 
     if (out->bytes) memcpy(out->bytes, bytes, sizeof(int) * ((nb + 7) / 8));
 }
 
+/* the host libm functions exactly as decode_SPA calls them (ldpc_decoder_SPA.cc:145,156) */
+void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out) {
+    for (int i = 0; i < n; i++) {
+        tanh_out[i] = tanh(in[i]);
+        atanh_out[i] = fabs(in[i]) < 1.0 ? atanh(in[i]) : 0.0;
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* Synthetic workload generator (the repo's own definition; DESIGN.md §"Synthetic inputs") */
 static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }

@@ -89,6 +89,9 @@ void morc_gen_frame(morc*, uint64_t seed, uint64_t frame, double noise_amp, int 
 /* apply the channel of morc_gen_frame to an already modulated frame (in place) */
 void morc_channel(morc*, uint64_t seed, uint64_t frame, double noise_amp, int channel, double* frame_c128);
 
+/* host libm tanh / atanh as the reference's decoder calls them; atanh_out is 0 where |x| >= 1 */
+void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out);
+
 /* cpu_baseline helper: run morc_rx on n frames laid out back to back; returns sum of iterations */
 long morc_rx_many(morc*, const double* baseband_c128, int n, int flags, int* iters_out, int* crc_out,
                   unsigned char* payload_out);

@@ -169,6 +169,13 @@ class Oracle(_Base):
         self.lib.morc_channel(self.h, C.c_uint64(seed), C.c_uint64(frame), C.c_double(noise_amp), C.c_int(channel), _p(x))
         return x
 
+    def libm_tanh_atanh(self, x):
+        xin = np.ascontiguousarray(x, np.float64).ravel()
+        t = np.zeros_like(xin)
+        a = np.zeros_like(xin)
+        self.lib.morc_libm_tanh_atanh(_p(xin), C.c_int(xin.size), _p(t), _p(a))
+        return t, a
+
     def rx_many(self, baseband, flags=FLAGS_RECEIVE_BYTE):
         bb = np.ascontiguousarray(baseband, np.complex128).reshape(-1, self.frame_samples)
         n = bb.shape[0]

@@ -250,3 +250,28 @@ def test_gpu_against_committed_reference_vectors(cfg):
             assert out["stats"]["crc"][idx] == g["crc"] and out["stats"]["all_zeros"][idx] == g["all_zeros"]
             assert np.array_equal(out["payload"][idx], arr[key + "_bytes"]), (cfg, idx, vname)
         rx.close()
+
+
+def test_spa_math_on_device_matches_host_libm():
+    """The decoder's device tanh/atanh (fdlibm restatement + guard-free division) against the host libm the
+    reference calls, bit for bit, on a few million arguments spanning every branch and the decoder's ranges."""
+    rx = _rx(8, max_batch=1)
+    rng = np.random.default_rng(12345)
+    n = 1 << 21
+    sign = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    xs = np.concatenate([
+        sign * np.exp2(rng.uniform(-60, 6, n)),                 # tanh arguments over 66 octaves
+        rng.uniform(-25, 25, n),
+        rng.uniform(-1, 1, n),                                  # atanh arguments
+        np.tanh(rng.uniform(-20, 20, n)) * np.tanh(rng.uniform(-20, 20, n)),   # products of tanh's, as in the check update
+        sign * (1.0 - np.exp(-rng.uniform(0, 36, n))),          # close to +-1
+        sign * np.exp(-rng.uniform(0, 40, n)),
+        np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.9999999, -0.9999999, 22.0, -22.0, 21.999999, 2.0 ** -55, 2.0 ** -54,
+                  2.0 ** -28, 2.0 ** -29, 0.34657359027997264, 1.0397207708399179, 19.061547465398498, 38.0, 44.0, 1e300]),
+    ])
+    t, a = rx.debug_spa_math(xs)
+    ref_t, ref_a = Oracle(8).libm_tanh_atanh(xs)      # the host libm, called from C exactly as the reference does
+    bad_t = np.flatnonzero(t.view(np.uint64) != ref_t.view(np.uint64))
+    bad_a = np.flatnonzero(a.view(np.uint64) != ref_a.view(np.uint64))
+    assert bad_t.size == 0, (bad_t.size, xs[bad_t[:5]], t[bad_t[:5]], ref_t[bad_t[:5]])
+    assert bad_a.size == 0, (bad_a.size, xs[bad_a[:5]], a[bad_a[:5]], ref_a[bad_a[:5]])
