@@ -139,7 +139,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         return k;
     };
     const SlotRegs pk = {load_slot(0), load_slot(1), load_slot(2), load_slot(3), load_slot(4), load_slot(5), load_slot(6), load_slot(7)};
-    if (tid == 0) flag[0] = 0;
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
 
     // parity of every check of this wave's bin from the sign bits of its edges' variables
@@ -163,10 +163,14 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         }
         if (unsat) flag[0] = 1;
     }
-    __syncthreads();
+    // The syndrome of pass `it` (0 = channel values) lands in flag[it & 1]. A wave's check update only
+    // reads T values its own lanes wrote, so it may start the next check update before anybody has
+    // looked at the flag: the verdict is read behind the barrier that follows that check update, and
+    // on convergence the speculative update is simply dropped (it never touches the posteriors).
     int iteration = 0;
-    if (flag[0]) {
-        for (iteration = 1; iteration <= T.max_iters; ++iteration) {
+    for (int it = 1;; ++it) {
+        const bool last = it > T.max_iters;
+        if (!last) {
             // check update (:129-160), in place
 #pragma unroll 1
             for (int r = 0; r < NE; ++r) {
@@ -188,43 +192,44 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
                 __builtin_amdgcn_wave_barrier();   // every lane of this wave has read its check's T values
                 if (valid) M[tid + r * LDPC_THREADS] = rr;
             }
-            if (tid == 0) flag[0] = 0;
-            __syncthreads();
-            // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count
-            for (int i = tid; i < N; i += LDPC_THREADS) {
-                // record: variable | deg<<11, then 10 u16 slot indices (reference slot order, zero padded)
-                const uint32_t* rec = T.vinfo + size_t(i) * 6;
-                const uint32_t vi = rec[0], w0 = rec[1], w1 = rec[2], w2 = rec[3], w3 = rec[4], w4 = rec[5];
-                const int v = vi & 0x7ff, deg = vi >> 11;
-                double s = Li[v];
-                const double m0 = M[w0 & 0xffff], m1 = M[w0 >> 16], m2 = M[w1 & 0xffff], m3 = M[w1 >> 16], m4 = M[w2 & 0xffff];
-                s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
-                s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
-                if (deg > 5) {
-                    const double m5 = M[w2 >> 16], m6 = M[w3 & 0xffff], m7 = M[w3 >> 16], m8 = M[w4 & 0xffff];
-                    s += m5;
-                    s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
-                }
-                Lt[v] = s;
-            }
-            __syncthreads();
-            // syndrome (:173-190) and Q = LLRtmp - R (:193-209) -> T for the next check update
-            bool unsat = false;
-#pragma unroll 1
-            for (int r = 0; r < NE; ++r) {
-                const uint32_t k = pk.get(r);
-                const bool valid = ((k >> 13) & 0x3f) != 0;
-                const double lt = valid ? Lt[k >> 19] : 0.0;
-                unsat |= check_parity(k, valid && lt < 0) && valid;
-                if (valid) {
-                    const int p = tid + r * LDPC_THREADS;
-                    M[p] = spa_tanh(0.5 * (lt - M[p]));
-                }
-            }
-            if (unsat) flag[0] = 1;
-            __syncthreads();
-            if (!flag[0]) break;
         }
+        __syncthreads();
+        const int unsat_prev = flag[(it - 1) & 1];          // syndrome of pass it-1
+        if (!unsat_prev) { iteration = it - 1; break; }
+        if (last) { iteration = T.max_iters + 1; break; }
+        if (tid == 0) flag[it & 1] = 0;
+        // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count
+        for (int i = tid; i < N; i += LDPC_THREADS) {
+            // record: variable | deg<<11, then 10 u16 slot indices (reference slot order, zero padded)
+            const uint32_t* rec = T.vinfo + size_t(i) * 6;
+            const uint32_t vi = rec[0], w0 = rec[1], w1 = rec[2], w2 = rec[3], w3 = rec[4], w4 = rec[5];
+            const int v = vi & 0x7ff, deg = vi >> 11;
+            double s = Li[v];
+            const double m0 = M[w0 & 0xffff], m1 = M[w0 >> 16], m2 = M[w1 & 0xffff], m3 = M[w1 >> 16], m4 = M[w2 & 0xffff];
+            s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
+            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+            if (deg > 5) {
+                const double m5 = M[w2 >> 16], m6 = M[w3 & 0xffff], m7 = M[w3 >> 16], m8 = M[w4 & 0xffff];
+                s += m5;
+                s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
+            }
+            Lt[v] = s;
+        }
+        __syncthreads();
+        // syndrome (:173-190) and Q = LLRtmp - R (:193-209) -> T for the next check update
+        bool unsat = false;
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t k = pk.get(r);
+            const bool valid = ((k >> 13) & 0x3f) != 0;
+            const double lt = valid ? Lt[k >> 19] : 0.0;
+            unsat |= check_parity(k, valid && lt < 0) && valid;
+            if (valid) {
+                const int p = tid + r * LDPC_THREADS;
+                M[p] = spa_tanh(0.5 * (lt - M[p]));
+            }
+        }
+        if (unsat) flag[it & 1] = 1;
     }
     for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
     __syncthreads();

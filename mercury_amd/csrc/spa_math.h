@@ -108,11 +108,14 @@ SPA_FN double spa_tanh(double x) {
     const double ya = spa_add_exponent(one - emx, k) - one;                              // k <= -2 || k > 56
     const double tb = SPA_MAKE(0x3ff00000u - (0x200000u >> (uint32_t(k) & 31u)), 0u);   // 1 - 2^-k, 2 <= k < 20
     const double yb = spa_add_exponent(tb - emx, k);
-    const double tc = SPA_MAKE(uint32_t(0x3ff - k) << 20, 0u);                           // 2^-k, 20 <= k <= 56
-    const double yc = spa_add_exponent((r - (e + tc)) + one, k);
-    double t = (k <= -2 || k > 56) ? ya : (k < 20 ? yb : yc);
+    double t = (k <= -2) ? ya : yb;
     t = (k == -1) ? resm1 : t;
     t = (k == 0) ? res0 : t;
+    if (k >= 20) {                       // |x| > 6.7: rare at the SNRs where the decoder iterates; a real branch
+        const double tc = SPA_MAKE(uint32_t(0x3ff - k) << 20, 0u);                       // 2^-k, 20 <= k <= 56
+        const double yc = spa_add_exponent((r - (e + tc)) + one, k);
+        t = (k > 56) ? ya : yc;
+    }
     // ---- tanh from t -------------------------------------------------------------------------
     const double q = spa_div(big ? two : -t, t + two);       // denominator in [1, 2^64]
     double z = big ? one - q : q;
