@@ -126,6 +126,10 @@ void ctx_alloc(mgpu_ctx* c) {
     d.payload_bytes = t.payload_bytes; d.payload_stride = t.payload_stride; d.frame_samples = t.frame_samples;
     d.agc = c->cfg.agc; d.var_eq = c->cfg.variance_source; d.max_iters = c->cfg.max_iters;
     d.pilot_boost = t.pilot_boost;
+    d.regular_lattice = 1;
+    for (int r = 0; r < t.Nsymb; ++r)
+        for (int q = 0; q < t.Nc; ++q)
+            if ((t.cell_type[size_t(r) * t.Nc + q] != 0) != (((r - q) % 3 + 3) % 3 == 0)) d.regular_lattice = 0;
     d.minsum_alpha = c->cfg.minsum_alpha > 0 ? c->cfg.minsum_alpha : 0.8f;
     LdpcDev& l = c->ldev;
     l.spack = d.spack; l.svar = d.svar; l.vptr = d.vptr; l.vslot = d.vslot; l.cinfo = d.cinfo; l.vinfo = d.vinfo; l.scrambler = d.scrambler;
@@ -177,7 +181,7 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
                      const MgpuTapsDev& taps, hipStream_t s) {
     const int slot = c->ev_count % mgpu_ctx::kEvRing;
     if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][0], s)); c->ev_fe[slot] = true; }
-    hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(F), dim3(256), c->lds_fe, s, c->dev, d_bb, F, d_llr, d_var, d_snrvar, taps);
+    hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(F), dim3(512), c->lds_fe, s, c->dev, d_bb, F, d_llr, d_var, d_snrvar, taps);
     HIPCK(hipGetLastError());
     if (c->timing) HIPCK(hipEventRecord(c->ev[slot][1], s));
 }

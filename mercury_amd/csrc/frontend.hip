@@ -66,11 +66,14 @@ __device__ __forceinline__ double get_angle(c2 v) {
 
 }  // namespace
 
-#define FE_THREADS 256
+#define FE_THREADS 512
+#define FE_WAVES (FE_THREADS / 64)
 
-// LDS carve (bytes): grid 16G | H 16G | fft 4*256*16 | tw 128*16 | llr 4*nBits(<=1600) | type G | scal 64
+// LDS carve (bytes): grid 16G | B = max(16G, FE_WAVES*4096) (FFT work area, later the channel/equalised grid)
+//                    | red/llr 6400 (reduction terms, later the demapper LLRs) | tw 2048 | type G | scal 64
 extern "C" size_t mgpu_frontend_lds_bytes(int G) {
-    return size_t(16) * G * 2 + 4 * 256 * 16 + 128 * 16 + 1600 * 4 + ((G + 15) & ~15) + 64;
+    const size_t b = size_t(16) * G > size_t(FE_WAVES) * 4096 ? size_t(16) * G : size_t(FE_WAVES) * 4096;
+    return size_t(16) * G + b + 6400 + 2048 + ((G + 15) & ~15) + 64;
 }
 
 extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
@@ -79,54 +82,53 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int G = T.G, Nc = 50, Ns = T.Nsymb;
     c2* grid = reinterpret_cast<c2*>(smem);
-    c2* H = grid + G;
-    c2* fftb = H + G;                       // 4 x 256
-    c2* tw = fftb + 4 * 256;                // 128
-    float* llr = reinterpret_cast<float*>(tw + 128);
-    uint8_t* type = reinterpret_cast<uint8_t*>(llr + 1600);
+    c2* H = grid + G;                                               // also the FFT work area (dead before H is born)
+    c2* fftb = H;
+    const size_t bsz = size_t(16) * G > size_t(FE_WAVES) * 4096 ? size_t(16) * G : size_t(FE_WAVES) * 4096;
+    double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(H) + bsz);   // <= 800 doubles
+    float* llr = reinterpret_cast<float*>(red);                     // demapper output reuses the reduction area
+    c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(red) + 6400);
+    int8_t* type = reinterpret_cast<int8_t*>(tw + 128);             // 0 data, +1 / -1 pilot with that sign
     double* scal = reinterpret_cast<double*>(type + ((G + 15) & ~15));
-    double* red = reinterpret_cast<double*>(fftb);  // reduction scratch (<= 800 doubles), reuses the FFT area
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f = blockIdx.x;
     if (f >= F) return;
     const c2* bb = reinterpret_cast<const c2*>(baseband) + size_t(f) * T.frame_samples;
+    const double boost = T.pilot_boost;
 
     for (int i = tid; i < 128; i += FE_THREADS) tw[i] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
-    for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i];
+    for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i] ? (T.pilot_val[i] < 0 ? int8_t(-1) : int8_t(1)) : int8_t(0);
     __syncthreads();
 
-    // ---- symbol_demod: one wave per symbol, 4 symbols per pass --------------------------------
-    const int passes = (Ns + 3) / 4;
-    for (int pass = 0; pass < passes; ++pass) {
-        const int s = pass * 4 + wave;
-        const bool act = s < Ns;
+    // ---- symbol_demod: one wave per symbol. The 256-point work buffer is private to the wave, LDS
+    // operations of one wave execute in order, so the 8 butterfly stages need no workgroup barrier.
+    for (int s = wave; s < Ns; s += FE_WAVES) {
         c2* v = fftb + wave * 256;
-        if (act) {
-            const c2* in = bb + size_t(s) * 272 + 16;            // gi_remover
-            for (int i = lane; i < 256; i += 64) v[__brev(unsigned(i)) >> 24] = in[i];  // bit-reversal permutation
-        }
-        __syncthreads();
+        const c2* in = bb + size_t(s) * 272 + 16;                   // gi_remover
+#pragma unroll
+        for (int i = lane; i < 256; i += 64) v[__brev(unsigned(i)) >> 24] = in[i];   // bit-reversal permutation
+        __builtin_amdgcn_wave_barrier();
         for (int size = 2; size <= 256; size <<= 1) {
             const int half = size >> 1, step = 256 / size;
-            if (act) {
-                for (int b = lane; b < 128; b += 64) {
-                    const int j = b & (half - 1);
-                    const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
-                    const c2 t = cmul(tw[j * step], v[i1]);
-                    const c2 u = v[i0];
-                    v[i1] = {u.re - t.re, u.im - t.im};
-                    v[i0] = {u.re + t.re, u.im + t.im};
-                }
+#pragma unroll
+            for (int b = lane; b < 128; b += 64) {
+                const int j = b & (half - 1);
+                const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
+                const c2 t = cmul(tw[j * step], v[i1]);
+                const c2 u = v[i0];
+                v[i1] = {u.re - t.re, u.im - t.im};
+                v[i0] = {u.re + t.re, u.im + t.im};
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
-        if (act && lane < 50) {                                   // 1/Nfft scale + zero_depadder
+        if (lane < 50) {                                            // 1/Nfft scale + zero_depadder
             const int bin = lane < 25 ? lane + 256 - 25 : lane - 25 + 1;
             grid[s * Nc + lane] = {v[bin].re / 256.0, v[bin].im / 256.0};
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
 
     // ---- automatic_gain_control ---------------------------------------------------------------
     if (T.agc) {
@@ -139,7 +141,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
             double amp = 0;
             for (int p = 0; p < T.nPilots; ++p) amp += red[p];
             amp /= T.nPilots;
-            scal[0] = T.pilot_boost / amp;
+            scal[0] = boost / amp;
         }
         __syncthreads();
         const double agc = scal[0];
@@ -154,23 +156,41 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     for (int p = tid; p < T.nPilots; p += FE_THREADS) {
         const int c = T.pilot_cell[p], i = c / Nc, j = c - i * Nc;
         if (T.estimator == 0) {            // ZF: Y / (x + 0i) reduces to two real divisions in __divdc3
-            const double x = T.pilot_val[c];
+            const double x = type[c] < 0 ? -boost : boost;
             H[c] = {grid[c].re / x, grid[c].im / x};
         } else {                           // LS over the (clipped) 21x21 window, row-major order
             const int k0 = max(i - hw, 0), k1 = min(i + hw, Ns - 1), l0 = max(j - hw, 0), l1 = min(j + hw, Nc - 1);
-            int n = 0;
-            for (int k = k0; k <= k1; ++k)
-                for (int l = l0; l <= l1; ++l) n += type[k * Nc + l];
-            const double w = T.ls_weight[n];
             double hr = 0, hi = 0;
-            for (int k = k0; k <= k1; ++k)
-                for (int l = l0; l <= l1; ++l) {
-                    const int q = k * Nc + l;
-                    if (!type[q]) continue;
-                    const double xw = T.pilot_val[q] < 0 ? -w : w;   // x' = x * (1/sum x^2)
-                    hr += xw * grid[q].re;
-                    hi += xw * grid[q].im;
+            if (T.regular_lattice) {       // pilots of row k sit at columns == k (mod 3): visit only those
+                int n = 0;
+                for (int k = k0; k <= k1; ++k) {
+                    const int first = l0 + ((k - l0) % 3 + 3) % 3;
+                    if (first <= l1) n += (l1 - first) / 3 + 1;
                 }
+                const double w = T.ls_weight[n];
+                for (int k = k0; k <= k1; ++k) {
+                    const int first = l0 + ((k - l0) % 3 + 3) % 3;
+                    for (int l = first; l <= l1; l += 3) {
+                        const int q = k * Nc + l;
+                        const double xw = type[q] < 0 ? -w : w;      // x' = x * (1/sum x^2)
+                        hr += xw * grid[q].re;
+                        hi += xw * grid[q].im;
+                    }
+                }
+            } else {
+                int n = 0;
+                for (int k = k0; k <= k1; ++k)
+                    for (int l = l0; l <= l1; ++l) n += type[k * Nc + l] != 0;
+                const double w = T.ls_weight[n];
+                for (int k = k0; k <= k1; ++k)
+                    for (int l = l0; l <= l1; ++l) {
+                        const int q = k * Nc + l;
+                        if (!type[q]) continue;
+                        const double xw = type[q] < 0 ? -w : w;
+                        hr += xw * grid[q].re;
+                        hi += xw * grid[q].im;
+                    }
+            }
             H[c] = {hr, hi};
         }
     }
@@ -200,7 +220,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
         for (int p = tid; p < T.nPilots; p += FE_THREADS) {      // measure_variance(equalized_data_without_amplitude_restoration)
             const int c = T.pilot_cell[p];
             const c2 e = cdiv(grid[c], H[c]);
-            const double dr = e.re - T.pilot_val[c], di = e.im - 0.0;
+            const double dr = e.re - (type[c] < 0 ? -boost : boost), di = e.im - 0.0;
             red[p] = dr * dr + di * di;
         }
         __syncthreads();
@@ -210,7 +230,6 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
             var /= double(T.nPilots);
             scal[2] = var;
         }
-        __syncthreads();
         for (int c = tid; c < G; c += FE_THREADS) {
             const double th = get_angle(H[c]);
             H[c] = {cos(th), sin(th)};
@@ -223,11 +242,10 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     if (!T.var_eq) {
         for (int p = tid; p < T.nPilots; p += FE_THREADS) {
             const int c = T.pilot_cell[p];
-            const double dr = grid[c].re - T.pilot_val[c], di = grid[c].im - 0.0;
+            const double dr = grid[c].re - (type[c] < 0 ? -boost : boost), di = grid[c].im - 0.0;
             red[p] = dr * dr + di * di;
         }
     }
-    __syncthreads();
     // ---- channel_equalizer (in place over H) ---------------------------------------------------
     for (int c = tid; c < G; c += FE_THREADS) H[c] = cdiv(grid[c], H[c]);
     __syncthreads();
@@ -236,7 +254,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     if (T.var_eq) {
         for (int p = tid; p < T.nPilots; p += FE_THREADS) {
             const int c = T.pilot_cell[p];
-            const double dr = eq[c].re - T.pilot_val[c], di = eq[c].im - 0.0;
+            const double dr = eq[c].re - (type[c] < 0 ? -boost : boost), di = eq[c].im - 0.0;
             red[p] = dr * dr + di * di;
         }
         __syncthreads();
