@@ -30,7 +30,8 @@ DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
 using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-extern "C" __global__ void mgpu_ldpc_minsum_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+#define DECL_MS(NE) extern "C" __global__ void mgpu_ldpc_minsum_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+DECL_MS(4) DECL_MS(5) DECL_MS(6) DECL_MS(7) DECL_MS(8)
 extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*);
 
 static_assert(sizeof(MgpuStatsDev) == sizeof(mgpu_frame_stats), "stats layout");
@@ -170,8 +171,16 @@ void ctx_alloc(mgpu_ctx* c) {
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_gbf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
         case MGPU_DEC_MINSUM:
-            c->lds_dec = mgpu_minsum_lds_bytes(d.E, d.N);
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_minsum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
+            c->lds_dec = mgpu_minsum_lds_bytes(d.S, d.N);
+            switch ((d.S + 1023) / 1024) {
+                case 1: case 2: case 3: case 4: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne4; break;
+                case 5: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne5; break;
+                case 6: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne6; break;
+                case 7: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne7; break;
+                case 8: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne8; break;
+                default: throw std::runtime_error("graph too large for the min-sum kernel");
+            }
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
         default: throw std::runtime_error("unknown decoder");
     }
@@ -198,7 +207,7 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
             hipLaunchKernelGGL(mgpu_ldpc_gbf_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
             break;
         default:
-            hipLaunchKernelGGL(mgpu_ldpc_minsum_kernel, dim3(F), dim3(512), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
+            hipLaunchKernelGGL(c->spa_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
             break;
     }
     HIPCK(hipGetLastError());

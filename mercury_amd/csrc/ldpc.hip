@@ -321,83 +321,139 @@ extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_gbf_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // Normalised min-sum, fp32, flooding schedule (BASELINE.json north_star variant; not in the
-// reference). Per iteration: (1) one lane per check reduces its edges' Q to {min1, min2, argmin,
-// sign product} and, from the posteriors' hard bits, the syndrome of the PREVIOUS iteration;
-// (2) one lane per variable rebuilds its R messages from the check summaries, forms the posterior
-// and writes the new extrinsic Q in place. Two barriers per iteration, all state in LDS.
-#define MS_THREADS 512
-
-extern "C" size_t mgpu_minsum_lds_bytes(int E, int N) {
-    return size_t(4) * E + size_t(16) * 1600 + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
+// reference). Same skeleton as the sum-product kernel: wave-private 64-slot bins, one message array
+// updated in place (Q -> R -> Q), slot descriptors in registers, ballot syndrome, two barriers per
+// iteration. Check update per edge: sign = product of the other edges' signs, magnitude = alpha *
+// min of the other edges' |Q| (each lane scans its check's <= 46 slots, all lanes of a check read
+// the same LDS word per step = broadcast).
+extern "C" size_t mgpu_minsum_lds_bytes(int S, int N) {
+    return size_t(4) * S + size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64;
 }
 
-extern "C" __global__ __launch_bounds__(MS_THREADS) void mgpu_ldpc_minsum_kernel(
-    LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
-    int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
-    const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+template <int NE>
+__device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
+                                              uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
+                                              uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+                                              const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int E = T.E, N = T.N, P = T.P;
-    float* Qc = reinterpret_cast<float*>(smem);                 // extrinsic var->check message per edge (check-major)
-    float4* summ = reinterpret_cast<float4*>(Qc + ((E + 3) & ~3));  // per check: min1, min2, argmin (bits), sign product (bits)
-    float* Li = reinterpret_cast<float*>(summ + 1600);
+    const int S = T.S, N = T.N;
+    float* M = reinterpret_cast<float*>(smem);        // Q or R per padded edge slot
+    float* Lt = M + S;                                // posterior per variable
+    float* Li = Lt + N;                               // channel LLR
     uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
     uint8_t* bytes = hard + ((N + 15) & ~15);
     int* flag = reinterpret_cast<int*>(bytes + 256);
     const int tid = threadIdx.x, f = blockIdx.x;
     if (f >= F) return;
     const float alpha = T.minsum_alpha;
-    for (int v = tid; v < N; v += MS_THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; hard[v] = l < 0; }
+    for (int v = tid; v < N; v += LDPC_THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; Lt[v] = l; }
+    auto load_slot = [&](int r) -> uint32_t {
+        const int p = tid + r * LDPC_THREADS;
+        uint32_t k = 0;
+        if (r < NE && p < S) {
+            const uint32_t sp = T.spack[p];
+            if (sp >> 31) k = (sp & 0x7ffffu) | (uint32_t(T.svar[p]) << 19);
+        }
+        return k;
+    };
+    const SlotRegs pk = {load_slot(0), load_slot(1), load_slot(2), load_slot(3), load_slot(4), load_slot(5), load_slot(6), load_slot(7)};
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
-    for (int e = tid; e < E; e += MS_THREADS) Qc[e] = Li[T.cvar[e]];
-    __syncthreads();
-    int iteration = 0;
+    auto check_parity = [&](uint32_t k, bool neg) -> bool {
+        const unsigned long long m = __ballot(neg);
+        const uint32_t deg = (k >> 13) & 0x3f, l0 = k & 63u;
+        const unsigned long long cm = ((deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << l0);
+        return (__popcll(m & cm) & 1) != 0;
+    };
+    {
+        bool unsat = false;
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t k = pk.get(r);
+            const bool valid = ((k >> 13) & 0x3f) != 0;
+            const float l = valid ? Li[k >> 19] : 0.0f;
+            unsat |= check_parity(k, valid && l < 0) && valid;
+            if (valid) M[tid + r * LDPC_THREADS] = l;
+        }
+        if (unsat) flag[0] = 1;
+    }
     // iteration counts follow the reference's convention: 0 = input already a codeword,
     // k = converged after k iterations, max+1 = never converged.
-    for (int it = 0; it <= T.max_iters; ++it) {
-        int bad = 0;
-        for (int c = tid; c < P; c += MS_THREADS) {
-            const uint32_t e0 = T.cptr[c], e1 = T.cptr[c + 1];
-            float m1 = __builtin_inff(), m2 = __builtin_inff();
-            uint32_t arg = 0, sgn = 0, syn = 0;
-            for (uint32_t e = e0; e < e1; ++e) {
-                const float q = Qc[e];
-                const float a = fabsf(q);
-                sgn ^= __float_as_uint(q) >> 31;
-                syn ^= hard[T.cvar[e]];
-                if (a < m1) { m2 = m1; m1 = a; arg = e; } else if (a < m2) { m2 = a; }
-            }
-            bad |= syn;
-            summ[c] = make_float4(m1 * alpha, m2 * alpha, __uint_as_float(arg), __uint_as_float(sgn));
-        }
-        if (bad) flag[it & 1] = 1;
-        __syncthreads();
-        const int unsat = flag[it & 1];   // the other flag word is reset below, so no lane can see a stale value
-        if (!unsat) { iteration = it; break; }
-        if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
-        for (int v = tid; v < N; v += MS_THREADS) {
-            const uint32_t q0 = T.vptr[v], q1 = T.vptr[v + 1];
-            float s = Li[v];
-            float r[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                if (q0 + k < q1) {
-                    const uint32_t e = T.vedge[q0 + k];
-                    const float4 sm = summ[T.echk[e]];
-                    const float q = Qc[e];
-                    const float mag = (__float_as_uint(sm.z) == e) ? sm.y : sm.x;
-                    const uint32_t sg = (__float_as_uint(sm.w) ^ (__float_as_uint(q) >> 31)) << 31;
-                    r[k] = __uint_as_float(__float_as_uint(mag) ^ sg);
-                    s += r[k];
+    int iteration = 0;
+    for (int it = 1;; ++it) {
+        const bool last = it > T.max_iters;
+        if (!last) {
+#pragma unroll 1
+            for (int r = 0; r < NE; ++r) {
+                const uint32_t k = pk.get(r);
+                const int deg = (k >> 13) & 0x3f;
+                const bool valid = deg != 0;
+                float rr = 0.0f;
+                if (valid) {
+                    const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
+                    float mn = __builtin_inff();
+                    uint32_t sg = 0;
+                    for (int j = 0; j < deg; ++j) {
+                        const float m = M[cs + j];
+                        const uint32_t mb = __float_as_uint(m);
+                        sg ^= (j == pos) ? 0u : mb;
+                        mn = fminf(mn, (j == pos) ? __builtin_inff() : __uint_as_float(mb & 0x7fffffffu));
+                    }
+                    rr = __uint_as_float(__float_as_uint(mn * alpha) | (sg & 0x80000000u));
                 }
+                __builtin_amdgcn_wave_barrier();
+                if (valid) M[tid + r * LDPC_THREADS] = rr;
             }
-            hard[v] = s < 0;
-#pragma unroll
-            for (int k = 0; k < 12; ++k)
-                if (q0 + k < q1) Qc[T.vedge[q0 + k]] = s - r[k];
         }
-        if (tid == 0) flag[(it + 1) & 1] = 0;
         __syncthreads();
+        const int unsat_prev = flag[(it - 1) & 1];
+        if (!unsat_prev) { iteration = it - 1; break; }
+        if (last) { iteration = T.max_iters + 1; break; }
+        if (tid == 0) flag[it & 1] = 0;
+        for (int i = tid; i < N; i += LDPC_THREADS) {
+            const uint32_t* rec = T.vinfo + size_t(i) * 6;
+            const uint32_t vi = rec[0], w0 = rec[1], w1 = rec[2], w2 = rec[3], w3 = rec[4], w4 = rec[5];
+            const int v = vi & 0x7ff, deg = vi >> 11;
+            float s = Li[v];
+            const float m0 = M[w0 & 0xffff], m1 = M[w0 >> 16], m2 = M[w1 & 0xffff], m3 = M[w1 >> 16], m4 = M[w2 & 0xffff];
+            s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
+            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+            if (deg > 5) {
+                const float m5 = M[w2 >> 16], m6 = M[w3 & 0xffff], m7 = M[w3 >> 16], m8 = M[w4 & 0xffff];
+                s += m5;
+                s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
+            }
+            Lt[v] = s;
+        }
+        __syncthreads();
+        bool unsat = false;
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t k = pk.get(r);
+            const bool valid = ((k >> 13) & 0x3f) != 0;
+            const float lt = valid ? Lt[k >> 19] : 0.0f;
+            unsat |= check_parity(k, valid && lt < 0) && valid;
+            if (valid) {
+                const int p = tid + r * LDPC_THREADS;
+                M[p] = lt - M[p];
+            }
+        }
+        if (unsat) flag[it & 1] = 1;
     }
+    for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
+    __syncthreads();
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
 }
+
+#define MINSUM_KERNEL(NE)                                                                                          \
+    extern "C" __global__ __launch_bounds__(LDPC_THREADS, 8) void mgpu_ldpc_minsum_kernel_ne##NE(                \
+        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                        \
+        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,      \
+        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                        \
+        minsum_decode<NE>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
+    }
+MINSUM_KERNEL(4)
+MINSUM_KERNEL(5)
+MINSUM_KERNEL(6)
+MINSUM_KERNEL(7)
+MINSUM_KERNEL(8)
