@@ -139,6 +139,27 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         return k;
     };
     const SlotRegs pk = {load_slot(0), load_slot(1), load_slot(2), load_slot(3), load_slot(4), load_slot(5), load_slot(6), load_slot(7)};
+    // variable records (variable | deg<<11, then 10 u16 slot indices in the reference's slot order)
+    struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
+    auto load_var = [&](int i) -> VarRec {
+        if (i >= N) return VarRec{0, 0, 0, 0, 0, 0};
+        const uint32_t* rec = T.vinfo + size_t(i) * 6;
+        return VarRec{rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]};
+    };
+    const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
+    auto var_update = [&](const VarRec& q) {
+        const int v = q.vi & 0x7ff, deg = q.vi >> 11;
+        double s = Li[v];
+        const double m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16], m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
+        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
+        s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+        if (deg > 5) {
+            const double m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
+            s += m5;
+            s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
+        }
+        Lt[v] = s;
+    };
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
 
@@ -198,23 +219,10 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         if (!unsat_prev) { iteration = it - 1; break; }
         if (last) { iteration = T.max_iters + 1; break; }
         if (tid == 0) flag[it & 1] = 0;
-        // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count
-        for (int i = tid; i < N; i += LDPC_THREADS) {
-            // record: variable | deg<<11, then 10 u16 slot indices (reference slot order, zero padded)
-            const uint32_t* rec = T.vinfo + size_t(i) * 6;
-            const uint32_t vi = rec[0], w0 = rec[1], w1 = rec[2], w2 = rec[3], w3 = rec[4], w4 = rec[5];
-            const int v = vi & 0x7ff, deg = vi >> 11;
-            double s = Li[v];
-            const double m0 = M[w0 & 0xffff], m1 = M[w0 >> 16], m2 = M[w1 & 0xffff], m3 = M[w1 >> 16], m4 = M[w2 & 0xffff];
-            s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
-            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
-            if (deg > 5) {
-                const double m5 = M[w2 >> 16], m6 = M[w3 & 0xffff], m7 = M[w3 >> 16], m8 = M[w4 & 0xffff];
-                s += m5;
-                s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
-            }
-            Lt[v] = s;
-        }
+        // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count;
+        // each lane owns variables tid and tid+1024 of that order, their records live in registers
+        var_update(va);
+        if (tid + LDPC_THREADS < N) var_update(vb);
         __syncthreads();
         // syndrome (:173-190) and Q = LLRtmp - R (:193-209) -> T for the next check update
         bool unsat = false;
@@ -357,6 +365,26 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
         return k;
     };
     const SlotRegs pk = {load_slot(0), load_slot(1), load_slot(2), load_slot(3), load_slot(4), load_slot(5), load_slot(6), load_slot(7)};
+    struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
+    auto load_var = [&](int i) -> VarRec {
+        if (i >= N) return VarRec{0, 0, 0, 0, 0, 0};
+        const uint32_t* rec = T.vinfo + size_t(i) * 6;
+        return VarRec{rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]};
+    };
+    const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
+    auto var_update = [&](const VarRec& q) {
+        const int v = q.vi & 0x7ff, deg = q.vi >> 11;
+        float s = Li[v];
+        const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16], m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
+        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
+        s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+        if (deg > 5) {
+            const float m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
+            s += m5;
+            s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
+        }
+        Lt[v] = s;
+    };
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
     auto check_parity = [&](uint32_t k, bool neg) -> bool {
@@ -391,15 +419,21 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
                 float rr = 0.0f;
                 if (valid) {
                     const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
-                    float mn = __builtin_inff();
+                    // two smallest magnitudes and the sign product over ALL edges of the check (every lane of the
+                    // check runs the same scan on broadcast reads); the own edge is taken out afterwards:
+                    // min over the others = (|own| == min1) ? min2 : min1  (a tie leaves min2 == min1).
+                    float mn1 = __builtin_inff(), mn2 = __builtin_inff();
                     uint32_t sg = 0;
                     for (int j = 0; j < deg; ++j) {
                         const float m = M[cs + j];
-                        const uint32_t mb = __float_as_uint(m);
-                        sg ^= (j == pos) ? 0u : mb;
-                        mn = fminf(mn, (j == pos) ? __builtin_inff() : __uint_as_float(mb & 0x7fffffffu));
+                        sg ^= __float_as_uint(m);
+                        const float a = __builtin_fabsf(m);
+                        mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);   // second smallest of {mn1, mn2, a}
+                        mn1 = fminf(mn1, a);
                     }
-                    rr = __uint_as_float(__float_as_uint(mn * alpha) | (sg & 0x80000000u));
+                    const float own = M[cs + pos];
+                    const float mag = (__builtin_fabsf(own) == mn1) ? mn2 : mn1;
+                    rr = __uint_as_float(__float_as_uint(mag * alpha) | ((sg ^ __float_as_uint(own)) & 0x80000000u));
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (valid) M[tid + r * LDPC_THREADS] = rr;
@@ -410,21 +444,8 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
         if (!unsat_prev) { iteration = it - 1; break; }
         if (last) { iteration = T.max_iters + 1; break; }
         if (tid == 0) flag[it & 1] = 0;
-        for (int i = tid; i < N; i += LDPC_THREADS) {
-            const uint32_t* rec = T.vinfo + size_t(i) * 6;
-            const uint32_t vi = rec[0], w0 = rec[1], w1 = rec[2], w2 = rec[3], w3 = rec[4], w4 = rec[5];
-            const int v = vi & 0x7ff, deg = vi >> 11;
-            float s = Li[v];
-            const float m0 = M[w0 & 0xffff], m1 = M[w0 >> 16], m2 = M[w1 & 0xffff], m3 = M[w1 >> 16], m4 = M[w2 & 0xffff];
-            s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
-            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
-            if (deg > 5) {
-                const float m5 = M[w2 >> 16], m6 = M[w3 & 0xffff], m7 = M[w3 >> 16], m8 = M[w4 & 0xffff];
-                s += m5;
-                s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
-            }
-            Lt[v] = s;
-        }
+        var_update(va);
+        if (tid + LDPC_THREADS < N) var_update(vb);
         __syncthreads();
         bool unsat = false;
 #pragma unroll 1
