@@ -129,16 +129,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-per-core", type=int, default=160)
     ap.add_argument("--nbuf", type=int, default=2, help="distinct input batches cycled through")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for tests)")
+    ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the reduction tensors live
 
     decoder = {"spa": DEC_SPA, "minsum": DEC_MINSUM, "gbf": DEC_GBF}[args.decoder]
     agc, vs = (1, 1) if args.variant == "receive_byte" else (0, 0)
@@ -194,8 +202,8 @@ def main():
     fe_ms, dec_ms, nl = rx.kernel_ms_avg()
     rx.enable_timing(False)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    sums = torch.stack([iters_acc, decoded_acc]).to(torch.float64)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    sums = torch.stack([iters_acc, decoded_acc]).to(torch.float64).to(rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)

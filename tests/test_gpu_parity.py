@@ -275,3 +275,26 @@ def test_spa_math_on_device_matches_host_libm():
     bad_a = np.flatnonzero(a.view(np.uint64) != ref_a.view(np.uint64))
     assert bad_t.size == 0, (bad_t.size, xs[bad_t[:5]], t[bad_t[:5]], ref_t[bad_t[:5]])
     assert bad_a.size == 0, (bad_a.size, xs[bad_a[:5]], a[bad_a[:5]], ref_a[bad_a[:5]])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N>1 code path of bench.py (frame sharding by rank, barrier, MAX-time and counter reductions, one
+    JSON line from rank 0) with two ranks sharing GPU 0 over gloo — the driver's 8-GPU run uses the same
+    code with backend nccl and one GPU per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--frames", "256", "--esn0", "2.5", "--backend", "gloo", "--share-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["unit"] == "frames/s"
+    assert j["decoded_fraction"] > 0.97            # both ranks' frames decode (disjoint frame ranges, same seed)
+    assert abs(j["value"] - 2 * 256 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-6 * j["value"]
+    assert "roofline" in j and "cpu_baseline" not in j

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: sweep all 17 OFDM modes (each with the LDPC rate the reference pairs it
+with), report per-mode RX throughput for the sum-product (reference) and min-sum decoders, at the
+worst case (every frame runs all 50 iterations, Es/N0 = -15 dB) and at the operating point.
+Writes one JSON document; run on the GPU box:  python tools/sweep_modes.py > gpurun_out/sweep.json
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import OPERATING_ESN0  # noqa: E402
+
+
+def run(cfg, decoder, esn0, frames, steps=3):
+    variant = "baseband_test" if cfg in (15, 16) else "receive_byte"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cfg", str(cfg), "--decoder", decoder, "--esn0", str(esn0),
+           "--frames", str(frames), "--steps", str(steps), "--warmup", "1", "--nbuf", "1", "--variant", variant, "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
+    j = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    return {"frames_per_s": j["value"], "ldpc_iters_per_s": j["ldpc_iters_per_s"], "avg_iters": j["avg_iters_per_frame"],
+            "decoded_fraction": j["decoded_fraction"], "frontend_ms": j["kernel_ms"]["frontend"], "ldpc_ms": j["kernel_ms"]["ldpc"],
+            "roofline_frac": j["roofline"]["frac"], "variant": variant}
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    res = {"frames_per_step": frames, "modes": {}}
+    for cfg in range(17):
+        m = {}
+        for dec in ("spa", "minsum"):
+            m[dec + "_50iters"] = run(cfg, dec, -15.0, frames)
+            m[dec + "_operating"] = run(cfg, dec, OPERATING_ESN0[cfg] + 1.0, frames)
+        res["modes"][str(cfg)] = m
+        print("cfg %2d  spa@50 %9.0f f/s  minsum@50 %9.0f f/s  spa@op %9.0f f/s (%.1f it, %.3f ok)  minsum@op %9.0f f/s (%.3f ok)" % (
+            cfg, m["spa_50iters"]["frames_per_s"], m["minsum_50iters"]["frames_per_s"], m["spa_operating"]["frames_per_s"],
+            m["spa_operating"]["avg_iters"], m["spa_operating"]["decoded_fraction"], m["minsum_operating"]["frames_per_s"],
+            m["minsum_operating"]["decoded_fraction"]), file=sys.stderr)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
