@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-per-core", type=int, default=160)
     ap.add_argument("--nbuf", type=int, default=2, help="distinct input batches cycled through")
+    ap.add_argument("--channel", type=int, default=0, help="0 = AWGN, 1 = static 2-path + AWGN (BASELINE.json configs[3])")
+    ap.add_argument("--ldpc-only", action="store_true",
+                    help="BASELINE.json configs[4]: decoder-only soak on noise-only LLRs (every codeword runs --iters iterations)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -162,9 +165,15 @@ def main():
     for b in range(nbuf):
         lo, _ = frame_range(rank, world, F * world)
         frame0 = b * F * world + lo
+        if args.ldpc_only:
+            # noise-only LLRs (no codeword underneath): llr = 2y/sigma^2 with y ~ N(0, sigma^2), sigma = 1
+            g = torch.Generator(device=dev)
+            g.manual_seed(SEED + frame0)
+            bufs.append(2.0 * torch.randn((F, rx.N), generator=g, dtype=torch.float32, device=dev))
+            continue
         bb = torch.empty((F, rx.frame_samples, 2), dtype=torch.float64, device=dev)
         pl = torch.empty((F, rx.payload_stride), dtype=torch.uint8, device=dev)
-        rx.txgen_dev(SEED, frame0, F, noise_amp, bb.data_ptr(), pl.data_ptr(), stream=stream)
+        rx.txgen_dev(SEED, frame0, F, noise_amp, bb.data_ptr(), pl.data_ptr(), channel=args.channel, stream=stream)
         bufs.append(bb)
         sent.append(pl)
     payload = torch.empty((F, rx.payload_stride), dtype=torch.uint8, device=dev)
@@ -175,7 +184,10 @@ def main():
     decoded_acc = torch.zeros((), dtype=torch.int64, device=dev)
 
     def step(i):
-        rx.receive_dev(bufs[i % nbuf].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
+        if args.ldpc_only:
+            rx.ldpc_decode_dev(bufs[i % nbuf].data_ptr(), F, d_payload=payload.data_ptr(), d_stats=stats.data_ptr(), stream=stream)
+        else:
+            rx.receive_dev(bufs[i % nbuf].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
         # iterations actually executed (max+1 means "never converged" after max iterations)
         iters_acc.add_(stats[:, 0].clamp(max=args.iters).sum())
         decoded_acc.add_(stats[:, 3].sum())
@@ -224,14 +236,18 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters),
+            "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (rx.K, args.iters)) if args.ldpc_only else
+                      ("RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters)),
             "value": frames_total / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.decoder == "spa" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: %d mode-%d OFDM frames per GPU per step through AWGN at Es/N0 %+.1f dB, "
-                                   "%s variant, decoder=%s, max %d iterations" % (F, args.cfg, args.esn0, args.variant, args.decoder, args.iters),
+            "config": {"workload": ("BASELINE.json configs[4]-style decoder-only soak: %d rate-%d/1600 codewords per GPU per step, noise-only LLRs, "
+                                    "decoder=%s, max %d iterations" % (F, rx.K, args.decoder, args.iters)) if args.ldpc_only else
+                                   ("BASELINE.json configs[1]: %d mode-%d OFDM frames per GPU per step through %s at Es/N0 %+.1f dB, "
+                                    "%s variant, decoder=%s, max %d iterations" % (F, args.cfg, "2-path+AWGN" if args.channel else "AWGN",
+                                                                                   args.esn0, args.variant, args.decoder, args.iters)),
                        "frames_per_step_per_gpu": F, "cfg": args.cfg, "esn0_db": args.esn0, "decoder": args.decoder,
                        "parallelism": "frame-sharded x%d, no collectives" % world},
             "ldpc_iters_per_s": iters_total / dt,
@@ -244,7 +260,7 @@ def main():
                          "bytes_per_codeword_iteration": b_iter,
                          "note": "algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are LDS-resident so real HBM traffic is far lower"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.ldpc_only:
             cores = usable_cores()
             S = min(F, args.cpu_sample_per_core * cores)
             last = (args.steps - 1) % nbuf

@@ -298,3 +298,70 @@ def test_bench_two_ranks_on_one_gpu():
     assert j["decoded_fraction"] > 0.97            # both ranks' frames decode (disjoint frame ranges, same seed)
     assert abs(j["value"] - 2 * 256 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-6 * j["value"]
     assert "roofline" in j and "cpu_baseline" not in j
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 12])
+def test_decoder_only_all_eight_rates_bpsk_llrs(cfg):
+    """every LDPC rate with BPSK LLRs llr = 2y/sigma^2 around the waterfall, so that the
+    batch mixes early exits, late convergence and failures; all-zero codeword + noise (linear code)."""
+    orc = Oracle(cfg, 50)
+    rng = np.random.default_rng(100 + cfg)
+    rate = orc.K / 1600.0
+    F = 24
+    # Es/N0 for BPSK ~ a bit above capacity for the rate; spread over a few tenths of a dB
+    base_db = {100: -9.5, 200: -7.0, 300: -5.3, 400: -4.0, 500: -2.9, 600: -1.9, 800: -0.2, 1400: 5.6}[orc.K]
+    llr = np.zeros((F, 1600), np.float32)
+    for f in range(F):
+        snr = 10 ** ((base_db + 0.25 * (f % 8)) / 10)
+        sigma = np.sqrt(1 / (2 * snr))
+        y = 1.0 + sigma * rng.standard_normal(1600)
+        llr[f] = (2 * y / sigma ** 2).astype(np.float32)
+    rx = _rx(cfg, max_batch=F)
+    bits, iters = rx.ldpc_decode(llr)
+    conv = 0
+    for f in range(F):
+        rb, ri = orc.ldpc_decode(llr[f])
+        assert iters[f] == ri, (cfg, f, iters[f], ri)
+        assert np.array_equal(bits[f], rb.astype(np.uint8)), (cfg, f)
+        conv += ri <= 50
+    assert 0 < conv, "test SNRs should produce some converged frames"
+    assert rate > 0
+
+
+@pytest.mark.parametrize("F", [1, 3, 63, 65, 257])
+def test_ragged_batch_sizes(F):
+    cfg = 9
+    orc = Oracle(cfg, 50)
+    bb, payloads = _frames(orc, [OPERATING_ESN0[cfg] + (i % 3) for i in range(F)], seed=4242)
+    rx = _rx(cfg, max_batch=300)
+    out = rx.receive(bb)
+    for f in sorted(set([0, F // 2, F - 1])):
+        ref = orc.rx(bb[f], FLAGS_RECEIVE_BYTE)
+        assert out["stats"]["iterations_done"][f] == ref["iterations"]
+        assert np.array_equal(out["payload"][f], ref["bytes"].astype(np.uint8))
+    assert (out["stats"]["message_decoded"] == 1).mean() > 0.9
+
+
+def test_descrambler_crc_and_stats_fields():
+    """bit_energy_dispersal / bit_to_byte / CRC16 / all_zeros / SNR against the oracle for decoded, failed and
+    all-zero outcomes (telecom_system.cc:1313-1372)."""
+    cfg = 8
+    orc = Oracle(cfg, 50)
+    zeros = np.zeros(orc.payload_bytes, np.int32)
+    frames = [orc.gen_frame(1, 1, noise_amp_for(6.0))[0], orc.gen_frame(1, 2, noise_amp_for(-15.0))[0]]
+    # a frame carrying the all-zero PAYLOAD still has a non-zero CRC; the all_zeros flag needs every byte zero
+    bits0 = orc.payload_to_bits(zeros)
+    frames.append(orc.channel(orc.tx(bits0, 1), 5, 5, noise_amp_for(20.0)))
+    bb = np.stack(frames)
+    rx = _rx(cfg, max_batch=4)
+    out = rx.receive(bb)
+    for f in range(3):
+        ref = orc.rx(bb[f], FLAGS_RECEIVE_BYTE)
+        st = out["stats"][f]
+        assert (st["iterations_done"], st["crc"], st["all_zeros"]) == (ref["iterations"], ref["crc"], ref["all_zeros"])
+        decoded = not (ref["all_zeros"] or ref["crc"] != 0)
+        assert st["message_decoded"] == int(decoded)
+        if not decoded:
+            assert abs(st["snr_db"] + 99.9) < 1e-4
+        else:
+            assert 0 < st["snr_db"] < 40
