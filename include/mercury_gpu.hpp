@@ -1,0 +1,157 @@
+// mercury_gpu.hpp — C++ host-side mirror of the reference's physical-layer RX surface, header-only,
+// over the C-ABI of mercury_gpu.h.  Same names, argument meaning and failure signalling as the
+// reference classes so that source/physical_layer/telecom_system.cc can call it unchanged:
+//
+//   mgpu::cl_ldpc          <->  class cl_ldpc            (include/physical_layer/ldpc.h:32-93)
+//        N, P, K, rate, framesize, standard, decoding_algorithm, GBF_eta, nIteration_max,
+//        init(), deinit(), int decode(const float* data, int* decoded_data)
+//   mgpu::cl_rx_phy        <->  the RX members of class cl_telecom_system
+//                                (include/physical_layer/telecom_system.h:85-198)
+//        load_configuration(int)              telecom_system.cc:2487
+//        get_frame_size_bytes()/bits()        telecom_system.cc:332-340
+//        receive_frame(baseband, out)         the per-frame span of receive_byte, telecom_system.cc:1132-1345
+//        receive_batch(...)                   the same over F frames (what RX_SHM would batch)
+//   mgpu::st_receive_stats <->  struct st_receive_stats  (telecom_system.h:63-82; fields this path produces)
+//
+// Like the reference, failure to decode is reported through the stats (iterations_done > max-1,
+// crc != 0, all_zeros, message_decoded == NO, SNR == -99.9); unlike the reference nothing exit()s:
+// set-up errors throw std::runtime_error carrying mgpu_last_error().
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mercury_gpu.h"
+
+namespace mgpu {
+
+enum { GBF = 0, SPA = 1, MINSUM = 2 };   // physical_defines.h:44-45 (+ the fp32 variant)
+enum { NO = 0, YES = 1 };
+
+struct st_receive_stats {
+    int iterations_done = -1;
+    int message_decoded = NO;
+    double SNR = -99.9;
+    int crc = 0;
+    int all_zeros = NO;
+    float variance = 0;
+};
+
+namespace detail {
+inline void check(int rc, mgpu_ctx* ctx, const char* what) {
+    if (rc != MGPU_OK) throw std::runtime_error(std::string(what) + ": " + mgpu_last_error(ctx));
+}
+inline st_receive_stats convert(const mgpu_frame_stats& s) {
+    st_receive_stats r;
+    r.iterations_done = s.iterations_done;
+    r.message_decoded = s.message_decoded ? YES : NO;
+    r.SNR = s.message_decoded ? double(s.snr_db) : -99.9;
+    r.crc = s.crc;
+    r.all_zeros = s.all_zeros ? YES : NO;
+    r.variance = s.variance;
+    return r;
+}
+}  // namespace detail
+
+// ---- cl_ldpc --------------------------------------------------------------------------------
+class cl_ldpc {
+public:
+    int N = 0, P = 0, K = 0;
+    int standard = 0;                 // MERCURY
+    int framesize = 1600;             // MERCURY_NORMAL
+    float rate = 0;
+    int decoding_algorithm = SPA;
+    float GBF_eta = 0.5f;
+    int nIteration_max = 50;
+    int print_nIteration = NO;
+    int device = 0;
+
+    ~cl_ldpc() { deinit(); }
+
+    // ldpc.cc:62-74: K = (int)((float)N*rate); the graph of that rate is selected (ldpc.cc:140-251)
+    void init() {
+        deinit();
+        N = framesize;
+        K = int(float(N) * rate);
+        P = N - K;
+        static const int rate_to_cfg[8][2] = {{100, 0}, {200, 1}, {300, 2}, {400, 3}, {500, 4}, {600, 5}, {800, 6}, {1400, 12}};
+        int cfg = -1;
+        for (auto& rc : rate_to_cfg) if (rc[0] == K) cfg = rc[1];
+        if (cfg < 0) throw std::runtime_error("cl_ldpc::init: wrong code rate");   // the reference exits here (ldpc.cc:246-249)
+        mgpu_config c{};
+        c.cfg = cfg; c.max_iters = nIteration_max; c.decoder = decoding_algorithm; c.agc = 1; c.variance_source = 1;
+        c.device = device; c.max_batch = 1;
+        detail::check(mgpu_create(&c, &ctx_), nullptr, "cl_ldpc::init");
+    }
+    void deinit() {
+        if (ctx_) mgpu_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+    // ldpc.h:90 — returns the number of iterations used; > nIteration_max means the word may be corrupt
+    int decode(const float* data, int* decoded_data) {
+        std::vector<uint8_t> bits(K);
+        int iters = 0;
+        detail::check(mgpu_ldpc_batch(ctx_, data, 1, bits.data(), &iters), ctx_, "cl_ldpc::decode");
+        for (int i = 0; i < K; ++i) decoded_data[i] = bits[i];
+        return iters;
+    }
+
+private:
+    mgpu_ctx* ctx_ = nullptr;
+};
+
+// ---- RX half of cl_telecom_system ---------------------------------------------------------------
+class cl_rx_phy {
+public:
+    int current_configuration = -1;   // CONFIG_NONE
+    int ldpc_nIteration_max = 50;     // cl_configuration_telecom_system default (physical_config.cc:74)
+    int ldpc_decoding_algorithm = SPA;
+    int max_batch = 1;
+    int device = 0;
+    st_receive_stats receive_stats;
+    mgpu_info info{};
+
+    ~cl_rx_phy() { if (ctx_) mgpu_destroy(ctx_); }
+
+    // telecom_system.cc:2487 — re-initialises everything the mode owns; a no-op for the current mode
+    void load_configuration(int configuration) {
+        if (configuration == current_configuration && ctx_) return;
+        if (configuration < 0 || configuration > 16) return;    // the reference returns silently too (:2494-2497)
+        if (ctx_) mgpu_destroy(ctx_);
+        ctx_ = nullptr;
+        mgpu_config c{};
+        c.cfg = configuration; c.max_iters = ldpc_nIteration_max; c.decoder = ldpc_decoding_algorithm;
+        c.agc = 1; c.variance_source = 1; c.device = device; c.max_batch = max_batch;
+        detail::check(mgpu_create(&c, &ctx_), nullptr, "load_configuration");
+        detail::check(mgpu_get_info(ctx_, &info), ctx_, "load_configuration");
+        current_configuration = configuration;
+    }
+    int get_frame_size_bytes() const { return info.payload_bytes; }          // telecom_system.cc:332-335
+    int get_frame_size_bits() const { return info.payload_bytes * 8; }
+
+    // One synchronised frame: `baseband` points at the first data symbol, i.e. what receive_byte passes to
+    // symbol_demod (&baseband_data[Nofdm*preamble_nSymb], telecom_system.cc:1137). `out` receives
+    // get_frame_size_bytes() ints, one byte each, like receive_byte's `int* out` (:1329-1332).
+    st_receive_stats receive_frame(const std::complex<double>* baseband, int* out) {
+        std::vector<uint8_t> bytes(info.payload_stride);
+        mgpu_frame_stats s{};
+        detail::check(mgpu_rx_batch(ctx_, reinterpret_cast<const double*>(baseband), 1, bytes.data(), &s, nullptr), ctx_, "receive_frame");
+        for (int i = 0; i < info.payload_bytes; ++i) out[i] = bytes[i];
+        receive_stats = detail::convert(s);
+        return receive_stats;
+    }
+    // F frames laid out back to back; payload: F x payload_stride bytes.
+    void receive_batch(const std::complex<double>* baseband, int F, uint8_t* payload, std::vector<st_receive_stats>& stats) {
+        std::vector<mgpu_frame_stats> s(F);
+        detail::check(mgpu_rx_batch(ctx_, reinterpret_cast<const double*>(baseband), F, payload, s.data(), nullptr), ctx_, "receive_batch");
+        stats.resize(F);
+        for (int f = 0; f < F; ++f) stats[f] = detail::convert(s[f]);
+    }
+
+private:
+    mgpu_ctx* ctx_ = nullptr;
+};
+
+}  // namespace mgpu

@@ -110,14 +110,8 @@ void ctx_alloc(mgpu_ctx* c) {
     d.bit_il = c->keep(upload(t.bit_il));
     d.cptr = c->keep(upload(t.graph.cptr));
     d.cvar = c->keep(upload(t.graph.cvar));
-    d.epack = c->keep(upload(t.graph.epack));
-    d.vptr = c->keep(upload(t.graph.vptr));
-    d.vedge = c->keep(upload(t.graph.vedge));
-    d.echk = c->keep(upload(t.graph.echk));
     d.spack = c->keep(upload(t.graph.spack));
     d.svar = c->keep(upload(t.graph.svar));
-    d.vslot = c->keep(upload(t.graph.vslot));
-    d.cinfo = c->keep(upload(t.graph.cinfo));
     d.vinfo = c->keep(upload(t.graph.vinfo));
     d.S = t.graph.S;
     d.M = t.M; d.bps = t.bps; d.K = t.K; d.P = t.P; d.N = t.N; d.E = t.graph.E;
@@ -133,8 +127,8 @@ void ctx_alloc(mgpu_ctx* c) {
             if ((t.cell_type[size_t(r) * t.Nc + q] != 0) != (((r - q) % 3 + 3) % 3 == 0)) d.regular_lattice = 0;
     d.minsum_alpha = c->cfg.minsum_alpha > 0 ? c->cfg.minsum_alpha : 0.8f;
     LdpcDev& l = c->ldev;
-    l.spack = d.spack; l.svar = d.svar; l.vptr = d.vptr; l.vslot = d.vslot; l.cinfo = d.cinfo; l.vinfo = d.vinfo; l.scrambler = d.scrambler;
-    l.cptr = d.cptr; l.cvar = d.cvar; l.vedge = d.vedge; l.echk = d.echk;
+    l.spack = d.spack; l.svar = d.svar; l.vinfo = d.vinfo; l.scrambler = d.scrambler;
+    l.cptr = d.cptr; l.cvar = d.cvar;
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
 

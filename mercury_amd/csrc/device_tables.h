@@ -17,17 +17,11 @@ struct MgpuDev {
     // generator
     const uint16_t* bit_il;        // [nBits]
     // LDPC graph
-    const uint32_t* cptr;          // [P+1]
-    const uint16_t* cvar;          // [E]
-    const uint32_t* epack;         // [E]
-    const uint32_t* vptr;          // [N+1]
-    const uint16_t* vedge;         // [E]   edge of (variable, slot)
-    const uint16_t* echk;          // [E]   check of edge e
+    const uint32_t* cptr;          // [P+1] check-major edge list in the reference's row order
+    const uint16_t* cvar;          // [E]   variable of edge e
     const uint32_t* spack;         // [S]   wave-private padded layout (see tables.hpp)
     const uint16_t* svar;          // [S]
-    const uint16_t* vslot;         // [E]
-    const uint32_t* cinfo;         // [P]
-    const uint32_t* vinfo;         // [N]
+    const uint32_t* vinfo;         // [N][6]
     int S;
     int M, bps, K, P, N, E;
     int Nsymb, G, nData, nBits, nPilots, nVirtual, nReal;
@@ -42,10 +36,9 @@ struct MgpuDev {
 // Slim argument block for the decoder kernels: only what they touch, so the kernarg does not
 // inflate the SGPR allocation (occupancy on gfx950 drops below 8 waves/SIMD above 80 SGPRs).
 struct LdpcDev {
-    const uint32_t* spack; const uint16_t* svar; const uint32_t* vptr; const uint16_t* vslot; const uint32_t* cinfo;
-    const uint32_t* vinfo;
+    const uint32_t* spack; const uint16_t* svar; const uint32_t* vinfo;   // sum-product / min-sum layout
+    const uint32_t* cptr; const uint16_t* cvar;                           // plain check-major lists (GBF)
     const uint8_t* scrambler;
-    const uint32_t* cptr; const uint16_t* cvar; const uint16_t* vedge; const uint16_t* echk;
     int S, N, P, K, E, nReal, payload_stride, max_iters;
     float minsum_alpha;
 };

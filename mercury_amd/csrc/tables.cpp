@@ -125,15 +125,13 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         const uint8_t* cflat = cdeg + P;
         const uint8_t* vdeg = cflat + 2 * size_t(E);
         const uint8_t* vflat = vdeg + N;
-        g.cptr.resize(P + 1); g.cvar.resize(E); g.epack.resize(E); g.vptr.resize(N + 1); g.vedge.resize(E); g.eslot.resize(E); g.echk.resize(E);
+        g.cptr.resize(P + 1); g.cvar.resize(E); g.vptr.resize(N + 1); g.vedge.resize(E);
         uint32_t e = 0;
         for (uint32_t c = 0; c < P; ++c) {
             g.cptr[c] = e;
             for (uint32_t j = 0; j < cdeg[c]; ++j, ++e) {
                 uint16_t v; std::memcpy(&v, cflat + 2 * size_t(e), 2);
                 g.cvar[e] = v;
-                g.echk[e] = uint16_t(c);
-                g.epack[e] = g.cptr[c] | (uint32_t(cdeg[c]) << 16) | (j << 24);
             }
         }
         g.cptr[P] = e;
@@ -148,7 +146,6 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
                     if (g.cvar[q] == v) { found = q; break; }
                 if (found == UINT32_MAX) throw std::runtime_error("LDPC table blob: C/V adjacency mismatch");
                 g.vedge[s] = uint16_t(found);
-                g.eslot[found] = uint16_t(s);
             }
         }
         g.vptr[N] = s;
@@ -172,14 +169,11 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         if (g.S >= 8192) throw std::runtime_error("padded edge count exceeds the 13-bit slot field");
         g.spack.assign(g.S, 0u);
         g.svar.assign(g.S, 0);
-        g.vslot.resize(E);
-        g.cinfo.clear();
         std::vector<uint32_t> slot_of_edge(E);
         for (size_t b = 0; b < members.size(); ++b) {
             uint32_t p = uint32_t(b) * 64;
             for (uint32_t c : members[b]) {
                 const uint32_t cs = p, d = cdeg[c];
-                g.cinfo.push_back(cs | (d << 16));
                 for (uint32_t j = 0; j < d; ++j, ++p) {
                     const uint32_t eo = g.cptr[c] + j;
                     g.spack[p] = cs | (d << 13) | (j << 19) | 0x80000000u;
@@ -193,14 +187,12 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         for (uint32_t v = 0; v < N; ++v) vorder[v] = v;
         std::stable_sort(vorder.begin(), vorder.end(), [&](uint32_t a, uint32_t b) { return vdeg[a] > vdeg[b]; });
         g.vinfo.assign(size_t(N) * 6, 0u);   // per variable: v | deg<<11, then 10 u16 slot indices in 5 words
-        uint32_t w = 0;
         for (uint32_t i = 0; i < N; ++i) {
             const uint32_t v = vorder[i], d = vdeg[v];
             if (d > 9) throw std::runtime_error("variable degree exceeds the unrolled update");
             g.vinfo[size_t(i) * 6] = v | (d << 11);
             for (uint32_t j = 0; j < d; ++j) {
                 const uint32_t slot = slot_of_edge[g.vedge[g.vptr[v] + j]];
-                g.vslot[w++] = uint16_t(slot);
                 g.vinfo[size_t(i) * 6 + 1 + j / 2] |= slot << (16 * (j & 1));
             }
         }

@@ -35,19 +35,14 @@ struct LdpcGraph {
     int K = 0, P = 0, N = 1600, E = 0, Cwidth = 0, Vwidth = 0;
     std::vector<uint32_t> cptr;    // [P+1] first edge of each check (edges are check-major, reference row order)
     std::vector<uint16_t> cvar;    // [E]   variable of edge e
-    std::vector<uint32_t> epack;   // [E]   check_start | deg<<16 | pos<<24
     std::vector<uint32_t> vptr;    // [N+1] first slot of each variable
     std::vector<uint16_t> vedge;   // [E]   edge index of (variable, slot) in the reference's slot order
-    std::vector<uint16_t> echk;    // [E]   check of edge e
-    std::vector<uint16_t> eslot;   // [E]   vptr[v]+slot for edge e (inverse of vedge)
     // wave-private layout for the sum-product kernel: whole checks bin-packed (first-fit decreasing)
     // into 64-slot bins so that one wavefront owns every edge of the checks it updates
     int S = 0;                     // padded slot count = 64 * bins
     std::vector<uint32_t> spack;   // [S] check_start_slot | deg<<13 | pos<<19 | valid<<31 (0 for padding)
     std::vector<uint16_t> svar;    // [S] variable of the slot's edge (0 for padding)
-    std::vector<uint16_t> vslot;   // [E] padded slot of (variable, slot j), variables in vinfo order, j in the reference's slot order
     std::vector<uint32_t> vinfo;   // [N][6] variable | deg<<11, then 10 u16 padded-slot indices; rows sorted by degree (descending)
-    std::vector<uint32_t> cinfo;   // [P] check_start_slot | deg<<16, in bin order
 };
 
 struct ModeTables {

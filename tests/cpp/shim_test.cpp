@@ -1,0 +1,71 @@
+// Host-language (C++) test of the drop-in boundary: drives include/mercury_gpu.hpp the way
+// telecom_system.cc drives the reference classes, on inputs written by tests/test_cpp_shim.py, and
+// writes the results back for comparison with the CPU oracle.
+//   usage: shim_test <cfg> <nframes> <baseband.bin> <llr.bin> <out.bin>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "mercury_gpu.hpp"
+
+template <typename T>
+static std::vector<T> slurp(const char* path, size_t n) {
+    std::vector<T> v(n);
+    FILE* f = fopen(path, "rb");
+    if (!f || fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "cannot read %s\n", path); exit(2); }
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 6) return 2;
+    const int cfg = atoi(argv[1]), F = atoi(argv[2]);
+    try {
+        mgpu::cl_rx_phy phy;
+        phy.max_batch = F;
+        phy.load_configuration(cfg);                     // telecom_system.cc:824 / :2487
+        phy.load_configuration(cfg);                     // second call is a no-op, as in the reference (:2489-2492)
+        const int fs = phy.info.frame_samples, pb = phy.get_frame_size_bytes();
+        auto bb = slurp<std::complex<double>>(argv[3], size_t(F) * fs);
+        auto llr = slurp<float>(argv[4], size_t(F) * 1600);
+        FILE* out = fopen(argv[5], "wb");
+        // 1) frame at a time, the way receive_byte is called
+        for (int f = 0; f < F; ++f) {
+            std::vector<int> bytes(pb);
+            mgpu::st_receive_stats st = phy.receive_frame(&bb[size_t(f) * fs], bytes.data());
+            int rec[4] = {st.iterations_done, st.crc, st.all_zeros, st.message_decoded};
+            fwrite(rec, sizeof(int), 4, out);
+            fwrite(bytes.data(), sizeof(int), pb, out);
+        }
+        // 2) one batched call
+        std::vector<uint8_t> payload(size_t(F) * phy.info.payload_stride);
+        std::vector<mgpu::st_receive_stats> stats;
+        phy.receive_batch(bb.data(), F, payload.data(), stats);
+        for (int f = 0; f < F; ++f) {
+            int rec[4] = {stats[f].iterations_done, stats[f].crc, stats[f].all_zeros, stats[f].message_decoded};
+            fwrite(rec, sizeof(int), 4, out);
+        }
+        fwrite(payload.data(), 1, payload.size(), out);
+        // 3) cl_ldpc alone, exactly the reference's call sequence (ldpc.init(); ldpc.decode(llr, bits))
+        mgpu::cl_ldpc ldpc;
+        ldpc.rate = float(phy.info.K) / 1600.0f;
+        ldpc.nIteration_max = 50;
+        ldpc.init();
+        for (int f = 0; f < F; ++f) {
+            std::vector<int> bits(ldpc.K);
+            int it = ldpc.decode(&llr[size_t(f) * 1600], bits.data());
+            fwrite(&it, sizeof(int), 1, out);
+            fwrite(bits.data(), sizeof(int), ldpc.K, out);
+        }
+        fclose(out);
+        // 4) error behaviour: a wrong code rate throws instead of exit(1)
+        mgpu::cl_ldpc bad;
+        bad.rate = 7.0f / 16.0f;
+        try { bad.init(); return 3; } catch (const std::runtime_error&) {}
+    } catch (const std::exception& e) {
+        fprintf(stderr, "shim_test: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
