@@ -258,7 +258,9 @@ def main():
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
                          "bytes_per_codeword_iteration": b_iter,
-                         "note": "algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are LDS-resident so real HBM traffic is far lower"},
+                         "note": "algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are LDS-resident so real HBM "
+                                 "traffic is far lower; the decoder is VALU-issue bound (profiles/r01_pmc_sq_*.csv: SQ_ACTIVE_INST_VALU "
+                                 "~99% of SIMD cycles for spa, fp64), not HBM bound"},
         }
         if world == 1 and not args.no_cpu_baseline and not args.ldpc_only:
             cores = usable_cores()
@@ -273,6 +275,12 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload[:S].cpu().numpy(), stats[:S].cpu().numpy())
                 line["cpu_baseline"]["note"] = "CPU runs the reference's sum-product decoder; mismatches vs %s are expected on non-converged frames" % args.decoder
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            # the same call through the host-buffer entry point (pageable host memory -> H2D, kernels, D2H): never `value`
+            Sh = min(S, 1024)
+            rx.receive(bb_h[:Sh])
+            t0 = time.perf_counter()
+            rx.receive(bb_h[:Sh])
+            line["pcie_inclusive_frames_per_s"] = Sh / (time.perf_counter() - t0)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
