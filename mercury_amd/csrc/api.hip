@@ -24,7 +24,9 @@ extern "C" size_t mgpu_gbf_lds_bytes(int N);
 extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
 extern "C" size_t mgpu_txgen_lds_bytes(int G);
 
-extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, MgpuTapsDev);
+extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
+extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
+extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
 #define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
@@ -74,6 +76,7 @@ struct mgpu_ctx {
     uint8_t* d_payload = nullptr;
     MgpuStatsDev* d_stats = nullptr;
     uint8_t* d_bits = nullptr;
+    double* d_eqdata = nullptr;     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
     int* d_iters = nullptr;
     hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
     static constexpr int kEvRing = 64;
@@ -108,6 +111,8 @@ void ctx_alloc(mgpu_ctx* c) {
     d.ls_weight = c->keep(upload(t.ls_weight));
     d.scrambler = c->keep(upload(t.scrambler));
     d.bit_il = c->keep(upload(t.bit_il));
+    d.tf_inv = c->keep(upload(t.tf_inv));
+    d.data_cell = c->keep(upload(t.data_cell));
     d.cptr = c->keep(upload(t.graph.cptr));
     d.cvar = c->keep(upload(t.graph.cvar));
     d.spack = c->keep(upload(t.graph.spack));
@@ -140,6 +145,7 @@ void ctx_alloc(mgpu_ctx* c) {
     HIPCK(hipMalloc(&c->d_stats, B * sizeof(MgpuStatsDev)));
     HIPCK(hipMalloc(&c->d_bits, B * t.K));
     HIPCK(hipMalloc(&c->d_iters, B * sizeof(int)));
+    if (t.estimator == MGPU_EST_ZF) HIPCK(hipMalloc(&c->d_eqdata, B * t.nData * 16));
     HIPCK(hipStreamCreate(&c->stream));
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));
 
@@ -184,9 +190,17 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
                      const MgpuTapsDev& taps, hipStream_t s) {
     const int slot = c->ev_count % mgpu_ctx::kEvRing;
     if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][0], s)); c->ev_fe[slot] = true; }
-    hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(F), dim3(512), c->lds_fe, s, c->dev, d_bb, F, d_llr, d_var, d_snrvar, taps);
+    hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(F), dim3(512), c->lds_fe, s, c->dev, d_bb, F, d_llr, d_var, d_snrvar, c->d_eqdata, taps);
     HIPCK(hipGetLastError());
     if (c->timing) HIPCK(hipEventRecord(c->ev[slot][1], s));
+}
+
+// zero-forcing modes: SNR from the re-encoded decision (telecom_system.cc:1374-1396); needs the payload and
+// the de-framed equalised symbols the front-end kept.
+void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s) {
+    if (c->tab.estimator != MGPU_EST_ZF || !d_payload || !d_stats) return;
+    hipLaunchKernelGGL(mgpu_zf_snr_kernel, dim3(F), dim3(256), mgpu_zfsnr_lds_bytes(c->tab.nData), s, c->dev, d_payload, c->d_eqdata, F, d_stats);
+    HIPCK(hipGetLastError());
 }
 
 void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int* d_iters, uint8_t* d_payload,
@@ -277,7 +291,7 @@ void mgpu_destroy(mgpu_ctx* c) {
     if (!c) return;
     for (void* p : c->owned) (void)hipFree(p);
     (void)hipFree(c->d_baseband); (void)hipFree(c->d_llr); (void)hipFree(c->d_variance); (void)hipFree(c->d_snrvar);
-    (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters);
+    (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters); (void)hipFree(c->d_eqdata);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto& q : c->ev) for (auto& e : q) if (e) (void)hipEventDestroy(e);
     delete c;
@@ -365,6 +379,7 @@ int mgpu_rx_batch_dev(mgpu_ctx* c, const void* d_bb, int F, void* d_payload, voi
         launch_frontend(c, static_cast<const double*>(d_bb), F, llr, c->d_variance, c->d_snrvar, taps, s);
         launch_decoder(c, llr, F, nullptr, nullptr, static_cast<uint8_t*>(d_payload), static_cast<MgpuStatsDev*>(d_stats),
                        c->d_variance, c->d_snrvar, s);
+        launch_zf_snr(c, F, static_cast<uint8_t*>(d_payload), static_cast<MgpuStatsDev*>(d_stats), s);
     });
 }
 
@@ -426,6 +441,7 @@ int mgpu_rx_batch_taps(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, m
         }
         launch_frontend(c, c->d_baseband, F, c->d_llr, c->d_variance, c->d_snrvar, dt, s);
         launch_decoder(c, c->d_llr, F, nullptr, nullptr, c->d_payload, c->d_stats, c->d_variance, c->d_snrvar, s);
+        launch_zf_snr(c, F, c->d_payload, c->d_stats, s);
         if (payload) HIPCK(hipMemcpyAsync(payload, c->d_payload, size_t(F) * t.payload_stride, hipMemcpyDeviceToHost, s));
         if (stats) HIPCK(hipMemcpyAsync(stats, c->d_stats, size_t(F) * sizeof(MgpuStatsDev), hipMemcpyDeviceToHost, s));
         if (taps) {

@@ -16,6 +16,8 @@ struct MgpuDev {
     const uint8_t* scrambler;      // [1600]
     // generator
     const uint16_t* bit_il;        // [nBits]
+    const uint16_t* tf_inv;        // [nData] modulated-symbol index landing at de-framed position i
+    const uint16_t* data_cell;     // [nData] grid cell of de-framed position i
     // LDPC graph
     const uint32_t* cptr;          // [P+1] check-major edge list in the reference's row order
     const uint16_t* cvar;          // [E]   variable of edge e

@@ -78,7 +78,7 @@ extern "C" size_t mgpu_frontend_lds_bytes(int G) {
 
 extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
-    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, MgpuTapsDev taps) {
+    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int G = T.G, Nc = 50, Ns = T.Nsymb;
     c2* grid = reinterpret_cast<c2*>(smem);
@@ -251,6 +251,8 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     __syncthreads();
     c2* eq = H;
     if (taps.eq) for (int c = tid; c < G; c += FE_THREADS) { taps.eq[(size_t(f) * G + c) * 2] = eq[c].re; taps.eq[(size_t(f) * G + c) * 2 + 1] = eq[c].im; }
+    if (eqdata_out)   // de-framed equalised symbols, kept for the zero-forcing modes' post-decode SNR (ofdm_deframed_data)
+        for (int i = tid; i < T.nData; i += FE_THREADS) { const c2 e = eq[T.data_cell[i]]; eqdata_out[(size_t(f) * T.nData + i) * 2] = e.re; eqdata_out[(size_t(f) * T.nData + i) * 2 + 1] = e.im; }
     if (T.var_eq) {
         for (int p = tid; p < T.nPilots; p += FE_THREADS) {
             const int c = T.pilot_cell[p];

@@ -268,7 +268,9 @@ ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
     };
     const std::vector<int> tf = deint_src(t.nData, t.tf_blk);
     t.sym_src.resize(t.nData);
-    for (int k = 0; k < t.nData; ++k) t.sym_src[k] = data_cell[tf[k]];
+    t.tf_inv.resize(t.nData);
+    for (int k = 0; k < t.nData; ++k) { t.sym_src[k] = data_cell[tf[k]]; t.tf_inv[tf[k]] = uint16_t(k); }
+    t.data_cell = data_cell;
     const std::vector<int> bd = deint_src(t.nBits, t.bit_blk);
     // decoder input p <- de-interleaved index: telecom_system.cc:1300-1308
     t.llr_src.resize(t.N);

@@ -62,6 +62,8 @@ struct ModeTables {
     std::vector<double> ls_weight;          // [lsw*lsw+1] boost/sum_n(boost^2) per window population n
     // TX-side permutations for the synthetic generator
     std::vector<uint16_t> bit_il;           // [nBits] interleaved position <- encoded index: out[bit_il[i]] = in[i]
+    std::vector<uint16_t> tf_inv;           // [nData] symbol k with tf-deinterleave source i (inverse of the RX gather)
+    std::vector<uint16_t> data_cell;        // [nData] grid cell of de-framed position i (deframer order)
     std::vector<uint16_t> sym_cell;         // [nData] grid cell of modulated symbol k (tf-interleave + framer)
     LdpcGraph graph;
 };

@@ -641,7 +641,7 @@ void morc_rx(morc* o, const double* baseband_c128, int flags, morc_rx_out* out) 
     for (int i = o->P - 1; i >= 0; i--) dei[i + o->nReal + o->nVirtual] = dei[i + o->nReal];
     for (int i = 0; i < o->nVirtual; i++) dei[o->nReal + i] = dei[i];
     if (out->llr_ldpc) memcpy(out->llr_ldpc, dei, sizeof(float) * N_MAX);
-    out->iterations = -1; out->crc = -1; out->all_zeros = -1;
+    out->iterations = -1; out->crc = -1; out->all_zeros = -1; out->snr_db = -99.9;
     if (flags & MORC_FLAG_NO_LDPC) return;
     int hd[N_MAX], bytes[N_MAX];
     out->iterations = decode_spa(o, dei, hd);
@@ -657,6 +657,41 @@ void morc_rx(morc* o, const double* baseband_c128, int flags, morc_rx_out* out) 
     out->crc = 0;
     if (!out->all_zeros) out->crc = morc_crc16(bytes, nb / 8);
     if (out->bytes) memcpy(out->bytes, bytes, sizeof(int) * ((nb + 7) / 8));
+    /* receive_stats.SNR — telecom_system.cc:1343-1396 */
+    if (out->all_zeros || out->crc != 0) { out->snr_db = -99.9; return; }
+    if (o->estimator == EST_LS) {
+        if (o->amp_restore) {       /* measure_variance(equalized_data_without_amplitude_restoration), into the float */
+            double v2 = 0; int n2 = 0;
+            for (int c = 0; c < G; c++) if (o->type[c] == PILOT) {
+                cd d = o->eq_noamp[c] - o->pilot_grid[c];
+                v2 += creal(d) * creal(d) + cimag(d) * cimag(d); n2++;
+            }
+            v2 /= (double)n2;
+            variance = v2;
+        }
+        out->snr_db = 10.0 * log10(1.0 / variance);
+    } else {                        /* ZF: re-encode, re-map, measure_SNR ofdm.cc:1622-1635 */
+        int db[N_MAX], enc[N_MAX], bi[N_MAX];
+        for (int i = 0; i < o->nReal; i++) db[i] = hd[i] ^ o->scrambler[i];    /* hd was de-scrambled in place above */
+        for (int i = 0; i < o->nVirtual; i++) db[o->nReal + i] = db[i];
+        ldpc_encode(o, db, enc);
+        for (int i = 0; i < o->P; i++) enc[o->nReal + i] = enc[i + o->K];
+        il_int(enc, bi, o->nBits, o->bit_blk, 0);
+        for (int i = 0; i < o->nBits; i += o->bps) {
+            unsigned loc = 0;
+            for (int j = 0; j < o->bps; j++) { loc += bi[i + j]; loc <<= 1; }
+            loc >>= 1;
+            o->modulated[i / o->bps] = o->constellation[loc];
+        }
+        il_cd(o->modulated, o->tfi, o->nData, o->tf_blk, 0);
+        double v2 = 0;
+        for (int i = 0; i < o->nData; i++) {
+            cd d = o->tfi[i] - o->deframed[i];
+            v2 += creal(d) * creal(d) + cimag(d) * cimag(d);
+        }
+        v2 /= o->nData;
+        out->snr_db = -10.0 * log10(v2);
+    }
 }
 
 /* the host libm functions exactly as decode_SPA calls them (ldpc_decoder_SPA.cc:145,156) */

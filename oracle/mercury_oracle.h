@@ -51,6 +51,7 @@ typedef struct morc_rx_out {
     int iterations;
     int crc;
     int all_zeros;
+    double snr_db;    /* receive_stats.SNR per telecom_system.cc:1343-1396; -99.9 when not decoded */
 } morc_rx_out;
 
 #define MORC_FLAG_AGC 1        /* receive_byte variant: automatic_gain_control first */

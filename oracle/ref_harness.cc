@@ -322,6 +322,7 @@ struct mref_rx_out {
     int iterations;
     int crc;
     int all_zeros;
+    double snr_db;       // receive_stats.SNR as telecom_system.cc:1343-1396 sets it (-99.9 when not decoded)
 };
 
 // flags: bit0 = AGC (receive_byte variant, telecom_system.cc:1197)
@@ -386,7 +387,7 @@ void mref_rx(void* h, const double* baseband_c128, int flags, mref_rx_out* o) {
         r->deinterleaved[i + r->nReal + r->nVirtual] = r->deinterleaved[i + r->nReal];
     for (int i = 0; i < r->nVirtual; i++) r->deinterleaved[r->nReal + i] = r->deinterleaved[i];
     if (o->llr_ldpc) memcpy(o->llr_ldpc, r->deinterleaved, sizeof(float) * N_MAX);
-    o->iterations = -1; o->crc = -1; o->all_zeros = -1;
+    o->iterations = -1; o->crc = -1; o->all_zeros = -1; o->snr_db = -99.9;
     if (flags & 4) return;
     // telecom_system.cc:198 / :1310
     o->iterations = r->ldpc.decode(r->deinterleaved, r->hd_bits);
@@ -400,6 +401,21 @@ void mref_rx(void* h, const double* baseband_c128, int flags, mref_rx_out* o) {
     o->crc = 0;
     if (o->all_zeros == NO) o->crc = CRC16_MODBUS_RTU_calc(r->hd_bytes, r->nReal / 8);
     if (o->bytes) memcpy(o->bytes, r->hd_bytes, sizeof(int) * ((r->nReal + 7) / 8));
+    // telecom_system.cc:1343-1396 (outer_code == CRC16_MODBUS_RTU)
+    if (o->all_zeros == YES || o->crc != 0) { o->snr_db = -99.9; return; }
+    if (ofdm.channel_estimator == LEAST_SQUARE) {
+        if (ofdm.channel_estimator_amplitude_restoration == YES) variance = ofdm.measure_variance(r->eq_noamp);
+        o->snr_db = 10.0 * log10(1.0 / variance);
+    } else {
+        bit_energy_dispersal(r->hd_bits, r->scrambler, r->hd_bits, r->nReal);
+        for (int i = 0; i < r->nVirtual; i++) r->hd_bits[r->nReal + i] = r->hd_bits[i];
+        r->ldpc.encode(r->hd_bits, r->encoded);
+        for (int i = 0; i < r->ldpc.P; i++) r->encoded[r->nReal + i] = r->encoded[i + r->ldpc.K];
+        interleaver(r->encoded, r->bit_inter, r->nBits, r->bit_blk);
+        r->psk.mod(r->bit_inter, r->nBits, r->modulated);
+        interleaver(r->modulated, r->tf_inter, r->nData, r->tf_blk);
+        o->snr_db = ofdm.measure_SNR(r->deframed, r->tf_inter, r->nData);   // amplitude restoration is off for the ZF modes
+    }
 }
 
 // cl_ldpc::decode alone (ldpc.h:90). alg: 1 = SPA (default), 0 = GBF.

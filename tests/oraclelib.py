@@ -34,7 +34,8 @@ class RxOut(C.Structure):
                 ("syms", C.c_void_p), ("llr_demod", C.c_void_p), ("llr_ldpc", C.c_void_p),
                 ("bits", C.c_void_p), ("bytes", C.c_void_p),
                 ("variance", C.c_double), ("variance_f", C.c_float), ("agc_gain", C.c_double),
-                ("mean_H", C.c_double), ("iterations", C.c_int), ("crc", C.c_int), ("all_zeros", C.c_int)]
+                ("mean_H", C.c_double), ("iterations", C.c_int), ("crc", C.c_int), ("all_zeros", C.c_int),
+                ("snr_db", C.c_double)]
 
 
 def build_oracle():
@@ -121,7 +122,7 @@ class _Base:
             setattr(o, k, v.ctypes.data)
         self._fn("rx")(self.h, _p(bb), C.c_int(flags), C.byref(o))
         res = dict(bufs)
-        for k in ("variance", "variance_f", "agc_gain", "mean_H", "iterations", "crc", "all_zeros"):
+        for k in ("variance", "variance_f", "agc_gain", "mean_H", "iterations", "crc", "all_zeros", "snr_db"):
             res[k] = getattr(o, k)
         return res
 

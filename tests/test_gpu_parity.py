@@ -365,3 +365,19 @@ def test_descrambler_crc_and_stats_fields():
             assert abs(st["snr_db"] + 99.9) < 1e-4
         else:
             assert 0 < st["snr_db"] < 40
+
+
+@pytest.mark.parametrize("cfg,esn0", [(0, -6.0), (8, 4.0), (10, 8.0), (13, 12.0), (15, 40.0), (16, 40.0), (16, 24.0)])
+def test_receive_stats_snr_matches_reference_definition(cfg, esn0):
+    """receive_stats.SNR (telecom_system.cc:1343-1396): 10log10(1/variance) for the LS modes (variance of the
+    non-amplitude-restored equalisation for PSK), re-encode + measure_SNR for the zero-forcing modes,
+    -99.9 when the frame did not decode."""
+    orc = Oracle(cfg, 50)
+    bb, _ = _frames(orc, [esn0, esn0 + 1, -15.0], seed=31)
+    rx = _rx(cfg, max_batch=4)
+    out = rx.receive(bb)
+    for f in range(3):
+        ref = orc.rx(bb[f], FLAGS_RECEIVE_BYTE)
+        st = out["stats"][f]
+        assert st["message_decoded"] == int(not (ref["all_zeros"] or ref["crc"] != 0))
+        assert abs(float(st["snr_db"]) - ref["snr_db"]) <= 2e-5 * max(1.0, abs(ref["snr_db"])), (cfg, f, st["snr_db"], ref["snr_db"])
