@@ -130,6 +130,25 @@ int mgpu_ldpc_batch_dev(mgpu_ctx* ctx, const void* d_llr, int F, void* d_bits_op
 int mgpu_txgen_dev(mgpu_ctx* ctx, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel,
                    void* d_baseband_c128, void* d_payload_opt, void* stream);
 
+/* ---- synchroniser building blocks in front of the path, batched over W capture windows,
+ * host buffers, blocking. Sample rate 48 kHz and carrier amplitude sqrt(2) as in the reference
+ * (telecom_system.cc:69,1569); FIR designs as load_configuration makes them (physical_config.cc:90-98).
+ *
+ * mgpu_passband_to_baseband = cl_ofdm::passband_to_baseband (ofdm.cc:2316-2339): mixer, 33-tap FIR
+ *   (filter 0 = FIR_rx_time_sync, 1 = FIR_rx_data), decimation. Output k of window w is the filtered sample at
+ *   input index start[w] + k*decimation (start == NULL means 0), k < count; (start = NULL, count = in_size/decimation)
+ *   is the reference call, (start = delay, decimation = 4, count = frame samples) additionally fuses the
+ *   rational_resampler call of telecom_system.cc:1105 and filters only the samples that are kept.
+ * mgpu_time_sync_preamble = cl_ofdm::time_sync_preamble_with_metric (ofdm.cc:1846-1967), interpolation rate 4.
+ * mgpu_freq_sync = cl_ofdm::carrier_sampling_frequency_sync (Moose, ofdm.cc:540-595) on the preamble of each
+ *   window; `stride` = complex samples between windows; returns Hz (carrier_freq_width = bandwidth/Nc). */
+int mgpu_passband_to_baseband(mgpu_ctx* ctx, const double* passband /*[W][in_size]*/, int W, int in_size,
+                              const double* carrier_hz /*[W]*/, int filter, const int* start /*[W] or NULL*/, int count,
+                              int decimation, double* out_c128 /*[W][count][2]*/);
+int mgpu_time_sync_preamble(mgpu_ctx* ctx, const double* baseband_interp_c128 /*[W][size][2]*/, int W, int size, int step,
+                            int location_to_return, int nTrials_max, int* delay /*[W]*/, double* correlation /*[W] or NULL*/);
+int mgpu_freq_sync(mgpu_ctx* ctx, const double* baseband_c128 /*[W][stride][2]*/, int W, int stride, double* freq_offset_hz /*[W]*/);
+
 /* Kernel timing with HIP events recorded on the launch stream around each kernel.
  * mgpu_enable_timing(ctx,1) resets the counters; mgpu_kernel_ms_avg returns the average launch
  * duration in ms over the launches since then (at most the last 64): [0]=front-end kernel,

@@ -16,7 +16,7 @@ BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libmercury_gpu.so")
 TABLES = os.path.join(HERE, "data", "mercury_ldpc_tables.bin")
 
-HIP_SOURCES = ["api.hip", "frontend.hip", "ldpc.hip", "txgen.hip", "stats.hip"]
+HIP_SOURCES = ["api.hip", "frontend.hip", "ldpc.hip", "txgen.hip", "stats.hip", "sync.hip"]
 CXX_SOURCES = ["tables.cpp"]
 HEADERS = ["device_tables.h", "tables.hpp", "spa_math.h", os.path.join(ROOT, "include", "mercury_gpu.h")]
 

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <algorithm>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -27,6 +28,9 @@ extern "C" size_t mgpu_txgen_lds_bytes(int G);
 extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
 extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
+extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*);
+extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, int, int, int, int, int, double*);
+extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double, double*);
 #define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
@@ -76,7 +80,8 @@ struct mgpu_ctx {
     uint8_t* d_payload = nullptr;
     MgpuStatsDev* d_stats = nullptr;
     uint8_t* d_bits = nullptr;
-    double* d_eqdata = nullptr;     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
+    double* d_eqdata = nullptr;
+    double* d_fir[2] = {nullptr, nullptr};   // FIR_rx_time_sync, FIR_rx_data taps     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
     int* d_iters = nullptr;
     hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
     static constexpr int kEvRing = 64;
@@ -111,6 +116,8 @@ void ctx_alloc(mgpu_ctx* c) {
     d.ls_weight = c->keep(upload(t.ls_weight));
     d.scrambler = c->keep(upload(t.scrambler));
     d.bit_il = c->keep(upload(t.bit_il));
+    c->d_fir[0] = c->keep(upload(t.fir_time_sync));
+    c->d_fir[1] = c->keep(upload(t.fir_data));
     d.tf_inv = c->keep(upload(t.tf_inv));
     d.data_cell = c->keep(upload(t.data_cell));
     d.cptr = c->keep(upload(t.graph.cptr));
@@ -242,6 +249,20 @@ int guard(mgpu_ctx* c, const std::function<void()>& fn) {
 }
 void need(bool ok, const char* what) { if (!ok) throw std::invalid_argument(what); }
 }  // namespace
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { HIPCK(hipMalloc(&p, bytes ? bytes : 16)); }
+    ~DevBuf() { (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+constexpr double kSampleRate = 48000.0;          // telecom_system.cc:1569
+const double kCarrierAmplitude = 1.4142135623730951;   // sqrt(2.0), telecom_system.cc:69
+}  // namespace
+
 
 extern "C" {
 
@@ -392,6 +413,85 @@ int mgpu_txgen_dev(mgpu_ctx* c, uint64_t seed, uint64_t frame0, int F, double no
         hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(F), dim3(256), c->lds_tx, static_cast<hipStream_t>(stream), c->dev, seed,
                            frame0, F, noise_amp, channel, static_cast<double*>(d_bb), static_cast<uint8_t*>(d_payload_opt));
         HIPCK(hipGetLastError());
+    });
+}
+
+// ---- synchroniser building blocks (host-buffer, blocking) ---------------------------------------
+int mgpu_passband_to_baseband(mgpu_ctx* c, const double* passband, int W, int in_size, const double* carrier_hz, int filter,
+                              const int* start, int count, int decimation, double* out_c128) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(passband && carrier_hz && out_c128 && W > 0 && in_size > 0 && count > 0 && decimation >= 1 && (filter == 0 || filter == 1),
+             "bad argument");
+        const auto& taps = filter ? c->tab.fir_data : c->tab.fir_time_sync;
+        DevBuf d_in(size_t(W) * in_size * 8), d_fc(size_t(W) * 8), d_out(size_t(W) * count * 16), d_start(size_t(W) * 4);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_in.p, passband, size_t(W) * in_size * 8, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_fc.p, carrier_hz, size_t(W) * 8, hipMemcpyHostToDevice, s));
+        if (start) HIPCK(hipMemcpyAsync(d_start.p, start, size_t(W) * 4, hipMemcpyHostToDevice, s));
+        const int ntaps = int(taps.size());
+        const size_t lds = size_t(255 * decimation + ntaps) * 16;
+        need(lds <= 64 * 1024 && ntaps <= 64, "decimation too large for the staging buffer");
+        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((count + 255) / 256, W), dim3(256), lds, s, d_in.as<double>(), in_size, d_fc.as<double>(),
+                           start ? d_start.as<int>() : nullptr, 0, count, decimation, c->d_fir[filter], ntaps, kSampleRate, kCarrierAmplitude,
+                           d_out.as<double>());
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(out_c128, d_out.p, size_t(W) * count * 16, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int step, int location_to_return, int nTrials_max,
+                            int* delay, double* correlation) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        const auto& t = c->tab;
+        const int interp = 4, sym = t.Nofdm * interp, L = t.preamble * sym;
+        need(bb && delay && W > 0 && size > L && step >= 1 && nTrials_max >= 1 && nTrials_max <= size, "bad argument");
+        const int ncand = (size - L + step - 1) / step;
+        DevBuf d_in(size_t(W) * size * 16), d_vals(size_t(W) * ncand * 8);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(mgpu_tsync_metric_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, ncand, step,
+                           t.preamble, t.Ngi * interp, t.Nfft * interp, d_vals.as<double>());
+        HIPCK(hipGetLastError());
+        std::vector<double> cand(size_t(W) * ncand);
+        HIPCK(hipMemcpyAsync(cand.data(), d_vals.p, cand.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        // the reference's selection (ofdm.cc:1943-1964): overwrite-not-swap partial sort over the full-size array
+        if (location_to_return >= nTrials_max) location_to_return = nTrials_max - 1;
+        std::vector<double> vals(size);
+        std::vector<int> loc(size);
+        for (int w = 0; w < W; ++w) {
+            std::fill(vals.begin(), vals.end(), 0.0);
+            std::fill(loc.begin(), loc.end(), -1);
+            for (int k = 0; k < ncand; ++k) { vals[size_t(k) * step] = cand[size_t(w) * ncand + k]; loc[size_t(k) * step] = k * step; }
+            for (int j = 0; j < nTrials_max; ++j) {
+                loc[j] = j;
+                for (int i = j + 1; i < size; ++i)
+                    if (vals[i] > vals[j]) { vals[j] = vals[i]; loc[j] = i; }
+            }
+            delay[w] = loc[location_to_return];
+            if (correlation) correlation[w] = vals[location_to_return];
+        }
+    });
+}
+
+int mgpu_freq_sync(mgpu_ctx* c, const double* bb, int W, int stride, double* freq_offset_hz) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        const auto& t = c->tab;
+        int pre_half = t.preamble / 2 == 0 ? 1 : t.preamble / 2;            // ofdm.cc:548-555
+        need(bb && freq_offset_hz && W > 0 && stride >= pre_half * t.Nofdm, "bad argument");
+        DevBuf d_in(size_t(W) * stride * 16), d_out(size_t(W) * 8);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * stride * 16, hipMemcpyHostToDevice, s));
+        const double bandwidth = 48000.0 * 50.0 / 256 / 4;
+        hipLaunchKernelGGL(mgpu_fsync_kernel, dim3(W), dim3(256), 0, s, d_in.as<double>(), stride, pre_half, c->dev.twiddle,
+                           bandwidth / double(t.Nc), d_out.as<double>());
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(freq_offset_hz, d_out.p, size_t(W) * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
     });
 }
 

@@ -203,6 +203,25 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
 
 }  // namespace
 
+// cl_FIR::design for type LPF with a Hamming window (fir_filter.cc:45-131)
+static std::vector<double> design_lpf_hamming(double transition_bw, double cut, double fs) {
+    int n = int(4.0 / (transition_bw / (fs / 2.0)));
+    if (n % 2 == 0) ++n;
+    std::vector<double> c(n);
+    const double Ts = 1.0 / fs;
+    c[n / 2] = 1;
+    for (int i = 0; i < n / 2; ++i) {
+        const double temp = 2 * M_PI * cut * double(n / 2 - i) * Ts;
+        c[i] = std::sin(temp) / temp;
+        c[n - i - 1] = c[i];
+    }
+    double sum = 0;
+    for (int i = 0; i < n; ++i) sum += c[i];
+    for (int i = 0; i < n; ++i) c[i] /= sum;
+    for (int i = 0; i < n; ++i) c[i] *= 0.54 - 0.46 * std::cos(2.0 * M_PI * double(i) / (n - 1));
+    return c;
+}
+
 ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
     if (cfg < 0 || cfg > 16) throw std::runtime_error("cfg must be 0..16");
     const ModeRow& row = kModeTable[cfg];
@@ -295,6 +314,11 @@ ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
     for (int i = 0; i < t.nBits; ++i) t.bit_il[bd[i]] = uint16_t(i);  // interleaver is the inverse gather: out[bd[i]] = in[i]
     t.sym_cell.resize(t.nData);
     for (int k = 0; k < t.nData; ++k) t.sym_cell[k] = t.sym_src[k];   // symbol k lands where the RX reads it back
+    {   // physical_config.cc:80,90-98 ; telecom_system.cc:1569,1910-1922
+        const double bandwidth = 48000.0 * 50.0 / 256 / 4, fs = 48000.0;
+        t.fir_time_sync = design_lpf_hamming(3000.0, 0.9 * bandwidth / 2, fs);
+        t.fir_data = design_lpf_hamming(3000.0, 1.0 * bandwidth / 2, fs);
+    }
     t.graph = load_graph(t.K, blob, blob_size);
     if (t.graph.P != t.P) throw std::runtime_error("LDPC graph does not match the mode");
     return t;

@@ -59,6 +59,7 @@ struct ModeTables {
     std::vector<Cplx> twiddle;              // [128] exp(-2 pi i k/256)
     std::vector<uint16_t> sym_src;          // [nData] grid cell feeding de-interleaved symbol k
     std::vector<uint16_t> llr_src;          // [1600] index into the demod LLR vector feeding decoder input p
+    std::vector<double> fir_time_sync, fir_data;   // receive FIRs (fir_filter.cc:45-131, parameters physical_config.cc:90-98)
     std::vector<double> ls_weight;          // [lsw*lsw+1] boost/sum_n(boost^2) per window population n
     // TX-side permutations for the synthetic generator
     std::vector<uint16_t> bit_il;           // [nBits] interleaved position <- encoded index: out[bit_il[i]] = in[i]

@@ -79,7 +79,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
-    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math",
+    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync",
 ]
 
 
@@ -171,6 +171,39 @@ class RxPhy:
 
     def txgen_dev(self, seed, frame0, F, noise_amp, d_baseband, d_payload=None, channel=0, stream=None):
         self._ck(self.lib.mgpu_txgen_dev(self.h, seed, frame0, F, noise_amp, channel, d_baseband, d_payload, stream))
+
+    # ---- synchroniser building blocks -------------------------------------------
+    def passband_to_baseband(self, passband, carrier_hz, which=0, start=None, count=None, decimation=1):
+        """passband: float64 [W, in_size]; carrier_hz scalar or [W]. -> complex128 [W, count]."""
+        x = np.ascontiguousarray(passband, np.float64)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        W, n = x.shape
+        fc = np.ascontiguousarray(np.broadcast_to(np.asarray(carrier_hz, np.float64), (W,)))
+        st = None if start is None else np.ascontiguousarray(np.broadcast_to(np.asarray(start, np.int32), (W,)))
+        if count is None:
+            count = (n + decimation - 1) // decimation
+        out = np.zeros((W, count), np.complex128)
+        self._ck(self.lib.mgpu_passband_to_baseband(self.h, _ptr(x), C.c_int(W), C.c_int(n), _ptr(fc), C.c_int(which), _ptr(st),
+                                                    C.c_int(count), C.c_int(decimation), _ptr(out)))
+        return out
+
+    def time_sync_preamble(self, baseband_interp, step, location_to_return=0, nTrials_max=1):
+        z = np.ascontiguousarray(baseband_interp, np.complex128)
+        z = z.reshape(1, -1) if z.ndim == 1 else z
+        W, size = z.shape
+        delay = np.zeros(W, np.int32)
+        corr = np.zeros(W, np.float64)
+        self._ck(self.lib.mgpu_time_sync_preamble(self.h, _ptr(z), C.c_int(W), C.c_int(size), C.c_int(step), C.c_int(location_to_return),
+                                                  C.c_int(nTrials_max), _ptr(delay), _ptr(corr)))
+        return delay, corr
+
+    def freq_sync(self, baseband):
+        z = np.ascontiguousarray(baseband, np.complex128)
+        z = z.reshape(1, -1) if z.ndim == 1 else z
+        W, stride = z.shape
+        out = np.zeros(W, np.float64)
+        self._ck(self.lib.mgpu_freq_sync(self.h, _ptr(z), C.c_int(W), C.c_int(stride), _ptr(out)))
+        return out
 
     def debug_spa_math(self, x):
         """Device tanh / atanh (csrc/spa_math.h) of a float64 array -> (tanh, atanh[0 where |x|>=1])."""

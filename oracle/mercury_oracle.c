@@ -83,6 +83,8 @@ struct morc {
     int scrambler[N_MAX];
     cd tw[128];
     int bitrev[256];
+    double fir_ts[64], fir_data[64]; int fir_ntaps;   /* FIR_rx_time_sync / FIR_rx_data */
+    cd* preamble_vals;  /* [preamble*Nc] preamble carrier values */
     /* LDPC graph, reference layout (padded with -1) */
     int *C, *V, *Vdeg, *Cdeg;
     double *R, *Q;
@@ -169,6 +171,51 @@ static void build_pilots(morc* o) {
     for (int c = 0; c < Ns * Nc; c++) if (o->type[c] == PILOT) o->pilot_grid[c] = o->pilot_seq[pi++];
 }
 
+/* cl_FIR::design for an LPF with a Hamming window — fir_filter.cc:45-131 */
+static void design_lpf_hamming(double* c, int* ntaps, double transition_bw, double cut, double fs) {
+    int n = (int)(4.0 / (transition_bw / (fs / 2.0)));
+    if (n % 2 == 0) n++;
+    double Ts = 1.0 / fs, temp;
+    c[n / 2] = 1;
+    for (int i = 0; i < n / 2; i++) {
+        temp = 2 * M_PI * cut * (double)(n / 2 - i) * Ts;
+        c[i] = sin(temp) / temp;
+        c[n - i - 1] = c[i];
+    }
+    temp = 0;
+    for (int i = 0; i < n; i++) temp += c[i];
+    for (int i = 0; i < n; i++) c[i] /= temp;
+    for (int i = 0; i < n; i++) c[i] *= 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (n - 1));
+    *ntaps = n;
+}
+
+/* cl_preamble_configurator::configure + init — ofdm.cc:1126-1230: carriers whose FFT bin is odd are ZERO,
+ * the others carry a QPSK sequence drawn from __random() after __srandom(1). */
+static void build_preamble(morc* o) {
+    int Nc = o->Nc, np = o->preamble;
+    int zero_bin[256], z[64];
+    for (int j = 0; j < 256; j++) zero_bin[j] = (j % 2 == 1) ? 0 : 1;
+    for (int j = 0; j < 25; j++) z[j] = zero_bin[j + 256 - 25];
+    for (int j = 25; j < 50; j++) z[j] = zero_bin[j - 25 + 1];
+    o->preamble_vals = calloc((size_t)np * Nc, sizeof(cd));
+    cd* seq = malloc(sizeof(cd) * np * Nc);
+    prng_t p; prng_seed(&p, 1);
+    for (int i = 0; i < np * Nc; i++) {
+        /* std::complex<double>(2*(__random()%2)-1, 2*(__random()%2)-1): g++ evaluates the second argument first */
+        int b = 2 * (prng_next(&p) % 2) - 1;
+        int a = 2 * (prng_next(&p) % 2) - 1;
+        double s2 = sqrt(2);
+        seq[i] = ((double)a / s2) + ((double)b / s2) * I;
+    }
+    int idx = 0;
+    for (int i = 0; i < np; i++)
+        for (int j = 0; j < Nc; j++) {
+            if (z[j] == 0) o->preamble_vals[i * Nc + j] = 0;
+            else o->preamble_vals[i * Nc + j] = seq[idx++];
+        }
+    free(seq);
+}
+
 static int load_tables(morc* o, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return -1;
@@ -242,6 +289,9 @@ morc* morc_create(int cfg, int max_iters, const char* tables_path) {
         for (int j = 0; j < 8; j++) if (i & (1 << j)) rev |= 1 << (7 - j);
         o->bitrev[i] = rev;
     }
+    design_lpf_hamming(o->fir_ts, &o->fir_ntaps, 3000.0, 0.9 * (48000.0 * 50.0 / 256 / 4) / 2, 48000.0);
+    design_lpf_hamming(o->fir_data, &o->fir_ntaps, 3000.0, 1.0 * (48000.0 * 50.0 / 256 / 4) / 2, 48000.0);
+    build_preamble(o);
     if (load_tables(o, tables_path) != 0) { free(o); return NULL; }
     int g = o->Nsymb * o->Nc;
     o->grid = malloc(sizeof(cd) * g); o->eq = malloc(sizeof(cd) * g); o->eq_noamp = malloc(sizeof(cd) * g);
@@ -255,7 +305,7 @@ void morc_destroy(morc* o) {
     if (!o) return;
     free(o->type); free(o->pilot_seq); free(o->pilot_grid); free(o->C); free(o->V); free(o->Cdeg); free(o->Vdeg);
     free(o->R); free(o->Q); free(o->Vpos); free(o->grid); free(o->eq); free(o->eq_noamp); free(o->H); free(o->Hna);
-    free(o->Hst); free(o->deframed); free(o->tfd); free(o->framed); free(o->tfi); free(o->modulated);
+    free(o->Hst); free(o->deframed); free(o->tfd); free(o->framed); free(o->tfi); free(o->modulated); free(o->preamble_vals);
     free(o);
 }
 
@@ -692,6 +742,148 @@ void morc_rx(morc* o, const double* baseband_c128, int flags, morc_rx_out* out) 
         v2 /= o->nData;
         out->snr_db = -10.0 * log10(v2);
     }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Synchroniser building blocks */
+void morc_get_preamble(morc* o, double* out) { memcpy(out, o->preamble_vals, sizeof(cd) * o->preamble * o->Nc); }
+int morc_fir_taps(morc* o, int filter, double* taps) {
+    memcpy(taps, filter ? o->fir_data : o->fir_ts, sizeof(double) * o->fir_ntaps);
+    return o->fir_ntaps;
+}
+
+/* cl_ofdm::passband_to_baseband — ofdm.cc:2316-2339; cl_FIR::apply — fir_filter.cc:164-187; decimation :2267-2278 */
+void morc_passband_to_baseband(morc* o, const double* in, int in_size, double fs, double carrier_hz, double amplitude,
+                               int decimation, int filter, double* out_c128) {
+    const double* c = filter ? o->fir_data : o->fir_ts;
+    int nt = o->fir_ntaps, h = (nt - 1) / 2;
+    double Ts = 1.0 / fs;
+    cd* l = malloc(sizeof(cd) * in_size);
+    for (int i = 0; i < in_size; i++) {
+        double ph = 2 * M_PI * carrier_hz * (double)i * Ts;
+        l[i] = (in[i] * amplitude * cos(ph)) + (in[i] * amplitude * sin(ph)) * I;
+    }
+    cd* out = (cd*)out_c128;
+    int index = 0;
+    for (int n = 0; n < in_size; n += decimation) {
+        double ar = 0, ai = 0;
+        int i = n + h;
+        for (int j = 0; j < nt; j++)
+            if ((i - j) >= 0 && (i - j) < in_size) { ar += creal(l[i - j]) * c[j]; ai += cimag(l[i - j]) * c[j]; }
+        out[index++] = ar + ai * I;
+    }
+    free(l);
+}
+
+/* cl_ofdm::time_sync_preamble_with_metric — ofdm.cc:1846-1967 (including its overwrite-not-swap selection) */
+int morc_time_sync_preamble(morc* o, const double* in_c128, int size, int interp, int location_to_return, int step,
+                            int nTrials_max, double* correlation) {
+    const cd* in = (const cd*)in_c128;
+    int* loc = malloc(sizeof(int) * size);
+    double* vals = malloc(sizeof(double) * size);
+    for (int i = 0; i < size; i++) { loc[i] = -1; vals[i] = 0; }
+    int sym = (o->Ngi + o->Nfft) * interp, L = o->preamble * sym;
+    for (int i = 0; i < size - L; i += step) {
+        const cd* data = in + i;
+        double cc = 0, na = 0, nb = 0;
+        for (int l = 0; l < o->preamble; l++) {
+            const cd* a = data + l * sym;
+            const cd* b = data + l * sym + o->Nfft * interp;
+            for (int m = 0; m < o->Ngi * interp; m++) {
+                cc += creal(a[m]) * creal(b[m]); na += creal(a[m]) * creal(a[m]); nb += creal(b[m]) * creal(b[m]);
+                cc += cimag(a[m]) * cimag(b[m]); na += cimag(a[m]) * cimag(a[m]); nb += cimag(b[m]) * cimag(b[m]);
+            }
+            a = data + l * sym + o->Ngi * interp;
+            b = data + l * sym + (o->Ngi + o->Nfft / 2) * interp;
+            for (int m = 0; m < (o->Nfft / 2) * interp; m++) {
+                cc += creal(a[m]) * creal(b[m]); na += creal(a[m]) * creal(a[m]); nb += creal(b[m]) * creal(b[m]);
+                cc += cimag(a[m]) * cimag(b[m]); na += cimag(a[m]) * cimag(a[m]); nb += cimag(b[m]) * cimag(b[m]);
+            }
+        }
+        if (na < 0.001 || nb < 0.001) cc = 0.0; else cc = cc / sqrt(na * nb);
+        vals[i] = cc; loc[i] = i;
+    }
+    if (location_to_return >= nTrials_max) location_to_return = nTrials_max - 1;
+    for (int j = 0; j < nTrials_max; j++) {
+        loc[j] = j;
+        for (int i = j + 1; i < size; i++)
+            if (vals[i] > vals[j]) { vals[j] = vals[i]; loc[j] = i; }
+    }
+    int delay = loc[location_to_return];
+    if (correlation) *correlation = vals[location_to_return];
+    free(loc); free(vals);
+    return delay;
+}
+
+/* cl_ofdm::carrier_sampling_frequency_sync (Moose) — ofdm.cc:540-595 */
+double morc_freq_sync(morc* o, const double* in_c128, double carrier_freq_width, int preamble_nSymb, double fs) {
+    const cd* in = (const cd*)in_c128;
+    (void)fs;
+    if (preamble_nSymb / 2 == 0) preamble_nSymb = 1; else preamble_nSymb /= 2;
+    cd mul = 0;
+    for (int j = 0; j < preamble_nSymb; j++) {
+        cd f1[256], f2[256], d1[64], d2[64];
+        for (int i = 0; i < 128; i++) { f1[i] = in[j * 272 + i]; f1[i + 128] = in[j * 272 + i]; }
+        for (int i = 0; i < 128; i++) { f2[i] = in[j * 272 + i + 128]; f2[i + 128] = in[j * 272 + i + 128]; }
+        fft256(o, f1, 0); fft256(o, f2, 0);
+        for (int i = 0; i < 256; i++) { f1[i] = (creal(f1[i]) / 256.0) + (cimag(f1[i]) / 256.0) * I; f2[i] = (creal(f2[i]) / 256.0) + (cimag(f2[i]) / 256.0) * I; }
+        for (int i = 0; i < 25; i++) { d1[i] = f1[i + 256 - 25]; d2[i] = f2[i + 256 - 25]; }
+        for (int i = 25; i < 50; i++) { d1[i] = f1[i - 25 + 1]; d2[i] = f2[i - 25 + 1]; }
+        for (int i = 0; i < 50; i++) mul += cmul(conj(d2[i]), d1[i]);
+    }
+    return (get_angle(mul) / M_PI) * carrier_freq_width;
+}
+
+/* Test-input generator mirroring oracle/ref_harness.cc:mref_tx_passband (transmit_bit, telecom_system.cc:470-532,
+ * without pre-equalisation, clipping and TX filters): rational_resampler INTERPOLATION ofdm.cc:2279-2292,
+ * baseband_to_passband :2294-2315. */
+int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, double amplitude, double* out) {
+    int pre = o->preamble, interp = 4, nb = (pre + o->Nsymb) * o->Nofdm;
+    cd* bb = malloc(sizeof(cd) * nb);
+    cd* frame = bb + pre * o->Nofdm;
+    morc_tx(o, bits, 1, (double*)frame);
+    for (int s = 0; s < pre; s++) {
+        cd z[256];
+        memset(z, 0, sizeof z);
+        const cd* in = &o->preamble_vals[s * o->Nc];
+        for (int j = 0; j < 25; j++) z[j + 256 - 25] = in[j];
+        for (int j = 25; j < 50; j++) z[j - 25 + 1] = in[j];
+        fft256(o, z, 1);
+        cd* y = &bb[s * o->Nofdm];
+        for (int j = 0; j < 256; j++) y[j + 16] = z[j];
+        for (int j = 0; j < 16; j++) y[j] = z[j + 256 - 16];
+    }
+    float pn = sqrt((double)(o->Nfft * interp));
+    double pw = sqrt(0.1), boost = sqrt(2);
+    for (int j = 0; j < o->Nofdm * pre; j++) {
+        bb[j] = (creal(bb[j]) / (double)pn) + (cimag(bb[j]) / (double)pn) * I;
+        double m = pw * boost * 1.0;
+        bb[j] = (creal(bb[j]) * m) + (cimag(bb[j]) * m) * I;
+    }
+    for (int j = 0; j < o->Nofdm * o->Nsymb; j++) {
+        frame[j] = (creal(frame[j]) / (double)pn) + (cimag(frame[j]) / (double)pn) * I;
+        double m = pw * 1.0;
+        frame[j] = (creal(frame[j]) * m) + (cimag(frame[j]) * m) * I;
+    }
+    double Ts = 1.0 / fs;
+    unsigned long start = 0;
+    for (int part = 0; part < 2; part++) {
+        const cd* in = part ? frame : bb;
+        int n = part ? o->Nofdm * o->Nsymb : o->Nofdm * pre;
+        double* dst = out + (part ? o->Nofdm * pre * interp : 0);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < interp; j++) {
+                cd v;
+                if (i < n - 1) v = lerp(in[i], 0, in[i + 1], interp, j);
+                else v = lerp(in[n - 2], 0, in[n - 1], interp, interp + j);
+                double ph = 2 * M_PI * carrier_hz * (double)start * Ts;
+                dst[i * interp + j] = creal(v) * amplitude * cos(ph);
+                dst[i * interp + j] += cimag(v) * amplitude * sin(ph);
+                start++;
+            }
+    }
+    free(bb);
+    return nb * interp;
 }
 
 /* the host libm functions exactly as decode_SPA calls them (ldpc_decoder_SPA.cc:145,156) */

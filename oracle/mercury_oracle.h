@@ -90,6 +90,16 @@ void morc_gen_frame(morc*, uint64_t seed, uint64_t frame, double noise_amp, int 
 /* apply the channel of morc_gen_frame to an already modulated frame (in place) */
 void morc_channel(morc*, uint64_t seed, uint64_t frame, double noise_amp, int channel, double* frame_c128);
 
+/* ---- synchroniser building blocks; same argument meaning as the cl_ofdm methods ---- */
+void morc_get_preamble(morc*, double* out_c128);   /* [preamble_nsymb*Nc] */
+int morc_fir_taps(morc*, int filter, double* taps);   /* 0 = FIR_rx_time_sync, 1 = FIR_rx_data */
+void morc_passband_to_baseband(morc*, const double* in, int in_size, double fs, double carrier_hz, double amplitude,
+                               int decimation, int filter, double* out_c128);
+int morc_time_sync_preamble(morc*, const double* in_c128, int size, int interpolation_rate, int location_to_return,
+                            int step, int nTrials_max, double* correlation);
+double morc_freq_sync(morc*, const double* in_c128, double carrier_freq_width, int preamble_nSymb, double fs);
+int morc_tx_passband(morc*, const int* bits, double fs, double carrier_hz, double amplitude, double* out_passband);
+
 /* host libm tanh / atanh as the reference's decoder calls them; atanh_out is 0 where |x| >= 1 */
 void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out);
 

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <fcntl.h>
 #include <unistd.h>
+#include <vector>
 
 #include "physical_layer/ofdm.h"
 #include "physical_layer/psk.h"
@@ -156,6 +157,23 @@ void* mref_create(int cfg, int max_iters) {
     r->ldpc.GBF_eta = 0.5;
     r->ldpc.nIteration_max = max_iters;
     r->ldpc.print_nIteration = NO;
+    // receive filters: physical_config.cc:90-98 defaults copied by telecom_system.cc:2847-2856, designed at :1910-1922
+    {
+        const double bandwidth = 48000.0 * 50.0 / 256 / 4;                       // physical_config.cc:80
+        const double fs = 4 * (bandwidth / 50) * 256;                            // telecom_system.cc:1569
+        r->ofdm.FIR_rx_time_sync.filter_window = HAMMING;
+        r->ofdm.FIR_rx_time_sync.filter_transition_bandwidth = 3000;
+        r->ofdm.FIR_rx_time_sync.lpf_filter_cut_frequency = 0.9 * bandwidth / 2;
+        r->ofdm.FIR_rx_time_sync.type = LPF;
+        r->ofdm.FIR_rx_time_sync.sampling_frequency = fs;
+        r->ofdm.FIR_rx_time_sync.design();
+        r->ofdm.FIR_rx_data.filter_window = HAMMING;
+        r->ofdm.FIR_rx_data.filter_transition_bandwidth = 3000;
+        r->ofdm.FIR_rx_data.lpf_filter_cut_frequency = 1.0 * bandwidth / 2;
+        r->ofdm.FIR_rx_data.type = LPF;
+        r->ofdm.FIR_rx_data.sampling_frequency = fs;
+        r->ofdm.FIR_rx_data.design();
+    }
     // telecom_system.cc:2886
     r->psk.set_predefined_constellation(m.M);
     // telecom_system.cc:1883-1905 (init)
@@ -416,6 +434,71 @@ void mref_rx(void* h, const double* baseband_c128, int flags, mref_rx_out* o) {
         interleaver(r->modulated, r->tf_inter, r->nData, r->tf_blk);
         o->snr_db = ofdm.measure_SNR(r->deframed, r->tf_inter, r->nData);   // amplitude restoration is off for the ZF modes
     }
+}
+
+void mref_get_preamble(void* h, double* out) {
+    Ref* r = (Ref*)h;
+    for (int i = 0; i < r->preamble_nsymb * r->Nc; i++) { out[2 * i] = r->ofdm.ofdm_preamble[i].value.real(); out[2 * i + 1] = r->ofdm.ofdm_preamble[i].value.imag(); }
+}
+
+// ---- synchroniser building blocks (the "next" row f1 of SURVEY.md §8) ---------------------------
+// cl_ofdm::passband_to_baseband (ofdm.cc:2316-2339). filter: 0 = FIR_rx_time_sync, 1 = FIR_rx_data.
+void mref_passband_to_baseband(void* h, const double* in, int in_size, double fs, double carrier_hz, double amplitude,
+                               int decimation, int filter, double* out_c128) {
+    Ref* r = (Ref*)h;
+    Silence s;
+    r->ofdm.passband_to_baseband((double*)in, in_size, (cd*)out_c128, fs, carrier_hz, amplitude, decimation,
+                                 filter ? &r->ofdm.FIR_rx_data : &r->ofdm.FIR_rx_time_sync);
+}
+int mref_fir_taps(void* h, int filter, double* taps) {   // coefficients are private: read them as the impulse response
+    Ref* r = (Ref*)h;
+    cl_FIR* f = filter ? &r->ofdm.FIR_rx_data : &r->ofdm.FIR_rx_time_sync;
+    int n = f->filter_nTaps;
+    std::vector<cd> in(n, cd(0, 0)), out(n);
+    in[0] = cd(1, 0);
+    std::vector<cd> big(3 * n, cd(0, 0)), bout(3 * n);
+    big[n] = cd(1, 0);
+    f->apply(big.data(), bout.data(), 3 * n);
+    for (int j = 0; j < n; j++) taps[j] = bout[n - (n - 1) / 2 + j].real();
+    return n;
+}
+// cl_ofdm::time_sync_preamble_with_metric (ofdm.cc:1846-1967)
+int mref_time_sync_preamble(void* h, const double* in_c128, int size, int interpolation_rate, int location_to_return,
+                            int step, int nTrials_max, double* correlation) {
+    Ref* r = (Ref*)h;
+    Silence s;
+    TimeSyncResult t = r->ofdm.time_sync_preamble_with_metric((cd*)in_c128, size, interpolation_rate, location_to_return, step, nTrials_max);
+    if (correlation) *correlation = t.correlation;
+    return t.delay;
+}
+// cl_ofdm::carrier_sampling_frequency_sync (ofdm.cc:540-595)
+double mref_freq_sync(void* h, const double* in_c128, double carrier_freq_width, int preamble_nSymb, double fs) {
+    Ref* r = (Ref*)h;
+    Silence s;
+    return r->ofdm.carrier_sampling_frequency_sync((cd*)in_c128, carrier_freq_width, preamble_nSymb, fs);
+}
+// Test-input generator: preamble + data frame at passband, following transmit_bit (telecom_system.cc:470-532)
+// without pre-equalisation, peak clipping and the TX FIRs (none of which the RX building blocks require).
+// Returns the number of passband samples written: (preamble+Nsymb)*Nofdm*4.
+extern "C" void mref_tx(void* h, const int* bits, int scramble, double* out_c128);
+int mref_tx_passband(void* h, const int* bits, double fs, double carrier_hz, double amplitude, double* out_passband) {
+    Ref* r = (Ref*)h;
+    std::vector<double> frame(2 * size_t(r->Nofdm) * r->Nsymb);
+    mref_tx(h, bits, 1, frame.data());
+    Silence s;
+    const int pre = r->preamble_nsymb, interp = 4;
+    std::vector<cd> pre_data(size_t(pre) * r->Nc), pre_mod(size_t(pre) * r->Nofdm);
+    for (int i = 0; i < pre * r->Nc; i++) pre_data[i] = r->ofdm.ofdm_preamble[i].value;       // telecom_system.cc:466-472
+    for (int i = 0; i < pre; i++) r->ofdm.symbol_mod(&pre_data[i * r->Nc], &pre_mod[i * r->Nofdm]);
+    cd* data = (cd*)frame.data();
+    const float power_normalization = sqrt((double)(r->Nfft * interp));                       // telecom_system.cc:388
+    const double pw = sqrt(0.1);                                                               // output_power_Watt
+    for (int j = 0; j < r->Nofdm * pre; j++) { pre_mod[j] /= power_normalization; pre_mod[j] *= pw * r->ofdm.preamble_configurator.boost * 1.0; }
+    for (int j = 0; j < r->Nofdm * r->Nsymb; j++) { data[j] /= power_normalization; data[j] *= pw * 1.0; }
+    r->ofdm.passband_start_sample = 0;
+    r->ofdm.baseband_to_passband(pre_mod.data(), r->Nofdm * pre, out_passband, fs, carrier_hz, amplitude, interp);
+    r->ofdm.baseband_to_passband(data, r->Nofdm * r->Nsymb, &out_passband[r->Nofdm * pre * interp], fs, carrier_hz, amplitude, interp);
+    return (pre + r->Nsymb) * r->Nofdm * interp;
 }
 
 // cl_ldpc::decode alone (ldpc.h:90). alg: 1 = SPA (default), 0 = GBF.

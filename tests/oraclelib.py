@@ -213,3 +213,61 @@ class RefLib(_Base):
 def noise_amp_for(esn0_db):
     """Per-component AWGN amplitude at the reference's 1/sqrt(Nfft) scale (telecom_system.cc:100,147)."""
     return float(10.0 ** (-esn0_db / 20.0) / np.sqrt(2.0))
+
+
+# ---- synchroniser building blocks (SURVEY.md §8 row f1): same calls on both checkers ----------------
+FS = 48000.0
+BANDWIDTH = 48000.0 * 50.0 / 256 / 4          # physical_config.cc:80
+CARRIER = BANDWIDTH / 2 + 300                 # physical_config.cc:84 with carrier_frequency_offset = 0
+AMPLITUDE = float(np.sqrt(2.0))               # telecom_system.cc:69
+
+
+def _sync_methods(cls):
+    def preamble(self):
+        out = np.zeros(self.preamble_nsymb * self.Nc, np.complex128)
+        self._fn("get_preamble")(self.h, _p(out))
+        return out
+
+    def fir_taps(self, which):
+        t = np.zeros(64)
+        f = self._fn("fir_taps")
+        f.restype = C.c_int
+        n = f(self.h, C.c_int(which), _p(t))
+        return t[:n].copy()
+
+    def passband_to_baseband(self, x, carrier=CARRIER, decimation=1, which=0, fs=FS, amplitude=AMPLITUDE):
+        xin = np.ascontiguousarray(x, np.float64)
+        out = np.zeros((xin.size + decimation - 1) // decimation, np.complex128)
+        self._fn("passband_to_baseband")(self.h, _p(xin), C.c_int(xin.size), C.c_double(fs), C.c_double(carrier),
+                                         C.c_double(amplitude), C.c_int(decimation), C.c_int(which), _p(out))
+        return out
+
+    def time_sync_preamble(self, bb, step, location_to_return=0, nTrials_max=1, interp=4):
+        z = np.ascontiguousarray(bb, np.complex128)
+        corr = C.c_double(0)
+        f = self._fn("time_sync_preamble")
+        f.restype = C.c_int
+        d = f(self.h, _p(z), C.c_int(z.size), C.c_int(interp), C.c_int(location_to_return), C.c_int(step), C.c_int(nTrials_max), C.byref(corr))
+        return int(d), float(corr.value)
+
+    def freq_sync(self, bb, fs=FS):
+        z = np.ascontiguousarray(bb, np.complex128)
+        f = self._fn("freq_sync")
+        f.restype = C.c_double
+        return float(f(self.h, _p(z), C.c_double(BANDWIDTH / self.Nc), C.c_int(self.preamble_nsymb), C.c_double(fs)))
+
+    def tx_passband(self, bits, carrier=CARRIER, fs=FS, amplitude=AMPLITUDE):
+        b = np.zeros(1600, np.int32)
+        b[: self.nReal] = bits[: self.nReal]
+        out = np.zeros((self.preamble_nsymb + self.Nsymb) * self.Nofdm * 4)
+        f = self._fn("tx_passband")
+        f.restype = C.c_int
+        n = f(self.h, _p(b), C.c_double(fs), C.c_double(carrier), C.c_double(amplitude), _p(out))
+        assert n == out.size
+        return out
+
+    for fn in (preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband):
+        setattr(cls, fn.__name__, fn)
+
+
+_sync_methods(_Base)

@@ -1,0 +1,155 @@
+"""Synchroniser building blocks in front of the RX hot path:
+passband_to_baseband (mixer + FIR + decimation), Schmidl-Cox time sync, Moose frequency sync.
+
+CPU part: the C oracle against the compiled reference (bit-identical). GPU part: the HIP kernels against
+the oracle — indices and correlation-free integer outputs exact, floating point within 1e-11 relative
+(the device's cos/sin/atan differ from glibc in the last ulp), plus an end-to-end capture-window chain.
+"""
+import numpy as np
+import pytest
+
+import oraclelib
+from conftest import SEED
+from oraclelib import CARRIER, Oracle, RefLib
+
+
+def _window(orc, delay, noise=0.01, seed=1, carrier=CARRIER, frame_idx=1):
+    payload = orc.gen_payload(SEED, frame_idx)
+    bits = orc.payload_to_bits(payload)
+    pb = orc.tx_passband(bits, carrier=carrier)
+    W = orc.Nofdm * 85 * 4                      # buffer_Nsymb = 85 (SURVEY.md §8c anchor for cfg 8)
+    rng = np.random.default_rng(seed)
+    win = rng.standard_normal(W) * noise
+    win[delay: delay + pb.size] += pb
+    return win, payload
+
+
+@pytest.mark.skipif(not RefLib.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("cfg", [8, 10, 16])
+def test_oracle_sync_blocks_identical_to_reference(cfg):
+    o, r = Oracle(cfg), RefLib(cfg)
+    assert o.preamble().tobytes() == r.preamble().tobytes()
+    for w in (0, 1):
+        assert o.fir_taps(w).tobytes() == r.fir_taps(w).tobytes() and o.fir_taps(w).size == 33
+    win, _ = _window(o, 9321)
+    bits = o.payload_to_bits(o.gen_payload(SEED, 1))
+    assert o.tx_passband(bits).tobytes() == r.tx_passband(bits).tobytes()
+    for w in (0, 1):
+        assert o.passband_to_baseband(win, which=w).tobytes() == r.passband_to_baseband(win, which=w).tobytes()
+    assert o.passband_to_baseband(win[777:], which=1, decimation=4).tobytes() == r.passband_to_baseband(win[777:], which=1, decimation=4).tobytes()
+    bbi = o.passband_to_baseband(win, which=0)
+    assert o.time_sync_preamble(bbi, 100) == r.time_sync_preamble(bbi, 100)
+    d, _ = o.time_sync_preamble(bbi, 100)
+    ps = max(1, d // (o.Nofdm * 4))
+    seg = bbi[(ps - 1) * o.Nofdm * 4: (ps - 1) * o.Nofdm * 4 + (o.preamble_nsymb + 4) * o.Nofdm * 4]
+    for loc in (0, 1):
+        assert o.time_sync_preamble(seg, 1, loc, 2) == r.time_sync_preamble(seg, 1, loc, 2)
+    fine = (ps - 1) * o.Nofdm * 4 + o.time_sync_preamble(seg, 1, 0, 2)[0]
+    bb = o.passband_to_baseband(win, which=1)[fine::4]
+    assert o.freq_sync(bb[16:]) == r.freq_sync(bb[16:])
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 16])
+def test_gpu_passband_to_baseband(cfg):
+    from mercury_amd import RxPhy
+    o = Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=1)
+    wins = np.stack([_window(o, 5000 + 1111 * i, seed=i)[0] for i in range(3)])
+    carriers = np.array([CARRIER, CARRIER + 3.7, CARRIER - 11.0])
+    for which in (0, 1):
+        got = rx.passband_to_baseband(wins, carriers, which=which)
+        for w in range(3):
+            ref = o.passband_to_baseband(wins[w], carrier=carriers[w], which=which)
+            assert _rel(got[w], ref) < 1e-11, (cfg, which, w)
+    # fused extraction: only the kept samples are filtered (rational_resampler of telecom_system.cc:1105 folded in)
+    starts = np.array([4001, 17, 60000], np.int32)
+    count = (o.preamble_nsymb + o.Nsymb) * o.Nofdm
+    got = rx.passband_to_baseband(wins, carriers, which=1, start=starts, count=count, decimation=4)
+    for w in range(3):
+        full = o.passband_to_baseband(wins[w], carrier=carriers[w], which=1)
+        ref = full[starts[w]::4][:count]
+        assert _rel(got[w, : ref.size], ref) < 1e-11
+    # edges of the window: taps that fall outside the input are skipped exactly like cl_FIR::apply
+    short = wins[0, :300]
+    assert _rel(rx.passband_to_baseband(short, CARRIER, which=0)[0], o.passband_to_baseband(short, which=0)) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 13, 16])
+def test_gpu_time_and_frequency_sync(cfg):
+    from mercury_amd import RxPhy
+    o = Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=1)
+    delays = [9321, 20500, 3000]
+    wins = np.stack([_window(o, d, seed=10 + i, carrier=CARRIER + (0.0, 4.0, -6.0)[i])[0] for i, d in enumerate(delays)])
+    bbi = np.stack([o.passband_to_baseband(w, which=0) for w in wins])     # identical inputs for both sides
+    d_gpu, c_gpu = rx.time_sync_preamble(bbi, 100)
+    for w in range(3):
+        d_ref, c_ref = o.time_sync_preamble(bbi[w], 100)
+        assert d_gpu[w] == d_ref and abs(c_gpu[w] - c_ref) <= 1e-12 * abs(c_ref)
+    sym = o.Nofdm * 4
+    segs, bases = [], []
+    for w in range(3):
+        ps = max(1, int(d_gpu[w]) // sym)
+        bases.append((ps - 1) * sym)
+        segs.append(bbi[w, bases[-1]: bases[-1] + (o.preamble_nsymb + 4) * sym])
+    segs = np.stack(segs)
+    for loc in (0, 1, 2):
+        d2, c2 = rx.time_sync_preamble(segs, 1, loc, 2)
+        for w in range(3):
+            d_ref, c_ref = o.time_sync_preamble(segs[w], 1, loc, 2)
+            assert d2[w] == d_ref and abs(c2[w] - c_ref) <= 1e-12 * abs(c_ref)
+    d2, _ = rx.time_sync_preamble(segs, 1, 0, 2)
+    frames = np.stack([o.passband_to_baseband(wins[w], which=1)[bases[w] + int(d2[w])::4][: (o.preamble_nsymb + o.Nsymb) * o.Nofdm]
+                       for w in range(3)])
+    f_gpu = rx.freq_sync(frames[:, 16:])
+    for w in range(3):
+        f_ref = o.freq_sync(frames[w, 16:])
+        assert abs(f_gpu[w] - f_ref) <= 1e-9 * max(1.0, abs(f_ref)), (f_gpu[w], f_ref)
+
+
+@pytest.mark.gpu
+def test_capture_window_to_payload_chain_on_gpu():
+    """receive_byte's happy path (telecom_system.cc:676-1345) assembled from the GPU building blocks:
+    passband window -> time-sync filter -> coarse + fine Schmidl-Cox -> data filter + decimate at the found
+    delay -> Moose -> [re-mix if needed] -> hot path. The payload must come back, and every integer decision
+    (delays, iterations, bytes) must equal what the CPU oracle gets on the same windows."""
+    from mercury_amd import RxPhy
+    cfg = 8
+    o = Oracle(cfg, 50)
+    W = 6
+    rx = RxPhy(cfg, max_batch=W)
+    delays = [5000, 7777, 12345, 30011, 41234, 60000]
+    wins, payloads = zip(*[_window(o, d, noise=0.03, seed=50 + i, frame_idx=100 + i) for i, d in enumerate(delays)])
+    wins = np.stack(wins)
+    sym = o.Nofdm * 4
+    bbi = rx.passband_to_baseband(wins, CARRIER, which=0)
+    coarse, _ = rx.time_sync_preamble(bbi, 100)
+    bases = [(max(1, int(c) // sym) - 1) * sym for c in coarse]
+    segs = np.stack([bbi[w, bases[w]: bases[w] + (o.preamble_nsymb + 4) * sym] for w in range(W)])
+    fine, _ = rx.time_sync_preamble(segs, 1, 0, 2)
+    start = np.array([bases[w] + int(fine[w]) for w in range(W)], np.int32)
+    nfr = (o.preamble_nsymb + o.Nsymb) * o.Nofdm
+    bb = rx.passband_to_baseband(wins, CARRIER, which=1, start=start, count=nfr, decimation=4)
+    foff = rx.freq_sync(bb[:, 16:])
+    assert np.abs(foff).max() < 2.0                     # no carrier offset was applied
+    out = rx.receive(bb[:, o.preamble_nsymb * o.Nofdm:])
+    for w in range(W):
+        assert delays[w] - 64 <= int(start[w]) <= delays[w]    # inside the guard interval (16 samples x 4)
+        assert out["stats"]["message_decoded"][w] == 1
+        assert np.array_equal(out["payload"][w][: o.payload_bytes], payloads[w].astype(np.uint8))
+        # the same chain on the CPU oracle
+        bbi_o = o.passband_to_baseband(wins[w], which=0)
+        c_o, _ = o.time_sync_preamble(bbi_o, 100)
+        base_o = (max(1, c_o // sym) - 1) * sym
+        f_o, _ = o.time_sync_preamble(bbi_o[base_o: base_o + (o.preamble_nsymb + 4) * sym], 1, 0, 2)
+        assert (c_o, base_o + f_o) == (int(coarse[w]), int(start[w]))
+        bb_o = o.passband_to_baseband(wins[w], which=1)[base_o + f_o::4][:nfr]
+        ref = o.rx(bb_o[o.preamble_nsymb * o.Nofdm:], oraclelib.FLAGS_RECEIVE_BYTE)
+        assert out["stats"]["iterations_done"][w] == ref["iterations"]
+        assert np.array_equal(out["payload"][w], ref["bytes"].astype(np.uint8))
