@@ -148,6 +148,8 @@ int mgpu_passband_to_baseband(mgpu_ctx* ctx, const double* passband /*[W][in_siz
 int mgpu_time_sync_preamble(mgpu_ctx* ctx, const double* baseband_interp_c128 /*[W][size][2]*/, int W, int size, int step,
                             int location_to_return, int nTrials_max, int* delay /*[W]*/, double* correlation /*[W] or NULL*/);
 int mgpu_freq_sync(mgpu_ctx* ctx, const double* baseband_c128 /*[W][stride][2]*/, int W, int stride, double* freq_offset_hz /*[W]*/);
+/* duration (ms, HIP events on the launch stream) of the kernel of the most recent synchroniser call */
+int mgpu_last_sync_kernel_ms(mgpu_ctx* ctx, float* ms);
 
 /* Kernel timing with HIP events recorded on the launch stream around each kernel.
  * mgpu_enable_timing(ctx,1) resets the counters; mgpu_kernel_ms_avg returns the average launch

@@ -81,7 +81,9 @@ struct mgpu_ctx {
     MgpuStatsDev* d_stats = nullptr;
     uint8_t* d_bits = nullptr;
     double* d_eqdata = nullptr;
-    double* d_fir[2] = {nullptr, nullptr};   // FIR_rx_time_sync, FIR_rx_data taps     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
+    double* d_fir[2] = {nullptr, nullptr};   // FIR_rx_time_sync, FIR_rx_data taps
+    hipEvent_t sync_ev[2]{};        // around the most recent synchroniser kernel
+    float last_sync_ms = -1.f;     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
     int* d_iters = nullptr;
     hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
     static constexpr int kEvRing = 64;
@@ -155,6 +157,7 @@ void ctx_alloc(mgpu_ctx* c) {
     if (t.estimator == MGPU_EST_ZF) HIPCK(hipMalloc(&c->d_eqdata, B * t.nData * 16));
     HIPCK(hipStreamCreate(&c->stream));
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));
+    for (auto& e : c->sync_ev) HIPCK(hipEventCreate(&e));
 
     c->lds_fe = mgpu_frontend_lds_bytes(d.G);
     c->lds_tx = mgpu_txgen_lds_bytes(d.G);
@@ -315,6 +318,7 @@ void mgpu_destroy(mgpu_ctx* c) {
     (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters); (void)hipFree(c->d_eqdata);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto& q : c->ev) for (auto& e : q) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->sync_ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -432,10 +436,12 @@ int mgpu_passband_to_baseband(mgpu_ctx* c, const double* passband, int W, int in
         const int ntaps = int(taps.size());
         const size_t lds = size_t(255 * decimation + ntaps) * 16;
         need(lds <= 64 * 1024 && ntaps <= 64, "decimation too large for the staging buffer");
+        HIPCK(hipEventRecord(c->sync_ev[0], s));
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((count + 255) / 256, W), dim3(256), lds, s, d_in.as<double>(), in_size, d_fc.as<double>(),
                            start ? d_start.as<int>() : nullptr, 0, count, decimation, c->d_fir[filter], ntaps, kSampleRate, kCarrierAmplitude,
                            d_out.as<double>());
         HIPCK(hipGetLastError());
+        HIPCK(hipEventRecord(c->sync_ev[1], s));
         HIPCK(hipMemcpyAsync(out_c128, d_out.p, size_t(W) * count * 16, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
     });
@@ -452,9 +458,11 @@ int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int 
         DevBuf d_in(size_t(W) * size * 16), d_vals(size_t(W) * ncand * 8);
         hipStream_t s = c->stream;
         HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
+        HIPCK(hipEventRecord(c->sync_ev[0], s));
         hipLaunchKernelGGL(mgpu_tsync_metric_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, ncand, step,
                            t.preamble, t.Ngi * interp, t.Nfft * interp, d_vals.as<double>());
         HIPCK(hipGetLastError());
+        HIPCK(hipEventRecord(c->sync_ev[1], s));
         std::vector<double> cand(size_t(W) * ncand);
         HIPCK(hipMemcpyAsync(cand.data(), d_vals.p, cand.size() * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
@@ -487,11 +495,21 @@ int mgpu_freq_sync(mgpu_ctx* c, const double* bb, int W, int stride, double* fre
         hipStream_t s = c->stream;
         HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * stride * 16, hipMemcpyHostToDevice, s));
         const double bandwidth = 48000.0 * 50.0 / 256 / 4;
+        HIPCK(hipEventRecord(c->sync_ev[0], s));
         hipLaunchKernelGGL(mgpu_fsync_kernel, dim3(W), dim3(256), 0, s, d_in.as<double>(), stride, pre_half, c->dev.twiddle,
                            bandwidth / double(t.Nc), d_out.as<double>());
         HIPCK(hipGetLastError());
+        HIPCK(hipEventRecord(c->sync_ev[1], s));
         HIPCK(hipMemcpyAsync(freq_offset_hz, d_out.p, size_t(W) * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+int mgpu_last_sync_kernel_ms(mgpu_ctx* c, float* ms) {
+    if (!c || !ms) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        HIPCK(hipEventSynchronize(c->sync_ev[1]));
+        HIPCK(hipEventElapsedTime(ms, c->sync_ev[0], c->sync_ev[1]));
     });
 }
 

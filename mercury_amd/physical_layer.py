@@ -79,7 +79,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
-    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync",
+    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
 ]
 
 
@@ -204,6 +204,11 @@ class RxPhy:
         out = np.zeros(W, np.float64)
         self._ck(self.lib.mgpu_freq_sync(self.h, _ptr(z), C.c_int(W), C.c_int(stride), _ptr(out)))
         return out
+
+    def last_sync_kernel_ms(self):
+        ms = C.c_float(0)
+        self._ck(self.lib.mgpu_last_sync_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
 
     def debug_spa_math(self, x):
         """Device tanh / atanh (csrc/spa_math.h) of a float64 array -> (tanh, atanh[0 where |x|>=1])."""
