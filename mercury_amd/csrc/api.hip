@@ -555,6 +555,7 @@ int mgpu_rx_batch_taps(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, m
             if (taps->syms) dt.syms = static_cast<double*>(dalloc(size_t(F) * t.nData * 16));
             if (taps->llr_demod) dt.llr_demod = static_cast<float*>(dalloc(size_t(F) * t.nBits * 4));
             if (taps->variance) dt.variance = static_cast<double*>(dalloc(size_t(F) * 8));
+            if (taps->cycles) { dt.cycles = static_cast<long long*>(dalloc(16 * 8)); HIPCK(hipMemsetAsync(dt.cycles, 0, 16 * 8, s)); }
             if (taps->agc_gain) { dt.agc_gain = static_cast<double*>(dalloc(size_t(F) * 8)); HIPCK(hipMemsetAsync(dt.agc_gain, 0, size_t(F) * 8, s)); }
         }
         launch_frontend(c, c->d_baseband, F, c->d_llr, c->d_variance, c->d_snrvar, dt, s);
@@ -568,6 +569,7 @@ int mgpu_rx_batch_taps(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, m
             back(taps->syms, dt.syms, size_t(F) * t.nData * 16); back(taps->llr_demod, dt.llr_demod, size_t(F) * t.nBits * 4);
             back(taps->variance, dt.variance, size_t(F) * 8); back(taps->agc_gain, dt.agc_gain, size_t(F) * 8);
             back(taps->llr_ldpc, c->d_llr, size_t(F) * t.N * 4);
+            back(taps->cycles, dt.cycles, 16 * 8);
         }
         HIPCK(hipStreamSynchronize(s));
         for (void* p : tmp) (void)hipFree(p);

@@ -47,6 +47,7 @@ struct LdpcDev {
 
 struct MgpuTapsDev {
     double* grid; double* H; double* eq; double* syms; float* llr_demod; double* variance; double* agc_gain;
+    long long* cycles;   // optional: s_memtime stamps at the phase boundaries of frame 0 (profiling aid)
 };
 
 struct MgpuStatsDev {  // must match mgpu_frame_stats

@@ -66,14 +66,29 @@ __device__ __forceinline__ double get_angle(c2 v) {
 
 }  // namespace
 
+// Sum n doubles from LDS in index order with one lane: the additions are a dependent chain by
+// construction (the reference's `+=` loop), so the only thing to hide is the LDS latency: fetch eight
+// ahead while the previous eight are being added.
+__device__ __forceinline__ double serial_sum(const double* red, int n) {
+    double acc = 0;
+    int p = 0;
+    for (; p + 8 <= n; p += 8) {
+        const double a0 = red[p], a1 = red[p + 1], a2 = red[p + 2], a3 = red[p + 3];
+        const double a4 = red[p + 4], a5 = red[p + 5], a6 = red[p + 6], a7 = red[p + 7];
+        acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+    }
+    for (; p < n; ++p) acc += red[p];
+    return acc;
+}
+
 #define FE_THREADS 512
 #define FE_WAVES (FE_THREADS / 64)
 
 // LDS carve (bytes): grid 16G | B = max(16G, FE_WAVES*4096) (FFT work area, later the channel/equalised grid)
-//                    | red/llr 6400 (reduction terms, later the demapper LLRs) | tw 2048 | type G | scal 64
+//                    | red/yp/llr 12800 (reduction terms, signed pilots, later the demapper LLRs) | tw 2048 | type G | scal 64
 extern "C" size_t mgpu_frontend_lds_bytes(int G) {
     const size_t b = size_t(16) * G > size_t(FE_WAVES) * 4096 ? size_t(16) * G : size_t(FE_WAVES) * 4096;
-    return size_t(16) * G + b + 6400 + 2048 + ((G + 15) & ~15) + 64;
+    return size_t(16) * G + b + 12800 + 2048 + ((G + 15) & ~15) + 64;
 }
 
 extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
@@ -87,7 +102,8 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     const size_t bsz = size_t(16) * G > size_t(FE_WAVES) * 4096 ? size_t(16) * G : size_t(FE_WAVES) * 4096;
     double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(H) + bsz);   // <= 800 doubles
     float* llr = reinterpret_cast<float*>(red);                     // demapper output reuses the reduction area
-    c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(red) + 6400);
+    c2* yp = reinterpret_cast<c2*>(red);                            // pilots in row-major pilot order, multiplied by their sign
+    c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(red) + 12800);
     int8_t* type = reinterpret_cast<int8_t*>(tw + 128);             // 0 data, +1 / -1 pilot with that sign
     double* scal = reinterpret_cast<double*>(type + ((G + 15) & ~15));
 
@@ -96,40 +112,71 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     if (f >= F) return;
     const c2* bb = reinterpret_cast<const c2*>(baseband) + size_t(f) * T.frame_samples;
     const double boost = T.pilot_boost;
+    int stamp_i = 0;
+#define FE_STAMP() do { if (taps.cycles && f == 0 && tid == 0) taps.cycles[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
+    FE_STAMP();
 
     for (int i = tid; i < 128; i += FE_THREADS) tw[i] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
     for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i] ? (T.pilot_val[i] < 0 ? int8_t(-1) : int8_t(1)) : int8_t(0);
     __syncthreads();
 
-    // ---- symbol_demod: one wave per symbol. The 256-point work buffer is private to the wave, LDS
-    // operations of one wave execute in order, so the 8 butterfly stages need no workgroup barrier.
+    // ---- symbol_demod: one wave per symbol ------------------------------------------------------
+    // The reference's radix-2 DIT (bit-reversal permutation, then stages size = 2..256) is run with the data
+    // left in natural order: element idx of the permuted array lives at position p = brev8(idx), so stage s
+    // pairs positions p and p + 2^(8-s) and bin k ends up at position brev8(k). Every butterfly has the same
+    // operands and the same twiddle as the reference's, so the results are bit-identical, but (a) the global
+    // load and all LDS accesses are contiguous (no bit-reversed scatter, no bank conflicts) and (b) the first
+    // two stages pair elements 128 and 64 apart, which one lane holds in registers. The work buffer is private
+    // to the wave and LDS operations of one wave execute in order: no workgroup barrier inside.
+    // the next symbol's samples are requested before the current symbol's butterflies start, so the HBM latency
+    // of symbol s+8 hides behind the LDS stages of symbol s
+    c2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
+    if (wave < Ns) {
+        const c2* in = bb + size_t(wave) * 272 + 16;                // gi_remover
+        n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
+    }
     for (int s = wave; s < Ns; s += FE_WAVES) {
         c2* v = fftb + wave * 256;
-        const c2* in = bb + size_t(s) * 272 + 16;                   // gi_remover
-#pragma unroll
-        for (int i = lane; i < 256; i += 64) v[__brev(unsigned(i)) >> 24] = in[i];   // bit-reversal permutation
+        c2 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+        if (s + FE_WAVES < Ns) {
+            const c2* in = bb + size_t(s + FE_WAVES) * 272 + 16;
+            n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
+        }
+        {   // stage 1 (size 2): positions p, p+128 ; idx0 = brev8(p) is even, j = 0
+            const c2 w = tw[0];
+            c2 t = cmul(w, r2); c2 u = r0; r2 = {u.re - t.re, u.im - t.im}; r0 = {u.re + t.re, u.im + t.im};
+            t = cmul(w, r3); u = r1; r3 = {u.re - t.re, u.im - t.im}; r1 = {u.re + t.re, u.im + t.im};
+        }
+        {   // stage 2 (size 4): positions p, p+64 ; j = idx0 & 1 = bit 7 of p -> twiddle 0 for (r0,r1), 64 for (r2,r3)
+            c2 t = cmul(tw[0], r1); c2 u = r0; r1 = {u.re - t.re, u.im - t.im}; r0 = {u.re + t.re, u.im + t.im};
+            t = cmul(tw[64], r3); u = r2; r3 = {u.re - t.re, u.im - t.im}; r2 = {u.re + t.re, u.im + t.im};
+        }
+        v[lane] = r0; v[lane + 64] = r1; v[lane + 128] = r2; v[lane + 192] = r3;
         __builtin_amdgcn_wave_barrier();
-        for (int size = 2; size <= 256; size <<= 1) {
-            const int half = size >> 1, step = 256 / size;
+#pragma unroll
+        for (int st = 3; st <= 8; ++st) {
+            const int d = 256 >> st, half = 1 << (st - 1), step = 256 >> st;   // pair distance, idx-space half size, twiddle stride
 #pragma unroll
             for (int b = lane; b < 128; b += 64) {
-                const int j = b & (half - 1);
-                const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
-                const c2 t = cmul(tw[j * step], v[i1]);
-                const c2 u = v[i0];
-                v[i1] = {u.re - t.re, u.im - t.im};
-                v[i0] = {u.re + t.re, u.im + t.im};
+                const int p0 = ((b / d) * 2 * d) + (b % d), p1 = p0 + d;
+                const int j = int(__brev(unsigned(p0)) >> 24) & (half - 1);
+                const c2 t = cmul(tw[j * step], v[p1]);
+                const c2 u = v[p0];
+                v[p1] = {u.re - t.re, u.im - t.im};
+                v[p0] = {u.re + t.re, u.im + t.im};
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane < 50) {                                            // 1/Nfft scale + zero_depadder
+        if (lane < 50) {                                            // 1/Nfft scale + zero_depadder; bin k sits at brev8(k)
             const int bin = lane < 25 ? lane + 256 - 25 : lane - 25 + 1;
-            grid[s * Nc + lane] = {v[bin].re / 256.0, v[bin].im / 256.0};
+            const c2 x = v[__brev(unsigned(bin)) >> 24];
+            grid[s * Nc + lane] = {x.re / 256.0, x.im / 256.0};
         }
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
 
+    FE_STAMP();   // 1: FFT done
     // ---- automatic_gain_control ---------------------------------------------------------------
     if (T.agc) {
         for (int p = tid; p < T.nPilots; p += FE_THREADS) {
@@ -138,8 +185,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
         }
         __syncthreads();
         if (tid == 0) {
-            double amp = 0;
-            for (int p = 0; p < T.nPilots; ++p) amp += red[p];
+            double amp = serial_sum(red, T.nPilots);
             amp /= T.nPilots;
             scal[0] = boost / amp;
         }
@@ -151,8 +197,18 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     }
     if (taps.grid) for (int c = tid; c < G; c += FE_THREADS) { taps.grid[(size_t(f) * G + c) * 2] = grid[c].re; taps.grid[(size_t(f) * G + c) * 2 + 1] = grid[c].im; }
 
+    FE_STAMP();   // 2: AGC done
     // ---- channel estimate at the pilots -------------------------------------------------------
     const int hw = T.lsw / 2;
+    const bool ls_fast = T.estimator != 0 && T.regular_lattice;
+    if (ls_fast) {       // x*y for the LS sums: the pilot's sign applied once ((-w)*y == w*(-y) exactly), in pilot order
+        for (int p = tid; p < T.nPilots; p += FE_THREADS) {
+            const int q = T.pilot_cell[p];
+            const c2 y = grid[q];
+            yp[p] = type[q] < 0 ? c2{-y.re, -y.im} : y;
+        }
+        __syncthreads();
+    }
     for (int p = tid; p < T.nPilots; p += FE_THREADS) {
         const int c = T.pilot_cell[p], i = c / Nc, j = c - i * Nc;
         if (T.estimator == 0) {            // ZF: Y / (x + 0i) reduces to two real divisions in __divdc3
@@ -161,21 +217,40 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
         } else {                           // LS over the (clipped) 21x21 window, row-major order
             const int k0 = max(i - hw, 0), k1 = min(i + hw, Ns - 1), l0 = max(j - hw, 0), l1 = min(j + hw, Nc - 1);
             double hr = 0, hi = 0;
-            if (T.regular_lattice) {       // pilots of row k sit at columns == k (mod 3): visit only those
+            if (ls_fast) {
+                // pilots of row k sit at columns == k (mod 3); rows hold 17,17,16 pilots cyclically, so the pilot
+                // index of (k, l) is 50*(k/3) + {0,17,34}[k%3] + (l - k%3)/3 and a row's window pilots are contiguous
+                // per column residue r = k % 3: first window column == r (mod 3), how many pilots, and the offset of
+                // that first pilot inside its row; computed once per pilot, then rows just cycle through r
+                int cntr[3], offr[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int first = l0 + ((r - l0) % 3 + 3) % 3;
+                    cntr[r] = first <= l1 ? (l1 - first) / 3 + 1 : 0;
+                    offr[r] = (r == 0 ? 0 : r == 1 ? 17 : 34) + (first - r) / 3;
+                }
                 int n = 0;
-                for (int k = k0; k <= k1; ++k) {
-                    const int first = l0 + ((k - l0) % 3 + 3) % 3;
-                    if (first <= l1) n += (l1 - first) / 3 + 1;
+                {
+                    int r = k0 % 3;
+                    for (int k = k0; k <= k1; ++k) { n += r == 0 ? cntr[0] : r == 1 ? cntr[1] : cntr[2]; r = r == 2 ? 0 : r + 1; }
                 }
                 const double w = T.ls_weight[n];
+                int km = k0 % 3, rowbase = 50 * (k0 / 3);
                 for (int k = k0; k <= k1; ++k) {
-                    const int first = l0 + ((k - l0) % 3 + 3) % 3;
-                    for (int l = first; l <= l1; l += 3) {
-                        const int q = k * Nc + l;
-                        const double xw = type[q] < 0 ? -w : w;      // x' = x * (1/sum x^2)
-                        hr += xw * grid[q].re;
-                        hi += xw * grid[q].im;
-                    }
+                    const int cnt = km == 0 ? cntr[0] : km == 1 ? cntr[1] : cntr[2];
+                    const c2* row = yp + rowbase + (km == 0 ? offr[0] : km == 1 ? offr[1] : offr[2]);
+                    if (km == 2) { km = 0; rowbase += 50; } else ++km;
+                    if (cnt == 0) continue;
+                    // a window row holds at most 7 pilots: fetch all seven at once (one LDS latency per row; reading past
+                    // the row's end stays inside the LDS carve), add the first cnt in order
+                    const c2 v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3], v4 = row[4], v5 = row[5], v6 = row[6];
+                    hr += w * v0.re; hi += w * v0.im;
+                    if (cnt > 1) { hr += w * v1.re; hi += w * v1.im; }
+                    if (cnt > 2) { hr += w * v2.re; hi += w * v2.im; }
+                    if (cnt > 3) { hr += w * v3.re; hi += w * v3.im; }
+                    if (cnt > 4) { hr += w * v4.re; hi += w * v4.im; }
+                    if (cnt > 5) { hr += w * v5.re; hi += w * v5.im; }
+                    if (cnt > 6) { hr += w * v6.re; hi += w * v6.im; }
                 }
             } else {
                 int n = 0;
@@ -195,6 +270,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
         }
     }
     __syncthreads();
+    FE_STAMP();   // 3: estimate done
     // ---- interpolate_linear_col for the data cells --------------------------------------------
     for (int c = tid; c < G; c += FE_THREADS) {
         if (type[c]) continue;
@@ -215,6 +291,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     }
     __syncthreads();
 
+    FE_STAMP();   // 4: interpolation done
     // ---- amplitude restoration (PSK modes) + SNR variance on the non-restored equalisation ----
     if (T.amp_restore) {
         for (int p = tid; p < T.nPilots; p += FE_THREADS) {      // measure_variance(equalized_data_without_amplitude_restoration)
@@ -225,8 +302,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
         }
         __syncthreads();
         if (tid == 0) {
-            double var = 0;
-            for (int p = 0; p < T.nPilots; ++p) var += red[p];
+            double var = serial_sum(red, T.nPilots);
             var /= double(T.nPilots);
             scal[2] = var;
         }
@@ -238,6 +314,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     }
     if (taps.H) for (int c = tid; c < G; c += FE_THREADS) { taps.H[(size_t(f) * G + c) * 2] = H[c].re; taps.H[(size_t(f) * G + c) * 2 + 1] = H[c].im; }
 
+    FE_STAMP();   // 5: amplitude restoration done
     // ---- variance terms from the un-equalised grid (baseband_test_EsN0 variant) ----------------
     if (!T.var_eq) {
         for (int p = tid; p < T.nPilots; p += FE_THREADS) {
@@ -262,8 +339,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
         __syncthreads();
     }
     if (tid == 0) {
-        double var = 0;
-        for (int p = 0; p < T.nPilots; ++p) var += red[p];
+        double var = serial_sum(red, T.nPilots);
         var /= double(T.nPilots);
         scal[1] = var;
     }
@@ -275,6 +351,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
         if (taps.variance) taps.variance[f] = scal[1];
     }
 
+    FE_STAMP();   // 6: equalise + variance done
     // ---- deframe + time/freq de-interleave + max-log demap -------------------------------------
     const float inv_var = 1 / variance;
     const int M = T.M, bps = T.bps;
@@ -301,6 +378,9 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     }
     __syncthreads();
     if (taps.llr_demod) for (int i = tid; i < T.nBits; i += FE_THREADS) taps.llr_demod[size_t(f) * T.nBits + i] = llr[i];
+    FE_STAMP();   // 7: demap done
     // ---- bit de-interleave + shortening re-pack -------------------------------------------------
     for (int p = tid; p < T.N; p += FE_THREADS) llr_out[size_t(f) * T.N + p] = llr[T.llr_src[p]];
+    FE_STAMP();   // 8: end
+#undef FE_STAMP
 }

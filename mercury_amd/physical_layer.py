@@ -37,7 +37,7 @@ class Info(C.Structure):
 
 
 class Taps(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in "grid H eq syms llr_demod llr_ldpc variance agc_gain".split()]
+    _fields_ = [(n, C.c_void_p) for n in "grid H eq syms llr_demod llr_ldpc variance agc_gain cycles".split()]
 
 
 STATS_DTYPE = np.dtype([("iterations_done", "<i4"), ("crc", "<i4"), ("all_zeros", "<i4"),
@@ -139,7 +139,7 @@ class RxPhy:
             t = dict(grid=np.zeros((F, G), np.complex128), H=np.zeros((F, G), np.complex128),
                      eq=np.zeros((F, G), np.complex128), syms=np.zeros((F, self.nData), np.complex128),
                      llr_demod=np.zeros((F, self.nBits), np.float32), llr_ldpc=np.zeros((F, 1600), np.float32),
-                     variance=np.zeros(F, np.float64), agc_gain=np.zeros(F, np.float64))
+                     variance=np.zeros(F, np.float64), agc_gain=np.zeros(F, np.float64), cycles=np.zeros(16, np.int64))
             ts = Taps(**{k: v.ctypes.data for k, v in t.items()})
             self._ck(self.lib.mgpu_rx_batch_taps(self.h, _ptr(bb), C.c_int(F), _ptr(payload), _ptr(stats), C.byref(ts)))
             out.update(t)
