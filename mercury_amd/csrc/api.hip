@@ -30,6 +30,7 @@ extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const dou
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
 extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*);
 extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, int, int, int, int, int, double*);
+extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double, double*);
 #define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
@@ -459,7 +460,7 @@ int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int 
         hipStream_t s = c->stream;
         HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
         HIPCK(hipEventRecord(c->sync_ev[0], s));
-        hipLaunchKernelGGL(mgpu_tsync_metric_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, ncand, step,
+        hipLaunchKernelGGL(step < 16 ? mgpu_tsync_metric_dense_kernel : mgpu_tsync_metric_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, ncand, step,
                            t.preamble, t.Ngi * interp, t.Nfft * interp, d_vals.as<double>());
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(c->sync_ev[1], s));

@@ -63,8 +63,62 @@ extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
     out[(size_t(w) * count + k) * 2 + 1] = ai;
 }
 
-// One lane per candidate offset i = cand*step; the three accumulators run in the reference's order.
+// Schmidl-Cox metric. One lane per candidate offset i = cand*step; the three accumulators run in the
+// reference's order (a dependent chain of 2*(Ngi+Nfft/2)*Nsymb additions each), so the parallelism is across
+// candidates. Lanes of a wave are `step` samples apart, which would make every global load touch 64 different
+// cache lines; instead the wave walks the preamble in chunks of TS_CH samples and stages, per chunk, the two
+// sample rows (a and b) of each of its 64 candidates in LDS with coalesced row loads (row r = 64 consecutive
+// samples = 1 KiB = one wave-wide load), padded by one element per row so the per-lane reads are conflict-free.
+#define TS_CH 64
+
 extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_kernel(
+    const double* __restrict__ bb, int size, int ncand, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    __shared__ c2 ra[64][TS_CH + 1];
+    __shared__ c2 rb[64][TS_CH + 1];
+    const int w = blockIdx.y, lane = threadIdx.x;
+    const int cand0 = blockIdx.x * 64;
+    const int cand = cand0 + lane;
+    const c2* win = reinterpret_cast<const c2*>(bb) + size_t(w) * size;
+    const int sym = ngi_i + nfft_i;
+    double cc = 0, na = 0, nb = 0;
+    // segments of the reference's loops: per preamble symbol l, (a = l*sym, b = a + Nfft, len Ngi) then
+    // (a = l*sym + Ngi, b = a + Nfft/2, len Nfft/2)
+    for (int l = 0; l < pre_nsymb; ++l) {
+        for (int part = 0; part < 2; ++part) {
+            const int a_off = l * sym + (part ? ngi_i : 0);
+            const int b_off = a_off + (part ? nfft_i / 2 : nfft_i);
+            const int len = part ? nfft_i / 2 : ngi_i;
+            for (int m0 = 0; m0 < len; m0 += TS_CH) {
+                const int n = min(TS_CH, len - m0);
+                // stage rows: row r belongs to candidate cand0 + r
+                for (int r = 0; r < 64; ++r) {
+                    const long base = long(cand0 + r) * step;
+                    if (cand0 + r < ncand && lane < n) {
+                        ra[r][lane] = win[base + a_off + m0 + lane];
+                        rb[r][lane] = win[base + b_off + m0 + lane];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (cand < ncand) {
+                    for (int m = 0; m < n; ++m) {
+                        const c2 x = ra[lane][m], y = rb[lane][m];
+                        cc += x.re * y.re; na += x.re * x.re; nb += y.re * y.re;
+                        cc += x.im * y.im; na += x.im * x.im; nb += y.im * y.im;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (cand >= ncand) return;
+    if (na < 0.001 || nb < 0.001) cc = 0.0;
+    else cc = cc / sqrt(na * nb);
+    vals[size_t(w) * ncand + cand] = cc;
+}
+
+// Same metric for small steps (fine search, step 1): neighbouring lanes read neighbouring samples, so plain
+// global loads are already coalesced and L1 serves the 64-fold overlap between candidates.
+extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_dense_kernel(
     const double* __restrict__ bb, int size, int ncand, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
     const int w = blockIdx.y;
     const int cand = blockIdx.x * 64 + threadIdx.x;
