@@ -136,6 +136,15 @@ void ctx_alloc(mgpu_ctx* c) {
     d.payload_bytes = t.payload_bytes; d.payload_stride = t.payload_stride; d.frame_samples = t.frame_samples;
     d.agc = c->cfg.agc; d.var_eq = c->cfg.variance_source; d.max_iters = c->cfg.max_iters;
     d.pilot_boost = t.pilot_boost;
+    d.staircase = 1;
+    for (int q = 0; q < t.P && d.staircase; ++q) {
+        int others = 0;
+        for (uint32_t e = t.graph.cptr[q]; e < t.graph.cptr[q + 1]; ++e) {
+            const int v = t.graph.cvar[e];
+            if (v >= t.K && v != t.K + q) { ++others; if (v != t.K + q - 1) d.staircase = 0; }
+        }
+        if (others != (q == 0 ? 0 : 1)) d.staircase = 0;
+    }
     d.regular_lattice = 1;
     for (int r = 0; r < t.Nsymb; ++r)
         for (int q = 0; q < t.Nc; ++q)
@@ -147,15 +156,6 @@ void ctx_alloc(mgpu_ctx* c) {
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
 
-    const size_t B = size_t(c->max_batch);
-    HIPCK(hipMalloc(&c->d_llr, B * t.N * sizeof(float)));
-    HIPCK(hipMalloc(&c->d_variance, B * sizeof(float)));
-    HIPCK(hipMalloc(&c->d_snrvar, B * sizeof(float)));
-    HIPCK(hipMalloc(&c->d_payload, B * t.payload_stride));
-    HIPCK(hipMalloc(&c->d_stats, B * sizeof(MgpuStatsDev)));
-    HIPCK(hipMalloc(&c->d_bits, B * t.K));
-    HIPCK(hipMalloc(&c->d_iters, B * sizeof(int)));
-    if (t.estimator == MGPU_EST_ZF) HIPCK(hipMalloc(&c->d_eqdata, B * t.nData * 16));
     HIPCK(hipStreamCreate(&c->stream));
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));
     for (auto& e : c->sync_ev) HIPCK(hipEventCreate(&e));
@@ -197,39 +197,81 @@ void ctx_alloc(mgpu_ctx* c) {
     }
 }
 
+// Workspaces sized by max_batch are created on first use, so a context that only ever runs e.g. the
+// decoder on caller-owned device buffers (the 10^7-codeword soak) does not pin tens of GB it never touches.
+enum : unsigned { WS_FRONTEND = 1, WS_LLR = 2, WS_OUT = 4, WS_BITS = 8 };
+void ensure_workspaces(mgpu_ctx* c, unsigned what) {
+    const auto& t = c->tab;
+    const size_t B = size_t(c->max_batch);
+    if ((what & WS_FRONTEND) && !c->d_variance) {
+        HIPCK(hipMalloc(&c->d_variance, B * sizeof(float)));
+        HIPCK(hipMalloc(&c->d_snrvar, B * sizeof(float)));
+        if (t.estimator == MGPU_EST_ZF) HIPCK(hipMalloc(&c->d_eqdata, B * t.nData * 16));
+    }
+    if ((what & WS_LLR) && !c->d_llr) HIPCK(hipMalloc(&c->d_llr, B * t.N * sizeof(float)));
+    if ((what & WS_OUT) && !c->d_payload) {
+        HIPCK(hipMalloc(&c->d_payload, B * t.payload_stride));
+        HIPCK(hipMalloc(&c->d_stats, B * sizeof(MgpuStatsDev)));
+    }
+    if ((what & WS_BITS) && !c->d_bits) {
+        HIPCK(hipMalloc(&c->d_bits, B * t.K));
+        HIPCK(hipMalloc(&c->d_iters, B * sizeof(int)));
+    }
+}
+
+// HIP caps gridDim*blockDim below 2^32 threads, so very large batches go out in chunks of frames.
+constexpr int kMaxFramesPerLaunch = 1 << 21;
+template <typename T> T* at(T* p, size_t off) { return p ? p + off : nullptr; }
+
 void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float* d_var, float* d_snrvar,
                      const MgpuTapsDev& taps, hipStream_t s) {
     const int slot = c->ev_count % mgpu_ctx::kEvRing;
+    const auto& t = c->tab;
     if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][0], s)); c->ev_fe[slot] = true; }
-    hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(F), dim3(512), c->lds_fe, s, c->dev, d_bb, F, d_llr, d_var, d_snrvar, c->d_eqdata, taps);
-    HIPCK(hipGetLastError());
+    for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
+        const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
+        if (off && (taps.grid || taps.H || taps.eq || taps.syms || taps.llr_demod || taps.variance || taps.agc_gain))
+            throw std::invalid_argument("stage taps are limited to 2^21 frames per call");
+        hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(n), dim3(512), c->lds_fe, s, c->dev, d_bb + size_t(off) * t.frame_samples * 2, n,
+                           d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), at(c->d_eqdata, size_t(off) * t.nData * 2), taps);
+        HIPCK(hipGetLastError());
+    }
     if (c->timing) HIPCK(hipEventRecord(c->ev[slot][1], s));
 }
 
 // zero-forcing modes: SNR from the re-encoded decision (telecom_system.cc:1374-1396); needs the payload and
 // the de-framed equalised symbols the front-end kept.
 void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s) {
-    if (c->tab.estimator != MGPU_EST_ZF || !d_payload || !d_stats) return;
-    hipLaunchKernelGGL(mgpu_zf_snr_kernel, dim3(F), dim3(256), mgpu_zfsnr_lds_bytes(c->tab.nData), s, c->dev, d_payload, c->d_eqdata, F, d_stats);
-    HIPCK(hipGetLastError());
+    const auto& t = c->tab;
+    if (t.estimator != MGPU_EST_ZF || !d_payload || !d_stats) return;
+    for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
+        const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
+        hipLaunchKernelGGL(mgpu_zf_snr_kernel, dim3(n), dim3(256), mgpu_zfsnr_lds_bytes(t.nData), s, c->dev,
+                           d_payload + size_t(off) * t.payload_stride, c->d_eqdata + size_t(off) * t.nData * 2, n, d_stats + off);
+        HIPCK(hipGetLastError());
+    }
 }
 
 void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int* d_iters, uint8_t* d_payload,
                     MgpuStatsDev* d_stats, const float* d_var, const float* d_snrvar, hipStream_t s) {
     const int slot = c->ev_count % mgpu_ctx::kEvRing;
+    const auto& t = c->tab;
     if (c->timing) HIPCK(hipEventRecord(c->ev[slot][2], s));
-    switch (c->cfg.decoder) {
-        case MGPU_DEC_SPA:
-            hipLaunchKernelGGL(c->spa_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
-            break;
-        case MGPU_DEC_GBF:
-            hipLaunchKernelGGL(mgpu_ldpc_gbf_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
-            break;
-        default:
-            hipLaunchKernelGGL(c->spa_kernel, dim3(F), dim3(1024), c->lds_dec, s, c->ldev, d_llr, F, d_bits, d_iters, d_payload, d_stats, d_var, d_snrvar);
-            break;
+    for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
+        const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
+        const float* llr = d_llr + size_t(off) * t.N;
+        uint8_t* bits = at(d_bits, size_t(off) * t.K);
+        int* iters = at(d_iters, off);
+        uint8_t* pay = at(d_payload, size_t(off) * t.payload_stride);
+        MgpuStatsDev* st = at(d_stats, off);
+        const float* var = at(d_var, off);
+        const float* sv = at(d_snrvar, off);
+        if (c->cfg.decoder == MGPU_DEC_GBF)
+            hipLaunchKernelGGL(mgpu_ldpc_gbf_kernel, dim3(n), dim3(1024), c->lds_dec, s, c->ldev, llr, n, bits, iters, pay, st, var, sv);
+        else   // sum-product or min-sum, the variant for this graph's round count
+            hipLaunchKernelGGL(c->spa_kernel, dim3(n), dim3(1024), c->lds_dec, s, c->ldev, llr, n, bits, iters, pay, st, var, sv);
+        HIPCK(hipGetLastError());
     }
-    HIPCK(hipGetLastError());
     if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][3], s)); ++c->ev_count; c->ev_fe[c->ev_count % mgpu_ctx::kEvRing] = false; }
 }
 
@@ -376,6 +418,7 @@ int mgpu_frontend_dev(mgpu_ctx* c, const void* d_bb, int F, void* d_llr, void* d
     return guard(c, [&] {
         need(d_bb && d_llr && F >= 0 && F <= c->max_batch, "bad argument (F must be <= max_batch)");
         if (F == 0) return;
+        ensure_workspaces(c, WS_FRONTEND);
         MgpuTapsDev taps{};
         launch_frontend(c, static_cast<const double*>(d_bb), F, static_cast<float*>(d_llr),
                         d_variance_f ? static_cast<float*>(d_variance_f) : c->d_variance, c->d_snrvar, taps, static_cast<hipStream_t>(stream));
@@ -400,6 +443,7 @@ int mgpu_rx_batch_dev(mgpu_ctx* c, const void* d_bb, int F, void* d_payload, voi
         need(d_bb && d_payload && d_stats && F >= 0 && F <= c->max_batch, "bad argument (F must be <= max_batch)");
         if (F == 0) return;
         hipStream_t s = static_cast<hipStream_t>(stream);
+        ensure_workspaces(c, WS_FRONTEND | (d_llr_opt ? 0u : unsigned(WS_LLR)));
         float* llr = d_llr_opt ? static_cast<float*>(d_llr_opt) : c->d_llr;
         MgpuTapsDev taps{};
         launch_frontend(c, static_cast<const double*>(d_bb), F, llr, c->d_variance, c->d_snrvar, taps, s);
@@ -415,9 +459,13 @@ int mgpu_txgen_dev(mgpu_ctx* c, uint64_t seed, uint64_t frame0, int F, double no
     return guard(c, [&] {
         need(d_bb && F >= 0 && (channel == 0 || channel == 1), "bad argument");
         if (F == 0) return;
-        hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(F), dim3(256), c->lds_tx, static_cast<hipStream_t>(stream), c->dev, seed,
-                           frame0, F, noise_amp, channel, static_cast<double*>(d_bb), static_cast<uint8_t*>(d_payload_opt));
-        HIPCK(hipGetLastError());
+        for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
+            const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
+            hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(n), dim3(256), c->lds_tx, static_cast<hipStream_t>(stream), c->dev, seed,
+                               frame0 + uint64_t(off), n, noise_amp, channel, static_cast<double*>(d_bb) + size_t(off) * c->tab.frame_samples * 2,
+                               at(static_cast<uint8_t*>(d_payload_opt), size_t(off) * c->tab.payload_stride));
+            HIPCK(hipGetLastError());
+        }
     });
 }
 
@@ -537,6 +585,7 @@ int mgpu_rx_batch_taps(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, m
         if (F == 0) return;
         const auto& t = c->tab;
         const size_t in_bytes = size_t(F) * t.frame_samples * 16;
+        ensure_workspaces(c, WS_FRONTEND | WS_LLR | WS_OUT);
         if (c->baseband_cap < in_bytes) {
             (void)hipFree(c->d_baseband);
             c->d_baseband = nullptr; c->baseband_cap = 0;
@@ -590,6 +639,7 @@ int mgpu_ldpc_batch(mgpu_ctx* c, const float* llr, int F, uint8_t* bits, int* it
         if (F == 0) return;
         const auto& t = c->tab;
         hipStream_t s = c->stream;
+        ensure_workspaces(c, WS_LLR | WS_BITS);
         HIPCK(hipMemcpyAsync(c->d_llr, llr, size_t(F) * t.N * 4, hipMemcpyHostToDevice, s));
         launch_decoder(c, c->d_llr, F, c->d_bits, c->d_iters, nullptr, nullptr, nullptr, nullptr, s);
         if (bits) HIPCK(hipMemcpyAsync(bits, c->d_bits, size_t(F) * t.K, hipMemcpyDeviceToHost, s));

@@ -30,6 +30,7 @@ struct MgpuDev {
     int estimator, amp_restore, lsw;
     int payload_bytes, payload_stride, frame_samples;
     int agc, var_eq, max_iters;
+    int staircase;                 // LDPC parity part is the plain IRA staircase (check c holds parity c-1 and c only)
     int regular_lattice;           // pilots exactly where (row - col) % 3 == 0 (true for all 17 modes)
     double pilot_boost;
     float minsum_alpha;

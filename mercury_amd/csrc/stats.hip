@@ -22,7 +22,8 @@ extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_zf_snr_kernel(
     uint8_t* bits = smem;               // K data bits (re-scrambled, virtual copy)
     uint8_t* enc = bits + 1600;         // N encoded bits
     uint8_t* inter = enc + 1600;        // nBits interleaved
-    uint8_t* par = inter + 1600;        // info part of each parity check
+    uint8_t* par = inter + 1600;
+    __shared__ uint8_t wpar[32];        // info part of each parity check
     double* term = reinterpret_cast<double*>(par + 1600);
     const int tid = threadIdx.x, f = blockIdx.x;
     if (f >= F) return;
@@ -40,7 +41,24 @@ extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_zf_snr_kernel(
         par[c] = x;
     }
     __syncthreads();
-    if (tid == 0) {
+    // IRA staircase: check c (c >= 1) holds, besides its own parity bit K+c, only parity bit K+c-1, so
+    // parity[c] = XOR of par[0..c]: a prefix XOR done in three small steps (word parities, carries, per-bit)
+    if (T.staircase) {
+        const int nw = (P + 63) / 64;
+        for (int k = tid; k < nw; k += ST_THREADS) {
+            uint8_t x = 0;
+            for (int c = k * 64; c < min(P, k * 64 + 64); ++c) x ^= par[c];
+            wpar[k] = x;
+        }
+        __syncthreads();
+        if (tid == 0) { uint8_t x = 0; for (int k = 0; k < nw; ++k) { const uint8_t y = wpar[k]; wpar[k] = x; x ^= y; } }
+        __syncthreads();
+        for (int c = tid; c < P; c += ST_THREADS) {
+            uint8_t x = wpar[c >> 6];
+            for (int q = c & ~63; q <= c; ++q) x ^= par[q];
+            enc[K + c] = x;
+        }
+    } else if (tid == 0) {
         for (int c = 0; c < P; ++c) {
             uint8_t x = par[c];
             for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) { const int v = T.cvar[e]; if (v >= K && v != K + c) x ^= enc[v]; }

@@ -50,6 +50,7 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
     uint8_t* enc = bits + 1600;         // encoded word N
     uint8_t* inter = enc + 1600;        // interleaved nBits
     uint8_t* par = inter + 1600;        // info-part parity per check
+    __shared__ uint8_t wpar[32];        // parity of each 64-check word (prefix-XOR carries)
     c2* grid = reinterpret_cast<c2*>(par + 1600);
     c2* fftb = grid + T.G;
     c2* tw = fftb + 4 * 256;
@@ -102,7 +103,24 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
         par[c] = x;
     }
     __syncthreads();
-    if (tid == 0) {
+    // IRA staircase: check c (c >= 1) holds, besides its own parity bit K+c, only parity bit K+c-1, so
+    // parity[c] = XOR of par[0..c]: a prefix XOR done in three small steps (word parities, carries, per-bit)
+    if (T.staircase) {
+        const int nw = (P + 63) / 64;
+        for (int k = tid; k < nw; k += TX_THREADS) {
+            uint8_t x = 0;
+            for (int c = k * 64; c < min(P, k * 64 + 64); ++c) x ^= par[c];
+            wpar[k] = x;
+        }
+        __syncthreads();
+        if (tid == 0) { uint8_t x = 0; for (int k = 0; k < nw; ++k) { const uint8_t y = wpar[k]; wpar[k] = x; x ^= y; } }
+        __syncthreads();
+        for (int c = tid; c < P; c += TX_THREADS) {
+            uint8_t x = wpar[c >> 6];
+            for (int q = c & ~63; q <= c; ++q) x ^= par[q];
+            enc[K + c] = x;
+        }
+    } else if (tid == 0) {
         for (int c = 0; c < P; ++c) {
             uint8_t x = par[c];
             for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) { const int v = T.cvar[e]; if (v >= K && v != K + c) x ^= enc[v]; }
