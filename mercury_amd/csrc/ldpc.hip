@@ -92,7 +92,7 @@ extern "C" size_t mgpu_spa_lds_bytes(int S, int N) {
 // the two edge-parallel phases touch no index memory at all. The syndrome costs nothing extra: in
 // the Q/tanh phase every lane already holds the posterior of its edge's variable, one 64-bit ballot
 // of the sign bits gives every check its parity.
-// Per iteration: check update | barrier | variable update | barrier | syndrome + Q/tanh | barrier.
+// Per iteration: check update | barrier | variable update | barrier | syndrome [| barrier | verdict] | Q/tanh.
 // Up to eight slot descriptors per lane held in named registers (an indexed array would be demoted
 // to scratch memory); get(r) selects by the wave-uniform round number.
 struct SlotRegs {
@@ -171,60 +171,33 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         return (__popcll(m & cm) & 1) != 0;
     };
 
-    // initial syndrome (ldpc_decoder_SPA.cc:62-76) and Q = llr on every edge (:106-122) -> T
-    {
+    // Pass p (0 = channel values, 1..max = after iteration p) leaves its syndrome verdict in flag[p & 1].
+    // syndrome_pass: every lane holds the posterior of its edge's variable -> ballot + popcount per check.
+    auto syndrome_pass = [&](int p) {
         bool unsat = false;
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
             const uint32_t k = pk.get(r);
             const bool valid = ((k >> 13) & 0x3f) != 0;
-            const float l = valid ? Li[k >> 19] : 0.0f;
-            unsat |= check_parity(k, valid && l < 0) && valid;
-            if (valid) M[tid + r * LDPC_THREADS] = spa_tanh(0.5 * double(l));
+            const double lt = valid ? Lt[k >> 19] : 0.0;
+            unsat |= check_parity(k, valid && lt < 0) && valid;
         }
-        if (unsat) flag[0] = 1;
-    }
-    // The syndrome of pass `it` (0 = channel values) lands in flag[it & 1]. A wave's check update only
-    // reads T values its own lanes wrote, so it may start the next check update before anybody has
-    // looked at the flag: the verdict is read behind the barrier that follows that check update, and
-    // on convergence the speculative update is simply dropped (it never touches the posteriors).
-    int iteration = 0;
-    for (int it = 1;; ++it) {
-        const bool last = it > T.max_iters;
-        if (!last) {
-            // check update (:129-160), in place
+        if (unsat) flag[p & 1] = 1;
+    };
+    // tanh_pass: Q = LLRtmp - R (:193-209; R == 0 before the first iteration, :106-122) -> T = tanh(0.5*Q) in place
+    auto tanh_pass = [&](bool first) {
 #pragma unroll 1
-            for (int r = 0; r < NE; ++r) {
-                const uint32_t k = pk.get(r);
-                const int deg = (k >> 13) & 0x3f;
-                const bool valid = deg != 0;
-                double rr = 0.0;
-                if (valid) {
-                    const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
-                    double temp = 1;
-                    for (int j = 0; j < deg; ++j) {
-                        const double m = M[cs + j];
-                        temp *= (j == pos) ? 1.0 : m;      // x * 1.0 == x exactly: same product as skipping j == pos
-                    }
-                    if (temp == 1) temp = 0.9999999;
-                    if (temp == -1) temp = -0.9999999;
-                    rr = 2 * spa_atanh(temp);
-                }
-                __builtin_amdgcn_wave_barrier();   // every lane of this wave has read its check's T values
-                if (valid) M[tid + r * LDPC_THREADS] = rr;
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t k = pk.get(r);
+            if (((k >> 13) & 0x3f) != 0) {
+                const int p = tid + r * LDPC_THREADS;
+                const double q = first ? double(Li[k >> 19]) : Lt[k >> 19] - M[p];
+                M[p] = spa_tanh(0.5 * q);
             }
         }
-        __syncthreads();
-        const int unsat_prev = flag[(it - 1) & 1];          // syndrome of pass it-1
-        if (!unsat_prev) { iteration = it - 1; break; }
-        if (last) { iteration = T.max_iters + 1; break; }
-        if (tid == 0) flag[it & 1] = 0;
-        // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count;
-        // each lane owns variables tid and tid+1024 of that order, their records live in registers
-        var_update(va);
-        if (tid + LDPC_THREADS < N) var_update(vb);
-        __syncthreads();
-        // syndrome (:173-190) and Q = LLRtmp - R (:193-209) -> T for the next check update
+    };
+    // fused_pass: both in one sweep (one posterior read per edge) for the iterations whose verdict is deferred
+    auto fused_pass = [&](int p) {
         bool unsat = false;
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
@@ -233,11 +206,70 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             const double lt = valid ? Lt[k >> 19] : 0.0;
             unsat |= check_parity(k, valid && lt < 0) && valid;
             if (valid) {
-                const int p = tid + r * LDPC_THREADS;
-                M[p] = spa_tanh(0.5 * (lt - M[p]));
+                const int q = tid + r * LDPC_THREADS;
+                M[q] = spa_tanh(0.5 * (lt - M[q]));
             }
         }
-        if (unsat) flag[it & 1] = 1;
+        if (unsat) flag[p & 1] = 1;
+    };
+    // The first kSpecStart passes are judged exactly: syndrome | barrier | verdict, and only unconverged frames
+    // pay for the tanh pass and the next check update (at the operating SNRs most frames stop within a few
+    // iterations, so nothing is computed in vain). From then on a frame is likely to run long and the verdict
+    // moves behind the barrier that follows the NEXT check update: a wave's check update reads only T values its
+    // own lanes wrote, so it can start at once; on convergence the speculative update is dropped (it never
+    // touches the posteriors). That saves one barrier per iteration where iterations are many.
+    constexpr int kSpecStart = 8;
+    int iteration = 0;
+    syndrome_pass(0);                                   // initial syndrome (ldpc_decoder_SPA.cc:62-76)
+    __syncthreads();
+    if (flag[0]) {
+        tanh_pass(true);
+        for (int it = 1;; ++it) {
+            const bool past_end = it > T.max_iters;     // only reachable in speculative mode
+            if (!past_end) {
+                // check update (:129-160), in place
+#pragma unroll 1
+                for (int r = 0; r < NE; ++r) {
+                    const uint32_t k = pk.get(r);
+                    const int deg = (k >> 13) & 0x3f;
+                    const bool valid = deg != 0;
+                    double rr = 0.0;
+                    if (valid) {
+                        const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
+                        double temp = 1;
+                        for (int j = 0; j < deg; ++j) {
+                            const double m = M[cs + j];
+                            temp *= (j == pos) ? 1.0 : m;      // x * 1.0 == x exactly: same product as skipping j == pos
+                        }
+                        if (temp == 1) temp = 0.9999999;
+                        if (temp == -1) temp = -0.9999999;
+                        rr = 2 * spa_atanh(temp);
+                    }
+                    __builtin_amdgcn_wave_barrier();   // every lane of this wave has read its check's T values
+                    if (valid) M[tid + r * LDPC_THREADS] = rr;
+                }
+            }
+            __syncthreads();
+            if (it - 1 >= kSpecStart) {                 // deferred verdict of pass it-1
+                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
+                if (past_end) { iteration = T.max_iters + 1; break; }
+            }
+            if (tid == 0) flag[it & 1] = 0;
+            // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count;
+            // each lane owns variables tid and tid+1024 of that order, their records live in registers
+            var_update(va);
+            if (tid + LDPC_THREADS < N) var_update(vb);
+            __syncthreads();
+            if (it < kSpecStart) {
+                syndrome_pass(it);                      // (:173-190)
+                __syncthreads();
+                if (!flag[it & 1]) { iteration = it; break; }
+                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
+                tanh_pass(false);
+            } else {
+                fused_pass(it);
+            }
+        }
     }
     for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
     __syncthreads();
@@ -393,60 +425,28 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
         const unsigned long long cm = ((deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << l0);
         return (__popcll(m & cm) & 1) != 0;
     };
-    {
+    auto syndrome_pass = [&](int p) {
         bool unsat = false;
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
             const uint32_t k = pk.get(r);
             const bool valid = ((k >> 13) & 0x3f) != 0;
-            const float l = valid ? Li[k >> 19] : 0.0f;
-            unsat |= check_parity(k, valid && l < 0) && valid;
-            if (valid) M[tid + r * LDPC_THREADS] = l;
+            const float lt = valid ? Lt[k >> 19] : 0.0f;
+            unsat |= check_parity(k, valid && lt < 0) && valid;
         }
-        if (unsat) flag[0] = 1;
-    }
-    // iteration counts follow the reference's convention: 0 = input already a codeword,
-    // k = converged after k iterations, max+1 = never converged.
-    int iteration = 0;
-    for (int it = 1;; ++it) {
-        const bool last = it > T.max_iters;
-        if (!last) {
+        if (unsat) flag[p & 1] = 1;
+    };
+    auto extrinsic_pass = [&](bool first) {            // Q = posterior - R (R == 0 before the first iteration)
 #pragma unroll 1
-            for (int r = 0; r < NE; ++r) {
-                const uint32_t k = pk.get(r);
-                const int deg = (k >> 13) & 0x3f;
-                const bool valid = deg != 0;
-                float rr = 0.0f;
-                if (valid) {
-                    const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
-                    // two smallest magnitudes and the sign product over ALL edges of the check (every lane of the
-                    // check runs the same scan on broadcast reads); the own edge is taken out afterwards:
-                    // min over the others = (|own| == min1) ? min2 : min1  (a tie leaves min2 == min1).
-                    float mn1 = __builtin_inff(), mn2 = __builtin_inff();
-                    uint32_t sg = 0;
-                    for (int j = 0; j < deg; ++j) {
-                        const float m = M[cs + j];
-                        sg ^= __float_as_uint(m);
-                        const float a = __builtin_fabsf(m);
-                        mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);   // second smallest of {mn1, mn2, a}
-                        mn1 = fminf(mn1, a);
-                    }
-                    const float own = M[cs + pos];
-                    const float mag = (__builtin_fabsf(own) == mn1) ? mn2 : mn1;
-                    rr = __uint_as_float(__float_as_uint(mag * alpha) | ((sg ^ __float_as_uint(own)) & 0x80000000u));
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (valid) M[tid + r * LDPC_THREADS] = rr;
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t k = pk.get(r);
+            if (((k >> 13) & 0x3f) != 0) {
+                const int p = tid + r * LDPC_THREADS;
+                M[p] = first ? Li[k >> 19] : Lt[k >> 19] - M[p];
             }
         }
-        __syncthreads();
-        const int unsat_prev = flag[(it - 1) & 1];
-        if (!unsat_prev) { iteration = it - 1; break; }
-        if (last) { iteration = T.max_iters + 1; break; }
-        if (tid == 0) flag[it & 1] = 0;
-        var_update(va);
-        if (tid + LDPC_THREADS < N) var_update(vb);
-        __syncthreads();
+    };
+    auto fused_pass = [&](int p) {
         bool unsat = false;
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
@@ -455,11 +455,71 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
             const float lt = valid ? Lt[k >> 19] : 0.0f;
             unsat |= check_parity(k, valid && lt < 0) && valid;
             if (valid) {
-                const int p = tid + r * LDPC_THREADS;
-                M[p] = lt - M[p];
+                const int q = tid + r * LDPC_THREADS;
+                M[q] = lt - M[q];
             }
         }
-        if (unsat) flag[it & 1] = 1;
+        if (unsat) flag[p & 1] = 1;
+    };
+    // iteration counts follow the reference's convention: 0 = input already a codeword,
+    // k = converged after k iterations, max+1 = never converged. Exact verdicts for the first kSpecStart passes,
+    // deferred (speculative check update) afterwards — see the sum-product kernel.
+    constexpr int kSpecStart = 8;
+    int iteration = 0;
+    syndrome_pass(0);
+    __syncthreads();
+    if (flag[0]) {
+        extrinsic_pass(true);
+        for (int it = 1;; ++it) {
+            const bool past_end = it > T.max_iters;
+            if (!past_end) {
+#pragma unroll 1
+                for (int r = 0; r < NE; ++r) {
+                    const uint32_t k = pk.get(r);
+                    const int deg = (k >> 13) & 0x3f;
+                    const bool valid = deg != 0;
+                    float rr = 0.0f;
+                    if (valid) {
+                        const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
+                        // two smallest magnitudes and the sign product over ALL edges of the check (every lane of the
+                        // check runs the same scan on broadcast reads); the own edge is taken out afterwards:
+                        // min over the others = (|own| == min1) ? min2 : min1  (a tie leaves min2 == min1).
+                        float mn1 = __builtin_inff(), mn2 = __builtin_inff();
+                        uint32_t sg = 0;
+                        for (int j = 0; j < deg; ++j) {
+                            const float m = M[cs + j];
+                            sg ^= __float_as_uint(m);
+                            const float a = __builtin_fabsf(m);
+                            mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);   // second smallest of {mn1, mn2, a}
+                            mn1 = fminf(mn1, a);
+                        }
+                        const float own = M[cs + pos];
+                        const float mag = (__builtin_fabsf(own) == mn1) ? mn2 : mn1;
+                        rr = __uint_as_float(__float_as_uint(mag * alpha) | ((sg ^ __float_as_uint(own)) & 0x80000000u));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid) M[tid + r * LDPC_THREADS] = rr;
+                }
+            }
+            __syncthreads();
+            if (it - 1 >= kSpecStart) {
+                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
+                if (past_end) { iteration = T.max_iters + 1; break; }
+            }
+            if (tid == 0) flag[it & 1] = 0;
+            var_update(va);
+            if (tid + LDPC_THREADS < N) var_update(vb);
+            __syncthreads();
+            if (it < kSpecStart) {
+                syndrome_pass(it);
+                __syncthreads();
+                if (!flag[it & 1]) { iteration = it; break; }
+                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
+                extrinsic_pass(false);
+            } else {
+                fused_pass(it);
+            }
+        }
     }
     for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
     __syncthreads();
