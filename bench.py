@@ -115,6 +115,50 @@ def cpu_baseline(cfg, max_iters, bb_sample, flags, gpu_payload, gpu_stats):
     return out
 
 
+def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
+    """Secondary measurements on rank 0's GPU, outside the contract's timed region: the other decoder on the same
+    inputs, and the same decoder at the mode's operating point (threshold + 3 dB) where early termination works."""
+    import oraclelib  # only for the Es/N0 table of the modes (conftest constants), no compute
+    from conftest import OPERATING_ESN0
+    out = {}
+
+    def timed(phy, inputs, steps=3):
+        for i in range(2):
+            phy.receive_dev(inputs[i % len(inputs)].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        phy.enable_timing(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            phy.receive_dev(inputs[i % len(inputs)].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fe, dec, _ = phy.kernel_ms_avg()
+        phy.enable_timing(False)
+        it = float(stats[:, 0].clamp(max=args.iters).sum().item()) / F
+        ok = float(stats[:, 3].sum().item()) / F
+        return {"frames_per_s": F * steps / dt, "frontend_ms": fe, "ldpc_ms": dec, "avg_iters": it, "decoded_fraction": ok}
+
+    other = "minsum" if args.decoder == "spa" else "spa"
+    agc, vs = (1, 1) if args.variant == "receive_byte" else (0, 0)
+    rx2 = RxPhy(args.cfg, max_iters=args.iters, decoder={"spa": DEC_SPA, "minsum": DEC_MINSUM}[other], agc=agc, variance_source=vs,
+                device=dev.index, max_batch=F)
+    m = timed(rx2, bufs)
+    ldpc_bytes, _, _ = algorithmic_bytes(rx2, m["avg_iters"] * F, F)
+    m["roofline_frac_algorithmic"] = ldpc_bytes / (m["ldpc_ms"] * 1e-3) / HBM_PEAK
+    out["same_inputs_decoder_" + other] = m
+    op = OPERATING_ESN0[args.cfg] + 1.0
+    amp = float(10.0 ** (-op / 20.0) / np.sqrt(2.0))
+    bb = torch.empty((F, rx.frame_samples, 2), dtype=torch.float64, device=dev)
+    rx.txgen_dev(SEED, 1 << 40, F, amp, bb.data_ptr(), None, channel=args.channel, stream=stream)
+    torch.cuda.synchronize()
+    for name, phy in ((args.decoder, rx), (other, rx2)):
+        r = timed(phy, [bb])
+        r["esn0_db"] = op
+        out["operating_point_decoder_" + name] = r
+    rx2.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +176,7 @@ def main():
     ap.add_argument("--channel", type=int, default=0, help="0 = AWGN, 1 = static 2-path + AWGN (BASELINE.json configs[3])")
     ap.add_argument("--ldpc-only", action="store_true",
                     help="BASELINE.json configs[4]: decoder-only soak on noise-only LLRs (every codeword runs --iters iterations)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary per-GPU measurements (min-sum, operating point)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -262,6 +307,8 @@ def main():
                                  "traffic is far lower; the decoder is VALU-issue bound (profiles/r01_pmc_sq_*.csv: SQ_ACTIVE_INST_VALU "
                                  "~99% of SIMD cycles for spa, fp64), not HBM bound"},
         }
+        if not args.no_extras and not args.ldpc_only:
+            line["extras_per_gpu"] = extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp)
         if world == 1 and not args.no_cpu_baseline and not args.ldpc_only:
             cores = usable_cores()
             S = min(F, args.cpu_sample_per_core * cores)

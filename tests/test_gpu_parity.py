@@ -288,7 +288,7 @@ def test_bench_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29633", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--frames", "256", "--esn0", "2.5", "--backend", "gloo", "--share-device"]
+           "--frames", "256", "--esn0", "2.5", "--backend", "gloo", "--share-device", "--no-extras"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

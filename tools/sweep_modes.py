@@ -17,7 +17,7 @@ from conftest import OPERATING_ESN0  # noqa: E402
 def run(cfg, decoder, esn0, frames, steps=3):
     variant = "baseband_test" if cfg in (15, 16) else "receive_byte"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cfg", str(cfg), "--decoder", decoder, "--esn0", str(esn0),
-           "--frames", str(frames), "--steps", str(steps), "--warmup", "1", "--nbuf", "1", "--variant", variant, "--no-cpu-baseline"]
+           "--frames", str(frames), "--steps", str(steps), "--warmup", "1", "--nbuf", "1", "--variant", variant, "--no-cpu-baseline", "--no-extras"]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
     j = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     return {"frames_per_s": j["value"], "ldpc_iters_per_s": j["ldpc_iters_per_s"], "avg_iters": j["avg_iters_per_frame"],
