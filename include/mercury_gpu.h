@@ -17,7 +17,10 @@
  *                       (include/physical_layer/interleaver.h:28-34), cl_psk::demod
  *                       (include/physical_layer/psk.h:55), cl_ldpc::decode
  *                       (include/physical_layer/ldpc.h:90), bit_energy_dispersal, bit_to_byte,
- *                       CRC16_MODBUS_RTU_calc.
+ *                       CRC16_MODBUS_RTU_calc. For cfg 100..102 (ROBUST_0..2) the front half is the
+ *                       M == MOD_MFSK branch instead: symbol_demod + cl_mfsk::demod
+ *                       (include/physical_layer/mfsk.h:80 -> source/physical_layer/mfsk.cc:288-390),
+ *                       telecom_system.cc:1132-1192; agc / variance_source are ignored.
  *   mgpu_ldpc_batch*    int cl_ldpc::decode(const float* data, int* decoded_data)
  *                       (include/physical_layer/ldpc.h:90 -> source/physical_layer/ldpc.cc:266-278)
  *   mgpu_frame_stats    st_receive_stats fields iterations_done, crc, all_zeros, SNR,
@@ -57,7 +60,7 @@ extern "C" {
 typedef struct mgpu_ctx mgpu_ctx;
 
 typedef struct mgpu_config {
-    int cfg;              /* Mercury CONFIG_0..CONFIG_16 */
+    int cfg;              /* Mercury CONFIG_0..CONFIG_16, or 100..102 = ROBUST_0..2 (MFSK, common_defines.h:63-65) */
     int max_iters;        /* nIteration_max, reference default 50 (physical_config.cc:74), CLI 5..50 */
     int decoder;          /* MGPU_DEC_* */
     int agc;              /* 1 = automatic_gain_control before the estimator (receive_byte) */
@@ -65,6 +68,8 @@ typedef struct mgpu_config {
     int device;           /* HIP device ordinal */
     int max_batch;        /* largest F any call will pass; sizes the device workspaces */
     float minsum_alpha;   /* normalisation factor for MGPU_DEC_MINSUM (0 -> 0.8) */
+    int mfsk_ctrl_mode;   /* 1 = short MFSK control frames (cl_telecom_system::set_mfsk_ctrl_mode, telecom_system.cc:1572);
+                             ignored unless cfg is ROBUST_0 / ROBUST_1 */
 } mgpu_config;
 
 typedef struct mgpu_info {
@@ -76,7 +81,9 @@ typedef struct mgpu_info {
     int Cwidth, Vwidth, E;
     int payload_bytes;    /* (nReal-16)/8, telecom_system.cc:332-335 */
     int payload_stride;   /* bytes between consecutive frames in payload arrays = ceil(nReal/8) */
-    int frame_samples;    /* complex samples per frame = Nsymb*Nofdm */
+    int frame_samples;    /* complex samples per frame = active_nsymb*Nofdm */
+    int mfsk_M, mfsk_nStreams;       /* tones per stream / parallel streams (mfsk.h:36-39); 0 for the OFDM modes */
+    int active_nsymb, active_nbits;  /* get_active_nsymb / get_active_nbits (telecom_system.cc:1577-1585) */
 } mgpu_info;
 
 /* mirrors st_receive_stats (telecom_system.h:63-82) for the fields this path produces */
@@ -91,7 +98,7 @@ typedef struct mgpu_frame_stats {
 
 /* optional per-stage taps (host pointers, any may be NULL) for parity testing */
 typedef struct mgpu_stage_taps {
-    double* grid;       /* [F][Nsymb*Nc][2]  after symbol_demod (+AGC) */
+    double* grid;       /* [F][Nsymb*Nc][2]  after symbol_demod (+AGC); MFSK: first active_nsymb rows */
     double* H;          /* [F][Nsymb*Nc][2]  channel after estimate/interp/amp-restore */
     double* eq;         /* [F][Nsymb*Nc][2]  equalised grid */
     double* syms;       /* [F][nData][2]     de-framed, time/freq de-interleaved */

@@ -26,6 +26,8 @@ extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
 extern "C" size_t mgpu_txgen_lds_bytes(int G);
 
 extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
+extern "C" __global__ void mgpu_mfsk_frontend_kernel(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
+extern "C" int mgpu_mfsk_syms_per_block();
 extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
 extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*);
@@ -118,6 +120,7 @@ void ctx_alloc(mgpu_ctx* c) {
     d.llr_src = c->keep(upload(t.llr_src));
     d.ls_weight = c->keep(upload(t.ls_weight));
     d.scrambler = c->keep(upload(t.scrambler));
+    d.llr_dst = c->keep(upload(t.llr_dst));
     d.bit_il = c->keep(upload(t.bit_il));
     c->d_fir[0] = c->keep(upload(t.fir_time_sync));
     c->d_fir[1] = c->keep(upload(t.fir_data));
@@ -150,6 +153,9 @@ void ctx_alloc(mgpu_ctx* c) {
         for (int q = 0; q < t.Nc; ++q)
             if ((t.cell_type[size_t(r) * t.Nc + q] != 0) != (((r - q) % 3 + 3) % 3 == 0)) d.regular_lattice = 0;
     d.minsum_alpha = c->cfg.minsum_alpha > 0 ? c->cfg.minsum_alpha : 0.8f;
+    d.mfsk_M = t.mfsk_M; d.mfsk_nbits = t.mfsk_nbits; d.mfsk_nstreams = t.mfsk_nstreams; d.mfsk_hop = t.mfsk_hop;
+    d.mfsk_off0 = t.mfsk_off[0]; d.mfsk_off1 = t.mfsk_off[1];
+    d.active_nsymb = t.active_nsymb; d.active_nbits = t.active_nbits; d.mfsk_amp = t.mfsk_amp;
     LdpcDev& l = c->ldev;
     l.spack = d.spack; l.svar = d.svar; l.vinfo = d.vinfo; l.scrambler = d.scrambler;
     l.cptr = d.cptr; l.cvar = d.cvar;
@@ -160,9 +166,10 @@ void ctx_alloc(mgpu_ctx* c) {
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));
     for (auto& e : c->sync_ev) HIPCK(hipEventCreate(&e));
 
-    c->lds_fe = mgpu_frontend_lds_bytes(d.G);
-    c->lds_tx = mgpu_txgen_lds_bytes(d.G);
-    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_frontend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_fe)));
+    const bool mfsk = t.mfsk_M > 0;      // the MFSK front-end keeps no frame grid in LDS (csrc/mfsk.hip)
+    c->lds_fe = mfsk ? 0 : mgpu_frontend_lds_bytes(d.G);
+    c->lds_tx = mgpu_txgen_lds_bytes(mfsk ? 0 : d.G);
+    if (!mfsk) HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_frontend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_fe)));
     HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_txgen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_tx)));
     switch (c->cfg.decoder) {
         case MGPU_DEC_SPA:
@@ -228,6 +235,21 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
     const int slot = c->ev_count % mgpu_ctx::kEvRing;
     const auto& t = c->tab;
     if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][0], s)); c->ev_fe[slot] = true; }
+    if (t.mfsk_M > 0) {
+        // MFSK modes: workgroups of (frame, run of symbols); keep gridDim * blockDim below 2^32
+        const int per = mgpu_mfsk_syms_per_block(), chunks = (t.active_nsymb + per - 1) / per;
+        const int max_frames = (1 << 23) / chunks;
+        for (int off = 0; off < F; off += max_frames) {
+            const int n = F - off < max_frames ? F - off : max_frames;
+            if (off && (taps.grid || taps.llr_demod || taps.variance || taps.agc_gain))
+                throw std::invalid_argument("stage taps are limited to one launch per call");
+            hipLaunchKernelGGL(mgpu_mfsk_frontend_kernel, dim3(unsigned(n) * chunks), dim3(256), 0, s, c->dev,
+                               d_bb + size_t(off) * t.frame_samples * 2, n, chunks, d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), taps);
+            HIPCK(hipGetLastError());
+        }
+        if (c->timing) HIPCK(hipEventRecord(c->ev[slot][1], s));
+        return;
+    }
     for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
         const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
         if (off && (taps.grid || taps.H || taps.eq || taps.syms || taps.llr_demod || taps.variance || taps.agc_gain))
@@ -315,7 +337,10 @@ extern "C" {
 int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return MGPU_ERR_ARG; }
     *out = nullptr;
-    if (cfg->cfg < 0 || cfg->cfg > 16) { g_create_error = "cfg must be 0..16"; return MGPU_ERR_ARG; }
+    if (!((cfg->cfg >= 0 && cfg->cfg <= 16) || (cfg->cfg >= 100 && cfg->cfg <= 102))) {
+        g_create_error = "cfg must be 0..16 (OFDM modes) or 100..102 (ROBUST MFSK modes)";
+        return MGPU_ERR_ARG;
+    }
     if (cfg->max_iters < 1 || cfg->max_iters > 1000) { g_create_error = "max_iters out of range"; return MGPU_ERR_ARG; }
     if (cfg->decoder < 0 || cfg->decoder > 2) { g_create_error = "unknown decoder"; return MGPU_ERR_ARG; }
     if (cfg->max_batch < 1) { g_create_error = "max_batch must be >= 1"; return MGPU_ERR_ARG; }
@@ -334,7 +359,7 @@ int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
             blob_size = file_blob.size();
         }
         try {
-            c->tab = mgpu::build_mode_tables(cfg->cfg, blob, blob_size);
+            c->tab = mgpu::build_mode_tables(cfg->cfg, cfg->mfsk_ctrl_mode, blob, blob_size);
         } catch (const std::exception& e) {
             g_create_error = e.what();
             delete c;
@@ -377,6 +402,7 @@ int mgpu_get_info(mgpu_ctx* c, mgpu_info* i) {
     i->estimator = t.estimator; i->amp_restore = t.amp_restore; i->ls_window = t.lsw;
     i->Cwidth = t.graph.Cwidth; i->Vwidth = t.graph.Vwidth; i->E = t.graph.E;
     i->payload_bytes = t.payload_bytes; i->payload_stride = t.payload_stride; i->frame_samples = t.frame_samples;
+    i->mfsk_M = t.mfsk_M; i->mfsk_nStreams = t.mfsk_nstreams; i->active_nsymb = t.active_nsymb; i->active_nbits = t.active_nbits;
     return MGPU_OK;
 }
 
@@ -599,7 +625,8 @@ int mgpu_rx_batch_taps(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, m
         const size_t G = size_t(t.Nsymb) * t.Nc;
         auto dalloc = [&](size_t bytes) { void* p = nullptr; HIPCK(hipMalloc(&p, bytes)); tmp.push_back(p); return p; };
         if (taps) {
-            if (taps->grid) dt.grid = static_cast<double*>(dalloc(F * G * 16));
+            if (taps->grid) { dt.grid = static_cast<double*>(dalloc(F * G * 16)); if (t.mfsk_M > 0) HIPCK(hipMemsetAsync(dt.grid, 0, F * G * 16, s)); }
+            need(t.mfsk_M == 0 || !(taps->H || taps->eq || taps->syms), "the MFSK modes have no channel estimate / equalised grid to tap");
             if (taps->H) dt.H = static_cast<double*>(dalloc(F * G * 16));
             if (taps->eq) dt.eq = static_cast<double*>(dalloc(F * G * 16));
             if (taps->syms) dt.syms = static_cast<double*>(dalloc(size_t(F) * t.nData * 16));

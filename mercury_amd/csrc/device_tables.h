@@ -14,6 +14,7 @@ struct MgpuDev {
     const uint16_t* llr_src;       // [1600]
     const double* ls_weight;       // [lsw*lsw+1]
     const uint8_t* scrambler;      // [1600]
+    const uint16_t* llr_dst;       // [nBits] MFSK modes: decoder position of demodulated LLR i
     // generator
     const uint16_t* bit_il;        // [nBits]
     const uint16_t* tf_inv;        // [nData] modulated-symbol index landing at de-framed position i
@@ -34,6 +35,10 @@ struct MgpuDev {
     int regular_lattice;           // pilots exactly where (row - col) % 3 == 0 (true for all 17 modes)
     double pilot_boost;
     float minsum_alpha;
+    // MFSK modes (mfsk_M == 0 for the OFDM modes)
+    int mfsk_M, mfsk_nbits, mfsk_nstreams, mfsk_hop, mfsk_off0, mfsk_off1;
+    int active_nsymb, active_nbits;
+    double mfsk_amp;
 };
 
 // Slim argument block for the decoder kernels: only what they touch, so the kernarg does not

@@ -1,0 +1,68 @@
+// 256-point radix-2 DIT FFT of one OFDM symbol per wavefront, bit-identical to the reference's
+// _fft_fast / _ifft_fast (ofdm.cc:310-340, :343-377; twiddle table :256-290).
+//
+// The reference permutes the input by bit reversal and then runs stages size = 2..256 in place. Here the data
+// stay in natural order: element idx of the permuted array lives at position p = brev8(idx), so stage st pairs
+// positions p and p + 2^(8-st), and bin k ends up at position brev8(k). Every butterfly has the same operands
+// and the same twiddle (index (brev8(p0) & (2^(st-1)-1)) * 2^(8-st)) as the reference's, hence the same
+// roundings. A lane holds four elements and does two stages in registers between LDS transpositions
+// (partners 64, 16, 4 and 1 positions apart in turn): 3 round trips through LDS instead of 8, all of them
+// contiguous or padded (address = p + p/16) so that no access pattern collides on a bank. The work buffer is
+// private to the wavefront and the LDS operations of one wavefront execute in order, so only wave-level
+// scheduling barriers are needed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct c2 { double re, im; };
+
+__device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+
+#define FFT256_STRIDE 272   // c2 entries of wave-private LDS work space: 256 positions + one pad per 16
+
+__device__ __forceinline__ int brev8(int p) { return int(__brev(unsigned(p)) >> 24); }
+
+// In:  r_k = x[lane + 64 k]  (natural order).
+// Out: r_k = X[brev8(4 lane + k)]  (unscaled).
+// tw:  128 twiddles in LDS: exp(-2 pi i j / 256) for the forward transform, their conjugates for the inverse.
+__device__ __forceinline__ void wave_fft256(c2& r0, c2& r1, c2& r2, c2& r3, c2* v, const c2* tw, int lane) {
+    auto bfly = [&](c2& lo, c2& hi, int p0, int st) {
+        const int j = brev8(p0) & ((1 << (st - 1)) - 1);
+        const c2 t = cmul(tw[j << (8 - st)], hi);
+        const c2 u = lo;
+        hi = {u.re - t.re, u.im - t.im};
+        lo = {u.re + t.re, u.im + t.im};
+    };
+    auto padded = [](int p) { return p + (p >> 4); };
+    // stages 1, 2: positions lane + 64k
+    bfly(r0, r2, lane, 1); bfly(r1, r3, lane + 64, 1);
+    bfly(r0, r1, lane, 2); bfly(r2, r3, lane + 128, 2);
+    v[padded(lane)] = r0; v[padded(lane + 64)] = r1; v[padded(lane + 128)] = r2; v[padded(lane + 192)] = r3;
+    __builtin_amdgcn_wave_barrier();
+    // stages 3, 4: positions pb + 16k
+    const int pb = (lane >> 4) * 64 + (lane & 15);
+    r0 = v[padded(pb)]; r1 = v[padded(pb + 16)]; r2 = v[padded(pb + 32)]; r3 = v[padded(pb + 48)];
+    bfly(r0, r2, pb, 3); bfly(r1, r3, pb + 16, 3);
+    bfly(r0, r1, pb, 4); bfly(r2, r3, pb + 32, 4);
+    v[padded(pb)] = r0; v[padded(pb + 16)] = r1; v[padded(pb + 32)] = r2; v[padded(pb + 48)] = r3;
+    __builtin_amdgcn_wave_barrier();
+    // stages 5, 6: positions pc + 4k
+    const int pc = (lane >> 2) * 16 + (lane & 3);
+    r0 = v[padded(pc)]; r1 = v[padded(pc + 4)]; r2 = v[padded(pc + 8)]; r3 = v[padded(pc + 12)];
+    bfly(r0, r2, pc, 5); bfly(r1, r3, pc + 4, 5);
+    bfly(r0, r1, pc, 6); bfly(r2, r3, pc + 8, 6);
+    v[padded(pc)] = r0; v[padded(pc + 4)] = r1; v[padded(pc + 8)] = r2; v[padded(pc + 12)] = r3;
+    __builtin_amdgcn_wave_barrier();
+    // stages 7, 8: positions 4*lane + k
+    const int pd = 4 * lane;
+    r0 = v[padded(pd)]; r1 = v[padded(pd + 1)]; r2 = v[padded(pd + 2)]; r3 = v[padded(pd + 3)];
+    bfly(r0, r2, pd, 7); bfly(r1, r3, pd + 1, 7);
+    bfly(r0, r1, pd, 8); bfly(r2, r3, pd + 2, 8);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// zero_depadder (ofdm.cc:401-411) for Nc = 50, start_shift = 1: carrier column of FFT bin `bin`, or -1
+__device__ __forceinline__ int carrier_of_bin(int bin) {
+    if (bin >= 256 - 25) return bin - (256 - 25);
+    if (bin >= 1 && bin <= 25) return 25 + bin - 1;
+    return -1;
+}

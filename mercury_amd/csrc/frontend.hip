@@ -23,12 +23,9 @@
 #include <stdint.h>
 
 #include "device_tables.h"
+#include "fft256.h"
 
 namespace {
-
-struct c2 { double re, im; };
-
-__device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 
 // libgcc (GCC 11) __divdc3 main path
 __device__ __forceinline__ c2 cdiv(c2 n, c2 d) {
@@ -83,12 +80,11 @@ __device__ __forceinline__ double serial_sum(const double* red, int n) {
 
 #define FE_THREADS 512
 #define FE_WAVES (FE_THREADS / 64)
-#define FE_FFT_STRIDE 272   // 256 positions + one pad element per 16 (bank-conflict-free transpositions)
 
 // LDS carve (bytes): grid 16G | B = max(16G, FE_WAVES*272*16) (FFT work area, later the channel/equalised grid)
 //                    | red/yp/llr 12800 (reduction terms, signed pilots, later the demapper LLRs) | tw 2048 | type G | scal 64
 extern "C" size_t mgpu_frontend_lds_bytes(int G) {
-    const size_t b = size_t(16) * G > size_t(FE_WAVES) * FE_FFT_STRIDE * 16 ? size_t(16) * G : size_t(FE_WAVES) * FE_FFT_STRIDE * 16;
+    const size_t b = size_t(16) * G > size_t(FE_WAVES) * FFT256_STRIDE * 16 ? size_t(16) * G : size_t(FE_WAVES) * FFT256_STRIDE * 16;
     return size_t(16) * G + b + 12800 + 2048 + ((G + 15) & ~15) + 64;
 }
 
@@ -100,7 +96,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     c2* grid = reinterpret_cast<c2*>(smem);
     c2* H = grid + G;                                               // also the FFT work area (dead before H is born)
     c2* fftb = H;
-    const size_t bsz = size_t(16) * G > size_t(FE_WAVES) * FE_FFT_STRIDE * 16 ? size_t(16) * G : size_t(FE_WAVES) * FE_FFT_STRIDE * 16;
+    const size_t bsz = size_t(16) * G > size_t(FE_WAVES) * FFT256_STRIDE * 16 ? size_t(16) * G : size_t(FE_WAVES) * FFT256_STRIDE * 16;
     double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(H) + bsz);   // <= 800 doubles
     float* llr = reinterpret_cast<float*>(red);                     // demapper output reuses the reduction area
     c2* yp = reinterpret_cast<c2*>(red);                            // pilots in row-major pilot order, multiplied by their sign
@@ -121,70 +117,25 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i] ? (T.pilot_val[i] < 0 ? int8_t(-1) : int8_t(1)) : int8_t(0);
     __syncthreads();
 
-    // ---- symbol_demod: one wave per symbol ------------------------------------------------------
-    // The reference's radix-2 DIT (bit-reversal permutation, then stages size = 2..256) is run with the data
-    // left in natural order: element idx of the permuted array lives at position p = brev8(idx), so stage st
-    // pairs positions p and p + 2^(8-st) and bin k ends up at position brev8(k). Every butterfly has the same
-    // operands and the same twiddle (index (brev8(p0) & (2^(st-1)-1)) * 2^(8-st)) as the reference's, so the
-    // results are bit-identical. A lane holds four elements and does two stages in registers between LDS
-    // transpositions (positions 64, 16, 4 and 1 apart in turn): 3 round trips through LDS instead of 8, all of
-    // them contiguous or padded (address = p + p/16) so that no access pattern collides on a bank. The work
-    // buffer is private to the wave and LDS operations of one wave execute in order: no workgroup barrier.
-    // The next symbol's samples are requested before the current symbol's butterflies start.
-    auto bfly = [&](c2& lo, c2& hi, int p0, int st) {
-        const int j = int(__brev(unsigned(p0)) >> 24) & ((1 << (st - 1)) - 1);
-        const c2 t = cmul(tw[j << (8 - st)], hi);
-        const c2 u = lo;
-        hi = {u.re - t.re, u.im - t.im};
-        lo = {u.re + t.re, u.im + t.im};
-    };
-    auto padded = [](int p) { return p + (p >> 4); };
+    // ---- symbol_demod: one wave per symbol (fft256.h), next symbol's samples requested before the butterflies ----
     c2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
     if (wave < Ns) {
         const c2* in = bb + size_t(wave) * 272 + 16;                // gi_remover
         n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
     }
     for (int s = wave; s < Ns; s += FE_WAVES) {
-        c2* v = fftb + wave * FE_FFT_STRIDE;
         c2 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
         if (s + FE_WAVES < Ns) {
             const c2* in = bb + size_t(s + FE_WAVES) * 272 + 16;
             n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
         }
-        // stages 1, 2: positions lane + 64k
-        bfly(r0, r2, lane, 1); bfly(r1, r3, lane + 64, 1);
-        bfly(r0, r1, lane, 2); bfly(r2, r3, lane + 128, 2);
-        v[padded(lane)] = r0; v[padded(lane + 64)] = r1; v[padded(lane + 128)] = r2; v[padded(lane + 192)] = r3;
-        __builtin_amdgcn_wave_barrier();
-        // stages 3, 4: positions pb + 16k
-        const int pb = (lane >> 4) * 64 + (lane & 15);
-        r0 = v[padded(pb)]; r1 = v[padded(pb + 16)]; r2 = v[padded(pb + 32)]; r3 = v[padded(pb + 48)];
-        bfly(r0, r2, pb, 3); bfly(r1, r3, pb + 16, 3);
-        bfly(r0, r1, pb, 4); bfly(r2, r3, pb + 32, 4);
-        v[padded(pb)] = r0; v[padded(pb + 16)] = r1; v[padded(pb + 32)] = r2; v[padded(pb + 48)] = r3;
-        __builtin_amdgcn_wave_barrier();
-        // stages 5, 6: positions pc + 4k
-        const int pc = (lane >> 2) * 16 + (lane & 3);
-        r0 = v[padded(pc)]; r1 = v[padded(pc + 4)]; r2 = v[padded(pc + 8)]; r3 = v[padded(pc + 12)];
-        bfly(r0, r2, pc, 5); bfly(r1, r3, pc + 4, 5);
-        bfly(r0, r1, pc, 6); bfly(r2, r3, pc + 8, 6);
-        v[padded(pc)] = r0; v[padded(pc + 4)] = r1; v[padded(pc + 8)] = r2; v[padded(pc + 12)] = r3;
-        __builtin_amdgcn_wave_barrier();
-        // stages 7, 8: positions 4*lane + k
-        const int pd = 4 * lane;
-        r0 = v[padded(pd)]; r1 = v[padded(pd + 1)]; r2 = v[padded(pd + 2)]; r3 = v[padded(pd + 3)];
-        bfly(r0, r2, pd, 7); bfly(r1, r3, pd + 1, 7);
-        bfly(r0, r1, pd, 8); bfly(r2, r3, pd + 2, 8);
-        __builtin_amdgcn_wave_barrier();
+        wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
         // 1/Nfft scale + zero_depadder: position p holds bin brev8(p)
         auto emit = [&](const c2& x, int p) {
-            const int bin = int(__brev(unsigned(p)) >> 24);
-            int col = -1;
-            if (bin >= 256 - 25) col = bin - (256 - 25);
-            else if (bin >= 1 && bin <= 25) col = 25 + bin - 1;
+            const int col = carrier_of_bin(brev8(p));
             if (col >= 0) grid[s * Nc + col] = {x.re / 256.0, x.im / 256.0};
         };
-        emit(r0, pd); emit(r1, pd + 1); emit(r2, pd + 2); emit(r3, pd + 3);
+        emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
     }
     __syncthreads();
 

@@ -222,9 +222,11 @@ static std::vector<double> design_lpf_hamming(double transition_bw, double cut, 
     return c;
 }
 
-ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
-    if (cfg < 0 || cfg > 16) throw std::runtime_error("cfg must be 0..16");
-    const ModeRow& row = kModeTable[cfg];
+ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, size_t blob_size) {
+    const bool robust = cfg >= 100 && cfg <= 102;                             // common_defines.h:63-65
+    if (!robust && (cfg < 0 || cfg > 16)) throw std::runtime_error("cfg must be 0..16 (OFDM) or 100..102 (ROBUST MFSK)");
+    const ModeRow robust_row = {200 /* MOD_MFSK, mfsk.h:28 */, cfg == 102 ? 4 : 1, 4, 1};   // telecom_system.cc:2625-2645
+    const ModeRow& row = robust ? robust_row : kModeTable[cfg];
     ModeTables t;
     t.cfg = cfg;
     t.M = row.M;
@@ -240,11 +242,24 @@ ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
         case 16: t.Nsymb = 12; t.bps = 4; break;
         default: t.Nsymb = 9; t.bps = 5; break;
     }
+    if (robust) {                                                            // mfsk.cc:48-78 via telecom_system.cc:2900-2907
+        t.mfsk_M = cfg == 100 ? 32 : 16;
+        t.mfsk_nstreams = cfg == 100 ? 1 : 2;
+        t.mfsk_nbits = cfg == 100 ? 5 : 4;
+        t.mfsk_hop = t.mfsk_M == 32 ? 13 : 7;
+        const int global_offset = (t.Nc - t.mfsk_nstreams * t.mfsk_M) / 2;
+        for (int k = 0; k < t.mfsk_nstreams; ++k) t.mfsk_off[k] = global_offset + k * t.mfsk_M;
+        t.mfsk_amp = std::sqrt(double(t.Nc) / t.mfsk_nstreams);
+        t.bps = t.mfsk_nbits * t.mfsk_nstreams;                              // M_eff = 2^bps, telecom_system.cc:1944-1946
+        t.Nsymb = t.N / t.bps;                                               // telecom_system.cc:1812-1816
+        t.ctrl_nbits = cfg == 100 ? 1200 : cfg == 101 ? 1400 : 0;            // telecom_system.cc:2973-2988
+        t.ctrl_nsymb = t.ctrl_nbits / t.bps;
+    }
     const int G = t.Nsymb * t.Nc;
-    t.cell_type = make_pilot_lattice(t.Nsymb, t.Nc);
+    t.cell_type = robust ? std::vector<uint8_t>(G, 0) : make_pilot_lattice(t.Nsymb, t.Nc);   // MFSK frames carry no pilots
     t.pilot_boost = static_cast<double>(1.33f);                               // physical_config.h:53 (float)
     t.pilot_val.assign(G, 0.0);
-    {   // DBPSK pilot sequence, ofdm.cc:940-951
+    if (!robust) {   // DBPSK pilot sequence, ofdm.cc:940-951
         GlibcRandom rng(0);
         int last = 0;
         for (int c = 0; c < G; ++c) {
@@ -255,7 +270,7 @@ ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
             ++t.nPilots;
         }
     }
-    t.nData = G - t.nPilots;
+    t.nData = robust ? t.Nsymb : G - t.nPilots;                              // MFSK: one "symbol" per OFDM symbol period
     t.nBits = t.nData * t.bps;                                               // data_container.cc:93
     t.nVirtual = t.N - t.nBits;
     t.nReal = t.nBits - t.P;
@@ -263,8 +278,13 @@ ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
     t.tf_blk = t.nData / 10;
     t.payload_bytes = (t.nReal - 16) / 8;                                    // telecom_system.cc:332-335
     t.payload_stride = (t.nReal + 7) / 8;
-    t.frame_samples = t.Nsymb * t.Nofdm;
-    t.constellation = make_constellation(t.M);
+    {   // set_mfsk_ctrl_mode / get_active_nsymb / get_active_nbits, telecom_system.cc:1572-1585
+        const bool on = mfsk_ctrl_mode && robust && t.ctrl_nbits > 0 && t.ctrl_nbits < t.nBits;
+        t.active_nsymb = (on && t.ctrl_nsymb > 0) ? t.ctrl_nsymb : t.Nsymb;
+        t.active_nbits = (on && t.ctrl_nbits > 0) ? t.ctrl_nbits : t.nBits;
+    }
+    t.frame_samples = t.active_nsymb * t.Nofdm;
+    if (!robust) t.constellation = make_constellation(t.M);
     {   // telecom_system.cc:1961-1966
         GlibcRandom rng(0);
         t.scrambler.resize(t.N);
@@ -277,7 +297,7 @@ ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
     }
     // ---- RX gathers ---------------------------------------------------------------------
     std::vector<uint16_t> data_cell;                                         // deframer ofdm.cc:837-852
-    for (int c = 0; c < G; ++c) if (!t.cell_type[c]) data_cell.push_back(uint16_t(c));
+    for (int c = 0; c < G && int(data_cell.size()) < t.nData; ++c) if (!t.cell_type[c]) data_cell.push_back(uint16_t(c));
     auto deint_src = [](int n, int bs) {                                     // interleaver.cc:94-109
         std::vector<int> src(n);
         const int nb = n / bs;
@@ -299,6 +319,11 @@ ModeTables build_mode_tables(int cfg, const uint8_t* blob, size_t blob_size) {
         else if (p < t.nReal + t.nVirtual) d = p - t.nReal;       // virtual bits copy LLRs of bits [0,nVirtual)
         else d = p - t.nVirtual;                                  // parity shifted up by nVirtual
         t.llr_src[p] = uint16_t(bd[d]);
+    }
+    if (robust) {                    // nVirtual == 0: the gather is a permutation, the MFSK demapper scatters through its inverse
+        if (t.nVirtual != 0) throw std::runtime_error("MFSK mode with virtual bits");
+        t.llr_dst.assign(t.nBits, 0);
+        for (int p = 0; p < t.N; ++p) t.llr_dst[t.llr_src[p]] = uint16_t(p);
     }
     // LS weights: x' = x / sum(x*x) with x = +-boost, sums accumulated sequentially (misc.cc:73-91)
     t.ls_weight.assign(size_t(t.lsw) * t.lsw + 1, 0.0);

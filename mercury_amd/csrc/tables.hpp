@@ -3,6 +3,7 @@
 // These are the init-time computations of the reference (done once per load_configuration),
 // restated so that the device sees bit-identical constants:
 //   mode table ............ telecom_system.cc:2506-2654, :1806-1869, data_container.cc:90-99
+//   MFSK parameters ....... mfsk.cc:48-78, telecom_system.cc:1810-1816, :1940-1946, :2968-2989
 //   PRNG .................. source/common/os_interop.cc:192-283 (glibc TYPE_3 random())
 //   pilot lattice/values .. ofdm.cc:904-952, :976-1064
 //   constellation ......... psk.cc:65-256
@@ -51,6 +52,12 @@ struct ModeTables {
     int nData = 0, nBits = 0, nPilots = 0, nVirtual = 0, nReal = 0;
     int bit_blk = 0, tf_blk = 0, preamble = 0, estimator = 1, amp_restore = 0, lsw = 21;
     int payload_bytes = 0, payload_stride = 0, frame_samples = 0;
+    // MFSK modes (cfg 100..102 = ROBUST_0..2): cl_mfsk::init mfsk.cc:48-78; control frames telecom_system.cc:2968-2989
+    int mfsk_M = 0, mfsk_nbits = 0, mfsk_nstreams = 0, mfsk_hop = 0, mfsk_off[4] = {0, 0, 0, 0};
+    int ctrl_nbits = 0, ctrl_nsymb = 0;
+    int active_nbits = 0, active_nsymb = 0; // bits / symbols on the air (== nBits / Nsymb unless mfsk_ctrl_mode)
+    double mfsk_amp = 0;                    // sqrt(Nc / nStreams), mfsk.cc:243
+    std::vector<uint16_t> llr_dst;          // [nBits] MFSK only: decoder input position of demodulated LLR i (inverse of llr_src)
     double pilot_boost = 0;                 // (double)(float)1.33
     std::vector<uint8_t> cell_type;         // [G] 0 DATA / 1 PILOT
     std::vector<double> pilot_val;          // [G] real pilot value (0 at data cells)
@@ -70,7 +77,7 @@ struct ModeTables {
 };
 
 // Throws std::runtime_error on a bad cfg or unreadable/corrupt table blob.
-ModeTables build_mode_tables(int cfg, const uint8_t* ldpc_blob, size_t ldpc_blob_size);
+ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* ldpc_blob, size_t ldpc_blob_size);
 
 uint16_t crc16_modbus(const uint8_t* bytes, int n);
 

@@ -3,20 +3,20 @@
 // bit interleave -> constellation map -> time/freq interleave -> framer (pilots) -> IFFT + GI ->
 // channel (AWGN, optional static 2-path). It mirrors the reference TX chain
 // (telecom_system.cc:343-382 transmit_byte, :384-470 transmit_bit; ldpc.cc:111-132 encode;
-// psk.cc:259-272 mod; ofdm.cc:814-835 framer, :855-860 symbol_mod) and the AWGN scaling of
+// psk.cc:259-272 mod or, for the MFSK modes, mfsk.cc:232-285 mod; ofdm.cc:814-835 framer, :855-860
+// symbol_mod) and the AWGN scaling of
 // baseband_test_EsN0 (telecom_system.cc:141-153). Generator definition: DESIGN.md §Synthetic inputs;
 // the CPU twin used to validate it is oracle/mercury_oracle.c:morc_gen_frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "device_tables.h"
+#include "fft256.h"
 
 #define TX_THREADS 256
+#define TX_WAVES (TX_THREADS / 64)
 
 namespace {
-
-struct c2 { double re, im; };
-__device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 
 __device__ void philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2_, uint32_t c3, uint32_t out[4]) {
     uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
@@ -39,8 +39,8 @@ __device__ __forceinline__ double gauss_bm(uint32_t a, uint32_t b) {
 
 }  // namespace
 
-// LDS: bits 1600 | enc 1600 | inter 1600 | par 1600 (bytes) | grid 16*G | fft 4*256*16 | tw 128*16 | pay 256
-extern "C" size_t mgpu_txgen_lds_bytes(int G) { return 4 * 1600 + size_t(16) * G + 4 * 256 * 16 + 128 * 16 + 256 + 64; }
+// LDS: bits 1600 | enc 1600 | inter 1600 | par 1600 (bytes) | grid 16*G (G = 0 for MFSK) | fft 4*272*16 | tw 128*16 | pay 256
+extern "C" size_t mgpu_txgen_lds_bytes(int G) { return 4 * 1600 + size_t(16) * G + TX_WAVES * FFT256_STRIDE * 16 + 128 * 16 + 256 + 64; }
 
 extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
     MgpuDev T, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel,
@@ -51,9 +51,10 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
     uint8_t* inter = enc + 1600;        // interleaved nBits
     uint8_t* par = inter + 1600;        // info-part parity per check
     __shared__ uint8_t wpar[32];        // parity of each 64-check word (prefix-XOR carries)
+    const bool mfsk = T.mfsk_M > 0;
     c2* grid = reinterpret_cast<c2*>(par + 1600);
-    c2* fftb = grid + T.G;
-    c2* tw = fftb + 4 * 256;
+    c2* fftb = grid + (mfsk ? 0 : T.G);
+    c2* tw = fftb + TX_WAVES * FFT256_STRIDE;
     uint8_t* pay = reinterpret_cast<uint8_t*>(tw + 128);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,50 +135,48 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
         inter[pos] = src < nReal ? enc[src] : enc[src + T.nVirtual];
     }
     __syncthreads();
-    // pilots + mapped data into the frame grid
-    for (int c = tid; c < T.G; c += TX_THREADS) if (T.cell_type[c]) grid[c] = {T.pilot_val[c], 0.0};
-    for (int k = tid; k < T.nData; k += TX_THREADS) {
-        unsigned loc = 0;
-        for (int j = 0; j < T.bps; ++j) loc = (loc << 1) | inter[k * T.bps + j];
-        grid[T.sym_src[k]] = {T.constellation[2 * loc], T.constellation[2 * loc + 1]};
+    // pilots + mapped data into the frame grid (the MFSK modes build each symbol's carriers on the fly)
+    if (!mfsk) {
+        for (int c = tid; c < T.G; c += TX_THREADS) if (T.cell_type[c]) grid[c] = {T.pilot_val[c], 0.0};
+        for (int k = tid; k < T.nData; k += TX_THREADS) {
+            unsigned loc = 0;
+            for (int j = 0; j < T.bps; ++j) loc = (loc << 1) | inter[k * T.bps + j];
+            grid[T.sym_src[k]] = {T.constellation[2 * loc], T.constellation[2 * loc + 1]};
+        }
     }
     __syncthreads();
-    // symbol_mod: zero_padder + unnormalised IFFT + gi_adder, one wave per symbol
-    const int passes = (T.Nsymb + 3) / 4;
-    for (int pass = 0; pass < passes; ++pass) {
-        const int s = pass * 4 + wave;
-        const bool act = s < T.Nsymb;
-        c2* v = fftb + wave * 256;
-        if (act) {
-            for (int i = lane; i < 256; i += 64) {
-                c2 z = {0.0, 0.0};
-                if (i >= 256 - 25) z = grid[s * 50 + (i - (256 - 25))];
-                else if (i >= 1 && i <= 25) z = grid[s * 50 + 25 + (i - 1)];
-                v[__brev(unsigned(i)) >> 24] = z;
+    // symbol_mod: zero_padder + unnormalised IFFT (fft256.h with conjugated twiddles) + gi_adder, one wave per symbol
+    for (int s = wave; s < T.active_nsymb; s += TX_WAVES) {
+        int tone0 = -1, tone1 = -1;                 // MFSK: active carrier of each stream this symbol (mfsk.cc:252-282)
+        if (mfsk) {
+            for (int st = 0; st < T.mfsk_nstreams; ++st) {
+                int tone = 0;
+                for (int b = 0; b < T.mfsk_nbits; ++b)
+                    if (inter[s * T.bps + st * T.mfsk_nbits + b]) tone |= 1 << (T.mfsk_nbits - 1 - b);
+                int bin = tone;
+                for (int sh = 1; sh < T.mfsk_nbits; ++sh) bin ^= tone >> sh;          // Gray -> binary
+                if (bin >= T.mfsk_M) bin = T.mfsk_M - 1;
+                const int actual = (bin + s * T.mfsk_hop) % T.mfsk_M;                 // tone hopping
+                if (st == 0) tone0 = T.mfsk_off0 + actual; else tone1 = T.mfsk_off1 + actual;
             }
         }
-        __syncthreads();
-        for (int size = 2; size <= 256; size <<= 1) {
-            const int half = size >> 1, step = 256 / size;
-            if (act) {
-                for (int b = lane; b < 128; b += 64) {
-                    const int j = b & (half - 1);
-                    const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
-                    const c2 t = cmul(tw[j * step], v[i1]);
-                    const c2 u = v[i0];
-                    v[i1] = {u.re - t.re, u.im - t.im};
-                    v[i0] = {u.re + t.re, u.im + t.im};
-                }
-            }
-            __syncthreads();
-        }
-        if (act) {
-            c2* y = out + size_t(s) * 272;
-            for (int j = lane; j < 256; j += 64) y[j + 16] = v[j];
-            if (lane < 16) y[lane] = v[lane + 240];
-        }
-        __syncthreads();
+        auto carrier = [&](int i) -> c2 {            // zero_padder (ofdm.cc:379-400): FFT input bin i
+            const int col = carrier_of_bin(i);
+            if (col < 0) return {0.0, 0.0};
+            if (mfsk) return (col == tone0 || col == tone1) ? c2{T.mfsk_amp, 0.0} : c2{0.0, 0.0};
+            return grid[s * 50 + col];
+        };
+        c2 r0 = carrier(lane), r1 = carrier(lane + 64), r2 = carrier(lane + 128), r3 = carrier(lane + 192);
+        wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
+        c2* y = out + size_t(s) * 272;
+        auto emit = [&](const c2& x, int p) {        // gi_adder (ofdm.cc:412-422): sample n and its cyclic prefix copy
+            const int n = brev8(p);
+            y[n + 16] = x;
+            if (n >= 240) y[n - 240] = x;
+        };
+        emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
     }
+    __syncthreads();
     // channel, back to front in chunks so the 6-sample echo always reads clean samples
     const int n = T.frame_samples;
     c2 h1 = {0.0, 0.0};

@@ -5,7 +5,8 @@ This is only a thin loader: every computation happens in the HIP library
 GPU is visible, constructing :class:`RxPhy` raises.
 
 Naming follows the reference's physical layer (source/physical_layer/telecom_system.cc): a
-*frame* is one LDPC codeword worth of OFDM symbols for one ``CONFIG_n`` mode, ``receive`` runs
+*frame* is one LDPC codeword worth of OFDM symbols for one ``CONFIG_n`` (0..16) or ``ROBUST_n``
+(100..102, MFSK) mode, ``receive`` runs
 the span of ``receive_byte`` after synchronisation (telecom_system.cc:1132-1345) on a batch of
 frames, ``ldpc_decode`` is ``cl_ldpc::decode`` (ldpc.h:90) on a batch of LLR vectors.
 """
@@ -24,12 +25,12 @@ EST_ZF, EST_LS = 0, 1
 class Config(C.Structure):
     _fields_ = [("cfg", C.c_int), ("max_iters", C.c_int), ("decoder", C.c_int), ("agc", C.c_int),
                 ("variance_source", C.c_int), ("device", C.c_int), ("max_batch", C.c_int),
-                ("minsum_alpha", C.c_float)]
+                ("minsum_alpha", C.c_float), ("mfsk_ctrl_mode", C.c_int)]
 
 
 INFO_FIELDS = ("cfg M bits_per_symbol K P N Nsymb Nc Nfft Ngi Nofdm nData nBits nPilots nVirtual nReal "
                "bit_blk tf_blk preamble_nsymb estimator amp_restore ls_window Cwidth Vwidth E "
-               "payload_bytes payload_stride frame_samples").split()
+               "payload_bytes payload_stride frame_samples mfsk_M mfsk_nStreams active_nsymb active_nbits").split()
 
 
 class Info(C.Structure):
@@ -95,10 +96,10 @@ class RxPhy:
     """One GPU receive context for one Mercury mode (``load_configuration(cfg)`` equivalent)."""
 
     def __init__(self, cfg, max_iters=50, decoder=DEC_SPA, agc=1, variance_source=1, device=0,
-                 max_batch=4096, minsum_alpha=0.0):
+                 max_batch=4096, minsum_alpha=0.0, mfsk_ctrl_mode=False):
         self.lib = load_library()
         self.h = C.c_void_p()
-        c = Config(cfg, max_iters, decoder, agc, variance_source, device, max_batch, minsum_alpha)
+        c = Config(cfg, max_iters, decoder, agc, variance_source, device, max_batch, minsum_alpha, 1 if mfsk_ctrl_mode else 0)
         rc = self.lib.mgpu_create(C.byref(c), C.byref(self.h))
         if rc != 0:
             raise MgpuError("mgpu_create failed (%d): %s" % (rc, self.lib.mgpu_last_error(None).decode()))
@@ -140,6 +141,9 @@ class RxPhy:
                      eq=np.zeros((F, G), np.complex128), syms=np.zeros((F, self.nData), np.complex128),
                      llr_demod=np.zeros((F, self.nBits), np.float32), llr_ldpc=np.zeros((F, 1600), np.float32),
                      variance=np.zeros(F, np.float64), agc_gain=np.zeros(F, np.float64), cycles=np.zeros(16, np.int64))
+            if self.mfsk_M:      # no channel estimate / equalised grid on the MFSK path
+                for k in ("H", "eq", "syms"):
+                    del t[k]
             ts = Taps(**{k: v.ctypes.data for k, v in t.items()})
             self._ck(self.lib.mgpu_rx_batch_taps(self.h, _ptr(bb), C.c_int(F), _ptr(payload), _ptr(stats), C.byref(ts)))
             out.update(t)

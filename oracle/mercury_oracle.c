@@ -76,6 +76,9 @@ struct morc {
     int Nsymb, Nc, Nfft, Ngi, Nofdm, nData, nBits, nPilots, nVirtual, nReal;
     int bit_blk, tf_blk, preamble, estimator, amp_restore, lsw;
     int Cwidth, Vwidth;
+    /* MFSK modes (ROBUST_0..2 = cfg 100..102): mfsk.cc:48-162, telecom_system.cc:2968-2989 */
+    int mfsk_M, mfsk_nbits, mfsk_nstreams, mfsk_hop, mfsk_off[4];
+    int ctrl_nbits, ctrl_nsymb, active_nbits, active_nsymb;
     int* type;          /* [Nsymb*Nc] */
     cd* pilot_seq;      /* [nPilots] */
     cd* pilot_grid;     /* [Nsymb*Nc] pilot value at pilot cells */
@@ -259,25 +262,48 @@ static const struct { int M, rate16, preamble, est; } MODES[17] = {
     {4,5,4,EST_LS},{4,6,4,EST_LS},{4,8,4,EST_LS},{8,6,3,EST_LS},{8,8,3,EST_LS},{4,14,3,EST_LS},
     {16,8,2,EST_LS},{8,14,2,EST_LS},{16,14,2,EST_ZF},{32,14,1,EST_ZF}};
 
+#define MOD_MFSK 200   /* mfsk.h:28 */
 morc* morc_create(int cfg, int max_iters, const char* tables_path) {
-    if (cfg < 0 || cfg > 16) return NULL;
+    int robust = cfg >= 100 && cfg <= 102;                       /* common_defines.h:63-65 */
+    if (!robust && (cfg < 0 || cfg > 16)) return NULL;
     morc* o = calloc(1, sizeof(morc));
-    o->cfg = cfg; o->M = MODES[cfg].M; o->preamble = MODES[cfg].preamble; o->estimator = MODES[cfg].est;
+    o->cfg = cfg;
+    int rate16;
+    if (robust) {   /* telecom_system.cc:2625-2645 */
+        o->M = MOD_MFSK; o->preamble = 4; o->estimator = EST_LS; rate16 = cfg == 102 ? 4 : 1;
+    } else {
+        o->M = MODES[cfg].M; o->preamble = MODES[cfg].preamble; o->estimator = MODES[cfg].est; rate16 = MODES[cfg].rate16;
+    }
     o->max_iters = max_iters;
     o->amp_restore = (o->M == 2 || o->M == 4 || o->M == 8);   /* telecom_system.cc:2647-2654 */
     o->N = 1600;
-    o->K = (int)((float)o->N * (MODES[cfg].rate16 / 16.0f));    /* ldpc.cc:65 */
+    o->K = (int)((float)o->N * (rate16 / 16.0f));               /* ldpc.cc:65 */
     o->P = o->N - o->K;
     o->Nc = 50; o->Nfft = 256; o->Ngi = 16; o->Nofdm = 272;
     o->Nsymb = o->M == 2 ? 48 : o->M == 4 ? 24 : o->M == 8 ? 16 : o->M == 16 ? 12 : 9;
     o->bps = o->M == 2 ? 1 : o->M == 4 ? 2 : o->M == 8 ? 3 : o->M == 16 ? 4 : 5;
     o->lsw = 21;
+    if (robust) {   /* cl_mfsk::init mfsk.cc:48-78 as called from telecom_system.cc:2900-2907 */
+        o->mfsk_M = cfg == 100 ? 32 : 16;
+        o->mfsk_nstreams = cfg == 100 ? 1 : 2;
+        o->mfsk_nbits = cfg == 100 ? 5 : 4;
+        o->mfsk_hop = o->mfsk_M == 32 ? 13 : 7;
+        int global_offset = (o->Nc - o->mfsk_nstreams * o->mfsk_M) / 2;
+        for (int k = 0; k < o->mfsk_nstreams; k++) o->mfsk_off[k] = global_offset + k * o->mfsk_M;
+        o->bps = o->mfsk_nbits * o->mfsk_nstreams;              /* telecom_system.cc:1944-1946: M_eff = 2^bps */
+        o->Nsymb = N_MAX / o->bps;                               /* telecom_system.cc:1812-1816 */
+        o->ctrl_nbits = cfg == 100 ? 1200 : cfg == 101 ? 1400 : 0;   /* telecom_system.cc:2973-2988 */
+        o->ctrl_nsymb = o->ctrl_nbits / o->bps;
+    }
     build_pilots(o);
-    build_constellation(o);
+    if (robust) { o->nData = o->Nsymb; o->nPilots = 0; }        /* no pilots: nData = Nsymb */
+    else build_constellation(o);
+    o->active_nsymb = o->Nsymb;
     o->nBits = o->nData * o->bps;
     o->nVirtual = o->N - o->nBits;
     o->nReal = o->nBits - o->P;
     o->bit_blk = o->nBits / 10; o->tf_blk = o->nData / 10;       /* telecom_system.cc:2910-2911 */
+    o->active_nbits = o->nBits;
     prng_t p; prng_seed(&p, 0);                                  /* telecom_system.cc:1961-1966 */
     for (int i = 0; i < o->N; i++) o->scrambler[i] = prng_next(&p) % 2;
     for (int k = 0; k < 128; k++) {                              /* ofdm.cc:266-271 */
@@ -317,6 +343,14 @@ void morc_get_info(morc* o, morc_info* i) {
     i->estimator = o->estimator; i->amp_restore = o->amp_restore; i->ls_window = o->lsw;
     i->Cwidth = o->Cwidth; i->Vwidth = o->Vwidth; i->dwidth = 0;
     i->payload_bytes = (o->nReal - 16) / 8;
+    i->mfsk_M = o->mfsk_M; i->mfsk_nStreams = o->mfsk_nstreams;
+    i->active_nsymb = o->active_nsymb; i->active_nbits = o->active_nbits;
+}
+/* cl_telecom_system::set_mfsk_ctrl_mode / get_active_nsymb / get_active_nbits — telecom_system.cc:1572-1585 */
+void morc_set_ctrl_mode(morc* o, int enable) {
+    int on = enable && o->M == MOD_MFSK && o->ctrl_nbits > 0 && o->ctrl_nbits < o->nBits;
+    o->active_nsymb = (on && o->ctrl_nsymb > 0) ? o->ctrl_nsymb : o->Nsymb;
+    o->active_nbits = (on && o->ctrl_nbits > 0) ? o->ctrl_nbits : o->nBits;
 }
 void morc_get_frame_types(morc* o, int* t) { memcpy(t, o->type, sizeof(int) * o->Nsymb * o->Nc); }
 void morc_get_pilot_seq(morc* o, double* s) { memcpy(s, o->pilot_seq, sizeof(cd) * o->nPilots); }
@@ -382,6 +416,23 @@ void morc_tx(morc* o, const int* bits, int scramble, double* out_c128) {
     ldpc_encode(o, db, enc);
     for (int i = 0; i < o->P; i++) enc[o->nReal + i] = enc[i + o->K];
     il_int(enc, bi, o->nBits, o->bit_blk, 0);
+    int nsymb = o->Nsymb;
+    if (o->M == MOD_MFSK) {                                      /* cl_mfsk::mod mfsk.cc:232-285, active symbols only */
+        nsymb = o->active_nbits / o->bps;
+        double amp = sqrt((double)o->Nc / o->mfsk_nstreams);
+        for (int s = 0; s < nsymb; s++) {
+            for (int k = 0; k < o->Nc; k++) o->framed[s * o->Nc + k] = 0.0;
+            for (int st = 0; st < o->mfsk_nstreams; st++) {
+                int off = s * o->bps + st * o->mfsk_nbits, tone = 0;
+                for (int b = 0; b < o->mfsk_nbits; b++) if (bi[off + b]) tone |= 1 << (o->mfsk_nbits - 1 - b);
+                int bin = tone;
+                for (int sh = 1; sh < o->mfsk_nbits; sh++) bin ^= tone >> sh;   /* Gray -> binary */
+                if (bin >= o->mfsk_M) bin = o->mfsk_M - 1;
+                int actual = (bin + s * o->mfsk_hop) % o->mfsk_M;               /* tone hopping */
+                o->framed[s * o->Nc + o->mfsk_off[st] + actual] = amp;
+            }
+        }
+    } else {
     for (int i = 0; i < o->nBits; i += o->bps) {                 /* psk.cc:259-272 */
         unsigned loc = 0;
         for (int j = 0; j < o->bps; j++) { loc += bi[i + j]; loc <<= 1; }
@@ -394,8 +445,9 @@ void morc_tx(morc* o, const int* bits, int scramble, double* out_c128) {
         if (o->type[c] == DATA) o->framed[c] = o->tfi[di++];
         else o->framed[c] = o->pilot_seq[pi++];
     }
+    }
     cd* out = (cd*)out_c128;
-    for (int s = 0; s < o->Nsymb; s++) {                         /* symbol_mod ofdm.cc:855-860 */
+    for (int s = 0; s < nsymb; s++) {                            /* symbol_mod ofdm.cc:855-860 */
         cd z[256];
         memset(z, 0, sizeof z);
         const cd* in = &o->framed[s * o->Nc];
@@ -623,20 +675,97 @@ int morc_ldpc_decode(morc* o, const float* llr, int* bits, int alg) {
     return alg == MORC_DEC_GBF ? decode_gbf(o, llr, bits) : decode_spa(o, llr, bits);
 }
 
+/* cl_mfsk::demod — mfsk.cc:288-390: per symbol, noise variance from the carriers outside the tone band, tone
+ * energies with the hop undone, max-log LLR per Gray-mapped bit, clamped to +-5 */
+static void mfsk_demod(const morc* o, const cd* fft_in, int total_bits, float* llr_out) {
+    int M = o->mfsk_M, nBits = o->mfsk_nbits, nStreams = o->mfsk_nstreams, Nc = o->Nc;
+    int bps = nBits * nStreams, nSymbols = total_bits / bps;
+    for (int s = 0; s < nSymbols; s++) {
+        int band_start = o->mfsk_off[0], band_end = o->mfsk_off[nStreams - 1] + M;
+        double noise_sum = 0.0; int noise_bins = 0;
+        for (int k = 0; k < Nc; k++) if (k < band_start || k >= band_end) {
+            cd val = fft_in[s * Nc + k];
+            double e = creal(val) * creal(val) + cimag(val) * cimag(val);
+            if (isfinite(e)) { noise_sum += e; noise_bins++; }
+        }
+        double noise_var = noise_bins > 0 ? noise_sum / noise_bins : 1e-30;
+        if (noise_var < 1e-30) noise_var = 1e-30;
+        double llr_scale = 1.0 / (2.0 * noise_var);
+        for (int st = 0; st < nStreams; st++) {
+            double E_raw[64], E[64];
+            for (int m = 0; m < M; m++) {
+                cd val = fft_in[s * Nc + o->mfsk_off[st] + m];
+                E_raw[m] = creal(val) * creal(val) + cimag(val) * cimag(val);
+                if (!isfinite(E_raw[m])) E_raw[m] = 0.0;
+            }
+            int hop = (s * o->mfsk_hop) % M;
+            for (int m = 0; m < M; m++) E[m] = E_raw[(m + hop) % M];
+            int llr_offset = s * bps + st * nBits;
+            for (int k = 0; k < nBits; k++) {
+                int mask = 1 << (nBits - 1 - k);
+                double max_E1 = -1e30, max_E0 = -1e30;
+                for (int m = 0; m < M; m++) {
+                    int gray_m = m ^ (m >> 1);
+                    if (gray_m & mask) { if (E[m] > max_E1) max_E1 = E[m]; }
+                    else { if (E[m] > max_E0) max_E0 = E[m]; }
+                }
+                double llr = (max_E0 - max_E1) * llr_scale;
+                if (!isfinite(llr)) llr = 0.0;
+                else if (llr > 5.0) llr = 5.0;
+                else if (llr < -5.0) llr = -5.0;
+                llr_out[llr_offset + k] = (float)llr;
+            }
+        }
+    }
+}
+
+static void symbol_demod(const morc* o, const cd* in, cd* g) {
+    /* symbol_demod ofdm.cc:862-867 = gi_remover :423-429 + fft :431-444 + zero_depadder :401-411 */
+    cd v[256];
+    for (int j = 0; j < 256; j++) v[j] = in[j + 16];
+    fft256(o, v, 0);
+    for (int j = 0; j < 256; j++) v[j] = (creal(v[j]) / 256.0) + (cimag(v[j]) / 256.0) * I;
+    for (int j = 0; j < 25; j++) g[j] = v[j + 256 - 25];
+    for (int j = 25; j < 50; j++) g[j] = v[j - 25 + 1];
+}
+
+/* the M == MOD_MFSK branch of receive_byte, telecom_system.cc:1132-1192 and the shared tail :1298-1367 */
+static void rx_mfsk(morc* o, const cd* bb, int flags, morc_rx_out* out) {
+    int Nc = o->Nc;
+    for (int s = 0; s < o->active_nsymb; s++) symbol_demod(o, &bb[s * o->Nofdm], &o->grid[s * Nc]);
+    out->agc_gain = 0; out->variance = 0; out->variance_f = 0; out->mean_H = -1.0;
+    if (out->grid) memcpy(out->grid, o->grid, sizeof(cd) * o->active_nsymb * Nc);
+    float dem[N_MAX], dei[N_MAX];
+    mfsk_demod(o, o->grid, o->active_nbits, dem);
+    for (int i = o->active_nbits; i < o->nBits; i++) dem[i] = 0.0f;      /* punctured tail, :1183-1191 */
+    if (out->llr_demod) memcpy(out->llr_demod, dem, sizeof(float) * o->nBits);
+    il_float(dem, dei, o->nBits, o->bit_blk, 1);
+    for (int i = o->P - 1; i >= 0; i--) dei[i + o->nReal + o->nVirtual] = dei[i + o->nReal];
+    for (int i = 0; i < o->nVirtual; i++) dei[o->nReal + i] = dei[i];
+    if (out->llr_ldpc) memcpy(out->llr_ldpc, dei, sizeof(float) * N_MAX);
+    out->iterations = -1; out->crc = -1; out->all_zeros = -1; out->snr_db = -99.9;
+    if (flags & MORC_FLAG_NO_LDPC) return;
+    int hd[N_MAX], bytes[N_MAX];
+    out->iterations = decode_spa(o, dei, hd);
+    if (out->bits) memcpy(out->bits, hd, sizeof(int) * o->K);
+    for (int i = 0; i < o->nReal; i++) hd[i] ^= o->scrambler[i];
+    int nb = o->nReal;
+    for (int i = 0; i < nb / 8; i++) { bytes[i] = 0; for (int j = 0; j < 8; j++) bytes[i] |= hd[i * 8 + j] << j; }
+    if (nb % 8) { bytes[nb / 8] = 0; for (int j = 0; j < nb % 8; j++) bytes[nb / 8] |= hd[nb - (nb % 8) + j] << j; }
+    out->all_zeros = 1;
+    for (int i = 0; i < nb / 8; i++) if (bytes[i] != 0) { out->all_zeros = 0; break; }
+    out->crc = 0;
+    if (!out->all_zeros) out->crc = morc_crc16(bytes, nb / 8);
+    if (out->bytes) memcpy(out->bytes, bytes, sizeof(int) * ((nb + 7) / 8));
+    out->snr_db = (out->all_zeros || out->crc != 0) ? -99.9 : 0.0;       /* :1362-1367: no SNR estimate for MFSK */
+}
+
 /* The hot path: telecom_system.cc:155-198 (flags=0) and :1132-1345 (flags = AGC|VAR_EQ) */
 void morc_rx(morc* o, const double* baseband_c128, int flags, morc_rx_out* out) {
     const cd* bb = (const cd*)baseband_c128;
     int Nc = o->Nc, Ns = o->Nsymb, G = Ns * Nc;
-    /* symbol_demod ofdm.cc:862-867 = gi_remover :423-429 + fft :431-444 + zero_depadder :401-411 */
-    for (int s = 0; s < Ns; s++) {
-        cd v[256];
-        for (int j = 0; j < 256; j++) v[j] = bb[s * o->Nofdm + j + 16];
-        fft256(o, v, 0);
-        for (int j = 0; j < 256; j++) v[j] = (creal(v[j]) / 256.0) + (cimag(v[j]) / 256.0) * I;
-        cd* g = &o->grid[s * Nc];
-        for (int j = 0; j < 25; j++) g[j] = v[j + 256 - 25];
-        for (int j = 25; j < 50; j++) g[j] = v[j - 25 + 1];
-    }
+    if (o->M == MOD_MFSK) { rx_mfsk(o, bb, flags, out); return; }
+    for (int s = 0; s < Ns; s++) symbol_demod(o, &bb[s * o->Nofdm], &o->grid[s * Nc]);
     out->agc_gain = 0;
     if (flags & MORC_FLAG_AGC) {   /* automatic_gain_control ofdm.cc:1467-1498 */
         double amp = 0; int n = 0;
@@ -926,7 +1055,7 @@ static inline double gauss_bm(uint32_t a, uint32_t b) {
 
 void morc_channel(morc* o, uint64_t seed, uint64_t frame, double noise_amp, int channel, double* frame_c128) {
     cd* x = (cd*)frame_c128;
-    int n = o->Nsymb * o->Nofdm;
+    int n = o->active_nsymb * o->Nofdm;
     if (channel == 1) {
         uint32_t w[4];
         morc_philox(seed, 0u, 2u, (uint32_t)frame, (uint32_t)(frame >> 32), w);
@@ -957,7 +1086,7 @@ void morc_gen_frame(morc* o, uint64_t seed, uint64_t frame, double noise_amp, in
 long morc_rx_many(morc* o, const double* bb, int n, int flags, int* iters_out, int* crc_out, unsigned char* payload_out) {
     long total = 0;
     int bytes[N_MAX];
-    size_t stride = (size_t)o->Nsymb * o->Nofdm * 2;
+    size_t stride = (size_t)o->active_nsymb * o->Nofdm * 2;
     int pb = (o->nReal - 16) / 8;
     for (int f = 0; f < n; f++) {
         morc_rx_out r; memset(&r, 0, sizeof r);

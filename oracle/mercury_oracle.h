@@ -32,10 +32,12 @@ typedef struct morc_info {
     int estimator, amp_restore, ls_window;
     int Cwidth, Vwidth, dwidth;
     int payload_bytes;
+    int mfsk_M, mfsk_nStreams;      /* 0 for the OFDM modes; cfg 100..102 = ROBUST_0..2 (MFSK) */
+    int active_nsymb, active_nbits; /* symbols / interleaved bits on the air (short MFSK control frames) */
 } morc_info;
 
 typedef struct morc_rx_out {
-    double* grid;     /* [Nsymb*Nc*2] */
+    double* grid;     /* [Nsymb*Nc*2] (MFSK: first active_nsymb rows) */
     double* H;        /* [Nsymb*Nc*2] */
     double* H_noamp;  /* [Nsymb*Nc*2] */
     double* eq;       /* [Nsymb*Nc*2] */
@@ -65,6 +67,7 @@ typedef struct morc_rx_out {
 morc* morc_create(int cfg, int max_iters, const char* tables_path);
 void morc_destroy(morc*);
 void morc_get_info(morc*, morc_info*);
+void morc_set_ctrl_mode(morc*, int enable);         /* cl_telecom_system::set_mfsk_ctrl_mode, telecom_system.cc:1572 */
 
 void morc_get_frame_types(morc*, int* types);       /* [Nsymb*Nc] 0=DATA 1=PILOT */
 void morc_get_pilot_seq(morc*, double* seq);        /* [nPilots*2] */

@@ -33,6 +33,7 @@
 
 #include "physical_layer/ofdm.h"
 #include "physical_layer/psk.h"
+#include "physical_layer/mfsk.h"
 #include "physical_layer/ldpc.h"
 #include "physical_layer/interleaver.h"
 #include "physical_layer/crc16_modbus_rtu.h"
@@ -76,6 +77,9 @@ struct Ref {
     cl_ofdm ofdm;
     cl_psk psk;
     cl_ldpc ldpc;
+    cl_mfsk mfsk;                    // ROBUST_0..2 (cfg 100..102) only
+    int ctrl_nBits, ctrl_nsymb;      // telecom_system.cc:2968-2989
+    int active_nbits, active_nsymb;  // get_active_nbits / get_active_nsymb, telecom_system.cc:1577-1585
     int cfg, M, bps;
     int Nsymb, Nc, Nfft, Nofdm, nData, nBits, nPilots;
     int nVirtual, nReal;
@@ -102,13 +106,17 @@ struct mref_info {
     int estimator, amp_restore, ls_window;
     int Cwidth, Vwidth, dwidth;
     int payload_bytes;
+    int mfsk_M, mfsk_nStreams, active_nsymb, active_nbits;
 };
 
 void* mref_create(int cfg, int max_iters) {
-    if (cfg < 0 || cfg > 16) return nullptr;
+    const bool robust = cfg >= ROBUST_0 && cfg <= ROBUST_2;   // common_defines.h:63-65
+    if (!robust && (cfg < 0 || cfg > 16)) return nullptr;
     Silence s;
     Ref* r = new Ref();
-    const ModeRow& m = kModes[cfg];
+    // telecom_system.cc:2625-2645: the three MFSK modes
+    const ModeRow robust_row = {MOD_MFSK, cfg == ROBUST_2 ? 4 : 1, 4, LEAST_SQUARE};
+    const ModeRow& m = robust ? robust_row : kModes[cfg];
     r->cfg = cfg;
     r->M = m.M;
     // telecom_system.cc:2647-2654
@@ -129,9 +137,14 @@ void* mref_create(int cfg, int max_iters) {
     if (m.M == MOD_8PSK) Nsymb = 16;
     if (m.M == MOD_16QAM) Nsymb = 12;
     if (m.M == MOD_32QAM) Nsymb = 9;
+    if (robust) {
+        // telecom_system.cc:2876-2882 / :2900-2907, then init() :1810-1816
+        if (cfg == ROBUST_0) r->mfsk.init(32, 50, 1); else r->mfsk.init(16, 50, 2);
+        Nsymb = N_MAX / r->mfsk.bits_per_symbol();
+    }
     r->ofdm.Nsymb = Nsymb;
     r->ofdm.pilot_configurator.Dx = 1;
-    r->ofdm.pilot_configurator.Dy = 3;
+    r->ofdm.pilot_configurator.Dy = robust ? Nsymb : 3;     // telecom_system.cc:1873-1877
     r->ofdm.pilot_configurator.first_row = DATA;
     r->ofdm.pilot_configurator.last_row = DATA;
     r->ofdm.pilot_configurator.first_col = DATA;
@@ -175,7 +188,7 @@ void* mref_create(int cfg, int max_iters) {
         r->ofdm.FIR_rx_data.design();
     }
     // telecom_system.cc:2886
-    r->psk.set_predefined_constellation(m.M);
+    if (!robust) r->psk.set_predefined_constellation(m.M);
     // telecom_system.cc:1883-1905 (init)
     r->ofdm.init();
     r->ldpc.init();
@@ -187,6 +200,11 @@ void* mref_create(int cfg, int max_iters) {
     r->nData = r->ofdm.pilot_configurator.nData;
     r->nPilots = r->ofdm.pilot_configurator.nPilots;
     r->bps = (int)log2(m.M);
+    if (robust) {   // telecom_system.cc:1940-1946: nData = Nsymb, M_eff = 2^(nBits*nStreams)
+        r->nData = Nsymb;
+        r->nPilots = 0;
+        r->bps = (int)log2(1 << r->mfsk.bits_per_symbol());
+    }
     r->nBits = r->nData * r->bps;
     r->preamble_nsymb = m.preamble;
     // telecom_system.cc:1961-1966
@@ -197,6 +215,11 @@ void* mref_create(int cfg, int max_iters) {
     r->tf_blk = r->nData / 10;
     r->nVirtual = r->ldpc.N - r->nBits;
     r->nReal = r->nBits - r->ldpc.P;
+    // telecom_system.cc:2968-2989
+    r->ctrl_nBits = cfg == ROBUST_0 ? 1200 : cfg == ROBUST_1 ? 1400 : 0;
+    r->ctrl_nsymb = robust ? r->ctrl_nBits / r->mfsk.bits_per_symbol() : 0;
+    r->active_nbits = r->nBits;
+    r->active_nsymb = r->Nsymb;
     int g = r->Nsymb * r->Nc;
     r->modulated = new cd[g];
     r->tf_inter = new cd[g];
@@ -208,6 +231,14 @@ void* mref_create(int cfg, int max_iters) {
     r->deframed = new cd[g];
     r->tf_deinter = new cd[g];
     return r;
+}
+
+// cl_telecom_system::set_mfsk_ctrl_mode (telecom_system.cc:1572-1585): short control frames
+void mref_set_ctrl_mode(void* h, int enable) {
+    Ref* r = (Ref*)h;
+    const bool on = enable && r->M == MOD_MFSK && r->ctrl_nBits > 0 && r->ctrl_nBits < r->nBits;
+    r->active_nsymb = (on && r->ctrl_nsymb > 0) ? r->ctrl_nsymb : r->Nsymb;
+    r->active_nbits = (on && r->ctrl_nBits > 0) ? r->ctrl_nBits : r->nBits;
 }
 
 void mref_destroy(void* h) {
@@ -227,6 +258,10 @@ void mref_get_info(void* h, mref_info* o) {
     o->amp_restore = r->ofdm.channel_estimator_amplitude_restoration;
     o->ls_window = r->ofdm.LS_window_width;
     o->payload_bytes = (r->nReal - 16) / 8;  // telecom_system.cc:332-335
+    o->mfsk_M = r->M == MOD_MFSK ? r->mfsk.M : 0;
+    o->mfsk_nStreams = r->M == MOD_MFSK ? r->mfsk.nStreams : 0;
+    o->active_nsymb = r->active_nsymb;
+    o->active_nbits = r->active_nbits;
     // widths come from the table globals selected by ldpc.cc:140-251
     int k = r->ldpc.K;
 #define SEL(R) { o->Cwidth = mercury_normal_Cwidth_##R##_16; o->Vwidth = mercury_normal_Vwidth_##R##_16; o->dwidth = mercury_normal_dwidth_##R##_16; }
@@ -300,6 +335,14 @@ void mref_tx(void* h, const int* bits, int scramble, double* out_c128) {
     r->ldpc.encode(r->data_bit_ed, r->encoded);
     for (int i = 0; i < r->ldpc.P; i++) r->encoded[r->nReal + i] = r->encoded[i + r->ldpc.K];
     interleaver(r->encoded, r->bit_inter, r->nBits, r->bit_blk);
+    if (r->M == MOD_MFSK) {
+        // telecom_system.cc:411-416, :500-505: one-hot tones straight into the framed grid, active symbols only
+        r->mfsk.mod(r->bit_inter, r->active_nbits, r->framed);
+        for (int i = 0; i < r->active_nsymb; i++)
+            r->ofdm.symbol_mod(&r->framed[i * r->Nc], &r->symbol_mod[i * r->Nofdm]);
+        memcpy(out_c128, r->symbol_mod, sizeof(cd) * r->Nofdm * r->active_nsymb);
+        return;
+    }
     r->psk.mod(r->bit_inter, r->nBits, r->modulated);
     interleaver(r->modulated, r->tf_inter, r->nData, r->tf_blk);
     r->ofdm.framer(r->tf_inter, r->framed);
@@ -352,9 +395,37 @@ void mref_rx(void* h, const double* baseband_c128, int flags, mref_rx_out* o) {
     Silence s;
     cl_ofdm& ofdm = r->ofdm;
     cd* bb = (cd*)baseband_c128;
+    o->agc_gain = 0;
+    if (r->M == MOD_MFSK) {
+        // telecom_system.cc:1132-1192: active symbols only, non-coherent tone-energy demod, punctured tail zeroed
+        for (int i = 0; i < r->active_nsymb; i++) ofdm.symbol_demod(&bb[i * r->Nofdm], &r->demod_grid[i * r->Nc]);
+        if (o->grid) memcpy(o->grid, r->demod_grid, sizeof(cd) * r->active_nsymb * r->Nc);
+        r->mfsk.demod(r->demod_grid, r->active_nbits, r->demodulated);
+        for (int i = r->active_nbits; i < r->nBits; i++) r->demodulated[i] = 0.0f;
+        o->variance = 0; o->variance_f = 0; o->mean_H = -1.0;
+        if (o->llr_demod) memcpy(o->llr_demod, r->demodulated, sizeof(float) * r->nBits);
+        deinterleaver(r->demodulated, r->deinterleaved, r->nBits, r->bit_blk);
+        for (int i = r->ldpc.P - 1; i >= 0; i--)
+            r->deinterleaved[i + r->nReal + r->nVirtual] = r->deinterleaved[i + r->nReal];
+        for (int i = 0; i < r->nVirtual; i++) r->deinterleaved[r->nReal + i] = r->deinterleaved[i];
+        if (o->llr_ldpc) memcpy(o->llr_ldpc, r->deinterleaved, sizeof(float) * N_MAX);
+        o->iterations = -1; o->crc = -1; o->all_zeros = -1; o->snr_db = -99.9;
+        if (flags & 4) return;
+        o->iterations = r->ldpc.decode(r->deinterleaved, r->hd_bits);
+        if (o->bits) memcpy(o->bits, r->hd_bits, sizeof(int) * r->ldpc.K);
+        bit_energy_dispersal(r->hd_bits, r->scrambler, r->hd_bits, r->nReal);
+        bit_to_byte(r->hd_bits, r->hd_bytes, r->nReal);
+        o->all_zeros = YES;
+        for (int i = 0; i < r->nReal / 8; i++)
+            if (r->hd_bytes[i] != 0) { o->all_zeros = NO; break; }
+        o->crc = 0;
+        if (o->all_zeros == NO) o->crc = CRC16_MODBUS_RTU_calc(r->hd_bytes, r->nReal / 8);
+        if (o->bytes) memcpy(o->bytes, r->hd_bytes, sizeof(int) * ((r->nReal + 7) / 8));
+        o->snr_db = (o->all_zeros == YES || o->crc != 0) ? -99.9 : 0.0;   // telecom_system.cc:1362-1367
+        return;
+    }
     // telecom_system.cc:155-158 / :1135-1138
     for (int i = 0; i < r->Nsymb; i++) ofdm.symbol_demod(&bb[i * r->Nofdm], &r->demod_grid[i * r->Nc]);
-    o->agc_gain = 0;
     if (flags & 1) {
         // recover the gain the reference applies (ofdm.cc:1467-1498) by probing one cell
         cd before = r->demod_grid[0];

@@ -24,5 +24,8 @@ def _built_checkers():
 # Es/N0 (dB) at which each mode is exercised: FER<0.1 threshold of include/common/common_defines.h:130-147
 # plus 2 dB; the two zero-forcing modes need more in the baseband loop.
 OPERATING_ESN0 = {0: -8.0, 1: -6.0, 2: -4.5, 3: -3.0, 4: -1.5, 5: -0.5, 6: 1.0, 7: 1.5, 8: 2.5, 9: 4.0,
-                  10: 5.5, 11: 7.0, 12: 8.5, 13: 9.5, 14: 11.5, 15: 16.0, 16: 20.0}
+                  10: 5.5, 11: 7.0, 12: 8.5, 13: 9.5, 14: 11.5, 15: 16.0, 16: 20.0,
+                  # ROBUST_0..2 (MFSK): waterfalls -13 / -11 / -8 dB (telecom_system.cc:2970-2972) plus ~3 dB
+                  100: -10.0, 101: -8.0, 102: -5.0}
+MFSK_CFGS = (100, 101, 102)
 SEED = 0x4D455243

@@ -13,6 +13,9 @@ telecom_system.cc:155-198, and receive_byte, :1132-1345), and the reference's ou
     symbols, demapper LLRs) as SHA-256 digests — the CPU oracle is required to match them bit for bit;
   * static tables per mode (pilot lattice + signs, scrambler, constellation) and KATs (PRNG, CRC).
 
+`--mfsk` writes golden_mfsk.{npz,json} for the three MFSK modes (cfg 100..102 = ROBUST_0..2): the
+M == MOD_MFSK branch of receive_byte (telecom_system.cc:1132-1192), full and short control frames.
+
 Fixtures are DATA (inputs are regenerated from the recorded seeds; a digest of the input guards
 against generator drift). No reference source text is stored.
 """
@@ -81,5 +84,49 @@ def main():
     print("wrote golden_rx.npz (%d arrays), golden_rx.json" % len(arrays))
 
 
+def main_mfsk():
+    """ROBUST_0..2 (cfg 100..102): the MFSK branch of receive_byte, full frames and short control frames."""
+    assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
+    arrays = {}
+    meta = {"seed": SEED, "modes": {}}
+    for cfg in (100, 101, 102):
+        ref = oraclelib.RefLib(cfg, 50)
+        orc = oraclelib.Oracle(cfg, 50)   # input generator only
+        m = {n: getattr(ref, n) for n in oraclelib.INFO_FIELDS if n != "dwidth"}
+        op = OPERATING_ESN0[cfg]
+        cases = [(op, 0, 0), (op + 1.0, 0, 0), (-20.0, 0, 0), (60.0, 0, 0)]
+        if ref.mfsk_M and cfg != 102:
+            cases += [(op + 1.0, 0, 1), (60.0, 0, 1)]      # short control frames (set_mfsk_ctrl_mode)
+        frames = []
+        for idx, (snr, ch, ctrl) in enumerate(cases):
+            ref.set_ctrl_mode(ctrl)
+            orc.set_ctrl_mode(ctrl)
+            bb, pl = orc.gen_frame(SEED, 100 * cfg + idx, oraclelib.noise_amp_for(snr), ch)
+            r = ref.rx(bb, oraclelib.FLAGS_RECEIVE_BYTE)
+            key = "cfg%d_f%d" % (cfg, idx)
+            arrays[key + "_llr_ldpc"] = r["llr_ldpc"]
+            arrays[key + "_bits"] = np.packbits(r["bits"].astype(np.uint8))
+            arrays[key + "_bytes"] = r["bytes"].astype(np.uint8)
+            n = ref.active_nsymb * ref.Nc
+            frames.append({"frame": 100 * cfg + idx, "esn0_db": snr, "channel": ch, "ctrl_mode": ctrl,
+                           "active_nsymb": ref.active_nsymb, "active_nbits": ref.active_nbits,
+                           "input_sha256": digest(bb), "payload_sha256": digest(pl.astype(np.uint8)),
+                           "iterations": int(r["iterations"]), "crc": int(r["crc"]), "all_zeros": int(r["all_zeros"]),
+                           "snr_db": float(r["snr_db"]),
+                           "sha256": {"grid": digest(r["grid"][:n]), "llr_demod": digest(r["llr_demod"]),
+                                      "llr_ldpc": digest(r["llr_ldpc"])}})
+        ref.set_ctrl_mode(0)
+        m["frames"] = frames
+        meta["modes"][str(cfg)] = m
+        print("cfg", cfg, "done")
+    np.savez_compressed(os.path.join(HERE, "golden_mfsk.npz"), **arrays)
+    with open(os.path.join(HERE, "golden_mfsk.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote golden_mfsk.npz (%d arrays), golden_mfsk.json" % len(arrays))
+
+
 if __name__ == "__main__":
-    main()
+    if "--mfsk" in sys.argv:
+        main_mfsk()     # separate fixture files: the OFDM fixtures are not regenerated
+    else:
+        main()

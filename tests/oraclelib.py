@@ -22,7 +22,8 @@ FLAGS_BASEBAND_TEST = 0                    # telecom_system.cc:155-198
 FLAGS_RECEIVE_BYTE = FLAG_AGC | FLAG_VAR_EQ  # telecom_system.cc:1132-1345
 
 INFO_FIELDS = ("cfg M bits_per_symbol K P N Nsymb Nc Nfft Ngi Nofdm nData nBits nPilots nVirtual nReal "
-               "bit_blk tf_blk preamble_nsymb estimator amp_restore ls_window Cwidth Vwidth dwidth payload_bytes").split()
+               "bit_blk tf_blk preamble_nsymb estimator amp_restore ls_window Cwidth Vwidth dwidth payload_bytes "
+               "mfsk_M mfsk_nStreams active_nsymb active_nbits").split()
 
 
 class Info(C.Structure):
@@ -59,7 +60,12 @@ class _Base:
         self.info = i
         for n in INFO_FIELDS:
             setattr(self, n, getattr(i, n))
-        self.frame_samples = self.Nsymb * self.Nofdm
+        self.frame_samples = self.active_nsymb * self.Nofdm
+
+    def set_ctrl_mode(self, enable):
+        """cl_telecom_system::set_mfsk_ctrl_mode (telecom_system.cc:1572-1585): short MFSK control frames."""
+        self._fn("set_ctrl_mode")(self.h, C.c_int(1 if enable else 0))
+        self._init_info()
 
     # ---- tables
     def frame_types(self):

@@ -30,8 +30,8 @@ def test_struct_layouts_match_header():
     from mercury_amd import STATS_DTYPE
     from mercury_amd.physical_layer import Config, Info
     assert STATS_DTYPE.itemsize == 24           # 4 ints + 2 floats
-    assert C.sizeof(Config) == 32
-    assert C.sizeof(Info) == 4 * 28
+    assert C.sizeof(Config) == 36               # 7 ints, 1 float, mfsk_ctrl_mode
+    assert C.sizeof(Info) == 4 * 32
 
 
 def test_bad_arguments_return_error_codes():
@@ -39,7 +39,8 @@ def test_bad_arguments_return_error_codes():
     from mercury_amd.physical_layer import Config
     lib = load_library()
     h = C.c_void_p()
-    for bad in (Config(17, 50, 1, 1, 1, 0, 16, 0.0), Config(-1, 50, 1, 1, 1, 0, 16, 0.0),
+    for bad in (Config(17, 50, 1, 1, 1, 0, 16, 0.0), Config(-1, 50, 1, 1, 1, 0, 16, 0.0), Config(99, 50, 1, 1, 1, 0, 16, 0.0),
+                Config(103, 50, 1, 1, 1, 0, 16, 0.0),
                 Config(8, 0, 1, 1, 1, 0, 16, 0.0), Config(8, 50, 7, 1, 1, 0, 16, 0.0), Config(8, 50, 1, 1, 1, 0, 0, 0.0)):
         rc = lib.mgpu_create(C.byref(bad), C.byref(h))
         assert rc == 1 and not h.value

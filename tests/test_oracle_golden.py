@@ -92,3 +92,40 @@ def test_interleaver_tail_passthrough_modes():
         payload = np.arange(orc.payload_bytes, dtype=np.int32) % 251
         r = orc.rx(orc.tx(orc.payload_to_bits(payload), 1), oraclelib.FLAGS_BASEBAND_TEST)
         assert np.array_equal(r["bytes"][: orc.payload_bytes], payload)
+
+
+# ---- MFSK modes (ROBUST_0..2 = cfg 100..102): fixtures from tests/golden/make_golden.py --mfsk -----------------
+META_MFSK = json.load(open(os.path.join(HERE, "golden", "golden_mfsk.json")))
+ARR_MFSK = np.load(os.path.join(HERE, "golden", "golden_mfsk.npz"))
+
+
+@pytest.mark.parametrize("cfg", [100, 101, 102])
+def test_mfsk_rx_chain_matches_reference_vectors(cfg):
+    orc = oraclelib.Oracle(cfg, 50)
+    m = META_MFSK["modes"][str(cfg)]
+    for k, v in m.items():
+        if k != "frames":
+            assert getattr(orc, k) == v, (cfg, k)
+    assert (orc.M, orc.nPilots, orc.nVirtual, orc.nBits) == (200, 0, 0, 1600)      # MOD_MFSK, no pilots, no shortening
+    for idx, rec in enumerate(m["frames"]):
+        orc.set_ctrl_mode(rec["ctrl_mode"])
+        assert (orc.active_nsymb, orc.active_nbits) == (rec["active_nsymb"], rec["active_nbits"])
+        bb, pl = orc.gen_frame(SEED, rec["frame"], oraclelib.noise_amp_for(rec["esn0_db"]), rec["channel"])
+        assert bb.size == rec["active_nsymb"] * orc.Nofdm
+        assert digest(bb) == rec["input_sha256"], "generator drift (libm?)"
+        assert digest(pl.astype(np.uint8)) == rec["payload_sha256"]
+        r = orc.rx(bb)
+        n = orc.active_nsymb * orc.Nc
+        assert digest(r["grid"][:n]) == rec["sha256"]["grid"]
+        assert digest(r["llr_demod"]) == rec["sha256"]["llr_demod"]
+        key = "cfg%d_f%d" % (cfg, idx)
+        assert r["llr_ldpc"].tobytes() == ARR_MFSK[key + "_llr_ldpc"].tobytes()
+        assert np.array_equal(np.packbits(r["bits"].astype(np.uint8)), ARR_MFSK[key + "_bits"])
+        assert np.array_equal(r["bytes"].astype(np.uint8), ARR_MFSK[key + "_bytes"])
+        assert (r["iterations"], r["crc"], r["all_zeros"], r["snr_db"]) == (rec["iterations"], rec["crc"], rec["all_zeros"], rec["snr_db"])
+        assert np.abs(r["llr_ldpc"]).max() <= 5.0                                   # mfsk.cc:382-384 clamp
+        if rec["ctrl_mode"]:
+            assert np.count_nonzero(r["llr_demod"][orc.active_nbits:]) == 0         # punctured tail, telecom_system.cc:1183-1191
+        if rec["esn0_db"] == 60.0:
+            assert r["crc"] == 0 and r["snr_db"] == 0.0 and np.array_equal(r["bytes"][: orc.payload_bytes], pl)
+    orc.set_ctrl_mode(0)

@@ -41,3 +41,28 @@ def test_ldpc_decode_identical(cfg):
         b1, i1 = orc.ldpc_decode(llr)
         b2, i2 = ref.ldpc_decode(llr)
         assert i1 == i2 and np.array_equal(b1, b2)
+
+
+@pytest.mark.parametrize("cfg", [100, 101, 102])
+def test_mfsk_modes_identical(cfg):
+    """ROBUST_0..2: cl_mfsk::mod / demod (mfsk.cc:232-390) and the MFSK branch of receive_byte, full and control frames."""
+    orc, ref = oraclelib.Oracle(cfg, 50), oraclelib.RefLib(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    for ctrl in (0, 1):
+        orc.set_ctrl_mode(ctrl)
+        ref.set_ctrl_mode(ctrl)
+        for n in oraclelib.INFO_FIELDS:
+            if n != "dwidth":
+                assert getattr(orc, n) == getattr(ref, n), n
+        for i, snr in enumerate((op, op - 2.0, 40.0)):
+            bb, pl = orc.gen_frame(77, 10 * cfg + 3 * ctrl + i, oraclelib.noise_amp_for(snr))
+            bits = orc.payload_to_bits(pl)
+            assert np.array_equal(bits, ref.payload_to_bits(pl))
+            assert orc.tx(bits, 1).tobytes() == ref.tx(bits, 1).tobytes()
+            a, b = orc.rx(bb), ref.rx(bb)
+            n = orc.active_nsymb * orc.Nc
+            assert a["grid"][:n].tobytes() == b["grid"][:n].tobytes()
+            for k in ("llr_demod", "llr_ldpc", "bits", "bytes"):
+                assert a[k].tobytes() == b[k].tobytes(), (cfg, ctrl, snr, k)
+            for k in ("iterations", "crc", "all_zeros", "snr_db"):
+                assert a[k] == b[k], (cfg, ctrl, snr, k)
