@@ -26,7 +26,8 @@ extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
 extern "C" size_t mgpu_txgen_lds_bytes(int G);
 
 extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
-extern "C" __global__ void mgpu_mfsk_frontend_kernel(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
+extern "C" __global__ void mgpu_mfsk_frontend_kernel_m32(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
+extern "C" __global__ void mgpu_mfsk_frontend_kernel_m16x2(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
 extern "C" int mgpu_mfsk_syms_per_block();
 extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
@@ -238,12 +239,15 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
     if (t.mfsk_M > 0) {
         // MFSK modes: workgroups of (frame, run of symbols); keep gridDim * blockDim below 2^32
         const int per = mgpu_mfsk_syms_per_block(), chunks = (t.active_nsymb + per - 1) / per;
+        if (!((t.mfsk_M == 32 && t.mfsk_nstreams == 1) || (t.mfsk_M == 16 && t.mfsk_nstreams == 2)) || t.mfsk_off[0] != 9 ||
+            (t.mfsk_nstreams == 2 && t.mfsk_off[1] != 25) || t.Nc != 50)
+            throw std::runtime_error("MFSK tone plan differs from the one the kernel is specialised for");
         const int max_frames = (1 << 23) / chunks;
         for (int off = 0; off < F; off += max_frames) {
             const int n = F - off < max_frames ? F - off : max_frames;
             if (off && (taps.grid || taps.llr_demod || taps.variance || taps.agc_gain))
                 throw std::invalid_argument("stage taps are limited to one launch per call");
-            hipLaunchKernelGGL(mgpu_mfsk_frontend_kernel, dim3(unsigned(n) * chunks), dim3(256), 0, s, c->dev,
+            hipLaunchKernelGGL(t.mfsk_M == 32 ? mgpu_mfsk_frontend_kernel_m32 : mgpu_mfsk_frontend_kernel_m16x2, dim3(unsigned(n) * chunks), dim3(256), 0, s, c->dev,
                                d_bb + size_t(off) * t.frame_samples * 2, n, chunks, d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), taps);
             HIPCK(hipGetLastError());
         }

@@ -24,18 +24,22 @@ __device__ __forceinline__ int brev8(int p) { return int(__brev(unsigned(p)) >> 
 // In:  r_k = x[lane + 64 k]  (natural order).
 // Out: r_k = X[brev8(4 lane + k)]  (unscaled).
 // tw:  128 twiddles in LDS: exp(-2 pi i j / 256) for the forward transform, their conjugates for the inverse.
-__device__ __forceinline__ void wave_fft256(c2& r0, c2& r1, c2& r2, c2& r3, c2* v, const c2* tw, int lane) {
-    auto bfly = [&](c2& lo, c2& hi, int p0, int st) {
-        const int j = brev8(p0) & ((1 << (st - 1)) - 1);
-        const c2 t = cmul(tw[j << (8 - st)], hi);
+__device__ __forceinline__ void wave_fft256(c2& r0, c2& r1, c2& r2, c2& r3, c2* __restrict__ v, const c2* __restrict__ tw, int lane) {
+    auto bfly_w = [](c2& lo, c2& hi, const c2& w) {
+        const c2 t = cmul(w, hi);
         const c2 u = lo;
         hi = {u.re - t.re, u.im - t.im};
         lo = {u.re + t.re, u.im + t.im};
     };
+    auto bfly = [&](c2& lo, c2& hi, int p0, int st) {
+        const int j = brev8(p0) & ((1 << (st - 1)) - 1);
+        bfly_w(lo, hi, tw[j << (8 - st)]);
+    };
     auto padded = [](int p) { return p + (p >> 4); };
-    // stages 1, 2: positions lane + 64k
-    bfly(r0, r2, lane, 1); bfly(r1, r3, lane + 64, 1);
-    bfly(r0, r1, lane, 2); bfly(r2, r3, lane + 128, 2);
+    // stages 1, 2: positions lane + 64k; their twiddle indices are wave-uniform (0, 0, 0 and 64)
+    const c2 w0 = tw[0], w64 = tw[64];
+    bfly_w(r0, r2, w0); bfly_w(r1, r3, w0);
+    bfly_w(r0, r1, w0); bfly_w(r2, r3, w64);
     v[padded(lane)] = r0; v[padded(lane + 64)] = r1; v[padded(lane + 128)] = r2; v[padded(lane + 192)] = r3;
     __builtin_amdgcn_wave_barrier();
     // stages 3, 4: positions pb + 16k

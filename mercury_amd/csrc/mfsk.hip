@@ -24,9 +24,28 @@
 
 extern "C" int mgpu_mfsk_syms_per_block() { return MF_SYMS; }
 
-extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_mfsk_frontend_kernel(
-    MgpuDev T, const double* __restrict__ baseband, int F, int chunks, float* __restrict__ llr_out,
-    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, MgpuTapsDev taps) {
+namespace {
+
+// In every MFSK mode the tone band is carriers [9, 41) of the 50 (cl_mfsk::init, mfsk.cc:69-76: nStreams * M == 32
+// bins centred in Nc == 50); the host checks this before launching (api.hip).
+constexpr int kBandStart = 9, kBandEnd = 41, kNoiseBins = 50 - (kBandEnd - kBandStart);
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const unsigned lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const unsigned hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(int(hi), int(lo));
+}
+
+// max of two non-NaN doubles (the operands are energies or the -1e30 floor): one v_max_f64
+__device__ __forceinline__ double shfl_xor_max(double v, int d) { return __builtin_fmax(__shfl_xor(v, d), v); }
+
+// M tones per stream (32 or 16), NS streams (1 or 2): M * NS == 32 tone lanes per symbol
+template <int M, int NS>
+__device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __restrict__ baseband, int F, int chunks,
+                                              float* __restrict__ llr_out, float* __restrict__ variance_out,
+                                              float* __restrict__ snr_variance_out, const MgpuTapsDev& taps) {
+    constexpr int NB = M == 32 ? 5 : 4, BPS = NB * NS, HOP = M == 32 ? 13 : 7;   // mfsk.cc:56-66
+    static_assert(M * NS == kBandEnd - kBandStart, "tone band");
     __shared__ c2 tw[128];
     __shared__ c2 fftb[MF_WAVES * FFT256_STRIDE];
     __shared__ double en[MF_WAVES][64];          // |carrier|^2 of the wave's current symbol, carrier order
@@ -34,7 +53,7 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_mfsk_frontend_kern
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f = blockIdx.x / chunks, chunk = blockIdx.x - f * chunks;
     if (f >= F) return;
-    const int Nc = 50, ns = T.active_nsymb, bps = T.bps, M = T.mfsk_M, nb = T.mfsk_nbits;
+    const int Nc = 50, ns = T.active_nsymb;
     const int s0 = chunk * MF_SYMS, s1 = min(ns, s0 + MF_SYMS);
     const c2* bb = reinterpret_cast<const c2*>(baseband) + size_t(f) * T.frame_samples;
     float* out = llr_out + size_t(f) * T.N;
@@ -56,8 +75,13 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_mfsk_frontend_kern
     }
     __syncthreads();
 
-    const int band_start = T.mfsk_off0;
-    const int band_end = (T.mfsk_nstreams > 1 ? T.mfsk_off1 : T.mfsk_off0) + M;
+    // lane roles in the demapper: lane (st, m) = data tone m of stream st; lanes 0..17 also fetch the out-of-band carriers
+    const int st = lane >= M ? 1 : 0, m = lane & (M - 1);
+    const bool tone_lane = lane < M * NS;
+    const int gray_m = m ^ (m >> 1);
+    const int tone_off = kBandStart + st * M;
+    const int noise_col = lane < kBandStart ? lane : lane + (kBandEnd - kBandStart);   // 0..8, 41..49 for lanes 0..17
+
     c2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
     if (s0 + wave < s1) {
         const c2* in = bb + size_t(s0 + wave) * 272 + 16;            // gi_remover
@@ -83,38 +107,77 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_mfsk_frontend_kern
         };
         emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
         __builtin_amdgcn_wave_barrier();
-        // noise variance: the out-of-band energies added in carrier order (every lane computes the same value)
+
+        // ---- noise variance: the out-of-band energies added in carrier order (mfsk.cc:303-318) ----
+        const double ev = lane < kNoiseBins ? E[noise_col] : 0.0;
         double noise_sum = 0.0;
         int noise_bins = 0;
-        for (int k = 0; k < Nc; ++k) {
-            if (k >= band_start && k < band_end) continue;
-            const double e = E[k];
-            if (isfinite(e)) { noise_sum += e; ++noise_bins; }
+        if (__builtin_amdgcn_ballot_w64(!isfinite(ev)) == 0) {       // the usual case: every term counts
+#pragma unroll
+            for (int k = 0; k < kNoiseBins; ++k) noise_sum += readlane_f64(ev, k);
+            noise_bins = kNoiseBins;
+        } else {                                                     // NaN / Inf samples: skip those terms
+            for (int k = 0; k < Nc; ++k) {
+                if (k >= kBandStart && k < kBandEnd) continue;
+                const double e = E[k];
+                if (isfinite(e)) { noise_sum += e; ++noise_bins; }
+            }
         }
         double noise_var = noise_bins > 0 ? noise_sum / noise_bins : 1e-30;
         if (noise_var < 1e-30) noise_var = 1e-30;
         const double llr_scale = 1.0 / (2.0 * noise_var);
-        if (lane < bps) {                                            // one lane per bit of the symbol period
-            const int st = lane / nb, k = lane - st * nb;
-            const int off = st == 0 ? T.mfsk_off0 : T.mfsk_off1;
-            const int hop = (s * T.mfsk_hop) % M;
-            const int mask = 1 << (nb - 1 - k);
-            double max_E1 = -1e30, max_E0 = -1e30;
-            for (int m = 0; m < M; ++m) {
-                double e = E[off + ((m + hop) % M)];
-                if (!isfinite(e)) e = 0.0;
-                const int gray_m = m ^ (m >> 1);
-                if (gray_m & mask) { if (e > max_E1) max_E1 = e; }
-                else { if (e > max_E0) max_E0 = e; }
-            }
-            double llr = (max_E0 - max_E1) * llr_scale;
+
+        // ---- max-log LLRs (mfsk.cc:322-388). Tone energies with the hop undone sit one per lane; bit k of a
+        // stream needs the maxima over the tones whose Gray label g = m ^ (m >> 1) has bit j = NB-1-k set / clear.
+        // g_j = m_j ^ m_(j+1): the two sets are unions of aligned 2^j-blocks in the pattern 0 1 1 0 | 0 1 1 0 ...
+        // Maxima are order-independent, so a butterfly gives the reference's sequential result exactly:
+        // blk = max over the lane's aligned 2^j-block (shared tree), then xor 3*2^j and xor 4*2^j, 8*2^j, ... stay
+        // inside the lane's own set, and one exchange at xor 2^j fetches the other set's maximum.
+        double e = -1e30;
+        if (tone_lane) {
+            const int hop = (s * HOP) & (M - 1);
+            e = E[tone_off + ((m + hop) & (M - 1))];
+            if (!isfinite(e)) e = 0.0;
+        }
+        double blk = e;                                              // max over the aligned 2^j-block, j = 0 now
+        double diff = 0.0;                                           // max_E0 - max_E1 of the bit this lane writes
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double own = blk;
+            if ((2 << j) < M) own = shfl_xor_max(own, 3 << j);
+#pragma unroll
+            for (int d = 4 << j; d < M; d <<= 1) own = shfl_xor_max(own, d);
+            double other;
+            if ((2 << j) <= M && (1 << j) < M) other = __shfl_xor(own, 1 << j);
+            else other = -1e30;
+            const bool set1 = (gray_m >> j) & 1;
+            const double max_E1 = set1 ? own : other, max_E0 = set1 ? other : own;
+            if (m == NB - 1 - j) diff = max_E0 - max_E1;             // lane m writes bit k = m of its stream
+            if (j + 1 < NB) blk = shfl_xor_max(blk, 1 << j);         // next level of the shared tree
+        }
+        if (tone_lane && m < NB) {
+            double llr = diff * llr_scale;
             if (!isfinite(llr)) llr = 0.0;
             else if (llr > 5.0) llr = 5.0;
             else if (llr < -5.0) llr = -5.0;
-            const int idx = s * bps + lane;
+            const int idx = s * BPS + st * NB + m;
             out[T.llr_dst[idx]] = float(llr);
             if (taps.llr_demod) taps.llr_demod[size_t(f) * T.nBits + idx] = float(llr);
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_mfsk_frontend_kernel_m32(
+    MgpuDev T, const double* __restrict__ baseband, int F, int chunks, float* __restrict__ llr_out,
+    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, MgpuTapsDev taps) {
+    mfsk_frontend<32, 1>(T, baseband, F, chunks, llr_out, variance_out, snr_variance_out, taps);
+}
+
+extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_mfsk_frontend_kernel_m16x2(
+    MgpuDev T, const double* __restrict__ baseband, int F, int chunks, float* __restrict__ llr_out,
+    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, MgpuTapsDev taps) {
+    mfsk_frontend<16, 2>(T, baseband, F, chunks, llr_out, variance_out, snr_variance_out, taps);
 }

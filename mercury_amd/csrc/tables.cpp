@@ -246,7 +246,7 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
         t.mfsk_M = cfg == 100 ? 32 : 16;
         t.mfsk_nstreams = cfg == 100 ? 1 : 2;
         t.mfsk_nbits = cfg == 100 ? 5 : 4;
-        t.mfsk_hop = t.mfsk_M == 32 ? 13 : 7;
+        t.mfsk_hop = t.mfsk_M == 32 ? 13 : 7;                                // M is a power of two: the kernels reduce mod M with a mask
         const int global_offset = (t.Nc - t.mfsk_nstreams * t.mfsk_M) / 2;
         for (int k = 0; k < t.mfsk_nstreams; ++k) t.mfsk_off[k] = global_offset + k * t.mfsk_M;
         t.mfsk_amp = std::sqrt(double(t.Nc) / t.mfsk_nstreams);

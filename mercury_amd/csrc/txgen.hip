@@ -156,7 +156,7 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
                 int bin = tone;
                 for (int sh = 1; sh < T.mfsk_nbits; ++sh) bin ^= tone >> sh;          // Gray -> binary
                 if (bin >= T.mfsk_M) bin = T.mfsk_M - 1;
-                const int actual = (bin + s * T.mfsk_hop) % T.mfsk_M;                 // tone hopping
+                const int actual = (bin + s * T.mfsk_hop) & (T.mfsk_M - 1);           // tone hopping (M is 16 or 32)
                 if (st == 0) tone0 = T.mfsk_off0 + actual; else tone1 = T.mfsk_off1 + actual;
             }
         }
