@@ -290,7 +290,7 @@ def main():
             "dtype": "f64" if args.decoder == "spa" else "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[4]-style decoder-only soak: %d rate-%d/1600 codewords per GPU per step, noise-only LLRs, "
                                     "decoder=%s, max %d iterations" % (F, rx.K, args.decoder, args.iters)) if args.ldpc_only else
-                                   ("BASELINE.json configs[1]: %d mode-%d OFDM frames per GPU per step through %s at Es/N0 %+.1f dB, "
+                                   ("BASELINE.json configs[1]: %d mode-%d frames per GPU per step through %s at Es/N0 %+.1f dB, "
                                     "%s variant, decoder=%s, max %d iterations" % (F, args.cfg, "2-path+AWGN" if args.channel else "AWGN",
                                                                                    args.esn0, args.variant, args.decoder, args.iters)),
                        "frames_per_step_per_gpu": F, "cfg": args.cfg, "esn0_db": args.esn0, "decoder": args.decoder,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2]: sweep all 17 OFDM modes (each with the LDPC rate the reference pairs it
-with), report per-mode RX throughput for the sum-product (reference) and min-sum decoders, at the
-worst case (every frame runs all 50 iterations, Es/N0 = -15 dB) and at the operating point.
+with) and the three MFSK modes (ROBUST_0..2 = cfg 100..102), report per-mode RX throughput for the sum-product (reference) and min-sum decoders, at the
+worst case (every frame runs all 50 iterations, Es/N0 = -15 dB; -25 dB for the MFSK modes) and at the operating point.
 Writes one JSON document; run on the GPU box:  python tools/sweep_modes.py > gpurun_out/sweep.json
 """
 import json
@@ -28,13 +28,13 @@ def run(cfg, decoder, esn0, frames, steps=3):
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
     res = {"frames_per_step": frames, "modes": {}}
-    for cfg in range(17):
+    for cfg in list(range(17)) + [100, 101, 102]:
         m = {}
         for dec in ("spa", "minsum"):
-            m[dec + "_50iters"] = run(cfg, dec, -15.0, frames)
+            m[dec + "_50iters"] = run(cfg, dec, -25.0 if cfg >= 100 else -15.0, frames)
             m[dec + "_operating"] = run(cfg, dec, OPERATING_ESN0[cfg] + 1.0, frames)
         res["modes"][str(cfg)] = m
-        print("cfg %2d  spa@50 %9.0f f/s  minsum@50 %9.0f f/s  spa@op %9.0f f/s (%.1f it, %.3f ok)  minsum@op %9.0f f/s (%.3f ok)" % (
+        print("cfg %3d  spa@50 %9.0f f/s  minsum@50 %9.0f f/s  spa@op %9.0f f/s (%.1f it, %.3f ok)  minsum@op %9.0f f/s (%.3f ok)" % (
             cfg, m["spa_50iters"]["frames_per_s"], m["minsum_50iters"]["frames_per_s"], m["spa_operating"]["frames_per_s"],
             m["spa_operating"]["avg_iters"], m["spa_operating"]["decoded_fraction"], m["minsum_operating"]["frames_per_s"],
             m["minsum_operating"]["decoded_fraction"]), file=sys.stderr)
