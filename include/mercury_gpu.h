@@ -156,6 +156,18 @@ int mgpu_passband_to_baseband(mgpu_ctx* ctx, const double* passband /*[W][in_siz
 int mgpu_time_sync_preamble(mgpu_ctx* ctx, const double* baseband_interp_c128 /*[W][size][2]*/, int W, int size, int step,
                             int location_to_return, int nTrials_max, int* delay /*[W]*/, double* correlation /*[W] or NULL*/);
 int mgpu_freq_sync(mgpu_ctx* ctx, const double* baseband_c128 /*[W][stride][2]*/, int W, int stride, double* freq_offset_hz /*[W]*/);
+/* MFSK modes: cl_ofdm::time_sync_mfsk (ofdm.cc:1969-2062) with the arguments receive_byte passes
+ * (telecom_system.cc:686: the mode's preamble tones / streams, interpolation rate 4): symbol-slot search of the known
+ * preamble tone sequence; delay[w] is in interpolated samples. cfg 100..102 only.
+ * Every mode: cl_ofdm::detect_ack_pattern (ofdm.cc:2064-2187) on the universal 16-tone pattern of
+ * detect_ack_pattern_from_passband (telecom_system.cc:1643-1651, pattern = 1) or the BREAK tones of
+ * detect_break_pattern_from_passband (:1698-1706, pattern = 2); metric[w] is the best window metric (0..16),
+ * matched[w] (may be NULL) its count of symbols whose expected tone was the band's peak.
+ * Both take baseband at the interpolated rate as passband_to_baseband (decimation 1) leaves it. */
+int mgpu_time_sync_mfsk(mgpu_ctx* ctx, const double* baseband_interp_c128 /*[W][size][2]*/, int W, int size, int search_start_symb,
+                        int* delay /*[W]*/);
+int mgpu_detect_ack_pattern(mgpu_ctx* ctx, const double* baseband_interp_c128 /*[W][size][2]*/, int W, int size, int pattern,
+                            double* metric /*[W]*/, int* matched /*[W] or NULL*/);
 /* duration (ms, HIP events on the launch stream) of the kernel of the most recent synchroniser call */
 int mgpu_last_sync_kernel_ms(mgpu_ctx* ctx, float* ms);
 

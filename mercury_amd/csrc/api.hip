@@ -29,6 +29,7 @@ extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, flo
 extern "C" __global__ void mgpu_mfsk_frontend_kernel_m32(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
 extern "C" __global__ void mgpu_mfsk_frontend_kernel_m16x2(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
 extern "C" int mgpu_mfsk_syms_per_block();
+extern "C" __global__ void mgpu_slot_energy_kernel(const double*, int, int, int, const double*, double*);
 extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
 extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*);
@@ -581,6 +582,104 @@ int mgpu_freq_sync(mgpu_ctx* c, const double* bb, int W, int stride, double* fre
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         HIPCK(hipMemcpyAsync(freq_offset_hz, d_out.p, size_t(W) * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+// ---- MFSK synchroniser / signalling blocks (host buffers, blocking) -----------------------------------
+namespace {
+// mfsk.cc:82-95, :120-126, :149-155; the universal ACK/BREAK patterns use M = 16, one stream centred in Nc = 50
+// (telecom_system.cc:3006), hop step 7, 8 tones sent twice.
+constexpr int kPreamble32[4] = {4, 20, 12, 28}, kPreamble16[4] = {2, 10, 6, 14};
+constexpr int kAckTones[8] = {4, 7, 5, 12, 13, 1, 9, 15}, kBreakTones[8] = {6, 14, 2, 3, 10, 8, 11, 15};
+constexpr int kAckM = 16, kAckNsymb = 16, kAckLen = 8, kAckHop = 7, kAckOffset = 17, kInterp = 4;
+
+// carrier energies of every symbol slot of W windows: [W][nslots][50] on the host
+std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size, int nslots) {
+    const auto& t = c->tab;
+    DevBuf d_in(size_t(W) * size * 16), d_e(size_t(W) * nslots * t.Nc * 8);
+    hipStream_t s = c->stream;
+    HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
+    HIPCK(hipMemsetAsync(d_e.p, 0, size_t(W) * nslots * t.Nc * 8, s));
+    HIPCK(hipEventRecord(c->sync_ev[0], s));
+    hipLaunchKernelGGL(mgpu_slot_energy_kernel, dim3((nslots + 3) / 4, W), dim3(256), 0, s, d_in.as<double>(), size, nslots, kInterp,
+                       c->dev.twiddle, d_e.as<double>());
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(c->sync_ev[1], s));
+    std::vector<double> e(size_t(W) * nslots * t.Nc);
+    HIPCK(hipMemcpyAsync(e.data(), d_e.p, e.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    return e;
+}
+}  // namespace
+
+int mgpu_time_sync_mfsk(mgpu_ctx* c, const double* bb, int W, int size, int search_start_symb, int* delay) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        const auto& t = c->tab;
+        need(t.mfsk_M > 0, "time_sync_mfsk needs an MFSK mode (cfg 100..102)");
+        const int sym_period = t.Nofdm * kInterp, nslots = size / sym_period, np = t.preamble;
+        need(bb && delay && W > 0 && nslots >= np, "bad argument");
+        const std::vector<double> E = slot_energies(c, bb, W, size, nslots);
+        const int* tones = t.mfsk_M == 32 ? kPreamble32 : kPreamble16;
+        for (int w = 0; w < W; ++w) {                                  // ofdm.cc:2004-2058
+            double best_metric = -1;
+            int best = 0;
+            for (int s = search_start_symb > 0 ? search_start_symb : 0; s <= nslots - np; ++s) {
+                double metric = 0;
+                for (int p = 0; p < np; ++p) {
+                    if ((s + p) * sym_period + t.Ngi * kInterp + t.Nfft * kInterp > size) break;
+                    const double* e = &E[(size_t(w) * nslots + s + p) * t.Nc];
+                    double e_target = 0;
+                    for (int st = 0; st < t.mfsk_nstreams; ++st) e_target += e[t.mfsk_off[st] + tones[p % np]];
+                    double e_total = 0;
+                    for (int k = 0; k < t.Nc; ++k) e_total += e[k];
+                    if (e_total > 0) metric += e_target / e_total;
+                }
+                if (metric > best_metric) { best_metric = metric; best = s; }
+            }
+            delay[w] = best * sym_period;
+        }
+    });
+}
+
+int mgpu_detect_ack_pattern(mgpu_ctx* c, const double* bb, int W, int size, int pattern, double* metric_out, int* matched_out) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        const auto& t = c->tab;
+        const int sym_period = t.Nofdm * kInterp, nslots = size / sym_period;
+        need(bb && metric_out && W > 0 && size > 0 && (pattern == 1 || pattern == 2) && t.Nc == 50, "bad argument");
+        if (nslots < kAckNsymb) {                                      // ofdm.cc:2075
+            for (int w = 0; w < W; ++w) { metric_out[w] = 0.0; if (matched_out) matched_out[w] = 0; }
+            return;
+        }
+        const std::vector<double> E = slot_energies(c, bb, W, size, nslots);
+        const int* tones = pattern == 2 ? kBreakTones : kAckTones;
+        for (int w = 0; w < W; ++w) {                                  // ofdm.cc:2085-2178
+            double best_metric = 0.0;
+            int best_matched = 0;
+            for (int s = 0; s <= nslots - kAckNsymb; ++s) {
+                double metric = 0;
+                int matched = 0;
+                for (int p = 0; p < kAckNsymb; ++p) {
+                    if ((s + p) * sym_period + t.Ngi * kInterp + t.Nfft * kInterp > size) break;
+                    const double* e = &E[(size_t(w) * nslots + s + p) * t.Nc];
+                    const int actual = (tones[p % kAckLen] + p * kAckHop) % kAckM;
+                    const double e_expected = e[kAckOffset + actual];
+                    double e_target = 0;
+                    e_target += e_expected;
+                    double peak_e = -1.0;
+                    for (int q = 0; q < kAckM; ++q) if (e[kAckOffset + q] > peak_e) peak_e = e[kAckOffset + q];
+                    if (!(e_expected >= peak_e)) continue;             // the expected tone must be the band's peak
+                    ++matched;
+                    double e_total = 0;
+                    for (int k = 0; k < t.Nc; ++k) e_total += e[k];
+                    if (e_total > 0) metric += e_target / e_total;
+                }
+                if (metric > best_metric) { best_metric = metric; best_matched = matched; }
+            }
+            metric_out[w] = best_metric;
+            if (matched_out) matched_out[w] = best_matched;
+        }
     });
 }
 

@@ -181,3 +181,34 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_mfsk_frontend_kern
     float* __restrict__ variance_out, float* __restrict__ snr_variance_out, MgpuTapsDev taps) {
     mfsk_frontend<16, 2>(T, baseband, F, chunks, llr_out, variance_out, snr_variance_out, taps);
 }
+
+// ---- carrier energies of every symbol slot of a capture window: the FFT half of cl_ofdm::time_sync_mfsk
+// (ofdm.cc:2011-2024) and cl_ofdm::detect_ack_pattern (ofdm.cc:2097-2105). Slot s of window w starts at
+// s * Nofdm * interp + Ngi * interp; its 256 samples are taken `interp` apart (the reference's decimation), transformed
+// with the 1/Nfft scale, and |X|^2 of the 50 carriers is written in carrier order. The sliding-window sums and
+// the arg-max over slots are a few hundred scalar operations per window and stay on the host (api.hip).
+extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_slot_energy_kernel(
+    const double* __restrict__ baseband_interp, int size, int nslots, int interp, const double* __restrict__ twiddle,
+    double* __restrict__ energy /*[W][nslots][50]*/) {
+    __shared__ c2 tw[128];
+    __shared__ c2 fftb[MF_WAVES * FFT256_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.y, s = blockIdx.x * MF_WAVES + wave;
+    for (int i = tid; i < 128; i += MF_THREADS) tw[i] = {twiddle[2 * i], twiddle[2 * i + 1]};
+    __syncthreads();
+    if (s >= nslots) return;
+    const int offset = s * 272 * interp + 16 * interp;
+    if (offset + 256 * interp > size) return;
+    const c2* in = reinterpret_cast<const c2*>(baseband_interp) + size_t(w) * size + offset;
+    c2 r0 = in[size_t(lane) * interp], r1 = in[size_t(lane + 64) * interp];
+    c2 r2 = in[size_t(lane + 128) * interp], r3 = in[size_t(lane + 192) * interp];
+    wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
+    double* E = energy + (size_t(w) * nslots + s) * 50;
+    auto emit = [&](const c2& x, int p) {
+        const int col = carrier_of_bin(brev8(p));
+        if (col < 0) return;
+        const double re = x.re / 256.0, im = x.im / 256.0;
+        E[col] = re * re + im * im;
+    };
+    emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
+}

@@ -81,6 +81,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
+    "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern",
 ]
 
 
@@ -208,6 +209,25 @@ class RxPhy:
         out = np.zeros(W, np.float64)
         self._ck(self.lib.mgpu_freq_sync(self.h, _ptr(z), C.c_int(W), C.c_int(stride), _ptr(out)))
         return out
+
+    def time_sync_mfsk(self, baseband_interp, search_start_symb=0):
+        """cl_ofdm::time_sync_mfsk on W windows of interpolated baseband -> delay [W] (MFSK modes only)."""
+        z = np.ascontiguousarray(baseband_interp, np.complex128)
+        z = z.reshape(1, -1) if z.ndim == 1 else z
+        W, size = z.shape
+        delay = np.zeros(W, np.int32)
+        self._ck(self.lib.mgpu_time_sync_mfsk(self.h, _ptr(z), C.c_int(W), C.c_int(size), C.c_int(search_start_symb), _ptr(delay)))
+        return delay
+
+    def detect_ack_pattern(self, baseband_interp, pattern=1):
+        """cl_ofdm::detect_ack_pattern (pattern 1 = ACK, 2 = BREAK) -> (metric [W], matched [W])."""
+        z = np.ascontiguousarray(baseband_interp, np.complex128)
+        z = z.reshape(1, -1) if z.ndim == 1 else z
+        W, size = z.shape
+        metric = np.zeros(W, np.float64)
+        matched = np.zeros(W, np.int32)
+        self._ck(self.lib.mgpu_detect_ack_pattern(self.h, _ptr(z), C.c_int(W), C.c_int(size), C.c_int(pattern), _ptr(metric), _ptr(matched)))
+        return metric, matched
 
     def last_sync_kernel_ms(self):
         ms = C.c_float(0)

@@ -1016,6 +1016,118 @@ int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, dou
 }
 
 /* the host libm functions exactly as decode_SPA calls them (ldpc_decoder_SPA.cc:145,156) */
+/* ------------------------------------------------------------------------------------ */
+/* MFSK synchroniser / signalling blocks */
+static const int MFSK_PREAMBLE_32[4] = {4, 20, 12, 28}, MFSK_PREAMBLE_16[4] = {2, 10, 6, 14};   /* mfsk.cc:82-95 */
+static const int ACK_TONES_16[8] = {4, 7, 5, 12, 13, 1, 9, 15};                                   /* mfsk.cc:120-126 */
+static const int BREAK_TONES_16[8] = {6, 14, 2, 3, 10, 8, 11, 15};                                /* mfsk.cc:149-155 */
+#define ACK_M 16
+#define ACK_NSYMB 16
+#define ACK_LEN 8
+#define ACK_HOP 7
+#define ACK_OFFSET 17     /* (Nc - 16) / 2: the universal ack_mfsk is M=16, one stream (telecom_system.cc:3006) */
+
+static void symbol_mod(const morc* o, const cd* in, cd* y) {   /* ofdm.cc:855-860 */
+    cd z[256];
+    memset(z, 0, sizeof z);
+    for (int j = 0; j < 25; j++) z[j + 256 - 25] = in[j];
+    for (int j = 25; j < 50; j++) z[j - 25 + 1] = in[j];
+    fft256(o, z, 1);
+    for (int j = 0; j < 256; j++) y[j + 16] = z[j];
+    for (int j = 0; j < 16; j++) y[j] = z[j + 256 - 16];
+}
+
+/* generate_preamble / generate_ack_pattern / generate_break_pattern (mfsk.cc:165-230) + symbol_mod */
+int morc_mfsk_pattern(morc* o, int which, double* out_c128) {
+    cd car[50];
+    cd* out = (cd*)out_c128;
+    if (which == 0) {
+        if (o->M != MOD_MFSK) return 0;
+        const int* tones = o->mfsk_M == 32 ? MFSK_PREAMBLE_32 : MFSK_PREAMBLE_16;
+        double amp = sqrt((double)o->Nc / o->mfsk_nstreams);
+        for (int s = 0; s < o->preamble; s++) {
+            for (int k = 0; k < 50; k++) car[k] = 0.0;
+            for (int st = 0; st < o->mfsk_nstreams; st++) car[o->mfsk_off[st] + tones[s % 4]] = amp;
+            symbol_mod(o, car, &out[s * o->Nofdm]);
+        }
+        return o->preamble;
+    }
+    const int* tones = which == 2 ? BREAK_TONES_16 : ACK_TONES_16;
+    double amp = sqrt((double)o->Nc / 1);
+    for (int s = 0; s < ACK_NSYMB; s++) {
+        for (int k = 0; k < 50; k++) car[k] = 0.0;
+        car[ACK_OFFSET + (tones[s % ACK_LEN] + s * ACK_HOP) % ACK_M] = amp;
+        symbol_mod(o, car, &out[s * o->Nofdm]);
+    }
+    return ACK_NSYMB;
+}
+
+static inline int carrier_bin(int subcarrier) {   /* ofdm.cc:1994-1998 with Nc = 50, start_shift = 1 */
+    return subcarrier < 25 ? 256 - 25 + subcarrier : 1 + (subcarrier - 25);
+}
+static void decimated_fft(const morc* o, const cd* in, int offset, int interp, cd* out) {   /* ofdm.cc:2020-2024 */
+    for (int i = 0; i < 256; i++) out[i] = in[offset + i * interp];
+    fft256(o, out, 0);
+    for (int i = 0; i < 256; i++) out[i] = (creal(out[i]) / 256.0) + (cimag(out[i]) / 256.0) * I;
+}
+static inline double energy(cd v) { return creal(v) * creal(v) + cimag(v) * cimag(v); }
+
+/* cl_ofdm::time_sync_mfsk — ofdm.cc:1969-2062 */
+int morc_time_sync_mfsk(morc* o, const double* in_c128, int size, int interp, int search_start_symb) {
+    if (o->M != MOD_MFSK) return -1;
+    const cd* in = (const cd*)in_c128;
+    int sym_period = o->Nofdm * interp, buffer_nsymb = size / sym_period, np = o->preamble;
+    const int* tones = o->mfsk_M == 32 ? MFSK_PREAMBLE_32 : MFSK_PREAMBLE_16;
+    double best_metric = -1; int best = 0;
+    cd F[256];
+    for (int s = search_start_symb > 0 ? search_start_symb : 0; s <= buffer_nsymb - np; s++) {
+        double metric = 0;
+        for (int p = 0; p < np; p++) {
+            int offset = (s + p) * sym_period + o->Ngi * interp;
+            if (offset + o->Nfft * interp > size) break;
+            decimated_fft(o, in, offset, interp, F);
+            double e_target = 0;
+            for (int st = 0; st < o->mfsk_nstreams; st++) e_target += energy(F[carrier_bin(o->mfsk_off[st] + tones[p % np])]);
+            double e_total = 0;
+            for (int k = 0; k < o->Nc; k++) e_total += energy(F[carrier_bin(k)]);
+            if (e_total > 0) metric += e_target / e_total;
+        }
+        if (metric > best_metric) { best_metric = metric; best = s; }
+    }
+    return best * sym_period;
+}
+
+/* cl_ofdm::detect_ack_pattern — ofdm.cc:2064-2187, on the universal ack_mfsk; which 1 = ACK tones, 2 = BREAK tones */
+double morc_detect_ack_pattern(morc* o, const double* in_c128, int size, int interp, int which, int* out_matched) {
+    const cd* in = (const cd*)in_c128;
+    int sym_period = o->Nofdm * interp, buffer_nsymb = size / sym_period;
+    if (buffer_nsymb < ACK_NSYMB) return 0.0;
+    const int* tones = which == 2 ? BREAK_TONES_16 : ACK_TONES_16;
+    double best_metric = 0.0; int best_matched = 0;
+    cd F[256];
+    for (int s = 0; s <= buffer_nsymb - ACK_NSYMB; s++) {
+        double metric = 0; int matched = 0;
+        for (int p = 0; p < ACK_NSYMB; p++) {
+            int offset = (s + p) * sym_period + o->Ngi * interp;
+            if (offset + o->Nfft * interp > size) break;
+            decimated_fft(o, in, offset, interp, F);
+            int actual = (tones[p % ACK_LEN] + p * ACK_HOP) % ACK_M;
+            double e_expected = energy(F[carrier_bin(ACK_OFFSET + actual)]);
+            double e_target = 0; e_target += e_expected;
+            double peak_e = -1.0;
+            for (int t = 0; t < ACK_M; t++) { double e = energy(F[carrier_bin(ACK_OFFSET + t)]); if (e > peak_e) peak_e = e; }
+            if (!(e_expected >= peak_e)) continue;       /* order-aware: the expected tone must be the stream's peak */
+            matched++;
+            double e_total = 0;
+            for (int k = 0; k < o->Nc; k++) e_total += energy(F[carrier_bin(k)]);
+            if (e_total > 0) metric += e_target / e_total;
+        }
+        if (metric > best_metric) { best_metric = metric; best_matched = matched; }
+    }
+    if (out_matched) *out_matched = best_matched;
+    return best_metric;
+}
+
 void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out) {
     for (int i = 0; i < n; i++) {
         tanh_out[i] = tanh(in[i]);

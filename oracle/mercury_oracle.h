@@ -103,6 +103,13 @@ int morc_time_sync_preamble(morc*, const double* in_c128, int size, int interpol
 double morc_freq_sync(morc*, const double* in_c128, double carrier_freq_width, int preamble_nSymb, double fs);
 int morc_tx_passband(morc*, const int* bits, double fs, double carrier_hz, double amplitude, double* out_passband);
 
+/* ---- MFSK synchroniser / signalling blocks: time_sync_mfsk (ofdm.cc:1969-2062, arguments of telecom_system.cc:686),
+ * detect_ack_pattern (ofdm.cc:2064-2187; which 1 = ACK tones as telecom_system.cc:1643, 2 = BREAK tones as :1698), and the
+ * known tone patterns as unscaled time-domain symbols (which 0 = the mode's MFSK preamble, 1 = ACK, 2 = BREAK) ---- */
+int morc_mfsk_pattern(morc*, int which, double* out_c128);   /* returns the symbol count; out [n*Nofdm] */
+int morc_time_sync_mfsk(morc*, const double* in_c128, int size, int interpolation_rate, int search_start_symb);
+double morc_detect_ack_pattern(morc*, const double* in_c128, int size, int interpolation_rate, int which, int* matched);
+
 /* host libm tanh / atanh as the reference's decoder calls them; atanh_out is 0 where |x| >= 1 */
 void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out);
 

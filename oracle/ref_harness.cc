@@ -78,6 +78,7 @@ struct Ref {
     cl_psk psk;
     cl_ldpc ldpc;
     cl_mfsk mfsk;                    // ROBUST_0..2 (cfg 100..102) only
+    cl_mfsk ack_mfsk;                // universal ACK / BREAK tone patterns, every mode (telecom_system.cc:3003-3006)
     int ctrl_nBits, ctrl_nsymb;      // telecom_system.cc:2968-2989
     int active_nbits, active_nsymb;  // get_active_nbits / get_active_nsymb, telecom_system.cc:1577-1585
     int cfg, M, bps;
@@ -220,6 +221,7 @@ void* mref_create(int cfg, int max_iters) {
     r->ctrl_nsymb = robust ? r->ctrl_nBits / r->mfsk.bits_per_symbol() : 0;
     r->active_nbits = r->nBits;
     r->active_nsymb = r->Nsymb;
+    r->ack_mfsk.init(16, r->Nc, 1);  // telecom_system.cc:3006
     int g = r->Nsymb * r->Nc;
     r->modulated = new cd[g];
     r->tf_inter = new cd[g];
@@ -570,6 +572,45 @@ int mref_tx_passband(void* h, const int* bits, double fs, double carrier_hz, dou
     r->ofdm.baseband_to_passband(pre_mod.data(), r->Nofdm * pre, out_passband, fs, carrier_hz, amplitude, interp);
     r->ofdm.baseband_to_passband(data, r->Nofdm * r->Nsymb, &out_passband[r->Nofdm * pre * interp], fs, carrier_hz, amplitude, interp);
     return (pre + r->Nsymb) * r->Nofdm * interp;
+}
+
+// ---- MFSK synchroniser / signalling blocks ------------------------------------------------------------
+// Known tone patterns as time-domain symbols (symbol_mod applied, unscaled): which 0 = the mode's MFSK preamble
+// (generate_preamble, telecom_system.cc:461-465; MFSK modes only), 1 = ACK, 2 = BREAK (generate_ack_pattern /
+// generate_break_pattern on the universal ack_mfsk, telecom_system.cc:1600, :1664). Returns the symbol count.
+int mref_mfsk_pattern(void* h, int which, double* out_c128) {
+    Ref* r = (Ref*)h;
+    Silence s;
+    int n = 0;
+    std::vector<cd> carriers(size_t(cl_mfsk::ACK_PATTERN_NSYMB) * r->Nc);
+    if (which == 0) {
+        if (r->M != MOD_MFSK) return 0;
+        n = r->preamble_nsymb;
+        r->mfsk.generate_preamble(carriers.data(), n);
+    } else {
+        n = cl_mfsk::ACK_PATTERN_NSYMB;
+        if (which == 1) r->ack_mfsk.generate_ack_pattern(carriers.data());
+        else r->ack_mfsk.generate_break_pattern(carriers.data());
+    }
+    for (int i = 0; i < n; i++) r->ofdm.symbol_mod(&carriers[size_t(i) * r->Nc], &((cd*)out_c128)[size_t(i) * r->Nofdm]);
+    return n;
+}
+// cl_ofdm::time_sync_mfsk (ofdm.cc:1969-2062) with the arguments of telecom_system.cc:686
+int mref_time_sync_mfsk(void* h, const double* in_c128, int size, int interpolation_rate, int search_start_symb) {
+    Ref* r = (Ref*)h;
+    Silence s;
+    if (r->M != MOD_MFSK) return -1;
+    return r->ofdm.time_sync_mfsk((cd*)in_c128, size, interpolation_rate, r->preamble_nsymb, r->mfsk.preamble_tones, r->mfsk.M,
+                                  r->mfsk.nStreams, r->mfsk.stream_offsets, search_start_symb);
+}
+// cl_ofdm::detect_ack_pattern (ofdm.cc:2064-2187) with the arguments of telecom_system.cc:1643-1651 (which = 1)
+// and :1698-1706 (which = 2, BREAK tones)
+double mref_detect_ack_pattern(void* h, const double* in_c128, int size, int interpolation_rate, int which, int* matched) {
+    Ref* r = (Ref*)h;
+    Silence s;
+    return r->ofdm.detect_ack_pattern((cd*)in_c128, size, interpolation_rate, cl_mfsk::ACK_PATTERN_NSYMB,
+                                      which == 2 ? r->ack_mfsk.break_tones : r->ack_mfsk.ack_tones, cl_mfsk::ACK_PATTERN_LEN,
+                                      r->ack_mfsk.tone_hop_step, r->ack_mfsk.M, r->ack_mfsk.nStreams, r->ack_mfsk.stream_offsets, matched);
 }
 
 // cl_ldpc::decode alone (ldpc.h:90). alg: 1 = SPA (default), 0 = GBF.

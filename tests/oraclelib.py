@@ -272,7 +272,30 @@ def _sync_methods(cls):
         assert n == out.size
         return out
 
-    for fn in (preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband):
+    def mfsk_pattern(self, which):
+        """Known tone pattern as unscaled time-domain symbols: 0 = the mode's MFSK preamble, 1 = ACK, 2 = BREAK."""
+        out = np.zeros(16 * self.Nofdm, np.complex128)
+        f = self._fn("mfsk_pattern")
+        f.restype = C.c_int
+        n = f(self.h, C.c_int(which), _p(out))
+        return out[: n * self.Nofdm].copy()
+
+    def time_sync_mfsk(self, bb, search_start_symb=0, interp=4):
+        z = np.ascontiguousarray(bb, np.complex128)
+        f = self._fn("time_sync_mfsk")
+        f.restype = C.c_int
+        return int(f(self.h, _p(z), C.c_int(z.size), C.c_int(interp), C.c_int(search_start_symb)))
+
+    def detect_ack_pattern(self, bb, which=1, interp=4):
+        z = np.ascontiguousarray(bb, np.complex128)
+        matched = C.c_int(0)
+        f = self._fn("detect_ack_pattern")
+        f.restype = C.c_double
+        m = f(self.h, _p(z), C.c_int(z.size), C.c_int(interp), C.c_int(which), C.byref(matched))
+        return float(m), int(matched.value)
+
+    for fn in (preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband, mfsk_pattern, time_sync_mfsk,
+               detect_ack_pattern):
         setattr(cls, fn.__name__, fn)
 
 

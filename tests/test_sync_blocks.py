@@ -153,3 +153,89 @@ def test_capture_window_to_payload_chain_on_gpu():
         ref = o.rx(bb_o[o.preamble_nsymb * o.Nofdm:], oraclelib.FLAGS_RECEIVE_BYTE)
         assert out["stats"]["iterations_done"][w] == ref["iterations"]
         assert np.array_equal(out["payload"][w], ref["bytes"].astype(np.uint8))
+
+
+# ---- MFSK synchroniser / ACK-BREAK pattern detector ------------------------------------------------------------
+def _pattern_windows(orc, which, W, nsym, sigmas, rng, slot0=5):
+    """W capture windows of interpolated baseband: noise + the known tone pattern (zero-order hold x4, so the
+    reference's decimation recovers the symbol samples) starting at a different symbol slot in each window."""
+    pat = np.repeat(orc.mfsk_pattern(which) / 16.0, 4)
+    out, slots = [], []
+    for w in range(W):
+        sigma = sigmas[w % len(sigmas)]
+        buf = sigma * (rng.standard_normal(nsym * 1088) + 1j * rng.standard_normal(nsym * 1088))
+        slot = slot0 + 3 * w
+        buf[slot * 1088: slot * 1088 + pat.size] += pat
+        out.append(buf)
+        slots.append(slot)
+    return np.stack(out), slots
+
+
+@pytest.mark.parametrize("cfg", [100, 101, 102])
+def test_time_sync_mfsk_oracle_vs_ref_and_finds_the_preamble(cfg):
+    orc = oraclelib.Oracle(cfg)
+    rng = np.random.default_rng(cfg)
+    bufs, slots = _pattern_windows(orc, 0, 4, 40, (0.05, 0.5, 1.0, 2.0), rng)
+    for w in range(4):
+        d = orc.time_sync_mfsk(bufs[w])
+        assert d == slots[w] * 1088                                   # low enough noise: the preamble slot is found
+        assert orc.time_sync_mfsk(bufs[w], slots[w] + 1) != d         # anti-re-decode start skips it (telecom_system.cc:683-686)
+        if oraclelib.RefLib.available():
+            ref = oraclelib.RefLib(cfg)
+            assert ref.time_sync_mfsk(bufs[w]) == d
+            assert ref.time_sync_mfsk(bufs[w], slots[w] + 1) == orc.time_sync_mfsk(bufs[w], slots[w] + 1)
+
+
+@pytest.mark.parametrize("cfg", [8, 100])
+def test_detect_ack_pattern_oracle_vs_ref(cfg):
+    orc = oraclelib.Oracle(cfg)
+    rng = np.random.default_rng(50 + cfg)
+    for which in (1, 2):
+        assert orc.mfsk_pattern(which).size == 16 * 272
+        bufs, _ = _pattern_windows(orc, which, 3, 36, (0.05, 1.0, 3.0), rng)
+        for w in range(3):
+            m, n = orc.detect_ack_pattern(bufs[w], which)
+            other, _ = orc.detect_ack_pattern(bufs[w], 3 - which)
+            assert m > other                                          # ACK and BREAK tone sets do not alias
+            if w == 0:
+                assert n == 16 and m > 15.5
+            if oraclelib.RefLib.available():
+                ref = oraclelib.RefLib(cfg)
+                assert ref.mfsk_pattern(which).tobytes() == orc.mfsk_pattern(which).tobytes()
+                assert ref.detect_ack_pattern(bufs[w], which) == (m, n)
+    assert orc.detect_ack_pattern(np.zeros(15 * 1088, np.complex128)) == (0.0, 0)   # shorter than the pattern, ofdm.cc:2075
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [100, 101, 102])
+def test_gpu_time_sync_mfsk_matches_oracle(cfg):
+    from mercury_amd import RxPhy
+    orc = oraclelib.Oracle(cfg)
+    rng = np.random.default_rng(7 * cfg)
+    bufs, slots = _pattern_windows(orc, 0, 6, 44, (0.05, 0.5, 1.0, 2.0, 4.0, 8.0), rng)
+    rx = RxPhy(cfg, max_batch=1)
+    for start in (0, 9):
+        got = rx.time_sync_mfsk(bufs, start)
+        want = [orc.time_sync_mfsk(b, start) for b in bufs]
+        assert list(got) == want, (cfg, start)
+    assert list(rx.time_sync_mfsk(bufs)[:3]) == [s * 1088 for s in slots[:3]]
+    rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 100])
+def test_gpu_detect_ack_pattern_matches_oracle(cfg):
+    from mercury_amd import RxPhy
+    orc = oraclelib.Oracle(cfg)
+    rng = np.random.default_rng(11 * cfg + 1)
+    rx = RxPhy(cfg, max_batch=1)
+    for which in (1, 2):
+        bufs, _ = _pattern_windows(orc, which, 5, 40, (0.05, 1.0, 2.0, 3.0, 5.0), rng)
+        for pattern in (1, 2):
+            metric, matched = rx.detect_ack_pattern(bufs, pattern)
+            for w in range(5):
+                m, n = orc.detect_ack_pattern(bufs[w], pattern)
+                assert metric[w] == m and matched[w] == n, (cfg, which, pattern, w)      # bit-exact metric
+    m, n = rx.detect_ack_pattern(np.zeros((2, 10 * 1088), np.complex128))
+    assert list(m) == [0.0, 0.0] and list(n) == [0, 0]
+    rx.close()

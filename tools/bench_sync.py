@@ -36,6 +36,22 @@ def main():
     res["moose_ms"] = rx.last_sync_kernel_ms()
     tot = res["p2b_full_ms"] + res["p2b_extract_ms"] + res["tsync_coarse_ms"] + res["tsync_fine_ms"] + res["moose_ms"]
     res["windows_per_s_kernels_only"] = W / tot * 1e3
+    # universal ACK / BREAK tone-pattern detector (every mode) on the same windows
+    rx.detect_ack_pattern(bbi, 1)
+    rx.detect_ack_pattern(bbi, 1)
+    res["ack_detect_slot_energy_ms"] = rx.last_sync_kernel_ms()
+    rx.close()
+    # MFSK time sync: ROBUST_0 frames are 324 symbols, the reference's capture buffer holds two of them
+    rx = RxPhy(100, max_batch=1)
+    Wm = max(1, W // 8)
+    nm = rx.Nofdm * 2 * (rx.Nsymb + rx.preamble_nsymb) * 4
+    bbm = (rng.standard_normal((Wm, nm)) + 1j * rng.standard_normal((Wm, nm))) * 0.05
+    rx.time_sync_mfsk(bbm)
+    rx.time_sync_mfsk(bbm)
+    res["mfsk_windows"] = Wm
+    res["mfsk_window_samples"] = nm
+    res["mfsk_tsync_slot_energy_ms"] = rx.last_sync_kernel_ms()
+    res["mfsk_tsync_GBps"] = Wm * nm * 16 / res["mfsk_tsync_slot_energy_ms"] / 1e6
     print(json.dumps(res))
 
 
