@@ -17,8 +17,9 @@ LIB = os.path.join(HERE, "libmercury_gpu.so")
 TABLES = os.path.join(HERE, "data", "mercury_ldpc_tables.bin")
 
 HIP_SOURCES = ["api.hip", "frontend.hip", "mfsk.hip", "ldpc.hip", "txgen.hip", "stats.hip", "sync.hip"]
-CXX_SOURCES = ["tables.cpp"]
-HEADERS = ["device_tables.h", "tables.hpp", "spa_math.h", "fft256.h", os.path.join(ROOT, "include", "mercury_gpu.h")]
+CXX_SOURCES = ["tables.cpp", "shm_transport.cpp"]
+HEADERS = ["device_tables.h", "tables.hpp", "spa_math.h", "fft256.h", os.path.join(ROOT, "include", "mercury_gpu.h"),
+           os.path.join(ROOT, "include", "mercury_shm.h")]
 
 # -ffp-contract=off: the reference runs without FMA contraction (baseline x86-64); the FP64 front-end
 # and the sum-product decoder reproduce its roundings exactly, which an fma() would break.
@@ -89,7 +90,7 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lrt"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,5 +1,5 @@
-"""CPU tests of the drop-in boundary: the C-ABI library loads, exports exactly what include/mercury_gpu.h
-declares, and refuses loudly (error code + message, no crash, no CPU fallback) when it cannot run."""
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports exactly what include/mercury_gpu.h and
+include/mercury_shm.h declare, and refuses loudly (error code + message, no crash, no CPU fallback) when it cannot run."""
 import ctypes as C
 import os
 import re
@@ -11,9 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_functions():
-    text = open(os.path.join(ROOT, "include", "mercury_gpu.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mgpu_[a-z_0-9]+)\s*\(", text)))
+    names = set()
+    for header in ("mercury_gpu.h", "mercury_shm.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(mgpu_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -22,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     declared = _header_functions()
     assert declared, "no declarations parsed"
     for name in declared:
-        assert hasattr(lib, name), "declared in mercury_gpu.h but not exported: " + name
+        assert hasattr(lib, name), "declared in include/*.h but not exported: " + name
     assert sorted(EXPORTED_SYMBOLS) == declared
 
 
