@@ -35,6 +35,7 @@ extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
 extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*);
 extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, int, int, int, int, int, double*);
+extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double, double*);
 #define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
@@ -539,8 +540,13 @@ int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int 
         hipStream_t s = c->stream;
         HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
         HIPCK(hipEventRecord(c->sync_ev[0], s));
-        hipLaunchKernelGGL(step < 16 ? mgpu_tsync_metric_dense_kernel : mgpu_tsync_metric_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, ncand, step,
-                           t.preamble, t.Ngi * interp, t.Nfft * interp, d_vals.as<double>());
+        const int ngi_i = t.Ngi * interp, nfft_i = t.Nfft * interp;
+        if (ngi_i % 64 || (nfft_i / 2) % 64)    // the staged kernels walk the preamble in chunks of 8 / 64 pairs
+            hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, ncand, step,
+                               t.preamble, ngi_i, nfft_i, d_vals.as<double>());
+        else
+            hipLaunchKernelGGL(step <= 4 ? mgpu_tsync_metric_dense_kernel : mgpu_tsync_metric_kernel, dim3((ncand + 255) / 256, W), dim3(256), 0, s,
+                               d_in.as<double>(), size, ncand, step, t.preamble, ngi_i, nfft_i, d_vals.as<double>());
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         std::vector<double> cand(size_t(W) * ncand);
@@ -586,6 +592,7 @@ int mgpu_freq_sync(mgpu_ctx* c, const double* bb, int W, int stride, double* fre
 }
 
 // ---- MFSK synchroniser / signalling blocks (host buffers, blocking) -----------------------------------
+extern "C++" {
 namespace {
 // mfsk.cc:82-95, :120-126, :149-155; the universal ACK/BREAK patterns use M = 16, one stream centred in Nc = 50
 // (telecom_system.cc:3006), hop step 7, 8 tones sent twice.
@@ -611,6 +618,7 @@ std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size
     return e;
 }
 }  // namespace
+}  // extern "C++"
 
 int mgpu_time_sync_mfsk(mgpu_ctx* c, const double* bb, int W, int size, int search_start_symb, int* delay) {
     if (!c) return MGPU_ERR_ARG;

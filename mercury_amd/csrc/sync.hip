@@ -63,52 +63,103 @@ extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
     out[(size_t(w) * count + k) * 2 + 1] = ai;
 }
 
-// Schmidl-Cox metric. One lane per candidate offset i = cand*step; the three accumulators run in the
-// reference's order (a dependent chain of 2*(Ngi+Nfft/2)*Nsymb additions each), so the parallelism is across
-// candidates. Lanes of a wave are `step` samples apart, which would make every global load touch 64 different
-// cache lines; instead the wave walks the preamble in chunks of TS_CH samples and stages, per chunk, the two
-// sample rows (a and b) of each of its 64 candidates in LDS with coalesced row loads (row r = 64 consecutive
-// samples = 1 KiB = one wave-wide load), padded by one element per row so the per-lane reads are conflict-free.
-#define TS_CH 64
+// Schmidl-Cox metric (ofdm.cc:1893-1941). One lane per candidate offset i = cand*step; the three accumulators run
+// in the reference's order (a dependent chain of 2*(Ngi+Nfft/2)*Nsymb additions each), so the parallelism is
+// across candidates: a wavefront owns 64 consecutive candidates and walks the preamble in chunks of TS_CH pairs.
+// Work per candidate is fixed (2304 sample pairs, 12 fp64 operations each); what has to be engineered is the
+// operand delivery, because lanes of a wave are `step` samples apart.
+//
+//  * mgpu_tsync_metric_kernel (step >= 5, the coarse search uses 100): a direct load would touch 64 cache lines
+//    per instruction. Instead TS_CH lanes fetch one candidate's TS_CH-sample row, so a load instruction
+//    covers 64/TS_CH rows; the rows are transposed through a small wave-private LDS tile (row stride TS_CH+1
+//    elements: conflict-free for the per-lane reads). The next chunk's rows are requested before the current
+//    chunk is consumed. 10 KB of LDS per wave.
+//  * mgpu_tsync_metric_dense_kernel (step <= 4, the fine search uses 1): the 64 candidates overlap almost
+//    completely, so the wave stages the contiguous span 63*step + TS_DCH samples once (coalesced) and every lane
+//    reads its own offset from LDS.
+#define TS_CH 8
+#define TS_RPL (64 / TS_CH)     // candidate rows covered by one wave-wide load
+#define TS_NLD (64 / TS_RPL)    // loads per array and chunk
+#define TS_WAVES 4
 
-extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_kernel(
+namespace {
+typedef double v2d __attribute__((ext_vector_type(2)));   // one complex sample as a native 16-byte vector (keeps prefetch arrays in registers)
+struct TsSeg { int a_off, b_off, len; };
+// segment q of the reference's loops: per preamble symbol l, (a = l*sym, b = a + Nfft, len Ngi) then
+// (a = l*sym + Ngi, b = a + Nfft/2, len Nfft/2)
+__device__ __forceinline__ TsSeg ts_segment(int q, int ngi_i, int nfft_i) {
+    const int l = q >> 1, part = q & 1, sym = ngi_i + nfft_i;
+    const int a_off = l * sym + (part ? ngi_i : 0);
+    return {a_off, a_off + (part ? nfft_i / 2 : nfft_i), part ? nfft_i / 2 : ngi_i};
+}
+// the chunk after (q, m0) in the walk over the 2*pre_nsymb segments; the last chunk is its own successor, so the
+// software pipeline can always prefetch without a branch
+__device__ __forceinline__ void ts_next_chunk(int q, int m0, int ch, int nseg, int ngi_i, int nfft_i, int& qn, int& mn) {
+    const int len = (q & 1) ? nfft_i / 2 : ngi_i;
+    qn = q; mn = m0 + ch;
+    if (mn >= len) { ++qn; mn = 0; }
+    if (qn >= nseg) { qn = q; mn = m0; }
+}
+__device__ __forceinline__ void ts_accumulate(const c2& x, const c2& y, double& cc, double& na, double& nb) {
+    cc += x.re * y.re; na += x.re * x.re; nb += y.re * y.re;
+    cc += x.im * y.im; na += x.im * x.im; nb += y.im * y.im;
+}
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_kernel(
     const double* __restrict__ bb, int size, int ncand, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
-    __shared__ c2 ra[64][TS_CH + 1];
-    __shared__ c2 rb[64][TS_CH + 1];
-    const int w = blockIdx.y, lane = threadIdx.x;
-    const int cand0 = blockIdx.x * 64;
+    // requires ngi_i % TS_CH == 0 and (nfft_i / 2) % TS_CH == 0 (the host checks; 64 and 512 in the reference's calls)
+    __shared__ c2 tile[TS_WAVES][2][64][TS_CH + 1];
+    const int w = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cand0 = (blockIdx.x * TS_WAVES + wave) * 64;
+    if (cand0 >= ncand) return;
     const int cand = cand0 + lane;
-    const c2* win = reinterpret_cast<const c2*>(bb) + size_t(w) * size;
-    const int sym = ngi_i + nfft_i;
+    const char* win = reinterpret_cast<const char*>(bb) + size_t(w) * size * 16;
+    c2 (*ra)[TS_CH + 1] = tile[wave][0];
+    c2 (*rb)[TS_CH + 1] = tile[wave][1];
+    const int rsub = lane / TS_CH, col = lane % TS_CH;           // staging role: row rr*TS_RPL + rsub, sample col
+    // byte offset of this lane's element in each of its rows; rows past the last candidate re-read the last one
+    // (their lanes' results are discarded), so no load needs a predicate
+    unsigned rowbyte[TS_NLD];
+#pragma unroll
+    for (int rr = 0; rr < TS_NLD; ++rr)
+        rowbyte[rr] = (unsigned(min(cand0 + rr * TS_RPL + rsub, ncand - 1)) * unsigned(step) + unsigned(col)) * 16u;
+    const int nseg = 2 * pre_nsymb;
+    v2d pa[TS_NLD], pb[TS_NLD];                                  // rows in flight for the next chunk
     double cc = 0, na = 0, nb = 0;
-    // segments of the reference's loops: per preamble symbol l, (a = l*sym, b = a + Nfft, len Ngi) then
-    // (a = l*sym + Ngi, b = a + Nfft/2, len Nfft/2)
-    for (int l = 0; l < pre_nsymb; ++l) {
-        for (int part = 0; part < 2; ++part) {
-            const int a_off = l * sym + (part ? ngi_i : 0);
-            const int b_off = a_off + (part ? nfft_i / 2 : nfft_i);
-            const int len = part ? nfft_i / 2 : ngi_i;
-            for (int m0 = 0; m0 < len; m0 += TS_CH) {
-                const int n = min(TS_CH, len - m0);
-                // stage rows: row r belongs to candidate cand0 + r
-                for (int r = 0; r < 64; ++r) {
-                    const long base = long(cand0 + r) * step;
-                    if (cand0 + r < ncand && lane < n) {
-                        ra[r][lane] = win[base + a_off + m0 + lane];
-                        rb[r][lane] = win[base + b_off + m0 + lane];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (cand < ncand) {
-                    for (int m = 0; m < n; ++m) {
-                        const c2 x = ra[lane][m], y = rb[lane][m];
-                        cc += x.re * y.re; na += x.re * x.re; nb += y.re * y.re;
-                        cc += x.im * y.im; na += x.im * x.im; nb += y.im * y.im;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
+    int q = 0, m0 = 0;
+    {
+        const TsSeg sg = ts_segment(0, ngi_i, nfft_i);
+#pragma unroll
+        for (int rr = 0; rr < TS_NLD; ++rr) {
+            pa[rr] = *reinterpret_cast<const v2d*>(win + size_t(sg.a_off) * 16 + rowbyte[rr]);
+            pb[rr] = *reinterpret_cast<const v2d*>(win + size_t(sg.b_off) * 16 + rowbyte[rr]);
+        }
+    }
+    const int nchunks = pre_nsymb * (ngi_i + nfft_i / 2) / TS_CH;
+    for (int it = 0; it < nchunks; ++it) {
+#pragma unroll
+        for (int rr = 0; rr < TS_NLD; ++rr) {
+            ra[rr * TS_RPL + rsub][col] = {pa[rr].x, pa[rr].y};
+            rb[rr * TS_RPL + rsub][col] = {pb[rr].x, pb[rr].y};
+        }
+        int qn, mn;
+        ts_next_chunk(q, m0, TS_CH, nseg, ngi_i, nfft_i, qn, mn);
+        {
+            const TsSeg sg = ts_segment(qn, ngi_i, nfft_i);
+            const char* abase = win + size_t(sg.a_off + mn) * 16;    // wave-uniform
+            const char* bbase = win + size_t(sg.b_off + mn) * 16;
+#pragma unroll
+            for (int rr = 0; rr < TS_NLD; ++rr) {
+                pa[rr] = *reinterpret_cast<const v2d*>(abase + rowbyte[rr]);
+                pb[rr] = *reinterpret_cast<const v2d*>(bbase + rowbyte[rr]);
             }
         }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < TS_CH; ++m) ts_accumulate(ra[lane][m], rb[lane][m], cc, na, nb);
+        __builtin_amdgcn_wave_barrier();
+        q = qn; m0 = mn;
     }
     if (cand >= ncand) return;
     if (na < 0.001 || nb < 0.001) cc = 0.0;
@@ -116,32 +167,84 @@ extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_kernel(
     vals[size_t(w) * ncand + cand] = cc;
 }
 
-// Same metric for small steps (fine search, step 1): neighbouring lanes read neighbouring samples, so plain
-// global loads are already coalesced and L1 serves the 64-fold overlap between candidates.
-extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_dense_kernel(
+// Fallback for segment lengths that are not multiples of TS_CH: one lane per candidate, direct loads.
+extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_generic_kernel(
     const double* __restrict__ bb, int size, int ncand, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
     const int w = blockIdx.y;
     const int cand = blockIdx.x * 64 + threadIdx.x;
     if (cand >= ncand) return;
     const c2* data = reinterpret_cast<const c2*>(bb) + size_t(w) * size + size_t(cand) * step;
-    const int sym = ngi_i + nfft_i;
     double cc = 0, na = 0, nb = 0;
-    for (int l = 0; l < pre_nsymb; ++l) {
-        const c2* a = data + l * sym;
-        const c2* b = a + nfft_i;
-        for (int m = 0; m < ngi_i; ++m) {
-            const c2 x = a[m], y = b[m];
-            cc += x.re * y.re; na += x.re * x.re; nb += y.re * y.re;
-            cc += x.im * y.im; na += x.im * x.im; nb += y.im * y.im;
-        }
-        a = data + l * sym + ngi_i;
-        b = data + l * sym + ngi_i + nfft_i / 2;
-        for (int m = 0; m < nfft_i / 2; ++m) {
-            const c2 x = a[m], y = b[m];
-            cc += x.re * y.re; na += x.re * x.re; nb += y.re * y.re;
-            cc += x.im * y.im; na += x.im * x.im; nb += y.im * y.im;
+    for (int q = 0; q < 2 * pre_nsymb; ++q) {
+        const TsSeg sg = ts_segment(q, ngi_i, nfft_i);
+        for (int m = 0; m < sg.len; ++m) ts_accumulate(data[sg.a_off + m], data[sg.b_off + m], cc, na, nb);
+    }
+    if (na < 0.001 || nb < 0.001) cc = 0.0;
+    else cc = cc / sqrt(na * nb);
+    vals[size_t(w) * ncand + cand] = cc;
+}
+
+#define TS_DCH 64
+#define TS_DSPAN (63 * 4 + TS_DCH)      // step <= 4
+
+extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_dense_kernel(
+    const double* __restrict__ bb, int size, int ncand, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    __shared__ c2 span[TS_WAVES][2][TS_DSPAN];
+    const int w = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cand0 = (blockIdx.x * TS_WAVES + wave) * 64;
+    if (cand0 >= ncand) return;
+    const int cand = cand0 + lane;
+    const c2* win = reinterpret_cast<const c2*>(bb) + size_t(w) * size + size_t(cand0) * step;
+    const long avail = long(size) - long(cand0) * step;         // samples from the wave's first candidate to the end
+    c2* sa = span[wave][0];
+    c2* sb = span[wave][1];
+    const int nseg = 2 * pre_nsymb;
+    const int width = 63 * step + TS_DCH;                        // <= TS_DSPAN
+    constexpr int kLoads = (TS_DSPAN + 63) / 64;
+    const int nld = (width + 63) / 64;                           // 2 for step 1
+    const int last = int(avail) - 1;                             // clamp instead of predicating: clamped elements feed discarded lanes only
+    v2d pa[kLoads], pb[kLoads];
+    const v2d* winv = reinterpret_cast<const v2d*>(win);
+    double cc = 0, na = 0, nb = 0;
+    int q = 0, m0 = 0;
+    {
+        const TsSeg sg = ts_segment(0, ngi_i, nfft_i);
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) {
+            const int t = j * 64 + lane;
+            pa[j] = winv[min(sg.a_off + t, last)];
+            pb[j] = winv[min(sg.b_off + t, last)];
         }
     }
+    const int nchunks = pre_nsymb * (ngi_i + nfft_i / 2) / TS_DCH;
+    for (int it = 0; it < nchunks; ++it) {
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) {
+            const int t = j * 64 + lane;
+            if (j < nld && t < TS_DSPAN) { sa[t] = {pa[j].x, pa[j].y}; sb[t] = {pb[j].x, pb[j].y}; }
+        }
+        int qn, mn;
+        ts_next_chunk(q, m0, TS_DCH, nseg, ngi_i, nfft_i, qn, mn);
+        {
+            const TsSeg sg = ts_segment(qn, ngi_i, nfft_i);
+#pragma unroll
+            for (int j = 0; j < kLoads; ++j) {
+                if (j < nld) {
+                    const int t = j * 64 + lane;
+                    pa[j] = winv[min(sg.a_off + mn + t, last)];
+                    pb[j] = winv[min(sg.b_off + mn + t, last)];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const c2* la = sa + lane * step;
+        const c2* lb = sb + lane * step;
+#pragma unroll 8
+        for (int m = 0; m < TS_DCH; ++m) ts_accumulate(la[m], lb[m], cc, na, nb);
+        __builtin_amdgcn_wave_barrier();
+        q = qn; m0 = mn;
+    }
+    if (cand >= ncand) return;
     if (na < 0.001 || nb < 0.001) cc = 0.0;
     else cc = cc / sqrt(na * nb);
     vals[size_t(w) * ncand + cand] = cc;
