@@ -126,3 +126,26 @@ def test_mfsk_minsum_and_ragged_batches():
         for f in np.nonzero(ok)[0]:
             assert np.array_equal(out["payload"][f][: orc.payload_bytes], frames[f][1].astype(np.uint8))
         rx.close()
+
+
+@pytest.mark.parametrize("cfg", [100, 101])
+def test_mfsk_degenerate_inputs_behave_like_the_reference(cfg):
+    """Zero, denormal, huge, NaN / Inf polluted frames through the MFSK demapper: the isfinite() guards of
+    mfsk.cc:310-316, :331, :381 and the 1e-30 noise floor are reproduced bit for bit."""
+    orc = Oracle(cfg, 50)
+    n = orc.frame_samples
+    good, _ = orc.gen_frame(5, 1, noise_amp_for(OPERATING_ESN0[cfg] + 5.0))
+    cases = [np.zeros(n, np.complex128), good * 1e-300, good * 1e150, good.copy(), good.copy(), -good, good * 1e160]
+    cases[3][100] = np.nan
+    cases[4][200] = np.inf
+    rx = _rx(cfg, max_iters=50, max_batch=len(cases))
+    with np.errstate(all="ignore"):
+        out = rx.receive(np.stack(cases), taps=True)
+        for i, x in enumerate(cases):
+            ref = orc.rx(x)
+            assert out["llr_demod"][i].tobytes() == ref["llr_demod"].tobytes(), (cfg, i)      # no NaN ever reaches the LLRs
+            assert out["llr_ldpc"][i].tobytes() == ref["llr_ldpc"].tobytes(), (cfg, i)
+            st = out["stats"][i]
+            assert (st["iterations_done"], st["crc"], st["all_zeros"]) == (ref["iterations"], ref["crc"], ref["all_zeros"]), (cfg, i)
+            assert np.array_equal(out["payload"][i], ref["bytes"].astype(np.uint8)), (cfg, i)
+    rx.close()

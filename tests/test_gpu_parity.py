@@ -381,3 +381,32 @@ def test_receive_stats_snr_matches_reference_definition(cfg, esn0):
         st = out["stats"][f]
         assert st["message_decoded"] == int(not (ref["all_zeros"] or ref["crc"] != 0))
         assert abs(float(st["snr_db"]) - ref["snr_db"]) <= 2e-5 * max(1.0, abs(ref["snr_db"])), (cfg, f, st["snr_db"], ref["snr_db"])
+
+
+@pytest.mark.parametrize("cfg", [0, 8, 13, 16])
+def test_degenerate_inputs_behave_like_the_reference(cfg):
+    """All-zero, denormal-scale, 1e150-scale, NaN / Inf polluted, sign-flipped and DC-only frames: whatever the
+    reference arithmetic does with them (divisions by zero in the AGC, NaN variances, ...) the GPU does too —
+    integer outputs identical, LLRs bit-identical where they are numbers, NaNs in the same places (x86 and CDNA
+    differ only in the sign bit of a generated NaN)."""
+    orc = Oracle(cfg, 50)
+    n = orc.frame_samples
+    good, _ = orc.gen_frame(5, 1, noise_amp_for(OPERATING_ESN0[cfg] + 6.0))
+    cases = [np.zeros(n, np.complex128), good * 1e-300, good * 1e150, good.copy(), good.copy(), -good,
+             np.full(n, 1 + 1j, np.complex128)]
+    cases[3][100] = np.nan
+    cases[4][200] = np.inf
+    agc, vs, flags = _variants(cfg)[0]
+    rx = _rx(cfg, max_batch=len(cases), agc=agc, variance_source=vs)
+    with np.errstate(all="ignore"):
+        out = rx.receive(np.stack(cases), want_llr=True)
+        for i, x in enumerate(cases):
+            ref = orc.rx(x, flags)
+            got = out["llr_ldpc"][i]
+            nan = np.isnan(ref["llr_ldpc"])
+            assert np.array_equal(np.isnan(got), nan), (cfg, i)
+            assert np.array_equal(got[~nan].view(np.uint32), ref["llr_ldpc"][~nan].view(np.uint32)), (cfg, i)
+            st = out["stats"][i]
+            assert (st["iterations_done"], st["crc"], st["all_zeros"]) == (ref["iterations"], ref["crc"], ref["all_zeros"]), (cfg, i)
+            assert np.array_equal(out["payload"][i], ref["bytes"].astype(np.uint8)), (cfg, i)
+    rx.close()
