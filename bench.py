@@ -155,6 +155,16 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
         r = timed(phy, [bb])
         r["esn0_db"] = op
         out["operating_point_decoder_" + name] = r
+    # one frame per call through the blocking host-buffer entry point (mgpu_rx_batch, F = 1): what a receive_byte
+    # patched as in INTEGRATION.md §1.2 waits for, PCIe copies and launch overheads included
+    for name, src in (("worst_case", bufs[0]), ("operating_point", bb)):
+        one = src[:1].cpu().numpy().view(np.complex128).reshape(1, -1)
+        lat = []
+        for i in range(12):
+            t0 = time.perf_counter()
+            rx.receive(one)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        out["single_frame_latency_ms_" + name] = float(np.median(lat[2:]))
     rx2.close()
     return out
 
