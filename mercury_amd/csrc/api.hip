@@ -164,6 +164,14 @@ void ctx_alloc(mgpu_ctx* c) {
     l.cptr = d.cptr; l.cvar = d.cvar;
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
+    {   // min-sum check update: segmented wave scans pay off once a check has more edges than the scans have steps to hide
+        int maxdeg = 0;
+        for (int q = 0; q < t.P; ++q) maxdeg = std::max(maxdeg, int(t.graph.cptr[q + 1] - t.graph.cptr[q]));
+        int steps = 0;
+        while ((1 << steps) < maxdeg - 1) ++steps;      // exclusive scans cover deg - 1 other edges
+        const char* force = std::getenv("MERCURY_MINSUM_SCAN");
+        l.scan_steps = (force ? std::atoi(force) != 0 : maxdeg > 16) ? steps : 0;
+    }
 
     HIPCK(hipStreamCreate(&c->stream));
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));

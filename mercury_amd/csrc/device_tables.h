@@ -49,6 +49,7 @@ struct LdpcDev {
     const uint8_t* scrambler;
     int S, N, P, K, E, nReal, payload_stride, max_iters;
     float minsum_alpha;
+    int scan_steps;   // min-sum: 0 = every lane scans its check's edges; > 0 = segmented wave scans with this many doubling steps
 };
 
 struct MgpuTapsDev {
