@@ -12,99 +12,11 @@
 #include <string>
 #include <vector>
 
-#include "../../include/mercury_gpu.h"
-#include "device_tables.h"
-#include "tables.hpp"
-
-extern "C" const unsigned char mgpu_ldpc_blob[];
-extern "C" const unsigned long mgpu_ldpc_blob_size;
-
-extern "C" size_t mgpu_frontend_lds_bytes(int G);
-extern "C" size_t mgpu_spa_lds_bytes(int E, int N);
-extern "C" size_t mgpu_gbf_lds_bytes(int N);
-extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
-extern "C" size_t mgpu_txgen_lds_bytes(int G);
-
-extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
-extern "C" __global__ void mgpu_mfsk_frontend_kernel_m32(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
-extern "C" __global__ void mgpu_mfsk_frontend_kernel_m16x2(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
-extern "C" int mgpu_mfsk_syms_per_block();
-extern "C" __global__ void mgpu_slot_energy_kernel(const double*, int, int, int, const double*, double*);
-extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
-extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
-extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*);
-extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, int, int, int, int, int, double*);
-extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, int, int, int, int, int, double*);
-extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, int, int, int, int, int, double*);
-extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double, double*);
-#define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
-extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
-using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-#define DECL_MS(NE) extern "C" __global__ void mgpu_ldpc_minsum_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-DECL_MS(4) DECL_MS(5) DECL_MS(6) DECL_MS(7) DECL_MS(8)
-extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*);
-
-static_assert(sizeof(MgpuStatsDev) == sizeof(mgpu_frame_stats), "stats layout");
-
-namespace {
+#include "ctx.hpp"
 
 thread_local std::string g_create_error;
 
-struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
-#define HIPCK(expr)                                                                              \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-template <typename T>
-T* upload(const std::vector<T>& v) {
-    T* d = nullptr;
-    HIPCK(hipMalloc(&d, v.size() * sizeof(T) + 16));
-    HIPCK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return d;
-}
-
-}  // namespace
-
-struct mgpu_ctx {
-    mgpu_config cfg{};
-    mgpu::ModeTables tab;
-    MgpuDev dev{};
-    LdpcDev ldev{};
-    std::vector<void*> owned;       // device allocations freed in destroy
-    std::string err;
-    int max_batch = 0;
-    // workspaces (device)
-    double* d_baseband = nullptr;   // lazily sized for the host-buffer entry points
-    size_t baseband_cap = 0;
-    float* d_llr = nullptr;
-    float* d_variance = nullptr;
-    float* d_snrvar = nullptr;
-    uint8_t* d_payload = nullptr;
-    MgpuStatsDev* d_stats = nullptr;
-    uint8_t* d_bits = nullptr;
-    double* d_eqdata = nullptr;
-    double* d_fir[2] = {nullptr, nullptr};   // FIR_rx_time_sync, FIR_rx_data taps
-    hipEvent_t sync_ev[2]{};        // around the most recent synchroniser kernel
-    float last_sync_ms = -1.f;     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
-    int* d_iters = nullptr;
-    hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
-    static constexpr int kEvRing = 64;
-    hipEvent_t ev[kEvRing][4]{};    // per launch: front-end start/stop, decoder start/stop
-    bool timing = false;
-    int ev_count = 0;               // launches recorded since timing was enabled (ring of kEvRing)
-    bool ev_fe[kEvRing]{};          // whether the front-end ran in that slot
-    size_t lds_fe = 0, lds_dec = 0, lds_tx = 0;
-    DecoderKernel spa_kernel = nullptr;
-
-    template <typename T>
-    T* keep(T* p) { owned.push_back(p); return p; }
-};
-
-namespace {
+namespace mgpu_detail {
 
 void ctx_alloc(mgpu_ctx* c) {
     const auto& t = c->tab;
@@ -217,7 +129,6 @@ void ctx_alloc(mgpu_ctx* c) {
 
 // Workspaces sized by max_batch are created on first use, so a context that only ever runs e.g. the
 // decoder on caller-owned device buffers (the 10^7-codeword soak) does not pin tens of GB it never touches.
-enum : unsigned { WS_FRONTEND = 1, WS_LLR = 2, WS_OUT = 4, WS_BITS = 8 };
 void ensure_workspaces(mgpu_ctx* c, unsigned what) {
     const auto& t = c->tab;
     const size_t B = size_t(c->max_batch);
@@ -237,14 +148,14 @@ void ensure_workspaces(mgpu_ctx* c, unsigned what) {
     }
 }
 
-// HIP caps gridDim*blockDim below 2^32 threads, so very large batches go out in chunks of frames.
-constexpr int kMaxFramesPerLaunch = 1 << 21;
-template <typename T> T* at(T* p, size_t off) { return p ? p + off : nullptr; }
 
 void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float* d_var, float* d_snrvar,
-                     const MgpuTapsDev& taps, hipStream_t s) {
+                     const MgpuTapsDev& taps, hipStream_t s, int frame_stride) {
     const int slot = c->ev_count % mgpu_ctx::kEvRing;
     const auto& t = c->tab;
+    MgpuDev dev = c->dev;                        // kernel argument; the frame stride can differ from the frame length
+    if (frame_stride > 0) dev.frame_samples = frame_stride;
+    const size_t stride = size_t(dev.frame_samples);
     if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][0], s)); c->ev_fe[slot] = true; }
     if (t.mfsk_M > 0) {
         // MFSK modes: workgroups of (frame, run of symbols); keep gridDim * blockDim below 2^32
@@ -257,8 +168,8 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
             const int n = F - off < max_frames ? F - off : max_frames;
             if (off && (taps.grid || taps.llr_demod || taps.variance || taps.agc_gain))
                 throw std::invalid_argument("stage taps are limited to one launch per call");
-            hipLaunchKernelGGL(t.mfsk_M == 32 ? mgpu_mfsk_frontend_kernel_m32 : mgpu_mfsk_frontend_kernel_m16x2, dim3(unsigned(n) * chunks), dim3(256), 0, s, c->dev,
-                               d_bb + size_t(off) * t.frame_samples * 2, n, chunks, d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), taps);
+            hipLaunchKernelGGL(t.mfsk_M == 32 ? mgpu_mfsk_frontend_kernel_m32 : mgpu_mfsk_frontend_kernel_m16x2, dim3(unsigned(n) * chunks), dim3(256), 0, s, dev,
+                               d_bb + size_t(off) * stride * 2, n, chunks, d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), taps);
             HIPCK(hipGetLastError());
         }
         if (c->timing) HIPCK(hipEventRecord(c->ev[slot][1], s));
@@ -266,9 +177,9 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
     }
     for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
         const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
-        if (off && (taps.grid || taps.H || taps.eq || taps.syms || taps.llr_demod || taps.variance || taps.agc_gain))
+        if (off && (taps.grid || taps.H || taps.eq || taps.syms || taps.llr_demod || taps.variance || taps.agc_gain || taps.mean_H))
             throw std::invalid_argument("stage taps are limited to 2^21 frames per call");
-        hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(n), dim3(512), c->lds_fe, s, c->dev, d_bb + size_t(off) * t.frame_samples * 2, n,
+        hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(n), dim3(512), c->lds_fe, s, dev, d_bb + size_t(off) * stride * 2, n,
                            d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), at(c->d_eqdata, size_t(off) * t.nData * 2), taps);
         HIPCK(hipGetLastError());
     }
@@ -277,6 +188,20 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
 
 // zero-forcing modes: SNR from the re-encoded decision (telecom_system.cc:1374-1396); needs the payload and
 // the de-framed equalised symbols the front-end kept.
+void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr) {
+    if (location_to_return >= nTrials_max) location_to_return = nTrials_max - 1;
+    std::vector<double> vals(size, 0.0);
+    std::vector<int> loc(size, -1);
+    for (int k = 0; k < ncand; ++k) { vals[size_t(k) * step] = cand_vals[k]; loc[size_t(k) * step] = k * step; }
+    for (int j = 0; j < nTrials_max; ++j) {
+        loc[j] = j;
+        for (int i = j + 1; i < size; ++i)
+            if (vals[i] > vals[j]) { vals[j] = vals[i]; loc[j] = i; }
+    }
+    *delay = loc[location_to_return];
+    *corr = vals[location_to_return];
+}
+
 void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s) {
     const auto& t = c->tab;
     if (t.estimator != MGPU_EST_ZF || !d_payload || !d_stats) return;
@@ -311,40 +236,7 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
     if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][3], s)); ++c->ev_count; c->ev_fe[c->ev_count % mgpu_ctx::kEvRing] = false; }
 }
 
-}  // namespace
-
-namespace {
-int guard(mgpu_ctx* c, const std::function<void()>& fn) {
-    try {
-        fn();
-        return MGPU_OK;
-    } catch (const HipError& e) {
-        if (c) c->err = e.what();
-        return MGPU_ERR_DEVICE;
-    } catch (const std::invalid_argument& e) {
-        if (c) c->err = e.what();
-        return MGPU_ERR_ARG;
-    } catch (const std::exception& e) {
-        if (c) c->err = e.what();
-        return MGPU_ERR_DEVICE;
-    }
-}
-void need(bool ok, const char* what) { if (!ok) throw std::invalid_argument(what); }
-}  // namespace
-
-namespace {
-struct DevBuf {
-    void* p = nullptr;
-    explicit DevBuf(size_t bytes) { HIPCK(hipMalloc(&p, bytes ? bytes : 16)); }
-    ~DevBuf() { (void)hipFree(p); }
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    template <typename T> T* as() { return static_cast<T*>(p); }
-};
-constexpr double kSampleRate = 48000.0;          // telecom_system.cc:1569
-const double kCarrierAmplitude = 1.4142135623730951;   // sqrt(2.0), telecom_system.cc:69
-}  // namespace
-
+}  // namespace mgpu_detail
 
 extern "C" {
 
@@ -383,7 +275,7 @@ int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
         HIPCK(hipGetDeviceCount(&ndev));
         if (ndev < 1) throw HipError("no HIP device visible (the MI355X path has no CPU fallback)");
         HIPCK(hipSetDevice(cfg->device));
-        ctx_alloc(c);
+        mgpu_detail::ctx_alloc(c);
     } catch (const std::exception& e) {
         g_create_error = e.what();
         mgpu_destroy(c);
@@ -528,7 +420,7 @@ int mgpu_passband_to_baseband(mgpu_ctx* c, const double* passband, int W, int in
         HIPCK(hipEventRecord(c->sync_ev[0], s));
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((count + 255) / 256, W), dim3(256), lds, s, d_in.as<double>(), in_size, d_fc.as<double>(),
                            start ? d_start.as<int>() : nullptr, 0, count, decimation, c->d_fir[filter], ntaps, kSampleRate, kCarrierAmplitude,
-                           d_out.as<double>());
+                           d_out.as<double>(), nullptr);
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         HIPCK(hipMemcpyAsync(out_c128, d_out.p, size_t(W) * count * 16, hipMemcpyDeviceToHost, s));
@@ -550,31 +442,20 @@ int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int 
         HIPCK(hipEventRecord(c->sync_ev[0], s));
         const int ngi_i = t.Ngi * interp, nfft_i = t.Nfft * interp;
         if (ngi_i % 64 || (nfft_i / 2) % 64)    // the staged kernels walk the preamble in chunks of 8 / 64 pairs
-            hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, ncand, step,
-                               t.preamble, ngi_i, nfft_i, d_vals.as<double>());
+            hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, nullptr, nullptr,
+                               nullptr, ncand, step, t.preamble, ngi_i, nfft_i, d_vals.as<double>());
         else
             hipLaunchKernelGGL(step <= 4 ? mgpu_tsync_metric_dense_kernel : mgpu_tsync_metric_kernel, dim3((ncand + 255) / 256, W), dim3(256), 0, s,
-                               d_in.as<double>(), size, ncand, step, t.preamble, ngi_i, nfft_i, d_vals.as<double>());
+                               d_in.as<double>(), size, nullptr, nullptr, nullptr, ncand, step, t.preamble, ngi_i, nfft_i, d_vals.as<double>());
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         std::vector<double> cand(size_t(W) * ncand);
         HIPCK(hipMemcpyAsync(cand.data(), d_vals.p, cand.size() * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
-        // the reference's selection (ofdm.cc:1943-1964): overwrite-not-swap partial sort over the full-size array
-        if (location_to_return >= nTrials_max) location_to_return = nTrials_max - 1;
-        std::vector<double> vals(size);
-        std::vector<int> loc(size);
         for (int w = 0; w < W; ++w) {
-            std::fill(vals.begin(), vals.end(), 0.0);
-            std::fill(loc.begin(), loc.end(), -1);
-            for (int k = 0; k < ncand; ++k) { vals[size_t(k) * step] = cand[size_t(w) * ncand + k]; loc[size_t(k) * step] = k * step; }
-            for (int j = 0; j < nTrials_max; ++j) {
-                loc[j] = j;
-                for (int i = j + 1; i < size; ++i)
-                    if (vals[i] > vals[j]) { vals[j] = vals[i]; loc[j] = i; }
-            }
-            delay[w] = loc[location_to_return];
-            if (correlation) correlation[w] = vals[location_to_return];
+            double corr = 0;
+            select_peak(&cand[size_t(w) * ncand], ncand, step, size, location_to_return, nTrials_max, &delay[w], &corr);
+            if (correlation) correlation[w] = corr;
         }
     });
 }

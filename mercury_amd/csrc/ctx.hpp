@@ -1,0 +1,154 @@
+// Private to the library: the context behind the opaque mgpu_ctx handle, the kernel declarations and the helpers
+// that the host-side translation units (api.hip, rxloop.hip) share. Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mercury_gpu.h"
+#include "device_tables.h"
+#include "tables.hpp"
+
+extern "C" const unsigned char mgpu_ldpc_blob[];
+extern "C" const unsigned long mgpu_ldpc_blob_size;
+
+extern "C" size_t mgpu_frontend_lds_bytes(int G);
+extern "C" size_t mgpu_spa_lds_bytes(int E, int N);
+extern "C" size_t mgpu_gbf_lds_bytes(int N);
+extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
+extern "C" size_t mgpu_txgen_lds_bytes(int G);
+
+extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
+extern "C" __global__ void mgpu_mfsk_frontend_kernel_m32(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
+extern "C" __global__ void mgpu_mfsk_frontend_kernel_m16x2(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
+extern "C" int mgpu_mfsk_syms_per_block();
+extern "C" __global__ void mgpu_slot_energy_kernel(const double*, int, int, int, const double*, double*);
+extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
+extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
+extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*, const int*);
+extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
+extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
+extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
+extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double, double*);
+extern "C" __global__ void mgpu_span_energy_kernel(const double*, int, const int*, const int*, int, int, double*, int*);
+extern "C" __global__ void mgpu_decimate_kernel(const double*, int, const int*, const int*, int, int, double*);
+#define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
+extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
+using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+#define DECL_MS(NE) extern "C" __global__ void mgpu_ldpc_minsum_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+DECL_MS(4) DECL_MS(5) DECL_MS(6) DECL_MS(7) DECL_MS(8)
+extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*);
+
+static_assert(sizeof(MgpuStatsDev) == sizeof(mgpu_frame_stats), "stats layout");
+
+namespace mgpu_detail {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIPCK(expr)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+T* upload(const std::vector<T>& v) {
+    T* d = nullptr;
+    HIPCK(hipMalloc(&d, v.size() * sizeof(T) + 16));
+    HIPCK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+}  // namespace mgpu_detail
+using namespace mgpu_detail;
+
+struct mgpu_ctx {
+    mgpu_config cfg{};
+    mgpu::ModeTables tab;
+    MgpuDev dev{};
+    LdpcDev ldev{};
+    std::vector<void*> owned;       // device allocations freed in destroy
+    std::string err;
+    int max_batch = 0;
+    // workspaces (device)
+    double* d_baseband = nullptr;   // lazily sized for the host-buffer entry points
+    size_t baseband_cap = 0;
+    float* d_llr = nullptr;
+    float* d_variance = nullptr;
+    float* d_snrvar = nullptr;
+    uint8_t* d_payload = nullptr;
+    MgpuStatsDev* d_stats = nullptr;
+    uint8_t* d_bits = nullptr;
+    double* d_eqdata = nullptr;
+    double* d_fir[2] = {nullptr, nullptr};   // FIR_rx_time_sync, FIR_rx_data taps
+    hipEvent_t sync_ev[2]{};        // around the most recent synchroniser kernel
+    float last_sync_ms = -1.f;     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
+    int* d_iters = nullptr;
+    hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
+    static constexpr int kEvRing = 64;
+    hipEvent_t ev[kEvRing][4]{};    // per launch: front-end start/stop, decoder start/stop
+    bool timing = false;
+    int ev_count = 0;               // launches recorded since timing was enabled (ring of kEvRing)
+    bool ev_fe[kEvRing]{};          // whether the front-end ran in that slot
+    size_t lds_fe = 0, lds_dec = 0, lds_tx = 0;
+    DecoderKernel spa_kernel = nullptr;
+
+    template <typename T>
+    T* keep(T* p) { owned.push_back(p); return p; }
+};
+
+
+namespace mgpu_detail {
+
+// Workspaces sized by max_batch are created on first use (api.hip)
+enum : unsigned { WS_FRONTEND = 1, WS_LLR = 2, WS_OUT = 4, WS_BITS = 8 };
+void ensure_workspaces(mgpu_ctx* c, unsigned what);
+
+// HIP caps gridDim*blockDim below 2^32 threads, so very large batches go out in chunks of frames.
+constexpr int kMaxFramesPerLaunch = 1 << 21;
+template <typename T> T* at(T* p, size_t off) { return p ? p + off : nullptr; }
+
+// frame_stride (complex samples between consecutive frames of d_bb) defaults to the mode's frame_samples
+void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float* d_var, float* d_snrvar, const MgpuTapsDev& taps,
+                     hipStream_t s, int frame_stride = 0);
+void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s);
+void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int* d_iters, uint8_t* d_payload, MgpuStatsDev* d_stats,
+                    const float* d_var, const float* d_snrvar, hipStream_t s);
+
+// the reference's peak selection (ofdm.cc:1943-1964): overwrite-not-swap partial sort over an array of `size` entries that
+// holds the metric of candidate k at index k*step and 0 elsewhere; returns the index (delay) and value of entry
+// `location_to_return` after nTrials_max passes
+void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr);
+
+inline int guard(mgpu_ctx* c, const std::function<void()>& fn) {
+    try {
+        fn();
+        return MGPU_OK;
+    } catch (const HipError& e) {
+        if (c) c->err = e.what();
+        return MGPU_ERR_DEVICE;
+    } catch (const std::invalid_argument& e) {
+        if (c) c->err = e.what();
+        return MGPU_ERR_ARG;
+    } catch (const std::exception& e) {
+        if (c) c->err = e.what();
+        return MGPU_ERR_DEVICE;
+    }
+}
+inline void need(bool ok, const char* what) { if (!ok) throw std::invalid_argument(what); }
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { HIPCK(hipMalloc(&p, bytes ? bytes : 16)); }
+    ~DevBuf() { (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+constexpr double kSampleRate = 48000.0;          // telecom_system.cc:1569
+const double kCarrierAmplitude = 1.4142135623730951;   // sqrt(2.0), telecom_system.cc:69
+
+}  // namespace mgpu_detail

@@ -254,6 +254,12 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
     }
     __syncthreads();
 
+    if (taps.mean_H) {      // mean |H| over the MEASURED (pilot) cells in cell order, telecom_system.cc:1224-1243
+        for (int p = tid; p < T.nPilots; p += FE_THREADS) { const c2 h = H[T.pilot_cell[p]]; red[p] = hypot(h.re, h.im); }
+        __syncthreads();
+        if (tid == 0) taps.mean_H[f] = T.nPilots > 0 ? serial_sum(red, T.nPilots) / T.nPilots : -1.0;
+        __syncthreads();
+    }
     FE_STAMP();   // 4: interpolation done
     // ---- amplitude restoration (PSK modes) + SNR variance on the non-restored equalisation ----
     if (T.amp_restore) {

@@ -22,11 +22,11 @@ __device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.
 extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
     const double* __restrict__ passband, int in_size, const double* __restrict__ carrier_hz, const int* __restrict__ start_opt,
     int start_all, int count, int decim, const double* __restrict__ taps, int ntaps, double fs, double amplitude,
-    double* __restrict__ out) {
+    double* __restrict__ out, const int* __restrict__ widx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c2* l = reinterpret_cast<c2*>(smem);
     __shared__ double c[P2B_MAXTAPS];
-    const int w = blockIdx.y, tid = threadIdx.x;
+    const int w = widx ? widx[blockIdx.y] : blockIdx.y, tid = threadIdx.x;   // optional subset of the windows
     const int start = start_opt ? start_opt[w] : start_all;
     const int k0 = blockIdx.x * P2B_THREADS;
     const int h = (ntaps - 1) / 2;
@@ -107,14 +107,21 @@ __device__ __forceinline__ void ts_accumulate(const c2& x, const c2& y, double& 
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_kernel(
-    const double* __restrict__ bb, int size, int ncand, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
+    const int* __restrict__ ncand_w, int ncand_max, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    // window k of the launch is window widx[k] (or k) of the buffer, searched from sample start[k] (or 0) with ncand_w[k]
+    // (or ncand_max) candidates; vals is [gridDim.y][ncand_max]
+    const int wsel = widx ? widx[blockIdx.y] : blockIdx.y;
+    const int wstart = start ? start[blockIdx.y] : 0;
+    const int ncand = ncand_w ? ncand_w[blockIdx.y] : ncand_max;
+    const int size = stride - wstart;
     // requires ngi_i % TS_CH == 0 and (nfft_i / 2) % TS_CH == 0 (the host checks; 64 and 512 in the reference's calls)
     __shared__ c2 tile[TS_WAVES][2][64][TS_CH + 1];
-    const int w = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cand0 = (blockIdx.x * TS_WAVES + wave) * 64;
     if (cand0 >= ncand) return;
     const int cand = cand0 + lane;
-    const char* win = reinterpret_cast<const char*>(bb) + size_t(w) * size * 16;
+    const char* win = reinterpret_cast<const char*>(bb) + (size_t(wsel) * stride + wstart) * 16;
     c2 (*ra)[TS_CH + 1] = tile[wave][0];
     c2 (*rb)[TS_CH + 1] = tile[wave][1];
     const int rsub = lane / TS_CH, col = lane % TS_CH;           // staging role: row rr*TS_RPL + rsub, sample col
@@ -164,16 +171,22 @@ extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_ke
     if (cand >= ncand) return;
     if (na < 0.001 || nb < 0.001) cc = 0.0;
     else cc = cc / sqrt(na * nb);
-    vals[size_t(w) * ncand + cand] = cc;
+    vals[size_t(blockIdx.y) * ncand_max + cand] = cc;
 }
 
 // Fallback for segment lengths that are not multiples of TS_CH: one lane per candidate, direct loads.
 extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_generic_kernel(
-    const double* __restrict__ bb, int size, int ncand, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
-    const int w = blockIdx.y;
+    const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
+    const int* __restrict__ ncand_w, int ncand_max, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    // window k of the launch is window widx[k] (or k) of the buffer, searched from sample start[k] (or 0) with ncand_w[k]
+    // (or ncand_max) candidates; vals is [gridDim.y][ncand_max]
+    const int wsel = widx ? widx[blockIdx.y] : blockIdx.y;
+    const int wstart = start ? start[blockIdx.y] : 0;
+    const int ncand = ncand_w ? ncand_w[blockIdx.y] : ncand_max;
+    const int size = stride - wstart;
     const int cand = blockIdx.x * 64 + threadIdx.x;
     if (cand >= ncand) return;
-    const c2* data = reinterpret_cast<const c2*>(bb) + size_t(w) * size + size_t(cand) * step;
+    const c2* data = reinterpret_cast<const c2*>(bb) + size_t(wsel) * stride + wstart + size_t(cand) * step;
     double cc = 0, na = 0, nb = 0;
     for (int q = 0; q < 2 * pre_nsymb; ++q) {
         const TsSeg sg = ts_segment(q, ngi_i, nfft_i);
@@ -181,20 +194,27 @@ extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_generic_kerne
     }
     if (na < 0.001 || nb < 0.001) cc = 0.0;
     else cc = cc / sqrt(na * nb);
-    vals[size_t(w) * ncand + cand] = cc;
+    vals[size_t(blockIdx.y) * ncand_max + cand] = cc;
 }
 
 #define TS_DCH 64
 #define TS_DSPAN (63 * 4 + TS_DCH)      // step <= 4
 
 extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_dense_kernel(
-    const double* __restrict__ bb, int size, int ncand, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
+    const int* __restrict__ ncand_w, int ncand_max, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    // window k of the launch is window widx[k] (or k) of the buffer, searched from sample start[k] (or 0) with ncand_w[k]
+    // (or ncand_max) candidates; vals is [gridDim.y][ncand_max]
+    const int wsel = widx ? widx[blockIdx.y] : blockIdx.y;
+    const int wstart = start ? start[blockIdx.y] : 0;
+    const int ncand = ncand_w ? ncand_w[blockIdx.y] : ncand_max;
+    const int size = stride - wstart;
     __shared__ c2 span[TS_WAVES][2][TS_DSPAN];
-    const int w = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cand0 = (blockIdx.x * TS_WAVES + wave) * 64;
     if (cand0 >= ncand) return;
     const int cand = cand0 + lane;
-    const c2* win = reinterpret_cast<const c2*>(bb) + size_t(w) * size + size_t(cand0) * step;
+    const c2* win = reinterpret_cast<const c2*>(bb) + size_t(wsel) * stride + wstart + size_t(cand0) * step;
     const long avail = long(size) - long(cand0) * step;         // samples from the wave's first candidate to the end
     c2* sa = span[wave][0];
     c2* sb = span[wave][1];
@@ -247,7 +267,7 @@ extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_de
     if (cand >= ncand) return;
     if (na < 0.001 || nb < 0.001) cc = 0.0;
     else cc = cc / sqrt(na * nb);
-    vals[size_t(w) * ncand + cand] = cc;
+    vals[size_t(blockIdx.y) * ncand_max + cand] = cc;
 }
 
 // Moose: up to two preamble symbols, each as two 256-point FFTs of a half symbol repeated twice.
@@ -299,4 +319,32 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(
         else if (mul.re < 0 && mul.im < 0) theta = atan(mul.im / mul.re) - M_PI;
         freq_out[w] = (theta / M_PI) * carrier_freq_width;
     }
+}
+
+// Sums of |x|^2 over short spans of the interpolated baseband: the energy gates of receive_byte
+// (telecom_system.cc:758-766, :826-834, :1044-1066, ...). Span j lies in window wv[j] at offset off[j]; the terms
+// re*re + im*im are added in sample order for i < len while off + i < stride (the reference's loop bounds); the caller
+// divides by the count or by len as the call site does. One lane per span.
+extern "C" __global__ __launch_bounds__(64) void mgpu_span_energy_kernel(
+    const double* __restrict__ bb, int stride, const int* __restrict__ wv, const int* __restrict__ off, int n, int len,
+    double* __restrict__ sum, int* __restrict__ cnt) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n) return;
+    const c2* x = reinterpret_cast<const c2*>(bb) + size_t(wv[j]) * stride;
+    const int o = off[j];
+    double e = 0.0;
+    int c = 0;
+    for (int i = 0; i < len && o + i < stride; ++i) { const c2 v = x[o + i]; e += v.re * v.re + v.im * v.im; ++c; }
+    sum[j] = e;
+    cnt[j] = c;
+}
+
+// rational_resampler(..., DECIMATION) (ofdm.cc:2267-2278) from a per-window offset: out[k][i] = bb[widx[k]][delay[k] + i*rate]
+extern "C" __global__ __launch_bounds__(256) void mgpu_decimate_kernel(
+    const double* __restrict__ bb, int stride, const int* __restrict__ widx, const int* __restrict__ delay, int rate, int count,
+    double* __restrict__ out) {
+    const int k = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const c2* x = reinterpret_cast<const c2*>(bb) + size_t(widx[k]) * stride + delay[k];
+    reinterpret_cast<c2*>(out)[size_t(k) * count + i] = x[size_t(i) * rate];
 }

@@ -263,6 +263,14 @@ static const struct { int M, rate16, preamble, est; } MODES[17] = {
     {16,8,2,EST_LS},{8,14,2,EST_LS},{16,14,2,EST_ZF},{32,14,1,EST_ZF}};
 
 #define MOD_MFSK 200   /* mfsk.h:28 */
+static const int MFSK_PREAMBLE_32[4] = {4, 20, 12, 28}, MFSK_PREAMBLE_16[4] = {2, 10, 6, 14};   /* mfsk.cc:82-95 */
+static const int ACK_TONES_16[8] = {4, 7, 5, 12, 13, 1, 9, 15};                                   /* mfsk.cc:120-126 */
+static const int BREAK_TONES_16[8] = {6, 14, 2, 3, 10, 8, 11, 15};                                /* mfsk.cc:149-155 */
+#define ACK_M 16
+#define ACK_NSYMB 16
+#define ACK_LEN 8
+#define ACK_HOP 7
+#define ACK_OFFSET 17     /* (Nc - 16) / 2: the universal ack_mfsk is M=16, one stream (telecom_system.cc:3006) */
 morc* morc_create(int cfg, int max_iters, const char* tables_path) {
     int robust = cfg >= 100 && cfg <= 102;                       /* common_defines.h:63-65 */
     if (!robust && (cfg < 0 || cfg > 16)) return NULL;
@@ -967,14 +975,26 @@ double morc_freq_sync(morc* o, const double* in_c128, double carrier_freq_width,
  * without pre-equalisation, clipping and TX filters): rational_resampler INTERPOLATION ofdm.cc:2279-2292,
  * baseband_to_passband :2294-2315. */
 int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, double amplitude, double* out) {
-    int pre = o->preamble, interp = 4, nb = (pre + o->Nsymb) * o->Nofdm;
+    int pre = o->preamble, interp = 4, nsym = o->active_nsymb, nb = (pre + nsym) * o->Nofdm;
     cd* bb = malloc(sizeof(cd) * nb);
     cd* frame = bb + pre * o->Nofdm;
     morc_tx(o, bits, 1, (double*)frame);
+    /* MFSK modes: known single-tone preamble and the drive-level boost of telecom_system.cc:461-465, :506-524 */
+    double mfsk_boost = 1.0;
+    cd mfsk_pre[8 * 50];
+    if (o->M == MOD_MFSK) {
+        mfsk_boost = sqrt((double)o->Nc / o->mfsk_nstreams) * pow(10.0, -2.0 / 20.0);
+        const int* tones = o->mfsk_M == 32 ? MFSK_PREAMBLE_32 : MFSK_PREAMBLE_16;
+        double amp = sqrt((double)o->Nc / o->mfsk_nstreams);
+        for (int s = 0; s < pre; s++) {
+            for (int k = 0; k < 50; k++) mfsk_pre[s * 50 + k] = 0.0;
+            for (int st = 0; st < o->mfsk_nstreams; st++) mfsk_pre[s * 50 + o->mfsk_off[st] + tones[s % 4]] = amp;
+        }
+    }
     for (int s = 0; s < pre; s++) {
         cd z[256];
         memset(z, 0, sizeof z);
-        const cd* in = &o->preamble_vals[s * o->Nc];
+        const cd* in = o->M == MOD_MFSK ? &mfsk_pre[s * 50] : &o->preamble_vals[s * o->Nc];
         for (int j = 0; j < 25; j++) z[j + 256 - 25] = in[j];
         for (int j = 25; j < 50; j++) z[j - 25 + 1] = in[j];
         fft256(o, z, 1);
@@ -986,19 +1006,19 @@ int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, dou
     double pw = sqrt(0.1), boost = sqrt(2);
     for (int j = 0; j < o->Nofdm * pre; j++) {
         bb[j] = (creal(bb[j]) / (double)pn) + (cimag(bb[j]) / (double)pn) * I;
-        double m = pw * boost * 1.0;
+        double m = pw * boost * mfsk_boost;
         bb[j] = (creal(bb[j]) * m) + (cimag(bb[j]) * m) * I;
     }
-    for (int j = 0; j < o->Nofdm * o->Nsymb; j++) {
+    for (int j = 0; j < o->Nofdm * nsym; j++) {
         frame[j] = (creal(frame[j]) / (double)pn) + (cimag(frame[j]) / (double)pn) * I;
-        double m = pw * 1.0;
+        double m = pw * mfsk_boost;
         frame[j] = (creal(frame[j]) * m) + (cimag(frame[j]) * m) * I;
     }
     double Ts = 1.0 / fs;
     unsigned long start = 0;
     for (int part = 0; part < 2; part++) {
         const cd* in = part ? frame : bb;
-        int n = part ? o->Nofdm * o->Nsymb : o->Nofdm * pre;
+        int n = part ? o->Nofdm * nsym : o->Nofdm * pre;
         double* dst = out + (part ? o->Nofdm * pre * interp : 0);
         for (int i = 0; i < n; i++)
             for (int j = 0; j < interp; j++) {
@@ -1015,17 +1035,8 @@ int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, dou
     return nb * interp;
 }
 
-/* the host libm functions exactly as decode_SPA calls them (ldpc_decoder_SPA.cc:145,156) */
 /* ------------------------------------------------------------------------------------ */
 /* MFSK synchroniser / signalling blocks */
-static const int MFSK_PREAMBLE_32[4] = {4, 20, 12, 28}, MFSK_PREAMBLE_16[4] = {2, 10, 6, 14};   /* mfsk.cc:82-95 */
-static const int ACK_TONES_16[8] = {4, 7, 5, 12, 13, 1, 9, 15};                                   /* mfsk.cc:120-126 */
-static const int BREAK_TONES_16[8] = {6, 14, 2, 3, 10, 8, 11, 15};                                /* mfsk.cc:149-155 */
-#define ACK_M 16
-#define ACK_NSYMB 16
-#define ACK_LEN 8
-#define ACK_HOP 7
-#define ACK_OFFSET 17     /* (Nc - 16) / 2: the universal ack_mfsk is M=16, one stream (telecom_system.cc:3006) */
 
 static void symbol_mod(const morc* o, const cd* in, cd* y) {   /* ofdm.cc:855-860 */
     cd z[256];
@@ -1128,6 +1139,199 @@ double morc_detect_ack_pattern(morc* o, const double* in_c128, int size, int int
     return best_metric;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* cl_telecom_system::receive_byte, the whole function: capture window (passband) -> payload + receive_stats.
+ *
+ * PARITY OF THIS FUNCTION IS UNPINNED.  Every DSP block it calls is pinned against the compiled reference
+ * (tests/test_oracle_vs_ref.py, tests/test_sync_blocks.py), but the orchestration itself lives in
+ * telecom_system.cc, which cannot be built in this image (it needs the audio and GUI subsystems), so the control
+ * flow below is a restatement checked only by reading: telecom_system.cc:646-1503, block by block, each cited.
+ * Not restated: the GUI-only coarse frequency search of trial 1 (:949-1012, g_gui_state.coarse_freq_sync_enabled is
+ * false by default), mfsk_fixed_delay (BER-test hook), signal_stregth_dbm (display value), prints. */
+#define FIR_TS 0
+#define FIR_DATA 1
+static const double FS = 48000.0;                 /* telecom_system.cc:1569 */
+static const double CARRIER_AMPLITUDE = 1.4142135623730951;   /* sqrt(2.0), telecom_system.cc:69 */
+
+int morc_buffer_nsymb(morc* o) {                  /* data_container.cc:133-143 */
+    double sym_time_ms = 1000.0 * o->Nofdm * 4 / 48000.0;
+    int turnaround_symb = (int)ceil(1200.0 / sym_time_ms) + 4;
+    int frame_symb = o->preamble + o->Nsymb;
+    int min_buf = frame_symb * 2;
+    if (frame_symb + turnaround_symb > min_buf) min_buf = frame_symb + turnaround_symb;
+    if (min_buf < 32) min_buf = 32;
+    return min_buf;
+}
+
+/* mean energy of up to sym_samples samples starting at off (the loops at :758-766, :792-800, :826-834 ...) */
+static double span_energy(const cd* bbi, int off, int sym_samples, int buf_samples) {
+    double e = 0.0; int cnt = 0;
+    for (int i = 0; i < sym_samples && (off + i) < buf_samples; i++) { e += creal(bbi[off + i]) * creal(bbi[off + i]) + cimag(bbi[off + i]) * cimag(bbi[off + i]); cnt++; }
+    return cnt > 0 ? e / cnt : 0.0;
+}
+
+void morc_receive_byte(morc* o, const double* passband, double carrier_hz, int trials_max, int use_last_good_time_sync,
+                       int use_last_good_freq_offset, morc_link_state* st, int* out_bytes, morc_receive_stats* rs) {
+    const int interp = 4, sym = o->Nofdm * interp, pre = o->preamble;
+    const int buffer_nsymb = morc_buffer_nsymb(o), buf = o->Nofdm * buffer_nsymb * interp;
+    const int frame_i = o->Nofdm * (o->Nsymb + pre) * interp;
+    const double bandwidth = 48000.0 * 50.0 / 256 / 4;
+    cd* bbi = malloc(sizeof(cd) * buf);
+    cd* bb = malloc(sizeof(cd) * (frame_i / interp + 1));
+    int step = 100, pream;
+    double freq_offset_measured = 0;
+    /* receive_stats as init() leaves it (telecom_system.cc:1968-1981) + the per-call resets (:653-655) */
+    rs->iterations_done = -1; rs->crc = 0; rs->all_zeros = 0; rs->message_decoded = 0; rs->snr_db = -99.9;
+    rs->delay = 0; rs->sync_trials = 0; rs->freq_offset = 0; rs->coarse_metric = 0; rs->frame_overflow_symbols = 0; rs->mean_H = -1.0;
+    /* :676-696 */
+    morc_passband_to_baseband(o, passband, buf, FS, carrier_hz, CARRIER_AMPLITUDE, 1, FIR_TS, (double*)bbi);
+    if (o->M == MOD_MFSK) {
+        rs->delay = morc_time_sync_mfsk(o, (const double*)bbi, buf, interp, st ? st->mfsk_search_start : 0);
+    } else {
+        double corr = 0;
+        rs->delay = morc_time_sync_preamble(o, (const double*)bbi, buf, interp, 0, step, 1, &corr);
+        rs->coarse_metric = corr;
+    }
+    pream = rs->delay / sym;
+    if (pream < 1) pream = 1;
+    /* :702-718 MFSK frame completeness */
+    if (o->M == MOD_MFSK) {
+        int frame_end = rs->delay + (pre + o->active_nsymb) * sym;
+        if (frame_end > buf) {
+            rs->frame_overflow_symbols = (frame_end - buf + sym - 1) / sym;
+            free(bbi); free(bb);
+            return;
+        }
+    }
+    const int lower = pre, upper = buffer_nsymb - (o->Nsymb + pre);   /* :720-721 */
+#define IN_BOUNDS(p) ((p) > lower && (p) < upper)
+    /* :733-806 bounds recovery (OFDM) */
+    if (o->M != MOD_MFSK && !IN_BOUNDS(pream)) {
+        int signal_start = -1;
+        for (int s = lower + 1; s < upper; s++) if (span_energy(bbi, s * sym, sym, buf) > 0.001) { signal_start = s; break; }
+        if (signal_start >= 0) {
+            int search_start = signal_start * sym, available = buf - search_start;
+            if (available > pre * sym) {
+                double corr = 0;
+                int d = morc_time_sync_preamble(o, (const double*)&bbi[search_start], available, interp, 0, step, 1, &corr) + search_start;
+                int rsym = d / sym; if (rsym < 1) rsym = 1;
+                double re = span_energy(bbi, d, sym, buf);
+                if (re >= 0.001 && corr >= 0.5 && IN_BOUNDS(rsym)) { rs->delay = d; rs->coarse_metric = corr; pream = rsym; }
+            }
+        }
+    }
+    if (IN_BOUNDS(pream)) {
+        int energy_ok = 1;
+        if (o->M != MOD_MFSK) {   /* :808-928 energy / metric gates and the silence-skip recovery */
+            if (span_energy(bbi, rs->delay, sym, buf) < 0.001) energy_ok = 0;
+            if (energy_ok && rs->coarse_metric < 0.5) energy_ok = 0;
+            if (!energy_ok) {
+                int signal_start = -1;
+                for (int s = pream + 1; s < upper; s++) if (span_energy(bbi, s * sym, sym, buf) > 0.001) { signal_start = s; break; }
+                if (signal_start >= 0) {
+                    int search_start = signal_start * sym, available = buf - search_start;
+                    if (available > pre * sym) {
+                        double corr = 0;
+                        int d = morc_time_sync_preamble(o, (const double*)&bbi[search_start], available, interp, 0, step, 1, &corr) + search_start;
+                        int rsym = d / sym; if (rsym < 1) rsym = 1;
+                        double re = span_energy(bbi, d, sym, buf);
+                        if (re >= 0.001 && corr >= 0.5 && IN_BOUNDS(rsym)) { rs->delay = d; rs->coarse_metric = corr; pream = rsym; energy_ok = 1; }
+                    }
+                }
+            }
+        }
+        if (energy_ok) {
+            int skip_h_count = 0, recovery_attempted = 0;
+        retry_point:
+            while (rs->sync_trials <= trials_max) {   /* :931 */
+                if (o->M == MOD_MFSK) {
+                    if (rs->sync_trials > 0) break;   /* :939-944 */
+                } else if (rs->sync_trials == trials_max && use_last_good_time_sync && st && st->delay_of_last_decoded_message != -1) {
+                    rs->delay = st->delay_of_last_decoded_message;   /* :945-948 */
+                } else {   /* :1014-1018 fine search, k-th best peak for trial k */
+                    int base = (pream - 1) * sym;
+                    rs->delay = base + morc_time_sync_preamble(o, (const double*)&bbi[base], (pre + 4) * sym, interp, rs->sync_trials, 1, trials_max, NULL);
+                }
+                if (rs->delay < 0) rs->delay = 0;
+                if (rs->delay > buf - frame_i) rs->delay = buf - frame_i;   /* :1022-1031 */
+                if (o->M != MOD_MFSK) {   /* :1039-1071 post-fine-sync energy fix */
+                    double fine = 0.0;
+                    for (int i = 0; i < sym && (rs->delay + i) < buf; i++) fine += creal(bbi[rs->delay + i]) * creal(bbi[rs->delay + i]) + cimag(bbi[rs->delay + i]) * cimag(bbi[rs->delay + i]);
+                    fine /= sym;
+                    if (fine < 0.001) {
+                        int orig = rs->delay;
+                        for (int fwd = sym; fwd <= 3 * sym; fwd += sym) {
+                            int cand = orig + fwd;
+                            if (cand + sym > buf) break;
+                            double e = 0.0;
+                            for (int i = 0; i < sym; i++) e += creal(bbi[cand + i]) * creal(bbi[cand + i]) + cimag(bbi[cand + i]) * cimag(bbi[cand + i]);
+                            e /= sym;
+                            if (e >= 0.001) { rs->delay = cand; break; }
+                        }
+                    }
+                }
+                double eff_carrier = carrier_hz;   /* coarse_freq_offset stays 0 (GUI-only search not restated) */
+                /* :1083, :1105 */
+                morc_passband_to_baseband(o, passband, buf, FS, eff_carrier, CARRIER_AMPLITUDE, 1, FIR_DATA, (double*)bbi);
+                for (int i = 0, k = 0; i < frame_i; i += interp) bb[k++] = bbi[rs->delay + i];
+                /* :1108-1120 */
+                if (rs->sync_trials == trials_max && use_last_good_freq_offset && st && st->freq_offset_of_last_decoded_message != 0)
+                    freq_offset_measured = st->freq_offset_of_last_decoded_message;
+                else
+                    freq_offset_measured = morc_freq_sync(o, (const double*)&bb[o->Ngi], bandwidth / (double)o->Nc, pre, FS);
+                if (o->M != MOD_MFSK && fabs(freq_offset_measured) > 0.1) {   /* :1122-1131, freq_offset_ignore_limit */
+                    morc_passband_to_baseband(o, passband, buf, FS, eff_carrier + freq_offset_measured, CARRIER_AMPLITUDE, 1, FIR_DATA, (double*)bbi);
+                    for (int i = 0, k = 0; i < frame_i; i += interp) bb[k++] = bbi[rs->delay + i];
+                }
+                /* :1132-1345 the hot path on the data symbols */
+                morc_rx_out r; memset(&r, 0, sizeof r);
+                int bytes[N_MAX];
+                r.bytes = bytes;
+                const double* data = (const double*)&bb[pre * o->Nofdm];
+                if (o->M != MOD_MFSK) {
+                    morc_rx(o, data, MORC_FLAG_AGC | MORC_FLAG_VAR_EQ | MORC_FLAG_NO_LDPC, &r);
+                    rs->mean_H = r.mean_H;
+                    if (r.mean_H < 0.3) { skip_h_count++; rs->sync_trials++; continue; }   /* :1269-1280 */
+                }
+                morc_rx(o, data, MORC_FLAG_AGC | MORC_FLAG_VAR_EQ, &r);
+                rs->iterations_done = r.iterations; rs->crc = r.crc; rs->all_zeros = r.all_zeros;
+                int fs_bytes = (o->nReal - 16) / 8;
+                for (int i = 0; i < fs_bytes; i++) out_bytes[i] = bytes[i];                 /* :1329-1332 */
+                if (r.all_zeros || r.crc != 0) {   /* :1343-1360 */
+                    rs->snr_db = -99.9; rs->message_decoded = 0; rs->sync_trials++;
+                } else {
+                    rs->snr_db = r.snr_db; rs->message_decoded = 1;
+                    if (o->M != MOD_MFSK) { rs->freq_offset = freq_offset_measured; if (st) st->freq_offset_of_last_decoded_message = freq_offset_measured; }
+                    if (st) st->delay_of_last_decoded_message = rs->delay;
+                    break;
+                }
+            }
+            /* :1436-1497 SKIP-H recovery */
+            if (!rs->message_decoded && skip_h_count >= trials_max + 1 && !recovery_attempted) {
+                recovery_attempted = 1;
+                int search_start_symb = pream + 2, search_start = search_start_symb * sym;
+                int search_size = o->Nofdm * (2 * pre + o->Nsymb) * interp;
+                int available = buf - search_start;
+                if (available > search_size) available = search_size;
+                if (search_start_symb < upper && available > pre * sym) {
+                    morc_passband_to_baseband(o, passband, buf, FS, carrier_hz, CARRIER_AMPLITUDE, 1, FIR_TS, (double*)bbi);
+                    double corr = 0;
+                    int d = morc_time_sync_preamble(o, (const double*)&bbi[search_start], available, interp, 0, step, 1, &corr) + search_start;
+                    int rsym = d / sym; if (rsym < 1) rsym = 1;
+                    double re = span_energy(bbi, d, sym, buf);
+                    if (re >= 0.001 && IN_BOUNDS(rsym)) {
+                        rs->delay = d; rs->coarse_metric = corr; pream = rsym; rs->sync_trials = 0; skip_h_count = 0;
+                        goto retry_point;
+                    }
+                }
+            }
+        }
+    }
+#undef IN_BOUNDS
+    free(bbi); free(bb);
+}
+
+/* the host libm functions exactly as decode_SPA calls them (ldpc_decoder_SPA.cc:145,156) */
 void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out) {
     for (int i = 0; i < n; i++) {
         tanh_out[i] = tanh(in[i]);

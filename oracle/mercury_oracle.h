@@ -110,6 +110,26 @@ int morc_mfsk_pattern(morc*, int which, double* out_c128);   /* returns the symb
 int morc_time_sync_mfsk(morc*, const double* in_c128, int size, int interpolation_rate, int search_start_symb);
 double morc_detect_ack_pattern(morc*, const double* in_c128, int size, int interpolation_rate, int which, int* matched);
 
+/* ---- the whole of cl_telecom_system::receive_byte (telecom_system.cc:646-1503): one passband capture window of
+ * morc_buffer_nsymb()*Nofdm*4 samples in, payload + receive_stats out. PARITY UNPINNED for the orchestration (the DSP
+ * blocks it calls are pinned): telecom_system.cc cannot be built here. See the comment at the definition. ---- */
+typedef struct morc_link_state {          /* the cross-call members of st_receive_stats the loop consults */
+    int delay_of_last_decoded_message;    /* -1 = none yet (telecom_system.cc:1972) */
+    double freq_offset_of_last_decoded_message;
+    int mfsk_search_start;                /* receive_stats.mfsk_search_raw - nUnder_processing_events, clamped at 0 (:683-685) */
+} morc_link_state;
+typedef struct morc_receive_stats {
+    int iterations_done, crc, all_zeros, message_decoded;
+    double snr_db;
+    int delay, sync_trials;
+    double freq_offset, coarse_metric;
+    int frame_overflow_symbols;
+    double mean_H;                        /* of the last trial that got as far as the channel estimate */
+} morc_receive_stats;
+int morc_buffer_nsymb(morc*);             /* data_container.cc:133-143 */
+void morc_receive_byte(morc*, const double* passband, double carrier_hz, int time_sync_trials_max, int use_last_good_time_sync,
+                       int use_last_good_freq_offset, morc_link_state* state_or_null, int* out_bytes, morc_receive_stats* stats);
+
 /* host libm tanh / atanh as the reference's decoder calls them; atanh_out is 0 where |x| >= 1 */
 void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out);
 

@@ -556,22 +556,29 @@ double mref_freq_sync(void* h, const double* in_c128, double carrier_freq_width,
 extern "C" void mref_tx(void* h, const int* bits, int scramble, double* out_c128);
 int mref_tx_passband(void* h, const int* bits, double fs, double carrier_hz, double amplitude, double* out_passband) {
     Ref* r = (Ref*)h;
+    const int nsym = r->active_nsymb;                                                          // telecom_system.cc:500
     std::vector<double> frame(2 * size_t(r->Nofdm) * r->Nsymb);
     mref_tx(h, bits, 1, frame.data());
     Silence s;
     const int pre = r->preamble_nsymb, interp = 4;
     std::vector<cd> pre_data(size_t(pre) * r->Nc), pre_mod(size_t(pre) * r->Nofdm);
-    for (int i = 0; i < pre * r->Nc; i++) pre_data[i] = r->ofdm.ofdm_preamble[i].value;       // telecom_system.cc:466-472
+    double mfsk_boost = 1.0;
+    if (r->M == MOD_MFSK) {                                                                    // telecom_system.cc:461-465, :510-515
+        r->mfsk.generate_preamble(pre_data.data(), pre);
+        mfsk_boost = sqrt((double)r->Nc / r->mfsk.nStreams) * pow(10.0, -2.0 / 20.0);
+    } else {
+        for (int i = 0; i < pre * r->Nc; i++) pre_data[i] = r->ofdm.ofdm_preamble[i].value;   // telecom_system.cc:466-472
+    }
     for (int i = 0; i < pre; i++) r->ofdm.symbol_mod(&pre_data[i * r->Nc], &pre_mod[i * r->Nofdm]);
     cd* data = (cd*)frame.data();
     const float power_normalization = sqrt((double)(r->Nfft * interp));                       // telecom_system.cc:388
     const double pw = sqrt(0.1);                                                               // output_power_Watt
-    for (int j = 0; j < r->Nofdm * pre; j++) { pre_mod[j] /= power_normalization; pre_mod[j] *= pw * r->ofdm.preamble_configurator.boost * 1.0; }
-    for (int j = 0; j < r->Nofdm * r->Nsymb; j++) { data[j] /= power_normalization; data[j] *= pw * 1.0; }
+    for (int j = 0; j < r->Nofdm * pre; j++) { pre_mod[j] /= power_normalization; pre_mod[j] *= pw * r->ofdm.preamble_configurator.boost * mfsk_boost; }
+    for (int j = 0; j < r->Nofdm * nsym; j++) { data[j] /= power_normalization; data[j] *= pw * mfsk_boost; }
     r->ofdm.passband_start_sample = 0;
     r->ofdm.baseband_to_passband(pre_mod.data(), r->Nofdm * pre, out_passband, fs, carrier_hz, amplitude, interp);
-    r->ofdm.baseband_to_passband(data, r->Nofdm * r->Nsymb, &out_passband[r->Nofdm * pre * interp], fs, carrier_hz, amplitude, interp);
-    return (pre + r->Nsymb) * r->Nofdm * interp;
+    r->ofdm.baseband_to_passband(data, r->Nofdm * nsym, &out_passband[r->Nofdm * pre * interp], fs, carrier_hz, amplitude, interp);
+    return (pre + nsym) * r->Nofdm * interp;
 }
 
 // ---- MFSK synchroniser / signalling blocks ------------------------------------------------------------

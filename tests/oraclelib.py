@@ -195,6 +195,40 @@ class Oracle(_Base):
         return int(tot), iters, crc, pl
 
 
+class LinkState(C.Structure):
+    _fields_ = [("delay_of_last_decoded_message", C.c_int), ("freq_offset_of_last_decoded_message", C.c_double),
+                ("mfsk_search_start", C.c_int)]
+
+
+class ReceiveStats(C.Structure):
+    _fields_ = [("iterations_done", C.c_int), ("crc", C.c_int), ("all_zeros", C.c_int), ("message_decoded", C.c_int),
+                ("snr_db", C.c_double), ("delay", C.c_int), ("sync_trials", C.c_int), ("freq_offset", C.c_double),
+                ("coarse_metric", C.c_double), ("frame_overflow_symbols", C.c_int), ("mean_H", C.c_double)]
+
+
+def _receive_byte(self, passband, carrier=None, trials_max=2, use_last_time=1, use_last_freq=1, state=None):
+    """The whole cl_telecom_system::receive_byte on one capture window (oracle only; orchestration parity unpinned)."""
+    x = np.ascontiguousarray(passband, np.float64)
+    assert x.size == self.buffer_samples()
+    out = np.zeros(1600, np.int32)
+    rs = ReceiveStats()
+    st = state if state is not None else LinkState(-1, 0.0, 0)
+    self.lib.morc_receive_byte(self.h, _p(x), C.c_double(CARRIER if carrier is None else carrier), C.c_int(trials_max), C.c_int(use_last_time),
+                               C.c_int(use_last_freq), C.byref(st), _p(out), C.byref(rs))
+    res = {k: getattr(rs, k) for k, _ in ReceiveStats._fields_}
+    res["payload"] = out[: self.payload_bytes].astype(np.uint8)
+    res["state"] = st
+    return res
+
+
+def _buffer_samples(self):
+    return int(self.lib.morc_buffer_nsymb(self.h)) * self.Nofdm * 4
+
+
+Oracle.receive_byte = _receive_byte
+Oracle.buffer_samples = _buffer_samples
+
+
 class RefLib(_Base):
     prefix = "mref_"
 
@@ -265,7 +299,7 @@ def _sync_methods(cls):
     def tx_passband(self, bits, carrier=CARRIER, fs=FS, amplitude=AMPLITUDE):
         b = np.zeros(1600, np.int32)
         b[: self.nReal] = bits[: self.nReal]
-        out = np.zeros((self.preamble_nsymb + self.Nsymb) * self.Nofdm * 4)
+        out = np.zeros((self.preamble_nsymb + self.active_nsymb) * self.Nofdm * 4)
         f = self._fn("tx_passband")
         f.restype = C.c_int
         n = f(self.h, _p(b), C.c_double(fs), C.c_double(carrier), C.c_double(amplitude), _p(out))
