@@ -1,0 +1,62 @@
+/* mercury_rxloop.h — the whole of cl_telecom_system::receive_byte, batched.
+ *
+ * st_receive_stats cl_telecom_system::receive_byte(double* data, int* out)
+ * (include/physical_layer/telecom_system.h:142, source/physical_layer/telecom_system.cc:646-1503) takes one capture
+ * window of passband audio (buffer_Nsymb * Nofdm * 4 samples at 48 kHz), synchronises, runs up to
+ * time_sync_trials_max + 1 decode trials and returns the receive statistics. mgpu_receive_byte_batch does that for W
+ * independent windows at once; each window behaves as a fresh call whose cross-call memory (last good delay /
+ * frequency offset) is passed in and out through mgpu_link_state.
+ *
+ * PARITY of the control flow is UNPINNED: telecom_system.cc cannot be compiled in the build image (it needs the audio
+ * and GUI subsystems), so the gates, recoveries and the retry loop are restated from the source and checked against
+ * the repository's own CPU restatement (oracle/mercury_oracle.c:morc_receive_byte). Every DSP block underneath is
+ * checked against the compiled reference. Not built: the GUI-only coarse frequency search of trial 1
+ * (telecom_system.cc:949-1012, disabled by default), mfsk_fixed_delay (BER-test hook), signal_stregth_dbm.
+ */
+#ifndef MERCURY_RXLOOP_H
+#define MERCURY_RXLOOP_H
+
+#include <stdint.h>
+
+#include "mercury_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgpu_receive_config {
+    double carrier_hz;              /* carrier_frequency (physical_config.cc:84: bandwidth/2 + 300 + offset) */
+    int time_sync_trials_max;       /* physical_config.cc:85 (2) */
+    int use_last_good_time_sync;    /* physical_config.cc:86 (YES) */
+    int use_last_good_freq_offset;  /* physical_config.cc:87 (YES) */
+} mgpu_receive_config;
+
+/* the members of st_receive_stats that survive from one receive_byte call to the next and steer it */
+typedef struct mgpu_link_state {
+    int delay_of_last_decoded_message;             /* -1 = none yet (telecom_system.cc:1972) */
+    double freq_offset_of_last_decoded_message;
+    int mfsk_search_start;                         /* mfsk_search_raw - nUnder_processing_events, >= 0 (telecom_system.cc:683-685) */
+} mgpu_link_state;
+
+/* st_receive_stats (telecom_system.h:63-82), the fields this function sets */
+typedef struct mgpu_receive_stats {
+    int iterations_done, crc, all_zeros, message_decoded;
+    double snr_db;                  /* SNR */
+    int delay, sync_trials;
+    double freq_offset, coarse_metric;
+    int frame_overflow_symbols;
+    double mean_H;                  /* mean |H| of the last trial that reached the channel estimate (the :1269 gate); -1 if none */
+} mgpu_receive_stats;
+
+/* buffer_Nsymb (data_container.cc:133-143); a capture window is buffer_Nsymb * Nofdm * 4 passband samples */
+int mgpu_receive_buffer_nsymb(mgpu_ctx* ctx);
+
+/* passband: [W][buffer_Nsymb*Nofdm*4] doubles. state: NULL or [W], read and updated. payload: [W][payload_stride].
+ * stats: [W]. W <= max_batch. Blocking. */
+int mgpu_receive_byte_batch(mgpu_ctx* ctx, const double* passband, int W, const mgpu_receive_config* config,
+                            mgpu_link_state* state, uint8_t* payload, mgpu_receive_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERCURY_RXLOOP_H */

@@ -202,6 +202,28 @@ void select_peak(const double* cand_vals, int ncand, int step, int size, int loc
     *corr = vals[location_to_return];
 }
 
+int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb) {
+    static constexpr int kTones32[4] = {4, 20, 12, 28}, kTones16[4] = {2, 10, 6, 14};      // mfsk.cc:82-95
+    const int* tones = t.mfsk_M == 32 ? kTones32 : kTones16;
+    const int sym_period = t.Nofdm * 4, np = t.preamble;
+    double best_metric = -1;
+    int best = 0;
+    for (int s = search_start_symb > 0 ? search_start_symb : 0; s <= nslots - np; ++s) {
+        double metric = 0;
+        for (int p = 0; p < np; ++p) {
+            if ((s + p) * sym_period + t.Ngi * 4 + t.Nfft * 4 > size) break;
+            const double* e = &E[size_t(s + p) * t.Nc];
+            double e_target = 0;
+            for (int st = 0; st < t.mfsk_nstreams; ++st) e_target += e[t.mfsk_off[st] + tones[p % np]];
+            double e_total = 0;
+            for (int k = 0; k < t.Nc; ++k) e_total += e[k];
+            if (e_total > 0) metric += e_target / e_total;
+        }
+        if (metric > best_metric) { best_metric = metric; best = s; }
+    }
+    return best * sym_period;
+}
+
 void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s) {
     const auto& t = c->tab;
     if (t.estimator != MGPU_EST_ZF || !d_payload || !d_stats) return;
@@ -485,7 +507,6 @@ extern "C++" {
 namespace {
 // mfsk.cc:82-95, :120-126, :149-155; the universal ACK/BREAK patterns use M = 16, one stream centred in Nc = 50
 // (telecom_system.cc:3006), hop step 7, 8 tones sent twice.
-constexpr int kPreamble32[4] = {4, 20, 12, 28}, kPreamble16[4] = {2, 10, 6, 14};
 constexpr int kAckTones[8] = {4, 7, 5, 12, 13, 1, 9, 15}, kBreakTones[8] = {6, 14, 2, 3, 10, 8, 11, 15};
 constexpr int kAckM = 16, kAckNsymb = 16, kAckLen = 8, kAckHop = 7, kAckOffset = 17, kInterp = 4;
 
@@ -517,25 +538,7 @@ int mgpu_time_sync_mfsk(mgpu_ctx* c, const double* bb, int W, int size, int sear
         const int sym_period = t.Nofdm * kInterp, nslots = size / sym_period, np = t.preamble;
         need(bb && delay && W > 0 && nslots >= np, "bad argument");
         const std::vector<double> E = slot_energies(c, bb, W, size, nslots);
-        const int* tones = t.mfsk_M == 32 ? kPreamble32 : kPreamble16;
-        for (int w = 0; w < W; ++w) {                                  // ofdm.cc:2004-2058
-            double best_metric = -1;
-            int best = 0;
-            for (int s = search_start_symb > 0 ? search_start_symb : 0; s <= nslots - np; ++s) {
-                double metric = 0;
-                for (int p = 0; p < np; ++p) {
-                    if ((s + p) * sym_period + t.Ngi * kInterp + t.Nfft * kInterp > size) break;
-                    const double* e = &E[(size_t(w) * nslots + s + p) * t.Nc];
-                    double e_target = 0;
-                    for (int st = 0; st < t.mfsk_nstreams; ++st) e_target += e[t.mfsk_off[st] + tones[p % np]];
-                    double e_total = 0;
-                    for (int k = 0; k < t.Nc; ++k) e_total += e[k];
-                    if (e_total > 0) metric += e_target / e_total;
-                }
-                if (metric > best_metric) { best_metric = metric; best = s; }
-            }
-            delay[w] = best * sym_period;
-        }
+        for (int w = 0; w < W; ++w) delay[w] = mfsk_sync_from_energies(t, &E[size_t(w) * nslots * t.Nc], nslots, size, search_start_symb);
     });
 }
 

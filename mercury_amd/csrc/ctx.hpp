@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/mercury_gpu.h"
+#include "../../include/mercury_rxloop.h"
 #include "device_tables.h"
 #include "tables.hpp"
 
@@ -34,7 +35,7 @@ extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, co
 extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double, double*);
 extern "C" __global__ void mgpu_span_energy_kernel(const double*, int, const int*, const int*, int, int, double*, int*);
-extern "C" __global__ void mgpu_decimate_kernel(const double*, int, const int*, const int*, int, int, double*);
+extern "C" __global__ void mgpu_decimate_kernel(const double*, int, const int*, const int*, const int*, int, int, double*);
 #define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
@@ -122,6 +123,9 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
 // the reference's peak selection (ofdm.cc:1943-1964): overwrite-not-swap partial sort over an array of `size` entries that
 // holds the metric of candidate k at index k*step and 0 elsewhere; returns the index (delay) and value of entry
 // `location_to_return` after nTrials_max passes
+// the scalar half of cl_ofdm::time_sync_mfsk (ofdm.cc:2004-2060) on the slot energies of one window ([nslots][Nc])
+int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb);
+
 void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr);
 
 inline int guard(mgpu_ctx* c, const std::function<void()>& fn) {

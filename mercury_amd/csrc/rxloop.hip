@@ -1,0 +1,406 @@
+// cl_telecom_system::receive_byte as a whole (telecom_system.cc:646-1503), batched over W independent capture
+// windows: passband samples in, payload + receive_stats out. The DSP runs in the library's kernels
+// (passband_to_baseband, Schmidl-Cox / MFSK time sync, energy gates, decimation, Moose, the RX hot path); the
+// control flow — bounds / energy / metric gates, silence-skip and SKIP-H recoveries, the multi-trial retry loop with
+// its k-th-best-peak and last-good fallbacks — is host logic that advances all windows of the batch in lock-step
+// rounds, each round one batched kernel call per DSP step over the windows that still need it.
+//
+// Parity: every block is checked against the oracle / the compiled reference on its own; the orchestration is
+// checked against oracle/mercury_oracle.c:morc_receive_byte, whose own parity with telecom_system.cc is UNPINNED
+// (that file cannot be built in this image) — see DESIGN.md. Not built: the GUI-only coarse frequency search of
+// trial 1 (telecom_system.cc:949-1012, off by default), mfsk_fixed_delay, signal_stregth_dbm.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "ctx.hpp"
+
+namespace {
+
+constexpr int kInterp = 4, kCoarseStep = 100;
+constexpr double kEnergyGate = 0.001, kMetricGate = 0.5, kMeanHGate = 0.3, kFreqIgnore = 0.1;   // telecom_system.cc:843, :854, :1269; physical_config.cc:60
+
+struct Win {                       // one capture window's walk through receive_byte
+    int delay = 0, pream = 1, sync_trials = 0, skip_h = 0;
+    double metric = 0.0, freq = 0.0;
+    bool in_loop = false, recovery_attempted = false, decoded = false;
+    bool use_last_delay = false, use_last_freq = false;   // decided per trial
+};
+
+struct Loop {
+    mgpu_ctx* c;
+    const mgpu::ModeTables& t;
+    int W, buf, sym, pre, frame_i, frame_n, lower, upper, ngi_i, nfft_i, L;
+    bool mfsk;
+    hipStream_t s;
+    mgpu_receive_config rc;
+    DevBuf d_pass, d_bbi, d_frames, d_carrier, d_ia, d_ib, d_ic, d_vals, d_sum, d_cnt, d_freq, d_meanh;
+    std::vector<double> carrier;   // per window, as currently applied (carrier + fine offset of the running trial)
+
+    Loop(mgpu_ctx* ctx, int W_, const mgpu_receive_config& rc_, int buffer_nsymb)
+        : c(ctx), t(ctx->tab), W(W_), buf(t.Nofdm * buffer_nsymb * kInterp), sym(t.Nofdm * kInterp), pre(t.preamble),
+          frame_i(t.Nofdm * (t.Nsymb + t.preamble) * kInterp), frame_n(t.Nofdm * (t.Nsymb + t.preamble)), lower(t.preamble),
+          upper(buffer_nsymb - (t.Nsymb + t.preamble)), ngi_i(t.Ngi * kInterp), nfft_i(t.Nfft * kInterp), L(t.preamble * t.Nofdm * kInterp),
+          mfsk(t.mfsk_M > 0), s(ctx->stream), rc(rc_),
+          d_pass(size_t(W_) * buf * 8), d_bbi(size_t(W_) * buf * 16), d_frames(size_t(W_) * frame_n * 16), d_carrier(size_t(W_) * 8),
+          d_ia(size_t(W_) * 128 * 4), d_ib(size_t(W_) * 128 * 4), d_ic(size_t(W_) * 4), d_vals(size_t(W_) * size_t(buf) * 8),
+          d_sum(size_t(W_) * 128 * 8), d_cnt(size_t(W_) * 128 * 4), d_freq(size_t(W_) * 8), d_meanh(size_t(W_) * 8),
+          carrier(W_, rc_.carrier_hz) {}
+
+    bool in_bounds(int p) const { return p > lower && p < upper; }
+
+    void up(DevBuf& d, const void* h, size_t bytes) { HIPCK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, s)); }
+    void down(void* h, const DevBuf& d, size_t bytes) { HIPCK(hipMemcpyAsync(h, d.p, bytes, hipMemcpyDeviceToHost, s)); HIPCK(hipStreamSynchronize(s)); }
+
+    // passband_to_baseband of the whole buffer for the listed windows, overwriting their interpolated baseband
+    void p2b(const std::vector<int>& wins, int filter) {
+        if (wins.empty()) return;
+        up(d_ia, wins.data(), wins.size() * 4);
+        up(d_carrier, carrier.data(), size_t(W) * 8);
+        const auto& taps = filter ? t.fir_data : t.fir_time_sync;
+        const int ntaps = int(taps.size());
+        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((buf + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 + ntaps) * 16, s,
+                           d_pass.as<double>(), buf, d_carrier.as<double>(), nullptr, 0, buf, 1, c->d_fir[filter], ntaps, 48000.0,
+                           1.4142135623730951, d_bbi.as<double>(), d_ia.as<int>());
+        HIPCK(hipGetLastError());
+    }
+
+    // time_sync_preamble[_with_metric] on a sub-window [start, start + size) of each listed window
+    void tsync(const std::vector<int>& wins, const std::vector<int>& start, const std::vector<int>& size, int step,
+               const std::vector<int>& loc, int ntrials, std::vector<int>& delay, std::vector<double>& corr) {
+        const int n = int(wins.size());
+        delay.assign(n, 0);
+        corr.assign(n, 0.0);
+        if (!n) return;
+        std::vector<int> nc(n);
+        int ncmax = 1;
+        for (int k = 0; k < n; ++k) { nc[k] = size[k] > L ? (size[k] - L + step - 1) / step : 0; ncmax = std::max(ncmax, nc[k]); }
+        up(d_ia, wins.data(), size_t(n) * 4);
+        up(d_ib, start.data(), size_t(n) * 4);
+        up(d_ic, nc.data(), size_t(n) * 4);
+        if (ngi_i % 64 || (nfft_i / 2) % 64)
+            hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncmax + 63) / 64, n), dim3(64), 0, s, d_bbi.as<double>(), buf,
+                               d_ib.as<int>(), d_ia.as<int>(), d_ic.as<int>(), ncmax, step, pre, ngi_i, nfft_i, d_vals.as<double>());
+        else
+            hipLaunchKernelGGL(step <= 4 ? mgpu_tsync_metric_dense_kernel : mgpu_tsync_metric_kernel, dim3((ncmax + 255) / 256, n), dim3(256), 0, s,
+                               d_bbi.as<double>(), buf, d_ib.as<int>(), d_ia.as<int>(), d_ic.as<int>(), ncmax, step, pre, ngi_i, nfft_i,
+                               d_vals.as<double>());
+        HIPCK(hipGetLastError());
+        std::vector<double> vals(size_t(n) * ncmax);
+        down(vals.data(), d_vals, vals.size() * 8);
+        for (int k = 0; k < n; ++k) select_peak(&vals[size_t(k) * ncmax], nc[k], step, size[k], loc[k], ntrials, &delay[k], &corr[k]);
+    }
+
+    // sum and count of |x|^2 over [off, off + len) (clipped at the buffer end) for every (window, offset) pair
+    void energies(const std::vector<int>& wv, const std::vector<int>& off, std::vector<double>& sum, std::vector<int>& cnt) {
+        const int n = int(wv.size());
+        sum.assign(n, 0.0);
+        cnt.assign(n, 0);
+        for (int base = 0; base < n; base += W * 128) {              // the index buffers hold W * 128 entries
+            const int m = std::min(n - base, W * 128);
+            up(d_ia, wv.data() + base, size_t(m) * 4);
+            up(d_ib, off.data() + base, size_t(m) * 4);
+            hipLaunchKernelGGL(mgpu_span_energy_kernel, dim3((m + 63) / 64), dim3(64), 0, s, d_bbi.as<double>(), buf, d_ia.as<int>(), d_ib.as<int>(), m,
+                               sym, d_sum.as<double>(), d_cnt.as<int>());
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(sum.data() + base, d_sum.p, size_t(m) * 8, hipMemcpyDeviceToHost, s));
+            down(cnt.data() + base, d_cnt, size_t(m) * 4);
+        }
+    }
+    static double mean(double sum, int cnt) { return cnt > 0 ? sum / cnt : 0.0; }
+
+    // The "scan forward for signal energy, re-run Schmidl-Cox from there" recovery shared by the bounds check
+    // (telecom_system.cc:733-806), the silence skip (:862-925) and, with a fixed start and size, SKIP-H (:1436-1497)
+    void recover(std::vector<Win>& win, const std::vector<int>& wins, const std::vector<int>& scan_from, bool fixed_start, bool need_metric,
+                 std::vector<char>& ok) {
+        const int n = int(wins.size());
+        ok.assign(n, 0);
+        if (!n) return;
+        std::vector<int> search_start(n, -1);
+        if (fixed_start) {
+            for (int k = 0; k < n; ++k) if (scan_from[k] < upper) search_start[k] = scan_from[k] * sym;      // :1447-1456
+        } else {
+            std::vector<int> wv, off, first(n + 1, 0);
+            for (int k = 0; k < n; ++k) {
+                for (int q = scan_from[k]; q < upper; ++q) { wv.push_back(wins[k]); off.push_back(q * sym); }
+                first[k + 1] = int(wv.size());
+            }
+            std::vector<double> sum;
+            std::vector<int> cnt;
+            energies(wv, off, sum, cnt);
+            for (int k = 0; k < n; ++k)
+                for (int j = first[k]; j < first[k + 1]; ++j)
+                    if (mean(sum[j], cnt[j]) > kEnergyGate) { search_start[k] = off[j]; break; }
+        }
+        std::vector<int> sel, sw, ss, sz, loc;
+        for (int k = 0; k < n; ++k) {
+            if (search_start[k] < 0) continue;
+            int available = buf - search_start[k];
+            if (fixed_start) available = std::min(available, t.Nofdm * (2 * pre + t.Nsymb) * kInterp);
+            if (available <= pre * sym) continue;
+            sel.push_back(k); sw.push_back(wins[k]); ss.push_back(search_start[k]); sz.push_back(available); loc.push_back(0);
+        }
+        std::vector<int> d;
+        std::vector<double> corr;
+        tsync(sw, ss, sz, kCoarseStep, loc, 1, d, corr);
+        std::vector<int> off(sel.size());
+        for (size_t j = 0; j < sel.size(); ++j) { d[j] += ss[j]; off[j] = d[j]; }
+        std::vector<double> sum;
+        std::vector<int> cnt;
+        energies(sw, off, sum, cnt);
+        for (size_t j = 0; j < sel.size(); ++j) {
+            int rsym = d[j] / sym;
+            if (rsym < 1) rsym = 1;
+            if (mean(sum[j], cnt[j]) >= kEnergyGate && (!need_metric || corr[j] >= kMetricGate) && in_bounds(rsym)) {
+                Win& x = win[wins[sel[j]]];
+                x.delay = d[j]; x.metric = corr[j]; x.pream = rsym;
+                ok[sel[j]] = 1;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mgpu_receive_buffer_nsymb(mgpu_ctx* c) {
+    if (!c) return -1;
+    const auto& t = c->tab;                                      // data_container.cc:133-143
+    const double sym_time_ms = 1000.0 * t.Nofdm * kInterp / 48000.0;
+    const int turnaround_symb = int(std::ceil(1200.0 / sym_time_ms)) + 4;
+    const int frame_symb = t.preamble + t.Nsymb;
+    int min_buf = frame_symb * 2;
+    if (frame_symb + turnaround_symb > min_buf) min_buf = frame_symb + turnaround_symb;
+    if (min_buf < 32) min_buf = 32;
+    return min_buf;
+}
+
+int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mgpu_receive_config* rcp, mgpu_link_state* state,
+                            uint8_t* payload, mgpu_receive_stats* stats) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(passband && rcp && payload && stats && W > 0 && W <= c->max_batch, "bad argument (W must be 1..max_batch)");
+        need(rcp->time_sync_trials_max >= 0 && rcp->time_sync_trials_max < 64, "time_sync_trials_max out of range");
+        const auto& t = c->tab;
+        const int T = rcp->time_sync_trials_max;
+        Loop lp(c, W, *rcp, mgpu_receive_buffer_nsymb(c));
+        hipStream_t s = lp.s;
+        ensure_workspaces(c, WS_FRONTEND | WS_LLR | WS_OUT);
+        std::vector<Win> win(W);
+        std::vector<int> all(W);
+        for (int w = 0; w < W; ++w) all[w] = w;
+        // receive_stats as init() leaves it (telecom_system.cc:1968-1981) + the per-call resets (:653-655)
+        for (int w = 0; w < W; ++w) {
+            mgpu_receive_stats& r = stats[w];
+            r.iterations_done = -1; r.crc = 0; r.all_zeros = 0; r.message_decoded = 0; r.snr_db = -99.9;
+            r.delay = 0; r.sync_trials = 0; r.freq_offset = 0; r.coarse_metric = 0; r.frame_overflow_symbols = 0; r.mean_H = -1.0;
+        }
+        std::memset(payload, 0, size_t(W) * t.payload_stride);
+        HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyHostToDevice, s));
+
+        // ---- :676-696 coarse synchronisation on the FIR_rx_time_sync baseband ----
+        lp.p2b(all, 0);
+        std::vector<char> live(W, 1);                             // still on the way to the trial loop
+        if (lp.mfsk) {
+            const int nslots = lp.buf / lp.sym;
+            DevBuf d_e(size_t(W) * nslots * t.Nc * 8);
+            HIPCK(hipMemsetAsync(d_e.p, 0, size_t(W) * nslots * t.Nc * 8, s));
+            hipLaunchKernelGGL(mgpu_slot_energy_kernel, dim3((nslots + 3) / 4, W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, nslots, kInterp,
+                               c->dev.twiddle, d_e.as<double>());
+            HIPCK(hipGetLastError());
+            std::vector<double> E(size_t(W) * nslots * t.Nc);
+            lp.down(E.data(), d_e, E.size() * 8);
+            for (int w = 0; w < W; ++w)
+                win[w].delay = mfsk_sync_from_energies(t, &E[size_t(w) * nslots * t.Nc], nslots, lp.buf, state ? state[w].mfsk_search_start : 0);
+        } else {
+            std::vector<int> zero(W, 0), full(W, lp.buf), d;
+            std::vector<double> corr;
+            lp.tsync(all, zero, full, kCoarseStep, zero, 1, d, corr);
+            for (int w = 0; w < W; ++w) { win[w].delay = d[w]; win[w].metric = corr[w]; }
+        }
+        for (int w = 0; w < W; ++w) { win[w].pream = std::max(1, win[w].delay / lp.sym); }
+        // ---- :702-718 MFSK frame completeness ----
+        if (lp.mfsk)
+            for (int w = 0; w < W; ++w) {
+                const int frame_end = win[w].delay + (lp.pre + t.active_nsymb) * lp.sym;
+                if (frame_end > lp.buf) { stats[w].frame_overflow_symbols = (frame_end - lp.buf + lp.sym - 1) / lp.sym; live[w] = 0; }
+            }
+        if (!lp.mfsk) {
+            // ---- :733-806 preamble outside the valid bounds: scan the buffer for signal, search again from there ----
+            std::vector<int> wins, from;
+            for (int w = 0; w < W; ++w) if (!lp.in_bounds(win[w].pream)) { wins.push_back(w); from.push_back(lp.lower + 1); }
+            std::vector<char> ok;
+            lp.recover(win, wins, from, false, true, ok);
+        }
+        for (int w = 0; w < W; ++w) if (live[w] && !lp.in_bounds(win[w].pream)) live[w] = 0;
+        if (!lp.mfsk) {
+            // ---- :808-928 energy / metric gates and the silence-skip recovery ----
+            std::vector<int> wv, off;
+            for (int w = 0; w < W; ++w) if (live[w]) { wv.push_back(w); off.push_back(win[w].delay); }
+            std::vector<double> sum;
+            std::vector<int> cnt;
+            lp.energies(wv, off, sum, cnt);
+            std::vector<int> wins, from;
+            for (size_t j = 0; j < wv.size(); ++j) {
+                bool energy_ok = !(Loop::mean(sum[j], cnt[j]) < kEnergyGate);
+                if (energy_ok && win[wv[j]].metric < kMetricGate) energy_ok = false;
+                if (!energy_ok) { wins.push_back(wv[j]); from.push_back(win[wv[j]].pream + 1); }
+            }
+            std::vector<char> ok;
+            lp.recover(win, wins, from, false, true, ok);
+            for (size_t j = 0; j < wins.size(); ++j) if (!ok[j]) live[wins[j]] = 0;
+        }
+        for (int w = 0; w < W; ++w) { win[w].in_loop = live[w] != 0; }
+
+        // ---- :931-1431 the trial loop, one round per trial over the windows still in it ----
+        DevBuf d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * t.payload_stride);
+        std::vector<MgpuStatsDev> st_k(W);
+        std::vector<uint8_t> pay_k(size_t(W) * t.payload_stride);
+        for (;;) {
+            std::vector<int> act;
+            for (int w = 0; w < W; ++w) {
+                Win& x = win[w];
+                if (!x.in_loop) continue;
+                if (x.sync_trials > T || (lp.mfsk && x.sync_trials > 0)) { x.in_loop = false; continue; }   // :931, :939-944
+                act.push_back(w);
+            }
+            if (act.empty()) {
+                // ---- :1436-1497 SKIP-H recovery: every trial died on a low channel estimate -> look for a later preamble ----
+                std::vector<int> wins, from;
+                for (int w = 0; w < W; ++w) {
+                    Win& x = win[w];
+                    if (!lp.mfsk && live[w] && !x.decoded && x.skip_h >= T + 1 && !x.recovery_attempted) {
+                        x.recovery_attempted = true;
+                        wins.push_back(w); from.push_back(x.pream + 2);
+                    }
+                }
+                if (wins.empty()) break;
+                std::vector<int> searchable;
+                for (size_t j = 0; j < wins.size(); ++j) {
+                    const int start = from[j] * lp.sym;
+                    const int available = std::min(lp.buf - start, t.Nofdm * (2 * lp.pre + t.Nsymb) * kInterp);
+                    if (from[j] < lp.upper && available > lp.pre * lp.sym) { searchable.push_back(wins[j]); lp.carrier[wins[j]] = rcp->carrier_hz; }
+                }
+                lp.p2b(searchable, 0);                                // fresh FIR_rx_time_sync baseband for the search (:1458-1463)
+                std::vector<char> ok;
+                lp.recover(win, wins, from, true, false, ok);
+                bool any = false;
+                for (size_t j = 0; j < wins.size(); ++j)
+                    if (ok[j]) { Win& x = win[wins[j]]; x.sync_trials = 0; x.skip_h = 0; x.in_loop = true; any = true; }
+                if (!any) break;
+                continue;
+            }
+            const int n = int(act.size());
+            // -- delay for this trial: last good one on the final trial (:945-948), else the k-th best fine-search peak (:1014-1018)
+            std::vector<int> fw, fstart, fsize, floc;
+            for (int w : act) {
+                Win& x = win[w];
+                x.use_last_delay = !lp.mfsk && x.sync_trials == T && rcp->use_last_good_time_sync && state && state[w].delay_of_last_decoded_message != -1;
+                if (lp.mfsk) continue;
+                if (x.use_last_delay) { x.delay = state[w].delay_of_last_decoded_message; continue; }
+                fw.push_back(w); fstart.push_back((x.pream - 1) * lp.sym); fsize.push_back((lp.pre + 4) * lp.sym); floc.push_back(x.sync_trials);
+            }
+            {
+                std::vector<int> d;
+                std::vector<double> corr;
+                lp.tsync(fw, fstart, fsize, 1, floc, T, d, corr);
+                for (size_t j = 0; j < fw.size(); ++j) win[fw[j]].delay = fstart[j] + d[j];
+            }
+            for (int w : act) {                                      // :1020-1031
+                Win& x = win[w];
+                if (x.delay < 0) x.delay = 0;
+                if (x.delay > lp.buf - lp.frame_i) x.delay = lp.buf - lp.frame_i;
+            }
+            if (!lp.mfsk) {                                          // :1039-1071 post-fine-sync energy fix
+                std::vector<int> wv, off;
+                for (int w : act) for (int q = 0; q <= 3; ++q) { wv.push_back(w); off.push_back(std::min(win[w].delay + q * lp.sym, lp.buf)); }
+                std::vector<double> sum;
+                std::vector<int> cnt;
+                lp.energies(wv, off, sum, cnt);
+                for (int k = 0; k < n; ++k) {
+                    Win& x = win[act[k]];
+                    if (sum[size_t(k) * 4] / lp.sym < kEnergyGate) {
+                        const int orig = x.delay;
+                        for (int q = 1; q <= 3; ++q) {
+                            const int cand = orig + q * lp.sym;
+                            if (cand + lp.sym > lp.buf) break;
+                            if (sum[size_t(k) * 4 + q] / lp.sym >= kEnergyGate) { x.delay = cand; break; }
+                        }
+                    }
+                }
+            }
+            // -- :1083-1105 FIR_rx_data baseband at the (coarse-corrected) carrier, frame cut out at `delay`, decimated
+            for (int w : act) lp.carrier[w] = rcp->carrier_hz;
+            lp.p2b(act, 1);
+            auto extract = [&](const std::vector<int>& wins, const int* slot) {   // rational_resampler DECIMATION at `delay`
+                if (wins.empty()) return;
+                std::vector<int> dl(wins.size());
+                for (size_t j = 0; j < wins.size(); ++j) dl[j] = win[wins[j]].delay;
+                lp.up(lp.d_ia, wins.data(), wins.size() * 4);
+                lp.up(lp.d_ib, dl.data(), wins.size() * 4);
+                if (slot) lp.up(lp.d_ic, slot, wins.size() * 4);
+                hipLaunchKernelGGL(mgpu_decimate_kernel, dim3((lp.frame_n + 255) / 256, unsigned(wins.size())), dim3(256), 0, s, lp.d_bbi.as<double>(),
+                                   lp.buf, lp.d_ia.as<int>(), lp.d_ib.as<int>(), slot ? lp.d_ic.as<int>() : nullptr, kInterp, lp.frame_n,
+                                   lp.d_frames.as<double>());
+                HIPCK(hipGetLastError());
+            };
+            extract(act, nullptr);
+            // -- :1108-1131 fine frequency offset (Moose) or the last good one on the final trial; re-mix if it matters
+            std::vector<double> f(n, 0.0);
+            {
+                const int pre_half = lp.pre / 2 == 0 ? 1 : lp.pre / 2;
+                hipLaunchKernelGGL(mgpu_fsync_kernel, dim3(n), dim3(256), 0, s, lp.d_frames.as<double>() + size_t(t.Ngi) * 2, lp.frame_n, pre_half,
+                                   c->dev.twiddle, (48000.0 * 50.0 / 256 / 4) / double(t.Nc), lp.d_freq.as<double>());
+                HIPCK(hipGetLastError());
+                lp.down(f.data(), lp.d_freq, size_t(n) * 8);
+            }
+            std::vector<int> rw, rslot;
+            for (int k = 0; k < n; ++k) {
+                Win& x = win[act[k]];
+                if (x.sync_trials == T && rcp->use_last_good_freq_offset && state && state[act[k]].freq_offset_of_last_decoded_message != 0)
+                    f[k] = state[act[k]].freq_offset_of_last_decoded_message;
+                x.freq = f[k];
+                if (!lp.mfsk && std::fabs(f[k]) > kFreqIgnore) { lp.carrier[act[k]] = rcp->carrier_hz + f[k]; rw.push_back(act[k]); rslot.push_back(k); }
+            }
+            lp.p2b(rw, 1);
+            extract(rw, rslot.data());
+            // -- :1132-1345 the hot path on the data symbols (they start `preamble` symbols into each extracted frame)
+            MgpuTapsDev taps{};
+            if (!lp.mfsk) taps.mean_H = lp.d_meanh.as<double>();
+            launch_frontend(c, lp.d_frames.as<double>() + size_t(lp.pre) * t.Nofdm * 2, n, c->d_llr, c->d_variance, c->d_snrvar, taps, s, lp.frame_n);
+            launch_decoder(c, c->d_llr, n, nullptr, nullptr, d_payload_k.as<uint8_t>(), d_stats_k.as<MgpuStatsDev>(), c->d_variance, c->d_snrvar, s);
+            launch_zf_snr(c, n, d_payload_k.as<uint8_t>(), d_stats_k.as<MgpuStatsDev>(), s);
+            std::vector<double> mh(n, 1.0);
+            if (!lp.mfsk) HIPCK(hipMemcpyAsync(mh.data(), lp.d_meanh.p, size_t(n) * 8, hipMemcpyDeviceToHost, s));
+            HIPCK(hipMemcpyAsync(st_k.data(), d_stats_k.p, size_t(n) * sizeof(MgpuStatsDev), hipMemcpyDeviceToHost, s));
+            lp.down(pay_k.data(), d_payload_k, size_t(n) * t.payload_stride);
+            for (int k = 0; k < n; ++k) {
+                const int w = act[k];
+                Win& x = win[w];
+                mgpu_receive_stats& r = stats[w];
+                r.delay = x.delay;
+                if (!lp.mfsk) {
+                    r.mean_H = mh[k];
+                    if (mh[k] < kMeanHGate) { ++x.skip_h; ++x.sync_trials; r.sync_trials = x.sync_trials; continue; }   // :1269-1280: no decode this trial
+                }
+                const MgpuStatsDev& d = st_k[k];
+                r.iterations_done = d.iterations_done; r.crc = d.crc; r.all_zeros = d.all_zeros;
+                std::memcpy(payload + size_t(w) * t.payload_stride, &pay_k[size_t(k) * t.payload_stride], t.payload_stride);
+                if (!d.message_decoded) {                            // :1343-1360
+                    r.snr_db = -99.9; r.message_decoded = 0;
+                    ++x.sync_trials;
+                } else {                                             // :1361-1430
+                    r.snr_db = double(d.snr_db); r.message_decoded = 1;
+                    x.decoded = true; x.in_loop = false;
+                    if (!lp.mfsk) { r.freq_offset = x.freq; if (state) state[w].freq_offset_of_last_decoded_message = x.freq; }
+                    if (state) state[w].delay_of_last_decoded_message = x.delay;
+                }
+                r.sync_trials = x.sync_trials;
+            }
+        }
+        for (int w = 0; w < W; ++w) { stats[w].delay = win[w].delay; stats[w].coarse_metric = win[w].metric; stats[w].sync_trials = win[w].sync_trials; }
+    });
+}
+
+}  // extern "C"

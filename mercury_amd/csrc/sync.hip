@@ -339,12 +339,13 @@ extern "C" __global__ __launch_bounds__(64) void mgpu_span_energy_kernel(
     cnt[j] = c;
 }
 
-// rational_resampler(..., DECIMATION) (ofdm.cc:2267-2278) from a per-window offset: out[k][i] = bb[widx[k]][delay[k] + i*rate]
+// rational_resampler(..., DECIMATION) (ofdm.cc:2267-2278) from a per-window offset:
+// out[slot[k] or k][i] = bb[widx[k]][delay[k] + i*rate]
 extern "C" __global__ __launch_bounds__(256) void mgpu_decimate_kernel(
-    const double* __restrict__ bb, int stride, const int* __restrict__ widx, const int* __restrict__ delay, int rate, int count,
-    double* __restrict__ out) {
+    const double* __restrict__ bb, int stride, const int* __restrict__ widx, const int* __restrict__ delay, const int* __restrict__ slot,
+    int rate, int count, double* __restrict__ out) {
     const int k = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     const c2* x = reinterpret_cast<const c2*>(bb) + size_t(widx[k]) * stride + delay[k];
-    reinterpret_cast<c2*>(out)[size_t(k) * count + i] = x[size_t(i) * rate];
+    reinterpret_cast<c2*>(out)[size_t(slot ? slot[k] : k) * count + i] = x[size_t(i) * rate];
 }

@@ -41,6 +41,17 @@ class Taps(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in "grid H eq syms llr_demod llr_ldpc variance agc_gain cycles".split()]
 
 
+class ReceiveConfig(C.Structure):
+    _fields_ = [("carrier_hz", C.c_double), ("time_sync_trials_max", C.c_int), ("use_last_good_time_sync", C.c_int),
+                ("use_last_good_freq_offset", C.c_int)]
+
+
+LINK_STATE_DTYPE = np.dtype([("delay_of_last_decoded_message", "<i4"), ("freq_offset_of_last_decoded_message", "<f8"),
+                             ("mfsk_search_start", "<i4")], align=True)
+RECEIVE_STATS_DTYPE = np.dtype([("iterations_done", "<i4"), ("crc", "<i4"), ("all_zeros", "<i4"), ("message_decoded", "<i4"),
+                                ("snr_db", "<f8"), ("delay", "<i4"), ("sync_trials", "<i4"), ("freq_offset", "<f8"),
+                                ("coarse_metric", "<f8"), ("frame_overflow_symbols", "<i4"), ("mean_H", "<f8")], align=True)
+
 STATS_DTYPE = np.dtype([("iterations_done", "<i4"), ("crc", "<i4"), ("all_zeros", "<i4"),
                         ("message_decoded", "<i4"), ("variance", "<f4"), ("snr_db", "<f4")])
 
@@ -82,6 +93,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern",
+    "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch",
     "mgpu_shm_create", "mgpu_shm_connect", "mgpu_shm_close", "mgpu_shm_destroy", "mgpu_shm_used", "mgpu_shm_free", "mgpu_shm_capacity",
     "mgpu_shm_clear", "mgpu_shm_write", "mgpu_shm_read", "mgpu_shm_read_all", "mgpu_shm_publish_decoded",
 ]
@@ -230,6 +242,26 @@ class RxPhy:
         matched = np.zeros(W, np.int32)
         self._ck(self.lib.mgpu_detect_ack_pattern(self.h, _ptr(z), C.c_int(W), C.c_int(size), C.c_int(pattern), _ptr(metric), _ptr(matched)))
         return metric, matched
+
+    # ---- the whole of receive_byte on capture windows (include/mercury_rxloop.h) -------------
+    def receive_buffer_samples(self):
+        return int(self.lib.mgpu_receive_buffer_nsymb(self.h)) * self.Nofdm * 4
+
+    def receive_byte(self, passband, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1, state=None):
+        """passband: float64 [W, buffer samples]. Returns dict(payload [W, stride], stats [W] (RECEIVE_STATS_DTYPE), state)."""
+        x = np.ascontiguousarray(passband, np.float64)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        W, n = x.shape
+        if n != self.receive_buffer_samples():
+            raise MgpuError("a capture window is %d samples" % self.receive_buffer_samples())
+        cfg = ReceiveConfig(carrier_hz, trials_max, use_last_good_time_sync, use_last_good_freq_offset)
+        st = np.zeros(W, LINK_STATE_DTYPE) if state is None else np.ascontiguousarray(state, LINK_STATE_DTYPE)
+        if state is None:
+            st["delay_of_last_decoded_message"] = -1
+        payload = np.zeros((W, self.payload_stride), np.uint8)
+        stats = np.zeros(W, RECEIVE_STATS_DTYPE)
+        self._ck(self.lib.mgpu_receive_byte_batch(self.h, _ptr(x), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
+        return {"payload": payload, "stats": stats, "state": st}
 
     def last_sync_kernel_ms(self):
         ms = C.c_float(0)
