@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "mercury_gpu.h"
+#include "mercury_rxloop.h"
 
 namespace mgpu {
 
@@ -37,6 +38,14 @@ struct st_receive_stats {
     int crc = 0;
     int all_zeros = NO;
     float variance = 0;
+    // synchroniser side (set by cl_rx_phy::receive_byte only), telecom_system.h:63-82
+    int delay = 0;
+    int delay_of_last_decoded_message = -1;
+    int sync_trials = 0;
+    double freq_offset = 0;
+    double freq_offset_of_last_decoded_message = 0;
+    double coarse_metric = 0;
+    int frame_overflow_symbols = 0;
 };
 
 namespace detail {
@@ -118,7 +127,7 @@ public:
     // telecom_system.cc:2487 — re-initialises everything the mode owns; a no-op for the current mode
     void load_configuration(int configuration) {
         if (configuration == current_configuration && ctx_) return;
-        if (configuration < 0 || configuration > 16) return;    // the reference returns silently too (:2494-2497)
+        if (!((configuration >= 0 && configuration <= 16) || (configuration >= 100 && configuration <= 102))) return;   // the reference returns silently too (:2494-2497)
         if (ctx_) mgpu_destroy(ctx_);
         ctx_ = nullptr;
         mgpu_config c{};
@@ -130,6 +139,37 @@ public:
     }
     int get_frame_size_bytes() const { return info.payload_bytes; }          // telecom_system.cc:332-335
     int get_frame_size_bits() const { return info.payload_bytes * 8; }
+
+    // synchroniser parameters, cl_configuration_telecom_system defaults (physical_config.cc:84-87)
+    double carrier_frequency = 48000.0 * 50.0 / 256 / 4 / 2 + 300;
+    int time_sync_trials_max = 2;
+    int use_last_good_time_sync = YES;
+    int use_last_good_freq_offset = YES;
+
+    // Samples of one capture window: Nofdm * buffer_Nsymb * frequency_interpolation_rate (data_container.cc:133-143)
+    int capture_window_samples() const { return mgpu_receive_buffer_nsymb(ctx_) * info.Nofdm * 4; }
+
+    // st_receive_stats cl_telecom_system::receive_byte(double* data, int* out) — telecom_system.h:142, .cc:646-1503:
+    // one passband capture window in, get_frame_size_bytes() ints out, statistics returned and kept in
+    // receive_stats; the last good delay / frequency offset carry over to the next call as in the reference.
+    st_receive_stats receive_byte(const double* data, int* out) {
+        mgpu_receive_config rc{carrier_frequency, time_sync_trials_max, use_last_good_time_sync, use_last_good_freq_offset};
+        mgpu_link_state ls{receive_stats.delay_of_last_decoded_message, receive_stats.freq_offset_of_last_decoded_message, 0};
+        mgpu_receive_stats r{};
+        std::vector<uint8_t> bytes(info.payload_stride);
+        detail::check(mgpu_receive_byte_batch(ctx_, data, 1, &rc, &ls, bytes.data(), &r), ctx_, "receive_byte");
+        for (int i = 0; i < info.payload_bytes; ++i) out[i] = bytes[i];
+        if (r.iterations_done != -1 || r.message_decoded) {       // a decode was attempted: these members were written
+            receive_stats.iterations_done = r.iterations_done; receive_stats.crc = r.crc; receive_stats.all_zeros = r.all_zeros;
+        }
+        receive_stats.message_decoded = r.message_decoded; receive_stats.SNR = r.snr_db;
+        receive_stats.delay = r.delay; receive_stats.sync_trials = r.sync_trials; receive_stats.coarse_metric = r.coarse_metric;
+        receive_stats.frame_overflow_symbols = r.frame_overflow_symbols;
+        if (r.message_decoded) receive_stats.freq_offset = r.freq_offset;
+        receive_stats.delay_of_last_decoded_message = ls.delay_of_last_decoded_message;
+        receive_stats.freq_offset_of_last_decoded_message = ls.freq_offset_of_last_decoded_message;
+        return receive_stats;
+    }
 
     // One synchronised frame: `baseband` points at the first data symbol, i.e. what receive_byte passes to
     // symbol_demod (&baseband_data[Nofdm*preamble_nSymb], telecom_system.cc:1137). `out` receives

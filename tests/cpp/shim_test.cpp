@@ -1,10 +1,11 @@
 // Host-language (C++) test of the drop-in boundary: drives include/mercury_gpu.hpp the way
 // telecom_system.cc drives the reference classes, on inputs written by tests/test_cpp_shim.py, and
 // writes the results back for comparison with the CPU oracle.
-//   usage: shim_test <cfg> <nframes> <baseband.bin> <llr.bin> <out.bin>
+//   usage: shim_test <cfg> <nframes> <baseband.bin> <llr.bin> <out.bin> [<passband_windows.bin> <nwindows>]
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "mercury_gpu.hpp"
@@ -19,7 +20,7 @@ static std::vector<T> slurp(const char* path, size_t n) {
 }
 
 int main(int argc, char** argv) {
-    if (argc != 6) return 2;
+    if (argc != 6 && argc != 8) return 2;
     const int cfg = atoi(argv[1]), F = atoi(argv[2]);
     try {
         mgpu::cl_rx_phy phy;
@@ -59,7 +60,22 @@ int main(int argc, char** argv) {
             fwrite(bits.data(), sizeof(int), ldpc.K, out);
         }
         fclose(out);
-        // 4) error behaviour: a wrong code rate throws instead of exit(1)
+        // 4) the whole receive_byte on passband capture windows, one call per window like RX_SHM_process_main
+        //    (optional 7th argument: file of W windows; results appended to <out>.rb)
+        if (argc >= 8) {
+            const int W = atoi(argv[7]), n = phy.capture_window_samples();
+            auto pass = slurp<double>(argv[6], size_t(W) * n);
+            FILE* rb = fopen((std::string(argv[5]) + ".rb").c_str(), "wb");
+            for (int w = 0; w < W; ++w) {
+                std::vector<int> bytes(pb);
+                mgpu::st_receive_stats st = phy.receive_byte(&pass[size_t(w) * n], bytes.data());
+                int rec[6] = {st.iterations_done, st.crc, st.message_decoded, st.delay, st.sync_trials, st.delay_of_last_decoded_message};
+                fwrite(rec, sizeof(int), 6, rb);
+                fwrite(bytes.data(), sizeof(int), pb, rb);
+            }
+            fclose(rb);
+        }
+        // 5) error behaviour: a wrong code rate throws instead of exit(1)
         mgpu::cl_ldpc bad;
         bad.rate = 7.0f / 16.0f;
         try { bad.init(); return 3; } catch (const std::runtime_error&) {}

@@ -69,3 +69,31 @@ def test_cpp_shim_matches_oracle(tmp_path, cfg):
             bits = take(K, np.int32)
             rb, ri = orc.ldpc_decode(llr[f])
             assert it == ri and np.array_equal(bits, rb)
+
+
+@pytest.mark.gpu
+def test_cpp_receive_byte_keeps_link_state_across_calls(tmp_path):
+    """mgpu::cl_rx_phy::receive_byte(double* data, int* out), called once per capture window like RX_SHM_process_main
+    does: the last good delay / frequency offset carry over between calls (members of receive_stats, as in the
+    reference), which the oracle reproduces when handed the same state."""
+    from test_receive_byte import make_windows
+    cfg = 8
+    exe = _build(tmp_path)
+    orc = oraclelib.Oracle(cfg, 50)
+    true_delay = 9 * 1088 + 100
+    wins = np.concatenate([make_windows(orc, [("frame", true_delay, noise, 2)], seed=5)[0] for noise in (0.01, 0.1, 0.15)])
+    bb = np.zeros((1, orc.frame_samples), np.complex128)
+    (tmp_path / "bb.bin").write_bytes(bb.tobytes())
+    (tmp_path / "llr.bin").write_bytes(np.zeros((1, 1600), np.float32).tobytes())
+    (tmp_path / "pass.bin").write_bytes(wins.tobytes())
+    r = subprocess.run([str(exe), str(cfg), "1", str(tmp_path / "bb.bin"), str(tmp_path / "llr.bin"), str(tmp_path / "out.bin"),
+                        str(tmp_path / "pass.bin"), "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(str(tmp_path / "out.bin") + ".rb", np.int32).reshape(3, 6 + orc.payload_bytes)
+    state = oraclelib.LinkState(-1, 0.0, 0)
+    for w in range(3):
+        ref = orc.receive_byte(wins[w], state=state)      # state is updated in place, like the reference's members
+        assert list(raw[w][:5]) == [ref["iterations_done"], ref["crc"], ref["message_decoded"], ref["delay"], ref["sync_trials"]], w
+        assert raw[w][5] == state.delay_of_last_decoded_message
+        assert np.array_equal(raw[w][6:], ref["payload"])
+    assert list(raw[:, 2]) == [1, 1, 1]                    # the noisy windows decode thanks to the first one's sync state

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Whole-chain rate of the batched receive_byte (passband capture windows -> payloads) next to the CPU oracle's
+restatement on the same windows. Host buffers in, host buffers out: PCIe copies and the host-side control flow are
+inside the timed region. Usage: python tools/bench_receive_byte.py [cfg] [W]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oraclelib  # noqa: E402  (CPU twin, timed beside the GPU as the baseline)
+from mercury_amd import RxPhy  # noqa: E402
+
+
+def main():
+    cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    W = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    orc = oraclelib.Oracle(cfg)
+    n = orc.buffer_samples()
+    rng = np.random.default_rng(1)
+    wins = rng.standard_normal((W, n)) * 0.01
+    payloads = []
+    nframe = None
+    for w in range(W):
+        pl = rng.integers(0, 256, orc.payload_bytes)
+        pb = orc.tx_passband(orc.payload_to_bits(pl))
+        nframe = pb.size
+        d = int(rng.integers(5 * 1088, n - pb.size - 5 * 1088))
+        wins[w, d: d + pb.size] += pb
+        payloads.append(pl)
+    rx = RxPhy(cfg, max_batch=W)
+    rx.receive_byte(wins[:8], oraclelib.CARRIER)          # warm-up (allocations, kernel load)
+    t0 = time.perf_counter()
+    out = rx.receive_byte(wins, oraclelib.CARRIER)
+    dt = time.perf_counter() - t0
+    ok = int(out["stats"]["message_decoded"].sum())
+    good = sum(int(np.array_equal(out["payload"][w][: orc.payload_bytes], payloads[w])) for w in range(W))
+    ncpu = min(W, 24)
+    t0 = time.perf_counter()
+    same = 0
+    for w in range(ncpu):
+        r = orc.receive_byte(wins[w])
+        same += int(r["message_decoded"] == out["stats"]["message_decoded"][w] and r["delay"] == out["stats"]["delay"][w])
+    dc = time.perf_counter() - t0
+    print(json.dumps({"cfg": cfg, "windows": W, "window_samples": n, "frame_samples_passband": nframe, "gpu_windows_per_s": W / dt,
+                      "gpu_ms_per_batch": dt * 1e3, "decoded": ok, "payload_correct": good, "avg_trials": float(out["stats"]["sync_trials"].mean()),
+                      "cpu_oracle_windows_per_s_1core": ncpu / dc, "cpu_sample": ncpu, "cpu_gpu_same_decision": same}))
+
+
+if __name__ == "__main__":
+    main()
