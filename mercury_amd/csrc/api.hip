@@ -189,17 +189,26 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
 // zero-forcing modes: SNR from the re-encoded decision (telecom_system.cc:1374-1396); needs the payload and
 // the de-framed equalised symbols the front-end kept.
 void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr) {
+    // The reference fills vals[k*step] = metric of candidate k, leaves every other entry 0, and for j = 0..nTrials_max-1
+    // sets loc[j] = j and scans i = j+1..size-1 replacing (vals[j], loc[j]) by any strictly larger vals[i] — nothing is
+    // swapped out, so later passes see the same maximum again. Emulated without the size-long arrays: a pass only
+    // meets candidates and zeros, and a zero matters only the first time it is met while the running value is negative.
     if (location_to_return >= nTrials_max) location_to_return = nTrials_max - 1;
-    std::vector<double> vals(size, 0.0);
-    std::vector<int> loc(size, -1);
-    for (int k = 0; k < ncand; ++k) { vals[size_t(k) * step] = cand_vals[k]; loc[size_t(k) * step] = k * step; }
-    for (int j = 0; j < nTrials_max; ++j) {
-        loc[j] = j;
-        for (int i = j + 1; i < size; ++i)
-            if (vals[i] > vals[j]) { vals[j] = vals[i]; loc[j] = i; }
+    const int j = location_to_return;
+    auto original = [&](int i) { return (i % step == 0 && i / step < ncand) ? cand_vals[i / step] : 0.0; };
+    double cur = j < size ? original(j) : 0.0;
+    int loc = j;
+    int p = j + 1;                                   // next index the scan visits
+    for (int k = (j + step) / step; k < ncand; ++k) {               // candidates with index k*step > j
+        const int ci = k * step;
+        if (ci <= j) continue;
+        if (p < ci && cur < 0) { cur = 0.0; loc = p; }               // a non-candidate (zero) entry comes first
+        if (cand_vals[k] > cur) { cur = cand_vals[k]; loc = ci; }
+        p = ci + 1;
     }
-    *delay = loc[location_to_return];
-    *corr = vals[location_to_return];
+    if (p < size && cur < 0) { cur = 0.0; loc = p; }
+    *delay = loc;
+    *corr = cur;
 }
 
 int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb) {
