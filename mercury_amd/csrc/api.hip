@@ -90,7 +90,7 @@ void ctx_alloc(mgpu_ctx* c) {
     for (auto& e : c->sync_ev) HIPCK(hipEventCreate(&e));
 
     const bool mfsk = t.mfsk_M > 0;      // the MFSK front-end keeps no frame grid in LDS (csrc/mfsk.hip)
-    c->lds_fe = mfsk ? 0 : mgpu_frontend_lds_bytes(d.G);
+    c->lds_fe = mfsk ? 0 : mgpu_frontend_lds_bytes(d.G, d.nPilots, d.nBits);
     c->lds_tx = mgpu_txgen_lds_bytes(mfsk ? 0 : d.G);
     if (!mfsk) HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_frontend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_fe)));
     HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_txgen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_tx)));

@@ -16,7 +16,7 @@
 extern "C" const unsigned char mgpu_ldpc_blob[];
 extern "C" const unsigned long mgpu_ldpc_blob_size;
 
-extern "C" size_t mgpu_frontend_lds_bytes(int G);
+extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits);
 extern "C" size_t mgpu_spa_lds_bytes(int E, int N);
 extern "C" size_t mgpu_gbf_lds_bytes(int N);
 extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);

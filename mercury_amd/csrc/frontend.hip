@@ -81,26 +81,36 @@ __device__ __forceinline__ double serial_sum(const double* red, int n) {
 #define FE_THREADS 512
 #define FE_WAVES (FE_THREADS / 64)
 
-// LDS carve (bytes): grid 16G | B = max(16G, FE_WAVES*272*16) (FFT work area, later the channel/equalised grid)
-//                    | red/yp/llr 12800 (reduction terms, signed pilots, later the demapper LLRs) | tw 2048 | type G | scal 64
-extern "C" size_t mgpu_frontend_lds_bytes(int G) {
-    const size_t b = size_t(16) * G > size_t(FE_WAVES) * FFT256_STRIDE * 16 ? size_t(16) * G : size_t(FE_WAVES) * FFT256_STRIDE * 16;
-    return size_t(16) * G + b + 12800 + 2048 + ((G + 15) & ~15) + 64;
+// LDS carve (bytes): grid 16G | work = H 16G + red/yp/llr rsz (the two together are the FFT work area first, later the
+//                    channel / equalised grid and the reduction terms, signed pilots, demapper LLRs) | tw 2048 | type G | scal 64
+// rsz = max(16 nPilots, 4 nBits); the FFT runs on as many waves as work areas fit (4..8). Mode 8: 48 KB -> 3 workgroups/CU.
+struct FeCarve { int fft_waves; size_t rsz, work, total; };
+__host__ __device__ inline FeCarve fe_carve(int G, int nPilots, int nBits) {
+    FeCarve c;
+    c.rsz = size_t(16) * nPilots > size_t(4) * nBits ? size_t(16) * nPilots : size_t(4) * nBits;
+    c.rsz = (c.rsz + 15) & ~size_t(15);
+    const size_t per_wave = size_t(FFT256_STRIDE) * 16;
+    size_t w = (size_t(16) * G + c.rsz) / per_wave;
+    c.fft_waves = int(w < 4 ? 4 : (w > FE_WAVES ? FE_WAVES : w));
+    c.work = size_t(16) * G + c.rsz > c.fft_waves * per_wave ? size_t(16) * G + c.rsz : c.fft_waves * per_wave;
+    c.total = size_t(16) * G + c.work + 2048 + ((G + 15) & ~15) + 64;
+    return c;
 }
+extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits) { return fe_carve(G, nPilots, nBits).total; }
 
-extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
+extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel(
     MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
     float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int G = T.G, Nc = 50, Ns = T.Nsymb;
+    const FeCarve carve = fe_carve(G, T.nPilots, T.nBits);
     c2* grid = reinterpret_cast<c2*>(smem);
-    c2* H = grid + G;                                               // also the FFT work area (dead before H is born)
+    c2* H = grid + G;                                               // H and red together are the FFT work area first
     c2* fftb = H;
-    const size_t bsz = size_t(16) * G > size_t(FE_WAVES) * FFT256_STRIDE * 16 ? size_t(16) * G : size_t(FE_WAVES) * FFT256_STRIDE * 16;
-    double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(H) + bsz);   // <= 800 doubles
+    double* red = reinterpret_cast<double*>(H + G);                 // nPilots doubles
     float* llr = reinterpret_cast<float*>(red);                     // demapper output reuses the reduction area
     c2* yp = reinterpret_cast<c2*>(red);                            // pilots in row-major pilot order, multiplied by their sign
-    c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(red) + 12800);
+    c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(H) + carve.work);
     int8_t* type = reinterpret_cast<int8_t*>(tw + 128);             // 0 data, +1 / -1 pilot with that sign
     double* scal = reinterpret_cast<double*>(type + ((G + 15) & ~15));
 
@@ -119,14 +129,15 @@ extern "C" __global__ __launch_bounds__(FE_THREADS) void mgpu_frontend_kernel(
 
     // ---- symbol_demod: one wave per symbol (fft256.h), next symbol's samples requested before the butterflies ----
     c2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
-    if (wave < Ns) {
+    const int nfw = carve.fft_waves;                                // waves that own an FFT work area
+    if (wave < nfw && wave < Ns) {
         const c2* in = bb + size_t(wave) * 272 + 16;                // gi_remover
         n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
     }
-    for (int s = wave; s < Ns; s += FE_WAVES) {
+    for (int s = wave; wave < nfw && s < Ns; s += nfw) {
         c2 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-        if (s + FE_WAVES < Ns) {
-            const c2* in = bb + size_t(s + FE_WAVES) * 272 + 16;
+        if (s + nfw < Ns) {
+            const c2* in = bb + size_t(s + nfw) * 272 + 16;
             n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
         }
         wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
