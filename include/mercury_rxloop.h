@@ -11,7 +11,7 @@
  * and GUI subsystems), so the gates, recoveries and the retry loop are restated from the source and checked against
  * the repository's own CPU restatement (oracle/mercury_oracle.c:morc_receive_byte). Every DSP block underneath is
  * checked against the compiled reference. Not built: the GUI-only coarse frequency search of trial 1
- * (telecom_system.cc:949-1012, disabled by default), mfsk_fixed_delay (BER-test hook), signal_stregth_dbm.
+ * (telecom_system.cc:949-1012, disabled by default), mfsk_fixed_delay (BER-test hook).
  */
 #ifndef MERCURY_RXLOOP_H
 #define MERCURY_RXLOOP_H
@@ -46,6 +46,7 @@ typedef struct mgpu_receive_stats {
     double freq_offset, coarse_metric;
     int frame_overflow_symbols;
     double mean_H;                  /* mean |H| of the last trial that reached the channel estimate (the :1269 gate); -1 if none */
+    double signal_strength_dbm;     /* signal_stregth_dbm: 10 log10(mean |x|^2 / 1 mW) of the time-sync baseband (:678, ofdm.cc:1523-1539) */
 } mgpu_receive_stats;
 
 /* buffer_Nsymb (data_container.cc:133-143); a capture window is buffer_Nsymb * Nofdm * 4 passband samples */

@@ -8,7 +8,7 @@
 // Parity: every block is checked against the oracle / the compiled reference on its own; the orchestration is
 // checked against oracle/mercury_oracle.c:morc_receive_byte, whose own parity with telecom_system.cc is UNPINNED
 // (that file cannot be built in this image) — see DESIGN.md. Not built: the GUI-only coarse frequency search of
-// trial 1 (telecom_system.cc:949-1012, off by default), mfsk_fixed_delay, signal_stregth_dbm.
+// trial 1 (telecom_system.cc:949-1012, off by default), mfsk_fixed_delay.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -92,7 +92,8 @@ struct Loop {
     }
 
     // sum and count of |x|^2 over [off, off + len) (clipped at the buffer end) for every (window, offset) pair
-    void energies(const std::vector<int>& wv, const std::vector<int>& off, std::vector<double>& sum, std::vector<int>& cnt) {
+    void energies(const std::vector<int>& wv, const std::vector<int>& off, std::vector<double>& sum, std::vector<int>& cnt, int len = 0) {
+        if (len <= 0) len = sym;
         const int n = int(wv.size());
         sum.assign(n, 0.0);
         cnt.assign(n, 0);
@@ -101,7 +102,7 @@ struct Loop {
             up(d_ia, wv.data() + base, size_t(m) * 4);
             up(d_ib, off.data() + base, size_t(m) * 4);
             hipLaunchKernelGGL(mgpu_span_energy_kernel, dim3((m + 63) / 64), dim3(64), 0, s, d_bbi.as<double>(), buf, d_ia.as<int>(), d_ib.as<int>(), m,
-                               sym, d_sum.as<double>(), d_cnt.as<int>());
+                               len, d_sum.as<double>(), d_cnt.as<int>());
             HIPCK(hipGetLastError());
             HIPCK(hipMemcpyAsync(sum.data() + base, d_sum.p, size_t(m) * 8, hipMemcpyDeviceToHost, s));
             down(cnt.data() + base, d_cnt, size_t(m) * 4);
@@ -195,12 +196,20 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             mgpu_receive_stats& r = stats[w];
             r.iterations_done = -1; r.crc = 0; r.all_zeros = 0; r.message_decoded = 0; r.snr_db = -99.9;
             r.delay = 0; r.sync_trials = 0; r.freq_offset = 0; r.coarse_metric = 0; r.frame_overflow_symbols = 0; r.mean_H = -1.0;
+            r.signal_strength_dbm = -999;
         }
         std::memset(payload, 0, size_t(W) * t.payload_stride);
         HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyHostToDevice, s));
 
         // ---- :676-696 coarse synchronisation on the FIR_rx_time_sync baseband ----
         lp.p2b(all, 0);
+        {   // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order
+            hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_sum.as<double>());
+            HIPCK(hipGetLastError());
+            std::vector<double> sum(W);
+            lp.down(sum.data(), lp.d_sum, size_t(W) * 8);
+            for (int w = 0; w < W; ++w) stats[w].signal_strength_dbm = 10.0 * std::log10((sum[w] / lp.buf) / 0.001);
+        }
         std::vector<char> live(W, 1);                             // still on the way to the trial loop
         if (lp.mfsk) {
             const int nslots = lp.buf / lp.sym;

@@ -349,3 +349,29 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_decimate_kernel(
     const c2* x = reinterpret_cast<const c2*>(bb) + size_t(widx[k]) * stride + delay[k];
     reinterpret_cast<c2*>(out)[size_t(slot ? slot[k] : k) * count + i] = x[size_t(i) * rate];
 }
+
+// cl_ofdm::measure_signal_stregth (ofdm.cc:1523-1539): sum over a whole window of re^2 + im^2, added in sample order.
+// One workgroup per window: the terms of a chunk are formed in parallel from coalesced loads, one lane adds them.
+#define WE_CHUNK 4096
+extern "C" __global__ __launch_bounds__(256) void mgpu_window_energy_kernel(
+    const double* __restrict__ bb, int stride, int n, double* __restrict__ out) {
+    __shared__ double term[WE_CHUNK];
+    const c2* x = reinterpret_cast<const c2*>(bb) + size_t(blockIdx.x) * stride;
+    double acc = 0.0;
+    for (int base = 0; base < n; base += WE_CHUNK) {
+        const int m = min(WE_CHUNK, n - base);
+        for (int i = threadIdx.x; i < m; i += 256) { const c2 v = x[base + i]; term[i] = v.re * v.re + v.im * v.im; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int p = 0;
+            for (; p + 8 <= m; p += 8) {
+                const double a0 = term[p], a1 = term[p + 1], a2 = term[p + 2], a3 = term[p + 3];
+                const double a4 = term[p + 4], a5 = term[p + 5], a6 = term[p + 6], a7 = term[p + 7];
+                acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+            }
+            for (; p < m; ++p) acc += term[p];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}

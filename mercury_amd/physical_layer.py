@@ -50,7 +50,8 @@ LINK_STATE_DTYPE = np.dtype([("delay_of_last_decoded_message", "<i4"), ("freq_of
                              ("mfsk_search_start", "<i4")], align=True)
 RECEIVE_STATS_DTYPE = np.dtype([("iterations_done", "<i4"), ("crc", "<i4"), ("all_zeros", "<i4"), ("message_decoded", "<i4"),
                                 ("snr_db", "<f8"), ("delay", "<i4"), ("sync_trials", "<i4"), ("freq_offset", "<f8"),
-                                ("coarse_metric", "<f8"), ("frame_overflow_symbols", "<i4"), ("mean_H", "<f8")], align=True)
+                                ("coarse_metric", "<f8"), ("frame_overflow_symbols", "<i4"), ("mean_H", "<f8"),
+                                ("signal_strength_dbm", "<f8")], align=True)
 
 STATS_DTYPE = np.dtype([("iterations_done", "<i4"), ("crc", "<i4"), ("all_zeros", "<i4"),
                         ("message_decoded", "<i4"), ("variance", "<f4"), ("snr_db", "<f4")])

@@ -1147,7 +1147,7 @@ double morc_detect_ack_pattern(morc* o, const double* in_c128, int size, int int
  * telecom_system.cc, which cannot be built in this image (it needs the audio and GUI subsystems), so the control
  * flow below is a restatement checked only by reading: telecom_system.cc:646-1503, block by block, each cited.
  * Not restated: the GUI-only coarse frequency search of trial 1 (:949-1012, g_gui_state.coarse_freq_sync_enabled is
- * false by default), mfsk_fixed_delay (BER-test hook), signal_stregth_dbm (display value), prints. */
+ * false by default), mfsk_fixed_delay (BER-test hook), prints. */
 #define FIR_TS 0
 #define FIR_DATA 1
 static const double FS = 48000.0;                 /* telecom_system.cc:1569 */
@@ -1182,9 +1182,15 @@ void morc_receive_byte(morc* o, const double* passband, double carrier_hz, int t
     double freq_offset_measured = 0;
     /* receive_stats as init() leaves it (telecom_system.cc:1968-1981) + the per-call resets (:653-655) */
     rs->iterations_done = -1; rs->crc = 0; rs->all_zeros = 0; rs->message_decoded = 0; rs->snr_db = -99.9;
-    rs->delay = 0; rs->sync_trials = 0; rs->freq_offset = 0; rs->coarse_metric = 0; rs->frame_overflow_symbols = 0; rs->mean_H = -1.0;
+    rs->delay = 0; rs->sync_trials = 0; rs->freq_offset = 0; rs->coarse_metric = 0; rs->frame_overflow_symbols = 0; rs->mean_H = -1.0; rs->signal_strength_dbm = -999;
     /* :676-696 */
     morc_passband_to_baseband(o, passband, buf, FS, carrier_hz, CARRIER_AMPLITUDE, 1, FIR_TS, (double*)bbi);
+    {   /* :678 measure_signal_stregth, ofdm.cc:1523-1539 */
+        double p = 0;
+        for (int i = 0; i < buf; i++) p += pow(creal(bbi[i]), 2) + pow(cimag(bbi[i]), 2);
+        p /= buf;
+        rs->signal_strength_dbm = 10.0 * log10(p / 0.001);
+    }
     if (o->M == MOD_MFSK) {
         rs->delay = morc_time_sync_mfsk(o, (const double*)bbi, buf, interp, st ? st->mfsk_search_start : 0);
     } else {

@@ -125,6 +125,7 @@ typedef struct morc_receive_stats {
     double freq_offset, coarse_metric;
     int frame_overflow_symbols;
     double mean_H;                        /* of the last trial that got as far as the channel estimate */
+    double signal_strength_dbm;           /* receive_stats.signal_stregth_dbm (telecom_system.cc:678) */
 } morc_receive_stats;
 int morc_buffer_nsymb(morc*);             /* data_container.cc:133-143 */
 void morc_receive_byte(morc*, const double* passband, double carrier_hz, int time_sync_trials_max, int use_last_good_time_sync,

@@ -203,7 +203,8 @@ class LinkState(C.Structure):
 class ReceiveStats(C.Structure):
     _fields_ = [("iterations_done", C.c_int), ("crc", C.c_int), ("all_zeros", C.c_int), ("message_decoded", C.c_int),
                 ("snr_db", C.c_double), ("delay", C.c_int), ("sync_trials", C.c_int), ("freq_offset", C.c_double),
-                ("coarse_metric", C.c_double), ("frame_overflow_symbols", C.c_int), ("mean_H", C.c_double)]
+                ("coarse_metric", C.c_double), ("frame_overflow_symbols", C.c_int), ("mean_H", C.c_double),
+                ("signal_strength_dbm", C.c_double)]
 
 
 def _receive_byte(self, passband, carrier=None, trials_max=2, use_last_time=1, use_last_freq=1, state=None):

@@ -69,6 +69,7 @@ def test_gpu_receive_byte_batch_matches_oracle_ofdm(cfg):
             for k in ("iterations_done", "crc", "all_zeros", "message_decoded", "delay", "sync_trials", "frame_overflow_symbols"):
                 assert st[k] == ref[k], (cfg, df, w, k, st[k], ref[k])
             assert abs(st["coarse_metric"] - ref["coarse_metric"]) <= 1e-11, (cfg, w)
+            assert abs(st["signal_strength_dbm"] - ref["signal_strength_dbm"]) <= 1e-9, (cfg, w)
             assert abs(st["freq_offset"] - ref["freq_offset"]) <= 1e-9 * max(1.0, abs(ref["freq_offset"])), (cfg, w)
             assert abs(st["mean_H"] - ref["mean_H"]) <= 1e-9 * max(1.0, abs(ref["mean_H"])), (cfg, w)
             assert abs(st["snr_db"] - ref["snr_db"]) <= 1e-4 * max(1.0, abs(ref["snr_db"])), (cfg, w)
