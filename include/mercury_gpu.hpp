@@ -145,6 +145,7 @@ public:
     int time_sync_trials_max = 2;
     int use_last_good_time_sync = YES;
     int use_last_good_freq_offset = YES;
+    int coarse_freq_sync_enabled = NO;      // g_gui_state.coarse_freq_sync_enabled (gui_state.h:143)
 
     // Samples of one capture window: Nofdm * buffer_Nsymb * frequency_interpolation_rate (data_container.cc:133-143)
     int capture_window_samples() const { return mgpu_receive_buffer_nsymb(ctx_) * info.Nofdm * 4; }
@@ -153,7 +154,7 @@ public:
     // one passband capture window in, get_frame_size_bytes() ints out, statistics returned and kept in
     // receive_stats; the last good delay / frequency offset carry over to the next call as in the reference.
     st_receive_stats receive_byte(const double* data, int* out) {
-        mgpu_receive_config rc{carrier_frequency, time_sync_trials_max, use_last_good_time_sync, use_last_good_freq_offset};
+        mgpu_receive_config rc{carrier_frequency, time_sync_trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync_enabled};
         mgpu_link_state ls{receive_stats.delay_of_last_decoded_message, receive_stats.freq_offset_of_last_decoded_message, 0};
         mgpu_receive_stats r{};
         std::vector<uint8_t> bytes(info.payload_stride);

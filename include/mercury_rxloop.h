@@ -10,8 +10,7 @@
  * PARITY of the control flow is UNPINNED: telecom_system.cc cannot be compiled in the build image (it needs the audio
  * and GUI subsystems), so the gates, recoveries and the retry loop are restated from the source and checked against
  * the repository's own CPU restatement (oracle/mercury_oracle.c:morc_receive_byte). Every DSP block underneath is
- * checked against the compiled reference. Not built: the GUI-only coarse frequency search of trial 1
- * (telecom_system.cc:949-1012, disabled by default), mfsk_fixed_delay (BER-test hook).
+ * checked against the compiled reference. Not built: mfsk_fixed_delay (BER-test hook).
  */
 #ifndef MERCURY_RXLOOP_H
 #define MERCURY_RXLOOP_H
@@ -29,6 +28,7 @@ typedef struct mgpu_receive_config {
     int time_sync_trials_max;       /* physical_config.cc:85 (2) */
     int use_last_good_time_sync;    /* physical_config.cc:86 (YES) */
     int use_last_good_freq_offset;  /* physical_config.cc:87 (YES) */
+    int coarse_freq_sync_enabled;   /* g_gui_state.coarse_freq_sync_enabled (gui_state.h:143, default false): +-30 Hz search before trial 1 */
 } mgpu_receive_config;
 
 /* the members of st_receive_stats that survive from one receive_byte call to the next and steer it */

@@ -7,8 +7,7 @@
 //
 // Parity: every block is checked against the oracle / the compiled reference on its own; the orchestration is
 // checked against oracle/mercury_oracle.c:morc_receive_byte, whose own parity with telecom_system.cc is UNPINNED
-// (that file cannot be built in this image) — see DESIGN.md. Not built: the GUI-only coarse frequency search of
-// trial 1 (telecom_system.cc:949-1012, off by default), mfsk_fixed_delay.
+// (that file cannot be built in this image) — see DESIGN.md. Not built: mfsk_fixed_delay (BER-test hook).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -22,7 +21,7 @@ constexpr double kEnergyGate = 0.001, kMetricGate = 0.5, kMeanHGate = 0.3, kFreq
 
 struct Win {                       // one capture window's walk through receive_byte
     int delay = 0, pream = 1, sync_trials = 0, skip_h = 0;
-    double metric = 0.0, freq = 0.0;
+    double metric = 0.0, freq = 0.0, coarse_freq_offset = 0.0;
     bool in_loop = false, recovery_attempted = false, decoded = false;
     bool use_last_delay = false, use_last_freq = false;   // decided per trial
 };
@@ -296,19 +295,49 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
                 lp.recover(win, wins, from, true, false, ok);
                 bool any = false;
                 for (size_t j = 0; j < wins.size(); ++j)
-                    if (ok[j]) { Win& x = win[wins[j]]; x.sync_trials = 0; x.skip_h = 0; x.in_loop = true; any = true; }
+                    if (ok[j]) { Win& x = win[wins[j]]; x.sync_trials = 0; x.skip_h = 0; x.coarse_freq_offset = 0.0; x.in_loop = true; any = true; }
                 if (!any) break;
                 continue;
             }
             const int n = int(act.size());
             // -- delay for this trial: last good one on the final trial (:945-948), else the k-th best fine-search peak (:1014-1018)
-            std::vector<int> fw, fstart, fsize, floc;
+            std::vector<int> fw, fstart, fsize, floc, cw;
             for (int w : act) {
                 Win& x = win[w];
                 x.use_last_delay = !lp.mfsk && x.sync_trials == T && rcp->use_last_good_time_sync && state && state[w].delay_of_last_decoded_message != -1;
                 if (lp.mfsk) continue;
                 if (x.use_last_delay) { x.delay = state[w].delay_of_last_decoded_message; continue; }
+                if (x.sync_trials == 1 && rcp->coarse_freq_sync_enabled) { cw.push_back(w); continue; }
                 fw.push_back(w); fstart.push_back((x.pream - 1) * lp.sym); fsize.push_back((lp.pre + 4) * lp.sym); floc.push_back(x.sync_trials);
+            }
+            if (!cw.empty()) {   // :949-1012 coarse frequency search before trial 1: Schmidl-Cox at carrier -30 / 0 / +30 Hz
+                const double freq_search[3] = {-30.0, 0.0, 30.0};
+                const int nc = int(cw.size());
+                std::vector<double> best_corr(nc, 0.0), best_off(nc, 0.0), zero_corr(nc, 0.0);
+                std::vector<int> best_delay(nc), zero(nc, 0), ssize(nc, t.Nofdm * (2 * lp.pre + t.Nsymb) * kInterp);
+                for (int j = 0; j < nc; ++j) best_delay[j] = win[cw[j]].delay;
+                for (int i = 0; i < 3; ++i) {
+                    for (int w : cw) lp.carrier[w] = rcp->carrier_hz + freq_search[i];
+                    lp.p2b(cw, 0);
+                    std::vector<int> d;
+                    std::vector<double> corr;
+                    lp.tsync(cw, zero, ssize, kCoarseStep, zero, 1, d, corr);
+                    for (int j = 0; j < nc; ++j) {
+                        if (std::fabs(freq_search[i]) < 0.1) zero_corr[j] = corr[j];
+                        if (corr[j] > best_corr[j]) { best_corr[j] = corr[j]; best_off[j] = freq_search[i]; best_delay[j] = d[j]; }
+                    }
+                }
+                for (int j = 0; j < nc; ++j) {
+                    Win& x = win[cw[j]];
+                    if (std::fabs(best_off[j]) > 1.0 && best_corr[j] > 0.5 && best_corr[j] > zero_corr[j] + 0.1) {
+                        x.coarse_freq_offset = best_off[j];
+                        x.delay = best_delay[j];
+                        x.pream = std::max(1, x.delay / lp.sym);
+                    }
+                    lp.carrier[cw[j]] = rcp->carrier_hz + x.coarse_freq_offset;
+                }
+                lp.p2b(cw, 0);                                       // time-sync baseband at the (possibly corrected) carrier
+                for (int w : cw) { fw.push_back(w); fstart.push_back((win[w].pream - 1) * lp.sym); fsize.push_back((lp.pre + 4) * lp.sym); floc.push_back(win[w].sync_trials); }
             }
             {
                 std::vector<int> d;
@@ -340,7 +369,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
                 }
             }
             // -- :1083-1105 FIR_rx_data baseband at the (coarse-corrected) carrier, frame cut out at `delay`, decimated
-            for (int w : act) lp.carrier[w] = rcp->carrier_hz;
+            for (int w : act) lp.carrier[w] = rcp->carrier_hz + win[w].coarse_freq_offset;   // effective_carrier_freq, :1074
             lp.p2b(act, 1);
             auto extract = [&](const std::vector<int>& wins, const int* slot) {   // rational_resampler DECIMATION at `delay`
                 if (wins.empty()) return;
@@ -370,7 +399,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
                 if (x.sync_trials == T && rcp->use_last_good_freq_offset && state && state[act[k]].freq_offset_of_last_decoded_message != 0)
                     f[k] = state[act[k]].freq_offset_of_last_decoded_message;
                 x.freq = f[k];
-                if (!lp.mfsk && std::fabs(f[k]) > kFreqIgnore) { lp.carrier[act[k]] = rcp->carrier_hz + f[k]; rw.push_back(act[k]); rslot.push_back(k); }
+                if (!lp.mfsk && std::fabs(f[k]) > kFreqIgnore) { lp.carrier[act[k]] = rcp->carrier_hz + x.coarse_freq_offset + f[k]; rw.push_back(act[k]); rslot.push_back(k); }
             }
             lp.p2b(rw, 1);
             extract(rw, rslot.data());

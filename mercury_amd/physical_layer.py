@@ -43,7 +43,7 @@ class Taps(C.Structure):
 
 class ReceiveConfig(C.Structure):
     _fields_ = [("carrier_hz", C.c_double), ("time_sync_trials_max", C.c_int), ("use_last_good_time_sync", C.c_int),
-                ("use_last_good_freq_offset", C.c_int)]
+                ("use_last_good_freq_offset", C.c_int), ("coarse_freq_sync_enabled", C.c_int)]
 
 
 LINK_STATE_DTYPE = np.dtype([("delay_of_last_decoded_message", "<i4"), ("freq_offset_of_last_decoded_message", "<f8"),
@@ -248,14 +248,15 @@ class RxPhy:
     def receive_buffer_samples(self):
         return int(self.lib.mgpu_receive_buffer_nsymb(self.h)) * self.Nofdm * 4
 
-    def receive_byte(self, passband, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1, state=None):
+    def receive_byte(self, passband, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1, state=None,
+                     coarse_freq_sync=0):
         """passband: float64 [W, buffer samples]. Returns dict(payload [W, stride], stats [W] (RECEIVE_STATS_DTYPE), state)."""
         x = np.ascontiguousarray(passband, np.float64)
         x = x.reshape(1, -1) if x.ndim == 1 else x
         W, n = x.shape
         if n != self.receive_buffer_samples():
             raise MgpuError("a capture window is %d samples" % self.receive_buffer_samples())
-        cfg = ReceiveConfig(carrier_hz, trials_max, use_last_good_time_sync, use_last_good_freq_offset)
+        cfg = ReceiveConfig(carrier_hz, trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync)
         st = np.zeros(W, LINK_STATE_DTYPE) if state is None else np.ascontiguousarray(state, LINK_STATE_DTYPE)
         if state is None:
             st["delay_of_last_decoded_message"] = -1

@@ -1146,8 +1146,8 @@ double morc_detect_ack_pattern(morc* o, const double* in_c128, int size, int int
  * (tests/test_oracle_vs_ref.py, tests/test_sync_blocks.py), but the orchestration itself lives in
  * telecom_system.cc, which cannot be built in this image (it needs the audio and GUI subsystems), so the control
  * flow below is a restatement checked only by reading: telecom_system.cc:646-1503, block by block, each cited.
- * Not restated: the GUI-only coarse frequency search of trial 1 (:949-1012, g_gui_state.coarse_freq_sync_enabled is
- * false by default), mfsk_fixed_delay (BER-test hook), prints. */
+ * g_gui_state.coarse_freq_sync_enabled (false by default in the reference) is a parameter here. Not restated:
+ * mfsk_fixed_delay (BER-test hook), prints. */
 #define FIR_TS 0
 #define FIR_DATA 1
 static const double FS = 48000.0;                 /* telecom_system.cc:1569 */
@@ -1171,7 +1171,8 @@ static double span_energy(const cd* bbi, int off, int sym_samples, int buf_sampl
 }
 
 void morc_receive_byte(morc* o, const double* passband, double carrier_hz, int trials_max, int use_last_good_time_sync,
-                       int use_last_good_freq_offset, morc_link_state* st, int* out_bytes, morc_receive_stats* rs) {
+                       int use_last_good_freq_offset, int coarse_freq_sync_enabled, morc_link_state* st, int* out_bytes,
+                       morc_receive_stats* rs) {
     const int interp = 4, sym = o->Nofdm * interp, pre = o->preamble;
     const int buffer_nsymb = morc_buffer_nsymb(o), buf = o->Nofdm * buffer_nsymb * interp;
     const int frame_i = o->Nofdm * (o->Nsymb + pre) * interp;
@@ -1179,7 +1180,7 @@ void morc_receive_byte(morc* o, const double* passband, double carrier_hz, int t
     cd* bbi = malloc(sizeof(cd) * buf);
     cd* bb = malloc(sizeof(cd) * (frame_i / interp + 1));
     int step = 100, pream;
-    double freq_offset_measured = 0;
+    double freq_offset_measured = 0, coarse_freq_offset = 0.0;   /* :660 */
     /* receive_stats as init() leaves it (telecom_system.cc:1968-1981) + the per-call resets (:653-655) */
     rs->iterations_done = -1; rs->crc = 0; rs->all_zeros = 0; rs->message_decoded = 0; rs->snr_db = -99.9;
     rs->delay = 0; rs->sync_trials = 0; rs->freq_offset = 0; rs->coarse_metric = 0; rs->frame_overflow_symbols = 0; rs->mean_H = -1.0; rs->signal_strength_dbm = -999;
@@ -1254,6 +1255,26 @@ void morc_receive_byte(morc* o, const double* passband, double carrier_hz, int t
                     if (rs->sync_trials > 0) break;   /* :939-944 */
                 } else if (rs->sync_trials == trials_max && use_last_good_time_sync && st && st->delay_of_last_decoded_message != -1) {
                     rs->delay = st->delay_of_last_decoded_message;   /* :945-948 */
+                } else if (rs->sync_trials == 1 && coarse_freq_sync_enabled) {   /* :949-1012 coarse frequency search (+-30 Hz) */
+                    const double freq_search[3] = {-30.0, 0.0, 30.0};
+                    double best_correlation = 0.0, best_offset = 0.0, zero_hz_correlation = 0.0;
+                    int best_delay = rs->delay;
+                    for (int i = 0; i < 3; i++) {
+                        morc_passband_to_baseband(o, passband, buf, FS, carrier_hz + freq_search[i], CARRIER_AMPLITUDE, 1, FIR_TS, (double*)bbi);
+                        double corr = 0;
+                        int d = morc_time_sync_preamble(o, (const double*)bbi, o->Nofdm * (2 * pre + o->Nsymb) * interp, interp, 0, step, 1, &corr);
+                        if (fabs(freq_search[i]) < 0.1) zero_hz_correlation = corr;
+                        if (corr > best_correlation) { best_correlation = corr; best_offset = freq_search[i]; best_delay = d; }
+                    }
+                    if (fabs(best_offset) > 1.0 && best_correlation > 0.5 && best_correlation > zero_hz_correlation + 0.1) {
+                        coarse_freq_offset = best_offset;
+                        rs->delay = best_delay;
+                        pream = rs->delay / sym;
+                        if (pream < 1) pream = 1;
+                    }
+                    morc_passband_to_baseband(o, passband, buf, FS, carrier_hz + coarse_freq_offset, CARRIER_AMPLITUDE, 1, FIR_TS, (double*)bbi);
+                    int base = (pream - 1) * sym;
+                    rs->delay = base + morc_time_sync_preamble(o, (const double*)&bbi[base], (pre + 4) * sym, interp, rs->sync_trials, 1, trials_max, NULL);
                 } else {   /* :1014-1018 fine search, k-th best peak for trial k */
                     int base = (pream - 1) * sym;
                     rs->delay = base + morc_time_sync_preamble(o, (const double*)&bbi[base], (pre + 4) * sym, interp, rs->sync_trials, 1, trials_max, NULL);
@@ -1276,7 +1297,7 @@ void morc_receive_byte(morc* o, const double* passband, double carrier_hz, int t
                         }
                     }
                 }
-                double eff_carrier = carrier_hz;   /* coarse_freq_offset stays 0 (GUI-only search not restated) */
+                double eff_carrier = carrier_hz + coarse_freq_offset;   /* :1074 */
                 /* :1083, :1105 */
                 morc_passband_to_baseband(o, passband, buf, FS, eff_carrier, CARRIER_AMPLITUDE, 1, FIR_DATA, (double*)bbi);
                 for (int i = 0, k = 0; i < frame_i; i += interp) bb[k++] = bbi[rs->delay + i];
@@ -1327,6 +1348,7 @@ void morc_receive_byte(morc* o, const double* passband, double carrier_hz, int t
                     double re = span_energy(bbi, d, sym, buf);
                     if (re >= 0.001 && IN_BOUNDS(rsym)) {
                         rs->delay = d; rs->coarse_metric = corr; pream = rsym; rs->sync_trials = 0; skip_h_count = 0;
+                        coarse_freq_offset = 0.0;
                         goto retry_point;
                     }
                 }

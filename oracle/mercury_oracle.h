@@ -129,7 +129,8 @@ typedef struct morc_receive_stats {
 } morc_receive_stats;
 int morc_buffer_nsymb(morc*);             /* data_container.cc:133-143 */
 void morc_receive_byte(morc*, const double* passband, double carrier_hz, int time_sync_trials_max, int use_last_good_time_sync,
-                       int use_last_good_freq_offset, morc_link_state* state_or_null, int* out_bytes, morc_receive_stats* stats);
+                       int use_last_good_freq_offset, int coarse_freq_sync_enabled, morc_link_state* state_or_null, int* out_bytes,
+                       morc_receive_stats* stats);
 
 /* host libm tanh / atanh as the reference's decoder calls them; atanh_out is 0 where |x| >= 1 */
 void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out);

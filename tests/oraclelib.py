@@ -207,7 +207,7 @@ class ReceiveStats(C.Structure):
                 ("signal_strength_dbm", C.c_double)]
 
 
-def _receive_byte(self, passband, carrier=None, trials_max=2, use_last_time=1, use_last_freq=1, state=None):
+def _receive_byte(self, passband, carrier=None, trials_max=2, use_last_time=1, use_last_freq=1, state=None, coarse_freq_sync=0):
     """The whole cl_telecom_system::receive_byte on one capture window (oracle only; orchestration parity unpinned)."""
     x = np.ascontiguousarray(passband, np.float64)
     assert x.size == self.buffer_samples()
@@ -215,7 +215,7 @@ def _receive_byte(self, passband, carrier=None, trials_max=2, use_last_time=1, u
     rs = ReceiveStats()
     st = state if state is not None else LinkState(-1, 0.0, 0)
     self.lib.morc_receive_byte(self.h, _p(x), C.c_double(CARRIER if carrier is None else carrier), C.c_int(trials_max), C.c_int(use_last_time),
-                               C.c_int(use_last_freq), C.byref(st), _p(out), C.byref(rs))
+                               C.c_int(use_last_freq), C.c_int(coarse_freq_sync), C.byref(st), _p(out), C.byref(rs))
     res = {k: getattr(rs, k) for k, _ in ReceiveStats._fields_}
     res["payload"] = out[: self.payload_bytes].astype(np.uint8)
     res["state"] = st
