@@ -174,3 +174,35 @@ def test_gpu_coarse_frequency_search_matches_oracle():
             assert abs(st["mean_H"] - ref["mean_H"]) <= 1e-9 * max(1.0, abs(ref["mean_H"]))
             assert np.array_equal(out["payload"][w][: orc.payload_bytes], ref["payload"])
     rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,seed", [(8, 1), (8, 2), (5, 3), (13, 4)])
+def test_gpu_receive_byte_randomised_windows_match_oracle(cfg, seed):
+    """48 random capture windows per batch (delay anywhere in the buffer incl. out of bounds, noise from clean to buried,
+    silence, noise only, two frames in one window), random carrier error: every integer field of the statistics, the
+    payload bytes and the updated link state equal the oracle's, window by window."""
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    rng = np.random.default_rng(1000 + seed)
+    n = orc.buffer_samples()
+    frame = (orc.preamble_nsymb + orc.Nsymb) * 1088
+    specs = []
+    for i in range(48):
+        kind = rng.choice(["frame"] * 7 + ["silence", "noise", "two"])
+        specs.append((kind, int(rng.integers(0, n - frame)), float(10 ** rng.uniform(-2.3, -0.5)) if kind != "silence" else 1e-9, 100 + i))
+    wins, _ = make_windows(orc, specs, seed=seed)
+    df = float(rng.uniform(-12, 12))
+    rx = RxPhy(cfg, max_batch=len(specs))
+    out = rx.receive_byte(wins, CARRIER + df)
+    ndec = 0
+    for w in range(len(specs)):
+        ref = orc.receive_byte(wins[w], carrier=CARRIER + df)
+        st = out["stats"][w]
+        for k in ("iterations_done", "crc", "all_zeros", "message_decoded", "delay", "sync_trials", "frame_overflow_symbols"):
+            assert st[k] == ref[k], (cfg, seed, w, specs[w], k, st[k], ref[k])
+        assert np.array_equal(out["payload"][w][: orc.payload_bytes], ref["payload"]), (cfg, seed, w)
+        assert out["state"][w]["delay_of_last_decoded_message"] == ref["state"].delay_of_last_decoded_message
+        ndec += int(st["message_decoded"])
+    assert ndec >= 10
+    rx.close()
