@@ -168,6 +168,10 @@ int mgpu_time_sync_mfsk(mgpu_ctx* ctx, const double* baseband_interp_c128 /*[W][
                         int* delay /*[W]*/);
 int mgpu_detect_ack_pattern(mgpu_ctx* ctx, const double* baseband_interp_c128 /*[W][size][2]*/, int W, int size, int pattern,
                             double* metric /*[W]*/, int* matched /*[W] or NULL*/);
+/* cl_telecom_system::detect_ack_pattern_from_passband / detect_break_pattern_from_passband (telecom_system.cc:1628-1655,
+ * :1690-1710): passband audio in, mixed down at carrier_hz and filtered with FIR_rx_data on the device, then the detector. */
+int mgpu_detect_ack_pattern_from_passband(mgpu_ctx* ctx, const double* passband /*[W][size]*/, int W, int size, double carrier_hz,
+                                          int pattern, double* metric /*[W]*/, int* matched /*[W] or NULL*/);
 /* duration (ms, HIP events on the launch stream) of the kernel of the most recent synchroniser call */
 int mgpu_last_sync_kernel_ms(mgpu_ctx* ctx, float* ms);
 

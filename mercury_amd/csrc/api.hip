@@ -520,11 +520,26 @@ constexpr int kAckTones[8] = {4, 7, 5, 12, 13, 1, 9, 15}, kBreakTones[8] = {6, 1
 constexpr int kAckM = 16, kAckNsymb = 16, kAckLen = 8, kAckHop = 7, kAckOffset = 17, kInterp = 4;
 
 // carrier energies of every symbol slot of W windows: [W][nslots][50] on the host
-std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size, int nslots) {
+// `passband_carrier_hz` >= 0: `bb` is real passband audio ([W][size] doubles) that is first mixed down and filtered with
+// FIR_rx_data on the device (detect_ack_pattern_from_passband, telecom_system.cc:1628-1640); otherwise it is interpolated
+// baseband ([W][size] complex).
+std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size, int nslots, double passband_carrier_hz = -1.0) {
     const auto& t = c->tab;
     DevBuf d_in(size_t(W) * size * 16), d_e(size_t(W) * nslots * t.Nc * 8);
     hipStream_t s = c->stream;
-    HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
+    if (passband_carrier_hz >= 0) {
+        DevBuf d_pass(size_t(W) * size * 8), d_fc(size_t(W) * 8);
+        std::vector<double> fc(W, passband_carrier_hz);
+        HIPCK(hipMemcpyAsync(d_pass.p, bb, size_t(W) * size * 8, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_fc.p, fc.data(), size_t(W) * 8, hipMemcpyHostToDevice, s));
+        const int ntaps = int(t.fir_data.size());
+        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((size + 255) / 256, W), dim3(256), size_t(255 + ntaps) * 16, s, d_pass.as<double>(), size,
+                           d_fc.as<double>(), nullptr, 0, size, 1, c->d_fir[1], ntaps, kSampleRate, kCarrierAmplitude, d_in.as<double>(), nullptr);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s));          // d_pass / d_fc go out of scope here
+    } else {
+        HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
+    }
     HIPCK(hipMemsetAsync(d_e.p, 0, size_t(W) * nslots * t.Nc * 8, s));
     HIPCK(hipEventRecord(c->sync_ev[0], s));
     hipLaunchKernelGGL(mgpu_slot_energy_kernel, dim3((nslots + 3) / 4, W), dim3(256), 0, s, d_in.as<double>(), size, nslots, kInterp,
@@ -551,7 +566,21 @@ int mgpu_time_sync_mfsk(mgpu_ctx* c, const double* bb, int W, int size, int sear
     });
 }
 
+static int detect_ack_impl(mgpu_ctx* c, const double* bb, int W, int size, int pattern, double passband_carrier_hz, double* metric_out,
+                           int* matched_out);
+
 int mgpu_detect_ack_pattern(mgpu_ctx* c, const double* bb, int W, int size, int pattern, double* metric_out, int* matched_out) {
+    return detect_ack_impl(c, bb, W, size, pattern, -1.0, metric_out, matched_out);
+}
+
+int mgpu_detect_ack_pattern_from_passband(mgpu_ctx* c, const double* passband, int W, int size, double carrier_hz, int pattern,
+                                          double* metric_out, int* matched_out) {
+    if (!(carrier_hz >= 0)) return MGPU_ERR_ARG;
+    return detect_ack_impl(c, passband, W, size, pattern, carrier_hz, metric_out, matched_out);
+}
+
+static int detect_ack_impl(mgpu_ctx* c, const double* bb, int W, int size, int pattern, double passband_carrier_hz, double* metric_out,
+                           int* matched_out) {
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {
         const auto& t = c->tab;
@@ -561,7 +590,7 @@ int mgpu_detect_ack_pattern(mgpu_ctx* c, const double* bb, int W, int size, int 
             for (int w = 0; w < W; ++w) { metric_out[w] = 0.0; if (matched_out) matched_out[w] = 0; }
             return;
         }
-        const std::vector<double> E = slot_energies(c, bb, W, size, nslots);
+        const std::vector<double> E = slot_energies(c, bb, W, size, nslots, passband_carrier_hz);
         const int* tones = pattern == 2 ? kBreakTones : kAckTones;
         for (int w = 0; w < W; ++w) {                                  // ofdm.cc:2085-2178
             double best_metric = 0.0;

@@ -93,7 +93,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
-    "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern",
+    "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch",
     "mgpu_shm_create", "mgpu_shm_connect", "mgpu_shm_close", "mgpu_shm_destroy", "mgpu_shm_used", "mgpu_shm_free", "mgpu_shm_capacity",
     "mgpu_shm_clear", "mgpu_shm_write", "mgpu_shm_read", "mgpu_shm_read_all", "mgpu_shm_publish_decoded",
@@ -242,6 +242,17 @@ class RxPhy:
         metric = np.zeros(W, np.float64)
         matched = np.zeros(W, np.int32)
         self._ck(self.lib.mgpu_detect_ack_pattern(self.h, _ptr(z), C.c_int(W), C.c_int(size), C.c_int(pattern), _ptr(metric), _ptr(matched)))
+        return metric, matched
+
+    def detect_ack_pattern_from_passband(self, passband, carrier_hz, pattern=1):
+        """detect_ack_pattern_from_passband / detect_break_pattern_from_passband (telecom_system.cc:1628-1710)."""
+        x = np.ascontiguousarray(passband, np.float64)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        W, size = x.shape
+        metric = np.zeros(W, np.float64)
+        matched = np.zeros(W, np.int32)
+        self._ck(self.lib.mgpu_detect_ack_pattern_from_passband(self.h, _ptr(x), C.c_int(W), C.c_int(size), C.c_double(carrier_hz),
+                                                                C.c_int(pattern), _ptr(metric), _ptr(matched)))
         return metric, matched
 
     # ---- the whole of receive_byte on capture windows (SURVEY.md §8 row f2; include/mercury_rxloop.h) -------------

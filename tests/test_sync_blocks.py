@@ -239,3 +239,33 @@ def test_gpu_detect_ack_pattern_matches_oracle(cfg):
     m, n = rx.detect_ack_pattern(np.zeros((2, 10 * 1088), np.complex128))
     assert list(m) == [0.0, 0.0] and list(n) == [0, 0]
     rx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_detect_ack_pattern_from_passband_matches_oracle_chain():
+    """telecom_system.cc:1628-1655: passband -> FIR_rx_data baseband -> detector, fused on the device; against the oracle's
+    two calls. The mixer's device cos/sin differ from glibc in the last ulp, so the metric is compared to 1e-9."""
+    from mercury_amd import RxPhy
+    cfg = 8
+    orc = oraclelib.Oracle(cfg)
+    rng = np.random.default_rng(77)
+    n = 40 * 1088
+    wins = []
+    for which, noise in ((1, 0.01), (2, 0.05), (1, 0.3)):
+        pat = np.repeat(orc.mfsk_pattern(which) / 16.0 * np.sqrt(0.1), 4)            # interpolated baseband at TX power
+        t = np.arange(pat.size)
+        pb = (pat.real * np.cos(2 * np.pi * CARRIER * t / 48000.0) + pat.imag * np.sin(2 * np.pi * CARRIER * t / 48000.0)) * np.sqrt(2.0)
+        x = rng.standard_normal(n) * noise
+        x[9 * 1088: 9 * 1088 + pb.size] += pb
+        wins.append(x)
+    wins = np.stack(wins)
+    rx = RxPhy(cfg, max_batch=1)
+    for pattern in (1, 2):
+        metric, matched = rx.detect_ack_pattern_from_passband(wins, CARRIER, pattern)
+        for w in range(3):
+            bbi = orc.passband_to_baseband(wins[w], CARRIER, 1, 1)
+            m, k = orc.detect_ack_pattern(bbi, pattern)
+            assert abs(metric[w] - m) <= 1e-9 * max(1.0, m) and matched[w] == k, (pattern, w, metric[w], m)
+    m1, k1 = rx.detect_ack_pattern_from_passband(wins[:1], CARRIER, 1)
+    assert k1[0] == 16 and m1[0] > 12.0                                               # the ACK pattern is found in its window
+    rx.close()
