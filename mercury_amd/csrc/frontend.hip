@@ -61,6 +61,13 @@ __device__ __forceinline__ double get_angle(c2 v) {
     return theta;
 }
 
+// restore_channel_amplitude for one cell (ofdm.cc:1453-1466, set_complex misc.cc:65-71): kept out of line so that the
+// constant tables of atan / cos / sin do not stay live (and spill) across the rest of the front-end kernel
+__device__ __attribute__((noinline)) c2 unit_phasor(c2 h) {
+    const double th = get_angle(h);
+    return {cos(th), sin(th)};
+}
+
 }  // namespace
 
 // Sum n doubles from LDS in index order with one lane: the additions are a dependent chain by
@@ -286,10 +293,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel
             var /= double(T.nPilots);
             scal[2] = var;
         }
-        for (int c = tid; c < G; c += FE_THREADS) {
-            const double th = get_angle(H[c]);
-            H[c] = {cos(th), sin(th)};
-        }
+        for (int c = tid; c < G; c += FE_THREADS) H[c] = unit_phasor(H[c]);
         __syncthreads();
     }
     if (taps.H) for (int c = tid; c < G; c += FE_THREADS) { taps.H[(size_t(f) * G + c) * 2] = H[c].re; taps.H[(size_t(f) * G + c) * 2 + 1] = H[c].im; }
