@@ -26,7 +26,7 @@ def run(cfg, decoder, esn0, frames, steps=3):
 
 
 def main():
-    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 65536       # BASELINE.json configs[2]: 64k-frame batches
     res = {"frames_per_step": frames, "modes": {}}
     for cfg in list(range(17)) + [100, 101, 102]:
         m = {}
