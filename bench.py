@@ -338,6 +338,13 @@ def main():
             t0 = time.perf_counter()
             rx.receive(bb_h[:Sh])
             line["pcie_inclusive_frames_per_s"] = Sh / (time.perf_counter() - t0)
+            from mercury_amd.physical_layer import pinned_empty
+            pin = pinned_empty(bb_h[:Sh].shape, np.complex128)        # page-locked input (mgpu_alloc_host)
+            pin[...] = bb_h[:Sh]
+            rx.receive(pin)
+            t0 = time.perf_counter()
+            rx.receive(pin)
+            line["pcie_inclusive_pinned_frames_per_s"] = Sh / (time.perf_counter() - t0)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

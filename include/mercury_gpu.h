@@ -114,6 +114,12 @@ void mgpu_destroy(mgpu_ctx* ctx);
 const char* mgpu_last_error(mgpu_ctx* ctx);   /* ctx may be NULL: error of the last failed mgpu_create */
 int mgpu_get_info(mgpu_ctx* ctx, mgpu_info* info);
 
+/* Optional page-locked host memory for the arrays handed to the host-buffer entry points: transfers from / to it run at
+ * the full PCIe rate (about twice that of pageable memory). Plays the role of the reference's new[]/delete[] for
+ * caller-owned buffers (data_container.cc:90-172); any other host memory works too. */
+void* mgpu_alloc_host(size_t bytes);
+void mgpu_free_host(void* p);
+
 /* ---- host-buffer entry points (blocking; copy in, run, copy out) -------------------- */
 /* baseband_c128: [F][Nsymb*Nofdm] complex<double>, data symbols only (preamble already
  * stripped, i.e. the pointer receive_byte passes to symbol_demod at telecom_system.cc:1137).

@@ -327,6 +327,12 @@ void mgpu_destroy(mgpu_ctx* c) {
     delete c;
 }
 
+void* mgpu_alloc_host(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void mgpu_free_host(void* p) { if (p) (void)hipHostFree(p); }
+
 const char* mgpu_last_error(mgpu_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int mgpu_get_info(mgpu_ctx* c, mgpu_info* i) {

@@ -90,7 +90,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
+    "mgpu_alloc_host", "mgpu_free_host", "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
@@ -102,6 +102,28 @@ EXPORTED_SYMBOLS = [
 
 class MgpuError(RuntimeError):
     pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array over page-locked host memory from mgpu_alloc_host (keep the array alive while it is in use; the
+    memory is released when the returned array's base object is collected)."""
+    lib = load_library()
+    lib.mgpu_alloc_host.restype = C.c_void_p
+    lib.mgpu_alloc_host.argtypes = [C.c_size_t]
+    lib.mgpu_free_host.argtypes = [C.c_void_p]
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    ptr = lib.mgpu_alloc_host(n * dt.itemsize)
+    if not ptr:
+        raise MgpuError("mgpu_alloc_host failed")
+
+    class _Owner:
+        def __del__(self):
+            lib.mgpu_free_host(ptr)
+
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    buf._owner = _Owner()
+    return np.frombuffer(buf, dtype=dt).reshape(shape)
 
 
 def _ptr(a):
