@@ -25,6 +25,7 @@
 
 #include "mercury_gpu.h"
 #include "mercury_rxloop.h"
+#include "mercury_stages.h"
 
 namespace mgpu {
 
@@ -191,8 +192,80 @@ public:
         for (int f = 0; f < F; ++f) stats[f] = detail::convert(s[f]);
     }
 
+    mgpu_ctx* context() const { return ctx_; }       // for the per-method mirrors below
+
 private:
     mgpu_ctx* ctx_ = nullptr;
 };
+
+// ---- the RX methods of cl_ofdm / cl_psk and the free deinterleaver, one call each ------------------------------
+// For host code that keeps receive_byte's method-by-method sequence (telecom_system.cc:1132-1298). Same names, same
+// argument meaning; each call is one small GPU launch on one frame (use cl_rx_phy for throughput). The objects share the
+// context of a cl_rx_phy: `mgpu::cl_ofdm ofdm(phy); ofdm.symbol_demod(in, out); ...`.
+class cl_ofdm {
+public:
+    int Nc = 0, Nfft = 0, Nsymb = 0, Ngi = 0;
+    int channel_estimator = 0, channel_estimator_amplitude_restoration = NO;
+    std::vector<std::complex<double>> estimated_channel;          // st_channel_complex::value of every cell (ofdm.h:181)
+
+    cl_ofdm(mgpu_ctx* ctx, const mgpu_info& info) : ctx_(ctx), G_(info.Nsymb * info.Nc), nData_(info.nData) {
+        Nc = info.Nc; Nfft = info.Nfft; Nsymb = info.Nsymb; Ngi = info.Ngi;
+        channel_estimator = info.estimator; channel_estimator_amplitude_restoration = info.amp_restore ? YES : NO;
+        estimated_channel.assign(G_, {0.0, 0.0});
+    }
+    void symbol_demod(const std::complex<double>* in, std::complex<double>* out) {                     // ofdm.cc:862-867
+        detail::check(mgpu_symbol_demod(ctx_, reinterpret_cast<const double*>(in), 1, reinterpret_cast<double*>(out)), ctx_, "symbol_demod");
+    }
+    void automatic_gain_control(std::complex<double>* in) {                                            // ofdm.cc:1467-1498
+        detail::check(mgpu_automatic_gain_control(ctx_, reinterpret_cast<double*>(in), 1), ctx_, "automatic_gain_control");
+    }
+    void LS_channel_estimator(const std::complex<double>* in) { estimate(in); }                        // ofdm.cc:1315-1451
+    void ZF_channel_estimator(const std::complex<double>* in) { estimate(in); }                        // ofdm.cc:1266-1313
+    void restore_channel_amplitude() {                                                                 // ofdm.cc:1453-1466
+        detail::check(mgpu_restore_channel_amplitude(ctx_, reinterpret_cast<double*>(estimated_channel.data()), 1), ctx_, "restore_channel_amplitude");
+    }
+    void channel_equalizer(const std::complex<double>* in, std::complex<double>* out) {                // ofdm.cc:1637-1647
+        detail::check(mgpu_channel_equalizer(ctx_, reinterpret_cast<const double*>(in), reinterpret_cast<const double*>(estimated_channel.data()), 1,
+                                             reinterpret_cast<double*>(out)), ctx_, "channel_equalizer");
+    }
+    double measure_variance(const std::complex<double>* in) {                                          // ofdm.cc:1500-1521
+        double v = 0;
+        detail::check(mgpu_measure_variance(ctx_, reinterpret_cast<const double*>(in), 1, &v), ctx_, "measure_variance");
+        return v;
+    }
+    void deframer(const std::complex<double>* in, std::complex<double>* out) {                         // ofdm.cc:837-852
+        detail::check(mgpu_deframer(ctx_, reinterpret_cast<const double*>(in), 1, reinterpret_cast<double*>(out)), ctx_, "deframer");
+    }
+
+private:
+    void estimate(const std::complex<double>* in) {
+        detail::check(mgpu_channel_estimator(ctx_, reinterpret_cast<const double*>(in), 1, reinterpret_cast<double*>(estimated_channel.data())), ctx_,
+                      "channel_estimator");
+    }
+    mgpu_ctx* ctx_;
+    int G_, nData_;
+};
+
+class cl_psk {
+public:
+    cl_psk(mgpu_ctx* ctx, const mgpu_info& info) : ctx_(ctx), nBits_(info.nBits) {}
+    // psk.h:55 — nItems is the number of BITS, as in the reference's call (telecom_system.cc:1296)
+    void demod(const std::complex<double>* in, int nItems, float* out, float variance) {
+        if (nItems != nBits_) throw std::runtime_error("cl_psk::demod: nItems must be the mode's nBits");
+        detail::check(mgpu_psk_demod(ctx_, reinterpret_cast<const double*>(in), 1, &variance, out), ctx_, "cl_psk::demod");
+    }
+
+private:
+    mgpu_ctx* ctx_;
+    int nBits_;
+};
+
+// interleaver.h:28-34
+inline void deinterleaver(mgpu_ctx* ctx, const std::complex<double>* in, std::complex<double>* out, int nItems, int block_size) {
+    detail::check(mgpu_deinterleaver_c128(ctx, reinterpret_cast<const double*>(in), 1, nItems, block_size, reinterpret_cast<double*>(out)), ctx, "deinterleaver");
+}
+inline void deinterleaver(mgpu_ctx* ctx, const float* in, float* out, int nItems, int block_size) {
+    detail::check(mgpu_deinterleaver_f32(ctx, in, 1, nItems, block_size, out), ctx, "deinterleaver");
+}
 
 }  // namespace mgpu

@@ -95,6 +95,8 @@ EXPORTED_SYMBOLS = [
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch",
+    "mgpu_symbol_demod", "mgpu_automatic_gain_control", "mgpu_channel_estimator", "mgpu_restore_channel_amplitude", "mgpu_channel_equalizer",
+    "mgpu_measure_variance", "mgpu_deframer", "mgpu_deinterleaver_c128", "mgpu_deinterleaver_f32", "mgpu_psk_demod",
     "mgpu_shm_create", "mgpu_shm_connect", "mgpu_shm_close", "mgpu_shm_destroy", "mgpu_shm_used", "mgpu_shm_free", "mgpu_shm_capacity",
     "mgpu_shm_clear", "mgpu_shm_write", "mgpu_shm_read", "mgpu_shm_read_all", "mgpu_shm_publish_decoded",
 ]
