@@ -268,4 +268,26 @@ inline void deinterleaver(mgpu_ctx* ctx, const float* in, float* out, int nItems
     detail::check(mgpu_deinterleaver_f32(ctx, in, 1, nItems, block_size, out), ctx, "deinterleaver");
 }
 
+// the integer tail, reference signatures (one int per bit / byte): interleaver.cc:111-117, misc.cc:107-130, crc16_modbus_rtu.cc:25-45.
+// `seq` is accepted for signature compatibility; the mode's own dispersal sequence (telecom_system.cc:1961-1966) is applied.
+inline void bit_energy_dispersal(mgpu_ctx* ctx, const int* in, const int* /*seq*/, int* out, int nItems) {
+    std::vector<uint8_t> a(nItems), b(nItems);
+    for (int i = 0; i < nItems; ++i) a[i] = uint8_t(in[i] & 1);
+    detail::check(mgpu_bit_energy_dispersal(ctx, a.data(), 1, nItems, b.data()), ctx, "bit_energy_dispersal");
+    for (int i = 0; i < nItems; ++i) out[i] = b[i];
+}
+inline void bit_to_byte(mgpu_ctx* ctx, const int* in, int* out, int nItems) {
+    std::vector<uint8_t> a(nItems), b((nItems + 7) / 8);
+    for (int i = 0; i < nItems; ++i) a[i] = uint8_t(in[i] & 1);
+    detail::check(mgpu_bit_to_byte(ctx, a.data(), 1, nItems, b.data()), ctx, "bit_to_byte");
+    for (size_t i = 0; i < b.size(); ++i) out[i] = b[i];
+}
+inline uint16_t CRC16_MODBUS_RTU_calc(mgpu_ctx* ctx, const int* data, int nItems) {
+    std::vector<uint8_t> a(nItems);
+    for (int i = 0; i < nItems; ++i) a[i] = uint8_t(data[i] & 0xff);
+    uint16_t crc = 0;
+    detail::check(mgpu_crc16_modbus_rtu(ctx, a.data(), 1, nItems, &crc), ctx, "CRC16_MODBUS_RTU_calc");
+    return crc;
+}
+
 }  // namespace mgpu

@@ -15,6 +15,10 @@
  *   mgpu_deframer                    void cl_ofdm::deframer(complex<double>* in, complex<double>* out)           ofdm.h:136
  *   mgpu_deinterleaver_c128 / _f32   void deinterleaver(T* in, T* out, int nItems, int block_size)               interleaver.h:28-34
  *   mgpu_psk_demod                   void cl_psk::demod(const complex<double>* in, int nItems, float* out, float variance)  psk.h:55
+ *   mgpu_bit_energy_dispersal        void bit_energy_dispersal(int* in, int* seq, int* out, int nItems)          interleaver.h:36 (seq = the mode's)
+ *   mgpu_bit_to_byte                 void bit_to_byte(int* in, int* out, int nItems)                            misc.h
+ *   mgpu_crc16_modbus_rtu            uint16_t CRC16_MODBUS_RTU_calc(int* data, int nItems)                      crc16_modbus_rtu.h
+ *                                    (bits and byte values travel as one uint8_t each instead of one int)
  * G = Nsymb*Nc cells per frame grid; complex arrays are interleaved (re, im) doubles. OFDM modes only.
  */
 #ifndef MERCURY_STAGES_H
@@ -36,6 +40,9 @@ int mgpu_deframer(mgpu_ctx* ctx, const double* grid_c128 /*[F][G]*/, int F, doub
 int mgpu_deinterleaver_c128(mgpu_ctx* ctx, const double* in, int F, int nItems, int block_size, double* out);
 int mgpu_deinterleaver_f32(mgpu_ctx* ctx, const float* in, int F, int nItems, int block_size, float* out);
 int mgpu_psk_demod(mgpu_ctx* ctx, const double* syms_c128 /*[F][nData]*/, int F, const float* variance /*[F]*/, float* llr /*[F][nBits]*/);
+int mgpu_bit_energy_dispersal(mgpu_ctx* ctx, const uint8_t* bits /*[F][n]*/, int F, int n, uint8_t* out /*[F][n]*/);
+int mgpu_bit_to_byte(mgpu_ctx* ctx, const uint8_t* bits /*[F][nbits]*/, int F, int nbits, uint8_t* bytes /*[F][ceil(nbits/8)]*/);
+int mgpu_crc16_modbus_rtu(mgpu_ctx* ctx, const uint8_t* bytes /*[F][n]*/, int F, int n, uint16_t* crc /*[F]*/);
 
 #ifdef __cplusplus
 }

@@ -164,3 +164,34 @@ extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_psk_demod_ke
         for (int b = 0; b < bps; ++b) o[k * bps + (bps - 1 - b)] = inv_var * (d1[b] - d0[b]);
     }
 }
+
+// ---- the integer tail as separate stages: bit_energy_dispersal (interleaver.cc:111-117), bit_to_byte (misc.cc:107-130),
+// CRC16_MODBUS_RTU_calc (crc16_modbus_rtu.cc:25-45). One byte per bit / per byte value, F rows.
+extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_dispersal_kernel(const uint8_t* __restrict__ in, const uint8_t* __restrict__ scrambler,
+                                                                                   int n, uint8_t* __restrict__ out) {
+    const size_t base = size_t(blockIdx.x) * n;
+    for (int i = threadIdx.x; i < n; i += ST_THREADS) out[base + i] = in[base + i] ^ scrambler[i];
+}
+
+extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_bit_to_byte_kernel(const uint8_t* __restrict__ bits, int nbits, uint8_t* __restrict__ bytes) {
+    const int nbytes = (nbits + 7) / 8;
+    const uint8_t* b = bits + size_t(blockIdx.x) * nbits;
+    uint8_t* o = bytes + size_t(blockIdx.x) * nbytes;
+    for (int j = threadIdx.x; j < nbytes; j += ST_THREADS) {
+        unsigned v = 0;
+        for (int q = 0; q < 8 && j * 8 + q < nbits; ++q) v |= unsigned(b[j * 8 + q] & 1) << q;      // LSB first, trailing partial byte
+        o[j] = uint8_t(v);
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64) void mgpu_stage_crc16_kernel(const uint8_t* __restrict__ bytes, int F, int n, uint16_t* __restrict__ crc_out) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= F) return;
+    const uint8_t* b = bytes + size_t(f) * n;
+    unsigned crc = 0xffff;
+    for (int j = 0; j < n; ++j) {
+        crc ^= b[j];
+        for (int i = 0; i < 8; ++i) crc = (crc & 1) ? ((crc >> 1) ^ 0xA001) : (crc >> 1);
+    }
+    crc_out[f] = uint16_t(crc);
+}

@@ -12,6 +12,10 @@ extern "C" __global__ void mgpu_stage_deframe_kernel(MgpuDev, const double*, dou
 extern "C" __global__ void mgpu_stage_deinterleave_kernel(const unsigned char*, int, int, int, unsigned char*);
 extern "C" __global__ void mgpu_stage_psk_demod_kernel(MgpuDev, const double*, const float*, float*);
 
+extern "C" __global__ void mgpu_stage_dispersal_kernel(const uint8_t*, const uint8_t*, int, uint8_t*);
+extern "C" __global__ void mgpu_stage_bit_to_byte_kernel(const uint8_t*, int, uint8_t*);
+extern "C" __global__ void mgpu_stage_crc16_kernel(const uint8_t*, int, int, uint16_t*);
+
 namespace {
 
 // run `launch(d_in..., d_out)` between an upload of the inputs and a download of the output
@@ -163,6 +167,46 @@ int mgpu_psk_demod(mgpu_ctx* c, const double* syms, int F, const float* variance
         hipLaunchKernelGGL(mgpu_stage_psk_demod_kernel, dim3(F), dim3(256), 0, io.s, c->dev, d_s.as<double>(), d_v.as<float>(), d_l.as<float>());
         HIPCK(hipGetLastError());
         io.down(llr, d_l, size_t(F) * t.nBits * 4);
+    });
+}
+
+int mgpu_bit_energy_dispersal(mgpu_ctx* c, const uint8_t* bits, int F, int n, uint8_t* out) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(bits && out && F > 0 && n > 0 && n <= c->tab.N, "bad argument");
+        Io io(c);
+        DevBuf d_i(size_t(F) * n), d_o(size_t(F) * n);
+        io.up(d_i, bits, size_t(F) * n);
+        hipLaunchKernelGGL(mgpu_stage_dispersal_kernel, dim3(F), dim3(256), 0, io.s, d_i.as<uint8_t>(), c->dev.scrambler, n, d_o.as<uint8_t>());
+        HIPCK(hipGetLastError());
+        io.down(out, d_o, size_t(F) * n);
+    });
+}
+
+int mgpu_bit_to_byte(mgpu_ctx* c, const uint8_t* bits, int F, int nbits, uint8_t* bytes) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(bits && bytes && F > 0 && nbits > 0, "bad argument");
+        const int nbytes = (nbits + 7) / 8;
+        Io io(c);
+        DevBuf d_i(size_t(F) * nbits), d_o(size_t(F) * nbytes);
+        io.up(d_i, bits, size_t(F) * nbits);
+        hipLaunchKernelGGL(mgpu_stage_bit_to_byte_kernel, dim3(F), dim3(256), 0, io.s, d_i.as<uint8_t>(), nbits, d_o.as<uint8_t>());
+        HIPCK(hipGetLastError());
+        io.down(bytes, d_o, size_t(F) * nbytes);
+    });
+}
+
+int mgpu_crc16_modbus_rtu(mgpu_ctx* c, const uint8_t* bytes, int F, int n, uint16_t* crc) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(bytes && crc && F > 0 && n >= 0, "bad argument");
+        Io io(c);
+        DevBuf d_i(size_t(F) * n + 16), d_o(size_t(F) * 2);
+        io.up(d_i, bytes, size_t(F) * n);
+        hipLaunchKernelGGL(mgpu_stage_crc16_kernel, dim3((F + 63) / 64), dim3(64), 0, io.s, d_i.as<uint8_t>(), F, n, d_o.as<uint16_t>());
+        HIPCK(hipGetLastError());
+        io.down(crc, d_o, size_t(F) * 2);
     });
 }
 

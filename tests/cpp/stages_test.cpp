@@ -37,6 +37,13 @@ int main(int argc, char** argv) {
         mgpu::deinterleaver(phy.context(), deframed.data(), tf.data(), I.nData, I.tf_blk);       // :1294
         psk.demod(tf.data(), I.nBits, demodulated.data(), variance);                             // :1296
         mgpu::deinterleaver(phy.context(), demodulated.data(), deinterleaved.data(), I.nBits, I.bit_blk);   // :1298
+        // the integer tail on a known pattern (telecom_system.cc:1313-1341): descramble, pack, CRC self-check
+        const int nReal = I.nReal;
+        std::vector<int> bits(nReal), desc(nReal), bytes((nReal + 7) / 8);
+        for (int i = 0; i < nReal; i++) bits[i] = (i * 7 + i / 3) & 1;
+        mgpu::bit_energy_dispersal(phy.context(), bits.data(), nullptr, desc.data(), nReal);
+        mgpu::bit_to_byte(phy.context(), desc.data(), bytes.data(), nReal);
+        const int crc = mgpu::CRC16_MODBUS_RTU_calc(phy.context(), bytes.data(), nReal / 8);
         FILE* o = fopen(argv[3], "wb");
         fwrite(demod.data(), sizeof(cd), G, o);
         fwrite(H.data(), sizeof(cd), G, o);
@@ -45,6 +52,9 @@ int main(int argc, char** argv) {
         fwrite(tf.data(), sizeof(cd), I.nData, o);
         fwrite(demodulated.data(), sizeof(float), I.nBits, o);
         fwrite(deinterleaved.data(), sizeof(float), I.nBits, o);
+        fwrite(desc.data(), sizeof(int), nReal, o);
+        fwrite(bytes.data(), sizeof(int), bytes.size(), o);
+        fwrite(&crc, sizeof(int), 1, o);
         fclose(o);
     } catch (const std::exception& e) {
         fprintf(stderr, "stages_test: %s\n", e.what());

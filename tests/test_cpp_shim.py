@@ -147,3 +147,16 @@ def test_cpp_per_method_sequence_matches_oracle(tmp_path, cfg):
         assert (np.abs(llr_demod - ref["llr_demod"]) <= tol).all()
         nreal = orc.nReal
         assert (np.abs(llr_deint[:nreal] - ref["llr_ldpc"][:nreal]) <= 1e-5 * np.maximum(1.0, np.abs(ref["llr_ldpc"][:nreal]))).all()
+    # integer tail: bit-exact
+    nreal = orc.nReal
+    if cfg >= 15:
+        off = G * 16 * 3 + 4 + nData * 16 + nBits * 4 * 2
+    desc, by, crc = take(nreal, np.int32), take((nreal + 7) // 8, np.int32), take(1, np.int32)[0]
+    bits = np.array([(i * 7 + i // 3) & 1 for i in range(nreal)], np.int32)
+    want = bits ^ orc.scrambler()[:nreal]
+    assert np.array_equal(desc, want)
+    packed = np.zeros((nreal + 7) // 8, np.int32)
+    for i in range(nreal):
+        packed[i // 8] |= int(want[i]) << (i % 8)
+    assert np.array_equal(by, packed)
+    assert crc == orc.crc16(packed[: nreal // 8])
