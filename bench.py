@@ -196,6 +196,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_device:
         local_rank = 0
+    elif torch.cuda.device_count() > 0:
+        local_rank %= torch.cuda.device_count()       # e.g. a launcher that exposes one device per rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
