@@ -321,6 +321,7 @@ void mgpu_destroy(mgpu_ctx* c) {
     for (void* p : c->owned) (void)hipFree(p);
     (void)hipFree(c->d_baseband); (void)hipFree(c->d_llr); (void)hipFree(c->d_variance); (void)hipFree(c->d_snrvar);
     (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters); (void)hipFree(c->d_eqdata);
+    if (c->rxloop_ws && c->rxloop_ws_free) c->rxloop_ws_free(c->rxloop_ws);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto& q : c->ev) for (auto& e : q) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->sync_ev) if (e) (void)hipEventDestroy(e);

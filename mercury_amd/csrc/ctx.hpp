@@ -90,6 +90,9 @@ struct mgpu_ctx {
     hipEvent_t sync_ev[2]{};        // around the most recent synchroniser kernel
     float last_sync_ms = -1.f;     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
     int* d_iters = nullptr;
+    void* rxloop_ws = nullptr;      // device workspace of mgpu_receive_byte_batch, kept between calls (rxloop.hip)
+    int rxloop_ws_windows = 0;
+    void (*rxloop_ws_free)(void*) = nullptr;
     hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
     static constexpr int kEvRing = 64;
     hipEvent_t ev[kEvRing][4]{};    // per launch: front-end start/stop, decoder start/stop

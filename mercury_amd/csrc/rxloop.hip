@@ -9,12 +9,28 @@
 // checked against oracle/mercury_oracle.c:morc_receive_byte, whose own parity with telecom_system.cc is UNPINNED
 // (that file cannot be built in this image) — see DESIGN.md. Not built: mfsk_fixed_delay (BER-test hook).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.hpp"
 
 namespace {
+
+// MERCURY_RXLOOP_TIMING=1: wall-clock per phase on stderr (the stream is synchronised at every mark)
+struct PhaseTimer {
+    bool on = std::getenv("MERCURY_RXLOOP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(hipStream_t s, const char* what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rxloop] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 constexpr int kInterp = 4, kCoarseStep = 100;
 constexpr double kEnergyGate = 0.001, kMetricGate = 0.5, kMeanHGate = 0.3, kFreqIgnore = 0.1;   // telecom_system.cc:843, :854, :1269; physical_config.cc:60
@@ -26,6 +42,23 @@ struct Win {                       // one capture window's walk through receive_
     bool use_last_delay = false, use_last_freq = false;   // decided per trial
 };
 
+// Device workspace for W windows; allocated on the first call and kept in the context (hipMalloc / hipFree of several GB
+// per call cost more than the kernels)
+struct Workspace {
+    DevBuf d_pass, d_bbi, d_frames, d_carrier, d_ia, d_ib, d_ic, d_vals, d_sum, d_cnt, d_freq, d_meanh, d_stats_k, d_payload_k;
+    size_t vals_per_window;
+    double* h_vals = nullptr;        // page-locked landing area for the synchroniser metrics (tens of MB per call)
+    ~Workspace() { if (h_vals) (void)hipHostFree(h_vals); }
+    Workspace(int W, int buf, int frame_n, size_t vals_per_window, int payload_stride)
+        : d_pass(size_t(W) * buf * 8), d_bbi(size_t(W) * buf * 16), d_frames(size_t(W) * frame_n * 16), d_carrier(size_t(W) * 8),
+          d_ia(size_t(W) * 128 * 4), d_ib(size_t(W) * 128 * 4), d_ic(size_t(W) * 4), d_vals(size_t(W) * vals_per_window * 8),
+          d_sum(size_t(W) * 128 * 8), d_cnt(size_t(W) * 128 * 4), d_freq(size_t(W) * 8), d_meanh(size_t(W) * 8),
+          d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * payload_stride), vals_per_window(vals_per_window) {
+        HIPCK(hipHostMalloc(&h_vals, size_t(W) * vals_per_window * 8, hipHostMallocDefault));
+    }
+};
+void free_workspace(void* p) { delete static_cast<Workspace*>(p); }
+
 struct Loop {
     mgpu_ctx* c;
     const mgpu::ModeTables& t;
@@ -33,23 +66,36 @@ struct Loop {
     bool mfsk;
     hipStream_t s;
     mgpu_receive_config rc;
-    DevBuf d_pass, d_bbi, d_frames, d_carrier, d_ia, d_ib, d_ic, d_vals, d_sum, d_cnt, d_freq, d_meanh;
+    Workspace& ws;
+    DevBuf &d_pass, &d_bbi, &d_frames, &d_carrier, &d_ia, &d_ib, &d_ic, &d_vals, &d_sum, &d_cnt, &d_freq, &d_meanh;
     std::vector<double> carrier;   // per window, as currently applied (carrier + fine offset of the running trial)
+
+    static Workspace& workspace(mgpu_ctx* ctx, int W, int buffer_nsymb) {
+        const auto& t = ctx->tab;
+        if (!ctx->rxloop_ws || ctx->rxloop_ws_windows < W) {
+            if (ctx->rxloop_ws) free_workspace(ctx->rxloop_ws);
+            ctx->rxloop_ws = nullptr;
+            const int buf = t.Nofdm * buffer_nsymb * kInterp, sym = t.Nofdm * kInterp;
+            const size_t vals = size_t(std::max(buf / kCoarseStep + 2, 4 * sym + 2));       // coarse / fine candidate counts
+            ctx->rxloop_ws = new Workspace(W, buf, t.Nofdm * (t.Nsymb + t.preamble), vals, t.payload_stride);
+            ctx->rxloop_ws_windows = W;
+            ctx->rxloop_ws_free = free_workspace;
+        }
+        return *static_cast<Workspace*>(ctx->rxloop_ws);
+    }
 
     Loop(mgpu_ctx* ctx, int W_, const mgpu_receive_config& rc_, int buffer_nsymb)
         : c(ctx), t(ctx->tab), W(W_), buf(t.Nofdm * buffer_nsymb * kInterp), sym(t.Nofdm * kInterp), pre(t.preamble),
           frame_i(t.Nofdm * (t.Nsymb + t.preamble) * kInterp), frame_n(t.Nofdm * (t.Nsymb + t.preamble)), lower(t.preamble),
           upper(buffer_nsymb - (t.Nsymb + t.preamble)), ngi_i(t.Ngi * kInterp), nfft_i(t.Nfft * kInterp), L(t.preamble * t.Nofdm * kInterp),
-          mfsk(t.mfsk_M > 0), s(ctx->stream), rc(rc_),
-          d_pass(size_t(W_) * buf * 8), d_bbi(size_t(W_) * buf * 16), d_frames(size_t(W_) * frame_n * 16), d_carrier(size_t(W_) * 8),
-          d_ia(size_t(W_) * 128 * 4), d_ib(size_t(W_) * 128 * 4), d_ic(size_t(W_) * 4), d_vals(size_t(W_) * size_t(buf) * 8),
-          d_sum(size_t(W_) * 128 * 8), d_cnt(size_t(W_) * 128 * 4), d_freq(size_t(W_) * 8), d_meanh(size_t(W_) * 8),
-          carrier(W_, rc_.carrier_hz) {}
+          mfsk(t.mfsk_M > 0), s(ctx->stream), rc(rc_), ws(workspace(ctx, W_, buffer_nsymb)),
+          d_pass(ws.d_pass), d_bbi(ws.d_bbi), d_frames(ws.d_frames), d_carrier(ws.d_carrier), d_ia(ws.d_ia), d_ib(ws.d_ib), d_ic(ws.d_ic),
+          d_vals(ws.d_vals), d_sum(ws.d_sum), d_cnt(ws.d_cnt), d_freq(ws.d_freq), d_meanh(ws.d_meanh), carrier(W_, rc_.carrier_hz) {}
 
     bool in_bounds(int p) const { return p > lower && p < upper; }
 
     void up(DevBuf& d, const void* h, size_t bytes) { HIPCK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, s)); }
-    void down(void* h, const DevBuf& d, size_t bytes) { HIPCK(hipMemcpyAsync(h, d.p, bytes, hipMemcpyDeviceToHost, s)); HIPCK(hipStreamSynchronize(s)); }
+    void down(void* h, DevBuf& d, size_t bytes) { HIPCK(hipMemcpyAsync(h, d.p, bytes, hipMemcpyDeviceToHost, s)); HIPCK(hipStreamSynchronize(s)); }
 
     // passband_to_baseband of the whole buffer for the listed windows, overwriting their interpolated baseband
     void p2b(const std::vector<int>& wins, int filter) {
@@ -74,6 +120,7 @@ struct Loop {
         std::vector<int> nc(n);
         int ncmax = 1;
         for (int k = 0; k < n; ++k) { nc[k] = size[k] > L ? (size[k] - L + step - 1) / step : 0; ncmax = std::max(ncmax, nc[k]); }
+        need(size_t(ncmax) <= ws.vals_per_window, "search window larger than the workspace");
         up(d_ia, wins.data(), size_t(n) * 4);
         up(d_ib, start.data(), size_t(n) * 4);
         up(d_ic, nc.data(), size_t(n) * 4);
@@ -85,8 +132,8 @@ struct Loop {
                                d_bbi.as<double>(), buf, d_ib.as<int>(), d_ia.as<int>(), d_ic.as<int>(), ncmax, step, pre, ngi_i, nfft_i,
                                d_vals.as<double>());
         HIPCK(hipGetLastError());
-        std::vector<double> vals(size_t(n) * ncmax);
-        down(vals.data(), d_vals, vals.size() * 8);
+        const double* vals = ws.h_vals;
+        down(ws.h_vals, d_vals, size_t(n) * ncmax * 8);
         for (int k = 0; k < n; ++k) select_peak(&vals[size_t(k) * ncmax], nc[k], step, size[k], loc[k], ntrials, &delay[k], &corr[k]);
     }
 
@@ -100,7 +147,7 @@ struct Loop {
             const int m = std::min(n - base, W * 128);
             up(d_ia, wv.data() + base, size_t(m) * 4);
             up(d_ib, off.data() + base, size_t(m) * 4);
-            hipLaunchKernelGGL(mgpu_span_energy_kernel, dim3((m + 63) / 64), dim3(64), 0, s, d_bbi.as<double>(), buf, d_ia.as<int>(), d_ib.as<int>(), m,
+            hipLaunchKernelGGL(mgpu_span_energy_kernel, dim3((m + 3) / 4), dim3(256), 0, s, d_bbi.as<double>(), buf, d_ia.as<int>(), d_ib.as<int>(), m,
                                len, d_sum.as<double>(), d_cnt.as<int>());
             HIPCK(hipGetLastError());
             HIPCK(hipMemcpyAsync(sum.data() + base, d_sum.p, size_t(m) * 8, hipMemcpyDeviceToHost, s));
@@ -184,8 +231,10 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
         need(rcp->time_sync_trials_max >= 0 && rcp->time_sync_trials_max < 64, "time_sync_trials_max out of range");
         const auto& t = c->tab;
         const int T = rcp->time_sync_trials_max;
+        PhaseTimer pt;
         Loop lp(c, W, *rcp, mgpu_receive_buffer_nsymb(c));
         hipStream_t s = lp.s;
+        pt.mark(s, "device buffers");
         ensure_workspaces(c, WS_FRONTEND | WS_LLR | WS_OUT);
         std::vector<Win> win(W);
         std::vector<int> all(W);
@@ -200,8 +249,10 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
         std::memset(payload, 0, size_t(W) * t.payload_stride);
         HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyHostToDevice, s));
 
+        pt.mark(s, "upload passband");
         // ---- :676-696 coarse synchronisation on the FIR_rx_time_sync baseband ----
         lp.p2b(all, 0);
+        pt.mark(s, "p2b time-sync filter");
         {   // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order
             hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_sum.as<double>());
             HIPCK(hipGetLastError());
@@ -209,6 +260,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             lp.down(sum.data(), lp.d_sum, size_t(W) * 8);
             for (int w = 0; w < W; ++w) stats[w].signal_strength_dbm = 10.0 * std::log10((sum[w] / lp.buf) / 0.001);
         }
+        pt.mark(s, "signal strength");
         std::vector<char> live(W, 1);                             // still on the way to the trial loop
         if (lp.mfsk) {
             const int nslots = lp.buf / lp.sym;
@@ -227,6 +279,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             lp.tsync(all, zero, full, kCoarseStep, zero, 1, d, corr);
             for (int w = 0; w < W; ++w) { win[w].delay = d[w]; win[w].metric = corr[w]; }
         }
+        pt.mark(s, "coarse time sync");
         for (int w = 0; w < W; ++w) { win[w].pream = std::max(1, win[w].delay / lp.sym); }
         // ---- :702-718 MFSK frame completeness ----
         if (lp.mfsk)
@@ -248,21 +301,26 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             for (int w = 0; w < W; ++w) if (live[w]) { wv.push_back(w); off.push_back(win[w].delay); }
             std::vector<double> sum;
             std::vector<int> cnt;
+            pt.mark(s, "gates: bounds recovery");
             lp.energies(wv, off, sum, cnt);
+            pt.mark(s, "gates: energy at delay");
             std::vector<int> wins, from;
             for (size_t j = 0; j < wv.size(); ++j) {
                 bool energy_ok = !(Loop::mean(sum[j], cnt[j]) < kEnergyGate);
                 if (energy_ok && win[wv[j]].metric < kMetricGate) energy_ok = false;
                 if (!energy_ok) { wins.push_back(wv[j]); from.push_back(win[wv[j]].pream + 1); }
             }
+            if (pt.on) std::fprintf(stderr, "[rxloop] %zu of %zu windows fail the energy / metric gate\n", wins.size(), wv.size());
             std::vector<char> ok;
             lp.recover(win, wins, from, false, true, ok);
             for (size_t j = 0; j < wins.size(); ++j) if (!ok[j]) live[wins[j]] = 0;
         }
         for (int w = 0; w < W; ++w) { win[w].in_loop = live[w] != 0; }
+        pt.mark(s, "bounds / energy gates");
 
         // ---- :931-1431 the trial loop, one round per trial over the windows still in it ----
-        DevBuf d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * t.payload_stride);
+        DevBuf& d_stats_k = lp.ws.d_stats_k;
+        DevBuf& d_payload_k = lp.ws.d_payload_k;
         std::vector<MgpuStatsDev> st_k(W);
         std::vector<uint8_t> pay_k(size_t(W) * t.payload_stride);
         for (;;) {
@@ -345,6 +403,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
                 lp.tsync(fw, fstart, fsize, 1, floc, T, d, corr);
                 for (size_t j = 0; j < fw.size(); ++j) win[fw[j]].delay = fstart[j] + d[j];
             }
+            pt.mark(s, "trial: fine time sync");
             for (int w : act) {                                      // :1020-1031
                 Win& x = win[w];
                 if (x.delay < 0) x.delay = 0;
@@ -368,6 +427,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
                     }
                 }
             }
+            pt.mark(s, "trial: energy fix");
             // -- :1083-1105 FIR_rx_data baseband at the (coarse-corrected) carrier, frame cut out at `delay`, decimated
             for (int w : act) lp.carrier[w] = rcp->carrier_hz + win[w].coarse_freq_offset;   // effective_carrier_freq, :1074
             lp.p2b(act, 1);
@@ -384,6 +444,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
                 HIPCK(hipGetLastError());
             };
             extract(act, nullptr);
+            pt.mark(s, "trial: p2b data filter + cut");
             // -- :1108-1131 fine frequency offset (Moose) or the last good one on the final trial; re-mix if it matters
             std::vector<double> f(n, 0.0);
             {
@@ -403,6 +464,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             }
             lp.p2b(rw, 1);
             extract(rw, rslot.data());
+            pt.mark(s, "trial: Moose + re-mix");
             // -- :1132-1345 the hot path on the data symbols (they start `preamble` symbols into each extracted frame)
             MgpuTapsDev taps{};
             if (!lp.mfsk) taps.mean_H = lp.d_meanh.as<double>();
@@ -413,6 +475,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             if (!lp.mfsk) HIPCK(hipMemcpyAsync(mh.data(), lp.d_meanh.p, size_t(n) * 8, hipMemcpyDeviceToHost, s));
             HIPCK(hipMemcpyAsync(st_k.data(), d_stats_k.p, size_t(n) * sizeof(MgpuStatsDev), hipMemcpyDeviceToHost, s));
             lp.down(pay_k.data(), d_payload_k, size_t(n) * t.payload_stride);
+            pt.mark(s, "trial: RX path + results");
             for (int k = 0; k < n; ++k) {
                 const int w = act[k];
                 Win& x = win[w];

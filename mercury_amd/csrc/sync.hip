@@ -324,19 +324,34 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(
 // Sums of |x|^2 over short spans of the interpolated baseband: the energy gates of receive_byte
 // (telecom_system.cc:758-766, :826-834, :1044-1066, ...). Span j lies in window wv[j] at offset off[j]; the terms
 // re*re + im*im are added in sample order for i < len while off + i < stride (the reference's loop bounds); the caller
-// divides by the count or by len as the call site does. One lane per span.
-extern "C" __global__ __launch_bounds__(64) void mgpu_span_energy_kernel(
+// divides by the count or by len as the call site does. One wavefront per span: the terms are formed in parallel from
+// coalesced loads into LDS, lane 0 adds them in order. len <= SE_MAXLEN.
+#define SE_MAXLEN 1088
+extern "C" __global__ __launch_bounds__(256) void mgpu_span_energy_kernel(
     const double* __restrict__ bb, int stride, const int* __restrict__ wv, const int* __restrict__ off, int n, int len,
     double* __restrict__ sum, int* __restrict__ cnt) {
-    const int j = blockIdx.x * 64 + threadIdx.x;
+    __shared__ double term[4][SE_MAXLEN];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wave;
     if (j >= n) return;
     const c2* x = reinterpret_cast<const c2*>(bb) + size_t(wv[j]) * stride;
     const int o = off[j];
-    double e = 0.0;
-    int c = 0;
-    for (int i = 0; i < len && o + i < stride; ++i) { const c2 v = x[o + i]; e += v.re * v.re + v.im * v.im; ++c; }
-    sum[j] = e;
-    cnt[j] = c;
+    int m = stride - o;                                           // terms that exist: i < len && o + i < stride
+    m = m < 0 ? 0 : (m > len ? len : m);
+    double* t = term[wave];
+    for (int i = lane; i < m; i += 64) { const c2 v = x[o + i]; t[i] = v.re * v.re + v.im * v.im; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        double e = 0.0;
+        int p = 0;
+        for (; p + 8 <= m; p += 8) {
+            const double a0 = t[p], a1 = t[p + 1], a2 = t[p + 2], a3 = t[p + 3], a4 = t[p + 4], a5 = t[p + 5], a6 = t[p + 6], a7 = t[p + 7];
+            e += a0; e += a1; e += a2; e += a3; e += a4; e += a5; e += a6; e += a7;
+        }
+        for (; p < m; ++p) e += t[p];
+        sum[j] = e;
+        cnt[j] = m;
+    }
 }
 
 // rational_resampler(..., DECIMATION) (ofdm.cc:2267-2278) from a per-window offset:
