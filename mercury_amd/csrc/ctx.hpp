@@ -90,6 +90,10 @@ struct mgpu_ctx {
     hipEvent_t sync_ev[2]{};        // around the most recent synchroniser kernel
     float last_sync_ms = -1.f;     // [max_batch][nData] c128, zero-forcing modes only (post-decode SNR)
     int* d_iters = nullptr;
+    // single-frame fast path of mgpu_rx_batch: the copy-in / front-end / decoder / copy-out sequence as one hipGraph
+    hipGraphExec_t one_frame_graph = nullptr;
+    void* h_one_in = nullptr;       // page-locked staging for one frame of samples
+    void* h_one_out = nullptr;      // page-locked staging for its payload + stats
     void* rxloop_ws = nullptr;      // device workspace of mgpu_receive_byte_batch, kept between calls (rxloop.hip)
     int rxloop_ws_windows = 0;
     void (*rxloop_ws_free)(void*) = nullptr;

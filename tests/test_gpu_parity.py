@@ -410,3 +410,23 @@ def test_degenerate_inputs_behave_like_the_reference(cfg):
             assert (st["iterations_done"], st["crc"], st["all_zeros"]) == (ref["iterations"], ref["crc"], ref["all_zeros"]), (cfg, i)
             assert np.array_equal(out["payload"][i], ref["bytes"].astype(np.uint8)), (cfg, i)
     rx.close()
+
+
+def test_single_frame_graph_path_equals_batched_path():
+    """mgpu_rx_batch with F = 1 replays a captured hipGraph over fixed staging buffers (api.hip:rx_one_frame): many
+    different frames through it, interleaved with batched calls, give exactly what the batched path gives."""
+    cfg = 8
+    orc = Oracle(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    snrs = [op, op + 2.0, -15.0, 60.0, op - 1.0, op + 0.5]
+    bb, _ = _frames(orc, snrs, seed=4321)
+    rx = _rx(cfg, max_batch=len(snrs))
+    batch = rx.receive(bb)
+    for rep in range(2):
+        for f in range(len(snrs)):
+            one = rx.receive(bb[f:f + 1])
+            assert np.array_equal(one["payload"][0], batch["payload"][f]), (rep, f)
+            assert one["stats"][0] == batch["stats"][f], (rep, f)
+        again = rx.receive(bb)                     # the batched path still works after graph launches
+        assert np.array_equal(again["payload"], batch["payload"]) and (again["stats"] == batch["stats"]).all()
+    rx.close()
