@@ -48,13 +48,23 @@ struct Workspace {
     DevBuf d_pass, d_bbi, d_frames, d_carrier, d_ia, d_ib, d_ic, d_vals, d_sum, d_cnt, d_freq, d_meanh, d_stats_k, d_payload_k;
     size_t vals_per_window;
     double* h_vals = nullptr;        // page-locked landing area for the synchroniser metrics (tens of MB per call)
-    ~Workspace() { if (h_vals) (void)hipHostFree(h_vals); }
+    hipStream_t side = nullptr;      // the signal-strength sum (a 92 k-term dependent chain per window) runs beside the synchroniser
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    ~Workspace() {
+        if (h_vals) (void)hipHostFree(h_vals);
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+    }
     Workspace(int W, int buf, int frame_n, size_t vals_per_window, int payload_stride)
         : d_pass(size_t(W) * buf * 8), d_bbi(size_t(W) * buf * 16), d_frames(size_t(W) * frame_n * 16), d_carrier(size_t(W) * 8),
           d_ia(size_t(W) * 128 * 4), d_ib(size_t(W) * 128 * 4), d_ic(size_t(W) * 4), d_vals(size_t(W) * vals_per_window * 8),
           d_sum(size_t(W) * 128 * 8), d_cnt(size_t(W) * 128 * 4), d_freq(size_t(W) * 8), d_meanh(size_t(W) * 8),
           d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * payload_stride), vals_per_window(vals_per_window) {
         HIPCK(hipHostMalloc(&h_vals, size_t(W) * vals_per_window * 8, hipHostMallocDefault));
+        HIPCK(hipStreamCreate(&side));
+        HIPCK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
     }
 };
 void free_workspace(void* p) { delete static_cast<Workspace*>(p); }
@@ -253,12 +263,14 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
         // ---- :676-696 coarse synchronisation on the FIR_rx_time_sync baseband ----
         lp.p2b(all, 0);
         pt.mark(s, "p2b time-sync filter");
-        {   // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order
-            hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_sum.as<double>());
+        {   // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order. The sum is a long
+            // dependent chain, so it runs on a side stream while the synchroniser works on the same (read-only) baseband; the
+            // main stream waits for it before the trial loop overwrites that baseband.
+            HIPCK(hipEventRecord(lp.ws.ev_ready, s));
+            HIPCK(hipStreamWaitEvent(lp.ws.side, lp.ws.ev_ready, 0));
+            hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(256), 0, lp.ws.side, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_freq.as<double>());
             HIPCK(hipGetLastError());
-            std::vector<double> sum(W);
-            lp.down(sum.data(), lp.d_sum, size_t(W) * 8);
-            for (int w = 0; w < W; ++w) stats[w].signal_strength_dbm = 10.0 * std::log10((sum[w] / lp.buf) / 0.001);
+            HIPCK(hipEventRecord(lp.ws.ev_done, lp.ws.side));
         }
         pt.mark(s, "signal strength");
         std::vector<char> live(W, 1);                             // still on the way to the trial loop
@@ -318,6 +330,12 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
         for (int w = 0; w < W; ++w) { win[w].in_loop = live[w] != 0; }
         pt.mark(s, "bounds / energy gates");
 
+        {   // the signal-strength sums must be out of the baseband before the trial loop re-filters it
+            HIPCK(hipStreamWaitEvent(s, lp.ws.ev_done, 0));
+            std::vector<double> sum(W);
+            lp.down(sum.data(), lp.d_freq, size_t(W) * 8);
+            for (int w = 0; w < W; ++w) stats[w].signal_strength_dbm = 10.0 * std::log10((sum[w] / lp.buf) / 0.001);
+        }
         // ---- :931-1431 the trial loop, one round per trial over the windows still in it ----
         DevBuf& d_stats_k = lp.ws.d_stats_k;
         DevBuf& d_payload_k = lp.ws.d_payload_k;
