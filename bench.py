@@ -118,7 +118,6 @@ def cpu_baseline(cfg, max_iters, bb_sample, flags, gpu_payload, gpu_stats):
 def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
     """Secondary measurements on rank 0's GPU, outside the contract's timed region: the other decoder on the same
     inputs, and the same decoder at the mode's operating point (threshold + 3 dB) where early termination works."""
-    import oraclelib  # only for the Es/N0 table of the modes (conftest constants), no compute
     from conftest import OPERATING_ESN0
     out = {}
 

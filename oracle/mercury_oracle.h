@@ -63,7 +63,7 @@ typedef struct morc_rx_out {
 #define MORC_DEC_GBF 0
 #define MORC_DEC_SPA 1
 
-/* tables_path: mercury_ldpc_tables.bin (derived data, see tools/gen_ldpc_tables.py) */
+/* tables_path: mercury_ldpc_tables.bin (derived data, see oracle/gen_ldpc_tables.py) */
 morc* morc_create(int cfg, int max_iters, const char* tables_path);
 void morc_destroy(morc*);
 void morc_get_info(morc*, morc_info*);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Whole-chain rate of the batched receive_byte (passband capture windows -> payloads) next to the CPU oracle's
 restatement on the same windows. Host buffers in, host buffers out: PCIe copies and the host-side control flow are
-inside the timed region. Usage: python tools/bench_receive_byte.py [cfg] [W]"""
+inside the timed region. Usage: python tests/tools/bench_receive_byte.py [cfg] [W]"""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oraclelib  # noqa: E402  (CPU twin, timed beside the GPU as the baseline)

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-mode soft-output deviation of the HIP front-end from the CPU oracle (record max abs/rel
-error per mode). Run on the GPU box: python tools/llr_error_table.py > gpurun_out/llr_error.json"""
+error per mode). Run on the GPU box: python tests/tools/llr_error_table.py > gpurun_out/llr_error.json"""
 import json
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oraclelib  # noqa: E402

@@ -25,7 +25,7 @@ if [ "$1" = "sweep" ]; then
   cd "$ROOT"
   python tools/sweep_modes.py > "$OUT/mode_sweep.json" 2> "$OUT/mode_sweep.txt"
   python tools/bench_sync.py > "$OUT/bench_sync_blocks.json"
-  python tools/bench_receive_byte.py 8 1024 > "$OUT/bench_receive_byte_cfg8.json"
-  python tools/llr_error_table.py > "$OUT/llr_error_by_mode.json" 2>/dev/null || true
+  python tests/tools/bench_receive_byte.py 8 1024 > "$OUT/bench_receive_byte_cfg8.json"
+  python tests/tools/llr_error_table.py > "$OUT/llr_error_by_mode.json" 2>/dev/null || true
 fi
 ls -la "$OUT"
