@@ -206,3 +206,42 @@ def test_gpu_receive_byte_randomised_windows_match_oracle(cfg, seed):
         ndec += int(st["message_decoded"])
     assert ndec >= 10
     rx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_receive_byte_mfsk_control_frames_overflow_and_search_start():
+    """MFSK specifics of receive_byte: short control frames (set_mfsk_ctrl_mode), the anti-re-decode search start
+    (telecom_system.cc:683-686) and the frame-overflow report when the frame runs past the capture window (:702-718)."""
+    from mercury_amd import RxPhy
+    from mercury_amd.physical_layer import LINK_STATE_DTYPE
+    cfg = 101
+    for ctrl in (0, 1):
+        orc = Oracle(cfg)
+        orc.set_ctrl_mode(ctrl)
+        n = orc.buffer_samples()
+        pl = np.random.default_rng(3).integers(0, 256, orc.payload_bytes)
+        pb = orc.tx_passband(orc.payload_to_bits(pl))
+        rng = np.random.default_rng(40 + ctrl)
+        wins = rng.standard_normal((3, n)) * 0.05
+        d0, d1 = 30 * 1088, 90 * 1088
+        wins[0, d0: d0 + pb.size] += pb                      # one frame
+        wins[1, d0: d0 + pb.size] += pb                      # two frames: the second is found when the search starts past the first
+        if d1 + pb.size + 200 * 1088 <= n:
+            wins[1, d0 + pb.size + 20 * 1088: d0 + 2 * pb.size + 20 * 1088] += pb
+        late = n - pb.size // 2
+        wins[2, late:] += pb[: n - late]                     # frame cut off by the end of the window -> overflow report
+        rx = RxPhy(cfg, max_batch=3, mfsk_ctrl_mode=bool(ctrl))
+        state = np.zeros(3, LINK_STATE_DTYPE)
+        state["delay_of_last_decoded_message"] = -1
+        state["mfsk_search_start"] = [0, d0 // 1088 + 2, 0]
+        out = rx.receive_byte(wins, CARRIER, state=state)
+        for w in range(3):
+            st0 = oraclelib.LinkState(-1, 0.0, int(state["mfsk_search_start"][w]))
+            ref = orc.receive_byte(wins[w], state=st0)
+            st = out["stats"][w]
+            for k in ("iterations_done", "crc", "all_zeros", "message_decoded", "delay", "sync_trials", "frame_overflow_symbols"):
+                assert st[k] == ref[k], (ctrl, w, k, st[k], ref[k])
+            assert np.array_equal(out["payload"][w][: orc.payload_bytes], ref["payload"]), (ctrl, w)
+        assert out["stats"]["message_decoded"][0] == 1 and np.array_equal(out["payload"][0][: orc.payload_bytes], pl)
+        assert out["stats"]["frame_overflow_symbols"][2] > 0 and out["stats"]["message_decoded"][2] == 0
+        rx.close()
