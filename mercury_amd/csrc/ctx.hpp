@@ -36,6 +36,7 @@ extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, 
 extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double, double*);
 extern "C" __global__ void mgpu_span_energy_kernel(const double*, int, const int*, const int*, int, int, double*, int*);
 extern "C" __global__ void mgpu_window_energy_kernel(const double*, int, int, double*);
+extern "C" __global__ void mgpu_select_peak_kernel(const double*, const int*, int, int, const int*, const int*, int, int, int*, double*);
 extern "C" __global__ void mgpu_decimate_kernel(const double*, int, const int*, const int*, const int*, int, int, double*);
 #define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)

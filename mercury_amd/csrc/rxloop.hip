@@ -142,9 +142,19 @@ struct Loop {
                                d_bbi.as<double>(), buf, d_ib.as<int>(), d_ia.as<int>(), d_ic.as<int>(), ncmax, step, pre, ngi_i, nfft_i,
                                d_vals.as<double>());
         HIPCK(hipGetLastError());
-        const double* vals = ws.h_vals;
-        down(ws.h_vals, d_vals, size_t(n) * ncmax * 8);
-        for (int k = 0; k < n; ++k) select_peak(&vals[size_t(k) * ncmax], nc[k], step, size[k], loc[k], ntrials, &delay[k], &corr[k]);
+        if (n >= 32) {   // peak selection where the metrics lie; only (delay, correlation) per window come back
+            up(d_ia, size.data(), size_t(n) * 4);                    // wins / start are consumed: reuse their index buffers
+            up(d_ib, loc.data(), size_t(n) * 4);
+            hipLaunchKernelGGL(mgpu_select_peak_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_vals.as<double>(), d_ic.as<int>(), ncmax, step,
+                               d_ia.as<int>(), d_ib.as<int>(), ntrials, n, d_cnt.as<int>(), d_sum.as<double>());
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(delay.data(), d_cnt.p, size_t(n) * 4, hipMemcpyDeviceToHost, s));
+            down(corr.data(), d_sum, size_t(n) * 8);
+        } else {         // a few windows: one lane per window would crawl through its candidates; the host is quicker
+            const double* vals = ws.h_vals;
+            down(ws.h_vals, d_vals, size_t(n) * ncmax * 8);
+            for (int k = 0; k < n; ++k) select_peak(&vals[size_t(k) * ncmax], nc[k], step, size[k], loc[k], ntrials, &delay[k], &corr[k]);
+        }
     }
 
     // sum and count of |x|^2 over [off, off + len) (clipped at the buffer end) for every (window, offset) pair

@@ -390,3 +390,32 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_window_energy_kernel(
     }
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
+
+// The reference's peak selection (ofdm.cc:1943-1964) for one window per lane, on the candidate metrics where they lie in
+// HBM: vals[k*step] = metric of candidate k, 0 elsewhere; pass j starts from entry j and takes every strictly larger
+// later entry (nothing is swapped out); the entry of pass `loc` is returned. Only candidates and the first zero met while
+// the running value is negative can change the outcome, so the size-long array is never materialised (same emulation as
+// select_peak in api.hip).
+extern "C" __global__ __launch_bounds__(64) void mgpu_select_peak_kernel(
+    const double* __restrict__ vals, const int* __restrict__ ncand_w, int ncand_max, int step, const int* __restrict__ size_w,
+    const int* __restrict__ loc_w, int ntrials, int n, int* __restrict__ delay, double* __restrict__ corr) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n) return;
+    const double* v = vals + size_t(k) * ncand_max;
+    const int ncand = ncand_w[k], size = size_w[k];
+    int j = loc_w[k];
+    if (j >= ntrials) j = ntrials - 1;
+    double cur = (j < size && j % step == 0 && j / step < ncand) ? v[j / step] : 0.0;
+    int loc = j, p = j + 1;
+    for (int c = (j + step) / step; c < ncand; ++c) {
+        const int ci = c * step;
+        if (ci <= j) continue;
+        if (p < ci && cur < 0) { cur = 0.0; loc = p; }
+        const double x = v[c];
+        if (x > cur) { cur = x; loc = ci; }
+        p = ci + 1;
+    }
+    if (p < size && cur < 0) { cur = 0.0; loc = p; }
+    delay[k] = loc;
+    corr[k] = cur;
+}
