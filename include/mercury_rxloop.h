@@ -25,7 +25,7 @@ extern "C" {
 
 typedef struct mgpu_receive_config {
     double carrier_hz;              /* carrier_frequency (physical_config.cc:84: bandwidth/2 + 300 + offset) */
-    int time_sync_trials_max;       /* physical_config.cc:85 (2) */
+    int time_sync_trials_max;       /* physical_config.cc:85 (2); 1..63 */
     int use_last_good_time_sync;    /* physical_config.cc:86 (YES) */
     int use_last_good_freq_offset;  /* physical_config.cc:87 (YES) */
     int coarse_freq_sync_enabled;   /* g_gui_state.coarse_freq_sync_enabled (gui_state.h:143, default false): +-30 Hz search before trial 1 */

@@ -248,7 +248,8 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {
         need(passband && rcp && payload && stats && W > 0 && W <= c->max_batch, "bad argument (W must be 1..max_batch)");
-        need(rcp->time_sync_trials_max >= 0 && rcp->time_sync_trials_max < 64, "time_sync_trials_max out of range");
+        need(rcp->time_sync_trials_max >= 1 && rcp->time_sync_trials_max < 64,
+             "time_sync_trials_max must be 1..63 (0 makes the reference index its peak table at -1)");
         const auto& t = c->tab;
         const int T = rcp->time_sync_trials_max;
         PhaseTimer pt;
