@@ -16,6 +16,9 @@ telecom_system.cc:155-198, and receive_byte, :1132-1345), and the reference's ou
 `--mfsk` writes golden_mfsk.{npz,json} for the three MFSK modes (cfg 100..102 = ROBUST_0..2): the
 M == MOD_MFSK branch of receive_byte (telecom_system.cc:1132-1192), full and short control frames.
 
+`--sync` writes golden_sync.json: every synchroniser block (passband_to_baseband, Schmidl-Cox coarse / fine with the k-th
+peak, Moose, time_sync_mfsk, the ACK / BREAK detector) of the compiled reference on one capture window per mode.
+
 Fixtures are DATA (inputs are regenerated from the recorded seeds; a digest of the input guards
 against generator drift). No reference source text is stored.
 """
@@ -125,8 +128,56 @@ def main_mfsk():
     print("wrote golden_mfsk.npz (%d arrays), golden_mfsk.json" % len(arrays))
 
 
+def sync_case(lib, cfg):
+    """One capture window through every synchroniser block of `lib` (RefLib when generating, Oracle when checking)."""
+    from oraclelib import CARRIER
+    rng = np.random.default_rng(7000 + cfg)
+    payload = rng.integers(0, 256, lib.payload_bytes)
+    pb = lib.tx_passband(lib.payload_to_bits(payload))
+    sym = lib.Nofdm * 4
+    n = 60 * sym if cfg < 100 else pb.size + 40 * sym
+    delay = 9 * sym + 321
+    win = rng.standard_normal(n) * 0.02
+    win[delay: delay + pb.size] += pb
+    rec = {"passband_sha256": digest(pb), "window_sha256": digest(win), "fir_taps": [digest(lib.fir_taps(0)), digest(lib.fir_taps(1))]}
+    bbi = lib.passband_to_baseband(win, CARRIER, 1, 0)
+    rec["p2b_time_sync_sha256"] = digest(bbi)
+    rec["p2b_data_sha256"] = digest(lib.passband_to_baseband(win, CARRIER + 3.0, 1, 1))
+    rec["p2b_data_decim4_sha256"] = digest(lib.passband_to_baseband(win[777:], CARRIER, 4, 1))
+    if cfg >= 100:
+        rec["mfsk_delay"] = [lib.time_sync_mfsk(bbi), lib.time_sync_mfsk(bbi, 12)]
+        rec["mfsk_preamble_sha256"] = digest(lib.mfsk_pattern(0))
+    else:
+        d, c = lib.time_sync_preamble(bbi, 100)
+        rec["coarse"] = [d, float(c).hex()]
+        ps = max(1, d // sym)
+        seg = bbi[(ps - 1) * sym: (ps - 1) * sym + (lib.preamble_nsymb + 4) * sym]
+        rec["fine"] = [[dd, float(cc).hex()] for dd, cc in (lib.time_sync_preamble(seg, 1, loc, 2) for loc in (0, 1, 2))]
+        fine = (ps - 1) * sym + rec["fine"][0][0]
+        bb = lib.passband_to_baseband(win, CARRIER, 1, 1)[fine::4]
+        rec["moose_hz"] = float(lib.freq_sync(bb[16:])).hex()
+        rec["preamble_sha256"] = digest(lib.preamble())
+    for which in (1, 2):
+        pat = np.repeat(lib.mfsk_pattern(which) / 16.0, 4)
+        buf = rng.standard_normal(40 * sym) * 0.5 + 1j * rng.standard_normal(40 * sym) * 0.5
+        buf[7 * sym: 7 * sym + pat.size] += pat
+        m, k = lib.detect_ack_pattern(buf, which)
+        rec["ack_%d" % which] = [float(m).hex(), k, digest(lib.mfsk_pattern(which))]
+    return rec
+
+
+def main_sync():
+    assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
+    meta = {str(cfg): sync_case(oraclelib.RefLib(cfg), cfg) for cfg in (8, 10, 16, 100, 101)}
+    with open(os.path.join(HERE, "golden_sync.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote golden_sync.json")
+
+
 if __name__ == "__main__":
-    if "--mfsk" in sys.argv:
+    if "--sync" in sys.argv:
+        main_sync()     # synchroniser blocks (SURVEY.md §8 row f1) and the MFSK sync / ACK detector
+    elif "--mfsk" in sys.argv:
         main_mfsk()     # separate fixture files: the OFDM fixtures are not regenerated
     else:
         main()

@@ -129,3 +129,15 @@ def test_mfsk_rx_chain_matches_reference_vectors(cfg):
         if rec["esn0_db"] == 60.0:
             assert r["crc"] == 0 and r["snr_db"] == 0.0 and np.array_equal(r["bytes"][: orc.payload_bytes], pl)
     orc.set_ctrl_mode(0)
+
+
+# ---- synchroniser blocks: fixtures from tests/golden/make_golden.py --sync (outputs of the compiled reference) ---------
+@pytest.mark.parametrize("cfg", [8, 10, 16, 100, 101])
+def test_sync_blocks_match_reference_vectors(cfg):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(HERE, "golden", "golden_sync.json")))[str(cfg)]
+    got = json.loads(json.dumps(mg.sync_case(oraclelib.Oracle(cfg), cfg)))          # same code path, the oracle as `lib`
+    assert got == want
