@@ -430,3 +430,31 @@ def test_single_frame_graph_path_equals_batched_path():
         again = rx.receive(bb)                     # the batched path still works after graph launches
         assert np.array_equal(again["payload"], batch["payload"]) and (again["stats"] == batch["stats"]).all()
     rx.close()
+
+
+def test_generator_and_receiver_are_invariant_to_how_frames_are_sharded():
+    """Frame-range sharding: frames are keyed by their global index, so generating / receiving them in one
+    call, in two halves or rank by rank (frame_range) gives identical samples, payloads and statistics."""
+    import torch
+    from mercury_amd.sharding import frame_range
+    cfg, F = 13, 96
+    rx = _rx(cfg, max_batch=F)
+    amp = noise_amp_for(OPERATING_ESN0[cfg] + 1.0)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(frame0, n):
+        bb = torch.empty((n, rx.frame_samples, 2), dtype=torch.float64, device="cuda")
+        sent = torch.empty((n, rx.payload_stride), dtype=torch.uint8, device="cuda")
+        got = torch.empty((n, rx.payload_stride), dtype=torch.uint8, device="cuda")
+        stats = torch.empty((n, 6), dtype=torch.int32, device="cuda")
+        rx.txgen_dev(SEED, frame0, n, amp, bb.data_ptr(), sent.data_ptr(), stream=st)
+        rx.receive_dev(bb.data_ptr(), n, got.data_ptr(), stats.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        return bb, sent, got, stats
+
+    whole = run(5000, F)
+    for world in (2, 3, 8):
+        parts = [run(5000 + frame_range(r, world, F)[0], frame_range(r, world, F)[1] - frame_range(r, world, F)[0]) for r in range(world)]
+        for i in range(4):
+            assert torch.equal(torch.cat([p[i] for p in parts]), whole[i]), (world, i)
+    rx.close()
