@@ -458,3 +458,59 @@ def test_generator_and_receiver_are_invariant_to_how_frames_are_sharded():
         for i in range(4):
             assert torch.equal(torch.cat([p[i] for p in parts]), whole[i]), (world, i)
     rx.close()
+
+
+def _load_graph(K):
+    """check -> variable lists of the rate with K information bits, from the library's derived table blob."""
+    import struct
+    blob = open(oraclelib.TABLES, "rb").read()
+    assert blob[:4] == b"MLDP"
+    nrates = struct.unpack_from("<I", blob, 8)[0]
+    off = 12
+    for _ in range(nrates):
+        k, P, N, E, cw, vw = struct.unpack_from("<6I", blob, off)
+        off += 24
+        cdeg = np.frombuffer(blob, np.uint8, P, off)
+        C = np.frombuffer(blob, np.uint16, E, off + P)
+        if k == K:
+            rows, e = [], 0
+            for d in cdeg:
+                rows.append(C[e: e + int(d)].astype(int))
+                e += int(d)
+            return rows, P, N
+        off += P + 2 * E + N + 2 * E
+    raise AssertionError("rate not in blob")
+
+
+@pytest.mark.parametrize("cfg,decoder", [(6, "spa"), (12, "spa"), (0, "spa"), (6, "minsum"), (12, "minsum")])
+def test_decoder_symmetry_under_codeword_sign_flips(cfg, decoder):
+    """Linearity of the code + sign symmetry of belief propagation: flipping the LLR signs along ANY codeword c turns the
+    decoder's output into output XOR c with the SAME iteration count — bit for bit, converged or not (tanh / atanh are odd
+    and IEEE rounding is symmetric). Size-independent property; c is built by IRA-encoding random information bits with
+    the graph from the library's table blob (ldpc.cc:111-132)."""
+    from mercury_amd import DEC_MINSUM, DEC_SPA
+    orc = Oracle(cfg, 50)
+    rows, P, N = _load_graph(orc.K)
+    K = orc.K
+    rng = np.random.default_rng(cfg)
+    F = 24
+    sigma = {6: 0.82, 12: 0.40, 0: 1.6}[cfg]
+    llr0 = (2.0 * (1.0 + sigma * rng.standard_normal((F, N))) / sigma ** 2).astype(np.float32)     # all-zero codeword + AWGN
+    llr0[-4:] = rng.standard_normal((4, N)).astype(np.float32)                                      # pure noise: never converges
+    cw = np.zeros((F, N), np.uint8)
+    cw[:, :K] = rng.integers(0, 2, (F, K))
+    for i in range(P):                                        # parity i = XOR of the other entries of check row i
+        acc = np.zeros(F, np.uint8)
+        for v in rows[i]:
+            if v != K + i:
+                acc ^= cw[:, v]
+        cw[:, K + i] = acc
+    for i in range(P):                                        # every check is satisfied: c is a codeword
+        assert not np.bitwise_xor.reduce(cw[:, rows[i]], axis=1).any()
+    rx = _rx(cfg, max_iters=50, decoder=DEC_SPA if decoder == "spa" else DEC_MINSUM, max_batch=F)
+    b0, i0 = rx.ldpc_decode(llr0)
+    b1, i1 = rx.ldpc_decode(llr0 * (1.0 - 2.0 * cw).astype(np.float32))
+    assert np.array_equal(i0, i1)
+    assert np.array_equal(b1, b0 ^ cw[:, :K])
+    assert (i0[:-4] <= 50).sum() >= F // 2 and (i0[-4:] == 51).all()       # both regimes are exercised
+    rx.close()
