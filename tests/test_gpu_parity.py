@@ -514,3 +514,55 @@ def test_decoder_symmetry_under_codeword_sign_flips(cfg, decoder):
     assert np.array_equal(b1, b0 ^ cw[:, :K])
     assert (i0[:-4] <= 50).sum() >= F // 2 and (i0[-4:] == 51).all()       # both regimes are exercised
     rx.close()
+
+
+def test_entry_points_reject_bad_arguments_without_crashing():
+    """Every entry point returns MGPU_ERR_ARG (1) with a message for null pointers, F / W beyond max_batch or negative
+    sizes, and MGPU_ERR_ARG / UNSUPPORTED for mode mismatches — never a crash, never exit() (the reference exits on bad
+    set-up, ldpc.cc:246-256)."""
+    import ctypes as C
+    from mercury_amd import load_library
+    lib = load_library()
+    rx = _rx(8, max_batch=4)
+    h = rx.h
+    buf = np.zeros(4 * rx.frame_samples * 2)
+    pay = np.zeros(4 * rx.payload_stride, np.uint8)
+    st = np.zeros(4 * 24, np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    calls = [
+        lambda: lib.mgpu_rx_batch(h, None, 1, p(pay), p(st), None),
+        lambda: lib.mgpu_rx_batch(h, p(buf), 5, p(pay), p(st), None),               # F > max_batch
+        lambda: lib.mgpu_rx_batch(h, p(buf), -1, p(pay), p(st), None),
+        lambda: lib.mgpu_ldpc_batch(h, None, 1, p(pay), p(st)),
+        lambda: lib.mgpu_ldpc_batch(h, p(buf), 9, p(pay), p(st)),
+        lambda: lib.mgpu_rx_batch_dev(h, None, 1, None, None, None, None),
+        lambda: lib.mgpu_frontend_dev(h, None, 1, None, None, None),
+        lambda: lib.mgpu_ldpc_batch_dev(h, None, 1, None, None, None, None, None, None),
+        lambda: lib.mgpu_txgen_dev(h, C.c_uint64(1), C.c_uint64(0), 1, C.c_double(0.1), 7, None, None, None),
+        lambda: lib.mgpu_passband_to_baseband(h, None, 1, 100, None, 0, None, 10, 1, None),
+        lambda: lib.mgpu_passband_to_baseband(h, p(buf), 1, 100, p(buf), 3, None, 10, 1, p(buf)),   # filter id
+        lambda: lib.mgpu_time_sync_preamble(h, p(buf), 1, 10, 1, 0, 1, p(st), None),                # window shorter than the preamble
+        lambda: lib.mgpu_freq_sync(h, p(buf), 1, 3, p(buf)),
+        lambda: lib.mgpu_time_sync_mfsk(h, p(buf), 1, 100000, 0, p(st)),                             # OFDM mode
+        lambda: lib.mgpu_detect_ack_pattern(h, p(buf), 1, 20000, 3, p(buf), None),                  # pattern id
+        lambda: lib.mgpu_receive_byte_batch(h, p(buf), 1, None, None, p(pay), p(st)),
+        lambda: lib.mgpu_receive_byte_batch(h, p(buf), 9, p(buf), None, p(pay), p(st)),
+        lambda: lib.mgpu_symbol_demod(h, None, 1, None),
+        lambda: lib.mgpu_psk_demod(h, None, 1, None, None),
+        lambda: lib.mgpu_deinterleaver_f32(h, p(buf), 1, 10, 20, p(buf)),                           # block larger than the vector
+        lambda: lib.mgpu_kernel_ms_avg(h, None, None),
+    ]
+    for i, call in enumerate(calls):
+        rc = call()
+        assert rc in (1, 4), (i, rc)
+        assert lib.mgpu_last_error(h), i
+    for fn in (lib.mgpu_get_info, lib.mgpu_enable_timing):
+        assert fn(None, None) == 1
+    lib.mgpu_destroy(None)                                        # no-op
+    out = rx.receive(np.zeros((1, rx.frame_samples), np.complex128))   # the context is still usable afterwards
+    assert out["stats"]["iterations_done"][0] == 0
+    mf = _rx(100, max_batch=1)
+    assert lib.mgpu_symbol_demod(mf.h, p(buf), 1, p(buf)) == 0     # plain FFT stage works in any mode
+    assert lib.mgpu_channel_estimator(mf.h, p(buf), 1, p(buf)) == 1   # the estimator stages exist for the OFDM modes only
+    mf.close()
+    rx.close()
