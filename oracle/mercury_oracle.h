@@ -4,11 +4,14 @@
  * that is only needed to make synthetic inputs).  It exists to CHECK the HIP implementation:
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
- * Parity status: PINNED.  The reference ships no golden vectors for this path,
- * so the restatement is pinned against the reference itself: oracle/_ref/libmercury_ref.so is
- * the reference's own DSP objects compiled from /root/reference (oracle/Makefile), and
- * tests/test_oracle_vs_ref.py + the committed fixtures in tests/golden/ (generated from that
- * build by tests/golden/make_golden.py) require bit-identical outputs for every stage.
+ * Parity status: PINNED for every DSP block (the RX path of the OFDM and MFSK modes, the TX chain, the synchroniser
+ * blocks, the ACK / BREAK detector).  The reference ships no golden vectors for this path, so the
+ * restatement is pinned against the reference itself: oracle/_ref/libmercury_ref.so is the reference's own DSP
+ * objects compiled from /root/reference (oracle/Makefile), and tests/test_oracle_vs_ref.py, tests/test_sync_blocks.py
+ * + the committed fixtures in tests/golden/ (golden_rx, golden_mfsk, golden_sync; generated from that build by
+ * tests/golden/make_golden.py) require bit-identical outputs for every stage.
+ * UNPINNED: morc_receive_byte, the restatement of receive_byte's control flow (telecom_system.cc cannot be built in
+ * this image); it calls only pinned blocks — see the comment at its declaration below.
  *
  * The struct layouts deliberately match oracle/ref_harness.cc (mref_*) so one test body can
  * drive either library.
