@@ -171,8 +171,8 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cfg", type=int, default=8)
     ap.add_argument("--frames", type=int, default=4096, help="frames per step per GPU")
     ap.add_argument("--iters", type=int, default=50)
