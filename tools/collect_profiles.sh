@@ -28,4 +28,5 @@ if [ "$1" = "sweep" ]; then
   python tests/tools/bench_receive_byte.py 8 1024 > "$OUT/bench_receive_byte_cfg8.json"
   python tests/tools/llr_error_table.py > "$OUT/llr_error_by_mode.json" 2>/dev/null || true
 fi
+python "$ROOT/tools/hbm_traffic_from_pmc.py" "$OUT" "$OUT" || true     # -> $OUT/hbm_traffic.json, r01_pmc_sq_summary.json
 ls -la "$OUT"
