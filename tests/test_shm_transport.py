@@ -245,3 +245,39 @@ def test_gpu_decoded_batch_reaches_a_reader_through_the_ring():
     reader.close()
     ring.close()
     rx.close()
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.skipif(not os.path.exists(RECEIVER), reason="reference example client not built")
+def test_batched_rx_shm_loop_feeds_the_unmodified_reference_client(tmp_path):
+    """examples/rx_shm_batch.cpp = RX_SHM_process_main batched, C-ABI only: passband capture windows in, decoded payloads out
+    through /mercury-comm, where the reference's own examples/receiver.c (unmodified) picks them up."""
+    from test_receive_byte import make_windows
+    from mercury_amd import ShmRing
+    exe = tmp_path / "rx_shm_batch"
+    lib = os.path.join(ROOT, "mercury_amd")
+    subprocess.run(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "rx_shm_batch.cpp"),
+                    "-o", str(exe), "-L", lib, "-lmercury_gpu", "-Wl,-rpath," + lib, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    cfg = 8
+    orc = oraclelib.Oracle(cfg)
+    specs = [("frame", 7 * 1088 + 333, 0.01, 1), ("silence", 0, 1e-9, 2), ("frame", 20 * 1088 + 17, 0.02, 3), ("noise", 0, 0.3, 4),
+             ("frame", 12 * 1088 + 5, 0.01, 5), ("frame", 30 * 1088, 0.02, 6), ("frame", 9 * 1088 + 100, 0.01, 7)]
+    wins, pls = make_windows(orc, specs, seed=123)
+    (tmp_path / "windows.f64").write_bytes(wins.tobytes())
+    want = b"".join(pls[i].astype(np.uint8).tobytes() for i, s in enumerate(specs) if s[0] == "frame")
+    ring = ShmRing("/mercury-comm", 131072)                # Mercury's ring; the program attaches to it
+    outfile = tmp_path / "rx.bin"
+    client = subprocess.Popen([RECEIVER, str(outfile)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        r = subprocess.run([str(exe), str(cfg), str(tmp_path / "windows.f64"), "3"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "7 windows, 5 decoded, 0 lost" in r.stdout, r.stdout
+        deadline = time.time() + 10
+        while time.time() < deadline and (not outfile.exists() or outfile.stat().st_size < len(want)):
+            time.sleep(0.05)
+        assert outfile.read_bytes() == want
+    finally:
+        client.kill()
+        client.wait()
+        ring.close()
