@@ -318,6 +318,9 @@ def main():
                                  "traffic is far lower; the decoder is VALU-issue bound (profiles/r01_pmc_sq_*.csv: SQ_ACTIVE_INST_VALU "
                                  "~99% of SIMD cycles for spa, fp64), not HBM bound"},
         }
+        # the outputs of the last timed step, kept aside before the extras reuse the buffers: the cpu_baseline leg checks them
+        S_chk = min(F, args.cpu_sample_per_core * usable_cores())
+        payload_chk, stats_chk = payload[:S_chk].cpu().numpy().copy(), stats[:S_chk].cpu().numpy().copy()
         if not args.no_extras and not args.ldpc_only:
             line["extras_per_gpu"] = extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp)
         if world == 1 and not args.no_cpu_baseline and not args.ldpc_only:
@@ -328,9 +331,9 @@ def main():
             import oraclelib
             flags = oraclelib.FLAGS_RECEIVE_BYTE if args.variant == "receive_byte" else oraclelib.FLAGS_BASEBAND_TEST
             if args.decoder == "spa":
-                line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload[:S].cpu().numpy(), stats[:S].cpu().numpy())
+                line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload_chk, stats_chk)
             else:
-                line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload[:S].cpu().numpy(), stats[:S].cpu().numpy())
+                line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload_chk, stats_chk)
                 line["cpu_baseline"]["note"] = "CPU runs the reference's sum-product decoder; mismatches vs %s are expected on non-converged frames" % args.decoder
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
             # the same call through the host-buffer entry point (pageable host memory -> H2D, kernels, D2H): never `value`
