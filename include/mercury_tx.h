@@ -1,0 +1,61 @@
+/* mercury_tx.h — cl_telecom_system::transmit_byte, batched (the TX mirror taken to the audio samples).
+ *
+ * void cl_telecom_system::transmit_byte(int* data, int nBytes, double* out, int message_location)
+ * (include/physical_layer/telecom_system.h, source/physical_layer/telecom_system.cc:342-382) pads the message to the frame,
+ * appends the CRC and calls transmit_bit (:384-556): bit energy dispersal, LDPC encode, bit interleave, PSK/QAM map (or MFSK
+ * tone select), time/frequency interleave, framer (pilots), IFFT + guard interval, preamble in front, power scaling,
+ * x4 linear interpolation + mixer to the carrier (cl_ofdm::baseband_to_passband, ofdm.cc:2294-2315), peak_clip of the
+ * preamble and data parts (:1565-1592) and, for SINGLE_MESSAGE, the two transmit filters FIR_tx1 / FIR_tx2
+ * (fir_filter.cc:189-210). mgpu_transmit_byte_batch does that for F messages at once, every step on the GPU.
+ *
+ * Parity: pinned. The same composition built from the reference's own objects (oracle/ref_harness.cc:mref_transmit_byte)
+ * fixes the CPU restatement bit for bit, and the GPU output must equal it bit for bit (tests/test_transmit_byte.py).
+ * Not built: the FIRST/MIDDLE/FLUSH_MESSAGE overlap-save variants (:559-590) that filter across consecutive frames, and
+ * pre_equalization_channel (all ones unless a GUI calibration sets it).
+ */
+#ifndef MERCURY_TX_H
+#define MERCURY_TX_H
+
+#include <stdint.h>
+
+#include "mercury_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGPU_SINGLE_MESSAGE 3      /* include/common/common_defines.h:200 */
+#define MGPU_NO_FILTER_MESSAGE 4   /* :201 — stop after peak_clip (what the ARQ batch sender asks for, arq_common.cc:2224) */
+
+typedef struct mgpu_transmit_config {
+    double carrier_hz;          /* carrier_frequency (+ test_tx_carrier_offset); physical_config.cc:84 */
+    double carrier_amplitude;   /* telecom_system.cc:69: sqrt(2) */
+    double output_power_watt;   /* physical_config.cc:88: 0.1 */
+    double preamble_papr_cut;   /* physical_config.cc:115: 7 (dB) */
+    double data_papr_cut;       /* :116: 10 (dB) */
+    uint64_t start_sample;      /* cl_ofdm::passband_start_sample when the call starts: the carrier phase origin (ofdm.cc:2311-2313) */
+    int message_location;       /* MGPU_SINGLE_MESSAGE or MGPU_NO_FILTER_MESSAGE */
+    int phase_continuous;       /* 0: every message starts at start_sample (F independent transmitters);
+                                   1: message f starts at start_sample + f * (active samples), as F consecutive calls would */
+} mgpu_transmit_config;
+
+/* total_frame_size = Nofdm * (Nsymb + preamble_nSymb) * 4 (data_container.cc:159): samples written per message */
+int mgpu_transmit_frame_samples(mgpu_ctx* ctx);
+
+/* payload: [F] rows of payload_stride bytes, the message in the first nbytes[f] (NULL: payload_bytes) of each; longer than
+ * payload_bytes is an error ("message too long.. not sent."). passband: [F][total_frame_size] doubles; behind a short MFSK
+ * control frame the row is zero. Host buffers, blocking. */
+int mgpu_transmit_byte_batch(mgpu_ctx* ctx, const uint8_t* payload, int payload_stride, const int* nbytes, int F,
+                             const mgpu_transmit_config* config, double* passband);
+/* the same on device buffers, launched on `stream` (NULL = the context's own stream); returns when the samples are written
+ * (the per-call work buffers are released on return) */
+int mgpu_transmit_byte_batch_dev(mgpu_ctx* ctx, const void* d_payload, int payload_stride, const void* d_nbytes, int F,
+                                 const mgpu_transmit_config* config, void* d_passband, void* stream);
+
+/* cl_ofdm::symbol_mod (ofdm.cc:855-860: zero_padder, unnormalised IFFT, gi_adder): [n][Nc] carriers -> [n][Nofdm] samples */
+int mgpu_symbol_mod(mgpu_ctx* ctx, const double* carriers_c128, int n_symbols, double* out_c128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

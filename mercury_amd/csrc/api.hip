@@ -322,6 +322,7 @@ void mgpu_destroy(mgpu_ctx* c) {
     (void)hipFree(c->d_baseband); (void)hipFree(c->d_llr); (void)hipFree(c->d_variance); (void)hipFree(c->d_snrvar);
     (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters); (void)hipFree(c->d_eqdata);
     if (c->rxloop_ws && c->rxloop_ws_free) c->rxloop_ws_free(c->rxloop_ws);
+    if (c->tx_state && c->tx_state_free) c->tx_state_free(c->tx_state);
     if (c->one_frame_graph) (void)hipGraphExecDestroy(c->one_frame_graph);
     if (c->h_one_in) (void)hipHostFree(c->h_one_in);
     if (c->h_one_out) (void)hipHostFree(c->h_one_out);
@@ -436,7 +437,8 @@ int mgpu_txgen_dev(mgpu_ctx* c, uint64_t seed, uint64_t frame0, int F, double no
             const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
             hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(n), dim3(256), c->lds_tx, static_cast<hipStream_t>(stream), c->dev, seed,
                                frame0 + uint64_t(off), n, noise_amp, channel, static_cast<double*>(d_bb) + size_t(off) * c->tab.frame_samples * 2,
-                               at(static_cast<uint8_t*>(d_payload_opt), size_t(off) * c->tab.payload_stride));
+                               at(static_cast<uint8_t*>(d_payload_opt), size_t(off) * c->tab.payload_stride),
+                               static_cast<const uint8_t*>(nullptr), 0, static_cast<const int*>(nullptr), 0, 0);
             HIPCK(hipGetLastError());
         }
     });

@@ -222,6 +222,36 @@ static std::vector<double> design_lpf_hamming(double transition_bw, double cut, 
     return c;
 }
 
+// cl_FIR::design (fir_filter.cc:45-162) for the two transmit filters, parameters of physical_config.cc:103-113:
+// FIR_tx1 = high-pass at carrier - bandwidth/2 (spectral inversion of the low-pass), Hamming window;
+// FIR_tx2 = low-pass at carrier + bandwidth/2, Blackman window; both with a 1 kHz transition band (97 taps at 48 kHz).
+std::vector<double> design_tx_fir(int which, double carrier_hz) {
+    const double bandwidth = 48000.0 * 50.0 / 256 / 4, fs = 48000.0, transition_bw = 1000.0;
+    const bool hpf = which == 0;
+    const double cut = hpf ? carrier_hz - bandwidth / 2 : carrier_hz + bandwidth / 2;
+    int n = int(4.0 / (transition_bw / (fs / 2.0)));
+    if (n % 2 == 0) ++n;
+    std::vector<double> c(n);
+    const double Ts = 1.0 / fs;
+    c[n / 2] = 1;
+    for (int i = 0; i < n / 2; ++i) {
+        const double temp = 2 * M_PI * cut * double(n / 2 - i) * Ts;
+        c[i] = std::sin(temp) / temp;
+        c[n - i - 1] = c[i];
+    }
+    double sum = 0;
+    for (int i = 0; i < n; ++i) sum += c[i];
+    for (int i = 0; i < n; ++i) c[i] /= sum;
+    if (hpf) {
+        for (int i = 0; i < n; ++i) c[i] *= -1;
+        c[(n - 1) / 2] += 1;
+        for (int i = 0; i < n; ++i) c[i] *= 0.54 - 0.46 * std::cos(2.0 * M_PI * double(i) / (n - 1));
+    } else {
+        for (int i = 0; i < n; ++i) c[i] *= 0.42 - 0.5 * std::cos(2.0 * M_PI * double(i) / n) + 0.08 * std::cos(4.0 * M_PI * double(i) / n);
+    }
+    return c;
+}
+
 ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, size_t blob_size) {
     const bool robust = cfg >= 100 && cfg <= 102;                             // common_defines.h:63-65
     if (!robust && (cfg < 0 || cfg > 16)) throw std::runtime_error("cfg must be 0..16 (OFDM) or 100..102 (ROBUST MFSK)");
@@ -339,6 +369,26 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
     for (int i = 0; i < t.nBits; ++i) t.bit_il[bd[i]] = uint16_t(i);  // interleaver is the inverse gather: out[bd[i]] = in[i]
     t.sym_cell.resize(t.nData);
     for (int k = 0; k < t.nData; ++k) t.sym_cell[k] = t.sym_src[k];   // symbol k lands where the RX reads it back
+    // ---- preamble carriers (transmit path): the mode's known symbols in front of every frame ----
+    t.preamble_carriers.assign(size_t(t.preamble) * t.Nc, Cplx{0.0, 0.0});
+    if (t.mfsk_M > 0) {                 // cl_mfsk::generate_preamble, mfsk.cc:172-193; tones :82-95
+        static constexpr int kTones32[4] = {4, 20, 12, 28}, kTones16[4] = {2, 10, 6, 14};
+        const int* tones = t.mfsk_M == 32 ? kTones32 : kTones16;
+        for (int s = 0; s < t.preamble; ++s)
+            for (int st = 0; st < t.mfsk_nstreams; ++st) t.preamble_carriers[size_t(s) * t.Nc + t.mfsk_off[st] + tones[s % 4]] = Cplx{t.mfsk_amp, 0.0};
+    } else {                            // cl_preamble_configurator::configure + init, ofdm.cc:1127-1232 (QPSK, seed 1, telecom_system.cc:2837-2841)
+        GlibcRandom rng(1);
+        const double s2 = std::sqrt(2.0);
+        for (int i = 0; i < t.preamble; ++i)
+            for (int j = 0; j < t.Nc; ++j) {
+                const int bin = j < t.Nc / 2 ? j + t.Nfft - t.Nc / 2 : j - t.Nc / 2 + 1;    // zero_padder placement, start_shift = 1
+                if (bin % 2 == 1) continue;                                               // odd FFT bins stay empty: two identical halves in time
+                // std::complex<double>(2*(__random()%2)-1, 2*(__random()%2)-1): the reference's compiler draws the imaginary part first
+                const int im = 2 * (rng.next() % 2) - 1;
+                const int re = 2 * (rng.next() % 2) - 1;
+                t.preamble_carriers[size_t(i) * t.Nc + j] = Cplx{double(re) / s2, double(im) / s2};
+            }
+    }
     {   // physical_config.cc:80,90-98 ; telecom_system.cc:1569,1910-1922
         const double bandwidth = 48000.0 * 50.0 / 256 / 4, fs = 48000.0;
         t.fir_time_sync = design_lpf_hamming(3000.0, 0.9 * bandwidth / 2, fs);

@@ -10,6 +10,8 @@
 //   FFT twiddles .......... ofdm.cc:256-290
 //   interleavers .......... interleaver.cc:77-109 ; re-pack telecom_system.cc:1300-1308
 //   scrambler ............. telecom_system.cc:1961-1966
+//   preamble .............. ofdm.cc:1127-1232 ; MFSK mfsk.cc:82-95, :172-193
+//   transmit filters ...... fir_filter.cc:45-162, physical_config.cc:103-113
 //   LDPC graph ............ mercury_normal_*_16.cc via mercury_ldpc_tables.bin (derived data)
 #pragma once
 #include <cstdint>
@@ -73,6 +75,7 @@ struct ModeTables {
     std::vector<uint16_t> tf_inv;           // [nData] symbol k with tf-deinterleave source i (inverse of the RX gather)
     std::vector<uint16_t> data_cell;        // [nData] grid cell of de-framed position i (deframer order)
     std::vector<uint16_t> sym_cell;         // [nData] grid cell of modulated symbol k (tf-interleave + framer)
+    std::vector<Cplx> preamble_carriers;    // [preamble][Nc] known symbols sent in front of the frame (ofdm.cc:1127-1232; MFSK: mfsk.cc:172-193)
     LdpcGraph graph;
 };
 
@@ -80,5 +83,8 @@ struct ModeTables {
 ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* ldpc_blob, size_t ldpc_blob_size);
 
 uint16_t crc16_modbus(const uint8_t* bytes, int n);
+
+// transmit filters for a given carrier: which 0 = FIR_tx1 (HPF, Hamming), 1 = FIR_tx2 (LPF, Blackman); physical_config.cc:103-113
+std::vector<double> design_tx_fir(int which, double carrier_hz);
 
 }  // namespace mgpu

@@ -1,0 +1,314 @@
+// transmit_byte on the GPU: kernels behind include/mercury_tx.h and their host entry points.
+//
+//   payload --txgen kernel (txgen.hip: CRC .. IFFT+GI, caller's bytes instead of the generator's)--> data baseband
+//   preamble carriers --symbol_mod kernel (once per context)--> preamble baseband
+//   both --tx_mix kernel: power scaling, x4 linear interpolation, mixer--> passband
+//   --peak_clip kernel (preamble part, data part)--> --fir kernel x2 (SINGLE_MESSAGE)--> out
+//
+// Everything is FP64 in the reference's operation order (no FMA contraction in this TU), so the samples equal the
+// reference's bit for bit; the carrier cos/sin and the two pow() constants come from the host libm like the reference's.
+#include <cmath>
+#include <map>
+
+#include "ctx.hpp"
+#include "fft256.h"
+#include "../../include/mercury_tx.h"
+
+// cl_ofdm::symbol_mod (ofdm.cc:855-860), one wavefront per symbol
+extern "C" __global__ __launch_bounds__(256) void mgpu_symbol_mod_kernel(const double* __restrict__ twiddle, const double* __restrict__ carriers,
+                                                                       int n, double* __restrict__ out) {
+    __shared__ c2 fftb[4 * FFT256_STRIDE];
+    __shared__ c2 tw[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 128; i += 256) tw[i] = {twiddle[2 * i], -twiddle[2 * i + 1]};       // conjugated: IFFT (ofdm.cc:365)
+    __syncthreads();
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= n) return;
+    const c2* in = reinterpret_cast<const c2*>(carriers) + size_t(s) * 50;
+    auto carrier = [&](int i) -> c2 {                    // zero_padder (ofdm.cc:379-400)
+        const int col = carrier_of_bin(i);
+        return col < 0 ? c2{0.0, 0.0} : in[col];
+    };
+    c2 r0 = carrier(lane), r1 = carrier(lane + 64), r2 = carrier(lane + 128), r3 = carrier(lane + 192);
+    wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
+    c2* y = reinterpret_cast<c2*>(out) + size_t(s) * 272;
+    auto emit = [&](const c2& x, int p) {                // gi_adder (ofdm.cc:412-422)
+        const int k = brev8(p);
+        y[k + 16] = x;
+        if (k >= 240) y[k - 240] = x;
+    };
+    emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
+}
+
+// Power scaling (telecom_system.cc:517-527), rational_resampler INTERPOLATION (ofdm.cc:2279-2291, interpolate_linear
+// interpolator.cc:43-50) and the mixer (ofdm.cc:2309-2314), one thread per passband sample. The preamble and the data part
+// are interpolated separately (two baseband_to_passband calls, :531-532), each extrapolating its own last sample.
+//   pre_bb  [npre]            preamble baseband, shared by every frame
+//   data_bb [F][data_stride]  data baseband (the first ndata samples of each row)
+//   cs      [..][2]           cos / sin of the carrier phase for sample cs_frame_stride * f + n
+extern "C" __global__ __launch_bounds__(256) void mgpu_tx_mix_kernel(
+    const double* __restrict__ pre_bb, int npre, const double* __restrict__ data_bb, int data_stride, int ndata, double pn, double m_pre,
+    double m_data, double amplitude, const double* __restrict__ cs, int cs_frame_stride, double* __restrict__ out, int total) {
+    const int f = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= total) return;
+    double* o = out + size_t(f) * total;
+    const int used = (npre + ndata) * 4;
+    if (n >= used) { o[n] = 0.0; return; }
+    const bool in_pre = n < npre * 4;
+    const c2* in = in_pre ? reinterpret_cast<const c2*>(pre_bb) : reinterpret_cast<const c2*>(data_bb) + size_t(f) * data_stride;
+    const int cnt = in_pre ? npre : ndata, k = in_pre ? n : n - npre * 4, i = k >> 2, j = k & 3;
+    const double m = in_pre ? m_pre : m_data;
+    const bool last = i == cnt - 1;
+    const c2 xa = in[last ? cnt - 2 : i], xb = in[last ? cnt - 1 : i + 1];
+    const c2 a = {(xa.re / pn) * m, (xa.im / pn) * m}, b = {(xb.re / pn) * m, (xb.im / pn) * m};
+    const double x = double(last ? 4 + j : j);
+    const c2 v = {a.re + ((b.re - a.re) * x) / 4.0, a.im + ((b.im - a.im) * x) / 4.0};
+    const double* c = cs + 2 * (size_t(cs_frame_stride) * f + n);
+    double y = v.re * amplitude * c[0];
+    y += v.im * amplitude * c[1];
+    o[n] = y;
+}
+
+// cl_ofdm::peak_clip (ofdm.cc:1565-1592) on one segment of every frame: blockIdx.y = 0 the preamble part, 1 the data part.
+// The mean power is a sum in sample order: terms formed in parallel a chunk at a time, one lane adds them.
+#define PC_CHUNK 4096
+extern "C" __global__ __launch_bounds__(256) void mgpu_peak_clip_kernel(double* __restrict__ x, int total, int npre4, int used, double pow_pre,
+                                                                      double pow_data) {
+    __shared__ double term[PC_CHUNK];
+    __shared__ double peak_s;
+    const int seg = blockIdx.y;
+    double* p = x + size_t(blockIdx.x) * total + (seg ? npre4 : 0);
+    const int n = seg ? used - npre4 : npre4;
+    double acc = 0.0;
+    for (int base = 0; base < n; base += PC_CHUNK) {
+        const int m = min(PC_CHUNK, n - base);
+        for (int i = threadIdx.x; i < m; i += 256) { const double v = p[base + i]; term[i] = v * v; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int q = 0;
+            for (; q + 8 <= m; q += 8) {
+                const double a0 = term[q], a1 = term[q + 1], a2 = term[q + 2], a3 = term[q + 3];
+                const double a4 = term[q + 4], a5 = term[q + 5], a6 = term[q + 6], a7 = term[q + 7];
+                acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+            }
+            for (; q < m; ++q) acc += term[q];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) peak_s = sqrt((acc / double(n)) * (seg ? pow_data : pow_pre));
+    __syncthreads();
+    const double peak = peak_s;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double v = p[i];
+        if (v > 0 && v > peak) v = peak;
+        if (v < 0 && v < -peak) v = -peak;
+        p[i] = v;
+    }
+}
+
+// cl_FIR::apply(double*) (fir_filter.cc:189-210): out[i] = sum_j in[i + h - j] * c[j] over the taps whose sample exists,
+// added in tap order. 256 outputs per workgroup from an LDS tile of 256 + ntaps - 1 inputs.
+extern "C" __global__ __launch_bounds__(256) void mgpu_fir_real_kernel(const double* __restrict__ in, int n, const double* __restrict__ taps,
+                                                                     int nt, double* __restrict__ out) {
+    extern __shared__ double fir_s[];
+    double* tile = fir_s;                       // in[i0 + h - (nt-1) .. i0 + h + 255]
+    double* c = fir_s + 256 + nt - 1;
+    const int h = (nt - 1) / 2, i0 = blockIdx.x * 256, lo = i0 + h - (nt - 1);
+    const double* x = in + size_t(blockIdx.y) * n;
+    for (int k = threadIdx.x; k < 256 + nt - 1; k += 256) { const int q = lo + k; tile[k] = (q >= 0 && q < n) ? x[q] : 0.0; }
+    for (int k = threadIdx.x; k < nt; k += 256) c[k] = taps[k];
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int j = 0; j < nt; ++j) {
+        const int q = i + h - j;
+        if (q >= 0 && q < n) acc += tile[q - lo] * c[j];
+    }
+    out[size_t(blockIdx.y) * n + i] = acc;
+}
+
+using namespace mgpu_detail;
+
+namespace {
+
+// per-context transmit state: preamble baseband, filter taps and carrier table for the last carrier / phase origin used
+struct TxState {
+    double* d_pre_bb = nullptr;
+    double carrier = -1;
+    double* d_fir[2] = {nullptr, nullptr};
+    int ntaps[2] = {0, 0};
+    double* d_cs = nullptr;
+    size_t cs_cap = 0;
+    double cs_carrier = -1;
+    uint64_t cs_start = 0;
+    size_t cs_count = 0;
+    ~TxState() {
+        (void)hipFree(d_pre_bb); (void)hipFree(d_fir[0]); (void)hipFree(d_fir[1]); (void)hipFree(d_cs);
+    }
+};
+void free_tx_state(void* p) { delete static_cast<TxState*>(p); }
+
+void launch_symbol_mod(mgpu_ctx* c, const double* d_carriers, int n, double* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(mgpu_symbol_mod_kernel, dim3((n + 3) / 4), dim3(256), 0, s, c->dev.twiddle, d_carriers, n, d_out);
+    HIPCK(hipGetLastError());
+}
+
+TxState& tx_state(mgpu_ctx* c, hipStream_t s) {
+    if (!c->tx_state) {
+        auto* st = new TxState;
+        c->tx_state = st;
+        c->tx_state_free = free_tx_state;
+        const auto& t = c->tab;
+        DevBuf d_car(t.preamble_carriers.size() * 16);
+        HIPCK(hipMemcpyAsync(d_car.p, t.preamble_carriers.data(), t.preamble_carriers.size() * 16, hipMemcpyHostToDevice, s));
+        HIPCK(hipMalloc(reinterpret_cast<void**>(&st->d_pre_bb), size_t(t.preamble) * t.Nofdm * 16));
+        launch_symbol_mod(c, d_car.as<double>(), t.preamble, st->d_pre_bb, s);
+        HIPCK(hipStreamSynchronize(s));
+    }
+    return *static_cast<TxState*>(c->tx_state);
+}
+
+void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, const int* d_nbytes, int F, const mgpu_transmit_config& cfg,
+                  double* d_out, hipStream_t s) {
+    const auto& t = c->tab;
+    const int interp = 4, npre = t.preamble * t.Nofdm, ndata = t.active_nsymb * t.Nofdm, total = t.Nofdm * (t.Nsymb + t.preamble) * interp;
+    const int used = (npre + ndata) * interp;
+    TxState& st = tx_state(c, s);
+    // carrier table from the host libm, as the reference evaluates it: cos / sin(2*M_PI*fc*(double)n*Ts), n from start_sample
+    const size_t cs_count = cfg.phase_continuous ? size_t(used) * F : size_t(used);
+    if (st.cs_carrier != cfg.carrier_hz || st.cs_start != cfg.start_sample || st.cs_count < cs_count) {
+        std::vector<double> cs(2 * cs_count);
+        const double Ts = 1.0 / kSampleRate;
+        for (size_t n = 0; n < cs_count; ++n) {
+            const unsigned long k = static_cast<unsigned long>(cfg.start_sample + n);
+            // the reference's build evaluates cos and sin of this one phase as a single sincos() call (the compiler
+            // merges them); glibc's sincos is not bit-for-bit its cos + sin, so the same call is made here
+            ::sincos(2 * M_PI * cfg.carrier_hz * double(k) * Ts, &cs[2 * n + 1], &cs[2 * n]);
+        }
+        HIPCK(hipStreamSynchronize(s));                      // nothing in flight still reads the old table
+        if (st.cs_cap < cs.size()) {
+            (void)hipFree(st.d_cs);
+            st.d_cs = nullptr;
+            HIPCK(hipMalloc(reinterpret_cast<void**>(&st.d_cs), cs.size() * 8));
+            st.cs_cap = cs.size();
+        }
+        HIPCK(hipMemcpy(st.d_cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
+        st.cs_carrier = cfg.carrier_hz; st.cs_start = cfg.start_sample; st.cs_count = cs_count;
+    }
+    const bool filtered = cfg.message_location == MGPU_SINGLE_MESSAGE;
+    if (filtered && st.carrier != cfg.carrier_hz) {
+        HIPCK(hipStreamSynchronize(s));
+        for (int w = 0; w < 2; ++w) {
+            const std::vector<double> taps = mgpu::design_tx_fir(w, cfg.carrier_hz);
+            (void)hipFree(st.d_fir[w]);
+            st.d_fir[w] = nullptr;
+            HIPCK(hipMalloc(reinterpret_cast<void**>(&st.d_fir[w]), taps.size() * 8));
+            HIPCK(hipMemcpy(st.d_fir[w], taps.data(), taps.size() * 8, hipMemcpyHostToDevice));
+            st.ntaps[w] = int(taps.size());
+        }
+        st.carrier = cfg.carrier_hz;
+    }
+    // scaling constants in the reference's types and order (telecom_system.cc:388, :506-527)
+    const float power_normalization = std::sqrt(double(t.Nfft * interp));
+    const double mfsk_boost = t.mfsk_M > 0 ? std::sqrt(double(t.Nc) / t.mfsk_nstreams) * std::pow(10.0, -2.0 / 20.0) : 1.0;
+    const double pw = std::sqrt(cfg.output_power_watt), preamble_boost = std::sqrt(2.0);          // telecom_system.cc:2840
+    const double m_pre = pw * preamble_boost * mfsk_boost, m_data = pw * mfsk_boost;
+    const double pow_pre = std::pow(10, cfg.preamble_papr_cut / 10.0), pow_data = std::pow(10, cfg.data_papr_cut / 10.0);
+
+    DevBuf d_bb(size_t(F) * t.frame_samples * 16), d_t0(filtered ? size_t(F) * total * 8 : 0), d_t1(filtered ? size_t(F) * total * 8 : 0);
+    double* clipped = filtered ? d_t0.as<double>() : d_out;
+    for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
+        const int n = std::min(F - off, kMaxFramesPerLaunch);
+        hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(n), dim3(256), c->lds_tx, s, c->dev, uint64_t(0), uint64_t(0), n, 0.0, -1,
+                           d_bb.as<double>() + size_t(off) * t.frame_samples * 2, static_cast<uint8_t*>(nullptr),
+                           d_payload + size_t(off) * payload_stride, payload_stride, at(d_nbytes, size_t(off)), 0, 0);
+        HIPCK(hipGetLastError());
+    }
+    const int kMaxY = 32768;                                   // gridDim.y limit is 65535
+    for (int off = 0; off < F; off += kMaxY) {
+        const int n = std::min(F - off, kMaxY);
+        double* o = clipped + size_t(off) * total;
+        hipLaunchKernelGGL(mgpu_tx_mix_kernel, dim3((total + 255) / 256, n), dim3(256), 0, s, st.d_pre_bb, npre,
+                           d_bb.as<double>() + size_t(off) * t.frame_samples * 2, t.frame_samples, ndata, double(power_normalization), m_pre, m_data,
+                           cfg.carrier_amplitude, st.d_cs + (cfg.phase_continuous ? 2 * size_t(used) * off : 0), cfg.phase_continuous ? used : 0,
+                           o, total);
+        HIPCK(hipGetLastError());
+        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(n, 2), dim3(256), 0, s, o, total, npre * interp, used, pow_pre, pow_data);
+        HIPCK(hipGetLastError());
+        if (filtered) {
+            double* t1 = d_t1.as<double>() + size_t(off) * total;
+            for (int w = 0; w < 2; ++w) {
+                const size_t lds = size_t(256 + 2 * st.ntaps[w] - 1) * 8;
+                hipLaunchKernelGGL(mgpu_fir_real_kernel, dim3((total + 255) / 256, n), dim3(256), lds, s, w ? t1 : o, total, st.d_fir[w], st.ntaps[w],
+                                   w ? d_out + size_t(off) * total : t1);
+                HIPCK(hipGetLastError());
+            }
+        }
+    }
+    HIPCK(hipStreamSynchronize(s));                            // the work buffers above are released on return
+}
+
+void check_config(const mgpu_ctx* c, const mgpu_transmit_config* cfg, int payload_stride, int F) {
+    need(cfg != nullptr && F >= 0, "bad argument");
+    need(cfg->message_location == MGPU_SINGLE_MESSAGE || cfg->message_location == MGPU_NO_FILTER_MESSAGE,
+         "message_location must be MGPU_SINGLE_MESSAGE or MGPU_NO_FILTER_MESSAGE");
+    need(payload_stride >= c->tab.payload_bytes, "payload_stride is shorter than the frame's payload");
+    need(cfg->carrier_hz > 0 && cfg->carrier_hz < kSampleRate / 2 && cfg->output_power_watt >= 0, "bad carrier or power");
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgpu_transmit_frame_samples(mgpu_ctx* c) {
+    return c ? c->tab.Nofdm * (c->tab.Nsymb + c->tab.preamble) * 4 : MGPU_ERR_ARG;
+}
+
+int mgpu_transmit_byte_batch_dev(mgpu_ctx* c, const void* d_payload, int payload_stride, const void* d_nbytes, int F,
+                                 const mgpu_transmit_config* cfg, void* d_passband, void* stream) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        check_config(c, cfg, payload_stride, F);
+        need(d_payload && d_passband, "bad argument");
+        if (F == 0) return;
+        transmit_dev(c, static_cast<const uint8_t*>(d_payload), payload_stride, static_cast<const int*>(d_nbytes), F, *cfg,
+                     static_cast<double*>(d_passband), stream ? static_cast<hipStream_t>(stream) : c->stream);
+    });
+}
+
+int mgpu_transmit_byte_batch(mgpu_ctx* c, const uint8_t* payload, int payload_stride, const int* nbytes, int F, const mgpu_transmit_config* cfg,
+                             double* passband) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        check_config(c, cfg, payload_stride, F);
+        need(payload && passband, "bad argument");
+        if (F == 0) return;
+        if (nbytes)
+            for (int f = 0; f < F; ++f) need(nbytes[f] >= 0 && nbytes[f] <= c->tab.payload_bytes, "message too long");
+        const size_t total = size_t(mgpu_transmit_frame_samples(c));
+        DevBuf d_pl(size_t(F) * payload_stride), d_nb(size_t(F) * 4), d_out(size_t(F) * total * 8);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_pl.p, payload, size_t(F) * payload_stride, hipMemcpyHostToDevice, s));
+        if (nbytes) HIPCK(hipMemcpyAsync(d_nb.p, nbytes, size_t(F) * 4, hipMemcpyHostToDevice, s));
+        transmit_dev(c, d_pl.as<uint8_t>(), payload_stride, nbytes ? d_nb.as<int>() : nullptr, F, *cfg, d_out.as<double>(), s);
+        HIPCK(hipMemcpyAsync(passband, d_out.p, size_t(F) * total * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+int mgpu_symbol_mod(mgpu_ctx* c, const double* carriers, int n, double* out) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(carriers && out && n >= 0, "bad argument");
+        if (n == 0) return;
+        DevBuf d_in(size_t(n) * c->tab.Nc * 16), d_out(size_t(n) * c->tab.Nofdm * 16);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_in.p, carriers, size_t(n) * c->tab.Nc * 16, hipMemcpyHostToDevice, s));
+        launch_symbol_mod(c, d_in.as<double>(), n, d_out.as<double>(), s);
+        HIPCK(hipMemcpyAsync(out, d_out.p, size_t(n) * c->tab.Nofdm * 16, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+}  // extern "C"

@@ -44,7 +44,8 @@ extern "C" size_t mgpu_txgen_lds_bytes(int G) { return 4 * 1600 + size_t(16) * G
 
 extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
     MgpuDev T, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel,
-    double* __restrict__ baseband, uint8_t* __restrict__ payload_out) {
+    double* __restrict__ baseband, uint8_t* __restrict__ payload_out,
+    const uint8_t* __restrict__ payload_in, int payload_in_stride, const int* __restrict__ nbytes_in, int out_stride, int out_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint8_t* bits = smem;               // data bits (scrambled, with virtual copy): K entries
     uint8_t* enc = bits + 1600;         // encoded word N
@@ -62,13 +63,19 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
     const uint64_t frame = frame0 + blockIdx.x;
     const uint32_t flo = uint32_t(frame), fhi = uint32_t(frame >> 32);
     const int K = T.K, P = T.P, nReal = T.nReal, fs = T.payload_bytes;
-    c2* out = reinterpret_cast<c2*>(baseband) + size_t(blockIdx.x) * T.frame_samples;
+    // out_stride / out_offset (complex samples): where frame f starts; the transmit path leaves room for the preamble
+    c2* out = reinterpret_cast<c2*>(baseband) + size_t(blockIdx.x) * (out_stride ? out_stride : T.frame_samples) + out_offset;
 
     for (int i = tid; i < 128; i += TX_THREADS) tw[i] = {T.twiddle[2 * i], -T.twiddle[2 * i + 1]};  // conj (ofdm.cc:365)
-    for (int j = tid; j < fs; j += TX_THREADS) {
-        uint32_t w[4];
-        philox4x32(seed, uint32_t(j >> 4), 0u, flo, fhi, w);
-        pay[j] = uint8_t(w[(j >> 2) & 3] >> (8 * (j & 3)));
+    if (payload_in) {                   // transmit_byte: the caller's message, zero-padded to the frame (telecom_system.cc:354-366)
+        const int nb = nbytes_in ? nbytes_in[blockIdx.x] : fs;
+        for (int j = tid; j < fs; j += TX_THREADS) pay[j] = j < nb ? payload_in[size_t(blockIdx.x) * payload_in_stride + j] : uint8_t(0);
+    } else {
+        for (int j = tid; j < fs; j += TX_THREADS) {
+            uint32_t w[4];
+            philox4x32(seed, uint32_t(j >> 4), 0u, flo, fhi, w);
+            pay[j] = uint8_t(w[(j >> 2) & 3] >> (8 * (j & 3)));
+        }
     }
     __syncthreads();
     if (tid == 0) {                     // CRC16 over the payload (telecom_system.cc:365-372)
@@ -176,6 +183,7 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
         };
         emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
     }
+    if (channel < 0) return;            // transmit path: no channel
     __syncthreads();
     // channel, back to front in chunks so the 6-sample echo always reads clean samples
     const int n = T.frame_samples;

@@ -46,6 +46,14 @@ class ReceiveConfig(C.Structure):
                 ("use_last_good_freq_offset", C.c_int), ("coarse_freq_sync_enabled", C.c_int)]
 
 
+class TransmitConfig(C.Structure):     # include/mercury_tx.h
+    _fields_ = [("carrier_hz", C.c_double), ("carrier_amplitude", C.c_double), ("output_power_watt", C.c_double),
+                ("preamble_papr_cut", C.c_double), ("data_papr_cut", C.c_double), ("start_sample", C.c_uint64),
+                ("message_location", C.c_int), ("phase_continuous", C.c_int)]
+
+
+SINGLE_MESSAGE, NO_FILTER_MESSAGE = 3, 4
+
 LINK_STATE_DTYPE = np.dtype([("delay_of_last_decoded_message", "<i4"), ("freq_offset_of_last_decoded_message", "<f8"),
                              ("mfsk_search_start", "<i4")], align=True)
 RECEIVE_STATS_DTYPE = np.dtype([("iterations_done", "<i4"), ("crc", "<i4"), ("all_zeros", "<i4"), ("message_decoded", "<i4"),
@@ -95,6 +103,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch",
+    "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_symbol_mod",
     "mgpu_symbol_demod", "mgpu_automatic_gain_control", "mgpu_channel_estimator", "mgpu_restore_channel_amplitude", "mgpu_channel_equalizer",
     "mgpu_measure_variance", "mgpu_deframer", "mgpu_deinterleaver_c128", "mgpu_deinterleaver_f32", "mgpu_psk_demod",
     "mgpu_bit_energy_dispersal", "mgpu_bit_to_byte", "mgpu_crc16_modbus_rtu",
@@ -300,6 +309,40 @@ class RxPhy:
         stats = np.zeros(W, RECEIVE_STATS_DTYPE)
         self._ck(self.lib.mgpu_receive_byte_batch(self.h, _ptr(x), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
         return {"payload": payload, "stats": stats, "state": st}
+
+    def transmit_frame_samples(self):
+        return int(self.lib.mgpu_transmit_frame_samples(self.h))
+
+    def transmit_config(self, carrier_hz, message_location=SINGLE_MESSAGE, start_sample=0, phase_continuous=0, carrier_amplitude=None,
+                        output_power_watt=0.1, preamble_papr_cut=7.0, data_papr_cut=10.0):
+        """The reference's defaults (telecom_system.cc:69, physical_config.cc:88,115-116) around the given carrier."""
+        amp = float(np.sqrt(2.0)) if carrier_amplitude is None else carrier_amplitude
+        return TransmitConfig(carrier_hz, amp, output_power_watt, preamble_papr_cut, data_papr_cut, start_sample, message_location,
+                              phase_continuous)
+
+    def transmit_byte(self, payload, carrier_hz, nbytes=None, **kw):
+        """cl_telecom_system::transmit_byte for F messages: payload uint8 [F, >= payload_bytes] -> float64 [F, total_frame_size]."""
+        pl = np.ascontiguousarray(payload, np.uint8)
+        pl = pl.reshape(1, -1) if pl.ndim == 1 else pl
+        F, stride = pl.shape
+        cfg = self.transmit_config(carrier_hz, **kw)
+        nb = None if nbytes is None else np.ascontiguousarray(nbytes, np.int32)
+        out = np.zeros((F, self.transmit_frame_samples()), np.float64)
+        self._ck(self.lib.mgpu_transmit_byte_batch(self.h, _ptr(pl), C.c_int(stride), None if nb is None else _ptr(nb), C.c_int(F), C.byref(cfg),
+                                                   _ptr(out)))
+        return out
+
+    def transmit_byte_dev(self, d_payload, payload_stride, F, d_passband, carrier_hz, d_nbytes=None, stream=None, **kw):
+        cfg = self.transmit_config(carrier_hz, **kw)
+        self._ck(self.lib.mgpu_transmit_byte_batch_dev(self.h, C.c_void_p(d_payload), C.c_int(payload_stride), C.c_void_p(d_nbytes), C.c_int(F),
+                                                       C.byref(cfg), C.c_void_p(d_passband), C.c_void_p(stream)))
+
+    def symbol_mod(self, carriers):
+        """cl_ofdm::symbol_mod: complex128 [n, Nc] -> [n, Nofdm]."""
+        x = np.ascontiguousarray(carriers, np.complex128).reshape(-1, self.Nc)
+        out = np.zeros((x.shape[0], self.Nofdm), np.complex128)
+        self._ck(self.lib.mgpu_symbol_mod(self.h, _ptr(x), C.c_int(x.shape[0]), _ptr(out)))
+        return out
 
     def last_sync_kernel_ms(self):
         ms = C.c_float(0)

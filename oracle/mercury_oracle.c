@@ -974,7 +974,8 @@ double morc_freq_sync(morc* o, const double* in_c128, double carrier_freq_width,
 /* Test-input generator mirroring oracle/ref_harness.cc:mref_tx_passband (transmit_bit, telecom_system.cc:470-532,
  * without pre-equalisation, clipping and TX filters): rational_resampler INTERPOLATION ofdm.cc:2279-2292,
  * baseband_to_passband :2294-2315. */
-int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, double amplitude, double* out) {
+static int tx_passband_impl(morc* o, const int* bits, double fs, double carrier_hz, double amplitude, double output_power_watt,
+                            unsigned long start, double* out) {
     int pre = o->preamble, interp = 4, nsym = o->active_nsymb, nb = (pre + nsym) * o->Nofdm;
     cd* bb = malloc(sizeof(cd) * nb);
     cd* frame = bb + pre * o->Nofdm;
@@ -1003,7 +1004,7 @@ int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, dou
         for (int j = 0; j < 16; j++) y[j] = z[j + 256 - 16];
     }
     float pn = sqrt((double)(o->Nfft * interp));
-    double pw = sqrt(0.1), boost = sqrt(2);
+    double pw = sqrt(output_power_watt), boost = sqrt(2);
     for (int j = 0; j < o->Nofdm * pre; j++) {
         bb[j] = (creal(bb[j]) / (double)pn) + (cimag(bb[j]) / (double)pn) * I;
         double m = pw * boost * mfsk_boost;
@@ -1015,7 +1016,6 @@ int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, dou
         frame[j] = (creal(frame[j]) * m) + (cimag(frame[j]) * m) * I;
     }
     double Ts = 1.0 / fs;
-    unsigned long start = 0;
     for (int part = 0; part < 2; part++) {
         const cd* in = part ? frame : bb;
         int n = part ? o->Nofdm * nsym : o->Nofdm * pre;
@@ -1034,6 +1034,83 @@ int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, dou
     free(bb);
     return nb * interp;
 }
+int morc_tx_passband(morc* o, const int* bits, double fs, double carrier_hz, double amplitude, double* out) {
+    return tx_passband_impl(o, bits, fs, carrier_hz, amplitude, 0.1 /* output_power_Watt, physical_config.cc:88 */, 0, out);
+}
+
+/* cl_FIR::design — fir_filter.cc:45-162, for the types and windows the transmit filters use:
+ * type 0 = LPF, 1 = HPF (spectral inversion); window 2 = HAMMING, 3 = BLACKMAN */
+static int design_fir(double* c, int type, int window, double transition_bw, double lpf_cut, double hpf_cut, double fs) {
+    double cut = type == 1 ? hpf_cut : lpf_cut;
+    int n = (int)(4.0 / (transition_bw / (fs / 2.0)));
+    if (n % 2 == 0) n++;
+    double Ts = 1.0 / fs, temp;
+    c[n / 2] = 1;
+    for (int i = 0; i < n / 2; i++) {
+        temp = 2 * M_PI * cut * (double)(n / 2 - i) * Ts;
+        c[i] = sin(temp) / temp;
+        c[n - i - 1] = c[i];
+    }
+    temp = 0;
+    for (int i = 0; i < n; i++) temp += c[i];
+    for (int i = 0; i < n; i++) c[i] /= temp;
+    if (type == 1) {
+        for (int i = 0; i < n; i++) c[i] *= -1;
+        c[(n - 1) / 2] += 1;
+    }
+    if (window == 2) for (int i = 0; i < n; i++) c[i] *= 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (n - 1));
+    else if (window == 3) for (int i = 0; i < n; i++) c[i] *= 0.42 - 0.5 * cos(2.0 * M_PI * (double)i / n) + 0.08 * cos(4.0 * M_PI * (double)i / n);
+    return n;
+}
+int morc_tx_fir_taps(double carrier_hz, int which, double* taps) {
+    const double bw = 48000.0 * 50.0 / 256 / 4;
+    return which == 0 ? design_fir(taps, 1, 2, 1000.0, carrier_hz + bw / 2, carrier_hz - bw / 2, 48000.0)      /* FIR_tx1: physical_config.cc:103-107 */
+                      : design_fir(taps, 0, 3, 1000.0, carrier_hz + bw / 2, carrier_hz - bw / 2, 48000.0);     /* FIR_tx2: :109-113 */
+}
+/* cl_FIR::apply(double*) — fir_filter.cc:189-210 */
+static void fir_apply_real(const double* c, int nt, const double* in, double* out, int n) {
+    int h = (nt - 1) / 2;
+    for (int i = 0; i < n + nt - 1; i++) {
+        double acc = 0;
+        for (int j = 0; j < nt; j++)
+            if ((i - j) >= 0 && (i - j) < n) acc += in[i - j] * c[j];
+        if (i >= h && i < n + h) out[i - h] = acc;
+    }
+}
+/* cl_ofdm::peak_clip(double*) — ofdm.cc:1565-1592 (pow(x,2) is x*x in the -O3 build) */
+static void peak_clip(double* in, int n, double papr) {
+    double avg = 0;
+    for (int i = 0; i < n; i++) avg += in[i] * in[i];
+    avg /= n;
+    double peak = sqrt(avg * pow(10, papr / 10.0));
+    for (int i = 0; i < n; i++) {
+        if (in[i] > 0 && in[i] > peak) in[i] = peak;
+        if (in[i] < 0 && in[i] < -peak) in[i] = -peak;
+    }
+}
+/* cl_telecom_system::transmit_byte + transmit_bit — telecom_system.cc:342-556, message_location 3 = SINGLE_MESSAGE (both
+ * transmit filters) or 4 = NO_FILTER_MESSAGE; same composition as oracle/ref_harness.cc:mref_transmit_byte, which pins it. */
+int morc_transmit_byte(morc* o, const int* payload, int nBytes, const morc_tx_config* c, double* out) {
+    const int interp = 4, total = o->Nofdm * (o->Nsymb + o->preamble) * interp;
+    if (nBytes > (o->nReal - 16) / 8) return -1;
+    int bits[N_MAX];
+    morc_payload_to_bits(o, payload, nBytes, bits);
+    double* tx = calloc(total, sizeof(double));
+    int used = tx_passband_impl(o, bits, 48000.0, c->carrier_hz, c->carrier_amplitude, c->output_power_watt, (unsigned long)c->start_sample, tx);
+    int npre = o->Nofdm * o->preamble * interp;
+    peak_clip(tx, npre, c->preamble_papr_cut);
+    peak_clip(tx + npre, used - npre, c->data_papr_cut);
+    if (c->message_location == 4) { memcpy(out, tx, sizeof(double) * total); free(tx); return total; }
+    if (c->message_location != 3) { free(tx); return -2; }
+    double t1c[128], t2c[128];
+    int n1 = morc_tx_fir_taps(c->carrier_hz, 0, t1c), n2 = morc_tx_fir_taps(c->carrier_hz, 1, t2c);
+    double* t1 = malloc(sizeof(double) * total);
+    fir_apply_real(t1c, n1, tx, t1, total);
+    fir_apply_real(t2c, n2, t1, out, total);
+    free(t1); free(tx);
+    return total;
+}
+
 
 /* ------------------------------------------------------------------------------------ */
 /* MFSK synchroniser / signalling blocks */

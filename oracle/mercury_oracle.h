@@ -106,6 +106,18 @@ int morc_time_sync_preamble(morc*, const double* in_c128, int size, int interpol
 double morc_freq_sync(morc*, const double* in_c128, double carrier_freq_width, int preamble_nSymb, double fs);
 int morc_tx_passband(morc*, const int* bits, double fs, double carrier_hz, double amplitude, double* out_passband);
 
+/* ---- cl_telecom_system::transmit_byte (telecom_system.cc:342-556): payload bytes -> CRC -> scramble -> encode -> interleave ->
+ * map -> frame -> IFFT+GI -> preamble -> scale -> x4 interpolation + mixer -> peak_clip -> (message_location 3 = SINGLE_MESSAGE)
+ * FIR_tx1, FIR_tx2. message_location 4 = NO_FILTER_MESSAGE stops before the filters. out: Nofdm*(Nsymb+preamble)*4 samples
+ * (zeros behind a short MFSK control frame). Returns the sample count, -1 = message too long. ---- */
+typedef struct morc_tx_config {
+    double carrier_hz, carrier_amplitude, output_power_watt, preamble_papr_cut, data_papr_cut;
+    unsigned long long start_sample;      /* cl_ofdm::passband_start_sample when the call starts (ofdm.cc:2311-2313) */
+    int message_location, reserved;
+} morc_tx_config;
+int morc_transmit_byte(morc*, const int* payload, int nBytes, const morc_tx_config* cfg, double* out_passband);
+int morc_tx_fir_taps(double carrier_hz, int which, double* taps);   /* 0 = FIR_tx1 (HPF, Hamming), 1 = FIR_tx2 (LPF, Blackman) */
+
 /* ---- MFSK synchroniser / signalling blocks: time_sync_mfsk (ofdm.cc:1969-2062, arguments of telecom_system.cc:686),
  * detect_ack_pattern (ofdm.cc:2064-2187; which 1 = ACK tones as telecom_system.cc:1643, 2 = BREAK tones as :1698), and the
  * known tone patterns as unscaled time-domain symbols (which 0 = the mode's MFSK preamble, 1 = ACK, 2 = BREAK) ---- */

@@ -554,8 +554,9 @@ double mref_freq_sync(void* h, const double* in_c128, double carrier_freq_width,
 // without pre-equalisation, peak clipping and the TX FIRs (none of which the RX building blocks require).
 // Returns the number of passband samples written: (preamble+Nsymb)*Nofdm*4.
 extern "C" void mref_tx(void* h, const int* bits, int scramble, double* out_c128);
-int mref_tx_passband(void* h, const int* bits, double fs, double carrier_hz, double amplitude, double* out_passband) {
-    Ref* r = (Ref*)h;
+static int tx_passband_impl(Ref* r, const int* bits, double fs, double carrier_hz, double amplitude, double output_power_watt,
+                            unsigned long start_sample, double* out_passband) {
+    void* h = r;
     const int nsym = r->active_nsymb;                                                          // telecom_system.cc:500
     std::vector<double> frame(2 * size_t(r->Nofdm) * r->Nsymb);
     mref_tx(h, bits, 1, frame.data());
@@ -572,13 +573,54 @@ int mref_tx_passband(void* h, const int* bits, double fs, double carrier_hz, dou
     for (int i = 0; i < pre; i++) r->ofdm.symbol_mod(&pre_data[i * r->Nc], &pre_mod[i * r->Nofdm]);
     cd* data = (cd*)frame.data();
     const float power_normalization = sqrt((double)(r->Nfft * interp));                       // telecom_system.cc:388
-    const double pw = sqrt(0.1);                                                               // output_power_Watt
+    const double pw = sqrt(output_power_watt);
     for (int j = 0; j < r->Nofdm * pre; j++) { pre_mod[j] /= power_normalization; pre_mod[j] *= pw * r->ofdm.preamble_configurator.boost * mfsk_boost; }
     for (int j = 0; j < r->Nofdm * nsym; j++) { data[j] /= power_normalization; data[j] *= pw * mfsk_boost; }
-    r->ofdm.passband_start_sample = 0;
+    r->ofdm.passband_start_sample = start_sample;
     r->ofdm.baseband_to_passband(pre_mod.data(), r->Nofdm * pre, out_passband, fs, carrier_hz, amplitude, interp);
     r->ofdm.baseband_to_passband(data, r->Nofdm * nsym, &out_passband[r->Nofdm * pre * interp], fs, carrier_hz, amplitude, interp);
     return (pre + nsym) * r->Nofdm * interp;
+}
+int mref_tx_passband(void* h, const int* bits, double fs, double carrier_hz, double amplitude, double* out_passband) {
+    return tx_passband_impl((Ref*)h, bits, fs, carrier_hz, amplitude, 0.1 /* output_power_Watt, physical_config.cc:88 */, 0, out_passband);
+}
+
+// cl_telecom_system::transmit_byte + transmit_bit (telecom_system.cc:342-556) composed from the reference's own objects:
+// payload bytes -> CRC -> ... -> passband, then peak_clip on the preamble and the data part (:534-535) and, for
+// SINGLE_MESSAGE (3), the two transmit filters (:546-556; designed as physical_config.cc:103-113 + telecom_system.cc:2856-2866,
+// :1924-1935 do); NO_FILTER_MESSAGE (4) returns the clipped signal. pre_equalization_channel is all ones by default and is
+// not applied. out has total_frame_size = Nofdm*(Nsymb+preamble)*4 samples; the part behind a short MFSK control frame is
+// zero here (the reference leaves whatever the previous frame put there).
+struct mref_tx_config {
+    double carrier_hz, carrier_amplitude, output_power_watt, preamble_papr_cut, data_papr_cut;
+    unsigned long long start_sample;       // cl_ofdm::passband_start_sample when the call starts
+    int message_location, reserved;
+};
+int mref_transmit_byte(void* h, const int* payload, int nBytes, const mref_tx_config* c, double* out) {
+    Ref* r = (Ref*)h;
+    const double bandwidth = 48000.0 * 50.0 / 256 / 4, fs = 48000.0;
+    const int interp = 4, total = r->Nofdm * (r->Nsymb + r->preamble_nsymb) * interp;
+    if (nBytes > (r->nReal - 16) / 8) return -1;                       // "message too long.. not sent."
+    std::vector<int> bits(N_MAX);
+    mref_payload_to_bits(h, payload, nBytes, bits.data());
+    std::vector<double> tx(total, 0.0);
+    const int used = tx_passband_impl(r, bits.data(), fs, c->carrier_hz, c->carrier_amplitude, c->output_power_watt, c->start_sample, tx.data());
+    const int npre = r->Nofdm * r->preamble_nsymb * interp;
+    r->ofdm.peak_clip(tx.data(), npre, c->preamble_papr_cut);
+    r->ofdm.peak_clip(tx.data() + npre, used - npre, c->data_papr_cut);
+    if (c->message_location == NO_FILTER_MESSAGE) { memcpy(out, tx.data(), sizeof(double) * total); return total; }
+    if (c->message_location != SINGLE_MESSAGE) return -2;
+    cl_FIR f1, f2;
+    f1.filter_window = HAMMING;  f1.filter_transition_bandwidth = 1000;
+    f1.lpf_filter_cut_frequency = c->carrier_hz + bandwidth / 2;  f1.hpf_filter_cut_frequency = c->carrier_hz - bandwidth / 2;
+    f1.type = HPF;  f1.sampling_frequency = fs;  f1.design();
+    f2.filter_window = BLACKMAN;  f2.filter_transition_bandwidth = 1000;
+    f2.lpf_filter_cut_frequency = c->carrier_hz + bandwidth / 2;  f2.hpf_filter_cut_frequency = c->carrier_hz - bandwidth / 2;
+    f2.type = LPF;  f2.sampling_frequency = fs;  f2.design();
+    std::vector<double> t1(total);
+    f1.apply(tx.data(), t1.data(), total);
+    f2.apply(t1.data(), out, total);
+    return total;
 }
 
 // ---- MFSK synchroniser / signalling blocks ------------------------------------------------------------

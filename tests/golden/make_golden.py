@@ -19,6 +19,10 @@ M == MOD_MFSK branch of receive_byte (telecom_system.cc:1132-1192), full and sho
 `--sync` writes golden_sync.json: every synchroniser block (passband_to_baseband, Schmidl-Cox coarse / fine with the k-th
 peak, Moose, time_sync_mfsk, the ACK / BREAK detector) of the compiled reference on one capture window per mode.
 
+`--tx` writes golden_tx.json: cl_telecom_system::transmit_byte composed from the compiled reference's objects
+(oracle/ref_harness.cc:mref_transmit_byte) for a seeded message per mode — filtered (SINGLE_MESSAGE) and unfiltered
+(NO_FILTER_MESSAGE), two carrier phase origins, a short message, MFSK control frames.
+
 Fixtures are DATA (inputs are regenerated from the recorded seeds; a digest of the input guards
 against generator drift). No reference source text is stored.
 """
@@ -166,6 +170,41 @@ def sync_case(lib, cfg):
     return rec
 
 
+TX_CFGS = (0, 5, 8, 11, 14, 16, 100, 101, 102)
+
+
+def tx_case(lib, cfg):
+    """transmit_byte outputs of `lib` (the compiled reference when generating, the oracle when checking) as digests plus
+    a few samples in hex; the message bytes are regenerated from the seed."""
+    rng = np.random.default_rng(7000 + cfg)
+    nb = (lib.nReal - 16) // 8
+    msg = rng.integers(0, 256, nb).astype(np.int32)
+    rec = {"message": digest(msg)}
+    cases = [("filtered", msg, dict(message_location=oraclelib.SINGLE_MESSAGE)),
+             ("unfiltered", msg, dict(message_location=oraclelib.NO_FILTER_MESSAGE)),
+             ("late_phase", msg, dict(message_location=oraclelib.SINGLE_MESSAGE, start_sample=3 * 10 ** 9 + 17)),
+             ("short", msg[: nb // 3], dict(message_location=oraclelib.NO_FILTER_MESSAGE, carrier=1650.0, output_power_watt=0.25,
+                                            preamble_papr_cut=5.0, data_papr_cut=6.0))]
+    for name, m, kw in cases:
+        y = lib.transmit_byte(m, **kw)
+        rec[name] = [digest(y), [float(v).hex() for v in y[[0, 1, 777, y.size // 2, y.size - 1]]]]
+    if cfg >= 100:
+        lib.set_ctrl_mode(1)
+        y = lib.transmit_byte(msg, message_location=oraclelib.SINGLE_MESSAGE)
+        rec["ctrl"] = [digest(y), int(np.count_nonzero(y))]
+        lib.set_ctrl_mode(0)
+    assert lib.transmit_byte(np.zeros(nb + 1, np.int32)) is None       # "message too long.. not sent."
+    return rec
+
+
+def main_tx():
+    assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
+    meta = {str(cfg): tx_case(oraclelib.RefLib(cfg), cfg) for cfg in TX_CFGS}
+    with open(os.path.join(HERE, "golden_tx.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote golden_tx.json")
+
+
 def main_sync():
     assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
     meta = {str(cfg): sync_case(oraclelib.RefLib(cfg), cfg) for cfg in (8, 10, 16, 100, 101)}
@@ -175,7 +214,9 @@ def main_sync():
 
 
 if __name__ == "__main__":
-    if "--sync" in sys.argv:
+    if "--tx" in sys.argv:
+        main_tx()       # transmit_byte (the TX mirror up to the audio samples)
+    elif "--sync" in sys.argv:
         main_sync()     # synchroniser blocks and the MFSK sync / ACK detector
     elif "--mfsk" in sys.argv:
         main_mfsk()     # separate fixture files: the OFDM fixtures are not regenerated

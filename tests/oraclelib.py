@@ -263,6 +263,15 @@ CARRIER = BANDWIDTH / 2 + 300                 # physical_config.cc:84 with carri
 AMPLITUDE = float(np.sqrt(2.0))               # telecom_system.cc:69
 
 
+SINGLE_MESSAGE, NO_FILTER_MESSAGE = 3, 4        # include/common/common_defines.h:200-201
+
+
+class TxConfig(C.Structure):
+    _fields_ = [("carrier_hz", C.c_double), ("carrier_amplitude", C.c_double), ("output_power_watt", C.c_double),
+                ("preamble_papr_cut", C.c_double), ("data_papr_cut", C.c_double), ("start_sample", C.c_ulonglong),
+                ("message_location", C.c_int), ("reserved", C.c_int)]
+
+
 def _sync_methods(cls):
     def preamble(self):
         out = np.zeros(self.preamble_nsymb * self.Nc, np.complex128)
@@ -329,8 +338,22 @@ def _sync_methods(cls):
         m = f(self.h, _p(z), C.c_int(z.size), C.c_int(interp), C.c_int(which), C.byref(matched))
         return float(m), int(matched.value)
 
+    def transmit_byte(self, payload, carrier=CARRIER, message_location=SINGLE_MESSAGE, start_sample=0, amplitude=AMPLITUDE,
+                      output_power_watt=0.1, preamble_papr_cut=7.0, data_papr_cut=10.0):
+        """cl_telecom_system::transmit_byte: payload bytes -> total_frame_size passband samples (None = message too long)."""
+        pl = np.ascontiguousarray(payload, np.int32)
+        c = TxConfig(carrier, amplitude, output_power_watt, preamble_papr_cut, data_papr_cut, start_sample, message_location, 0)
+        out = np.zeros((self.preamble_nsymb + self.Nsymb) * self.Nofdm * 4)
+        f = self._fn("transmit_byte")
+        f.restype = C.c_int
+        n = f(self.h, _p(pl), C.c_int(pl.size), C.byref(c), _p(out))
+        if n == -1:
+            return None
+        assert n == out.size, n
+        return out
+
     for fn in (preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband, mfsk_pattern, time_sync_mfsk,
-               detect_ack_pattern):
+               detect_ack_pattern, transmit_byte):
         setattr(cls, fn.__name__, fn)
 
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _header_functions():
     names = set()
-    for header in ("mercury_gpu.h", "mercury_shm.h", "mercury_rxloop.h", "mercury_stages.h"):
+    for header in ("mercury_gpu.h", "mercury_shm.h", "mercury_rxloop.h", "mercury_stages.h", "mercury_tx.h"):
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(mgpu_[a-z_0-9]+)\s*\(", text))
@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from mercury_amd import STATS_DTYPE
-    from mercury_amd.physical_layer import Config, Info
+    from mercury_amd.physical_layer import Config, Info, TransmitConfig
+    assert C.sizeof(TransmitConfig) == 56       # 5 doubles, uint64, 2 ints
     assert STATS_DTYPE.itemsize == 24           # 4 ints + 2 floats
     assert C.sizeof(Config) == 36               # 7 ints, 1 float, mfsk_ctrl_mode
     assert C.sizeof(Info) == 4 * 32

@@ -1,0 +1,203 @@
+"""cl_telecom_system::transmit_byte (telecom_system.cc:342-556; SURVEY.md §8 row f4, the TX mirror up to the audio samples).
+
+Pinning chain: the compiled reference objects composed as transmit_byte / transmit_bit compose them
+(oracle/ref_harness.cc:mref_transmit_byte) -> tests/golden/golden_tx.json -> the C restatement (morc_transmit_byte) ->
+the GPU path (include/mercury_tx.h, csrc/tx.hip), every link bit for bit."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib
+from oraclelib import CARRIER, NO_FILTER_MESSAGE, SINGLE_MESSAGE, Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+needs_ref = pytest.mark.skipif(not oraclelib.RefLib.available(), reason="oracle/_ref not built (no /root/reference here)")
+
+
+def _make_golden():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg
+
+
+MG = _make_golden()
+
+
+@pytest.mark.parametrize("cfg", MG.TX_CFGS)
+def test_oracle_transmit_byte_matches_the_reference_fixture(cfg):
+    want = json.load(open(os.path.join(HERE, "golden", "golden_tx.json")))[str(cfg)]
+    got = json.loads(json.dumps(MG.tx_case(Oracle(cfg), cfg)))      # same code path, the oracle as `lib`
+    assert got == want
+
+
+@needs_ref
+@pytest.mark.parametrize("cfg", [1, 3, 7, 9, 12, 13, 15])
+def test_oracle_transmit_byte_matches_reference_build_on_the_other_modes(cfg):
+    orc, ref = Oracle(cfg), oraclelib.RefLib(cfg)
+    rng = np.random.default_rng(cfg)
+    for loc in (SINGLE_MESSAGE, NO_FILTER_MESSAGE):
+        msg = rng.integers(0, 256, int(rng.integers(1, orc.payload_bytes + 1))).astype(np.int32)
+        start = int(rng.integers(0, 2 ** 40))
+        assert np.array_equal(orc.transmit_byte(msg, message_location=loc, start_sample=start),
+                              ref.transmit_byte(msg, message_location=loc, start_sample=start))
+
+
+def test_oracle_transmit_filters_have_the_reference_shape():
+    """97 taps at 48 kHz for a 1 kHz transition band. FIR_tx1 (high-pass at the lower band edge, Hamming) halves the amplitude at
+    its cut-off and passes the carrier; FIR_tx2 (low-pass at the upper band edge, the reference's periodic Blackman window) halves
+    it at the upper edge."""
+    import ctypes as C
+    f = Oracle(8).lib.morc_tx_fir_taps
+    f.restype = C.c_int
+    lo, hi = CARRIER - oraclelib.BANDWIDTH / 2, CARRIER + oraclelib.BANDWIDTH / 2
+
+    def gain(t, hz):
+        return abs(np.sum(t * np.exp(-2j * np.pi * hz / 48000.0 * np.arange(t.size))))
+
+    taps = np.zeros(128)
+    assert f(C.c_double(CARRIER), C.c_int(0), taps.ctypes.data_as(C.c_void_p)) == 97
+    t1 = taps[:97].copy()
+    assert np.allclose(t1, t1[::-1], rtol=0, atol=1e-16)                      # linear phase (the window is symmetric to rounding)
+    assert 0.45 < gain(t1, lo) < 0.6 and 0.95 < gain(t1, CARRIER) < 1.05 and gain(t1, 0.0) < gain(t1, lo)
+    assert f(C.c_double(CARRIER), C.c_int(1), taps.ctypes.data_as(C.c_void_p)) == 97
+    t2 = taps[:97].copy()
+    assert 0.45 < gain(t2, hi) < 0.55 and 0.95 < gain(t2, CARRIER) < 1.05 and gain(t2, hi + 1500) < 0.01
+
+
+def test_oracle_transmit_then_receive_round_trip():
+    """The transmitted audio (clipped, filtered) placed in a capture window is what receive_byte decodes. The receiver's audio
+    gain is 2: at unit gain the filtered 0.1 W frame sits just under receive_byte's 0.001 energy gate (telecom_system.cc:808-830)."""
+    for cfg in (8, 16, 101):
+        orc = Oracle(cfg)
+        msg = np.random.default_rng(cfg).integers(0, 256, orc.payload_bytes).astype(np.int32)
+        pb = orc.transmit_byte(msg)
+        n = orc.buffer_samples()
+        x = np.random.default_rng(1).standard_normal(n) * 1e-3
+        d = 9 * orc.Nofdm * 4 + 123
+        x[d: d + pb.size] += 2.0 * pb
+        r = orc.receive_byte(x)
+        assert r["message_decoded"] == 1 and np.array_equal(r["payload"], msg), cfg
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------------
+ALL_CFGS = list(range(17)) + [100, 101, 102]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ALL_CFGS)
+def test_gpu_transmit_byte_matches_oracle(cfg):
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=8)
+    assert rx.transmit_frame_samples() == (orc.preamble_nsymb + orc.Nsymb) * orc.Nofdm * 4
+    rng = np.random.default_rng(900 + cfg)
+    F = 4
+    pls = rng.integers(0, 256, (F, orc.payload_bytes)).astype(np.uint8)
+    nbytes = np.array([orc.payload_bytes, 1, orc.payload_bytes // 2, 0], np.int32)
+    for loc, start, nb in ((SINGLE_MESSAGE, 0, None), (NO_FILTER_MESSAGE, 0, None), (SINGLE_MESSAGE, 2 ** 33 + 5, nbytes)):
+        got = rx.transmit_byte(pls, CARRIER, nbytes=nb, message_location=loc, start_sample=start)
+        for f in range(F):
+            msg = pls[f, : (orc.payload_bytes if nb is None else nb[f])].astype(np.int32)
+            want = orc.transmit_byte(msg, message_location=loc, start_sample=start)
+            assert np.array_equal(got[f], want), (cfg, loc, start, f)
+    # non-default power, clipping levels and carrier
+    kw = dict(message_location=NO_FILTER_MESSAGE, output_power_watt=0.25, preamble_papr_cut=5.0, data_papr_cut=6.0)
+    got = rx.transmit_byte(pls[:1], 1650.0, **kw)
+    assert np.array_equal(got[0], orc.transmit_byte(pls[0].astype(np.int32), carrier=1650.0, **kw))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 100])
+def test_gpu_transmit_byte_phase_continuous_equals_consecutive_calls(cfg):
+    """phase_continuous: message f starts where message f-1 stopped, as cl_ofdm::passband_start_sample runs on from call to call."""
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=8)
+    pls = np.random.default_rng(cfg).integers(0, 256, (3, orc.payload_bytes)).astype(np.uint8)
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
+    got = rx.transmit_byte(pls, CARRIER, start_sample=1000, phase_continuous=1)
+    for f in range(3):
+        assert np.array_equal(got[f], orc.transmit_byte(pls[f].astype(np.int32), start_sample=1000 + f * used)), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [100, 101, 102])
+def test_gpu_transmit_byte_mfsk_control_frames(cfg):
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    orc.set_ctrl_mode(1)
+    rx = RxPhy(cfg, max_batch=4, mfsk_ctrl_mode=True)
+    pls = np.random.default_rng(cfg).integers(0, 256, (2, orc.payload_bytes)).astype(np.uint8)
+    for loc in (SINGLE_MESSAGE, NO_FILTER_MESSAGE):
+        got = rx.transmit_byte(pls, CARRIER, message_location=loc)
+        for f in range(2):
+            want = orc.transmit_byte(pls[f].astype(np.int32), message_location=loc)
+            assert np.array_equal(got[f], want), (cfg, loc, f)
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
+    assert (used < got.shape[1]) == (cfg != 102)                          # ROBUST_2 has no shorter control frame
+    assert not got[:, used + 60:].any()                                   # silence behind the short frame (filter tails aside)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 8, 13, 16, 100, 102])
+def test_gpu_loopback_transmit_then_receive_byte(cfg):
+    """GPU transmit_byte -> capture windows (unknown delay, noise) -> GPU receive_byte gives the messages back."""
+    from mercury_amd import RxPhy
+    rx = RxPhy(cfg, max_batch=8)
+    W = 6
+    rng = np.random.default_rng(50 + cfg)
+    pls = rng.integers(0, 256, (W, rx.payload_bytes)).astype(np.uint8)
+    pb = rx.transmit_byte(pls, CARRIER)
+    n = rx.receive_buffer_samples()
+    wins = rng.standard_normal((W, n)) * 2e-3
+    for w in range(W):
+        d = int(rng.integers(2 * rx.Nofdm * 4, n - pb.shape[1] - 2 * rx.Nofdm * 4))
+        wins[w, d: d + pb.shape[1]] += 2.0 * pb[w]          # receiver audio gain, see the oracle round trip above
+    r = rx.receive_byte(wins, CARRIER)
+    ok = r["stats"]["message_decoded"] == 1
+    orc = Oracle(cfg)
+    assert ok.tolist() == [orc.receive_byte(wins[w])["message_decoded"] == 1 for w in range(W)]    # the CPU chain agrees window by window
+    if cfg in (0, 8, 100, 102):
+        assert ok.all()
+    else:       # 32QAM / zero-forcing modes: clipping + filter ringing + a quarter-sample timing error cost some frames, on the CPU too
+        assert ok.sum() >= W // 2
+    assert np.array_equal(r["payload"][ok, : rx.payload_bytes], pls[ok])
+
+
+@pytest.mark.gpu
+def test_gpu_symbol_mod_is_the_unnormalised_ifft_with_guard_interval():
+    from mercury_amd import RxPhy
+    rx = RxPhy(8, max_batch=4)
+    rng = np.random.default_rng(3)
+    car = rng.standard_normal((7, 50)) + 1j * rng.standard_normal((7, 50))
+    y = rx.symbol_mod(car)
+    assert y.shape == (7, 272)
+    bins = np.zeros((7, 256), np.complex128)
+    bins[:, 231:256] = car[:, :25]                  # zero_padder (ofdm.cc:379-400), start_shift = 1
+    bins[:, 1:26] = car[:, 25:]
+    t = np.fft.ifft(bins, axis=1) * 256
+    assert np.allclose(y[:, 16:], t, atol=1e-12) and np.array_equal(y[:, :16], y[:, 256:])
+    # and symbol_demod undoes it exactly up to rounding
+    back = rx.stage_symbol_demod(y) if hasattr(rx, "stage_symbol_demod") else None
+    if back is not None:
+        assert np.allclose(back, car, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_transmit_byte_bad_arguments():
+    from mercury_amd import MgpuError, RxPhy
+    rx = RxPhy(8, max_batch=4)
+    pl = np.zeros((1, rx.payload_bytes), np.uint8)
+    with pytest.raises(MgpuError):
+        rx.transmit_byte(pl, CARRIER, message_location=1)                 # FIRST_MESSAGE: not built
+    with pytest.raises(MgpuError):
+        rx.transmit_byte(pl[:, :10], CARRIER)                              # rows shorter than the frame's payload
+    with pytest.raises(MgpuError):
+        rx.transmit_byte(pl, CARRIER, nbytes=np.array([rx.payload_bytes + 1], np.int32))   # "message too long.. not sent."
+    with pytest.raises(MgpuError):
+        rx.transmit_byte(pl, 30000.0)                                      # carrier above Nyquist
+    assert rx.transmit_byte(pl, CARRIER).shape == (1, rx.transmit_frame_samples())   # the context still works
