@@ -11,6 +11,8 @@
 //        get_frame_size_bytes()/bits()        telecom_system.cc:332-340
 //        receive_frame(baseband, out)         the per-frame span of receive_byte, telecom_system.cc:1132-1345
 //        receive_batch(...)                   the same over F frames (what RX_SHM would batch)
+//        receive_byte(passband, out)          the whole of receive_byte, telecom_system.cc:646-1503
+//        transmit_byte(data, nBytes, out, message_location)   telecom_system.cc:342-556
 //   mgpu::st_receive_stats <->  struct st_receive_stats  (telecom_system.h:63-82; fields this path produces)
 //
 // Like the reference, failure to decode is reported through the stats (iterations_done > max-1,
@@ -26,6 +28,7 @@
 #include "mercury_gpu.h"
 #include "mercury_rxloop.h"
 #include "mercury_stages.h"
+#include "mercury_tx.h"
 
 namespace mgpu {
 
@@ -171,6 +174,28 @@ public:
         receive_stats.delay_of_last_decoded_message = ls.delay_of_last_decoded_message;
         receive_stats.freq_offset_of_last_decoded_message = ls.freq_offset_of_last_decoded_message;
         return receive_stats;
+    }
+
+    // transmit side, cl_configuration_telecom_system defaults (telecom_system.cc:69, physical_config.cc:88,115-116)
+    double carrier_amplitude = 1.4142135623730951;
+    double output_power_Watt = 0.1;
+    double preamble_papr_cut = 7, data_papr_cut = 10;
+    unsigned long passband_start_sample = 0;     // cl_ofdm::passband_start_sample: runs on from call to call (ofdm.cc:2313)
+    int total_frame_size() const { return mgpu_transmit_frame_samples(ctx_); }     // data_container.cc:159
+
+    // void cl_telecom_system::transmit_byte(int* data, int nBytes, double* out, int message_location) — telecom_system.cc:342-556.
+    // `out` receives total_frame_size() samples. message_location: SINGLE_MESSAGE (3) or NO_FILTER_MESSAGE (4). A message
+    // longer than the frame is not sent (the reference prints "message too long.. not sent." and returns); returns whether
+    // samples were written.
+    bool transmit_byte(const int* data, int nBytes, double* out, int message_location) {
+        if (nBytes > info.payload_bytes || nBytes < 0) return false;
+        std::vector<uint8_t> bytes(info.payload_bytes, 0);
+        for (int i = 0; i < nBytes; ++i) bytes[i] = uint8_t(data[i]);
+        const mgpu_transmit_config tc{carrier_frequency, carrier_amplitude, output_power_Watt, preamble_papr_cut, data_papr_cut,
+                                      passband_start_sample, message_location, 0};
+        detail::check(mgpu_transmit_byte_batch(ctx_, bytes.data(), info.payload_bytes, &nBytes, 1, &tc, out), ctx_, "transmit_byte");
+        passband_start_sample += static_cast<unsigned long>(info.preamble_nsymb + info.active_nsymb) * info.Nofdm * 4;
+        return true;
     }
 
     // One synchronised frame: `baseband` points at the first data symbol, i.e. what receive_byte passes to

@@ -20,7 +20,7 @@ static std::vector<T> slurp(const char* path, size_t n) {
 }
 
 int main(int argc, char** argv) {
-    if (argc != 6 && argc != 8) return 2;
+    if (argc != 6 && argc != 8 && argc != 9) return 2;
     const int cfg = atoi(argv[1]), F = atoi(argv[2]);
     try {
         mgpu::cl_rx_phy phy;
@@ -74,6 +74,21 @@ int main(int argc, char** argv) {
                 fwrite(bytes.data(), sizeof(int), pb, rb);
             }
             fclose(rb);
+        }
+        // 4b) transmit_byte, three consecutive SINGLE_MESSAGE calls and one NO_FILTER_MESSAGE like the ARQ batch sender
+        //     (optional 9th argument: file of 4 messages, pb ints each; samples appended to <out>.tx)
+        if (argc >= 9) {
+            auto msgs = slurp<int>(argv[8], size_t(4) * pb);
+            const int total = phy.total_frame_size();
+            std::vector<double> audio(total);
+            FILE* tx = fopen((std::string(argv[5]) + ".tx").c_str(), "wb");
+            for (int m = 0; m < 4; ++m) {
+                if (!phy.transmit_byte(&msgs[size_t(m) * pb], m == 1 ? pb / 2 : pb, audio.data(), m == 3 ? MGPU_NO_FILTER_MESSAGE : MGPU_SINGLE_MESSAGE)) return 4;
+                fwrite(audio.data(), sizeof(double), total, tx);
+            }
+            fclose(tx);
+            std::vector<int> too_long(pb + 1, 0);
+            if (phy.transmit_byte(too_long.data(), pb + 1, audio.data(), MGPU_SINGLE_MESSAGE)) return 5;     // "message too long.. not sent."
         }
         // 5) error behaviour: a wrong code rate throws instead of exit(1)
         mgpu::cl_ldpc bad;

@@ -99,6 +99,31 @@ def test_cpp_receive_byte_keeps_link_state_across_calls(tmp_path):
     assert list(raw[:, 2]) == [1, 1, 1]                    # the noisy windows decode thanks to the first one's sync state
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 100])
+def test_cpp_transmit_byte_runs_the_carrier_on_across_calls(tmp_path, cfg):
+    """mgpu::cl_rx_phy::transmit_byte(int* data, int nBytes, double* out, int message_location): consecutive calls continue the
+    carrier phase (cl_ofdm::passband_start_sample), a short message is zero-padded, a too-long one is not sent."""
+    exe = _build(tmp_path)
+    orc = oraclelib.Oracle(cfg, 50)
+    pb = orc.payload_bytes
+    msgs = np.random.default_rng(cfg).integers(0, 256, (4, pb)).astype(np.int32)
+    (tmp_path / "bb.bin").write_bytes(np.zeros((1, orc.frame_samples), np.complex128).tobytes())
+    (tmp_path / "llr.bin").write_bytes(np.zeros((1, 1600), np.float32).tobytes())
+    (tmp_path / "pass.bin").write_bytes(np.zeros(orc.buffer_samples()).tobytes())
+    (tmp_path / "msgs.bin").write_bytes(msgs.tobytes())
+    r = subprocess.run([str(exe), str(cfg), "1", str(tmp_path / "bb.bin"), str(tmp_path / "llr.bin"), str(tmp_path / "out.bin"),
+                        str(tmp_path / "pass.bin"), "1", str(tmp_path / "msgs.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    total = (orc.preamble_nsymb + orc.Nsymb) * orc.Nofdm * 4
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
+    audio = np.fromfile(str(tmp_path / "out.bin") + ".tx", np.float64).reshape(4, total)
+    for m in range(4):
+        want = orc.transmit_byte(msgs[m, : pb // 2] if m == 1 else msgs[m], start_sample=m * used,
+                                 message_location=oraclelib.NO_FILTER_MESSAGE if m == 3 else oraclelib.SINGLE_MESSAGE)
+        assert np.array_equal(audio[m], want), m
+
+
 def _build_stages(tmp_path):
     exe = tmp_path / "stages_test"
     lib = os.path.join(ROOT, "mercury_amd")

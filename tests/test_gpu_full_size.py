@@ -81,3 +81,34 @@ def test_configs4_ldpc_soak_share_of_one_gpu():
     assert 0.45 < sums[0][0] / (F * rx.K) < 0.55                                          # hard decisions of noise: about half ones
     del llr
     rx.close()
+
+
+def test_audio_loopback_transmit_byte_to_receive_byte_1024_windows():
+    """The whole stack at scale, audio in the middle: 1024 messages -> transmit_byte on the GPU (filtered passband) -> capture
+    windows at random delays with receiver noise (torch, on the device) -> receive_byte on the GPU. Every window must come back
+    decoded with the message that went in, and the transmitter must be deterministic."""
+    import torch
+    from mercury_amd import RxPhy
+    cfg, W = 8, 1024
+    carrier = 48000.0 * 50.0 / 256 / 4 / 2 + 300
+    rx = RxPhy(cfg, max_batch=W)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED)
+    msgs = torch.randint(0, 256, (W, rx.payload_bytes), dtype=torch.uint8, device=dev, generator=g)
+    total, n = rx.transmit_frame_samples(), rx.receive_buffer_samples()
+    audio = torch.empty((W, total), dtype=torch.float64, device=dev)
+    rx.transmit_byte_dev(msgs.data_ptr(), rx.payload_bytes, W, audio.data_ptr(), carrier)
+    again = torch.empty_like(audio)
+    rx.transmit_byte_dev(msgs.data_ptr(), rx.payload_bytes, W, again.data_ptr(), carrier)
+    assert torch.equal(audio, again)
+    wins = torch.randn((W, n), dtype=torch.float64, device=dev, generator=g) * 2e-3
+    sym = rx.Nofdm * 4
+    delays = torch.randint(5 * sym, n - total - 5 * sym, (W,), device=dev, generator=g)
+    idx = delays[:, None] + torch.arange(total, device=dev)[None, :]
+    wins.scatter_add_(1, idx, 2.0 * audio)                   # receiver audio gain 2 (see tests/test_transmit_byte.py)
+    r = rx.receive_byte(wins.cpu().numpy(), carrier)
+    assert int(r["stats"]["message_decoded"].sum()) == W
+    assert np.array_equal(r["payload"][:, : rx.payload_bytes], msgs.cpu().numpy())
+    assert np.abs(r["stats"]["delay"] - delays.cpu().numpy()).max() <= 8 * 4          # within the guard interval's reach
+    rx.close()

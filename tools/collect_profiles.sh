@@ -26,6 +26,8 @@ if [ "$1" = "sweep" ]; then
   python tools/sweep_modes.py > "$OUT/mode_sweep.json" 2> "$OUT/mode_sweep.txt"
   python tools/bench_sync.py > "$OUT/bench_sync_blocks.json"
   python tests/tools/bench_receive_byte.py 8 1024 > "$OUT/bench_receive_byte_cfg8.json"
+  python tools/bench_tx.py 8 4096 > "$OUT/bench_tx_cfg8.json"
+  python tools/bench_tx.py 100 512 > "$OUT/bench_tx_cfg100.json"
   python tests/tools/llr_error_table.py > "$OUT/llr_error_by_mode.json" 2>/dev/null || true
 fi
 python "$ROOT/tools/hbm_traffic_from_pmc.py" "$OUT" "$OUT" || true     # -> $OUT/hbm_traffic.json, r01_pmc_sq_summary.json
