@@ -52,8 +52,9 @@ typedef struct mgpu_receive_stats {
 /* buffer_Nsymb (data_container.cc:133-143); a capture window is buffer_Nsymb * Nofdm * 4 passband samples */
 int mgpu_receive_buffer_nsymb(mgpu_ctx* ctx);
 
-/* passband: [W][buffer_Nsymb*Nofdm*4] doubles. state: NULL or [W], read and updated. payload: [W][payload_stride].
- * stats: [W]. W <= max_batch. Blocking. */
+/* passband: [W][buffer_Nsymb*Nofdm*4] doubles, in host memory (pageable or from mgpu_alloc_host) or in device memory — the
+ * pointer kind is detected. state: NULL or [W], read and updated. payload: [W][payload_stride]. stats: [W]; state, payload
+ * and stats are host arrays. W <= max_batch. Blocking. */
 int mgpu_receive_byte_batch(mgpu_ctx* ctx, const double* passband, int W, const mgpu_receive_config* config,
                             mgpu_link_state* state, uint8_t* payload, mgpu_receive_stats* stats);
 

@@ -268,7 +268,8 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             r.signal_strength_dbm = -999;
         }
         std::memset(payload, 0, size_t(W) * t.payload_stride);
-        HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyHostToDevice, s));
+        // hipMemcpyDefault: the windows may lie in host memory (the reference's capture buffer) or already in HBM
+        HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyDefault, s));
 
         pt.mark(s, "upload passband");
         // ---- :676-696 coarse synchronisation on the FIR_rx_time_sync baseband ----

@@ -344,6 +344,18 @@ class RxPhy:
         self._ck(self.lib.mgpu_symbol_mod(self.h, _ptr(x), C.c_int(x.shape[0]), _ptr(out)))
         return out
 
+    def receive_byte_dev(self, d_passband, W, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1, state=None,
+                         coarse_freq_sync=0):
+        """receive_byte on W capture windows that already lie in device memory (d_passband: raw pointer); host results as above."""
+        cfg = ReceiveConfig(carrier_hz, trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync)
+        st = np.zeros(W, LINK_STATE_DTYPE) if state is None else np.ascontiguousarray(state, LINK_STATE_DTYPE)
+        if state is None:
+            st["delay_of_last_decoded_message"] = -1
+        payload = np.zeros((W, self.payload_stride), np.uint8)
+        stats = np.zeros(W, RECEIVE_STATS_DTYPE)
+        self._ck(self.lib.mgpu_receive_byte_batch(self.h, C.c_void_p(d_passband), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
+        return {"payload": payload, "stats": stats, "state": st}
+
     def last_sync_kernel_ms(self):
         ms = C.c_float(0)
         self._ck(self.lib.mgpu_last_sync_kernel_ms(self.h, C.byref(ms)))

@@ -107,8 +107,10 @@ def test_audio_loopback_transmit_byte_to_receive_byte_1024_windows():
     delays = torch.randint(5 * sym, n - total - 5 * sym, (W,), device=dev, generator=g)
     idx = delays[:, None] + torch.arange(total, device=dev)[None, :]
     wins.scatter_add_(1, idx, 2.0 * audio)                   # receiver audio gain 2 (see tests/test_transmit_byte.py)
-    r = rx.receive_byte(wins.cpu().numpy(), carrier)
+    r = rx.receive_byte_dev(wins.data_ptr(), W, carrier)       # the windows stay in HBM
     assert int(r["stats"]["message_decoded"].sum()) == W
+    r_host = rx.receive_byte(wins[:64].cpu().numpy(), carrier)  # same windows from host memory: same answers
+    assert np.array_equal(r_host["payload"], r["payload"][:64]) and np.array_equal(r_host["stats"], r["stats"][:64])
     assert np.array_equal(r["payload"][:, : rx.payload_bytes], msgs.cpu().numpy())
     assert np.abs(r["stats"]["delay"] - delays.cpu().numpy()).max() <= 8 * 4          # within the guard interval's reach
     rx.close()
