@@ -52,6 +52,12 @@ int mgpu_transmit_byte_batch(mgpu_ctx* ctx, const uint8_t* payload, int payload_
 int mgpu_transmit_byte_batch_dev(mgpu_ctx* ctx, const void* d_payload, int payload_stride, const void* d_nbytes, int F,
                                  const mgpu_transmit_config* config, void* d_passband, void* stream);
 
+/* cl_telecom_system::generate_ack_pattern_passband (pattern 1; telecom_system.cc:1589-1631) and
+ * generate_break_pattern_passband (pattern 2; :1659-1689): the 16 known tone symbols the detector of mercury_gpu.h
+ * (mgpu_detect_ack_pattern_from_passband) looks for, as 16 * Nofdm * 4 passband samples; the same in every mode. Uses
+ * carrier_hz, carrier_amplitude, output_power_watt, data_papr_cut and start_sample of `config`. */
+int mgpu_generate_ack_pattern_passband(mgpu_ctx* ctx, int pattern, const mgpu_transmit_config* config, double* passband);
+
 /* cl_ofdm::symbol_mod (ofdm.cc:855-860: zero_padder, unnormalised IFFT, gi_adder): [n][Nc] carriers -> [n][Nofdm] samples */
 int mgpu_symbol_mod(mgpu_ctx* ctx, const double* carriers_c128, int n_symbols, double* out_c128);
 

@@ -526,10 +526,7 @@ int mgpu_freq_sync(mgpu_ctx* c, const double* bb, int W, int stride, double* fre
 // ---- MFSK synchroniser / signalling blocks (host buffers, blocking) -----------------------------------
 extern "C++" {
 namespace {
-// mfsk.cc:82-95, :120-126, :149-155; the universal ACK/BREAK patterns use M = 16, one stream centred in Nc = 50
-// (telecom_system.cc:3006), hop step 7, 8 tones sent twice.
-constexpr int kAckTones[8] = {4, 7, 5, 12, 13, 1, 9, 15}, kBreakTones[8] = {6, 14, 2, 3, 10, 8, 11, 15};
-constexpr int kAckM = 16, kAckNsymb = 16, kAckLen = 8, kAckHop = 7, kAckOffset = 17, kInterp = 4;
+constexpr int kInterp = 4;
 
 // carrier energies of every symbol slot of W windows: [W][nslots][50] on the host
 // `passband_carrier_hz` >= 0: `bb` is real passband audio ([W][size] doubles) that is first mixed down and filtered with

@@ -163,6 +163,10 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     template <typename T> T* as() { return static_cast<T*>(p); }
 };
+// mfsk.cc:82-95, :120-126, :149-155; the universal ACK/BREAK patterns use M = 16, one stream centred in Nc = 50
+// (telecom_system.cc:3006), hop step 7, 8 tones sent twice.
+constexpr int kAckTones[8] = {4, 7, 5, 12, 13, 1, 9, 15}, kBreakTones[8] = {6, 14, 2, 3, 10, 8, 11, 15};
+constexpr int kAckM = 16, kAckNsymb = 16, kAckLen = 8, kAckHop = 7, kAckOffset = 17;
 constexpr double kSampleRate = 48000.0;          // telecom_system.cc:1569
 const double kCarrierAmplitude = 1.4142135623730951;   // sqrt(2.0), telecom_system.cc:69
 

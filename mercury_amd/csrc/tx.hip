@@ -79,6 +79,7 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_peak_clip_kernel(double* 
     const int seg = blockIdx.y;
     double* p = x + size_t(blockIdx.x) * total + (seg ? npre4 : 0);
     const int n = seg ? used - npre4 : npre4;
+    if (n <= 0) return;
     double acc = 0.0;
     for (int base = 0; base < n; base += PC_CHUNK) {
         const int m = min(PC_CHUNK, n - base);
@@ -169,33 +170,35 @@ TxState& tx_state(mgpu_ctx* c, hipStream_t s) {
     return *static_cast<TxState*>(c->tx_state);
 }
 
+// carrier table from the host libm, as the reference evaluates it: cos / sin(2*M_PI*fc*(double)n*Ts), n from start_sample
+void ensure_carrier_table(TxState& st, double carrier_hz, uint64_t start_sample, size_t count, hipStream_t s) {
+    if (st.cs_carrier == carrier_hz && st.cs_start == start_sample && st.cs_count >= count) return;
+    std::vector<double> cs(2 * count);
+    const double Ts = 1.0 / kSampleRate;
+    for (size_t n = 0; n < count; ++n) {
+        const unsigned long k = static_cast<unsigned long>(start_sample + n);
+        // the reference's build evaluates cos and sin of this one phase as a single sincos() call (the compiler
+        // merges them); glibc's sincos is not bit-for-bit its cos + sin, so the same call is made here
+        ::sincos(2 * M_PI * carrier_hz * double(k) * Ts, &cs[2 * n + 1], &cs[2 * n]);
+    }
+    HIPCK(hipStreamSynchronize(s));                      // nothing in flight still reads the old table
+    if (st.cs_cap < cs.size()) {
+        (void)hipFree(st.d_cs);
+        st.d_cs = nullptr;
+        HIPCK(hipMalloc(reinterpret_cast<void**>(&st.d_cs), cs.size() * 8));
+        st.cs_cap = cs.size();
+    }
+    HIPCK(hipMemcpy(st.d_cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
+    st.cs_carrier = carrier_hz; st.cs_start = start_sample; st.cs_count = count;
+}
+
 void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, const int* d_nbytes, int F, const mgpu_transmit_config& cfg,
                   double* d_out, hipStream_t s) {
     const auto& t = c->tab;
     const int interp = 4, npre = t.preamble * t.Nofdm, ndata = t.active_nsymb * t.Nofdm, total = t.Nofdm * (t.Nsymb + t.preamble) * interp;
     const int used = (npre + ndata) * interp;
     TxState& st = tx_state(c, s);
-    // carrier table from the host libm, as the reference evaluates it: cos / sin(2*M_PI*fc*(double)n*Ts), n from start_sample
-    const size_t cs_count = cfg.phase_continuous ? size_t(used) * F : size_t(used);
-    if (st.cs_carrier != cfg.carrier_hz || st.cs_start != cfg.start_sample || st.cs_count < cs_count) {
-        std::vector<double> cs(2 * cs_count);
-        const double Ts = 1.0 / kSampleRate;
-        for (size_t n = 0; n < cs_count; ++n) {
-            const unsigned long k = static_cast<unsigned long>(cfg.start_sample + n);
-            // the reference's build evaluates cos and sin of this one phase as a single sincos() call (the compiler
-            // merges them); glibc's sincos is not bit-for-bit its cos + sin, so the same call is made here
-            ::sincos(2 * M_PI * cfg.carrier_hz * double(k) * Ts, &cs[2 * n + 1], &cs[2 * n]);
-        }
-        HIPCK(hipStreamSynchronize(s));                      // nothing in flight still reads the old table
-        if (st.cs_cap < cs.size()) {
-            (void)hipFree(st.d_cs);
-            st.d_cs = nullptr;
-            HIPCK(hipMalloc(reinterpret_cast<void**>(&st.d_cs), cs.size() * 8));
-            st.cs_cap = cs.size();
-        }
-        HIPCK(hipMemcpy(st.d_cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
-        st.cs_carrier = cfg.carrier_hz; st.cs_start = cfg.start_sample; st.cs_count = cs_count;
-    }
+    ensure_carrier_table(st, cfg.carrier_hz, cfg.start_sample, cfg.phase_continuous ? size_t(used) * F : size_t(used), s);
     const bool filtered = cfg.message_location == MGPU_SINGLE_MESSAGE;
     if (filtered && st.carrier != cfg.carrier_hz) {
         HIPCK(hipStreamSynchronize(s));
@@ -293,6 +296,38 @@ int mgpu_transmit_byte_batch(mgpu_ctx* c, const uint8_t* payload, int payload_st
         if (nbytes) HIPCK(hipMemcpyAsync(d_nb.p, nbytes, size_t(F) * 4, hipMemcpyHostToDevice, s));
         transmit_dev(c, d_pl.as<uint8_t>(), payload_stride, nbytes ? d_nb.as<int>() : nullptr, F, *cfg, d_out.as<double>(), s);
         HIPCK(hipMemcpyAsync(passband, d_out.p, size_t(F) * total * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+int mgpu_generate_ack_pattern_passband(mgpu_ctx* c, int pattern, const mgpu_transmit_config* cfg, double* out) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(cfg && out && (pattern == 1 || pattern == 2), "bad argument (pattern: 1 = ACK, 2 = BREAK)");
+        need(cfg->carrier_hz > 0 && cfg->carrier_hz < kSampleRate / 2 && cfg->output_power_watt >= 0, "bad carrier or power");
+        const auto& t = c->tab;
+        const int interp = 4, nbb = kAckNsymb * t.Nofdm, total = nbb * interp;
+        hipStream_t s = c->stream;
+        TxState& st = tx_state(c, s);
+        // cl_mfsk::generate_ack_pattern / generate_break_pattern (mfsk.cc:195-230): one tone per symbol, hopping
+        std::vector<mgpu::Cplx> car(size_t(kAckNsymb) * t.Nc, mgpu::Cplx{0.0, 0.0});
+        const int* tones = pattern == 2 ? kBreakTones : kAckTones;
+        const double amp = std::sqrt(double(t.Nc) / 1);
+        for (int p = 0; p < kAckNsymb; ++p) car[size_t(p) * t.Nc + kAckOffset + (tones[p % kAckLen] + p * kAckHop) % kAckM] = mgpu::Cplx{amp, 0.0};
+        DevBuf d_car(car.size() * 16), d_bb(size_t(nbb) * 16), d_out(size_t(total) * 8);
+        HIPCK(hipMemcpyAsync(d_car.p, car.data(), car.size() * 16, hipMemcpyHostToDevice, s));
+        launch_symbol_mod(c, d_car.as<double>(), kAckNsymb, d_bb.as<double>(), s);
+        ensure_carrier_table(st, cfg->carrier_hz, cfg->start_sample, size_t(total), s);
+        const float power_normalization = std::sqrt(double(t.Nfft * interp));                       // telecom_system.cc:1595
+        const double ack_boost = std::sqrt(double(t.Nc) / 1) * std::pow(10.0, -2.0 / 20.0);         // :1611
+        const double m = std::sqrt(cfg->output_power_watt) * ack_boost;
+        hipLaunchKernelGGL(mgpu_tx_mix_kernel, dim3((total + 255) / 256, 1), dim3(256), 0, s, d_bb.as<double>(), nbb, static_cast<const double*>(nullptr), 0,
+                           0, double(power_normalization), m, 0.0, cfg->carrier_amplitude, st.d_cs, 0, d_out.as<double>(), total);
+        HIPCK(hipGetLastError());
+        const double p10 = std::pow(10, cfg->data_papr_cut / 10.0);
+        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(1, 1), dim3(256), 0, s, d_out.as<double>(), total, total, total, p10, p10);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(out, d_out.p, size_t(total) * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
     });
 }

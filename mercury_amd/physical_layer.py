@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch",
-    "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_symbol_mod",
+    "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
     "mgpu_symbol_demod", "mgpu_automatic_gain_control", "mgpu_channel_estimator", "mgpu_restore_channel_amplitude", "mgpu_channel_equalizer",
     "mgpu_measure_variance", "mgpu_deframer", "mgpu_deinterleaver_c128", "mgpu_deinterleaver_f32", "mgpu_psk_demod",
     "mgpu_bit_energy_dispersal", "mgpu_bit_to_byte", "mgpu_crc16_modbus_rtu",
@@ -336,6 +336,13 @@ class RxPhy:
         cfg = self.transmit_config(carrier_hz, **kw)
         self._ck(self.lib.mgpu_transmit_byte_batch_dev(self.h, C.c_void_p(d_payload), C.c_int(payload_stride), C.c_void_p(d_nbytes), C.c_int(F),
                                                        C.byref(cfg), C.c_void_p(d_passband), C.c_void_p(stream)))
+
+    def generate_ack_pattern_passband(self, pattern=1, carrier_hz=None, **kw):
+        """cl_telecom_system::generate_ack_pattern_passband (pattern 1) / generate_break_pattern_passband (2) -> float64 [16*Nofdm*4]."""
+        cfg = self.transmit_config(carrier_hz, **kw)
+        out = np.zeros(16 * self.Nofdm * 4, np.float64)
+        self._ck(self.lib.mgpu_generate_ack_pattern_passband(self.h, C.c_int(pattern), C.byref(cfg), _ptr(out)))
+        return out
 
     def symbol_mod(self, carriers):
         """cl_ofdm::symbol_mod: complex128 [n, Nc] -> [n, Nofdm]."""

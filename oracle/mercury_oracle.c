@@ -974,6 +974,23 @@ double morc_freq_sync(morc* o, const double* in_c128, double carrier_freq_width,
 /* Test-input generator mirroring oracle/ref_harness.cc:mref_tx_passband (transmit_bit, telecom_system.cc:470-532,
  * without pre-equalisation, clipping and TX filters): rational_resampler INTERPOLATION ofdm.cc:2279-2292,
  * baseband_to_passband :2294-2315. */
+/* cl_ofdm::baseband_to_passband — ofdm.cc:2294-2315 with rational_resampler INTERPOLATION :2279-2292; *start is
+ * cl_ofdm::passband_start_sample, advanced by the samples written */
+static void b2p(const cd* in, int n, double* dst, double fs, double carrier_hz, double amplitude, unsigned long* start) {
+    const int interp = 4;
+    double Ts = 1.0 / fs;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < interp; j++) {
+            cd v;
+            if (i < n - 1) v = lerp(in[i], 0, in[i + 1], interp, j);
+            else v = lerp(in[n - 2], 0, in[n - 1], interp, interp + j);
+            double ph = 2 * M_PI * carrier_hz * (double)(*start) * Ts;
+            dst[i * interp + j] = creal(v) * amplitude * cos(ph);
+            dst[i * interp + j] += cimag(v) * amplitude * sin(ph);
+            (*start)++;
+        }
+}
+
 static int tx_passband_impl(morc* o, const int* bits, double fs, double carrier_hz, double amplitude, double output_power_watt,
                             unsigned long start, double* out) {
     int pre = o->preamble, interp = 4, nsym = o->active_nsymb, nb = (pre + nsym) * o->Nofdm;
@@ -1015,22 +1032,8 @@ static int tx_passband_impl(morc* o, const int* bits, double fs, double carrier_
         double m = pw * mfsk_boost;
         frame[j] = (creal(frame[j]) * m) + (cimag(frame[j]) * m) * I;
     }
-    double Ts = 1.0 / fs;
-    for (int part = 0; part < 2; part++) {
-        const cd* in = part ? frame : bb;
-        int n = part ? o->Nofdm * nsym : o->Nofdm * pre;
-        double* dst = out + (part ? o->Nofdm * pre * interp : 0);
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < interp; j++) {
-                cd v;
-                if (i < n - 1) v = lerp(in[i], 0, in[i + 1], interp, j);
-                else v = lerp(in[n - 2], 0, in[n - 1], interp, interp + j);
-                double ph = 2 * M_PI * carrier_hz * (double)start * Ts;
-                dst[i * interp + j] = creal(v) * amplitude * cos(ph);
-                dst[i * interp + j] += cimag(v) * amplitude * sin(ph);
-                start++;
-            }
-    }
+    for (int part = 0; part < 2; part++)
+        b2p(part ? frame : bb, part ? o->Nofdm * nsym : o->Nofdm * pre, out + (part ? o->Nofdm * pre * interp : 0), fs, carrier_hz, amplitude, &start);
     free(bb);
     return nb * interp;
 }
@@ -1088,6 +1091,26 @@ static void peak_clip(double* in, int n, double papr) {
         if (in[i] < 0 && in[i] < -peak) in[i] = -peak;
     }
 }
+/* cl_telecom_system::generate_ack_pattern_passband / generate_break_pattern_passband — telecom_system.cc:1589-1631, :1659-1689:
+ * the 16 known tone symbols (which 1 = ACK, 2 = BREAK) -> IFFT+GI -> drive-level scaling -> passband -> peak_clip at data_papr_cut */
+int morc_generate_ack_pattern_passband(morc* o, int which, const morc_tx_config* c, double* out) {
+    const int interp = 4, n = ACK_NSYMB * o->Nofdm;
+    cd* bb = malloc(sizeof(cd) * n);
+    morc_mfsk_pattern(o, which == 2 ? 2 : 1, (double*)bb);
+    float pn = sqrt((double)(o->Nfft * interp));
+    double ack_boost = sqrt((double)o->Nc / 1) * pow(10.0, -2.0 / 20.0);
+    double m = sqrt(c->output_power_watt) * ack_boost;
+    for (int j = 0; j < n; j++) {
+        bb[j] = (creal(bb[j]) / (double)pn) + (cimag(bb[j]) / (double)pn) * I;
+        bb[j] = (creal(bb[j]) * m) + (cimag(bb[j]) * m) * I;
+    }
+    unsigned long start = (unsigned long)c->start_sample;
+    b2p(bb, n, out, 48000.0, c->carrier_hz, c->carrier_amplitude, &start);
+    peak_clip(out, n * interp, c->data_papr_cut);
+    free(bb);
+    return n * interp;
+}
+
 /* cl_telecom_system::transmit_byte + transmit_bit — telecom_system.cc:342-556, message_location 3 = SINGLE_MESSAGE (both
  * transmit filters) or 4 = NO_FILTER_MESSAGE; same composition as oracle/ref_harness.cc:mref_transmit_byte, which pins it. */
 int morc_transmit_byte(morc* o, const int* payload, int nBytes, const morc_tx_config* c, double* out) {

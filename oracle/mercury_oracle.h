@@ -116,7 +116,10 @@ typedef struct morc_tx_config {
     int message_location, reserved;
 } morc_tx_config;
 int morc_transmit_byte(morc*, const int* payload, int nBytes, const morc_tx_config* cfg, double* out_passband);
-int morc_tx_fir_taps(double carrier_hz, int which, double* taps);   /* 0 = FIR_tx1 (HPF, Hamming), 1 = FIR_tx2 (LPF, Blackman) */
+int morc_tx_fir_taps(double carrier_hz, int which, double* taps);
+/* generate_ack_pattern_passband / generate_break_pattern_passband (telecom_system.cc:1589-1631, :1659-1689): which 1 = ACK,
+ * 2 = BREAK; out: 16*Nofdm*4 samples; uses carrier_hz, carrier_amplitude, output_power_watt, data_papr_cut, start_sample */
+int morc_generate_ack_pattern_passband(morc*, int which, const morc_tx_config* cfg, double* out_passband);   /* 0 = FIR_tx1 (HPF, Hamming), 1 = FIR_tx2 (LPF, Blackman) */
 
 /* ---- MFSK synchroniser / signalling blocks: time_sync_mfsk (ofdm.cc:1969-2062, arguments of telecom_system.cc:686),
  * detect_ack_pattern (ofdm.cc:2064-2187; which 1 = ACK tones as telecom_system.cc:1643, 2 = BREAK tones as :1698), and the

@@ -623,6 +623,24 @@ int mref_transmit_byte(void* h, const int* payload, int nBytes, const mref_tx_co
     return total;
 }
 
+// cl_telecom_system::generate_ack_pattern_passband / generate_break_pattern_passband (telecom_system.cc:1589-1631, :1659-1689)
+// composed from the reference's objects: which 1 = ACK, 2 = BREAK
+int mref_generate_ack_pattern_passband(void* h, int which, const mref_tx_config* c, double* out) {
+    Ref* r = (Ref*)h;
+    Silence s;
+    const int nsymb = cl_mfsk::ACK_PATTERN_NSYMB, interp = 4;
+    std::vector<cd> framed(size_t(nsymb) * r->Nc), mod(size_t(nsymb) * r->Nofdm);
+    if (which == 2) r->ack_mfsk.generate_break_pattern(framed.data()); else r->ack_mfsk.generate_ack_pattern(framed.data());
+    for (int i = 0; i < nsymb; i++) r->ofdm.symbol_mod(&framed[i * r->Nc], &mod[i * r->Nofdm]);
+    const float power_normalization = sqrt((double)(r->Nfft * interp));
+    const double ack_boost = sqrt((double)r->Nc / r->ack_mfsk.nStreams) * pow(10.0, -2.0 / 20.0);
+    for (int j = 0; j < r->Nofdm * nsymb; j++) { mod[j] /= power_normalization; mod[j] *= sqrt(c->output_power_watt) * ack_boost; }
+    r->ofdm.passband_start_sample = c->start_sample;
+    r->ofdm.baseband_to_passband(mod.data(), r->Nofdm * nsymb, out, 48000.0, c->carrier_hz, c->carrier_amplitude, interp);
+    r->ofdm.peak_clip(out, r->Nofdm * nsymb * interp, c->data_papr_cut);
+    return r->Nofdm * nsymb * interp;
+}
+
 // ---- MFSK synchroniser / signalling blocks ------------------------------------------------------------
 // Known tone patterns as time-domain symbols (symbol_mod applied, unscaled): which 0 = the mode's MFSK preamble
 // (generate_preamble, telecom_system.cc:461-465; MFSK modes only), 1 = ACK, 2 = BREAK (generate_ack_pattern /

@@ -193,6 +193,9 @@ def tx_case(lib, cfg):
         y = lib.transmit_byte(msg, message_location=oraclelib.SINGLE_MESSAGE)
         rec["ctrl"] = [digest(y), int(np.count_nonzero(y))]
         lib.set_ctrl_mode(0)
+    # generate_ack_pattern_passband / generate_break_pattern_passband (telecom_system.cc:1589-1689)
+    rec["ack"] = digest(lib.generate_ack_pattern_passband(1))
+    rec["break"] = digest(lib.generate_ack_pattern_passband(2, start_sample=10 ** 7 + 1, output_power_watt=0.05, data_papr_cut=3.0))
     assert lib.transmit_byte(np.zeros(nb + 1, np.int32)) is None       # "message too long.. not sent."
     return rec
 

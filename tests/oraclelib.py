@@ -352,8 +352,18 @@ def _sync_methods(cls):
         assert n == out.size, n
         return out
 
+    def generate_ack_pattern_passband(self, which=1, carrier=CARRIER, start_sample=0, amplitude=AMPLITUDE, output_power_watt=0.1,
+                                      data_papr_cut=10.0):
+        """cl_telecom_system::generate_ack_pattern_passband (which=1) / generate_break_pattern_passband (which=2)."""
+        c = TxConfig(carrier, amplitude, output_power_watt, 7.0, data_papr_cut, start_sample, SINGLE_MESSAGE, 0)
+        out = np.zeros(16 * self.Nofdm * 4)
+        f = self._fn("generate_ack_pattern_passband")
+        f.restype = C.c_int
+        assert f(self.h, C.c_int(which), C.byref(c), _p(out)) == out.size
+        return out
+
     for fn in (preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband, mfsk_pattern, time_sync_mfsk,
-               detect_ack_pattern, transmit_byte):
+               detect_ack_pattern, transmit_byte, generate_ack_pattern_passband):
         setattr(cls, fn.__name__, fn)
 
 

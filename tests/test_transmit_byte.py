@@ -169,6 +169,30 @@ def test_gpu_loopback_transmit_then_receive_byte(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 100])
+def test_gpu_ack_and_break_patterns_match_oracle_and_are_detected(cfg):
+    """generate_ack_pattern_passband / generate_break_pattern_passband: bit-exact samples, and the library's own detector
+    (mgpu_detect_ack_pattern_from_passband) finds each pattern — and not the other one — in a noisy buffer."""
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=4)
+    for which in (1, 2):
+        for kw in (dict(), dict(start_sample=987654321, output_power_watt=0.05, data_papr_cut=3.0)):
+            got = rx.generate_ack_pattern_passband(which, CARRIER, **kw)
+            assert np.array_equal(got, orc.generate_ack_pattern_passband(which, **kw)), (cfg, which, kw)
+    rng = np.random.default_rng(cfg)
+    n = 40 * orc.Nofdm * 4
+    for which in (1, 2):
+        x = rng.standard_normal(n) * 0.02
+        p = rx.generate_ack_pattern_passband(which, CARRIER)
+        x[7000: 7000 + p.size] += p
+        m, k = rx.detect_ack_pattern_from_passband(x, CARRIER, pattern=which)
+        mo, ko = rx.detect_ack_pattern_from_passband(x, CARRIER, pattern=3 - which)
+        # the pattern starts off the detector's symbol raster, so each tone's energy is split over two slots: metric ~6 of 16
+        assert float(m[0]) > 4 and int(k[0]) >= 12 and int(ko[0]) < 6 and float(mo[0]) < 0.5 * float(m[0]), (cfg, which, m, k, mo, ko)
+
+
+@pytest.mark.gpu
 def test_gpu_symbol_mod_is_the_unnormalised_ifft_with_guard_interval():
     from mercury_amd import RxPhy
     rx = RxPhy(8, max_batch=4)
