@@ -235,12 +235,17 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
                     const bool valid = deg != 0;
                     double rr = 0.0;
                     if (valid) {
-                        const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
+                        // the other deg-1 values of the check in slot order: step j reads slot j, or j+1 once the lane's own
+                        // slot has been passed (the loop counter is wave-uniform, so the skip is one compare + add-with-carry)
+                        const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs, degm1 = deg - 1;
                         double temp = 1;
-                        for (int j = 0; j < deg; ++j) {
-                            const double m = M[cs + j];
-                            temp *= (j == pos) ? 1.0 : m;      // x * 1.0 == x exactly: same product as skipping j == pos
+                        int j = 0;
+                        for (; j + 2 <= degm1; j += 2) {       // two reads in flight per LDS round trip; same multiplication order
+                            const double a = M[cs + j + (j >= pos ? 1 : 0)], b = M[cs + j + 1 + (j + 1 >= pos ? 1 : 0)];
+                            temp *= a;
+                            temp *= b;
                         }
+                        if (j < degm1) temp *= M[cs + j + (j >= pos ? 1 : 0)];
                         if (temp == 1) temp = 0.9999999;
                         if (temp == -1) temp = -0.9999999;
                         rr = 2 * spa_atanh(temp);
