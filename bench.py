@@ -316,7 +316,7 @@ def main():
                          "bytes_per_codeword_iteration": b_iter,
                          "note": "algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are LDS-resident so real HBM "
                                  "traffic is far lower; the decoder is VALU-issue bound (profiles/r01_pmc_sq_*.csv: SQ_ACTIVE_INST_VALU "
-                                 "~99% of SIMD cycles for spa, fp64), not HBM bound"},
+                                 "x 4 cycles ~95% of SIMD cycles for spa, fp64), not HBM bound"},
         }
         # the outputs of the last timed step, kept aside before the extras reuse the buffers: the cpu_baseline leg checks them
         S_chk = min(F, args.cpu_sample_per_core * usable_cores())
