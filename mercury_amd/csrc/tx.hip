@@ -129,6 +129,52 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_fir_real_kernel(const dou
     out[size_t(blockIdx.y) * n + i] = acc;
 }
 
+// The same filter for the tap count the reference's design always yields (97 at 48 kHz with a 1 kHz transition band), shaped for
+// the hardware: 1024 outputs per workgroup, 4 consecutive outputs per thread. Output i0+4t+r needs inputs 4t + m, m = r + 96 - j,
+// so the tile is stored by (m & 3, m >> 2): at every step all lanes read consecutive doubles (no bank conflicts), each thread
+// walks a sliding window of 100 inputs through registers (one LDS read per 4 multiply-adds instead of 8) and the taps arrive
+// through scalar loads. Samples outside the frame are zero in the tile: adding their +-0 products changes no sum (the
+// accumulators start at +0 and never become -0), so this equals the reference's skipping of those taps bit for bit.
+#define FIR97_NT 97
+#define FIR97_OUT 1024
+#define FIR97_S 281                             // doubles per residue class: (1024 + 96) / 4 = 280, + 1
+extern "C" __global__ __launch_bounds__(256) void mgpu_fir97_kernel(const double* __restrict__ in, int n, const double* __restrict__ taps,
+                                                                  double* __restrict__ out) {
+    __shared__ double tile[4 * FIR97_S];
+    const int t = threadIdx.x, h = (FIR97_NT - 1) / 2, i0 = blockIdx.x * FIR97_OUT, lo = i0 + h - (FIR97_NT - 1);
+    const double* x = in + size_t(blockIdx.y) * n;
+    for (int e = t; e < FIR97_OUT + FIR97_NT - 1; e += 256) {
+        const int q = lo + e;
+        tile[(e & 3) * FIR97_S + (e >> 2)] = (q >= 0 && q < n) ? x[q] : 0.0;
+    }
+    __syncthreads();
+    const double* w = tile + t;
+#define FIR97_W(m) w[((m) & 3) * FIR97_S + ((m) >> 2)]
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    double w0 = FIR97_W(96), w1 = FIR97_W(97), w2 = FIR97_W(98), w3 = FIR97_W(99);    // step j works on inputs 96-j .. 99-j
+    // 4 rounds of 24 taps (a round's taps fit the scalar registers; the window pointer moves back 6 doubles per round), then tap 96
+#pragma unroll 1
+    for (int jb = 0; jb < FIR97_NT - 1; jb += 24) {
+        const double* c = taps + jb;
+#pragma unroll
+        for (int jj = 0; jj < 24; ++jj) {
+            const double cj = c[jj];
+            a0 += w0 * cj; a1 += w1 * cj; a2 += w2 * cj; a3 += w3 * cj;
+            w3 = w2; w2 = w1; w1 = w0; w0 = FIR97_W(95 - jj);
+        }
+        w -= 6;
+    }
+    {
+        const double cj = taps[FIR97_NT - 1];
+        a0 += w0 * cj; a1 += w1 * cj; a2 += w2 * cj; a3 += w3 * cj;
+    }
+#undef FIR97_W
+    const int i = i0 + 4 * t;
+    double* y = out + size_t(blockIdx.y) * n + i;
+    if (i + 3 < n) { y[0] = a0; y[1] = a1; y[2] = a2; y[3] = a3; }
+    else { if (i < n) y[0] = a0; if (i + 1 < n) y[1] = a1; if (i + 2 < n) y[2] = a2; }
+}
+
 using namespace mgpu_detail;
 
 namespace {
@@ -242,9 +288,13 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
         if (filtered) {
             double* t1 = d_t1.as<double>() + size_t(off) * total;
             for (int w = 0; w < 2; ++w) {
-                const size_t lds = size_t(256 + 2 * st.ntaps[w] - 1) * 8;
-                hipLaunchKernelGGL(mgpu_fir_real_kernel, dim3((total + 255) / 256, n), dim3(256), lds, s, w ? t1 : o, total, st.d_fir[w], st.ntaps[w],
-                                   w ? d_out + size_t(off) * total : t1);
+                double* dst = w ? d_out + size_t(off) * total : t1;
+                if (st.ntaps[w] == FIR97_NT) {
+                    hipLaunchKernelGGL(mgpu_fir97_kernel, dim3((total + FIR97_OUT - 1) / FIR97_OUT, n), dim3(256), 0, s, w ? t1 : o, total, st.d_fir[w], dst);
+                } else {
+                    const size_t lds = size_t(256 + 2 * st.ntaps[w] - 1) * 8;
+                    hipLaunchKernelGGL(mgpu_fir_real_kernel, dim3((total + 255) / 256, n), dim3(256), lds, s, w ? t1 : o, total, st.d_fir[w], st.ntaps[w], dst);
+                }
                 HIPCK(hipGetLastError());
             }
         }
