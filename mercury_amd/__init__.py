@@ -1,4 +1,4 @@
-"""mercury_amd — MI355X-native implementation of Mercury's physical-layer RX hot path.
+"""mercury_amd — MI355X-native implementation of Mercury's physical-layer RX hot path (and its transmit mirror).
 
 Only what the path needs lives here: ``csrc/`` (hand-written HIP kernels for gfx950 + the C-ABI
 declared in ``include/mercury_gpu.h``), ``data/`` (the LDPC graphs as compact derived data) and

@@ -1,5 +1,6 @@
-// Synthetic-workload generator (NOT part of the RX path; bench.py and the scale tests use it so
-// that inputs are born in HBM): Philox-keyed payload -> CRC16 -> scrambler -> IRA LDPC encode ->
+// The transmit chain from message bytes to baseband samples, in two roles: (1) the synthetic-workload generator (NOT part
+// of the RX path; bench.py and the scale tests use it so that inputs are born in HBM), and (2) with the caller's bytes and the
+// channel switched off, the first stage of transmit_byte (tx.hip, include/mercury_tx.h). Philox-keyed payload -> CRC16 -> scrambler -> IRA LDPC encode ->
 // bit interleave -> constellation map -> time/freq interleave -> framer (pilots) -> IFFT + GI ->
 // channel (AWGN, optional static 2-path). It mirrors the reference TX chain
 // (telecom_system.cc:343-382 transmit_byte, :384-470 transmit_bit; ldpc.cc:111-132 encode;
