@@ -107,29 +107,8 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_peak_clip_kernel(double* 
     }
 }
 
-// cl_FIR::apply(double*) (fir_filter.cc:189-210): out[i] = sum_j in[i + h - j] * c[j] over the taps whose sample exists,
-// added in tap order. 256 outputs per workgroup from an LDS tile of 256 + ntaps - 1 inputs.
-extern "C" __global__ __launch_bounds__(256) void mgpu_fir_real_kernel(const double* __restrict__ in, int n, const double* __restrict__ taps,
-                                                                     int nt, double* __restrict__ out) {
-    extern __shared__ double fir_s[];
-    double* tile = fir_s;                       // in[i0 + h - (nt-1) .. i0 + h + 255]
-    double* c = fir_s + 256 + nt - 1;
-    const int h = (nt - 1) / 2, i0 = blockIdx.x * 256, lo = i0 + h - (nt - 1);
-    const double* x = in + size_t(blockIdx.y) * n;
-    for (int k = threadIdx.x; k < 256 + nt - 1; k += 256) { const int q = lo + k; tile[k] = (q >= 0 && q < n) ? x[q] : 0.0; }
-    for (int k = threadIdx.x; k < nt; k += 256) c[k] = taps[k];
-    __syncthreads();
-    const int i = i0 + threadIdx.x;
-    if (i >= n) return;
-    double acc = 0.0;
-    for (int j = 0; j < nt; ++j) {
-        const int q = i + h - j;
-        if (q >= 0 && q < n) acc += tile[q - lo] * c[j];
-    }
-    out[size_t(blockIdx.y) * n + i] = acc;
-}
-
-// The same filter for the tap count the reference's design always yields (97 at 48 kHz with a 1 kHz transition band), shaped for
+// cl_FIR::apply(double*) (fir_filter.cc:189-210): out[i] = sum_j in[i + h - j] * c[j] over the taps whose sample exists, added in
+// tap order — for the tap count the reference's design always yields (97 at 48 kHz with a 1 kHz transition band), shaped for
 // the hardware: 1024 outputs per workgroup, 4 consecutive outputs per thread. Output i0+4t+r needs inputs 4t + m, m = r + 96 - j,
 // so the tile is stored by (m & 3, m >> 2): at every step all lanes read consecutive doubles (no bank conflicts), each thread
 // walks a sliding window of 100 inputs through registers (one LDS read per 4 multiply-adds instead of 8) and the taps arrive
@@ -255,6 +234,7 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
             HIPCK(hipMalloc(reinterpret_cast<void**>(&st.d_fir[w]), taps.size() * 8));
             HIPCK(hipMemcpy(st.d_fir[w], taps.data(), taps.size() * 8, hipMemcpyHostToDevice));
             st.ntaps[w] = int(taps.size());
+            need(st.ntaps[w] == FIR97_NT, "transmit filter design changed: the filter kernel is built for 97 taps");
         }
         st.carrier = cfg.carrier_hz;
     }
@@ -289,12 +269,7 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
             double* t1 = d_t1.as<double>() + size_t(off) * total;
             for (int w = 0; w < 2; ++w) {
                 double* dst = w ? d_out + size_t(off) * total : t1;
-                if (st.ntaps[w] == FIR97_NT) {
-                    hipLaunchKernelGGL(mgpu_fir97_kernel, dim3((total + FIR97_OUT - 1) / FIR97_OUT, n), dim3(256), 0, s, w ? t1 : o, total, st.d_fir[w], dst);
-                } else {
-                    const size_t lds = size_t(256 + 2 * st.ntaps[w] - 1) * 8;
-                    hipLaunchKernelGGL(mgpu_fir_real_kernel, dim3((total + 255) / 256, n), dim3(256), lds, s, w ? t1 : o, total, st.d_fir[w], st.ntaps[w], dst);
-                }
+                hipLaunchKernelGGL(mgpu_fir97_kernel, dim3((total + FIR97_OUT - 1) / FIR97_OUT, n), dim3(256), 0, s, w ? t1 : o, total, st.d_fir[w], dst);
                 HIPCK(hipGetLastError());
             }
         }
