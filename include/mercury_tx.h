@@ -47,8 +47,8 @@ int mgpu_transmit_frame_samples(mgpu_ctx* ctx);
  * control frame the row is zero. Host buffers, blocking. */
 int mgpu_transmit_byte_batch(mgpu_ctx* ctx, const uint8_t* payload, int payload_stride, const int* nbytes, int F,
                              const mgpu_transmit_config* config, double* passband);
-/* the same on device buffers, launched on `stream` (NULL = the context's own stream); returns when the samples are written
- * (the per-call work buffers are released on return) */
+/* the same on device buffers: asynchronous on `stream` when one is given (the context's work buffers are reused by its next
+ * transmit call, so keep one context's calls on one stream); with NULL the context's own stream is used and synchronised */
 int mgpu_transmit_byte_batch_dev(mgpu_ctx* ctx, const void* d_payload, int payload_stride, const void* d_nbytes, int F,
                                  const mgpu_transmit_config* config, void* d_passband, void* stream);
 

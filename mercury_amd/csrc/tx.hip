@@ -70,22 +70,23 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_tx_mix_kernel(
 }
 
 // cl_ofdm::peak_clip (ofdm.cc:1565-1592) on one segment of every frame: blockIdx.y = 0 the preamble part, 1 the data part.
-// The mean power is a sum in sample order: terms formed in parallel a chunk at a time, one lane adds them.
-#define PC_CHUNK 4096
-extern "C" __global__ __launch_bounds__(256) void mgpu_peak_clip_kernel(double* __restrict__ x, int total, int npre4, int used, double pow_pre,
-                                                                      double pow_data) {
+// The mean power is a sum in sample order, i.e. one dependent chain of additions per segment: a single wavefront per segment
+// forms 512 terms at a time in parallel and its first lane adds them; the chip hides the chains' latency by running all
+// segments' wavefronts side by side (8 per SIMD, 4 KB of LDS each).
+#define PC_CHUNK 512
+extern "C" __global__ __launch_bounds__(64) void mgpu_peak_clip_kernel(double* __restrict__ x, int total, int npre4, int used, double pow_pre,
+                                                                     double pow_data) {
     __shared__ double term[PC_CHUNK];
-    __shared__ double peak_s;
-    const int seg = blockIdx.y;
+    const int seg = blockIdx.y, lane = threadIdx.x;
     double* p = x + size_t(blockIdx.x) * total + (seg ? npre4 : 0);
     const int n = seg ? used - npre4 : npre4;
     if (n <= 0) return;
     double acc = 0.0;
     for (int base = 0; base < n; base += PC_CHUNK) {
         const int m = min(PC_CHUNK, n - base);
-        for (int i = threadIdx.x; i < m; i += 256) { const double v = p[base + i]; term[i] = v * v; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
+        for (int i = lane; i < m; i += 64) { const double v = p[base + i]; term[i] = v * v; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
             int q = 0;
             for (; q + 8 <= m; q += 8) {
                 const double a0 = term[q], a1 = term[q + 1], a2 = term[q + 2], a3 = term[q + 3];
@@ -94,12 +95,11 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_peak_clip_kernel(double* 
             }
             for (; q < m; ++q) acc += term[q];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
-    if (threadIdx.x == 0) peak_s = sqrt((acc / double(n)) * (seg ? pow_data : pow_pre));
-    __syncthreads();
-    const double peak = peak_s;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    acc = __shfl(acc, 0);
+    const double peak = sqrt((acc / double(n)) * (seg ? pow_data : pow_pre));
+    for (int i = lane; i < n; i += 64) {
         double v = p[i];
         if (v > 0 && v > peak) v = peak;
         if (v < 0 && v < -peak) v = -peak;
@@ -166,11 +166,24 @@ struct TxState {
     int ntaps[2] = {0, 0};
     double* d_cs = nullptr;
     size_t cs_cap = 0;
+    void* d_work[3] = {nullptr, nullptr, nullptr};      // data baseband, clipped passband, first filter's output: grown on demand, kept
+    size_t work_cap[3] = {0, 0, 0};
+    void* work(int i, size_t bytes, hipStream_t s) {
+        if (work_cap[i] < bytes) {
+            HIPCK(hipStreamSynchronize(s));
+            (void)hipFree(d_work[i]);
+            d_work[i] = nullptr; work_cap[i] = 0;
+            HIPCK(hipMalloc(&d_work[i], bytes));
+            work_cap[i] = bytes;
+        }
+        return d_work[i];
+    }
     double cs_carrier = -1;
     uint64_t cs_start = 0;
     size_t cs_count = 0;
     ~TxState() {
         (void)hipFree(d_pre_bb); (void)hipFree(d_fir[0]); (void)hipFree(d_fir[1]); (void)hipFree(d_cs);
+        for (void* p : d_work) (void)hipFree(p);
     }
 };
 void free_tx_state(void* p) { delete static_cast<TxState*>(p); }
@@ -245,12 +258,14 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
     const double m_pre = pw * preamble_boost * mfsk_boost, m_data = pw * mfsk_boost;
     const double pow_pre = std::pow(10, cfg.preamble_papr_cut / 10.0), pow_data = std::pow(10, cfg.data_papr_cut / 10.0);
 
-    DevBuf d_bb(size_t(F) * t.frame_samples * 16), d_t0(filtered ? size_t(F) * total * 8 : 0), d_t1(filtered ? size_t(F) * total * 8 : 0);
-    double* clipped = filtered ? d_t0.as<double>() : d_out;
+    double* const bb = static_cast<double*>(st.work(0, size_t(F) * t.frame_samples * 16, s));
+    double* const t0 = filtered ? static_cast<double*>(st.work(1, size_t(F) * total * 8, s)) : nullptr;
+    double* const t1_all = filtered ? static_cast<double*>(st.work(2, size_t(F) * total * 8, s)) : nullptr;
+    double* clipped = filtered ? t0 : d_out;
     for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
         const int n = std::min(F - off, kMaxFramesPerLaunch);
         hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(n), dim3(256), c->lds_tx, s, c->dev, uint64_t(0), uint64_t(0), n, 0.0, -1,
-                           d_bb.as<double>() + size_t(off) * t.frame_samples * 2, static_cast<uint8_t*>(nullptr),
+                           bb + size_t(off) * t.frame_samples * 2, static_cast<uint8_t*>(nullptr),
                            d_payload + size_t(off) * payload_stride, payload_stride, at(d_nbytes, size_t(off)), 0, 0);
         HIPCK(hipGetLastError());
     }
@@ -259,14 +274,14 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
         const int n = std::min(F - off, kMaxY);
         double* o = clipped + size_t(off) * total;
         hipLaunchKernelGGL(mgpu_tx_mix_kernel, dim3((total + 255) / 256, n), dim3(256), 0, s, st.d_pre_bb, npre,
-                           d_bb.as<double>() + size_t(off) * t.frame_samples * 2, t.frame_samples, ndata, double(power_normalization), m_pre, m_data,
+                           bb + size_t(off) * t.frame_samples * 2, t.frame_samples, ndata, double(power_normalization), m_pre, m_data,
                            cfg.carrier_amplitude, st.d_cs + (cfg.phase_continuous ? 2 * size_t(used) * off : 0), cfg.phase_continuous ? used : 0,
                            o, total);
         HIPCK(hipGetLastError());
-        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(n, 2), dim3(256), 0, s, o, total, npre * interp, used, pow_pre, pow_data);
+        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(n, 2), dim3(64), 0, s, o, total, npre * interp, used, pow_pre, pow_data);
         HIPCK(hipGetLastError());
         if (filtered) {
-            double* t1 = d_t1.as<double>() + size_t(off) * total;
+            double* t1 = t1_all + size_t(off) * total;
             for (int w = 0; w < 2; ++w) {
                 double* dst = w ? d_out + size_t(off) * total : t1;
                 hipLaunchKernelGGL(mgpu_fir97_kernel, dim3((total + FIR97_OUT - 1) / FIR97_OUT, n), dim3(256), 0, s, w ? t1 : o, total, st.d_fir[w], dst);
@@ -274,7 +289,6 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
             }
         }
     }
-    HIPCK(hipStreamSynchronize(s));                            // the work buffers above are released on return
 }
 
 void check_config(const mgpu_ctx* c, const mgpu_transmit_config* cfg, int payload_stride, int F) {
@@ -302,6 +316,7 @@ int mgpu_transmit_byte_batch_dev(mgpu_ctx* c, const void* d_payload, int payload
         if (F == 0) return;
         transmit_dev(c, static_cast<const uint8_t*>(d_payload), payload_stride, static_cast<const int*>(d_nbytes), F, *cfg,
                      static_cast<double*>(d_passband), stream ? static_cast<hipStream_t>(stream) : c->stream);
+        if (!stream) HIPCK(hipStreamSynchronize(c->stream));
     });
 }
 
@@ -350,7 +365,7 @@ int mgpu_generate_ack_pattern_passband(mgpu_ctx* c, int pattern, const mgpu_tran
                            0, double(power_normalization), m, 0.0, cfg->carrier_amplitude, st.d_cs, 0, d_out.as<double>(), total);
         HIPCK(hipGetLastError());
         const double p10 = std::pow(10, cfg->data_papr_cut / 10.0);
-        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(1, 1), dim3(256), 0, s, d_out.as<double>(), total, total, total, p10, p10);
+        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(1, 1), dim3(64), 0, s, d_out.as<double>(), total, total, total, p10, p10);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(out, d_out.p, size_t(total) * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));

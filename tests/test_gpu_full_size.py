@@ -98,6 +98,7 @@ def test_audio_loopback_transmit_byte_to_receive_byte_1024_windows():
     msgs = torch.randint(0, 256, (W, rx.payload_bytes), dtype=torch.uint8, device=dev, generator=g)
     total, n = rx.transmit_frame_samples(), rx.receive_buffer_samples()
     audio = torch.empty((W, total), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                                  # the library works on its own stream
     rx.transmit_byte_dev(msgs.data_ptr(), rx.payload_bytes, W, audio.data_ptr(), carrier)
     again = torch.empty_like(audio)
     rx.transmit_byte_dev(msgs.data_ptr(), rx.payload_bytes, W, again.data_ptr(), carrier)
@@ -107,6 +108,7 @@ def test_audio_loopback_transmit_byte_to_receive_byte_1024_windows():
     delays = torch.randint(5 * sym, n - total - 5 * sym, (W,), device=dev, generator=g)
     idx = delays[:, None] + torch.arange(total, device=dev)[None, :]
     wins.scatter_add_(1, idx, 2.0 * audio)                   # receiver audio gain 2 (see tests/test_transmit_byte.py)
+    torch.cuda.synchronize()
     r = rx.receive_byte_dev(wins.data_ptr(), W, carrier)       # the windows stay in HBM
     assert int(r["stats"]["message_decoded"].sum()) == W
     r_host = rx.receive_byte(wins[:64].cpu().numpy(), carrier)  # same windows from host memory: same answers

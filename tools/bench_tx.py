@@ -26,6 +26,7 @@ def main():
     dev = torch.device("cuda", 0)
     pl = torch.randint(0, 256, (F, rx.payload_bytes), dtype=torch.uint8, device=dev)
     out = torch.empty((F, total), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                                  # the library works on its own stream
     res = {"cfg": cfg, "messages": F, "samples_per_message": total}
     for name, loc in (("single_message_filtered", SINGLE_MESSAGE), ("no_filter_message", NO_FILTER_MESSAGE)):
         for _ in range(2):
