@@ -150,9 +150,13 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     auto var_update = [&](const VarRec& q) {
         const int v = q.vi & 0x7ff, deg = q.vi >> 11;
         double s = Li[v];
-        const double m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16], m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
-        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
-        s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+        const double m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
+        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
+        if (deg > 2) {      // the rows are sorted by degree: whole wavefronts of degree-2 parity bits skip the rest
+            const double m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
+            s += m2;
+            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+        }
         if (deg > 5) {
             const double m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
             s += m5;
@@ -412,9 +416,13 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
     auto var_update = [&](const VarRec& q) {
         const int v = q.vi & 0x7ff, deg = q.vi >> 11;
         float s = Li[v];
-        const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16], m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
-        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s; s = deg > 2 ? s + m2 : s;
-        s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+        const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
+        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
+        if (deg > 2) {      // rows sorted by degree: wavefronts of degree-2 parity bits skip the rest
+            const float m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
+            s += m2;
+            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+        }
         if (deg > 5) {
             const float m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
             s += m5;
