@@ -169,6 +169,34 @@ def test_gpu_loopback_transmit_then_receive_byte(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [100, 101])
+def test_gpu_loopback_mfsk_control_frames(cfg):
+    """Short MFSK control frames (set_mfsk_ctrl_mode): GPU transmit -> capture windows -> GPU receive_byte, and the CPU chain agrees."""
+    from mercury_amd import RxPhy
+    rx = RxPhy(cfg, max_batch=4, mfsk_ctrl_mode=True)
+    orc = Oracle(cfg)
+    orc.set_ctrl_mode(1)
+    W = 3
+    rng = np.random.default_rng(70 + cfg)
+    pls = rng.integers(0, 256, (W, rx.payload_bytes)).astype(np.uint8)
+    pb = rx.transmit_byte(pls, CARRIER)
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
+    n = rx.receive_buffer_samples()
+    wins = rng.standard_normal((W, n)) * 2e-3
+    sym = rx.Nofdm * 4
+    for w in range(W):
+        d = int(rng.integers(6, (n - used) // sym - 2)) * sym + int(rng.integers(0, 48))      # past symbol 4 (receive_byte's bounds) and within the guard interval of a
+        # symbol slot: time_sync_mfsk resolves whole slots only (ofdm.cc:2058)
+        wins[w, d: d + used] += pb[w, :used]
+    r = rx.receive_byte(wins, CARRIER)
+    assert r["stats"]["message_decoded"].tolist() == [1] * W
+    assert np.array_equal(r["payload"][:, : rx.payload_bytes], pls)
+    for w in range(W):
+        ref = orc.receive_byte(wins[w])
+        assert ref["message_decoded"] == 1 and ref["delay"] == r["stats"]["delay"][w] and np.array_equal(ref["payload"], pls[w])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [8, 100])
 def test_gpu_ack_and_break_patterns_match_oracle_and_are_detected(cfg):
     """generate_ack_pattern_passband / generate_break_pattern_passband: bit-exact samples, and the library's own detector
