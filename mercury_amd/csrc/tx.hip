@@ -70,36 +70,42 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_tx_mix_kernel(
 }
 
 // cl_ofdm::peak_clip (ofdm.cc:1565-1592) on one segment of every frame: blockIdx.y = 0 the preamble part, 1 the data part.
-// The mean power is a sum in sample order, i.e. one dependent chain of additions per segment: a single wavefront per segment
-// forms 512 terms at a time in parallel and its first lane adds them; the chip hides the chains' latency by running all
-// segments' wavefronts side by side (8 per SIMD, 4 KB of LDS each).
-#define PC_CHUNK 512
-extern "C" __global__ __launch_bounds__(64) void mgpu_peak_clip_kernel(double* __restrict__ x, int total, int npre4, int used, double pow_pre,
-                                                                     double pow_data) {
-    __shared__ double term[PC_CHUNK];
-    const int seg = blockIdx.y, lane = threadIdx.x;
+// The mean power is a sum in sample order, i.e. one dependent chain of additions per segment (26,112 for a mode-8 data part,
+// 348,160 for ROBUST_0). One lane walks the chain through LDS while the other three wavefronts of the workgroup form the next
+// 1024 terms (double buffer), so the chain never waits for memory; the chains of a batch run side by side (8 per CU).
+#define PC_CHUNK 1024
+extern "C" __global__ __launch_bounds__(256) void mgpu_peak_clip_kernel(double* __restrict__ x, int total, int npre4, int used, double pow_pre,
+                                                                      double pow_data) {
+    __shared__ double term[2][PC_CHUNK];
+    __shared__ double peak_s;
+    const int seg = blockIdx.y, tid = threadIdx.x;
     double* p = x + size_t(blockIdx.x) * total + (seg ? npre4 : 0);
     const int n = seg ? used - npre4 : npre4;
     if (n <= 0) return;
+    for (int i = tid; i < min(PC_CHUNK, n); i += 256) { const double v = p[i]; term[0][i] = v * v; }
+    __syncthreads();
     double acc = 0.0;
-    for (int base = 0; base < n; base += PC_CHUNK) {
+    for (int base = 0, k = 0; base < n; base += PC_CHUNK, ++k) {
         const int m = min(PC_CHUNK, n - base);
-        for (int i = lane; i < m; i += 64) { const double v = p[base + i]; term[i] = v * v; }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
+        if (tid >= 64) {                                  // producers: the chunk after this one
+            const int nb = base + PC_CHUNK, mn = min(PC_CHUNK, n - nb);
+            for (int i = tid - 64; i < mn; i += 192) { const double v = p[nb + i]; term[(k + 1) & 1][i] = v * v; }
+        } else if (tid == 0) {                            // the chain
+            const double* t = term[k & 1];
             int q = 0;
             for (; q + 8 <= m; q += 8) {
-                const double a0 = term[q], a1 = term[q + 1], a2 = term[q + 2], a3 = term[q + 3];
-                const double a4 = term[q + 4], a5 = term[q + 5], a6 = term[q + 6], a7 = term[q + 7];
+                const double a0 = t[q], a1 = t[q + 1], a2 = t[q + 2], a3 = t[q + 3];
+                const double a4 = t[q + 4], a5 = t[q + 5], a6 = t[q + 6], a7 = t[q + 7];
                 acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
             }
-            for (; q < m; ++q) acc += term[q];
+            for (; q < m; ++q) acc += t[q];
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
-    acc = __shfl(acc, 0);
-    const double peak = sqrt((acc / double(n)) * (seg ? pow_data : pow_pre));
-    for (int i = lane; i < n; i += 64) {
+    if (tid == 0) peak_s = sqrt((acc / double(n)) * (seg ? pow_data : pow_pre));
+    __syncthreads();
+    const double peak = peak_s;
+    for (int i = tid; i < n; i += 256) {
         double v = p[i];
         if (v > 0 && v > peak) v = peak;
         if (v < 0 && v < -peak) v = -peak;
@@ -278,7 +284,7 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
                            cfg.carrier_amplitude, st.d_cs + (cfg.phase_continuous ? 2 * size_t(used) * off : 0), cfg.phase_continuous ? used : 0,
                            o, total);
         HIPCK(hipGetLastError());
-        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(n, 2), dim3(64), 0, s, o, total, npre * interp, used, pow_pre, pow_data);
+        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(n, 2), dim3(256), 0, s, o, total, npre * interp, used, pow_pre, pow_data);
         HIPCK(hipGetLastError());
         if (filtered) {
             double* t1 = t1_all + size_t(off) * total;
@@ -365,7 +371,7 @@ int mgpu_generate_ack_pattern_passband(mgpu_ctx* c, int pattern, const mgpu_tran
                            0, double(power_normalization), m, 0.0, cfg->carrier_amplitude, st.d_cs, 0, d_out.as<double>(), total);
         HIPCK(hipGetLastError());
         const double p10 = std::pow(10, cfg->data_papr_cut / 10.0);
-        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(1, 1), dim3(64), 0, s, d_out.as<double>(), total, total, total, p10, p10);
+        hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(1, 1), dim3(256), 0, s, d_out.as<double>(), total, total, total, p10, p10);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(out, d_out.p, size_t(total) * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
