@@ -291,6 +291,20 @@ def main():
                 traffic = json.load(open(tfile)).get("%s_cfg%d" % (args.decoder, args.cfg))
             except Exception:
                 traffic = None
+        # secondary view for the bound the decoders actually hit (vector-instruction issue): the instruction count of one launch
+        # of THIS workload from the committed PMC pass, over the launch time measured in this run
+        issue = None
+        sfile = os.path.join(ROOT, "profiles", "r01_pmc_sq_summary.json")
+        if (os.path.exists(sfile) and not args.ldpc_only and args.cfg == 8 and F == 4096 and args.iters == 50
+                and abs(iters_per_launch - 50.0 * F) < 1e-6 * F):
+            try:
+                insts = float(json.load(open(sfile))[args.decoder]["SQ_INSTS_VALU"])
+                peak = 256 * 4 * 2.4e9 / 4            # SIMDs x clock / 4 cycles per wave64 instruction (MI355X_MICROARCH.md)
+                issue = {"bound": "valu_issue", "achieved": insts / (dec_ms * 1e-3) / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+                         "frac": insts / (dec_ms * 1e-3) / peak,
+                         "source": "SQ_INSTS_VALU per launch from profiles/r01_pmc_sq_summary.json (same workload) / kernel time of this run"}
+            except Exception:
+                issue = None
         line = {
             "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (rx.K, args.iters)) if args.ldpc_only else
                       ("RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters)),
@@ -313,6 +327,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
+                         "secondary": issue,
                          "bytes_per_codeword_iteration": b_iter,
                          "note": "algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are LDS-resident so real HBM "
                                  "traffic is far lower; the decoder is VALU-issue bound (profiles/r01_pmc_sq_*.csv: SQ_ACTIVE_INST_VALU "
