@@ -26,6 +26,10 @@ extern "C" {
 
 #define MGPU_SINGLE_MESSAGE 3      /* include/common/common_defines.h:200 */
 #define MGPU_NO_FILTER_MESSAGE 4   /* :201 — stop after peak_clip (what the ARQ batch sender asks for, arq_common.cc:2224) */
+#define MGPU_BATCH_MESSAGE 16      /* not a reference constant: the whole signal path of cl_arq_controller::send_batch
+                                      (datalink_layer/arq_common.cc:2224-2248) — the F messages as NO_FILTER_MESSAGE frames with the
+                                      carrier phase running on from one to the next, the first frame repeated in front and the last
+                                      behind, FIR_tx1 / FIR_tx2 over the concatenation; the F filtered frames are returned */
 
 typedef struct mgpu_transmit_config {
     double carrier_hz;          /* carrier_frequency (+ test_tx_carrier_offset); physical_config.cc:84 */
@@ -34,9 +38,10 @@ typedef struct mgpu_transmit_config {
     double preamble_papr_cut;   /* physical_config.cc:115: 7 (dB) */
     double data_papr_cut;       /* :116: 10 (dB) */
     uint64_t start_sample;      /* cl_ofdm::passband_start_sample when the call starts: the carrier phase origin (ofdm.cc:2311-2313) */
-    int message_location;       /* MGPU_SINGLE_MESSAGE or MGPU_NO_FILTER_MESSAGE */
+    int message_location;       /* MGPU_SINGLE_MESSAGE, MGPU_NO_FILTER_MESSAGE or MGPU_BATCH_MESSAGE */
     int phase_continuous;       /* 0: every message starts at start_sample (F independent transmitters);
-                                   1: message f starts at start_sample + f * (active samples), as F consecutive calls would */
+                                   1: message f starts at start_sample + f * (active samples), as F consecutive calls would
+                                   (always so for MGPU_BATCH_MESSAGE) */
 } mgpu_transmit_config;
 
 /* total_frame_size = Nofdm * (Nsymb + preamble_nSymb) * 4 (data_container.cc:159): samples written per message */

@@ -123,10 +123,12 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_peak_clip_kernel(double* 
 #define FIR97_NT 97
 #define FIR97_OUT 1024
 #define FIR97_S 281                             // doubles per residue class: (1024 + 96) / 4 = 280, + 1
+// Outputs [out_begin, out_begin + out_count) of each row are written, to out[row][i - out_begin] (the batch form filters a
+// padded concatenation and keeps its middle).
 extern "C" __global__ __launch_bounds__(256) void mgpu_fir97_kernel(const double* __restrict__ in, int n, const double* __restrict__ taps,
-                                                                  double* __restrict__ out) {
+                                                                  double* __restrict__ out, int out_begin, int out_count) {
     __shared__ double tile[4 * FIR97_S];
-    const int t = threadIdx.x, h = (FIR97_NT - 1) / 2, i0 = blockIdx.x * FIR97_OUT, lo = i0 + h - (FIR97_NT - 1);
+    const int t = threadIdx.x, h = (FIR97_NT - 1) / 2, i0 = out_begin + blockIdx.x * FIR97_OUT, lo = i0 + h - (FIR97_NT - 1);
     const double* x = in + size_t(blockIdx.y) * n;
     for (int e = t; e < FIR97_OUT + FIR97_NT - 1; e += 256) {
         const int q = lo + e;
@@ -154,10 +156,10 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_fir97_kernel(const double
         a0 += w0 * cj; a1 += w1 * cj; a2 += w2 * cj; a3 += w3 * cj;
     }
 #undef FIR97_W
-    const int i = i0 + 4 * t;
-    double* y = out + size_t(blockIdx.y) * n + i;
-    if (i + 3 < n) { y[0] = a0; y[1] = a1; y[2] = a2; y[3] = a3; }
-    else { if (i < n) y[0] = a0; if (i + 1 < n) y[1] = a1; if (i + 2 < n) y[2] = a2; }
+    const int i = blockIdx.x * FIR97_OUT + 4 * t;            // relative to out_begin
+    double* y = out + size_t(blockIdx.y) * out_count + i;
+    if (i + 3 < out_count) { y[0] = a0; y[1] = a1; y[2] = a2; y[3] = a3; }
+    else { if (i < out_count) y[0] = a0; if (i + 1 < out_count) y[1] = a1; if (i + 2 < out_count) y[2] = a2; }
 }
 
 using namespace mgpu_detail;
@@ -242,8 +244,10 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
     const int interp = 4, npre = t.preamble * t.Nofdm, ndata = t.active_nsymb * t.Nofdm, total = t.Nofdm * (t.Nsymb + t.preamble) * interp;
     const int used = (npre + ndata) * interp;
     TxState& st = tx_state(c, s);
-    ensure_carrier_table(st, cfg.carrier_hz, cfg.start_sample, cfg.phase_continuous ? size_t(used) * F : size_t(used), s);
-    const bool filtered = cfg.message_location == MGPU_SINGLE_MESSAGE;
+    const bool batch = cfg.message_location == MGPU_BATCH_MESSAGE;
+    const bool filtered = cfg.message_location == MGPU_SINGLE_MESSAGE || batch;
+    const bool continuous = cfg.phase_continuous || batch;
+    ensure_carrier_table(st, cfg.carrier_hz, cfg.start_sample, continuous ? size_t(used) * F : size_t(used), s);
     if (filtered && st.carrier != cfg.carrier_hz) {
         HIPCK(hipStreamSynchronize(s));
         for (int w = 0; w < 2; ++w) {
@@ -265,9 +269,11 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
     const double pow_pre = std::pow(10, cfg.preamble_papr_cut / 10.0), pow_data = std::pow(10, cfg.data_papr_cut / 10.0);
 
     double* const bb = static_cast<double*>(st.work(0, size_t(F) * t.frame_samples * 16, s));
-    double* const t0 = filtered ? static_cast<double*>(st.work(1, size_t(F) * total * 8, s)) : nullptr;
-    double* const t1_all = filtered ? static_cast<double*>(st.work(2, size_t(F) * total * 8, s)) : nullptr;
-    double* clipped = filtered ? t0 : d_out;
+    // batch form: one padding frame in front of and behind the F frames (arq_common.cc:2236-2240)
+    const size_t pad = batch ? size_t(total) : 0;
+    double* const t0 = filtered ? static_cast<double*>(st.work(1, (size_t(F) * total + 2 * pad) * 8, s)) : nullptr;
+    double* const t1_all = filtered ? static_cast<double*>(st.work(2, (size_t(F) * total + 2 * pad) * 8, s)) : nullptr;
+    double* clipped = filtered ? t0 + pad : d_out;
     for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
         const int n = std::min(F - off, kMaxFramesPerLaunch);
         hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(n), dim3(256), c->lds_tx, s, c->dev, uint64_t(0), uint64_t(0), n, 0.0, -1,
@@ -281,26 +287,40 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
         double* o = clipped + size_t(off) * total;
         hipLaunchKernelGGL(mgpu_tx_mix_kernel, dim3((total + 255) / 256, n), dim3(256), 0, s, st.d_pre_bb, npre,
                            bb + size_t(off) * t.frame_samples * 2, t.frame_samples, ndata, double(power_normalization), m_pre, m_data,
-                           cfg.carrier_amplitude, st.d_cs + (cfg.phase_continuous ? 2 * size_t(used) * off : 0), cfg.phase_continuous ? used : 0,
+                           cfg.carrier_amplitude, st.d_cs + (continuous ? 2 * size_t(used) * off : 0), continuous ? used : 0,
                            o, total);
         HIPCK(hipGetLastError());
         hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(n, 2), dim3(256), 0, s, o, total, npre * interp, used, pow_pre, pow_data);
         HIPCK(hipGetLastError());
-        if (filtered) {
+        if (filtered && !batch) {
             double* t1 = t1_all + size_t(off) * total;
             for (int w = 0; w < 2; ++w) {
                 double* dst = w ? d_out + size_t(off) * total : t1;
-                hipLaunchKernelGGL(mgpu_fir97_kernel, dim3((total + FIR97_OUT - 1) / FIR97_OUT, n), dim3(256), 0, s, w ? t1 : o, total, st.d_fir[w], dst);
+                hipLaunchKernelGGL(mgpu_fir97_kernel, dim3((total + FIR97_OUT - 1) / FIR97_OUT, n), dim3(256), 0, s, w ? t1 : o, total, st.d_fir[w], dst, 0, total);
                 HIPCK(hipGetLastError());
             }
         }
+    }
+    if (batch) {        // arq_common.cc:2236-2248: pad with the first / last frame, filter the concatenation, keep the middle
+        const size_t ncat = size_t(F + 2) * total;
+        HIPCK(hipMemcpyAsync(t0, t0 + total, size_t(total) * 8, hipMemcpyDeviceToDevice, s));
+        HIPCK(hipMemcpyAsync(t0 + size_t(F + 1) * total, t0 + size_t(F) * total, size_t(total) * 8, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(mgpu_fir97_kernel, dim3(unsigned((ncat + FIR97_OUT - 1) / FIR97_OUT), 1), dim3(256), 0, s, t0, int(ncat), st.d_fir[0], t1_all, 0,
+                           int(ncat));
+        HIPCK(hipGetLastError());
+        const size_t nout = size_t(F) * total;
+        hipLaunchKernelGGL(mgpu_fir97_kernel, dim3(unsigned((nout + FIR97_OUT - 1) / FIR97_OUT), 1), dim3(256), 0, s, t1_all, int(ncat), st.d_fir[1], d_out,
+                           total, int(nout));
+        HIPCK(hipGetLastError());
     }
 }
 
 void check_config(const mgpu_ctx* c, const mgpu_transmit_config* cfg, int payload_stride, int F) {
     need(cfg != nullptr && F >= 0, "bad argument");
-    need(cfg->message_location == MGPU_SINGLE_MESSAGE || cfg->message_location == MGPU_NO_FILTER_MESSAGE,
-         "message_location must be MGPU_SINGLE_MESSAGE or MGPU_NO_FILTER_MESSAGE");
+    need(cfg->message_location == MGPU_SINGLE_MESSAGE || cfg->message_location == MGPU_NO_FILTER_MESSAGE || cfg->message_location == MGPU_BATCH_MESSAGE,
+         "message_location must be MGPU_SINGLE_MESSAGE, MGPU_NO_FILTER_MESSAGE or MGPU_BATCH_MESSAGE");
+    need(cfg->message_location != MGPU_BATCH_MESSAGE || (size_t(F) + 2) * size_t(mgpu_transmit_frame_samples(const_cast<mgpu_ctx*>(c))) < (size_t(1) << 31),
+         "batch too long for one filtering pass (2^31 samples)");
     need(payload_stride >= c->tab.payload_bytes, "payload_stride is shorter than the frame's payload");
     need(cfg->carrier_hz > 0 && cfg->carrier_hz < kSampleRate / 2 && cfg->output_power_watt >= 0, "bad carrier or power");
 }

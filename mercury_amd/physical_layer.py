@@ -52,7 +52,7 @@ class TransmitConfig(C.Structure):     # include/mercury_tx.h
                 ("message_location", C.c_int), ("phase_continuous", C.c_int)]
 
 
-SINGLE_MESSAGE, NO_FILTER_MESSAGE = 3, 4
+SINGLE_MESSAGE, NO_FILTER_MESSAGE, BATCH_MESSAGE = 3, 4, 16
 
 LINK_STATE_DTYPE = np.dtype([("delay_of_last_decoded_message", "<i4"), ("freq_offset_of_last_decoded_message", "<f8"),
                              ("mfsk_search_start", "<i4")], align=True)

@@ -1091,6 +1091,32 @@ static void peak_clip(double* in, int n, double papr) {
         if (in[i] < 0 && in[i] < -peak) in[i] = -peak;
     }
 }
+/* The signal path of cl_arq_controller::send_batch (datalink_layer/arq_common.cc:2224-2248): every queued message through
+ * transmit_byte(..., NO_FILTER_MESSAGE) with the carrier phase running on, one copy of the first frame in front and of the last
+ * behind, FIR_tx1 and FIR_tx2 over the whole concatenation, the F frames in the middle are what is played.
+ * payloads: [F][stride] ints; out: [F][total_frame_size]. */
+int morc_transmit_batch(morc* o, const int* payloads, int stride, const int* nbytes, int F, const morc_tx_config* c, double* out) {
+    const int interp = 4, total = o->Nofdm * (o->Nsymb + o->preamble) * interp, used = (o->preamble + o->active_nsymb) * o->Nofdm * interp;
+    double* cat = malloc(sizeof(double) * (size_t)(F + 2) * total);
+    morc_tx_config cc = *c;
+    cc.message_location = 4;
+    for (int i = 0; i < F; i++) {
+        cc.start_sample = c->start_sample + (unsigned long long)i * used;
+        if (morc_transmit_byte(o, payloads + (size_t)i * stride, nbytes ? nbytes[i] : (o->nReal - 16) / 8, &cc, cat + (size_t)(i + 1) * total) < 0) { free(cat); return -1; }
+    }
+    memcpy(cat, cat + total, sizeof(double) * total);
+    memcpy(cat + (size_t)(F + 1) * total, cat + (size_t)F * total, sizeof(double) * total);
+    double t1c[128], t2c[128];
+    int n1 = morc_tx_fir_taps(c->carrier_hz, 0, t1c), n2 = morc_tx_fir_taps(c->carrier_hz, 1, t2c);
+    int n = (F + 2) * total;
+    double* f1 = calloc(n, sizeof(double)); double* f2 = calloc(n, sizeof(double));
+    fir_apply_real(t1c, n1, cat, f1, n);
+    fir_apply_real(t2c, n2, f1, f2, n);
+    memcpy(out, f2 + total, sizeof(double) * (size_t)F * total);
+    free(cat); free(f1); free(f2);
+    return F * total;
+}
+
 /* cl_telecom_system::generate_ack_pattern_passband / generate_break_pattern_passband — telecom_system.cc:1589-1631, :1659-1689:
  * the 16 known tone symbols (which 1 = ACK, 2 = BREAK) -> IFFT+GI -> drive-level scaling -> passband -> peak_clip at data_papr_cut */
 int morc_generate_ack_pattern_passband(morc* o, int which, const morc_tx_config* c, double* out) {

@@ -117,6 +117,9 @@ typedef struct morc_tx_config {
 } morc_tx_config;
 int morc_transmit_byte(morc*, const int* payload, int nBytes, const morc_tx_config* cfg, double* out_passband);
 int morc_tx_fir_taps(double carrier_hz, int which, double* taps);
+/* the signal path of cl_arq_controller::send_batch (arq_common.cc:2224-2248): F messages unfiltered with the carrier running on,
+ * the first and last frame repeated as padding, both transmit filters over the concatenation; out: [F][total_frame_size] */
+int morc_transmit_batch(morc*, const int* payloads, int stride, const int* nbytes, int F, const morc_tx_config* cfg, double* out);
 /* generate_ack_pattern_passband / generate_break_pattern_passband (telecom_system.cc:1589-1631, :1659-1689): which 1 = ACK,
  * 2 = BREAK; out: 16*Nofdm*4 samples; uses carrier_hz, carrier_amplitude, output_power_watt, data_papr_cut, start_sample */
 int morc_generate_ack_pattern_passband(morc*, int which, const morc_tx_config* cfg, double* out_passband);   /* 0 = FIR_tx1 (HPF, Hamming), 1 = FIR_tx2 (LPF, Blackman) */

@@ -623,6 +623,36 @@ int mref_transmit_byte(void* h, const int* payload, int nBytes, const mref_tx_co
     return total;
 }
 
+// The signal path of cl_arq_controller::send_batch (datalink_layer/arq_common.cc:2224-2248; that file itself needs the whole
+// data-link layer and the audio ring): transmit_byte(NO_FILTER_MESSAGE) per message with the carrier running on, the first frame
+// repeated in front and the last behind, FIR_tx1 / FIR_tx2 (the reference's objects) over the concatenation, middle F frames out.
+int mref_transmit_batch(void* h, const int* payloads, int stride, const int* nbytes, int F, const mref_tx_config* c, double* out) {
+    Ref* r = (Ref*)h;
+    const double bandwidth = 48000.0 * 50.0 / 256 / 4, fs = 48000.0;
+    const int interp = 4, total = r->Nofdm * (r->Nsymb + r->preamble_nsymb) * interp, used = (r->preamble_nsymb + r->active_nsymb) * r->Nofdm * interp;
+    std::vector<double> cat(size_t(F + 2) * total);
+    mref_tx_config cc = *c;
+    cc.message_location = NO_FILTER_MESSAGE;
+    for (int i = 0; i < F; i++) {
+        cc.start_sample = c->start_sample + (unsigned long long)i * used;
+        if (mref_transmit_byte(h, payloads + size_t(i) * stride, nbytes ? nbytes[i] : (r->nReal - 16) / 8, &cc, &cat[size_t(i + 1) * total]) < 0) return -1;
+    }
+    for (int i = 0; i < total; i++) { cat[i] = cat[total + i]; cat[size_t(F + 1) * total + i] = cat[size_t(F) * total + i]; }   // arq_common.cc:2236-2240
+    cl_FIR f1, f2;
+    f1.filter_window = HAMMING;  f1.filter_transition_bandwidth = 1000;
+    f1.lpf_filter_cut_frequency = c->carrier_hz + bandwidth / 2;  f1.hpf_filter_cut_frequency = c->carrier_hz - bandwidth / 2;
+    f1.type = HPF;  f1.sampling_frequency = fs;  f1.design();
+    f2.filter_window = BLACKMAN;  f2.filter_transition_bandwidth = 1000;
+    f2.lpf_filter_cut_frequency = c->carrier_hz + bandwidth / 2;  f2.hpf_filter_cut_frequency = c->carrier_hz - bandwidth / 2;
+    f2.type = LPF;  f2.sampling_frequency = fs;  f2.design();
+    const int n = (F + 2) * total;
+    std::vector<double> t1(n, 0.0), t2(n, 0.0);                         // :2243-2245 memset
+    f1.apply(cat.data(), t1.data(), n);
+    f2.apply(t1.data(), t2.data(), n);
+    memcpy(out, &t2[total], sizeof(double) * size_t(F) * total);      // :2283 tx_transfer of frames 1..F
+    return F * total;
+}
+
 // cl_telecom_system::generate_ack_pattern_passband / generate_break_pattern_passband (telecom_system.cc:1589-1631, :1659-1689)
 // composed from the reference's objects: which 1 = ACK, 2 = BREAK
 int mref_generate_ack_pattern_passband(void* h, int which, const mref_tx_config* c, double* out) {

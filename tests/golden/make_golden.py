@@ -21,7 +21,8 @@ peak, Moose, time_sync_mfsk, the ACK / BREAK detector) of the compiled reference
 
 `--tx` writes golden_tx.json: cl_telecom_system::transmit_byte composed from the compiled reference's objects
 (oracle/ref_harness.cc:mref_transmit_byte) for a seeded message per mode — filtered (SINGLE_MESSAGE) and unfiltered
-(NO_FILTER_MESSAGE), two carrier phase origins, a short message, MFSK control frames.
+(NO_FILTER_MESSAGE), two carrier phase origins, a short message, MFSK control frames, the ARQ sender's batch form (frames
+filtered as one concatenation) and the ACK / BREAK tone patterns.
 
 Fixtures are DATA (inputs are regenerated from the recorded seeds; a digest of the input guards
 against generator drift). No reference source text is stored.
@@ -193,6 +194,9 @@ def tx_case(lib, cfg):
         y = lib.transmit_byte(msg, message_location=oraclelib.SINGLE_MESSAGE)
         rec["ctrl"] = [digest(y), int(np.count_nonzero(y))]
         lib.set_ctrl_mode(0)
+    # the signal path of cl_arq_controller::send_batch (arq_common.cc:2224-2248): three messages, one of them short
+    pl3 = rng.integers(0, 256, (3, nb)).astype(np.int32)
+    rec["send_batch"] = digest(lib.transmit_batch(pl3, np.array([nb, 2, nb // 2], np.int32), start_sample=31337))
     # generate_ack_pattern_passband / generate_break_pattern_passband (telecom_system.cc:1589-1689)
     rec["ack"] = digest(lib.generate_ack_pattern_passband(1))
     rec["break"] = digest(lib.generate_ack_pattern_passband(2, start_sample=10 ** 7 + 1, output_power_watt=0.05, data_papr_cut=3.0))

@@ -352,6 +352,20 @@ def _sync_methods(cls):
         assert n == out.size, n
         return out
 
+    def transmit_batch(self, payloads, nbytes=None, carrier=CARRIER, start_sample=0, amplitude=AMPLITUDE, output_power_watt=0.1,
+                       preamble_papr_cut=7.0, data_papr_cut=10.0):
+        """The signal path of cl_arq_controller::send_batch: [F, stride] message bytes -> [F, total_frame_size] filtered audio."""
+        pl = np.ascontiguousarray(payloads, np.int32)
+        F, stride = pl.shape
+        nb = None if nbytes is None else np.ascontiguousarray(nbytes, np.int32)
+        c = TxConfig(carrier, amplitude, output_power_watt, preamble_papr_cut, data_papr_cut, start_sample, NO_FILTER_MESSAGE, 0)
+        out = np.zeros((F, (self.preamble_nsymb + self.Nsymb) * self.Nofdm * 4))
+        f = self._fn("transmit_batch")
+        f.restype = C.c_int
+        n = f(self.h, _p(pl), C.c_int(stride), None if nb is None else _p(nb), C.c_int(F), C.byref(c), _p(out))
+        assert n == out.size, n
+        return out
+
     def generate_ack_pattern_passband(self, which=1, carrier=CARRIER, start_sample=0, amplitude=AMPLITUDE, output_power_watt=0.1,
                                       data_papr_cut=10.0):
         """cl_telecom_system::generate_ack_pattern_passband (which=1) / generate_break_pattern_passband (which=2)."""
@@ -363,7 +377,7 @@ def _sync_methods(cls):
         return out
 
     for fn in (preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband, mfsk_pattern, time_sync_mfsk,
-               detect_ack_pattern, transmit_byte, generate_ack_pattern_passband):
+               detect_ack_pattern, transmit_byte, generate_ack_pattern_passband, transmit_batch):
         setattr(cls, fn.__name__, fn)
 
 

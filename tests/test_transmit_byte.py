@@ -124,6 +124,45 @@ def test_gpu_transmit_byte_phase_continuous_equals_consecutive_calls(cfg):
         assert np.array_equal(got[f], orc.transmit_byte(pls[f].astype(np.int32), start_sample=1000 + f * used)), f
 
 
+@needs_ref
+@pytest.mark.parametrize("cfg", [8, 16, 101])
+def test_oracle_send_batch_signal_path_matches_reference_objects(cfg):
+    """cl_arq_controller::send_batch's DSP (arq_common.cc:2224-2248): unfiltered frames with the carrier running on, edge frames
+    repeated as padding, both transmit filters over the concatenation."""
+    orc, ref = Oracle(cfg), oraclelib.RefLib(cfg)
+    rng = np.random.default_rng(cfg)
+    pl = rng.integers(0, 256, (3, orc.payload_bytes)).astype(np.int32)
+    nb = np.array([orc.payload_bytes, 5, orc.payload_bytes // 2], np.int32)
+    assert np.array_equal(orc.transmit_batch(pl, nb, start_sample=777), ref.transmit_batch(pl, nb, start_sample=777))
+
+
+def test_oracle_send_batch_middle_frame_equals_filtering_with_its_neighbours():
+    """What the padding buys: away from the batch edges a frame's filtered samples do not depend on how the batch was cut."""
+    orc = Oracle(8)
+    pl = np.random.default_rng(5).integers(0, 256, (4, orc.payload_bytes)).astype(np.int32)
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
+    whole = orc.transmit_batch(pl)
+    tail = orc.transmit_batch(pl[1:], start_sample=used)          # the same frames 1..3 with the same carrier phase
+    assert np.array_equal(whole[2:], tail[1:]) and np.array_equal(whole[1][200:], tail[0][200:]) and not np.array_equal(whole[1][:48], tail[0][:48])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 8, 16, 100, 101])
+def test_gpu_send_batch_signal_path_matches_oracle(cfg):
+    from mercury_amd import RxPhy
+    from mercury_amd.physical_layer import BATCH_MESSAGE
+    orc = Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=8)
+    rng = np.random.default_rng(300 + cfg)
+    F = 5
+    pls = rng.integers(0, 256, (F, orc.payload_bytes)).astype(np.uint8)
+    nb = np.array([orc.payload_bytes, 3, orc.payload_bytes // 2, orc.payload_bytes, 0], np.int32)
+    got = rx.transmit_byte(pls, CARRIER, nbytes=nb, message_location=BATCH_MESSAGE, start_sample=4242)
+    assert np.array_equal(got, orc.transmit_batch(pls.astype(np.int32), nb, start_sample=4242))
+    one = rx.transmit_byte(pls[:1], CARRIER, message_location=BATCH_MESSAGE)              # a batch of one: padded with itself
+    assert np.array_equal(one, orc.transmit_batch(pls[:1].astype(np.int32)))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [100, 101, 102])
 def test_gpu_transmit_byte_mfsk_control_frames(cfg):

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 from mercury_amd import RxPhy  # noqa: E402
-from mercury_amd.physical_layer import NO_FILTER_MESSAGE, SINGLE_MESSAGE  # noqa: E402
+from mercury_amd.physical_layer import BATCH_MESSAGE, NO_FILTER_MESSAGE, SINGLE_MESSAGE  # noqa: E402
 
 
 def main():
@@ -28,7 +28,9 @@ def main():
     out = torch.empty((F, total), dtype=torch.float64, device=dev)
     torch.cuda.synchronize()                                  # the library works on its own stream
     res = {"cfg": cfg, "messages": F, "samples_per_message": total}
-    for name, loc in (("single_message_filtered", SINGLE_MESSAGE), ("no_filter_message", NO_FILTER_MESSAGE)):
+    for name, loc in (("single_message_filtered", SINGLE_MESSAGE), ("no_filter_message", NO_FILTER_MESSAGE), ("arq_batch_filtered", BATCH_MESSAGE)):
+        if loc == BATCH_MESSAGE and (F + 2) * total >= 2 ** 31:
+            continue
         for _ in range(2):
             rx.transmit_byte_dev(pl.data_ptr(), rx.payload_bytes, F, out.data_ptr(), carrier, message_location=loc)
         torch.cuda.synchronize()
