@@ -126,21 +126,26 @@ public:
     st_receive_stats receive_stats;
     mgpu_info info{};
 
-    ~cl_rx_phy() { if (ctx_) mgpu_destroy(ctx_); }
+    ~cl_rx_phy() { release(); }
 
     // telecom_system.cc:2487 — re-initialises everything the mode owns; a no-op for the current mode
     void load_configuration(int configuration) {
         if (configuration == current_configuration && ctx_) return;
         if (!((configuration >= 0 && configuration <= 16) || (configuration >= 100 && configuration <= 102))) return;   // the reference returns silently too (:2494-2497)
-        if (ctx_) mgpu_destroy(ctx_);
-        ctx_ = nullptr;
-        mgpu_config c{};
-        c.cfg = configuration; c.max_iters = ldpc_nIteration_max; c.decoder = ldpc_decoding_algorithm;
-        c.agc = 1; c.variance_source = 1; c.device = device; c.max_batch = max_batch;
-        detail::check(mgpu_create(&c, &ctx_), nullptr, "load_configuration");
-        detail::check(mgpu_get_info(ctx_, &info), ctx_, "load_configuration");
+        release();
         current_configuration = configuration;
+        mfsk_ctrl_mode = false;               // load_configuration leaves control-frame mode (telecom_system.cc:2990)
+        select(0);
     }
+    // void cl_telecom_system::set_mfsk_ctrl_mode(bool) (telecom_system.cc:1572-1584): short control frames in the MFSK modes.
+    // The frame geometry is part of a context's tables, so the mirror keeps one context per setting and switches between them.
+    bool mfsk_ctrl_mode = false;
+    void set_mfsk_ctrl_mode(bool enable) {
+        if (current_configuration < 100) return;          // only the ROBUST modes have control frames (:1574)
+        mfsk_ctrl_mode = enable;
+        select(enable ? 1 : 0);
+    }
+    int get_active_nsymb() const { return info.active_nsymb; }                // telecom_system.h: get_active_nsymb()
     int get_frame_size_bytes() const { return info.payload_bytes; }          // telecom_system.cc:332-335
     int get_frame_size_bits() const { return info.payload_bytes * 8; }
 
@@ -217,9 +222,53 @@ public:
         for (int f = 0; f < F; ++f) stats[f] = detail::convert(s[f]);
     }
 
+    // double cl_telecom_system::measure_signal_only(double* data) — telecom_system.cc:1520-1541
+    double measure_signal_only(const double* data) {
+        double dbm = 0;
+        detail::check(mgpu_measure_signal_only(ctx_, data, 1, carrier_frequency, &dbm), ctx_, "measure_signal_only");
+        return dbm;
+    }
+    // int generate_ack_pattern_passband(double* out) / generate_break_pattern_passband — telecom_system.cc:1589-1631, :1659-1689;
+    // returns the number of samples written (ack_pattern_passband_samples)
+    int ack_pattern_passband_samples() const { return 16 * info.Nofdm * 4; }
+    int generate_ack_pattern_passband(double* out) { return pattern_passband(1, out); }
+    int generate_break_pattern_passband(double* out) { return pattern_passband(2, out); }
+    // double detect_ack_pattern_from_passband(double* data, int size, int* out_matched) / detect_break_... — :1633-1655, :1692-1716
+    double detect_ack_pattern_from_passband(const double* data, int size, int* out_matched) { return detect_pattern(1, data, size, out_matched); }
+    double detect_break_pattern_from_passband(const double* data, int size, int* out_matched) { return detect_pattern(2, data, size, out_matched); }
+
     mgpu_ctx* context() const { return ctx_; }       // for the per-method mirrors below
 
 private:
+    int pattern_passband(int which, double* out) {
+        const mgpu_transmit_config tc{carrier_frequency, carrier_amplitude, output_power_Watt, preamble_papr_cut, data_papr_cut,
+                                      passband_start_sample, MGPU_SINGLE_MESSAGE, 0};
+        detail::check(mgpu_generate_ack_pattern_passband(ctx_, which, &tc, out), ctx_, "generate_ack_pattern_passband");
+        passband_start_sample += static_cast<unsigned long>(ack_pattern_passband_samples());
+        return ack_pattern_passband_samples();
+    }
+    double detect_pattern(int which, const double* data, int size, int* out_matched) {
+        double metric = 0;
+        int matched = 0;
+        detail::check(mgpu_detect_ack_pattern_from_passband(ctx_, data, 1, size, carrier_frequency, which, &metric, &matched), ctx_, "detect_ack_pattern");
+        if (out_matched) *out_matched = matched;
+        return metric;
+    }
+    void select(int which) {
+        if (!ctxs_[which]) {
+            mgpu_config c{};
+            c.cfg = current_configuration; c.max_iters = ldpc_nIteration_max; c.decoder = ldpc_decoding_algorithm;
+            c.agc = 1; c.variance_source = 1; c.device = device; c.max_batch = max_batch; c.mfsk_ctrl_mode = which;
+            detail::check(mgpu_create(&c, &ctxs_[which]), nullptr, "load_configuration");
+        }
+        ctx_ = ctxs_[which];
+        detail::check(mgpu_get_info(ctx_, &info), ctx_, "load_configuration");
+    }
+    void release() {
+        for (auto& c : ctxs_) { if (c) mgpu_destroy(c); c = nullptr; }
+        ctx_ = nullptr;
+    }
+    mgpu_ctx* ctxs_[2] = {nullptr, nullptr};     // [0] data frames, [1] MFSK control frames
     mgpu_ctx* ctx_ = nullptr;
 };
 

@@ -58,6 +58,11 @@ int mgpu_receive_buffer_nsymb(mgpu_ctx* ctx);
 int mgpu_receive_byte_batch(mgpu_ctx* ctx, const double* passband, int W, const mgpu_receive_config* config,
                             mgpu_link_state* state, uint8_t* payload, mgpu_receive_stats* stats);
 
+/* double cl_telecom_system::measure_signal_only(double* data) (telecom_system.cc:1520-1541): the capture window through the
+ * time-sync filter and its mean power in dBm (receive_stats.signal_stregth_dbm), without looking for a frame. passband as above
+ * (host or device), signal_strength_dbm: [W] host. */
+int mgpu_measure_signal_only(mgpu_ctx* ctx, const double* passband, int W, double carrier_hz, double* signal_strength_dbm);
+
 #ifdef __cplusplus
 }
 #endif

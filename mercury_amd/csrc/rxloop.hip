@@ -243,6 +243,26 @@ int mgpu_receive_buffer_nsymb(mgpu_ctx* c) {
     return min_buf;
 }
 
+// cl_telecom_system::measure_signal_only (telecom_system.cc:1520-1541): time-sync filter + whole-window power, nothing else
+int mgpu_measure_signal_only(mgpu_ctx* c, const double* passband, int W, double carrier_hz, double* signal_strength_dbm) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(passband && signal_strength_dbm && W > 0 && W <= c->max_batch, "bad argument (W must be 1..max_batch)");
+        const mgpu_receive_config rc = {carrier_hz, 1, 0, 0, 0};
+        Loop lp(c, W, rc, mgpu_receive_buffer_nsymb(c));
+        hipStream_t s = lp.s;
+        std::vector<int> all(W);
+        for (int w = 0; w < W; ++w) all[w] = w;
+        HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyDefault, s));
+        lp.p2b(all, 0);
+        hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_freq.as<double>());
+        HIPCK(hipGetLastError());
+        std::vector<double> sum(W);
+        lp.down(sum.data(), lp.d_freq, size_t(W) * 8);
+        for (int w = 0; w < W; ++w) signal_strength_dbm[w] = 10.0 * std::log10((sum[w] / lp.buf) / 0.001);     // ofdm.cc:1523-1539
+    });
+}
+
 int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mgpu_receive_config* rcp, mgpu_link_state* state,
                             uint8_t* payload, mgpu_receive_stats* stats) {
     if (!c) return MGPU_ERR_ARG;

@@ -102,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
-    "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch",
+    "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_measure_signal_only",
     "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
     "mgpu_symbol_demod", "mgpu_automatic_gain_control", "mgpu_channel_estimator", "mgpu_restore_channel_amplitude", "mgpu_channel_equalizer",
     "mgpu_measure_variance", "mgpu_deframer", "mgpu_deinterleaver_c128", "mgpu_deinterleaver_f32", "mgpu_psk_demod",
@@ -349,6 +349,16 @@ class RxPhy:
         x = np.ascontiguousarray(carriers, np.complex128).reshape(-1, self.Nc)
         out = np.zeros((x.shape[0], self.Nofdm), np.complex128)
         self._ck(self.lib.mgpu_symbol_mod(self.h, _ptr(x), C.c_int(x.shape[0]), _ptr(out)))
+        return out
+
+    def measure_signal_only(self, passband, carrier_hz):
+        """cl_telecom_system::measure_signal_only: float64 [W, buffer samples] -> signal strength in dBm per window."""
+        x = np.ascontiguousarray(passband, np.float64)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        if x.shape[1] != self.receive_buffer_samples():
+            raise MgpuError("a capture window is %d samples" % self.receive_buffer_samples())
+        out = np.zeros(x.shape[0], np.float64)
+        self._ck(self.lib.mgpu_measure_signal_only(self.h, _ptr(x), C.c_int(x.shape[0]), C.c_double(carrier_hz), _ptr(out)))
         return out
 
     def receive_byte_dev(self, d_passband, W, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1, state=None,

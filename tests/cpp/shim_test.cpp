@@ -89,6 +89,24 @@ int main(int argc, char** argv) {
             fclose(tx);
             std::vector<int> too_long(pb + 1, 0);
             if (phy.transmit_byte(too_long.data(), pb + 1, audio.data(), MGPU_SINGLE_MESSAGE)) return 5;     // "message too long.. not sent."
+            // 4c) the signalling calls the ARQ layer makes: ACK pattern out and back in, signal level, control-frame mode
+            const int n = phy.capture_window_samples(), na = phy.ack_pattern_passband_samples();
+            std::vector<double> buf(n, 0.0), ack(na);
+            if (phy.generate_ack_pattern_passband(ack.data()) != na) return 6;
+            for (int i = 0; i < na; ++i) buf[5000 + i] = ack[i];
+            int m_ack = 0, m_brk = 0;
+            const double metric = phy.detect_ack_pattern_from_passband(buf.data(), n, &m_ack);
+            phy.detect_break_pattern_from_passband(buf.data(), n, &m_brk);
+            const double dbm = phy.measure_signal_only(buf.data());
+            const int data_nsymb = phy.get_active_nsymb();
+            phy.set_mfsk_ctrl_mode(true);
+            const int ctrl_nsymb = phy.get_active_nsymb();
+            phy.set_mfsk_ctrl_mode(false);
+            const double sig[6] = {metric, double(m_ack), double(m_brk), dbm, double(data_nsymb), double(ctrl_nsymb)};
+            FILE* sg = fopen((std::string(argv[5]) + ".sig").c_str(), "wb");
+            fwrite(sig, sizeof(double), 6, sg);
+            fclose(sg);
+            if (phy.get_active_nsymb() != data_nsymb) return 7;
         }
         // 5) error behaviour: a wrong code rate throws instead of exit(1)
         mgpu::cl_ldpc bad;

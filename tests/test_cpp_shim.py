@@ -122,6 +122,13 @@ def test_cpp_transmit_byte_runs_the_carrier_on_across_calls(tmp_path, cfg):
         want = orc.transmit_byte(msgs[m, : pb // 2] if m == 1 else msgs[m], start_sample=m * used,
                                  message_location=oraclelib.NO_FILTER_MESSAGE if m == 3 else oraclelib.SINGLE_MESSAGE)
         assert np.array_equal(audio[m], want), m
+    # the signalling calls: the ACK pattern it generates is the one it detects (and not BREAK), the level of a buffer that holds only
+    # that pattern, and the control-frame switch (MFSK modes only)
+    metric, m_ack, m_brk, dbm, data_nsymb, ctrl_nsymb = np.fromfile(str(tmp_path / "out.bin") + ".sig", np.float64)
+    assert metric > 4 and m_ack >= 12 and m_brk < m_ack - 4      # silence around the pattern lets a few BREAK slots match by chance
+    assert -40 < dbm < 20
+    orc.set_ctrl_mode(1)
+    assert (int(data_nsymb), int(ctrl_nsymb)) == (orc.Nsymb, orc.active_nsymb if cfg >= 100 else orc.Nsymb)
 
 
 def _build_stages(tmp_path):

@@ -245,3 +245,19 @@ def test_gpu_receive_byte_mfsk_control_frames_overflow_and_search_start():
         assert out["stats"]["message_decoded"][0] == 1 and np.array_equal(out["payload"][0][: orc.payload_bytes], pl)
         assert out["stats"]["frame_overflow_symbols"][2] > 0 and out["stats"]["message_decoded"][2] == 0
         rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 100])
+def test_gpu_measure_signal_only_equals_receive_byte_signal_strength(cfg):
+    """cl_telecom_system::measure_signal_only is the first two steps of receive_byte (:676-678): same number, same bits."""
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    wins, _ = make_windows(orc, [("frame", 7 * 1088 + 333, 0.01, 1), ("silence", 0, 1e-9, 2), ("noise", 0, 0.3, 3)], seed=cfg)
+    rx = RxPhy(cfg, max_batch=4)
+    dbm = rx.measure_signal_only(wins, CARRIER)
+    full = rx.receive_byte(wins, CARRIER)["stats"]["signal_strength_dbm"]
+    assert np.array_equal(dbm, full)
+    ref = np.array([orc.receive_byte(wins[w])["signal_strength_dbm"] for w in range(3)])
+    assert np.allclose(dbm, ref, rtol=0, atol=1e-9)          # the mixer's cos/sin differ from glibc in the last ulp
+    assert dbm[1] < -100 and dbm[0] > dbm[1] + 100 and dbm[2] > dbm[1] + 100
