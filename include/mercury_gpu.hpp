@@ -146,6 +146,13 @@ public:
         select(enable ? 1 : 0);
     }
     int get_active_nsymb() const { return info.active_nsymb; }                // telecom_system.h: get_active_nsymb()
+    // char cl_telecom_system::get_configuration(double SNR) — telecom_system.cc:3036-3108: the fastest mode whose threshold the
+    // measured SNR clears (the thresholds of common_defines.h:130-147 as that function states them)
+    static char get_configuration(double SNR) {
+        static const double above[15] = {12.5, 9, 7.5, 6.5, 4, 3, 1.5, 0.5, -0.5, -1.5, -2.5, -3.5, -4.5, -6, -7.5};   // CONFIG_15 .. CONFIG_1
+        for (int i = 0; i < 15; ++i) if (SNR > above[i]) return char(15 - i);
+        return 0;
+    }
     int get_frame_size_bytes() const { return info.payload_bytes; }          // telecom_system.cc:332-335
     int get_frame_size_bits() const { return info.payload_bytes * 8; }
 

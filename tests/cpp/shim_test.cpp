@@ -108,6 +108,9 @@ int main(int argc, char** argv) {
             fclose(sg);
             if (phy.get_active_nsymb() != data_nsymb) return 7;
         }
+        // get_configuration (telecom_system.cc:3036-3108): spot checks on both sides of a few thresholds
+        if (mgpu::cl_rx_phy::get_configuration(13.0) != 15 || mgpu::cl_rx_phy::get_configuration(12.5) != 14 || mgpu::cl_rx_phy::get_configuration(0.6) != 8 ||
+            mgpu::cl_rx_phy::get_configuration(0.5) != 7 || mgpu::cl_rx_phy::get_configuration(-7.5) != 0 || mgpu::cl_rx_phy::get_configuration(-7.4) != 1) return 8;
         // 5) error behaviour: a wrong code rate throws instead of exit(1)
         mgpu::cl_ldpc bad;
         bad.rate = 7.0f / 16.0f;
