@@ -13,6 +13,9 @@
 //        receive_batch(...)                   the same over F frames (what RX_SHM would batch)
 //        receive_byte(passband, out)          the whole of receive_byte, telecom_system.cc:646-1503
 //        transmit_byte(data, nBytes, out, message_location)   telecom_system.cc:342-556
+//        set_mfsk_ctrl_mode / get_active_nsymb / measure_signal_only / get_configuration(SNR)
+//        generate_ack_pattern_passband, generate_break_pattern_passband, detect_ack_pattern_from_passband,
+//        detect_break_pattern_from_passband      telecom_system.cc:1520-1716 — i.e. every cl_telecom_system call the ARQ layer makes
 //   mgpu::st_receive_stats <->  struct st_receive_stats  (telecom_system.h:63-82; fields this path produces)
 //
 // Like the reference, failure to decode is reported through the stats (iterations_done > max-1,
