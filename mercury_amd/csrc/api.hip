@@ -211,6 +211,18 @@ void select_peak(const double* cand_vals, int ncand, int step, int size, int loc
     *corr = cur;
 }
 
+void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, const int* d_widx, const int* d_ncand, int ncand_max, int n, int step,
+                         int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s) {
+    if (ngi_i % 64 || (nfft_i / 2) % 64) {    // the staged kernels walk the preamble in chunks of 8 / 64 pairs
+        hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncand_max + 63) / 64, n), dim3(64), 0, s, d_bb, stride, d_start, d_widx, d_ncand,
+                           ncand_max, step, pre_nsymb, ngi_i, nfft_i, d_vals);
+    } else {
+        hipLaunchKernelGGL(step <= 4 ? mgpu_tsync_metric_dense_kernel : mgpu_tsync_metric_kernel, dim3((ncand_max + 255) / 256, n), dim3(256), 0, s,
+                           d_bb, stride, d_start, d_widx, d_ncand, ncand_max, step, pre_nsymb, ngi_i, nfft_i, d_vals);
+    }
+    HIPCK(hipGetLastError());
+}
+
 int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb) {
     static constexpr int kTones32[4] = {4, 20, 12, 28}, kTones16[4] = {2, 10, 6, 14};      // mfsk.cc:82-95
     const int* tones = t.mfsk_M == 32 ? kTones32 : kTones16;
@@ -484,12 +496,7 @@ int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int 
         HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
         HIPCK(hipEventRecord(c->sync_ev[0], s));
         const int ngi_i = t.Ngi * interp, nfft_i = t.Nfft * interp;
-        if (ngi_i % 64 || (nfft_i / 2) % 64)    // the staged kernels walk the preamble in chunks of 8 / 64 pairs
-            hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncand + 63) / 64, W), dim3(64), 0, s, d_in.as<double>(), size, nullptr, nullptr,
-                               nullptr, ncand, step, t.preamble, ngi_i, nfft_i, d_vals.as<double>());
-        else
-            hipLaunchKernelGGL(step <= 4 ? mgpu_tsync_metric_dense_kernel : mgpu_tsync_metric_kernel, dim3((ncand + 255) / 256, W), dim3(256), 0, s,
-                               d_in.as<double>(), size, nullptr, nullptr, nullptr, ncand, step, t.preamble, ngi_i, nfft_i, d_vals.as<double>());
+        launch_tsync_metric(d_in.as<double>(), size, nullptr, nullptr, nullptr, ncand, W, step, t.preamble, ngi_i, nfft_i, d_vals.as<double>(), s);
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         std::vector<double> cand(size_t(W) * ncand);

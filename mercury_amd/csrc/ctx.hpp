@@ -139,6 +139,11 @@ int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslo
 
 void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr);
 
+// Schmidl-Cox metrics of n windows (sync.hip): picks the kernel for the step and the segment lengths.
+// d_start / d_widx / d_ncand may be null (search from sample 0, window k = k, ncand_max candidates each).
+void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, const int* d_widx, const int* d_ncand, int ncand_max, int n, int step,
+                         int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s);
+
 inline int guard(mgpu_ctx* c, const std::function<void()>& fn) {
     try {
         fn();

@@ -134,14 +134,8 @@ struct Loop {
         up(d_ia, wins.data(), size_t(n) * 4);
         up(d_ib, start.data(), size_t(n) * 4);
         up(d_ic, nc.data(), size_t(n) * 4);
-        if (ngi_i % 64 || (nfft_i / 2) % 64)
-            hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncmax + 63) / 64, n), dim3(64), 0, s, d_bbi.as<double>(), buf,
-                               d_ib.as<int>(), d_ia.as<int>(), d_ic.as<int>(), ncmax, step, pre, ngi_i, nfft_i, d_vals.as<double>());
-        else
-            hipLaunchKernelGGL(step <= 4 ? mgpu_tsync_metric_dense_kernel : mgpu_tsync_metric_kernel, dim3((ncmax + 255) / 256, n), dim3(256), 0, s,
-                               d_bbi.as<double>(), buf, d_ib.as<int>(), d_ia.as<int>(), d_ic.as<int>(), ncmax, step, pre, ngi_i, nfft_i,
-                               d_vals.as<double>());
-        HIPCK(hipGetLastError());
+        launch_tsync_metric(d_bbi.as<double>(), buf, d_ib.as<int>(), d_ia.as<int>(), d_ic.as<int>(), ncmax, n, step, pre, ngi_i, nfft_i,
+                            d_vals.as<double>(), s);
         if (n >= 32) {   // peak selection where the metrics lie; only (delay, correlation) per window come back
             up(d_ia, size.data(), size_t(n) * 4);                    // wins / start are consumed: reuse their index buffers
             up(d_ib, loc.data(), size_t(n) * 4);
