@@ -80,7 +80,8 @@ extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
 #define TS_CH 8
 #define TS_RPL (64 / TS_CH)     // candidate rows covered by one wave-wide load
 #define TS_NLD (64 / TS_RPL)    // loads per array and chunk
-#define TS_WAVES 4
+#define TS_WAVES 2           // coarse kernel: wavefronts per workgroup
+#define TS_DWAVES 4          // dense kernel
 
 namespace {
 typedef double v2d __attribute__((ext_vector_type(2)));   // one complex sample as a native 16-byte vector (keeps prefetch arrays in registers)
@@ -111,14 +112,14 @@ extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_ke
     const int* __restrict__ ncand_w, int ncand_max, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
     // window k of the launch is window widx[k] (or k) of the buffer, searched from sample start[k] (or 0) with ncand_w[k]
     // (or ncand_max) candidates; vals is [gridDim.y][ncand_max]
-    const int wsel = widx ? widx[blockIdx.y] : blockIdx.y;
-    const int wstart = start ? start[blockIdx.y] : 0;
-    const int ncand = ncand_w ? ncand_w[blockIdx.y] : ncand_max;
+    const int wsel = widx ? widx[blockIdx.x] : blockIdx.x;
+    const int wstart = start ? start[blockIdx.x] : 0;
+    const int ncand = ncand_w ? ncand_w[blockIdx.x] : ncand_max;
     const int size = stride - wstart;
     // requires ngi_i % TS_CH == 0 and (nfft_i / 2) % TS_CH == 0 (the host checks; 64 and 512 in the reference's calls)
     __shared__ c2 tile[TS_WAVES][2][64][TS_CH + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cand0 = (blockIdx.x * TS_WAVES + wave) * 64;
+    const int cand0 = (blockIdx.y * TS_WAVES + wave) * 64;
     if (cand0 >= ncand) return;
     const int cand = cand0 + lane;
     const char* win = reinterpret_cast<const char*>(bb) + (size_t(wsel) * stride + wstart) * 16;
@@ -171,7 +172,7 @@ extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_ke
     if (cand >= ncand) return;
     if (na < 0.001 || nb < 0.001) cc = 0.0;
     else cc = cc / sqrt(na * nb);
-    vals[size_t(blockIdx.y) * ncand_max + cand] = cc;
+    vals[size_t(blockIdx.x) * ncand_max + cand] = cc;
 }
 
 // Fallback for segment lengths that are not multiples of TS_CH: one lane per candidate, direct loads.
@@ -200,7 +201,9 @@ extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_generic_kerne
 #define TS_DCH 64
 #define TS_DSPAN (63 * 4 + TS_DCH)      // step <= 4
 
-extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_dense_kernel(
+extern "C" int mgpu_tsync_coarse_threads() { return 64 * TS_WAVES; }
+
+extern "C" __global__ __launch_bounds__(64 * TS_DWAVES) void mgpu_tsync_metric_dense_kernel(
     const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
     const int* __restrict__ ncand_w, int ncand_max, int step, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
     // window k of the launch is window widx[k] (or k) of the buffer, searched from sample start[k] (or 0) with ncand_w[k]
@@ -209,9 +212,9 @@ extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_de
     const int wstart = start ? start[blockIdx.y] : 0;
     const int ncand = ncand_w ? ncand_w[blockIdx.y] : ncand_max;
     const int size = stride - wstart;
-    __shared__ c2 span[TS_WAVES][2][TS_DSPAN];
+    __shared__ c2 span[TS_DWAVES][2][TS_DSPAN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cand0 = (blockIdx.x * TS_WAVES + wave) * 64;
+    const int cand0 = (blockIdx.x * TS_DWAVES + wave) * 64;
     if (cand0 >= ncand) return;
     const int cand = cand0 + lane;
     const c2* win = reinterpret_cast<const c2*>(bb) + size_t(wsel) * stride + wstart + size_t(cand0) * step;
