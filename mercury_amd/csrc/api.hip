@@ -211,6 +211,25 @@ void select_peak(const double* cand_vals, int ncand, int step, int size, int loc
     *corr = cur;
 }
 
+const double* mixer_table(mgpu_ctx* c, double carrier_hz, size_t count, hipStream_t s) {
+    if (c->mix_carrier == carrier_hz && c->mix_count >= count) return c->d_mix_cs;
+    std::vector<double> cs(2 * count);
+    const double Ts = 1.0 / kSampleRate;
+    // ofdm.cc:2331-2332 evaluates cos and sin of one phase; the reference's compiler merges the pair into a single sincos() call, and glibc's
+    // sincos is not bit-for-bit its cos + sin, so the same call is made here
+    for (size_t i = 0; i < count; ++i) ::sincos(2 * M_PI * carrier_hz * double(int(i)) * Ts, &cs[2 * i + 1], &cs[2 * i]);
+    HIPCK(hipStreamSynchronize(s));
+    if (c->mix_cap < cs.size()) {
+        (void)hipFree(c->d_mix_cs);
+        c->d_mix_cs = nullptr; c->mix_cap = 0;
+        HIPCK(hipMalloc(reinterpret_cast<void**>(&c->d_mix_cs), cs.size() * 8));
+        c->mix_cap = cs.size();
+    }
+    HIPCK(hipMemcpy(c->d_mix_cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
+    c->mix_carrier = carrier_hz; c->mix_count = count;
+    return c->d_mix_cs;
+}
+
 void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, const int* d_widx, const int* d_ncand, int ncand_max, int n, int step,
                          int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s) {
     if (ngi_i % 64 || (nfft_i / 2) % 64) {    // the staged kernels walk the preamble in chunks of 8 / 64 pairs
@@ -347,6 +366,7 @@ void mgpu_destroy(mgpu_ctx* c) {
     (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters); (void)hipFree(c->d_eqdata);
     if (c->rxloop_ws && c->rxloop_ws_free) c->rxloop_ws_free(c->rxloop_ws);
     if (c->tx_state && c->tx_state_free) c->tx_state_free(c->tx_state);
+    (void)hipFree(c->d_mix_cs);
     if (c->one_frame_graph) (void)hipGraphExecDestroy(c->one_frame_graph);
     if (c->h_one_in) (void)hipHostFree(c->h_one_in);
     if (c->h_one_out) (void)hipHostFree(c->h_one_out);
@@ -484,10 +504,13 @@ int mgpu_passband_to_baseband(mgpu_ctx* c, const double* passband, int W, int in
         const int ntaps = int(taps.size());
         const size_t lds = size_t(255 * decimation + ntaps) * 16;
         need(lds <= 64 * 1024 && ntaps <= 64, "decimation too large for the staging buffer");
+        bool shared = true;                                           // one carrier for every window: the host-libm mixer table applies
+        for (int w = 1; w < W; ++w) shared = shared && carrier_hz[w] == carrier_hz[0];
+        const double* cs = shared ? mixer_table(c, carrier_hz[0], size_t(in_size), s) : nullptr;
         HIPCK(hipEventRecord(c->sync_ev[0], s));
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((count + 255) / 256, W), dim3(256), lds, s, d_in.as<double>(), in_size, d_fc.as<double>(),
                            start ? d_start.as<int>() : nullptr, 0, count, decimation, c->d_fir[filter], ntaps, kSampleRate, kCarrierAmplitude,
-                           d_out.as<double>(), nullptr);
+                           d_out.as<double>(), nullptr, cs);
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         HIPCK(hipMemcpyAsync(out_c128, d_out.p, size_t(W) * count * 16, hipMemcpyDeviceToHost, s));
@@ -561,8 +584,9 @@ std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size
         HIPCK(hipMemcpyAsync(d_pass.p, bb, size_t(W) * size * 8, hipMemcpyHostToDevice, s));
         HIPCK(hipMemcpyAsync(d_fc.p, fc.data(), size_t(W) * 8, hipMemcpyHostToDevice, s));
         const int ntaps = int(t.fir_data.size());
+        const double* cs = mixer_table(c, passband_carrier_hz, size_t(size), s);
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((size + 255) / 256, W), dim3(256), size_t(255 + ntaps) * 16, s, d_pass.as<double>(), size,
-                           d_fc.as<double>(), nullptr, 0, size, 1, c->d_fir[1], ntaps, kSampleRate, kCarrierAmplitude, d_in.as<double>(), nullptr);
+                           d_fc.as<double>(), nullptr, 0, size, 1, c->d_fir[1], ntaps, kSampleRate, kCarrierAmplitude, d_in.as<double>(), nullptr, cs);
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(s));          // d_pass / d_fc go out of scope here
     } else {

@@ -29,7 +29,7 @@ extern "C" int mgpu_mfsk_syms_per_block();
 extern "C" __global__ void mgpu_slot_energy_kernel(const double*, int, int, int, const double*, double*);
 extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
-extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*, const int*);
+extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*, const int*, const double*);
 extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" int mgpu_tsync_coarse_threads();
@@ -99,6 +99,9 @@ struct mgpu_ctx {
     void* rxloop_ws = nullptr;      // device workspace of mgpu_receive_byte_batch, kept between calls (rxloop.hip)
     int rxloop_ws_windows = 0;
     void (*rxloop_ws_free)(void*) = nullptr;
+    double* d_mix_cs = nullptr;     // receive mixer: cos / sin of the carrier phase per sample index (host libm) for mix_carrier
+    double mix_carrier = -1;
+    size_t mix_count = 0, mix_cap = 0;
     void* tx_state = nullptr;       // transmit path: preamble baseband, filter taps, carrier table (tx.hip)
     void (*tx_state_free)(void*) = nullptr;
     hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
@@ -139,6 +142,10 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
 int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb);
 
 void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr);
+
+// cos / sin table of the receive mixer for `carrier_hz`, at least `count` samples long (built on the host with the reference's libm call,
+// cached in the context); the stream is synchronised when the table has to be rebuilt
+const double* mixer_table(mgpu_ctx* c, double carrier_hz, size_t count, hipStream_t s);
 
 // Schmidl-Cox metrics of n windows (sync.hip): picks the kernel for the step and the segment lengths.
 // d_start / d_widx / d_ncand may be null (search from sample 0, window k = k, ncand_max candidates each).

@@ -114,9 +114,14 @@ struct Loop {
         up(d_carrier, carrier.data(), size_t(W) * 8);
         const auto& taps = filter ? t.fir_data : t.fir_time_sync;
         const int ntaps = int(taps.size());
+        // windows that all mix with one carrier (always so before a frequency offset has been measured) use the host-libm table:
+        // the reference's own cos / sin values, and no trigonometry on the device
+        bool shared = true;
+        for (int w : wins) shared = shared && carrier[w] == carrier[wins[0]];
+        const double* cs = shared ? mixer_table(c, carrier[wins[0]], size_t(buf), s) : nullptr;
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((buf + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 + ntaps) * 16, s,
                            d_pass.as<double>(), buf, d_carrier.as<double>(), nullptr, 0, buf, 1, c->d_fir[filter], ntaps, 48000.0,
-                           1.4142135623730951, d_bbi.as<double>(), d_ia.as<int>());
+                           1.4142135623730951, d_bbi.as<double>(), d_ia.as<int>(), cs);
         HIPCK(hipGetLastError());
     }
 

@@ -19,10 +19,12 @@ __device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.
 
 // One block = 256 consecutive outputs of one window. out[k] = sum_j l[n+h-j]*c[j], n = start + k*decim,
 // l[i] = in[i]*amp*(cos, sin)(2*pi*fc*i*Ts). The (255*decim + ntaps) mixed samples a block needs are formed once in LDS.
+// cs (optional): cos / sin per sample index from the host, for launches whose windows all share one carrier — the reference's
+// own libm values, so the output is then bit-identical to the reference's, and the device evaluates no trigonometry.
 extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
     const double* __restrict__ passband, int in_size, const double* __restrict__ carrier_hz, const int* __restrict__ start_opt,
     int start_all, int count, int decim, const double* __restrict__ taps, int ntaps, double fs, double amplitude,
-    double* __restrict__ out, const int* __restrict__ widx) {
+    double* __restrict__ out, const int* __restrict__ widx, const double* __restrict__ cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c2* l = reinterpret_cast<c2*>(smem);
     __shared__ double c[P2B_MAXTAPS];
@@ -40,9 +42,13 @@ extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
         const int i = base + t;
         c2 v = {0.0, 0.0};
         if (i >= 0 && i < in_size) {
-            const double ph = 2 * M_PI * fc * double(i) * Ts;
             const double a = in[i] * amplitude;
-            v = {a * cos(ph), a * sin(ph)};
+            if (cs) {                // every window of this launch uses the carrier the table was made for (host libm, see api.hip)
+                v = {a * cs[2 * i], a * cs[2 * i + 1]};
+            } else {
+                const double ph = 2 * M_PI * fc * double(i) * Ts;
+                v = {a * cos(ph), a * sin(ph)};
+            }
         }
         l[t] = v;
     }

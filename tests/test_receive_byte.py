@@ -68,8 +68,10 @@ def test_gpu_receive_byte_batch_matches_oracle_ofdm(cfg):
             st = out["stats"][w]
             for k in ("iterations_done", "crc", "all_zeros", "message_decoded", "delay", "sync_trials", "frame_overflow_symbols"):
                 assert st[k] == ref[k], (cfg, df, w, k, st[k], ref[k])
-            assert abs(st["coarse_metric"] - ref["coarse_metric"]) <= 1e-11, (cfg, w)
-            assert abs(st["signal_strength_dbm"] - ref["signal_strength_dbm"]) <= 1e-9, (cfg, w)
+            # up to the time synchronisation every window mixes with the same carrier: host-libm mixer table -> bit-identical baseband,
+            # hence bit-identical Schmidl-Cox metric and signal level (sums in the reference's order)
+            assert st["coarse_metric"] == ref["coarse_metric"], (cfg, w)
+            assert st["signal_strength_dbm"] == ref["signal_strength_dbm"], (cfg, w)
             assert abs(st["freq_offset"] - ref["freq_offset"]) <= 1e-9 * max(1.0, abs(ref["freq_offset"])), (cfg, w)
             assert abs(st["mean_H"] - ref["mean_H"]) <= 1e-9 * max(1.0, abs(ref["mean_H"])), (cfg, w)
             assert abs(st["snr_db"] - ref["snr_db"]) <= 1e-4 * max(1.0, abs(ref["snr_db"])), (cfg, w)
@@ -259,5 +261,5 @@ def test_gpu_measure_signal_only_equals_receive_byte_signal_strength(cfg):
     full = rx.receive_byte(wins, CARRIER)["stats"]["signal_strength_dbm"]
     assert np.array_equal(dbm, full)
     ref = np.array([orc.receive_byte(wins[w])["signal_strength_dbm"] for w in range(3)])
-    assert np.allclose(dbm, ref, rtol=0, atol=1e-9)          # the mixer's cos/sin differ from glibc in the last ulp
+    assert np.array_equal(dbm, ref)          # shared carrier: the mixer uses the host libm's values, the sum runs in sample order
     assert dbm[1] < -100 and dbm[0] > dbm[1] + 100 and dbm[2] > dbm[1] + 100

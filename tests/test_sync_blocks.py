@@ -2,8 +2,8 @@
 passband_to_baseband (mixer + FIR + decimation), Schmidl-Cox time sync, Moose frequency sync.
 
 CPU part: the C oracle against the compiled reference (bit-identical). GPU part: the HIP kernels against
-the oracle — indices and correlation-free integer outputs exact, floating point within 1e-11 relative
-(the device's cos/sin/atan differ from glibc in the last ulp), plus an end-to-end capture-window chain.
+the oracle — indices and integer outputs exact; the mixed-down baseband bit-identical when the windows share a carrier (host-libm
+mixer table) and within 1e-11 relative when every window has its own (device cos/sin, last ulp), plus an end-to-end capture-window chain.
 """
 import numpy as np
 import pytest
@@ -77,6 +77,16 @@ def test_gpu_passband_to_baseband(cfg):
     # edges of the window: taps that fall outside the input are skipped exactly like cl_FIR::apply
     short = wins[0, :300]
     assert _rel(rx.passband_to_baseband(short, CARRIER, which=0)[0], o.passband_to_baseband(short, which=0)) < 1e-11
+    # one carrier for all windows (every call receive_byte makes before a frequency offset is known): the mixer's cos / sin come from
+    # the host's libm the way the reference evaluates them, and the baseband is bit-identical
+    for which in (0, 1):
+        got = rx.passband_to_baseband(wins, np.full(3, CARRIER + 1.25), which=which)
+        for w in range(3):
+            assert np.array_equal(got[w], o.passband_to_baseband(wins[w], carrier=CARRIER + 1.25, which=which)), (cfg, which, w)
+    got = rx.passband_to_baseband(wins, np.full(3, CARRIER), which=1, start=starts, count=count, decimation=4)
+    for w in range(3):
+        ref = o.passband_to_baseband(wins[w], which=1)[starts[w]::4][:count]
+        assert np.array_equal(got[w, : ref.size], ref)
 
 
 @pytest.mark.gpu
