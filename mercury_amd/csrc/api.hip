@@ -551,17 +551,18 @@ int mgpu_freq_sync(mgpu_ctx* c, const double* bb, int W, int stride, double* fre
         const auto& t = c->tab;
         int pre_half = t.preamble / 2 == 0 ? 1 : t.preamble / 2;            // ofdm.cc:548-555
         need(bb && freq_offset_hz && W > 0 && stride >= pre_half * t.Nofdm, "bad argument");
-        DevBuf d_in(size_t(W) * stride * 16), d_out(size_t(W) * 8);
+        DevBuf d_in(size_t(W) * stride * 16), d_out(size_t(W) * 16);
         hipStream_t s = c->stream;
         HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * stride * 16, hipMemcpyHostToDevice, s));
         const double bandwidth = 48000.0 * 50.0 / 256 / 4;
         HIPCK(hipEventRecord(c->sync_ev[0], s));
-        hipLaunchKernelGGL(mgpu_fsync_kernel, dim3(W), dim3(256), 0, s, d_in.as<double>(), stride, pre_half, c->dev.twiddle,
-                           bandwidth / double(t.Nc), d_out.as<double>());
+        hipLaunchKernelGGL(mgpu_fsync_kernel, dim3(W), dim3(256), 0, s, d_in.as<double>(), stride, pre_half, c->dev.twiddle, d_out.as<double>());
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(c->sync_ev[1], s));
-        HIPCK(hipMemcpyAsync(freq_offset_hz, d_out.p, size_t(W) * 8, hipMemcpyDeviceToHost, s));
+        std::vector<double> mul(size_t(W) * 2);
+        HIPCK(hipMemcpyAsync(mul.data(), d_out.p, size_t(W) * 16, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
+        for (int w = 0; w < W; ++w) freq_offset_hz[w] = moose_hz(mul[2 * w], mul[2 * w + 1], bandwidth / double(t.Nc));
     });
 }
 

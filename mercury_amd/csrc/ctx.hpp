@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include <cmath>
 #include "../../include/mercury_gpu.h"
 #include "../../include/mercury_rxloop.h"
 #include "device_tables.h"
@@ -34,7 +35,7 @@ extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, const in
 extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" int mgpu_tsync_coarse_threads();
 extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
-extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double, double*);
+extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double*);
 extern "C" __global__ void mgpu_span_energy_kernel(const double*, int, const int*, const int*, int, int, double*, int*);
 extern "C" __global__ void mgpu_window_energy_kernel(const double*, int, int, double*);
 extern "C" __global__ void mgpu_select_peak_kernel(const double*, const int*, int, int, const int*, const int*, int, int, int*, double*);
@@ -142,6 +143,16 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
 int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb);
 
 void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr);
+
+// carrier_sampling_frequency_sync's last step (ofdm.cc:594 with get_angle, misc.cc:34-56) on the sum the Moose kernel returns
+inline double moose_hz(double re, double im, double carrier_freq_width) {
+    double theta = 0;
+    if (re == 0) theta = M_PI / 2;
+    else if (re > 0) theta = std::atan(im / re);
+    else if (re < 0 && im >= 0) theta = std::atan(im / re) + M_PI;
+    else if (re < 0 && im < 0) theta = std::atan(im / re) - M_PI;
+    return (theta / M_PI) * carrier_freq_width;
+}
 
 // cos / sin table of the receive mixer for `carrier_hz`, at least `count` samples long (built on the host with the reference's libm call,
 // cached in the context); the stream is synchronised when the table has to be rebuilt

@@ -59,7 +59,7 @@ struct Workspace {
     Workspace(int W, int buf, int frame_n, size_t vals_per_window, int payload_stride)
         : d_pass(size_t(W) * buf * 8), d_bbi(size_t(W) * buf * 16), d_frames(size_t(W) * frame_n * 16), d_carrier(size_t(W) * 8),
           d_ia(size_t(W) * 128 * 4), d_ib(size_t(W) * 128 * 4), d_ic(size_t(W) * 4), d_vals(size_t(W) * vals_per_window * 8),
-          d_sum(size_t(W) * 128 * 8), d_cnt(size_t(W) * 128 * 4), d_freq(size_t(W) * 8), d_meanh(size_t(W) * 8),
+          d_sum(size_t(W) * 128 * 8), d_cnt(size_t(W) * 128 * 4), d_freq(size_t(W) * 16), d_meanh(size_t(W) * 8),
           d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * payload_stride), vals_per_window(vals_per_window) {
         HIPCK(hipHostMalloc(&h_vals, size_t(W) * vals_per_window * 8, hipHostMallocDefault));
         HIPCK(hipStreamCreate(&side));
@@ -499,9 +499,11 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             {
                 const int pre_half = lp.pre / 2 == 0 ? 1 : lp.pre / 2;
                 hipLaunchKernelGGL(mgpu_fsync_kernel, dim3(n), dim3(256), 0, s, lp.d_frames.as<double>() + size_t(t.Ngi) * 2, lp.frame_n, pre_half,
-                                   c->dev.twiddle, (48000.0 * 50.0 / 256 / 4) / double(t.Nc), lp.d_freq.as<double>());
+                                   c->dev.twiddle, lp.d_freq.as<double>());
                 HIPCK(hipGetLastError());
-                lp.down(f.data(), lp.d_freq, size_t(n) * 8);
+                std::vector<double> mul(size_t(n) * 2);
+                lp.down(mul.data(), lp.d_freq, size_t(n) * 16);
+                for (int k = 0; k < n; ++k) f[k] = moose_hz(mul[2 * k], mul[2 * k + 1], (48000.0 * 50.0 / 256 / 4) / double(t.Nc));
             }
             std::vector<int> rw, rslot;
             for (int k = 0; k < n; ++k) {

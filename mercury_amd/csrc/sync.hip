@@ -281,8 +281,7 @@ extern "C" __global__ __launch_bounds__(64 * TS_DWAVES) void mgpu_tsync_metric_d
 
 // Moose: up to two preamble symbols, each as two 256-point FFTs of a half symbol repeated twice.
 extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(
-    const double* __restrict__ bb, int stride, int pre_half, const double* __restrict__ twiddle, double carrier_freq_width,
-    double* __restrict__ freq_out) {
+    const double* __restrict__ bb, int stride, int pre_half, const double* __restrict__ twiddle, double* __restrict__ freq_out) {
     __shared__ c2 v[4][256];
     __shared__ c2 tw[128];
     __shared__ c2 dep[4][50];
@@ -321,12 +320,10 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(
                 const c2 p = cmul({d2.re, -d2.im}, d1);          // conj(frame_depadded2[i]) * frame_depadded1[i]
                 mul = {mul.re + p.re, mul.im + p.im};
             }
-        double theta = 0;                                         // get_angle, misc.cc:34-56
-        if (mul.re == 0) theta = M_PI / 2;
-        else if (mul.re > 0) theta = atan(mul.im / mul.re);
-        else if (mul.re < 0 && mul.im >= 0) theta = atan(mul.im / mul.re) + M_PI;
-        else if (mul.re < 0 && mul.im < 0) theta = atan(mul.im / mul.re) - M_PI;
-        freq_out[w] = (theta / M_PI) * carrier_freq_width;
+        // the closing get_angle(mul) / pi * width (misc.cc:34-56, ofdm.cc:594) is one atan per window: the host does it with the
+        // reference's libm (moose_hz in ctx.hpp), so the offset is bit-identical; the sum leaves the device as it is
+        freq_out[2 * w] = mul.re;
+        freq_out[2 * w + 1] = mul.im;
     }
 }
 

@@ -72,7 +72,7 @@ def test_gpu_receive_byte_batch_matches_oracle_ofdm(cfg):
             # hence bit-identical Schmidl-Cox metric and signal level (sums in the reference's order)
             assert st["coarse_metric"] == ref["coarse_metric"], (cfg, w)
             assert st["signal_strength_dbm"] == ref["signal_strength_dbm"], (cfg, w)
-            assert abs(st["freq_offset"] - ref["freq_offset"]) <= 1e-9 * max(1.0, abs(ref["freq_offset"])), (cfg, w)
+            assert st["freq_offset"] == ref["freq_offset"], (cfg, w)     # Moose: bit-identical FFTs and sum, the closing atan on the host
             assert abs(st["mean_H"] - ref["mean_H"]) <= 1e-9 * max(1.0, abs(ref["mean_H"])), (cfg, w)
             assert abs(st["snr_db"] - ref["snr_db"]) <= 1e-4 * max(1.0, abs(ref["snr_db"])), (cfg, w)
             assert np.array_equal(out["payload"][w][: orc.payload_bytes], ref["payload"]), (cfg, df, w)
@@ -172,7 +172,7 @@ def test_gpu_coarse_frequency_search_matches_oracle():
             st = out["stats"][w]
             for k in ("iterations_done", "crc", "all_zeros", "message_decoded", "delay", "sync_trials"):
                 assert st[k] == ref[k], (df, w, k, st[k], ref[k])
-            assert abs(st["freq_offset"] - ref["freq_offset"]) <= 1e-9 * max(1.0, abs(ref["freq_offset"]))
+            assert st["freq_offset"] == ref["freq_offset"]
             assert abs(st["mean_H"] - ref["mean_H"]) <= 1e-9 * max(1.0, abs(ref["mean_H"]))
             assert np.array_equal(out["payload"][w][: orc.payload_bytes], ref["payload"])
     rx.close()

@@ -101,7 +101,7 @@ def test_gpu_time_and_frequency_sync(cfg):
     d_gpu, c_gpu = rx.time_sync_preamble(bbi, 100)
     for w in range(3):
         d_ref, c_ref = o.time_sync_preamble(bbi[w], 100)
-        assert d_gpu[w] == d_ref and abs(c_gpu[w] - c_ref) <= 1e-12 * abs(c_ref)
+        assert d_gpu[w] == d_ref and c_gpu[w] == c_ref
     sym = o.Nofdm * 4
     segs, bases = [], []
     for w in range(3):
@@ -113,14 +113,14 @@ def test_gpu_time_and_frequency_sync(cfg):
         d2, c2 = rx.time_sync_preamble(segs, 1, loc, 2)
         for w in range(3):
             d_ref, c_ref = o.time_sync_preamble(segs[w], 1, loc, 2)
-            assert d2[w] == d_ref and abs(c2[w] - c_ref) <= 1e-12 * abs(c_ref)
+            assert d2[w] == d_ref and c2[w] == c_ref          # same samples in, same sums in the same order
     d2, _ = rx.time_sync_preamble(segs, 1, 0, 2)
     frames = np.stack([o.passband_to_baseband(wins[w], which=1)[bases[w] + int(d2[w])::4][: (o.preamble_nsymb + o.Nsymb) * o.Nofdm]
                        for w in range(3)])
     f_gpu = rx.freq_sync(frames[:, 16:])
     for w in range(3):
         f_ref = o.freq_sync(frames[w, 16:])
-        assert abs(f_gpu[w] - f_ref) <= 1e-9 * max(1.0, abs(f_ref)), (f_gpu[w], f_ref)
+        assert f_gpu[w] == f_ref, (f_gpu[w], f_ref)          # bit-identical: FFTs and sum on the device in the reference's order, atan on the host
 
 
 @pytest.mark.gpu
