@@ -132,6 +132,9 @@ int mgpu_rx_batch_taps(mgpu_ctx* ctx, const double* baseband_c128, int F, uint8_
                        mgpu_frame_stats* stats, const mgpu_stage_taps* taps);
 /* llr: [F][1600] float. bits: [F][K] one byte per hard decision (0/1). iters: [F]. */
 int mgpu_ldpc_batch(mgpu_ctx* ctx, const float* llr, int F, uint8_t* bits, int* iters);
+/* void cl_ldpc::encode(const int* data, int* encoded_data) (ldpc.h:82, ldpc.cc:111-132) for F words: bits [F][K], one byte per bit
+ * -> encoded [F][N] = the data followed by the P parity bits. */
+int mgpu_ldpc_encode_batch(mgpu_ctx* ctx, const uint8_t* bits, int F, uint8_t* encoded);
 
 /* ---- device-buffer entry points (asynchronous on `stream`, a hipStream_t) ------------ */
 int mgpu_rx_batch_dev(mgpu_ctx* ctx, const void* d_baseband_c128, int F, void* d_payload,

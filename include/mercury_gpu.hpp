@@ -4,7 +4,7 @@
 //
 //   mgpu::cl_ldpc          <->  class cl_ldpc            (include/physical_layer/ldpc.h:32-93)
 //        N, P, K, rate, framesize, standard, decoding_algorithm, GBF_eta, nIteration_max,
-//        init(), deinit(), int decode(const float* data, int* decoded_data)
+//        init(), deinit(), int decode(const float* data, int* decoded_data), void encode(const int* data, int* encoded_data)
 //   mgpu::cl_rx_phy        <->  the RX members of class cl_telecom_system
 //                                (include/physical_layer/telecom_system.h:85-198)
 //        load_configuration(int)              telecom_system.cc:2487
@@ -112,6 +112,13 @@ public:
         detail::check(mgpu_ldpc_batch(ctx_, data, 1, bits.data(), &iters), ctx_, "cl_ldpc::decode");
         for (int i = 0; i < K; ++i) decoded_data[i] = bits[i];
         return iters;
+    }
+    // ldpc.h:82 — encoded_data = the K data bits followed by the P parity bits
+    void encode(const int* data, int* encoded_data) {
+        std::vector<uint8_t> in(K), out(N);
+        for (int i = 0; i < K; ++i) in[i] = uint8_t(data[i] & 1);
+        detail::check(mgpu_ldpc_encode_batch(ctx_, in.data(), 1, out.data()), ctx_, "cl_ldpc::encode");
+        for (int i = 0; i < N; ++i) encoded_data[i] = out[i];
     }
 
 private:

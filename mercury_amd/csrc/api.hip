@@ -817,4 +817,24 @@ int mgpu_ldpc_batch(mgpu_ctx* c, const float* llr, int F, uint8_t* bits, int* it
     });
 }
 
+int mgpu_ldpc_encode_batch(mgpu_ctx* c, const uint8_t* bits, int F, uint8_t* encoded) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(bits && encoded && F >= 0, "bad argument");
+        if (F == 0) return;
+        const auto& t = c->tab;
+        DevBuf d_in(size_t(F) * t.K), d_out(size_t(F) * t.N);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_in.p, bits, size_t(F) * t.K, hipMemcpyHostToDevice, s));
+        for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
+            const int n = std::min(F - off, kMaxFramesPerLaunch);
+            hipLaunchKernelGGL(mgpu_ldpc_encode_kernel, dim3(n), dim3(256), 0, s, c->dev, d_in.as<uint8_t>() + size_t(off) * t.K, n,
+                               d_out.as<uint8_t>() + size_t(off) * t.N);
+            HIPCK(hipGetLastError());
+        }
+        HIPCK(hipMemcpyAsync(encoded, d_out.p, size_t(F) * t.N, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
 }  // extern "C"

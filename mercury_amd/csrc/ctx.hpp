@@ -47,6 +47,7 @@ using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8
 extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 #define DECL_MS(NE) extern "C" __global__ void mgpu_ldpc_minsum_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_MS(4) DECL_MS(5) DECL_MS(6) DECL_MS(7) DECL_MS(8)
+extern "C" __global__ void mgpu_ldpc_encode_kernel(MgpuDev, const uint8_t*, int, uint8_t*);
 extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*, const uint8_t*, int, const int*, int, int);
 
 static_assert(sizeof(MgpuStatsDev) == sizeof(mgpu_frame_stats), "stats layout");

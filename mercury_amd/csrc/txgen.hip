@@ -211,3 +211,48 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
         __syncthreads();
     }
 }
+
+// cl_ldpc::encode alone (ldpc.cc:111-132) for F words: bits [F][K] (one byte per bit) -> enc [F][N]. Same two steps as in the
+// transmit kernel above: the information part of every check's parity in parallel, then the staircase as a prefix XOR.
+extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_ldpc_encode_kernel(MgpuDev T, const uint8_t* __restrict__ bits_in, int F,
+                                                                               uint8_t* __restrict__ enc_out) {
+    __shared__ uint8_t bits[1600], par[1600], wpar[32];
+    const int tid = threadIdx.x, K = T.K, P = T.P;
+    if (int(blockIdx.x) >= F) return;
+    const uint8_t* in = bits_in + size_t(blockIdx.x) * K;
+    uint8_t* enc = enc_out + size_t(blockIdx.x) * (K + P);
+    for (int i = tid; i < K; i += TX_THREADS) { const uint8_t b = in[i] & 1; bits[i] = b; enc[i] = b; }
+    __syncthreads();
+    for (int c = tid; c < P; c += TX_THREADS) {
+        uint8_t x = 0;
+        for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) { const int v = T.cvar[e]; if (v < K) x ^= bits[v]; }
+        par[c] = x;
+    }
+    __syncthreads();
+    if (T.staircase) {
+        const int nw = (P + 63) / 64;
+        for (int k = tid; k < nw; k += TX_THREADS) {
+            uint8_t x = 0;
+            for (int c = k * 64; c < min(P, k * 64 + 64); ++c) x ^= par[c];
+            wpar[k] = x;
+        }
+        __syncthreads();
+        if (tid == 0) { uint8_t x = 0; for (int k = 0; k < nw; ++k) { const uint8_t y = wpar[k]; wpar[k] = x; x ^= y; } }
+        __syncthreads();
+        for (int c = tid; c < P; c += TX_THREADS) {
+            uint8_t x = wpar[c >> 6];
+            for (int q = c & ~63; q <= c; ++q) x ^= par[q];
+            enc[K + c] = x;
+        }
+    } else {                          // general lower-triangular parity part: rows in order, as the reference does
+        __shared__ uint8_t pbit[1600];
+        if (tid == 0)
+            for (int c = 0; c < P; ++c) {
+                uint8_t x = par[c];
+                for (uint32_t e = T.cptr[c]; e < T.cptr[c + 1]; ++e) { const int v = T.cvar[e]; if (v >= K && v != K + c) x ^= pbit[v - K]; }
+                pbit[c] = x;
+            }
+        __syncthreads();
+        for (int c = tid; c < P; c += TX_THREADS) enc[K + c] = pbit[c];
+    }
+}

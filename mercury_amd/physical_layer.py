@@ -99,7 +99,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "mgpu_alloc_host", "mgpu_free_host", "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
-    "mgpu_ldpc_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
+    "mgpu_ldpc_batch", "mgpu_ldpc_encode_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_measure_signal_only",
@@ -214,6 +214,16 @@ class RxPhy:
         return bits, iters
 
     # ---- device-buffer entry points (raw device pointers, e.g. torch tensor.data_ptr()) --------
+    def ldpc_encode(self, bits):
+        """cl_ldpc::encode: uint8 [F, K] (one byte per bit) -> uint8 [F, N]."""
+        b = np.ascontiguousarray(bits, np.uint8)
+        b = b.reshape(1, -1) if b.ndim == 1 else b
+        if b.shape[1] != self.K:
+            raise MgpuError("a data word is K = %d bits" % self.K)
+        out = np.zeros((b.shape[0], self.N), np.uint8)
+        self._ck(self.lib.mgpu_ldpc_encode_batch(self.h, _ptr(b), C.c_int(b.shape[0]), _ptr(out)))
+        return out
+
     def receive_dev(self, d_baseband, F, d_payload, d_stats, d_llr=None, stream=None):
         self._ck(self.lib.mgpu_rx_batch_dev(self.h, d_baseband, F, d_payload, d_stats, d_llr, stream))
 

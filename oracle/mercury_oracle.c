@@ -416,6 +416,9 @@ static void ldpc_encode(const morc* o, const int* data, int* enc) {
     }
 }
 
+/* cl_ldpc::encode alone (ldpc.cc:111-132): K data bits -> N = K + P code bits */
+void morc_ldpc_encode(morc* o, const int* data_K, int* enc_N) { ldpc_encode(o, data_K, enc_N); }
+
 /* TX: telecom_system.cc:114-139 (scramble=0) / :428-470 (scramble=1) */
 void morc_tx(morc* o, const int* bits, int scramble, double* out_c128) {
     int db[N_MAX], enc[N_MAX], bi[N_MAX];

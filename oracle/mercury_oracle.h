@@ -83,6 +83,7 @@ void morc_tx(morc*, const int* bits, int scramble, double* out_c128);
 void morc_payload_to_bits(morc*, const int* payload, int nBytes, int* bits);
 void morc_rx(morc*, const double* baseband_c128, int flags, morc_rx_out* out);
 int morc_ldpc_decode(morc*, const float* llr, int* bits_K, int alg);
+void morc_ldpc_encode(morc*, const int* data_K, int* enc_N);     /* cl_ldpc::encode, ldpc.cc:111-132 */
 
 /* ---- synthetic workload generator (the repo's own) ---------------------
  * Philox4x32-10 keyed by seed, counter = (index, stream, frame_lo, frame_hi).

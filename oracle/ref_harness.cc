@@ -710,6 +710,12 @@ double mref_detect_ack_pattern(void* h, const double* in_c128, int size, int int
                                       r->ack_mfsk.tone_hop_step, r->ack_mfsk.M, r->ack_mfsk.nStreams, r->ack_mfsk.stream_offsets, matched);
 }
 
+// cl_ldpc::encode alone (ldpc.h:89, ldpc.cc:111-132)
+void mref_ldpc_encode(void* h, const int* data_K, int* enc_N) {
+    Ref* r = (Ref*)h;
+    r->ldpc.encode(data_K, enc_N);
+}
+
 // cl_ldpc::decode alone (ldpc.h:90). alg: 1 = SPA (default), 0 = GBF.
 int mref_ldpc_decode(void* h, const float* llr, int* bits_K) {
     Ref* r = (Ref*)h;

@@ -59,6 +59,14 @@ int main(int argc, char** argv) {
             fwrite(&it, sizeof(int), 1, out);
             fwrite(bits.data(), sizeof(int), ldpc.K, out);
         }
+        {   // cl_ldpc::encode then decode of the noiseless word: 0 iterations, the data back
+            std::vector<int> data(ldpc.K), enc(ldpc.N), back(ldpc.K);
+            for (int i = 0; i < ldpc.K; ++i) data[i] = (i * 7 + i / 3) & 1;
+            ldpc.encode(data.data(), enc.data());
+            std::vector<float> l(ldpc.N);
+            for (int i = 0; i < ldpc.N; ++i) l[i] = enc[i] ? -4.0f : 4.0f;
+            if (ldpc.decode(l.data(), back.data()) != 0 || back != data) return 9;
+        }
         fclose(out);
         // 4) the whole receive_byte on passband capture windows, one call per window like RX_SHM_process_main
         //    (optional 7th argument: file of W windows; results appended to <out>.rb)

@@ -106,6 +106,14 @@ class _Base:
         self._fn("payload_to_bits")(self.h, _p(pl), C.c_int(len(pl)), _p(bits))
         return bits[: self.nReal].copy()
 
+    def ldpc_encode(self, data):
+        """cl_ldpc::encode: K data bits -> N code bits."""
+        d = np.ascontiguousarray(data, np.int32)
+        assert d.size == self.K
+        out = np.zeros(self.N, np.int32)
+        self._fn("ldpc_encode")(self.h, _p(d), _p(out))
+        return out
+
     def tx(self, bits, scramble=1):
         b = np.zeros(1600, np.int32)
         b[: self.nReal] = bits[: self.nReal]

@@ -566,3 +566,28 @@ def test_entry_points_reject_bad_arguments_without_crashing():
     assert lib.mgpu_channel_estimator(mf.h, p(buf), 1, p(buf)) == 1   # the estimator stages exist for the OFDM modes only
     mf.close()
     rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 5, 8, 11, 16, 100, 102])     # the 8 code rates (+ the MFSK modes' reuse of 1/16 and 4/16)
+def test_ldpc_encode_matches_oracle_and_decodes_back(cfg):
+    """cl_ldpc::encode (ldpc.cc:111-132) for a batch: bit-exact parity bits; every encoded word is a codeword (0 iterations) and a
+    word with a few weak wrong bits decodes back to the data."""
+    from mercury_amd import RxPhy
+    orc = oraclelib.Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=8)
+    rng = np.random.default_rng(cfg)
+    data = rng.integers(0, 2, (6, orc.K)).astype(np.uint8)
+    data[0] = 0
+    data[1] = 1
+    enc = rx.ldpc_encode(data)
+    assert enc.shape == (6, 1600)
+    for f in range(6):
+        assert np.array_equal(enc[f], orc.ldpc_encode(data[f].astype(np.int32))), (cfg, f)
+    llr = np.where(enc == 1, -4.0, 4.0).astype(np.float32)            # the reference's sign convention: negative LLR = bit 1
+    bits, iters = rx.ldpc_decode(llr)
+    assert np.array_equal(bits, data) and not np.any(iters)
+    noisy = llr.copy()
+    noisy[:, rng.choice(1600, 12, replace=False)] *= -0.25
+    bits, iters = rx.ldpc_decode(noisy)
+    assert np.array_equal(bits, data) and np.all(iters >= 1) and np.all(iters <= 50)
