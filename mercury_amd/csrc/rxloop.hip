@@ -114,10 +114,11 @@ struct Loop {
         up(d_carrier, carrier.data(), size_t(W) * 8);
         const auto& taps = filter ? t.fir_data : t.fir_time_sync;
         const int ntaps = int(taps.size());
-        // windows that all mix with one carrier (always so before a frequency offset has been measured) use the host-libm table:
-        // the reference's own cos / sin values, and no trigonometry on the device
+        // windows that all mix with the call's own carrier (always so before a frequency offset has been measured) use the host-libm
+        // table: the reference's own cos / sin values, and no trigonometry on the device. A window re-mixed at its measured offset
+        // has a carrier of its own — never the table's, which would have to be rebuilt (3 ms of host time) for every such launch.
         bool shared = true;
-        for (int w : wins) shared = shared && carrier[w] == carrier[wins[0]];
+        for (int w : wins) shared = shared && carrier[w] == rc.carrier_hz;
         const double* cs = shared ? mixer_table(c, carrier[wins[0]], size_t(buf), s) : nullptr;
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((buf + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 + ntaps) * 16, s,
                            d_pass.as<double>(), buf, d_carrier.as<double>(), nullptr, 0, buf, 1, c->d_fir[filter], ntaps, 48000.0,
