@@ -132,6 +132,17 @@ int mgpu_rx_batch_taps(mgpu_ctx* ctx, const double* baseband_c128, int F, uint8_
                        mgpu_frame_stats* stats, const mgpu_stage_taps* taps);
 /* llr: [F][1600] float. bits: [F][K] one byte per hard decision (0/1). iters: [F]. */
 int mgpu_ldpc_batch(mgpu_ctx* ctx, const float* llr, int F, uint8_t* bits, int* iters);
+/* ---- host-side pieces of the library, callable without a GPU (the CPU test suite checks them against the oracle) ----
+ * mgpu_host_select_peak: the reference's peak selection (ofdm.cc:1943-1964, overwrite-not-swap partial sort over `size` entries of
+ *   which only every `step`-th is a candidate metric) on the candidate metrics alone, as the synchroniser entry points use it.
+ * mgpu_host_fir_taps: the filters the library designs (cl_FIR::design, fir_filter.cc:45-162): which 0 = FIR_rx_time_sync,
+ *   1 = FIR_rx_data, 2 = FIR_tx1, 3 = FIR_tx2 (the transmit filters depend on the carrier). taps: room for 128 doubles.
+ * mgpu_host_preamble_carriers: the mode's preamble symbols in the carrier domain, [n_symbols][50] complex128. */
+int mgpu_host_select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay,
+                          double* correlation);
+int mgpu_host_fir_taps(int which, double carrier_hz, double* taps, int* ntaps);
+int mgpu_host_preamble_carriers(int cfg, double* carriers_c128, int* n_symbols);
+
 /* void cl_ldpc::encode(const int* data, int* encoded_data) (ldpc.h:82, ldpc.cc:111-132) for F words: bits [F][K], one byte per bit
  * -> encoded [F][N] = the data followed by the P parity bits. */
 int mgpu_ldpc_encode_batch(mgpu_ctx* ctx, const uint8_t* bits, int F, uint8_t* encoded);

@@ -817,6 +817,41 @@ int mgpu_ldpc_batch(mgpu_ctx* c, const float* llr, int F, uint8_t* bits, int* it
     });
 }
 
+// ---- host-side pieces of the library, callable without a GPU (the CPU test suite checks them against the oracle) ----------------
+int mgpu_host_select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay,
+                          double* correlation) {
+    if (!cand_vals || !delay || ncand < 0 || step < 1 || size < 1 || nTrials_max < 1 || nTrials_max > size) return MGPU_ERR_ARG;
+    double corr = 0;
+    select_peak(cand_vals, ncand, step, size, location_to_return, nTrials_max, delay, &corr);
+    if (correlation) *correlation = corr;
+    return MGPU_OK;
+}
+
+int mgpu_host_fir_taps(int which, double carrier_hz, double* taps, int* ntaps) {
+    if (!taps || !ntaps || which < 0 || which > 3) return MGPU_ERR_ARG;
+    try {
+        std::vector<double> t;
+        if (which >= 2) t = mgpu::design_tx_fir(which - 2, carrier_hz);
+        else {
+            const mgpu::ModeTables m = mgpu::build_mode_tables(8, 0, mgpu_ldpc_blob, mgpu_ldpc_blob_size);
+            t = which ? m.fir_data : m.fir_time_sync;
+        }
+        std::copy(t.begin(), t.end(), taps);
+        *ntaps = int(t.size());
+        return MGPU_OK;
+    } catch (const std::exception&) { return MGPU_ERR_ARG; }
+}
+
+int mgpu_host_preamble_carriers(int cfg, double* carriers_c128, int* n_symbols) {
+    if (!carriers_c128 || !n_symbols) return MGPU_ERR_ARG;
+    try {
+        const mgpu::ModeTables m = mgpu::build_mode_tables(cfg, 0, mgpu_ldpc_blob, mgpu_ldpc_blob_size);
+        std::memcpy(carriers_c128, m.preamble_carriers.data(), m.preamble_carriers.size() * 16);
+        *n_symbols = m.preamble;
+        return MGPU_OK;
+    } catch (const std::exception&) { return MGPU_ERR_ARG; }
+}
+
 int mgpu_ldpc_encode_batch(mgpu_ctx* c, const uint8_t* bits, int F, uint8_t* encoded) {
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {

@@ -99,6 +99,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "mgpu_alloc_host", "mgpu_free_host", "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
+    "mgpu_host_select_peak", "mgpu_host_fir_taps", "mgpu_host_preamble_carriers",
     "mgpu_ldpc_batch", "mgpu_ldpc_encode_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",

@@ -95,3 +95,68 @@ def test_table_blob_is_wellformed():
     assert off == len(blob)
     # SURVEY.md §0 graph statistics
     assert seen == {100: 3574, 200: 3859, 300: 4439, 400: 4651, 500: 5409, 600: 5616, 800: 6049, 1400: 6604}
+
+
+# ---- the library's own host logic, through its GPU-free entry points ------------------------------------------------------------
+def _reference_selection(cand, step, size, loc, ntrials):
+    """ofdm.cc:1926-1964 as written: an array of `size` zeros with the candidate metrics at every `step`-th index, then the
+    overwrite-not-swap partial sort."""
+    vals = np.zeros(size)
+    vals[: len(cand) * step: step][: len(cand)] = cand
+    locs = -np.ones(size, int)
+    if loc >= ntrials:
+        loc = ntrials - 1
+    for j in range(ntrials):
+        locs[j] = j
+        for i in range(j + 1, size):
+            if vals[i] > vals[j]:
+                vals[j] = vals[i]
+                locs[j] = i
+    return int(locs[loc]), float(vals[loc])
+
+
+def test_host_select_peak_matches_the_reference_selection():
+    import ctypes as C
+    from hypothesis import given, settings, strategies as st
+    from mercury_amd import load_library
+    lib = load_library()
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(1, 12), st.integers(1, 7), st.integers(0, 5), st.integers(1, 4), st.integers(0, 3), st.data())
+    def check(ncand, step, extra, ntrials, loc, data):
+        size = (ncand - 1) * step + 1 + extra
+        ntrials = min(ntrials, size)
+        cand = np.array(data.draw(st.lists(st.sampled_from([-1.0, -0.25, 0.0, 0.125, 0.5, 0.5, 0.75, 1.0]), min_size=ncand, max_size=ncand)))
+        delay, corr = C.c_int(-7), C.c_double(-7)
+        rc = lib.mgpu_host_select_peak(cand.ctypes.data_as(C.c_void_p), C.c_int(ncand), C.c_int(step), C.c_int(size), C.c_int(loc), C.c_int(ntrials),
+                                       C.byref(delay), C.byref(corr))
+        assert rc == 0
+        assert (delay.value, corr.value) == _reference_selection(cand, step, size, loc, ntrials), (cand, step, size, loc, ntrials)
+
+    check()
+
+
+def test_host_filter_designs_and_preamble_match_the_oracle():
+    import ctypes as C
+    import oraclelib
+    from mercury_amd import load_library
+    lib = load_library()
+    orc = oraclelib.Oracle(8)
+    taps, n = np.zeros(128), C.c_int(0)
+    for which in (0, 1):
+        assert lib.mgpu_host_fir_taps(C.c_int(which), C.c_double(0.0), taps.ctypes.data_as(C.c_void_p), C.byref(n)) == 0
+        assert np.array_equal(taps[: n.value], orc.fir_taps(which))
+    f = orc.lib.morc_tx_fir_taps
+    f.restype = C.c_int
+    for carrier in (oraclelib.CARRIER, 1650.0):
+        for which in (0, 1):
+            want = np.zeros(128)
+            nw = f(C.c_double(carrier), C.c_int(which), want.ctypes.data_as(C.c_void_p))
+            assert lib.mgpu_host_fir_taps(C.c_int(2 + which), C.c_double(carrier), taps.ctypes.data_as(C.c_void_p), C.byref(n)) == 0
+            assert n.value == nw == 97 and np.array_equal(taps[:97], want[:97])
+    for cfg in (0, 8, 13, 16):
+        o = oraclelib.Oracle(cfg)
+        out, ns = np.zeros((8, 50), np.complex128), C.c_int(0)
+        assert lib.mgpu_host_preamble_carriers(C.c_int(cfg), out.ctypes.data_as(C.c_void_p), C.byref(ns)) == 0
+        assert ns.value == o.preamble_nsymb and np.array_equal(out[: ns.value].ravel(), o.preamble())
+    assert lib.mgpu_host_preamble_carriers(C.c_int(55), out.ctypes.data_as(C.c_void_p), C.byref(ns)) != 0
