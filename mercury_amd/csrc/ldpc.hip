@@ -83,28 +83,28 @@ extern "C" size_t mgpu_spa_lds_bytes(int S, int N) {
 // ---------------------------------------------------------------------------------------------
 // Sum-product, double precision, reference arithmetic.
 //
-// One message array M[] in LDS holds, alternately, T = tanh(0.5*Q) and R for every edge. Edges
+// One message array M[] in LDS holds, alternately, R and T = tanh(0.5*Q) for every edge. Edges
 // live in a padded, wave-private layout: whole checks are bin-packed into 64-slot bins, and a bin
-// is always processed by one wavefront in one instruction stream. All lanes of a wave finish
-// reading the T values of their checks before the (later) instruction that overwrites them with R
-// issues, so the check update runs in place without a workgroup barrier and without staging.
-// Each lane keeps the (constant) descriptors of its NE slots in registers for the whole decode, so
-// the two edge-parallel phases touch no index memory at all. The syndrome costs nothing extra: in
-// the Q/tanh phase every lane already holds the posterior of its edge's variable, one 64-bit ballot
-// of the sign bits gives every check its parity.
-// Per iteration: check update | barrier | variable update | barrier | syndrome [| barrier | verdict] | Q/tanh.
-// Up to eight slot descriptors per lane held in named registers (an indexed array would be demoted
-// to scratch memory); get(r) selects by the wave-uniform round number.
-struct SlotRegs {
-    uint32_t k0, k1, k2, k3, k4, k5, k6, k7;
-    __device__ __forceinline__ uint32_t get(int r) const {
-        uint32_t v = k0;
-        v = (r == 1) ? k1 : v; v = (r == 2) ? k2 : v; v = (r == 3) ? k3 : v; v = (r == 4) ? k4 : v;
-        v = (r == 5) ? k5 : v; v = (r == 6) ? k6 : v; v = (r == 7) ? k7 : v;
-        return v;
-    }
-};
-
+// is always processed by one wavefront in one instruction stream, so everything that happens to a
+// check between two variable updates needs no workgroup barrier:
+//     per bin:  Q = posterior - R  ->  T = tanh(0.5*Q) -> M   (own T stays in a register)
+//               wave barrier (every lane's T is in LDS)
+//               product of the check's other T values, in slot order -> clamp -> R = 2*atanh
+//               wave barrier (every lane has read its check's T values)
+//               R -> M
+// The syndrome costs nothing extra: in that pass every lane holds the posterior of its edge's
+// variable, one 64-bit ballot of the sign bits gives every check its parity.
+// Per iteration: [syndrome +] tanh + check update | barrier | variable update | barrier [| syndrome | barrier | verdict].
+// Slot descriptors (check start, degree, variable: one word per slot, T.sdesc) are shared by every
+// codeword; a wave fetches the word of its next bin while it works on the current one (one coalesced
+// cached load per bin), so no descriptor lives in registers or scratch across the loop.
+//
+// Instruction budget (profiles/r02_valu_cycles.json, r02_spa_instruction_mix.json): the kernel is bound by
+// vector-instruction issue; an fp64 operation costs 4 cycles per wavefront, v_rcp_f64 16, a 32-bit
+// integer/select operation 2-4. Per edge and iteration the reference's arithmetic needs ~105 fp64
+// operations + 5 reciprocal seeds (spa_math.h); everything else in the loop is kept to a few dozen
+// 32-bit operations: padding lanes and fdlibm's case distinctions are execution-mask branches (scalar
+// instructions only), not selects.
 template <int NE>
 __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
                                            uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
@@ -112,7 +112,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
                                            const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = T.S, N = T.N;
-    double* M = reinterpret_cast<double*>(smem);      // T or R per padded edge slot
+    double* M = reinterpret_cast<double*>(smem);      // R or T per padded edge slot
     double* Lt = M + S;                               // LLRtmp per variable
     float* Li = reinterpret_cast<float*>(Lt + N);     // channel LLR
     uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
@@ -127,145 +127,136 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         Li[v] = l;
         Lt[v] = l;
     }
-    // slot descriptors, one register each: check_start(13) | deg(6)<<13 | variable(11)<<19 ; deg == 0 marks padding.
+    for (int p = tid; p < S; p += LDPC_THREADS) M[p] = 0.0;     // R = 0 before the first iteration (:106-122)
+    // slot descriptor: check_start(13) | deg(6)<<13 | variable(11)<<19 ; deg == 0 marks padding.
     // The slot's position inside its check is p - check_start.
-    auto load_slot = [&](int r) -> uint32_t {
-        const int p = tid + r * LDPC_THREADS;
-        uint32_t k = 0;
-        if (r < NE && p < S) {
-            const uint32_t sp = T.spack[p];
-            if (sp >> 31) k = (sp & 0x7ffffu) | (uint32_t(T.svar[p]) << 19);
-        }
-        return k;
-    };
-    const SlotRegs pk = {load_slot(0), load_slot(1), load_slot(2), load_slot(3), load_slot(4), load_slot(5), load_slot(6), load_slot(7)};
+    const uint32_t* __restrict__ sdesc = T.sdesc + tid;
+    // bin_end[b]: bit l set <=> lane l holds the last edge of a check of bin b (wave w works on bin w + 16 r in round r)
+    const unsigned long long* __restrict__ bin_end = T.bin_end + __builtin_amdgcn_readfirstlane(tid >> 6);
     // variable records (variable | deg<<11, then 10 u16 slot indices in the reference's slot order)
     struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
-    auto load_var = [&](int i) -> VarRec {
+    // The records are fetched again in every iteration (two cached loads per lane, issued ahead of the barrier they hide
+    // behind) rather than held in 12 registers across the check-node pass, which needs all 64 of them.
+    auto load_var = [&](const uint32_t* vinfo, int i) -> VarRec {
         if (i >= N) return VarRec{0, 0, 0, 0, 0, 0};
-        const uint32_t* rec = T.vinfo + size_t(i) * 6;
-        return VarRec{rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]};
+        const uint4 lo = *reinterpret_cast<const uint4*>(vinfo + size_t(i) * 8);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vinfo + size_t(i) * 8 + 4);
+        return VarRec{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
     };
-    const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
+    // LLRtmp = LLR + R[slot 0] + R[slot 1] + ... in slot order (:162-170). Every "does this variable have a slot j" test is
+    // a branch on the execution mask (the rows are sorted by degree, so most wavefronts agree and skip whole blocks);
+    // deg is made opaque so that the nine lane masks are recomputed (one compare each) instead of being kept alive
+    // across the whole decode, where they do not fit the scalar register file.
     auto var_update = [&](const VarRec& q) {
-        const int v = q.vi & 0x7ff, deg = q.vi >> 11;
+        const uint32_t v = q.vi & 0x7ff;
+        uint32_t deg = q.vi >> 11;
+        asm volatile("" : "+v"(deg));
         double s = Li[v];
-        const double m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
-        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
-        if (deg > 2) {      // the rows are sorted by degree: whole wavefronts of degree-2 parity bits skip the rest
-            const double m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
-            s += m2;
-            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
-        }
-        if (deg > 5) {
-            const double m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
-            s += m5;
-            s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
+        if (deg > 0) { s += M[q.w0 & 0xffff]; SPA_KEEP(s); }
+        if (deg > 1) { s += M[q.w0 >> 16]; SPA_KEEP(s); }
+        if (deg > 2) {
+            s += M[q.w1 & 0xffff]; SPA_KEEP(s);
+            if (deg > 3) { s += M[q.w1 >> 16]; SPA_KEEP(s); }
+            if (deg > 4) { s += M[q.w2 & 0xffff]; SPA_KEEP(s); }
+            if (deg > 5) {
+                s += M[q.w2 >> 16]; SPA_KEEP(s);
+                if (deg > 6) { s += M[q.w3 & 0xffff]; SPA_KEEP(s); }
+                if (deg > 7) { s += M[q.w3 >> 16]; SPA_KEEP(s); }
+                if (deg > 8) { s += M[q.w4 & 0xffff]; SPA_KEEP(s); }
+            }
         }
         Lt[v] = s;
     };
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
 
-    // parity of every check of this wave's bin from the sign bits of its edges' variables
-    auto check_parity = [&](uint32_t k, bool neg) -> bool {
-        const unsigned long long m = __ballot(neg);
-        const uint32_t deg = (k >> 13) & 0x3f, l0 = k & 63u;
-        const unsigned long long cm = ((deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << l0);
-        return (__popcll(m & cm) & 1) != 0;
+    // Does any check of this wave's bin have odd parity? m = sign bits of the posteriors of the bin's 64 edges (a check
+    // is a run of consecutive lanes, padding lanes contribute 0). With px = prefix XOR of m, check i spanning lanes
+    // (e[i-1], e[i]] has parity px[e[i]] ^ px[e[i-1]], so all parities are even <=> px is 0 at every check end.
+    // Scalar instructions only (the ballot is wave-uniform).
+    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
+        m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
+        return (m & ends) != 0;
     };
 
     // Pass p (0 = channel values, 1..max = after iteration p) leaves its syndrome verdict in flag[p & 1].
-    // syndrome_pass: every lane holds the posterior of its edge's variable -> ballot + popcount per check.
     auto syndrome_pass = [&](int p) {
         bool unsat = false;
+        uint32_t k = sdesc[0];
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
-            const uint32_t k = pk.get(r);
+            const uint32_t kn = (r + 1 < NE) ? sdesc[(r + 1) * LDPC_THREADS] : 0u;
             const bool valid = ((k >> 13) & 0x3f) != 0;
-            const double lt = valid ? Lt[k >> 19] : 0.0;
-            unsat |= check_parity(k, valid && lt < 0) && valid;
+            double lt = 0.0;
+            if (valid) lt = Lt[k >> 19];
+            unsat |= bin_unsat(__ballot(lt < 0), bin_end[r * (LDPC_THREADS / 64)]);
+            k = kn;
         }
-        if (unsat) flag[p & 1] = 1;
+        if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
-    // tanh_pass: Q = LLRtmp - R (:193-209; R == 0 before the first iteration, :106-122) -> T = tanh(0.5*Q) in place
-    auto tanh_pass = [&](bool first) {
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t k = pk.get(r);
-            if (((k >> 13) & 0x3f) != 0) {
-                const int p = tid + r * LDPC_THREADS;
-                const double q = first ? double(Li[k >> 19]) : Lt[k >> 19] - M[p];
-                M[p] = spa_tanh(0.5 * q);
-            }
-        }
-    };
-    // fused_pass: both in one sweep (one posterior read per edge) for the iterations whose verdict is deferred
-    auto fused_pass = [&](int p) {
+    // cn_pass: Q = LLRtmp - R (:193-209) -> T = tanh(0.5*Q) (:145) -> product of the others, clamp, R = 2*atanh (:129-160),
+    // all inside the wavefront that owns the bin; with_syndrome additionally judges the posteriors it reads (pass p)
+    auto cn_pass = [&](bool with_syndrome, int p) {
         bool unsat = false;
+        uint32_t k = sdesc[0];
+        uint32_t slot = tid;
 #pragma unroll 1
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t k = pk.get(r);
-            const bool valid = ((k >> 13) & 0x3f) != 0;
-            const double lt = valid ? Lt[k >> 19] : 0.0;
-            unsat |= check_parity(k, valid && lt < 0) && valid;
+        for (int r = 0; r < NE; ++r, slot += LDPC_THREADS) {
+            const uint32_t kn = (r + 1 < NE) ? sdesc[(r + 1) * LDPC_THREADS] : 0u;
+            const uint32_t deg = (k >> 13) & 0x3f;
+            const bool valid = deg != 0;
+            double lt = 0.0;
+            if (valid) lt = Lt[k >> 19];
+            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0), bin_end[r * (LDPC_THREADS / 64)]);
+            if (valid) M[slot] = spa_tanh_half(lt - M[slot]);
+            __builtin_amdgcn_wave_barrier();        // every lane's T is written (LDS operations of a wave complete in order)
+            double rr = 0.0;
             if (valid) {
-                const int q = tid + r * LDPC_THREADS;
-                M[q] = spa_tanh(0.5 * (lt - M[q]));
+                // the other deg-1 values of the check in slot order: step j reads slot j, or j+1 once the lane's own
+                // slot has been passed; same multiplication order as the reference, starting from 1.0
+                const uint32_t cs = k & 0x1fff, pos = slot - cs, degm1 = deg - 1;
+                double temp = 1;
+                uint32_t j = 0;
+                for (; j + 2 <= degm1; j += 2) {       // two reads in flight per LDS round trip
+                    const double a = M[cs + j + (j >= pos ? 1 : 0)], b = M[cs + j + 1 + (j + 1 >= pos ? 1 : 0)];
+                    temp *= a;
+                    temp *= b;
+                }
+                if (j < degm1) temp *= M[cs + j + (j >= pos ? 1 : 0)];
+                rr = spa_atanh_x2(temp);              // clamps +-1 to +-0.9999999 first (:150-155)
             }
+            __builtin_amdgcn_wave_barrier();        // every lane of this wave has read its check's T values
+            if (valid) M[slot] = rr;
+            k = kn;
         }
-        if (unsat) flag[p & 1] = 1;
+        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
     // The first kSpecStart passes are judged exactly: syndrome | barrier | verdict, and only unconverged frames
-    // pay for the tanh pass and the next check update (at the operating SNRs most frames stop within a few
-    // iterations, so nothing is computed in vain). From then on a frame is likely to run long and the verdict
-    // moves behind the barrier that follows the NEXT check update: a wave's check update reads only T values its
-    // own lanes wrote, so it can start at once; on convergence the speculative update is dropped (it never
-    // touches the posteriors). That saves one barrier per iteration where iterations are many.
+    // pay for the next tanh + check update (at the operating SNRs most frames stop within a few iterations, so
+    // nothing is computed in vain). From then on a frame is likely to run long and the syndrome rides along with
+    // the next check-node pass (which reads the same posteriors); its verdict is read behind the barrier that
+    // follows. On convergence that speculative pass is simply dropped: it never touches the posteriors.
+    // That saves one barrier and one sweep over the edges per iteration where iterations are many.
     constexpr int kSpecStart = 8;
     int iteration = 0;
     syndrome_pass(0);                                   // initial syndrome (ldpc_decoder_SPA.cc:62-76)
     __syncthreads();
     if (flag[0]) {
-        tanh_pass(true);
         for (int it = 1;; ++it) {
-            const bool past_end = it > T.max_iters;     // only reachable in speculative mode
-            if (!past_end) {
-                // check update (:129-160), in place
-#pragma unroll 1
-                for (int r = 0; r < NE; ++r) {
-                    const uint32_t k = pk.get(r);
-                    const int deg = (k >> 13) & 0x3f;
-                    const bool valid = deg != 0;
-                    double rr = 0.0;
-                    if (valid) {
-                        // the other deg-1 values of the check in slot order: step j reads slot j, or j+1 once the lane's own
-                        // slot has been passed (the loop counter is wave-uniform, so the skip is one compare + add-with-carry)
-                        const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs, degm1 = deg - 1;
-                        double temp = 1;
-                        int j = 0;
-                        for (; j + 2 <= degm1; j += 2) {       // two reads in flight per LDS round trip; same multiplication order
-                            const double a = M[cs + j + (j >= pos ? 1 : 0)], b = M[cs + j + 1 + (j + 1 >= pos ? 1 : 0)];
-                            temp *= a;
-                            temp *= b;
-                        }
-                        if (j < degm1) temp *= M[cs + j + (j >= pos ? 1 : 0)];
-                        if (temp == 1) temp = 0.9999999;
-                        if (temp == -1) temp = -0.9999999;
-                        rr = 2 * spa_atanh(temp);
-                    }
-                    __builtin_amdgcn_wave_barrier();   // every lane of this wave has read its check's T values
-                    if (valid) M[tid + r * LDPC_THREADS] = rr;
-                }
-            }
+            const bool spec = it - 1 >= kSpecStart;     // this pass carries the syndrome of pass it-1
+            if (it <= T.max_iters) cn_pass(spec, it - 1);
+            else syndrome_pass(it - 1);                 // only reachable with spec: the last verdict is still open
+            const uint32_t* vinfo = T.vinfo;
+            asm volatile("" : "+s"(vinfo));             // a fresh fetch per iteration, not 12 registers kept (and spilled) across the loop
+            const VarRec va = load_var(vinfo, tid), vb = load_var(vinfo, tid + LDPC_THREADS);
             __syncthreads();
-            if (it - 1 >= kSpecStart) {                 // deferred verdict of pass it-1
+            if (spec) {
                 if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
-                if (past_end) { iteration = T.max_iters + 1; break; }
+                if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
             }
             if (tid == 0) flag[it & 1] = 0;
             // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count;
-            // each lane owns variables tid and tid+1024 of that order, their records live in registers
+            // each lane owns variables tid and tid+1024 of that order
             var_update(va);
             if (tid + LDPC_THREADS < N) var_update(vb);
             __syncthreads();
@@ -274,9 +265,6 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
                 __syncthreads();
                 if (!flag[it & 1]) { iteration = it; break; }
                 if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
-                tanh_pass(false);
-            } else {
-                fused_pass(it);
             }
         }
     }
@@ -375,6 +363,17 @@ extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_gbf_kernel(
 // iteration. Check update per edge: sign = product of the other edges' signs, magnitude = alpha *
 // min of the other edges' |Q| (each lane scans its check's <= 46 slots, all lanes of a check read
 // the same LDS word per step = broadcast).
+// Up to eight slot descriptors per lane held in named registers; get(r) selects by the wave-uniform round number.
+struct SlotRegs {
+    uint32_t k0, k1, k2, k3, k4, k5, k6, k7;
+    __device__ __forceinline__ uint32_t get(int r) const {
+        uint32_t v = k0;
+        v = (r == 1) ? k1 : v; v = (r == 2) ? k2 : v; v = (r == 3) ? k3 : v; v = (r == 4) ? k4 : v;
+        v = (r == 5) ? k5 : v; v = (r == 6) ? k6 : v; v = (r == 7) ? k7 : v;
+        return v;
+    }
+};
+
 extern "C" size_t mgpu_minsum_lds_bytes(int S, int N) {
     return size_t(4) * S + size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64;
 }
@@ -409,7 +408,7 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
     struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
     auto load_var = [&](int i) -> VarRec {
         if (i >= N) return VarRec{0, 0, 0, 0, 0, 0};
-        const uint32_t* rec = T.vinfo + size_t(i) * 6;
+        const uint32_t* rec = T.vinfo + size_t(i) * 8;
         return VarRec{rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]};
     };
     const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);

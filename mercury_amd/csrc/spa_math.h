@@ -11,22 +11,30 @@
 // (Sun Microsystems 1993, "Developed at SunPro ... Permission to use, copy, modify, and distribute
 // this software is freely granted, provided that this notice is preserved.") with FMA contraction
 // disabled gives identical bits on any IEEE machine. tests/test_spa_math.py checks this header
-// (compiled for the host) against the host libm on millions of arguments, including every branch,
-// and tests/test_gpu_parity.py::test_spa_math_on_device does the same for the device build.
+// (compiled for the host) against the host libm on millions of arguments, including every branch
+// boundary, and tests/test_gpu_parity.py::test_spa_math_on_device does the same for the device build.
 //
-// GPU shaping: the textbook routines are a tree of data-dependent branches; inside a 64-lane
-// wavefront neighbouring edges take different branches almost always, so every branch body would
-// be executed. The functions below perform, per lane, exactly the floating-point operations of
-// the branch that lane's argument selects, but share everything the branches have in common
-// (one expm1 body per tanh, one division per tanh beyond it, one log1p body per atanh) and pick
-// operands/results with selects. Each select only chooses between values the original would have
-// computed with the same operations, so results stay bit-identical. Branches the decoder's
-// argument ranges cannot reach are dropped (stated at each function).
-//
-// Division: IEEE-correct a/b on gfx950 is v_div_scale x2 + v_rcp + Newton/residual FMAs +
-// v_div_fmas + v_div_fixup. Scaling and fix-up only act on denormal/huge/non-finite operands; every
-// division below has operands in a stated normal range, so spa_div keeps the correctly-rounding core
-// (rcp, two Newton steps, quotient, residual, final FMA) and drops the three guard instructions.
+// GPU shaping (round 2; measured costs in profiles/r02_valu_cycles.json: an fp64 add/mul/fma issues
+// in 4 cycles, v_rcp_f64 in 16, a 64-bit select is 2 x v_cndmask + a compare = 8..12):
+//  * The decoder's call sites are tanh(0.5*Q) and 2*atanh(T): spa_tanh_half(Q) uses |Q| = 2|x| directly
+//    (the doubling and halving are exact) and spa_atanh_x2 returns +-log1p(..) (0.5*l*2 == l exactly).
+//  * expm1's argument is +-2|x|; everything up to the polynomial is odd in that sign, so the reduction
+//    (k, hi, lo, r, c) is done once for |a| and the sign is put back with two XORs on high words.
+//  * k comes from the general formula int(invln2*a +- 0.5) in both of fdlibm's explicit k = +-1 and
+//    k = 0 regions; only the sliver between 0.5*ln2 and the high-word threshold 0x3fd62e42ffffffff
+//    needs the k = 0 override (checked exhaustively around the thresholds by the host test).
+//  * Where fdlibm's branches compute DIFFERENT things from the shared intermediate values (expm1's
+//    k = 0 / -1 / <= -2 / 2..19 / 20..56 / > 56 endings, log1p's direct / normalised forms) each class is
+//    a real divergent branch: a lane executes exactly its own class's operations and writes its result
+//    under the execution mask, which costs scalar instructions only, instead of every lane computing
+//    every ending and choosing with 64-bit selects. Classes no lane of the wavefront is in are skipped.
+//    SPA_KEEP stops the compiler from converting those bodies back into selects.
+//  * Division: IEEE-correct a/b on gfx950 is v_div_scale x2 + v_rcp + 2 Newton steps + quotient +
+//    residual + v_div_fmas + v_div_fixup. Scaling and fix-up only act on denormal/huge/non-finite
+//    operands; every division here has operands in a stated normal range, so spa_div keeps the
+//    correctly-rounding core, with the two Newton steps (4 FMAs, error e^4) replaced by one cubic step
+//    r(1 + e + e^2) (3 FMAs, error e^3 = 2^-66 from the >= 22-bit seed): rcp, 3 FMAs, quotient, residual,
+//    final FMA. Checked against the host's division on 10^8 operand pairs per range on the device.
 //
 // Build note: the including TU must be compiled with -ffp-contract=off.
 #pragma once
@@ -37,12 +45,14 @@
 #define SPA_BITS_HI(x) uint32_t(__double2hiint(x))
 #define SPA_MAKE(hi, lo) __hiloint2double(int(hi), int(lo))
 #define SPA_LO(x) uint32_t(__double2loint(x))
-SPA_FN double spa_div(double n, double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(e, r, r);
-    e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(e, r, r);
+#define SPA_KEEP(x) asm volatile("" : "+v"(x))
+SPA_FN double spa_recip(double d) {          // 1/d to within an ulp, d normal
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r, 1.0);
+    const double p = __builtin_fma(e, e, e);
+    return __builtin_fma(r, p, r);
+}
+SPA_FN double spa_div_r(double n, double d, double r) {   // correctly rounded n/d given r = spa_recip(d)
     const double q = n * r;
     const double rem = __builtin_fma(-d, q, n);
     return __builtin_fma(rem, r, q);
@@ -56,128 +66,162 @@ static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_
 #define SPA_BITS_HI(x) spa_bits_hi_(x)
 #define SPA_LO(x) spa_bits_lo_(x)
 #define SPA_MAKE(hi, lo) spa_make_(hi, lo)
-SPA_FN double spa_div(double n, double d) { return n / d; }
+#define SPA_KEEP(x) (void)(x)
+SPA_FN double spa_recip(double d) { return d; }
+SPA_FN double spa_div_r(double n, double d, double) { return n / d; }
 #endif
 
-SPA_FN double spa_set_high(double x, uint32_t hi) { return SPA_MAKE(hi, SPA_LO(x)); }
+#if defined(__HIPCC__) || defined(__HIP__)
+SPA_FN double spa_fabs(double x) { return __builtin_fabs(x); }     // a source modifier, no instruction
+#else
 SPA_FN double spa_fabs(double x) { return SPA_MAKE(SPA_BITS_HI(x) & 0x7fffffffu, SPA_LO(x)); }
-SPA_FN double spa_add_exponent(double y, int32_t k) { return spa_set_high(y, SPA_BITS_HI(y) + (uint32_t(k) << 20)); }
+#endif
+SPA_FN double spa_div(double n, double d) { return spa_div_r(n, d, spa_recip(d)); }
 
-// tanh(x) for any finite x (s_tanh.c + s_expm1.c).
-// expm1 is only ever evaluated at -2|x| in [-2, -2^-54] (|x| < 1) or at 2|x| in [2, 44) (1 <= |x| < 22),
-// so of s_expm1.c's cases k = 0, k = -1, k <= -2, 2 <= k < 20, 20 <= k <= 56 and k > 56 remain
-// (k = +1, the |x| < 2^-54 shortcut and the x <= -56 ln2 shortcut cannot occur).
-SPA_FN double spa_tanh(double x) {
-    const double one = 1.0, two = 2.0;
+// tanh(0.5 * q)
+SPA_FN double spa_tanh_half(double q) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00;
     const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
                  Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
                  Q5 = -2.01099218183624371326e-07;
-    const uint32_t jx = SPA_BITS_HI(x);
-    const uint32_t ix = jx & 0x7fffffffu;
-    const double ax = spa_fabs(x);
-    const bool big = ix >= 0x3ff00000u;                      // |x| >= 1
-    // ---- t = expm1(big ? 2|x| : -2|x|) -------------------------------------------------------
-    double a = two * ax;                                     // exact
-    a = big ? a : -a;
-    const uint32_t ha = SPA_BITS_HI(a) & 0x7fffffffu;
-    const bool kzero = !(ha > 0x3fd62e42u);                  // |a| <= 0.5 ln2
-    const bool kone = !kzero && (ha < 0x3FF0A2B2u);          // 0.5 ln2 < |a| < 1.5 ln2 (only reached with a < 0)
-    int32_t k = int32_t(invln2 * a + (big ? 0.5 : -0.5));
-    k = kone ? -1 : k;
-    k = kzero ? 0 : k;
-    const double tk = double(k);
-    const double hi = a - tk * ln2_hi;                       // exact products for k = 0, -1
+    const uint32_t jq = SPA_BITS_HI(q), iq = jq & 0x7fffffffu;
+    const double A = spa_fabs(q);                      // = 2|x| (exact for |x| >= 2^-55)
+    const bool big = iq >= 0x40000000u;                      // |x| >= 1
+    int32_t kk = int32_t(invln2 * A + 0.5);
+    kk = (iq <= 0x3fd62e42u) ? 0 : kk;
+    const double tk = double(kk);
+    const double hi = A - tk * ln2_hi;
     const double lo = tk * ln2_lo;
-    const double r = hi - lo;
-    const double c = (hi - r) - lo;                          // 0 when k == 0
+    const double rp = hi - lo;
+    const double cp = (hi - rp) - lo;
+    const uint32_t sm = big ? 0u : 0x80000000u;
+    const double r = SPA_MAKE(SPA_BITS_HI(rp) ^ sm, SPA_LO(rp));
+    const double c = SPA_MAKE(SPA_BITS_HI(cp) ^ sm, SPA_LO(cp));
     const double hfx = 0.5 * r;
     const double hxs = r * hfx;
-    const double R1 = one + hxs * Q1, h2 = hxs * hxs;
+    const double R1 = 1.0 + hxs * Q1, h2 = hxs * hxs;
     const double R2 = Q2 + hxs * Q3, h4 = h2 * h2;
     const double R3 = Q4 + hxs * Q5;
     const double r1 = R1 + h2 * R2 + h4 * R3;
     const double tt = 3.0 - r1 * hfx;
-    double e = hxs * spa_div(r1 - tt, 6.0 - r * tt);         // denominator in [5, 7]
-    const double res0 = r - (r * e - hxs);                   // k == 0
-    e = (r * (e - c) - c);
-    e -= hxs;
-    const double resm1 = 0.5 * (r - e) - 0.5;                // k == -1
-    const double emx = e - r;
-    const double ya = spa_add_exponent(one - emx, k) - one;                              // k <= -2 || k > 56
-    const double tb = SPA_MAKE(0x3ff00000u - (0x200000u >> (uint32_t(k) & 31u)), 0u);   // 1 - 2^-k, 2 <= k < 20
-    const double yb = spa_add_exponent(tb - emx, k);
-    double t = (k <= -2) ? ya : yb;
-    t = (k == -1) ? resm1 : t;
-    t = (k == 0) ? res0 : t;
-    if (k >= 20) {                       // |x| > 6.7: rare at the SNRs where the decoder iterates; a real branch
-        const double tc = SPA_MAKE(uint32_t(0x3ff - k) << 20, 0u);                       // 2^-k, 20 <= k <= 56
-        const double yc = spa_add_exponent((r - (e + tc)) + one, k);
-        t = (k > 56) ? ya : yc;
+    const double den = 6.0 - r * tt;
+    const double e0 = hxs * spa_div_r(r1 - tt, den, spa_recip(den));
+    double t;
+    if (kk == 0) {
+        t = r - (r * e0 - hxs);
+        SPA_KEEP(t);
+    } else {
+        double e = (r * (e0 - c) - c);
+        e -= hxs;
+        if (big) {
+            if (kk < 20) {
+                const double tb = SPA_MAKE(0x3ff00000u - (0x200000u >> uint32_t(kk)), 0u);
+                const double y = tb - (e - r);
+                t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y));
+            } else if (kk <= 56) {
+                const double tc = SPA_MAKE(uint32_t(0x3ff - kk) << 20, 0u);
+                const double y = (r - (e + tc)) + 1.0;
+                t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y));
+            } else {
+                const double y = 1.0 - (e - r);
+                t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y)) - 1.0;
+            }
+            SPA_KEEP(t);
+        } else if (kk == 1) {
+            t = 0.5 * (r - e) - 0.5;
+            SPA_KEEP(t);
+        } else {
+            const double y = 1.0 - (e - r);
+            t = SPA_MAKE(SPA_BITS_HI(y) - (uint32_t(kk) << 20), SPA_LO(y)) - 1.0;
+            SPA_KEEP(t);
+        }
     }
-    // ---- tanh from t -------------------------------------------------------------------------
-    const double q = spa_div(big ? two : -t, t + two);       // denominator in [1, 2^64]
-    double z = big ? one - q : q;
-    z = (ix >= 0x40360000u) ? one : z;                       // |x| >= 22: one - tiny
-    const double res = (jx >> 31) ? -z : z;
-    // |x| < 2^-55 (incl. +-0): x*(one+x) == x ; non-finite arguments never reach the decoder
-    return (ix < 0x3c800000u) ? x : res;
+    const double d2 = t + 2.0;
+    const double rr = spa_recip(d2);
+    const double num = SPA_MAKE(big ? 0x40000000u : (SPA_BITS_HI(t) ^ 0x80000000u), big ? 0u : SPA_LO(t));
+    const double qq = spa_div_r(num, d2, rr);
+    double z = big ? 1.0 - qq : qq;
+    uint32_t zh = SPA_BITS_HI(z) | (jq & 0x80000000u);
+    double res = SPA_MAKE(zh, SPA_LO(z));
+    if (__builtin_expect(iq < 0x3c900000u || iq >= 0x40460000u, 0)) {
+        const double one = SPA_MAKE(0x3ff00000u | (jq & 0x80000000u), 0u);
+        res = (iq >= 0x40460000u) ? one : 0.5 * q;
+    }
+    return res;
 }
 
-// atanh(x) for |x| < 1 (e_atanh.c + s_log1p.c; the decoder clamps +-1 to +-0.9999999 first).
-// log1p is only ever evaluated at y = 2|x|/(1-|x|)-type arguments with 2^-27 <= y <= 2e7, so of
-// s_log1p.c's cases the y <= -0.2929, |y| < 2^-29 and y >= 2^53 ones cannot occur.
-SPA_FN double spa_atanh(double x) {
+// 2 * atanh(x) for |x| <= 1, with the decoder's clamp of +-1 to +-0.9999999 (ldpc_decoder_SPA.cc:150-156)
+SPA_FN double spa_atanh_x2(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                  Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
                  Lp7 = 1.479819860511658591e-01;
-    const double xa = spa_fabs(x);
+    const uint32_t jx = SPA_BITS_HI(x);
+    double xa = spa_fabs(x);
+    if (__builtin_expect(xa == 1.0, 0)) { xa = 0.9999999; SPA_KEEP(xa); }
     const bool small = xa < 0.5;
     const double t2 = xa + xa;
-    const double q = spa_div(small ? t2 * xa : t2, 1.0 - xa);    // denominator in [1e-7, 1]
-    const double y = small ? t2 + q : q;
-    // ---- log1p(y), y > 0 ----------------------------------------------------------------------
-    const int32_t hy = int32_t(SPA_BITS_HI(y));
-    const bool direct = hy < 0x3FDA827A;                     // y < 0.41422: f = y, k = 0
-    double u = 1.0 + y;
-    int32_t hu = int32_t(SPA_BITS_HI(u));
-    int32_t k = (hu >> 20) - 1023;
-    double c = (k > 0) ? 1.0 - (u - y) : y - (u - 1.0);
-    c = spa_div(c, u);                                       // u in [1, 2e7]; |c| <= 2^-53 or 0
-    hu &= 0x000fffff;
-    const bool lowhalf = hu < 0x6a09e;
-    u = spa_set_high(u, uint32_t(hu) | (lowhalf ? 0x3ff00000u : 0x3fe00000u));
-    k = lowhalf ? k : k + 1;
-    hu = lowhalf ? hu : (0x00100000 - hu) >> 2;
-    double f = u - 1.0;
-    f = direct ? y : f;
-    k = direct ? 0 : k;
-    c = direct ? 0.0 : c;
-    hu = direct ? 1 : hu;
-    const double dk = double(k);
-    const double hfsq = 0.5 * f * f;
-    double l;
-    if (hu == 0) {                       // |f| < 2^-20: rare, short
-        if (f == 0.0) {
-            l = (k == 0) ? 0.0 : dk * ln2_hi + (c + dk * ln2_lo);
-        } else {
-            const double R = hfsq * (1.0 - 0.66666666666666666 * f);
-            l = (k == 0) ? f - R : dk * ln2_hi - ((R - (dk * ln2_lo + c)) - f);
-        }
+    const double d1 = 1.0 - xa;
+    const double r1 = spa_recip(d1);
+    const double n1 = small ? t2 * xa : t2;
+    const double q1 = spa_div_r(n1, d1, r1);
+    const double y = small ? t2 + q1 : q1;
+    // log1p(y)
+    double f, l;
+    const bool direct = int32_t(SPA_BITS_HI(y)) < 0x3FDA827A;
+    if (direct) {
+        f = y;
+        SPA_KEEP(f);
     } else {
-        const double s = spa_div(f, 2.0 + f);                // denominator in [1.7, 2.42]
-        const double z = s * s;
-        const double R1 = z * Lp1, z2 = z * z;
-        const double R2 = Lp2 + z * Lp3, z4 = z2 * z2;
-        const double R3 = Lp4 + z * Lp5, z6 = z4 * z2;
-        const double R4 = Lp6 + z * Lp7;
-        const double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
-        const double sr = s * (hfsq + R);
-        l = (k == 0) ? f - (hfsq - sr) : dk * ln2_hi - ((hfsq - (sr + (dk * ln2_lo + c))) - f);
+        double u = 1.0 + y;
+        uint32_t hu = SPA_BITS_HI(u) & 0x000fffffu;
+        const bool lowhalf = hu < 0x6a09eu;
+        u = SPA_MAKE(hu | (lowhalf ? 0x3ff00000u : 0x3fe00000u), SPA_LO(u));
+        f = u - 1.0;
+        SPA_KEEP(f);
     }
-    double t = 0.5 * l;
-    t = (SPA_BITS_HI(x) >> 31) ? -t : t;
-    return (xa < 0x1.0p-28) ? x : t;
+    const double hfsq = 0.5 * f * f;
+    const double d3 = 2.0 + f;
+    const double s = spa_div_r(f, d3, spa_recip(d3));
+    const double z = s * s;
+    const double R1 = z * Lp1, z2 = z * z;
+    const double R2 = Lp2 + z * Lp3, z4 = z2 * z2;
+    const double R3 = Lp4 + z * Lp5, z6 = z4 * z2;
+    const double R4 = Lp6 + z * Lp7;
+    const double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
+    const double sr = s * (hfsq + R);
+    if (direct) {
+        l = f - (hfsq - sr);
+        SPA_KEEP(l);
+    } else {
+        const double u = 1.0 + y;
+        const int32_t hu0 = int32_t(SPA_BITS_HI(u));
+        int32_t k = (hu0 >> 20) - 1023;
+        double c = (k > 0) ? 1.0 - (u - y) : y - (u - 1.0);
+        c = spa_div_r(c, u, spa_recip(u));
+        const uint32_t hu = uint32_t(hu0) & 0x000fffffu;
+        const bool lowhalf = hu < 0x6a09eu;
+        k = lowhalf ? k : k + 1;
+        const double dk = double(k);
+        const uint32_t hz = lowhalf ? hu : (0x00100000u - hu) >> 2;
+        if (__builtin_expect(hz == 0, 0)) {
+            if (f == 0.0) {
+                l = dk * ln2_hi + (c + dk * ln2_lo);
+            } else {
+                const double Rz = hfsq * (1.0 - 0.66666666666666666 * f);
+                l = dk * ln2_hi - ((Rz - (dk * ln2_lo + c)) - f);
+            }
+        } else {
+            l = dk * ln2_hi - ((hfsq - (sr + (dk * ln2_lo + c))) - f);
+        }
+        SPA_KEEP(l);
+    }
+    double res = SPA_MAKE(SPA_BITS_HI(l) ^ (jx & 0x80000000u), SPA_LO(l));     // 2 * (+-0.5 * l)
+    if (__builtin_expect(xa < 0x1.0p-28, 0)) res = x + x;
+    return res;
 }
+
+// the plain forms (tests, probes): tanh(x) = tanh(0.5 * 2x), atanh(x) = 0.5 * (2 atanh(x)); both scalings are exact
+SPA_FN double spa_tanh(double x) { return spa_tanh_half(x + x); }
+SPA_FN double spa_atanh(double x) { return 0.5 * spa_atanh_x2(x); }

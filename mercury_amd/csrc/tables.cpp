@@ -169,6 +169,8 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         if (g.S >= 8192) throw std::runtime_error("padded edge count exceeds the 13-bit slot field");
         g.spack.assign(g.S, 0u);
         g.svar.assign(g.S, 0);
+        g.sdesc.assign(size_t((g.S + 1023) / 1024) * 1024, 0u);
+        g.bin_end.assign(size_t((g.S + 1023) / 1024) * 16, 0ull);
         std::vector<uint32_t> slot_of_edge(E);
         for (size_t b = 0; b < members.size(); ++b) {
             uint32_t p = uint32_t(b) * 64;
@@ -178,6 +180,8 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
                     const uint32_t eo = g.cptr[c] + j;
                     g.spack[p] = cs | (d << 13) | (j << 19) | 0x80000000u;
                     g.svar[p] = g.cvar[eo];
+                    g.sdesc[p] = cs | (d << 13) | (uint32_t(g.cvar[eo]) << 19);
+                    if (j + 1 == d) g.bin_end[p >> 6] |= 1ull << (p & 63);
                     slot_of_edge[eo] = p;
                 }
             }
@@ -186,14 +190,14 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         std::vector<uint32_t> vorder(N);
         for (uint32_t v = 0; v < N; ++v) vorder[v] = v;
         std::stable_sort(vorder.begin(), vorder.end(), [&](uint32_t a, uint32_t b) { return vdeg[a] > vdeg[b]; });
-        g.vinfo.assign(size_t(N) * 6, 0u);   // per variable: v | deg<<11, then 10 u16 slot indices in 5 words
+        g.vinfo.assign(size_t(N) * 8, 0u);   // per variable: v | deg<<11, then 10 u16 slot indices in 5 words; rows of 8 words (16-byte aligned)
         for (uint32_t i = 0; i < N; ++i) {
             const uint32_t v = vorder[i], d = vdeg[v];
             if (d > 9) throw std::runtime_error("variable degree exceeds the unrolled update");
-            g.vinfo[size_t(i) * 6] = v | (d << 11);
+            g.vinfo[size_t(i) * 8] = v | (d << 11);
             for (uint32_t j = 0; j < d; ++j) {
                 const uint32_t slot = slot_of_edge[g.vedge[g.vptr[v] + j]];
-                g.vinfo[size_t(i) * 6 + 1 + j / 2] |= slot << (16 * (j & 1));
+                g.vinfo[size_t(i) * 8 + 1 + j / 2] |= slot << (16 * (j & 1));
             }
         }
         return g;
