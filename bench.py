@@ -34,7 +34,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from mercury_amd import DEC_GBF, DEC_MINSUM, DEC_SPA, RxPhy
+from mercury_amd import DEC_GBF, DEC_MINSUM, DEC_SPA, DEC_SPA_FAST, RxPhy
+
+DECODERS = {"spa": DEC_SPA, "minsum": DEC_MINSUM, "gbf": DEC_GBF, "spa_fast": DEC_SPA_FAST}
 from mercury_amd.sharding import frame_range
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
@@ -137,20 +139,21 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
         ok = float(stats[:, 3].sum().item()) / F
         return {"frames_per_s": F * steps / dt, "frontend_ms": fe, "ldpc_ms": dec, "avg_iters": it, "decoded_fraction": ok}
 
-    other = "minsum" if args.decoder == "spa" else "spa"
     agc, vs = (1, 1) if args.variant == "receive_byte" else (0, 0)
-    rx2 = RxPhy(args.cfg, max_iters=args.iters, decoder={"spa": DEC_SPA, "minsum": DEC_MINSUM}[other], agc=agc, variance_source=vs,
-                device=dev.index, max_batch=F)
-    m = timed(rx2, bufs)
-    ldpc_bytes, _, _ = algorithmic_bytes(rx2, m["avg_iters"] * F, F)
-    m["roofline_frac_algorithmic"] = ldpc_bytes / (m["ldpc_ms"] * 1e-3) / HBM_PEAK
-    out["same_inputs_decoder_" + other] = m
+    others = {}
+    for other in [d for d in ("spa", "spa_fast", "minsum") if d != args.decoder]:
+        rx2 = RxPhy(args.cfg, max_iters=args.iters, decoder=DECODERS[other], agc=agc, variance_source=vs, device=dev.index, max_batch=F)
+        m = timed(rx2, bufs)
+        ldpc_bytes, _, _ = algorithmic_bytes(rx2, m["avg_iters"] * F, F)
+        m["roofline_frac_algorithmic"] = ldpc_bytes / (m["ldpc_ms"] * 1e-3) / HBM_PEAK
+        out["same_inputs_decoder_" + other] = m
+        others[other] = rx2
     op = OPERATING_ESN0[args.cfg] + 1.0
     amp = float(10.0 ** (-op / 20.0) / np.sqrt(2.0))
     bb = torch.empty((F, rx.frame_samples, 2), dtype=torch.float64, device=dev)
     rx.txgen_dev(SEED, 1 << 40, F, amp, bb.data_ptr(), None, channel=args.channel, stream=stream)
     torch.cuda.synchronize()
-    for name, phy in ((args.decoder, rx), (other, rx2)):
+    for name, phy in [(args.decoder, rx)] + list(others.items()):
         r = timed(phy, [bb])
         r["esn0_db"] = op
         out["operating_point_decoder_" + name] = r
@@ -164,7 +167,8 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
             rx.receive(one)
             lat.append((time.perf_counter() - t0) * 1e3)
         out["single_frame_latency_ms_" + name] = float(np.median(lat[2:]))
-    rx2.close()
+    for phy in others.values():
+        phy.close()
     return out
 
 
@@ -177,7 +181,7 @@ def main():
     ap.add_argument("--frames", type=int, default=4096, help="frames per step per GPU")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--esn0", type=float, default=-15.0)
-    ap.add_argument("--decoder", choices=["spa", "minsum", "gbf"], default="spa")
+    ap.add_argument("--decoder", choices=["spa", "minsum", "gbf", "spa_fast"], default="spa")
     ap.add_argument("--variant", choices=["receive_byte", "baseband_test"], default="receive_byte")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-per-core", type=int, default=160)
@@ -207,7 +211,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     rdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the reduction tensors live
 
-    decoder = {"spa": DEC_SPA, "minsum": DEC_MINSUM, "gbf": DEC_GBF}[args.decoder]
+    decoder = DECODERS[args.decoder]
     agc, vs = (1, 1) if args.variant == "receive_byte" else (0, 0)
     F = args.frames
     rx = RxPhy(args.cfg, max_iters=args.iters, decoder=decoder, agc=agc, variance_source=vs,

@@ -53,6 +53,7 @@ extern "C" {
 #define MGPU_DEC_GBF 0        /* gradient bit flipping, ldpc_decoder_GBF.cc:25-117 */
 #define MGPU_DEC_SPA 1        /* sum-product, double messages, ldpc_decoder_SPA.cc:25-218 (reference default) */
 #define MGPU_DEC_MINSUM 2     /* normalised min-sum, fp32 (not in the reference; fast variant) */
+#define MGPU_DEC_SPA_FAST 3   /* sum-product in fp32 with hardware exp/log (not the reference's arithmetic; the fast variant for every mode) */
 
 #define MGPU_EST_ZF 0
 #define MGPU_EST_LS 1

@@ -5,10 +5,10 @@ declared in ``include/mercury_gpu.h``), ``data/`` (the LDPC graphs as compact de
 ``physical_layer.py`` (a ctypes loader mirroring the reference's physical_layer surface), ``shm.py`` (the
 shared-memory ring decoded payloads are published through, ``include/mercury_shm.h``).
 """
-from .physical_layer import (DEC_GBF, DEC_MINSUM, DEC_SPA, EXPORTED_SYMBOLS, LIB_PATH, MgpuError, RxPhy,
+from .physical_layer import (DEC_GBF, DEC_MINSUM, DEC_SPA, DEC_SPA_FAST, EXPORTED_SYMBOLS, LIB_PATH, MgpuError, RxPhy,
                              STATS_DTYPE, load_library)
 
 from .shm import ShmRing  # noqa: E402
 
-__all__ = ["ShmRing", "RxPhy", "MgpuError", "DEC_GBF", "DEC_SPA", "DEC_MINSUM", "STATS_DTYPE", "load_library",
+__all__ = ["ShmRing", "RxPhy", "MgpuError", "DEC_GBF", "DEC_SPA", "DEC_MINSUM", "DEC_SPA_FAST", "STATS_DTYPE", "load_library",
            "LIB_PATH", "EXPORTED_SYMBOLS"]

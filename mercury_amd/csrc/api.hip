@@ -125,6 +125,18 @@ void ctx_alloc(mgpu_ctx* c) {
             }
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
+        case MGPU_DEC_SPA_FAST:
+            c->lds_dec = mgpu_spa_fast_lds_bytes(d.S, d.N);
+            switch ((d.S + 1023) / 1024) {
+                case 1: case 2: case 3: case 4: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne4; break;
+                case 5: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne5; break;
+                case 6: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne6; break;
+                case 7: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne7; break;
+                case 8: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne8; break;
+                default: throw std::runtime_error("graph too large for the fp32 sum-product kernel");
+            }
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
+            break;
         default: throw std::runtime_error("unknown decoder");
     }
 }
@@ -324,7 +336,7 @@ int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
         return MGPU_ERR_ARG;
     }
     if (cfg->max_iters < 1 || cfg->max_iters > 1000) { g_create_error = "max_iters out of range"; return MGPU_ERR_ARG; }
-    if (cfg->decoder < 0 || cfg->decoder > 2) { g_create_error = "unknown decoder"; return MGPU_ERR_ARG; }
+    if (cfg->decoder < 0 || cfg->decoder > MGPU_DEC_SPA_FAST) { g_create_error = "unknown decoder"; return MGPU_ERR_ARG; }
     if (cfg->max_batch < 1) { g_create_error = "max_batch must be >= 1"; return MGPU_ERR_ARG; }
     mgpu_ctx* c = new mgpu_ctx();
     c->cfg = *cfg;

@@ -21,6 +21,7 @@ extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits);
 extern "C" size_t mgpu_spa_lds_bytes(int E, int N);
 extern "C" size_t mgpu_gbf_lds_bytes(int N);
 extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
+extern "C" size_t mgpu_spa_fast_lds_bytes(int S, int N);
 extern "C" size_t mgpu_txgen_lds_bytes(int G);
 
 extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
@@ -47,6 +48,8 @@ using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8
 extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 #define DECL_MS(NE) extern "C" __global__ void mgpu_ldpc_minsum_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_MS(4) DECL_MS(5) DECL_MS(6) DECL_MS(7) DECL_MS(8)
+#define DECL_SF(NE) extern "C" __global__ void mgpu_ldpc_spa_fast_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+DECL_SF(4) DECL_SF(5) DECL_SF(6) DECL_SF(7) DECL_SF(8)
 extern "C" __global__ void mgpu_ldpc_encode_kernel(MgpuDev, const uint8_t*, int, uint8_t*);
 extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*, const uint8_t*, int, const int*, int, int);
 

@@ -286,6 +286,178 @@ SPA_KERNEL(6)
 SPA_KERNEL(7)
 SPA_KERNEL(8)
 
+// ---------------------------------------------------------------------------------------------
+// Sum-product, single precision ("spa_fast"; BASELINE.json north_star's fast variant, SURVEY.md §7.3-1: "SPA-equivalent
+// check node in FP32"). NOT the reference's arithmetic: the same flooding schedule, the same tanh rule
+// R = 2*atanh(prod_others tanh(Q/2)) and the same iteration/early-exit convention as ldpc_decoder_SPA.cc:25-218, evaluated
+// in fp32 with the hardware's exp2/log2/rcp. Parity for this decoder is therefore defined the way the reference's own
+// alternative decoder (GBF) relates to SPA: same codeword whenever both decode, decode rate within 0.5 % of the fp64
+// decoder at the operating points of all 20 modes (tests/test_gpu_parity.py::test_spa_fast_*).
+//
+// Same skeleton as the fp64 kernel (wave-private 64-slot bins, one in-place message array, scalar prefix-XOR syndrome,
+// descriptors from the shared table, two barriers per iteration), with what fp32 allows on top:
+//   * T = tanh(Q/2) = (1 - e)/(1 + e), e = exp(-|Q|): one v_exp_f32 + one v_rcp_f32; |T| is kept inside
+//     [2^-30, 1 - 2^-24] so that a product never contains an exact zero or one;
+//   * the check product is taken over ALL edges of the check (every lane of the check reads the same LDS words = broadcast
+//     reads, no own-edge skipping logic) and the own factor is divided out again: prod_others = P / T_own (exact zero
+//     excluded above; an underflowing P means every extrinsic of that check is < 1e-30 anyway);
+//   * R = 2*atanh(p) = ln2 * log2((1 + p)/(1 - p)): one v_rcp_f32 + one v_log_f32; 1 - |p| is exact (Sterbenz) and >= 2^-24,
+//     which caps |R| at 17.3 (the fp64 decoder's own clamp of +-1 to +-0.9999999 caps it at 16.8).
+extern "C" size_t mgpu_spa_fast_lds_bytes(int S, int N) {
+    return size_t(4) * S + size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64;
+}
+
+template <int NE, int THREADS>
+__device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
+                                                uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
+                                                uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+                                                const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = T.S, N = T.N;
+    float* M = reinterpret_cast<float*>(smem);        // R or T per padded edge slot
+    float* Lt = M + S;                                // posterior per variable
+    float* Li = Lt + N;                               // channel LLR
+    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
+    uint8_t* bytes = hard + ((N + 15) & ~15);
+    int* flag = reinterpret_cast<int*>(bytes + 256);
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (f >= F) return;
+    for (int v = tid; v < N; v += THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; Lt[v] = l; }
+    for (int p = tid; p < S; p += THREADS) M[p] = 0.0f;
+    const uint32_t* __restrict__ sdesc = T.sdesc + tid;
+    const unsigned long long* __restrict__ bin_end = T.bin_end + __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    __syncthreads();
+
+    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
+        m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
+        return (m & ends) != 0;
+    };
+    auto syndrome_pass = [&](int p) {
+        bool unsat = false;
+        uint32_t k = sdesc[0];
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t kn = (r + 1 < NE) ? sdesc[(r + 1) * THREADS] : 0u;
+            const bool valid = ((k >> 13) & 0x3f) != 0;
+            float lt = 0.0f;
+            if (valid) lt = Lt[k >> 19];
+            unsat |= bin_unsat(__ballot(lt < 0), bin_end[r * (THREADS / 64)]);
+            k = kn;
+        }
+        if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
+    };
+    auto cn_pass = [&](bool with_syndrome, int p) {
+        bool unsat = false;
+        uint32_t k = sdesc[0];
+        uint32_t slot = tid;
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r, slot += THREADS) {
+            const uint32_t kn = (r + 1 < NE) ? sdesc[(r + 1) * THREADS] : 0u;
+            const uint32_t deg = (k >> 13) & 0x3f;
+            const bool valid = deg != 0;
+            float lt = 0.0f;
+            if (valid) lt = Lt[k >> 19];
+            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0), bin_end[r * (THREADS / 64)]);
+            float t = 1.0f;
+            if (valid) {
+                const float q = lt - M[slot];
+                const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * __builtin_fabsf(q));
+                float a = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+                a = __builtin_amdgcn_fmed3f(a, 0x1.0p-30f, 0x1.fffffep-1f);
+                t = __builtin_copysignf(a, q);
+                M[slot] = t;
+            }
+            __builtin_amdgcn_wave_barrier();
+            float rr = 0.0f;
+            if (valid) {
+                const uint32_t cs = k & 0x1fff;
+                float prod = 1.0f;
+                uint32_t j = 0;
+                for (; j + 2 <= deg; j += 2) {
+                    const float x = M[cs + j], y = M[cs + j + 1];
+                    prod *= x;
+                    prod *= y;
+                }
+                if (j < deg) prod *= M[cs + j];
+                const float pe = prod * __builtin_amdgcn_rcpf(t);                        // product over the other edges
+                const float pa = fminf(__builtin_fabsf(pe), 0x1.fffffep-1f);
+                const float l2 = __builtin_amdgcn_logf((1.0f + pa) * __builtin_amdgcn_rcpf(1.0f - pa));
+                rr = __builtin_copysignf(0.693147180559945309f * l2, pe);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (valid) M[slot] = rr;
+            k = kn;
+        }
+        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
+    };
+    struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
+    auto load_var = [&](const uint32_t* vinfo, int i) -> VarRec {
+        const uint4 lo = *reinterpret_cast<const uint4*>(vinfo + size_t(i) * 8);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vinfo + size_t(i) * 8 + 4);
+        return VarRec{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+    };
+    auto var_update = [&](const VarRec& q) {
+        const uint32_t v = q.vi & 0x7ff, deg = q.vi >> 11;
+        float s = Li[v];
+        const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
+        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
+        if (deg > 2) {      // rows sorted by degree: wavefronts of degree-2 parity bits skip the rest
+            const float m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
+            s += m2;
+            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+        }
+        if (deg > 5) {
+            const float m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
+            s += m5;
+            s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
+        }
+        Lt[v] = s;
+    };
+    constexpr int kSpecStart = 8;
+    int iteration = 0;
+    syndrome_pass(0);
+    __syncthreads();
+    if (flag[0]) {
+        for (int it = 1;; ++it) {
+            const bool spec = it - 1 >= kSpecStart;
+            if (it <= T.max_iters) cn_pass(spec, it - 1);
+            else syndrome_pass(it - 1);
+            __syncthreads();
+            if (spec) {
+                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
+                if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
+            }
+            if (tid == 0) flag[it & 1] = 0;
+            for (int i = tid; i < N; i += THREADS) var_update(load_var(T.vinfo, i));
+            __syncthreads();
+            if (it < kSpecStart) {
+                syndrome_pass(it);
+                __syncthreads();
+                if (!flag[it & 1]) { iteration = it; break; }
+                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
+            }
+        }
+    }
+    for (int v = tid; v < N; v += THREADS) hard[v] = Lt[v] < 0;
+    __syncthreads();
+    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}
+
+#define SPA_FAST_KERNEL(NE)                                                                                        \
+    extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_spa_fast_kernel_ne##NE(                   \
+        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                        \
+        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,      \
+        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                        \
+        spa_fast_decode<NE, LDPC_THREADS>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in,  \
+                                          snr_variance_in);                                                         \
+    }
+SPA_FAST_KERNEL(4)
+SPA_FAST_KERNEL(5)
+SPA_FAST_KERNEL(6)
+SPA_FAST_KERNEL(7)
+SPA_FAST_KERNEL(8)
+
 // device probe of spa_math.h for tests: out_t[i] = tanh(in[i]); out_a[i] = atanh(in[i]) for |in[i]| < 1 else 0
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double* __restrict__ in, double* __restrict__ out_t,
                                                       double* __restrict__ out_a, int n) {

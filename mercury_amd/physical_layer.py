@@ -18,7 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmercury_gpu.so")
 
-DEC_GBF, DEC_SPA, DEC_MINSUM = 0, 1, 2
+DEC_GBF, DEC_SPA, DEC_MINSUM, DEC_SPA_FAST = 0, 1, 2, 3
 EST_ZF, EST_LS = 0, 1
 
 

@@ -141,6 +141,63 @@ def test_minsum_agrees_where_both_converge(cfg):
     assert both >= len(snrs) // 2
 
 
+@pytest.mark.parametrize("cfg", list(range(17)))
+def test_spa_fast_agrees_with_oracle_where_both_converge(cfg):
+    """The fp32 sum-product decoder (MGPU_DEC_SPA_FAST) is not the reference's arithmetic: its parity is defined like the
+    min-sum decoder's, on frames both it and the reference decoder converge on (a converged word is a codeword), and it
+    must converge on at least as many of them as the reference decoder minus one frame in 16."""
+    from mercury_amd import DEC_SPA_FAST
+    orc = Oracle(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    snrs = [op + 1.0] * 12 + [op - 1.0] * 4
+    bb, payloads = _frames(orc, snrs, seed=23)
+    variant = _variants(cfg)[0]
+    rx = _rx(cfg, decoder=DEC_SPA_FAST, agc=variant[0], variance_source=variant[1], max_batch=len(snrs))
+    out = rx.receive(bb)
+    both = ref_ok = 0
+    for f in range(len(snrs)):
+        ref = orc.rx(bb[f], variant[2])
+        ref_ok += ref["iterations"] <= 50
+        if ref["iterations"] <= 50 and out["stats"]["iterations_done"][f] <= 50:
+            both += 1
+            assert np.array_equal(out["payload"][f], ref["bytes"].astype(np.uint8)), (cfg, f)
+            assert out["stats"]["crc"][f] == ref["crc"]
+            assert abs(int(out["stats"]["iterations_done"][f]) - ref["iterations"]) <= 2
+    assert both >= ref_ok - 1 and both >= 8
+
+
+@pytest.mark.parametrize("cfg", list(range(17)) + [100, 101, 102])
+def test_spa_fast_decode_rate_matches_reference_decoder(cfg):
+    """on every mode, at its operating point and 1.5 dB below (inside the waterfall), the fp32
+    sum-product decoder decodes at least the reference decoder's fraction of frames minus 0.5 %, and every frame both
+    decode has the same payload. 2048 frames per point, generated on the device; the reference side is the bit-exact fp64
+    kernel (itself checked against the CPU oracle by the tests above)."""
+    import torch
+    from mercury_amd import DEC_SPA, DEC_SPA_FAST
+    F = 2048
+    agc, vs = (0, 0) if cfg in (15, 16) else (1, 1)
+    rx = {n: _rx(cfg, decoder=d, agc=agc, variance_source=vs, max_batch=F) for n, d in (("spa", DEC_SPA), ("fast", DEC_SPA_FAST))}
+    st = torch.cuda.current_stream().cuda_stream
+    bb = torch.empty((F, rx["spa"].frame_samples, 2), dtype=torch.float64, device="cuda")
+    for off in (0.0, -1.5):
+        amp = noise_amp_for(OPERATING_ESN0[cfg] + off)
+        rx["spa"].txgen_dev(SEED, 77 << 20, F, amp, bb.data_ptr(), None, stream=st)
+        torch.cuda.synchronize()
+        res = {}
+        for n, phy in rx.items():
+            payload = torch.zeros((F, phy.payload_stride), dtype=torch.uint8, device="cuda")
+            stats = torch.zeros((F, 6), dtype=torch.int32, device="cuda")
+            phy.receive_dev(bb.data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=st)
+            torch.cuda.synchronize()
+            res[n] = (payload.cpu().numpy(), stats.cpu().numpy())
+        ok_ref, ok_fast = res["spa"][1][:, 3] != 0, res["fast"][1][:, 3] != 0
+        assert ok_fast.mean() >= ok_ref.mean() - 0.005, (cfg, off, ok_ref.mean(), ok_fast.mean())
+        both = ok_ref & ok_fast
+        assert np.array_equal(res["spa"][0][both], res["fast"][0][both]), (cfg, off)
+    for phy in rx.values():
+        phy.close()
+
+
 def test_txgen_matches_cpu_generator_and_round_trips():
     """The on-device generator follows the same Philox streams as the oracle's: identical payload bytes,
     time-domain samples equal up to libm ulps in the Box-Muller noise; and everything it makes decodes."""
