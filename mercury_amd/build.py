@@ -17,10 +17,10 @@ LIB = os.path.join(HERE, "libmercury_gpu.so")
 TABLES = os.path.join(HERE, "data", "mercury_ldpc_tables.bin")
 
 HIP_SOURCES = ["api.hip", "rxloop.hip", "stages_api.hip", "stages.hip", "frontend.hip", "mfsk.hip", "ldpc.hip", "txgen.hip", "tx.hip", "stats.hip", "sync.hip"]
-CXX_SOURCES = ["tables.cpp", "shm_transport.cpp"]
+CXX_SOURCES = ["tables.cpp", "shm_transport.cpp", "pool.cpp"]
 HEADERS = ["device_tables.h", "tables.hpp", "spa_math.h", "fft256.h", "fe_math.h", "ctx.hpp", os.path.join(ROOT, "include", "mercury_gpu.h"),
            os.path.join(ROOT, "include", "mercury_shm.h"), os.path.join(ROOT, "include", "mercury_rxloop.h"), os.path.join(ROOT, "include", "mercury_stages.h"),
-           os.path.join(ROOT, "include", "mercury_tx.h")]
+           os.path.join(ROOT, "include", "mercury_tx.h"), os.path.join(ROOT, "include", "mercury_pool.h")]
 
 # -ffp-contract=off: the reference runs without FMA contraction (baseline x86-64); the FP64 front-end
 # and the sum-product decoder reproduce its roundings exactly, which an fma() would break.

@@ -164,7 +164,7 @@ void ensure_workspaces(mgpu_ctx* c, unsigned what) {
 
 
 void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float* d_var, float* d_snrvar,
-                     const MgpuTapsDev& taps, hipStream_t s, int frame_stride) {
+                     const MgpuTapsDev& taps, hipStream_t s, int frame_stride, int frame0) {
     const int slot = c->ev_count % mgpu_ctx::kEvRing;
     const auto& t = c->tab;
     MgpuDev dev = c->dev;                        // kernel argument; the frame stride can differ from the frame length
@@ -194,7 +194,7 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
         if (off && (taps.grid || taps.H || taps.eq || taps.syms || taps.llr_demod || taps.variance || taps.agc_gain || taps.mean_H))
             throw std::invalid_argument("stage taps are limited to 2^21 frames per call");
         hipLaunchKernelGGL(mgpu_frontend_kernel, dim3(n), dim3(512), c->lds_fe, s, dev, d_bb + size_t(off) * stride * 2, n,
-                           d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), at(c->d_eqdata, size_t(off) * t.nData * 2), taps);
+                           d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), at(c->d_eqdata, (size_t(frame0) + off) * t.nData * 2), taps);
         HIPCK(hipGetLastError());
     }
     if (c->timing) HIPCK(hipEventRecord(c->ev[slot][1], s));
@@ -290,13 +290,13 @@ int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslo
     return best * sym_period;
 }
 
-void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s) {
+void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s, int frame0) {
     const auto& t = c->tab;
     if (t.estimator != MGPU_EST_ZF || !d_payload || !d_stats) return;
     for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
         const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
         hipLaunchKernelGGL(mgpu_zf_snr_kernel, dim3(n), dim3(256), mgpu_zfsnr_lds_bytes(t.nData), s, c->dev,
-                           d_payload + size_t(off) * t.payload_stride, c->d_eqdata + size_t(off) * t.nData * 2, n, d_stats + off);
+                           d_payload + size_t(off) * t.payload_stride, c->d_eqdata + (size_t(frame0) + off) * t.nData * 2, n, d_stats + off);
         HIPCK(hipGetLastError());
     }
 }
@@ -375,6 +375,9 @@ int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
 
 void mgpu_destroy(mgpu_ctx* c) {
     if (!c) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != c->cfg.device && hipSetDevice(c->cfg.device) != hipSuccess) prev = -1;   // no device: nothing below was allocated
     for (void* p : c->owned) (void)hipFree(p);
     (void)hipFree(c->d_baseband); (void)hipFree(c->d_llr); (void)hipFree(c->d_variance); (void)hipFree(c->d_snrvar);
     (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters); (void)hipFree(c->d_eqdata);
@@ -387,6 +390,15 @@ void mgpu_destroy(mgpu_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto& q : c->ev) for (auto& e : q) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->sync_ev) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(c->d_one_in);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    for (auto& p : c->pipe) {
+        (void)hipFree(p.d_in);
+        if (p.stream) (void)hipStreamDestroy(p.stream);
+        if (p.done) (void)hipEventDestroy(p.done);
+        if (p.copied) (void)hipEventDestroy(p.copied);
+    }
+    if (prev >= 0 && prev != c->cfg.device) (void)hipSetDevice(prev);
     delete c;
 }
 
@@ -771,20 +783,18 @@ static int rx_one_frame(mgpu_ctx* c, const double* bb, uint8_t* payload, mgpu_fr
         hipStream_t s = c->stream;
         if (!c->one_frame_graph) {
             ensure_workspaces(c, WS_FRONTEND | WS_LLR | WS_OUT);
-            if (c->baseband_cap < in_bytes) {
-                (void)hipFree(c->d_baseband);
-                c->d_baseband = nullptr; c->baseband_cap = 0;
-                HIPCK(hipMalloc(&c->d_baseband, in_bytes));
-                c->baseband_cap = in_bytes;
-            }
-            HIPCK(hipHostMalloc(&c->h_one_in, in_bytes, hipHostMallocDefault));
-            HIPCK(hipHostMalloc(&c->h_one_out, out_bytes, hipHostMallocDefault));
+            // The graph bakes in every address it touches, so it reads from a device buffer and staging buffers of its own
+            // that live as long as the context (d_baseband may be reallocated by a larger batch later; the max_batch-sized
+            // workspaces never are). Nothing is published in the context until the whole graph exists.
+            if (!c->d_one_in) HIPCK(hipMalloc(&c->d_one_in, in_bytes));
+            if (!c->h_one_in) HIPCK(hipHostMalloc(&c->h_one_in, in_bytes, hipHostMallocDefault));
+            if (!c->h_one_out) HIPCK(hipHostMalloc(&c->h_one_out, out_bytes, hipHostMallocDefault));
             hipGraph_t graph = nullptr;
             HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             try {
-                HIPCK(hipMemcpyAsync(c->d_baseband, c->h_one_in, in_bytes, hipMemcpyHostToDevice, s));
+                HIPCK(hipMemcpyAsync(c->d_one_in, c->h_one_in, in_bytes, hipMemcpyHostToDevice, s));
                 MgpuTapsDev dt{};
-                launch_frontend(c, c->d_baseband, 1, c->d_llr, c->d_variance, c->d_snrvar, dt, s);
+                launch_frontend(c, c->d_one_in, 1, c->d_llr, c->d_variance, c->d_snrvar, dt, s);
                 launch_decoder(c, c->d_llr, 1, nullptr, nullptr, c->d_payload, c->d_stats, c->d_variance, c->d_snrvar, s);
                 launch_zf_snr(c, 1, c->d_payload, c->d_stats, s);
                 HIPCK(hipMemcpyAsync(c->h_one_out, c->d_payload, t.payload_stride, hipMemcpyDeviceToHost, s));
@@ -795,9 +805,11 @@ static int rx_one_frame(mgpu_ctx* c, const double* bb, uint8_t* payload, mgpu_fr
                 throw;
             }
             HIPCK(hipStreamEndCapture(s, &graph));
-            const hipError_t e = hipGraphInstantiate(&c->one_frame_graph, graph, nullptr, nullptr, 0);
+            hipGraphExec_t exec = nullptr;
+            const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             HIPCK(e);
+            c->one_frame_graph = exec;
         }
         std::memcpy(c->h_one_in, bb, in_bytes);
         HIPCK(hipGraphLaunch(c->one_frame_graph, s));
@@ -807,9 +819,88 @@ static int rx_one_frame(mgpu_ctx* c, const double* bb, uint8_t* payload, mgpu_fr
     });
 }
 
+// The blocking host-buffer entry point for F > 1 with no stage taps: classic double buffering. The batch goes through in
+// chunks; a copy stream brings chunk i+1 (104 KB per mode-8 frame over PCIe) into the second input buffer while the kernel
+// stream runs the front-end and the decoder of chunk i; the kernels stay in order on one stream (two decoder launches sharing
+// the CUs only delay each other), events hand the buffers back and forth, and the small payload / stats copies ride behind each
+// chunk into page-locked staging. The LLR / variance / payload / stats workspaces are the max_batch-sized ones, addressed by
+// frame offset. Results are byte-identical to the one-launch path (frames are independent).
+static void rx_batch_pipelined(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, mgpu_frame_stats* stats) {
+    const auto& t = c->tab;
+    ensure_workspaces(c, WS_FRONTEND | WS_LLR | WS_OUT);
+    const size_t frame_bytes = size_t(t.frame_samples) * 16;
+    // chunk size: a decoder launch keeps the whole chip busy only from 2 workgroups per CU upwards (512 codewords on 256 CUs; a
+    // smaller launch takes just as long), and a copy should carry a few MB; so chunks are multiples of that wave of workgroups
+    // and a batch that is not larger than one chunk goes through in one piece.
+    static const int wave_of_wgs = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 2 * (cus > 0 ? cus : 256);
+    }();
+    int chunk = wave_of_wgs;
+    while (size_t(chunk) * frame_bytes < (size_t(8) << 20)) chunk += wave_of_wgs;
+    if (const char* e = std::getenv("MERCURY_RX_CHUNK")) chunk = std::max(1, std::atoi(e));
+    chunk = std::min(chunk, F);
+    for (auto& p : c->pipe) {
+        if (!p.stream) HIPCK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+        if (!p.done) HIPCK(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+        if (!p.copied) HIPCK(hipEventCreateWithFlags(&p.copied, hipEventDisableTiming));
+        if (p.cap < size_t(chunk) * frame_bytes) {
+            HIPCK(hipStreamSynchronize(p.stream));
+            (void)hipFree(p.d_in);
+            p.d_in = nullptr; p.cap = 0;
+            HIPCK(hipMalloc(&p.d_in, size_t(chunk) * frame_bytes));
+            p.cap = size_t(chunk) * frame_bytes;
+        }
+    }
+    // Results come back through page-locked staging owned by the context: a device-to-host copy into the caller's pageable
+    // arrays would block the host until the chunk's kernels have finished, i.e. before the next chunk's input copy could even
+    // be queued, and nothing would overlap.
+    const size_t out_bytes = size_t(c->max_batch) * (t.payload_stride + sizeof(MgpuStatsDev));
+    if (!c->h_out) HIPCK(hipHostMalloc(&c->h_out, out_bytes + 16, hipHostMallocDefault));
+    uint8_t* h_payload = static_cast<uint8_t*>(c->h_out);
+    MgpuStatsDev* h_stats = reinterpret_cast<MgpuStatsDev*>(h_payload + ((size_t(c->max_batch) * t.payload_stride + 15) & ~size_t(15)));
+    MgpuTapsDev none{};
+    // Two ways to overlap, chosen by the kind of host memory (measured on MI355X / PCIe Gen5, tools/bench_host_path.py):
+    //  * page-locked input (mgpu_alloc_host, hipHostMalloc/Register): the copy is a true asynchronous DMA. One copy stream runs
+    //    ahead into the other input buffer while ONE kernel stream keeps the launches in order (two decoder launches sharing the
+    //    CUs only delay each other); events hand the buffers back and forth.
+    //  * pageable input: the runtime stages the copy itself and holds the calling thread until it is done, which already paces
+    //    the copies one behind the other; each chunk's copy and kernels then go to the stream that owns the chunk's input
+    //    buffer (two streams alternating), so a copy waits exactly for the front-end that last read its buffer.
+    hipPointerAttribute_t attr{};
+    const bool pinned = hipPointerGetAttributes(&attr, bb) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    int k = 0;
+    for (int off = 0; off < F; off += chunk, ++k) {
+        auto& p = c->pipe[k % mgpu_ctx::kPipes];                     // input buffer of this chunk
+        hipStream_t cs = pinned ? c->pipe[0].stream : p.stream, ks = pinned ? c->pipe[1].stream : p.stream;
+        const int n = std::min(chunk, F - off);
+        if (pinned && k >= mgpu_ctx::kPipes) HIPCK(hipStreamWaitEvent(cs, p.done, 0));          // the front-end of chunk k-2 has consumed it
+        HIPCK(hipMemcpyAsync(p.d_in, reinterpret_cast<const char*>(bb) + size_t(off) * frame_bytes, size_t(n) * frame_bytes, hipMemcpyHostToDevice, cs));
+        if (pinned) {
+            HIPCK(hipEventRecord(p.copied, cs));
+            HIPCK(hipStreamWaitEvent(ks, p.copied, 0));
+        }
+        launch_frontend(c, p.d_in, n, c->d_llr + size_t(off) * t.N, c->d_variance + off, c->d_snrvar + off, none, ks, 0, off);
+        if (pinned) HIPCK(hipEventRecord(p.done, ks));               // the front-end is the only reader of the input buffer
+        launch_decoder(c, c->d_llr + size_t(off) * t.N, n, nullptr, nullptr, c->d_payload + size_t(off) * t.payload_stride, c->d_stats + off,
+                       c->d_variance + off, c->d_snrvar + off, ks);
+        launch_zf_snr(c, n, c->d_payload + size_t(off) * t.payload_stride, c->d_stats + off, ks, off);
+        if (payload) HIPCK(hipMemcpyAsync(h_payload + size_t(off) * t.payload_stride, c->d_payload + size_t(off) * t.payload_stride,
+                                          size_t(n) * t.payload_stride, hipMemcpyDeviceToHost, ks));
+        if (stats) HIPCK(hipMemcpyAsync(h_stats + off, c->d_stats + off, size_t(n) * sizeof(MgpuStatsDev), hipMemcpyDeviceToHost, ks));
+    }
+    for (auto& p : c->pipe) HIPCK(hipStreamSynchronize(p.stream));
+    if (payload) std::memcpy(payload, h_payload, size_t(F) * t.payload_stride);
+    if (stats) std::memcpy(stats, h_stats, size_t(F) * sizeof(MgpuStatsDev));
+}
+
 int mgpu_rx_batch(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, mgpu_frame_stats* stats, float* llr_opt) {
     if (c && bb && F == 1 && !llr_opt && !c->timing && c->max_batch >= 1 && !std::getenv("MERCURY_NO_GRAPH"))
         return rx_one_frame(c, bb, payload, stats);
+    if (c && bb && F > 1 && F <= c->max_batch && !llr_opt && !c->timing && !std::getenv("MERCURY_NO_PIPELINE"))
+        return guard(c, [&] { rx_batch_pipelined(c, bb, F, payload, stats); });
     mgpu_stage_taps taps{};
     taps.llr_ldpc = llr_opt;
     return mgpu_rx_batch_taps(c, bb, F, payload, stats, llr_opt ? &taps : nullptr);

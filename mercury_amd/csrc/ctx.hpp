@@ -99,6 +99,7 @@ struct mgpu_ctx {
     int* d_iters = nullptr;
     // single-frame fast path of mgpu_rx_batch: the copy-in / front-end / decoder / copy-out sequence as one hipGraph
     hipGraphExec_t one_frame_graph = nullptr;
+    double* d_one_in = nullptr;     // the graph's own one-frame device buffer (never reallocated: the graph holds its address)
     void* h_one_in = nullptr;       // page-locked staging for one frame of samples
     void* h_one_out = nullptr;      // page-locked staging for its payload + stats
     void* rxloop_ws = nullptr;      // device workspace of mgpu_receive_byte_batch, kept between calls (rxloop.hip)
@@ -110,6 +111,10 @@ struct mgpu_ctx {
     void* tx_state = nullptr;       // transmit path: preamble baseband, filter taps, carrier table (tx.hip)
     void (*tx_state_free)(void*) = nullptr;
     hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
+    struct Pipe { hipStream_t stream = nullptr; hipEvent_t done = nullptr, copied = nullptr; double* d_in = nullptr; size_t cap = 0; };
+    void* h_out = nullptr;          // page-locked staging for the payloads + stats of a pipelined call ([max_batch])
+    static constexpr int kPipes = 2;
+    Pipe pipe[kPipes];                   // the two chunk pipelines of the blocking host-buffer entry points (api.hip rx_batch_pipelined)
     static constexpr int kEvRing = 64;
     hipEvent_t ev[kEvRing][4]{};    // per launch: front-end start/stop, decoder start/stop
     bool timing = false;
@@ -134,9 +139,10 @@ constexpr int kMaxFramesPerLaunch = 1 << 21;
 template <typename T> T* at(T* p, size_t off) { return p ? p + off : nullptr; }
 
 // frame_stride (complex samples between consecutive frames of d_bb) defaults to the mode's frame_samples
+// frame0: index of the call's first frame inside the context's max_batch-sized workspaces (the ZF modes keep their equalised symbols there)
 void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float* d_var, float* d_snrvar, const MgpuTapsDev& taps,
-                     hipStream_t s, int frame_stride = 0);
-void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s);
+                     hipStream_t s, int frame_stride = 0, int frame0 = 0);
+void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s, int frame0 = 0);
 void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int* d_iters, uint8_t* d_payload, MgpuStatsDev* d_stats,
                     const float* d_var, const float* d_snrvar, hipStream_t s);
 
@@ -167,9 +173,28 @@ const double* mixer_table(mgpu_ctx* c, double carrier_hz, size_t count, hipStrea
 void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, const int* d_widx, const int* d_ncand, int ncand_max, int n, int step,
                          int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s);
 
+// Every entry point that takes a context runs with the context's device current and puts the caller's device back
+// afterwards, so one host thread can hold contexts on several GPUs (lazy workspaces, per-call buffers, page-locked
+// staging and launches on c->stream all land on cfg.device, whatever the thread's current device was).
+struct DeviceScope {
+    int prev = -1, want = -1;
+    explicit DeviceScope(int device) : want(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) HIPCK(hipSetDevice(want));
+    }
+    ~DeviceScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 inline int guard(mgpu_ctx* c, const std::function<void()>& fn) {
     try {
-        fn();
+        if (c) {
+            DeviceScope on(c->cfg.device);
+            fn();
+        } else {
+            fn();
+        }
         return MGPU_OK;
     } catch (const HipError& e) {
         if (c) c->err = e.what();

@@ -110,6 +110,8 @@ EXPORTED_SYMBOLS = [
     "mgpu_bit_energy_dispersal", "mgpu_bit_to_byte", "mgpu_crc16_modbus_rtu",
     "mgpu_shm_create", "mgpu_shm_connect", "mgpu_shm_close", "mgpu_shm_destroy", "mgpu_shm_used", "mgpu_shm_free", "mgpu_shm_capacity",
     "mgpu_shm_clear", "mgpu_shm_write", "mgpu_shm_read", "mgpu_shm_read_all", "mgpu_shm_publish_decoded",
+    "mgpu_pool_create", "mgpu_pool_destroy", "mgpu_pool_size", "mgpu_pool_context", "mgpu_pool_last_error", "mgpu_pool_last_counters",
+    "mgpu_pool_shard", "mgpu_pool_rx_batch", "mgpu_pool_ldpc_batch", "mgpu_pool_receive_byte_batch",
 ]
 
 
@@ -406,3 +408,98 @@ class RxPhy:
         n = C.c_int(0)
         self._ck(self.lib.mgpu_kernel_ms_avg(self.h, ms, C.byref(n)))
         return float(ms[0]), float(ms[1]), int(n.value)
+
+
+# ---- multi-GPU pool (include/mercury_pool.h) ------------------------------------------------------------------------------
+POOL_MAX_DEVICES = 16
+
+
+class PoolCounters(C.Structure):
+    _fields_ = [("n_devices", C.c_int), ("frames", C.c_longlong), ("decoded", C.c_longlong), ("ldpc_iterations", C.c_longlong),
+                ("wall_ms", C.c_double), ("device_frames", C.c_int * POOL_MAX_DEVICES), ("device_ms", C.c_double * POOL_MAX_DEVICES)]
+
+
+def pool_shard(F, G, g):
+    """Frames of device g of G: (first, count) — mgpu_pool_shard, callable without a GPU."""
+    lib = load_library()
+    a, n = C.c_int(), C.c_int()
+    lib.mgpu_pool_shard(C.c_int(F), C.c_int(G), C.c_int(g), C.byref(a), C.byref(n))
+    return a.value, n.value
+
+
+class RxPool:
+    """One context + one host worker thread per device; a call is split into contiguous frame ranges (mgpu_pool_*)."""
+
+    def __init__(self, cfg, devices, max_iters=50, decoder=DEC_SPA, agc=1, variance_source=1, max_batch=4096, minsum_alpha=0.0,
+                 mfsk_ctrl_mode=False):
+        self.lib = load_library()
+        self.lib.mgpu_pool_context.restype = C.c_void_p
+        self.lib.mgpu_pool_last_error.restype = C.c_char_p
+        self.h = C.c_void_p()
+        c = Config(cfg, max_iters, decoder, agc, variance_source, 0, max_batch, minsum_alpha, 1 if mfsk_ctrl_mode else 0)
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self.lib.mgpu_pool_create(C.byref(c), devs, C.c_int(len(devices)), C.byref(self.h))
+        if rc != 0:
+            raise MgpuError("mgpu_pool_create failed (%d): %s" % (rc, self.lib.mgpu_pool_last_error(None).decode()))
+        self.n_devices = len(devices)
+        i = Info()
+        ctx0 = C.c_void_p(self.lib.mgpu_pool_context(self.h, 0))
+        if self.lib.mgpu_get_info(ctx0, C.byref(i)) != 0:
+            raise MgpuError("mgpu_get_info failed")
+        for n in INFO_FIELDS:
+            setattr(self, n, getattr(i, n))
+        self._ctx0 = ctx0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MgpuError("mgpu pool error %d: %s" % (rc, self.lib.mgpu_pool_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.mgpu_pool_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counters(self):
+        c = PoolCounters()
+        self._ck(self.lib.mgpu_pool_last_counters(self.h, C.byref(c)))
+        return {"n_devices": c.n_devices, "frames": c.frames, "decoded": c.decoded, "ldpc_iterations": c.ldpc_iterations, "wall_ms": c.wall_ms,
+                "device_frames": list(c.device_frames)[: c.n_devices], "device_ms": list(c.device_ms)[: c.n_devices]}
+
+    def receive(self, baseband):
+        bb = np.ascontiguousarray(baseband, np.complex128).reshape(-1, self.frame_samples)
+        F = bb.shape[0]
+        payload = np.zeros((F, self.payload_stride), np.uint8)
+        stats = np.zeros(F, STATS_DTYPE)
+        self._ck(self.lib.mgpu_pool_rx_batch(self.h, _ptr(bb), C.c_int(F), _ptr(payload), _ptr(stats)))
+        return {"payload": payload, "stats": stats}
+
+    def ldpc_decode(self, llr):
+        l = np.ascontiguousarray(llr, np.float32).reshape(-1, 1600)
+        F = l.shape[0]
+        bits = np.zeros((F, self.K), np.uint8)
+        iters = np.zeros(F, np.int32)
+        self._ck(self.lib.mgpu_pool_ldpc_batch(self.h, _ptr(l), C.c_int(F), _ptr(bits), _ptr(iters)))
+        return bits, iters
+
+    def receive_buffer_samples(self):
+        return int(self.lib.mgpu_receive_buffer_nsymb(self._ctx0)) * self.Nofdm * 4
+
+    def receive_byte(self, passband, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1, state=None,
+                     coarse_freq_sync=0):
+        x = np.ascontiguousarray(passband, np.float64)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        W = x.shape[0]
+        cfg = ReceiveConfig(carrier_hz, trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync)
+        st = np.zeros(W, LINK_STATE_DTYPE) if state is None else np.ascontiguousarray(state, LINK_STATE_DTYPE)
+        if state is None:
+            st["delay_of_last_decoded_message"] = -1
+        payload = np.zeros((W, self.payload_stride), np.uint8)
+        stats = np.zeros(W, RECEIVE_STATS_DTYPE)
+        self._ck(self.lib.mgpu_pool_receive_byte_batch(self.h, _ptr(x), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
+        return {"payload": payload, "stats": stats, "state": st}

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _header_functions():
     names = set()
-    for header in ("mercury_gpu.h", "mercury_shm.h", "mercury_rxloop.h", "mercury_stages.h", "mercury_tx.h"):
+    for header in ("mercury_gpu.h", "mercury_shm.h", "mercury_rxloop.h", "mercury_stages.h", "mercury_tx.h", "mercury_pool.h"):
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(mgpu_[a-z_0-9]+)\s*\(", text))

@@ -1,0 +1,170 @@
+"""The multi-GPU pool (include/mercury_pool.h, SURVEY.md §8 row e): frame-range sharding, one context + host thread per device,
+no collectives. CPU: the shard arithmetic, the ABI and the loud failure without a GPU. GPU: a pool of several contexts on
+device 0 must return exactly what one context returns, for ragged batch sizes, from Python and from a C++14 program."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oraclelib
+from conftest import OPERATING_ESN0, SEED
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shards_partition_every_batch():
+    from mercury_amd import pool_shard
+    from mercury_amd.sharding import frame_range, owner_of
+    for F in (0, 1, 2, 7, 8, 9, 63, 64, 65, 4096, 1000003):
+        for G in (1, 2, 3, 4, 8, 16):
+            nxt = 0
+            for g in range(G):
+                a, n = pool_shard(F, G, g)
+                assert a == nxt and n >= 0
+                assert (a, a + n) == tuple(frame_range(g, G, F))       # the same rule bench.py's ranks use
+                nxt = a + n
+                for f in {a, a + n - 1} if n else ():
+                    assert owner_of(f, G, F) == g
+            assert nxt == F
+
+
+def test_pool_fails_loudly_without_a_gpu():
+    import torch
+    from mercury_amd import MgpuError, RxPool
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(MgpuError) as e:
+        RxPool(8, [0, 0], max_batch=4)
+    assert "mgpu_pool_create failed (2)" in str(e.value)
+
+
+def test_pool_rejects_bad_arguments():
+    from mercury_amd import load_library
+    from mercury_amd.physical_layer import Config
+    lib = load_library()
+    h = C.c_void_p()
+    cfg = Config(8, 50, 1, 1, 1, 0, 4, 0.0, 0)
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.mgpu_pool_create(C.byref(cfg), devs, 0, C.byref(h)) == 1
+    assert lib.mgpu_pool_create(C.byref(cfg), devs, 17, C.byref(h)) == 1
+    assert lib.mgpu_pool_create(None, devs, 2, C.byref(h)) == 1
+    assert lib.mgpu_pool_rx_batch(None, None, 0, None, None) == 1
+    assert lib.mgpu_pool_size(None) == 0
+
+
+def _cpp(tmp_path):
+    exe = tmp_path / "pool_test"
+    lib = os.path.join(ROOT, "mercury_amd")
+    subprocess.run(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "pool_test.cpp"),
+                    "-o", str(exe), "-L", lib, "-lmercury_gpu", "-Wl,-rpath," + lib, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-pthread"], check=True)
+    return exe
+
+
+def test_cpp_pool_program_compiles(tmp_path):
+    assert _cpp(tmp_path).exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,n_ctx", [(1, 2), (5, 2), (37, 2), (37, 3), (64, 4)])
+def test_cpp_pool_equals_single_context(tmp_path, F, n_ctx):
+    exe = _cpp(tmp_path)
+    cfg = 8
+    orc = oraclelib.Oracle(cfg, 50)
+    snrs = [OPERATING_ESN0[cfg] + 1.0, -15.0, OPERATING_ESN0[cfg], 60.0]
+    bb = np.stack([orc.gen_frame(SEED, 4000 + i, oraclelib.noise_amp_for(snrs[i % 4]))[0] for i in range(F)])
+    (tmp_path / "bb.bin").write_bytes(bb.tobytes())
+    r = subprocess.run([str(exe), str(cfg), str(F), str(tmp_path / "bb.bin"), str(tmp_path / "out.bin"), str(n_ctx)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = (tmp_path / "out.bin").read_bytes()
+    half = len(raw) // 2
+    assert raw[:half] == raw[half:], "pool output differs from the single-context output"
+    stride = (orc.nReal + 7) // 8
+    pay = np.frombuffer(raw[: F * stride], np.uint8).reshape(F, stride)
+    for f in (0, F // 2, F - 1):                     # and that output is the oracle's
+        ref = orc.rx(bb[f], oraclelib.FLAGS_RECEIVE_BYTE)
+        assert np.array_equal(pay[f], ref["bytes"].astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_python_pool_rx_ldpc_and_receive_byte_equal_single_context():
+    from mercury_amd import RxPhy, RxPool
+    cfg, F = 5, 23
+    orc = oraclelib.Oracle(cfg, 50)
+    bb = np.stack([orc.gen_frame(SEED, 5000 + i, oraclelib.noise_amp_for(OPERATING_ESN0[cfg] + (1.0 if i % 3 else -20.0)))[0] for i in range(F)])
+    one = RxPhy(cfg, max_batch=F)
+    pool = RxPool(cfg, [0, 0, 0], max_batch=F)
+    a, b = one.receive(bb, want_llr=True), pool.receive(bb)
+    assert np.array_equal(a["payload"], b["payload"]) and a["stats"].tobytes() == b["stats"].tobytes()
+    k = pool.counters()
+    assert k["frames"] == F and sum(k["device_frames"]) == F and k["decoded"] == int((a["stats"]["message_decoded"] != 0).sum())
+    assert k["ldpc_iterations"] == int(np.minimum(a["stats"]["iterations_done"], 50).sum())
+    bits1, it1 = one.ldpc_decode(a["llr_ldpc"])
+    bits2, it2 = pool.ldpc_decode(a["llr_ldpc"])
+    assert np.array_equal(bits1, bits2) and np.array_equal(it1, it2)
+    # capture windows through receive_byte: windows are independent, so the split must not show
+    from test_receive_byte import SPECS, make_windows
+    from oraclelib import CARRIER
+    wins, _ = make_windows(orc, SPECS[:7], seed=77)
+    r1, r2 = one.receive_byte(wins, CARRIER), pool.receive_byte(wins, CARRIER)
+    assert np.array_equal(r1["payload"], r2["payload"]) and r1["stats"].tobytes() == r2["stats"].tobytes()
+    assert r1["state"].tobytes() == r2["state"].tobytes()
+    assert int((r1["stats"]["message_decoded"] != 0).sum()) >= 3
+    one.close()
+    pool.close()
+
+
+@pytest.mark.gpu
+def test_one_thread_two_contexts_graph_order_and_device_scope():
+    """(high) the single-frame hipGraph must survive a larger batch reallocating the context's input buffer
+    (order F=1, F=max, F=1 on a fresh context); (medium) every entry point runs on the context's own device whatever the
+    calling thread's current device is."""
+    import torch
+    from mercury_amd import RxPhy
+    cfg, F = 8, 9
+    orc = oraclelib.Oracle(cfg, 50)
+    bb = np.stack([orc.gen_frame(SEED, 6000 + i, oraclelib.noise_amp_for(OPERATING_ESN0[cfg] + 1.0))[0] for i in range(F)])
+    rx = RxPhy(cfg, max_batch=F)
+    first = rx.receive(bb[:1])
+    allf = rx.receive(bb)
+    again = rx.receive(bb[:1])
+    last = rx.receive(bb[F - 1:])
+    assert np.array_equal(first["payload"], again["payload"]) and first["stats"].tobytes() == again["stats"].tobytes()
+    assert np.array_equal(allf["payload"][:1], first["payload"]) and np.array_equal(allf["payload"][F - 1:], last["payload"])
+    ref = orc.rx(bb[0], oraclelib.FLAGS_RECEIVE_BYTE)
+    assert np.array_equal(first["payload"][0], ref["bytes"].astype(np.uint8))
+    if torch.cuda.device_count() > 1:
+        torch.cuda.set_device(1)
+        other = rx.receive(bb)
+        assert np.array_equal(other["payload"], allf["payload"])
+        assert torch.cuda.current_device() == 1
+        torch.cuda.set_device(0)
+    rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 16, 101])
+def test_pipelined_host_entry_point_equals_one_launch(cfg, monkeypatch):
+    """mgpu_rx_batch for F > 1 runs the batch in chunks on two streams (copy of chunk i+1 under the kernels of chunk i);
+    the result must be byte-identical to the one-launch path, whatever the chunk size (ragged last chunk, ZF modes with
+    their per-frame equalised-symbol workspace, MFSK modes)."""
+    from mercury_amd import RxPhy
+    F = 37
+    orc = oraclelib.Oracle(cfg, 50)
+    agc, vs = (0, 0) if cfg in (15, 16) else (1, 1)
+    snr = OPERATING_ESN0[cfg]
+    bb = np.stack([orc.gen_frame(SEED, 7000 + i, oraclelib.noise_amp_for(snr + (1.0 if i % 4 else -25.0)))[0] for i in range(F)])
+    rx = RxPhy(cfg, max_batch=F, agc=agc, variance_source=vs)
+    monkeypatch.setenv("MERCURY_NO_PIPELINE", "1")
+    ref = rx.receive(bb)
+    monkeypatch.delenv("MERCURY_NO_PIPELINE")
+    for chunk in ("7", "16", "36", "64"):
+        monkeypatch.setenv("MERCURY_RX_CHUNK", chunk)
+        out = rx.receive(bb)
+        assert np.array_equal(out["payload"], ref["payload"]) and out["stats"].tobytes() == ref["stats"].tobytes(), (cfg, chunk)
+    monkeypatch.delenv("MERCURY_RX_CHUNK")
+    out = rx.receive(bb)
+    assert np.array_equal(out["payload"], ref["payload"]) and out["stats"].tobytes() == ref["stats"].tobytes()
+    assert int((ref["stats"]["message_decoded"] != 0).sum()) >= F // 2
+    rx.close()
