@@ -47,7 +47,6 @@ void ctx_alloc(mgpu_ctx* c) {
     d.svar = c->keep(upload(t.graph.svar));
     d.vinfo = c->keep(upload(t.graph.vinfo));
     d.sdesc = c->keep(upload(t.graph.sdesc));
-    d.bin_end = reinterpret_cast<const unsigned long long*>(c->keep(upload(t.graph.bin_end)));
     d.S = t.graph.S;
     d.M = t.M; d.bps = t.bps; d.K = t.K; d.P = t.P; d.N = t.N; d.E = t.graph.E;
     d.Nsymb = t.Nsymb; d.G = t.Nsymb * t.Nc; d.nData = t.nData; d.nBits = t.nBits; d.nPilots = t.nPilots;
@@ -74,7 +73,7 @@ void ctx_alloc(mgpu_ctx* c) {
     d.mfsk_off0 = t.mfsk_off[0]; d.mfsk_off1 = t.mfsk_off[1];
     d.active_nsymb = t.active_nsymb; d.active_nbits = t.active_nbits; d.mfsk_amp = t.mfsk_amp;
     LdpcDev& l = c->ldev;
-    l.spack = d.spack; l.svar = d.svar; l.vinfo = d.vinfo; l.sdesc = d.sdesc; l.bin_end = d.bin_end; l.scrambler = d.scrambler;
+    l.spack = d.spack; l.svar = d.svar; l.vinfo = d.vinfo; l.sdesc = d.sdesc; l.scrambler = d.scrambler;
     l.cptr = d.cptr; l.cvar = d.cvar;
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;

@@ -26,7 +26,6 @@ struct MgpuDev {
     const uint16_t* svar;          // [S]
     const uint32_t* vinfo;         // [N][6]
     const uint32_t* sdesc;         // [ceil(S/1024)*1024]
-    const unsigned long long* bin_end;   // [ceil(S/1024)*16]
     int S;
     int M, bps, K, P, N, E;
     int Nsymb, G, nData, nBits, nPilots, nVirtual, nReal;
@@ -47,8 +46,7 @@ struct MgpuDev {
 // inflate the SGPR allocation (occupancy on gfx950 drops below 8 waves/SIMD above 80 SGPRs).
 struct LdpcDev {
     const uint32_t* spack; const uint16_t* svar; const uint32_t* vinfo;   // sum-product / min-sum layout
-    const unsigned long long* bin_end;   // [ceil(S/1024)*16] per 64-slot bin: bit l set <=> slot l is the last edge of a check
-    const uint32_t* sdesc;   // [NE*1024] per padded slot: check_start(13) | deg(6)<<13 | variable(11)<<19, 0 = padding (zero-filled up to a multiple of 1024)
+    const uint32_t* sdesc;   // [NE*1024] per padded slot: check_start(13) | deg(6)<<13 | variable(11)<<19 | last edge of its check<<31, 0 = padding (zero-filled, one spare round)
     const uint32_t* cptr; const uint16_t* cvar;                           // plain check-major lists (GBF)
     const uint8_t* scrambler;
     int S, N, P, K, E, nReal, payload_stride, max_iters;

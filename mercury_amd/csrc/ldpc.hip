@@ -105,16 +105,21 @@ extern "C" size_t mgpu_spa_lds_bytes(int S, int N) {
 // operations + 5 reciprocal seeds (spa_math.h); everything else in the loop is kept to a few dozen
 // 32-bit operations: padding lanes and fdlibm's case distinctions are execution-mask branches (scalar
 // instructions only), not selects.
+constexpr int kN = 1600;             // every Mercury code has N = 1600 (checked on the host); fixes the LDS layout below
+
 template <int NE>
 __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
                                            uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
                                            uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
                                            const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int S = T.S, N = T.N;
-    double* M = reinterpret_cast<double*>(smem);      // R or T per padded edge slot
-    double* Lt = M + S;                               // LLRtmp per variable
-    float* Li = reinterpret_cast<float*>(Lt + N);     // channel LLR
+    const int S = T.S;
+    constexpr int N = kN;
+    // LLRtmp first, at a compile-time offset, then the messages: every LDS address in the loop is one shift/mask of a
+    // descriptor field plus an immediate offset
+    double* Lt = reinterpret_cast<double*>(smem);     // LLRtmp per variable
+    double* M = Lt + N;                               // R or T per padded edge slot
+    float* Li = reinterpret_cast<float*>(M + S);      // channel LLR
     uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
     uint8_t* bytes = hard + ((N + 15) & ~15);
     int* flag = reinterpret_cast<int*>(bytes + 256);
@@ -128,11 +133,10 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         Lt[v] = l;
     }
     for (int p = tid; p < S; p += LDPC_THREADS) M[p] = 0.0;     // R = 0 before the first iteration (:106-122)
-    // slot descriptor: check_start(13) | deg(6)<<13 | variable(11)<<19 ; deg == 0 marks padding.
+    // slot descriptor (T.sdesc, NE+1 rounds of 1024 words, zero = padding):
+    //   check_start(13) | deg(6)<<13 | variable(11)<<19 | last-edge-of-its-check<<31 ; deg == 0 marks padding.
     // The slot's position inside its check is p - check_start.
-    const uint32_t* __restrict__ sdesc = T.sdesc + tid;
-    // bin_end[b]: bit l set <=> lane l holds the last edge of a check of bin b (wave w works on bin w + 16 r in round r)
-    const unsigned long long* __restrict__ bin_end = T.bin_end + __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t* __restrict__ sdesc = T.sdesc;
     // variable records (variable | deg<<11, then 10 u16 slot indices in the reference's slot order)
     struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
     // The records are fetched again in every iteration (two cached loads per lane, issued ahead of the barrier they hide
@@ -171,9 +175,9 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     __syncthreads();
 
     // Does any check of this wave's bin have odd parity? m = sign bits of the posteriors of the bin's 64 edges (a check
-    // is a run of consecutive lanes, padding lanes contribute 0). With px = prefix XOR of m, check i spanning lanes
-    // (e[i-1], e[i]] has parity px[e[i]] ^ px[e[i-1]], so all parities are even <=> px is 0 at every check end.
-    // Scalar instructions only (the ballot is wave-uniform).
+    // is a run of consecutive lanes, padding lanes contribute 0), ends = the lanes holding the last edge of a check.
+    // With px = prefix XOR of m, check i spanning lanes (e[i-1], e[i]] has parity px[e[i]] ^ px[e[i-1]], so all
+    // parities are even <=> px is 0 at every check end. Scalar instructions only (ballots are wave-uniform).
     auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
         m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
         return (m & ends) != 0;
@@ -182,14 +186,13 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     // Pass p (0 = channel values, 1..max = after iteration p) leaves its syndrome verdict in flag[p & 1].
     auto syndrome_pass = [&](int p) {
         bool unsat = false;
-        uint32_t k = sdesc[0];
+        uint32_t k = sdesc[tid];
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
-            const uint32_t kn = (r + 1 < NE) ? sdesc[(r + 1) * LDPC_THREADS] : 0u;
-            const bool valid = ((k >> 13) & 0x3f) != 0;
-            double lt = 0.0;
-            if (valid) lt = Lt[k >> 19];
-            unsat |= bin_unsat(__ballot(lt < 0), bin_end[r * (LDPC_THREADS / 64)]);
+            const uint32_t kn = sdesc[(r + 1) * LDPC_THREADS + tid];
+            const unsigned long long vmask = __ballot(((k >> 13) & 0x3f) != 0);
+            const double lt = Lt[(k >> 19) & 0x7ff];                 // padding reads variable 0; masked out below
+            unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
             k = kn;
         }
         if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
@@ -198,31 +201,45 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     // all inside the wavefront that owns the bin; with_syndrome additionally judges the posteriors it reads (pass p)
     auto cn_pass = [&](bool with_syndrome, int p) {
         bool unsat = false;
-        uint32_t k = sdesc[0];
+        uint32_t k = sdesc[tid];
         uint32_t slot = tid;
 #pragma unroll 1
         for (int r = 0; r < NE; ++r, slot += LDPC_THREADS) {
-            const uint32_t kn = (r + 1 < NE) ? sdesc[(r + 1) * LDPC_THREADS] : 0u;
+            const uint32_t kn = sdesc[(r + 1) * LDPC_THREADS + tid];
             const uint32_t deg = (k >> 13) & 0x3f;
             const bool valid = deg != 0;
-            double lt = 0.0;
-            if (valid) lt = Lt[k >> 19];
-            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0), bin_end[r * (LDPC_THREADS / 64)]);
+            const unsigned long long vmask = __ballot(valid);
+            if (vmask == 0) { k = kn; continue; }                    // an empty bin (only in the last round)
+            double lt;
+            if (valid) lt = Lt[(k >> 19) & 0x7ff];
+            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
             if (valid) M[slot] = spa_tanh_half(lt - M[slot]);
             __builtin_amdgcn_wave_barrier();        // every lane's T is written (LDS operations of a wave complete in order)
-            double rr = 0.0;
+            double rr;
             if (valid) {
-                // the other deg-1 values of the check in slot order: step j reads slot j, or j+1 once the lane's own
-                // slot has been passed; same multiplication order as the reference, starting from 1.0
-                const uint32_t cs = k & 0x1fff, pos = slot - cs, degm1 = deg - 1;
+                // Product of the check's OTHER T values in slot order, starting from 1.0, as the reference multiplies them.
+                // Every lane of a check walks the check's slots in order (all read the same word: a broadcast) and the lane
+                // whose own slot comes up sits that step out under the execution mask; the wave runs to the largest degree
+                // in the bin (its first check: bins are filled in order of decreasing degree) and lanes of shorter checks
+                // drop out at their own degree, a test only needed from the smallest degree in the bin (its last check) on.
+                const double* chk = M + (k & 0x1fff);
+                const uint32_t pos = slot - (k & 0x1fff);
+                const uint32_t dmax = __builtin_amdgcn_readfirstlane(deg);
+                const uint32_t dmin = __builtin_amdgcn_readlane(deg, 63 - __builtin_clzll(vmask));
                 double temp = 1;
-                uint32_t j = 0;
-                for (; j + 2 <= degm1; j += 2) {       // two reads in flight per LDS round trip
-                    const double a = M[cs + j + (j >= pos ? 1 : 0)], b = M[cs + j + 1 + (j + 1 >= pos ? 1 : 0)];
-                    temp *= a;
-                    temp *= b;
+                auto step = [&](uint32_t j) {
+                    const double a = chk[j];
+                    bool use = j != pos;
+                    if (j >= dmin) use = use && j < deg;
+                    if (use) { temp *= a; SPA_KEEP(temp); }
+                };
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    if (j >= dmax) break;
+                    step(j);
                 }
-                if (j < degm1) temp *= M[cs + j + (j >= pos ? 1 : 0)];
+#pragma unroll 1
+                for (uint32_t j = 8; j < dmax; ++j) step(j);
                 rr = spa_atanh_x2(temp);              // clamps +-1 to +-0.9999999 first (:150-155)
             }
             __builtin_amdgcn_wave_barrier();        // every lane of this wave has read its check's T values
@@ -324,8 +341,7 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     if (f >= F) return;
     for (int v = tid; v < N; v += THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; Lt[v] = l; }
     for (int p = tid; p < S; p += THREADS) M[p] = 0.0f;
-    const uint32_t* __restrict__ sdesc = T.sdesc + tid;
-    const unsigned long long* __restrict__ bin_end = T.bin_end + __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t* __restrict__ sdesc = T.sdesc;
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
 
@@ -335,30 +351,31 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     };
     auto syndrome_pass = [&](int p) {
         bool unsat = false;
-        uint32_t k = sdesc[0];
+        uint32_t k = sdesc[tid];
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
-            const uint32_t kn = (r + 1 < NE) ? sdesc[(r + 1) * THREADS] : 0u;
-            const bool valid = ((k >> 13) & 0x3f) != 0;
-            float lt = 0.0f;
-            if (valid) lt = Lt[k >> 19];
-            unsat |= bin_unsat(__ballot(lt < 0), bin_end[r * (THREADS / 64)]);
+            const uint32_t kn = sdesc[(r + 1) * THREADS + tid];
+            const unsigned long long vmask = __ballot(((k >> 13) & 0x3f) != 0);
+            const float lt = Lt[(k >> 19) & 0x7ff];
+            unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
             k = kn;
         }
         if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
     auto cn_pass = [&](bool with_syndrome, int p) {
         bool unsat = false;
-        uint32_t k = sdesc[0];
+        uint32_t k = sdesc[tid];
         uint32_t slot = tid;
 #pragma unroll 1
         for (int r = 0; r < NE; ++r, slot += THREADS) {
-            const uint32_t kn = (r + 1 < NE) ? sdesc[(r + 1) * THREADS] : 0u;
+            const uint32_t kn = sdesc[(r + 1) * THREADS + tid];
             const uint32_t deg = (k >> 13) & 0x3f;
             const bool valid = deg != 0;
-            float lt = 0.0f;
-            if (valid) lt = Lt[k >> 19];
-            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0), bin_end[r * (THREADS / 64)]);
+            const unsigned long long vmask = __ballot(valid);
+            if (vmask == 0) { k = kn; continue; }
+            float lt;
+            if (valid) lt = Lt[(k >> 19) & 0x7ff];
+            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
             float t = 1.0f;
             if (valid) {
                 const float q = lt - M[slot];

@@ -86,7 +86,7 @@ SPA_FN double spa_tanh_half(double q) {
                  Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
                  Q5 = -2.01099218183624371326e-07;
     const uint32_t jq = SPA_BITS_HI(q), iq = jq & 0x7fffffffu;
-    const double A = spa_fabs(q);                      // = 2|x| (exact for |x| >= 2^-55)
+    const double A = spa_fabs(q);                            // = 2|x| (exact for |x| >= 2^-55)
     const bool big = iq >= 0x40000000u;                      // |x| >= 1
     int32_t kk = int32_t(invln2 * A + 0.5);
     kk = (iq <= 0x3fd62e42u) ? 0 : kk;
@@ -139,11 +139,15 @@ SPA_FN double spa_tanh_half(double q) {
     }
     const double d2 = t + 2.0;
     const double rr = spa_recip(d2);
-    const double num = SPA_MAKE(big ? 0x40000000u : (SPA_BITS_HI(t) ^ 0x80000000u), big ? 0u : SPA_LO(t));
-    const double qq = spa_div_r(num, d2, rr);
-    double z = big ? 1.0 - qq : qq;
-    uint32_t zh = SPA_BITS_HI(z) | (jq & 0x80000000u);
-    double res = SPA_MAKE(zh, SPA_LO(z));
+    double z;
+    if (big) {
+        z = 1.0 - spa_div_r(2.0, d2, rr);
+        SPA_KEEP(z);
+    } else {
+        z = spa_div_r(-t, d2, rr);
+        SPA_KEEP(z);
+    }
+    double res = SPA_MAKE((SPA_BITS_HI(z) & 0x7fffffffu) | (jq & 0x80000000u), SPA_LO(z));     // z >= 0: one bit-field insert
     if (__builtin_expect(iq < 0x3c900000u || iq >= 0x40460000u, 0)) {
         const double one = SPA_MAKE(0x3ff00000u | (jq & 0x80000000u), 0u);
         res = (iq >= 0x40460000u) ? one : 0.5 * q;
@@ -157,28 +161,34 @@ SPA_FN double spa_atanh_x2(double x) {
     const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                  Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
                  Lp7 = 1.479819860511658591e-01;
+    if (__builtin_expect(spa_fabs(x) == 1.0, 0)) {
+        x = SPA_MAKE((SPA_BITS_HI(x) & 0x80000000u) | 0x3fefffffu, 0xca501acbu);      // +-0.9999999
+        SPA_KEEP(x);
+    }
     const uint32_t jx = SPA_BITS_HI(x);
-    double xa = spa_fabs(x);
-    if (__builtin_expect(xa == 1.0, 0)) { xa = 0.9999999; SPA_KEEP(xa); }
-    const bool small = xa < 0.5;
+    const double xa = spa_fabs(x);
     const double t2 = xa + xa;
     const double d1 = 1.0 - xa;
     const double r1 = spa_recip(d1);
-    const double n1 = small ? t2 * xa : t2;
-    const double q1 = spa_div_r(n1, d1, r1);
-    const double y = small ? t2 + q1 : q1;
+    double y;
+    if (xa < 0.5) {
+        y = t2 + spa_div_r(t2 * xa, d1, r1);
+        SPA_KEEP(y);
+    } else {
+        y = spa_div_r(t2, d1, r1);
+        SPA_KEEP(y);
+    }
     // log1p(y)
     double f, l;
     const bool direct = int32_t(SPA_BITS_HI(y)) < 0x3FDA827A;
+    const double u = 1.0 + y;
+    const uint32_t hu0 = SPA_BITS_HI(u), hu = hu0 & 0x000fffffu;
+    const bool lowhalf = hu < 0x6a09eu;
     if (direct) {
         f = y;
         SPA_KEEP(f);
     } else {
-        double u = 1.0 + y;
-        uint32_t hu = SPA_BITS_HI(u) & 0x000fffffu;
-        const bool lowhalf = hu < 0x6a09eu;
-        u = SPA_MAKE(hu | (lowhalf ? 0x3ff00000u : 0x3fe00000u), SPA_LO(u));
-        f = u - 1.0;
+        f = SPA_MAKE(hu | (lowhalf ? 0x3ff00000u : 0x3fe00000u), SPA_LO(u)) - 1.0;
         SPA_KEEP(f);
     }
     const double hfsq = 0.5 * f * f;
@@ -195,17 +205,22 @@ SPA_FN double spa_atanh_x2(double x) {
         l = f - (hfsq - sr);
         SPA_KEEP(l);
     } else {
-        const double u = 1.0 + y;
-        const int32_t hu0 = int32_t(SPA_BITS_HI(u));
-        int32_t k = (hu0 >> 20) - 1023;
-        double c = (k > 0) ? 1.0 - (u - y) : y - (u - 1.0);
+        // not direct => y >= 0.41421 => u >= 1.41421 => the biased exponent of u is 0x3ff (k = 0, mantissa in the upper half,
+        // normalised to u/2: k = 1) or larger (k > 0)
+        int32_t k = int32_t(hu0 >> 20) - 1023;
+        double c;
+        if (k > 0) {
+            c = 1.0 - (u - y);
+            SPA_KEEP(c);
+        } else {
+            c = y - (u - 1.0);
+            SPA_KEEP(c);
+        }
         c = spa_div_r(c, u, spa_recip(u));
-        const uint32_t hu = uint32_t(hu0) & 0x000fffffu;
-        const bool lowhalf = hu < 0x6a09eu;
         k = lowhalf ? k : k + 1;
         const double dk = double(k);
-        const uint32_t hz = lowhalf ? hu : (0x00100000u - hu) >> 2;
-        if (__builtin_expect(hz == 0, 0)) {
+        // |f| < 2^-20 <=> the normalised mantissa word is 0 (lower half) or within 3 of 2^20 (upper half, (2^20 - hu) >> 2 == 0)
+        if (__builtin_expect(((hu + 3u) & 0x000fffffu) < 4u, 0)) {
             if (f == 0.0) {
                 l = dk * ln2_hi + (c + dk * ln2_lo);
             } else {

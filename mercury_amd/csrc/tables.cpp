@@ -120,6 +120,7 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         if (off + need > size) throw std::runtime_error("LDPC table blob truncated");
         if (int(k) != K) { off += need; continue; }
         LdpcGraph g;
+        if (N != 1600) throw std::runtime_error("LDPC table blob: N must be 1600 (the decoders' LDS layout is fixed to it)");
         g.K = K; g.P = P; g.N = N; g.E = E; g.Cwidth = cw; g.Vwidth = vw;
         const uint8_t* cdeg = blob + off;
         const uint8_t* cflat = cdeg + P;
@@ -169,8 +170,7 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         if (g.S >= 8192) throw std::runtime_error("padded edge count exceeds the 13-bit slot field");
         g.spack.assign(g.S, 0u);
         g.svar.assign(g.S, 0);
-        g.sdesc.assign(size_t((g.S + 1023) / 1024) * 1024, 0u);
-        g.bin_end.assign(size_t((g.S + 1023) / 1024) * 16, 0ull);
+        g.sdesc.assign(size_t((g.S + 1023) / 1024 + 1) * 1024, 0u);    // one extra all-padding round: the kernels always prefetch round r+1
         std::vector<uint32_t> slot_of_edge(E);
         for (size_t b = 0; b < members.size(); ++b) {
             uint32_t p = uint32_t(b) * 64;
@@ -180,8 +180,7 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
                     const uint32_t eo = g.cptr[c] + j;
                     g.spack[p] = cs | (d << 13) | (j << 19) | 0x80000000u;
                     g.svar[p] = g.cvar[eo];
-                    g.sdesc[p] = cs | (d << 13) | (uint32_t(g.cvar[eo]) << 19);
-                    if (j + 1 == d) g.bin_end[p >> 6] |= 1ull << (p & 63);
+                    g.sdesc[p] = cs | (d << 13) | (uint32_t(g.cvar[eo]) << 19) | (j + 1 == d ? 0x80000000u : 0u);
                     slot_of_edge[eo] = p;
                 }
             }

@@ -45,8 +45,7 @@ struct LdpcGraph {
     int S = 0;                     // padded slot count = 64 * bins
     std::vector<uint32_t> spack;   // [S] check_start_slot | deg<<13 | pos<<19 | valid<<31 (0 for padding)
     std::vector<uint16_t> svar;    // [S] variable of the slot's edge (0 for padding)
-    std::vector<uint64_t> bin_end; // [ceil(S/1024)*16] per bin: bit l set <=> slot 64*bin + l is the last edge of a check
-    std::vector<uint32_t> sdesc;   // [ceil(S/1024)*1024] what the decoders read per slot: check_start | deg<<13 | variable<<19, 0 for padding
+    std::vector<uint32_t> sdesc;   // [(ceil(S/1024)+1)*1024] what the decoders read per slot: check_start | deg<<13 | variable<<19 | last-edge-of-check<<31, 0 for padding
     std::vector<uint32_t> vinfo;   // [N][8] (6 used) variable | deg<<11, then 10 u16 padded-slot indices; rows sorted by degree (descending)
 };
 
