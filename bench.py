@@ -295,20 +295,40 @@ def main():
                 traffic = json.load(open(tfile)).get("%s_cfg%d" % (args.decoder, args.cfg))
             except Exception:
                 traffic = None
-        # secondary view for the bound the decoders actually hit (vector-instruction issue): the instruction count of one launch
-        # of THIS workload from the committed PMC pass, over the launch time measured in this run
+        # secondary view for the bound the decoders actually hit (vector-instruction issue). The dynamic opcode mix of one
+        # launch of THIS workload comes from the committed PMC passes (profiles/r02_instruction_mix.json, tools/collect_pmc_mix.sh),
+        # the issue cost of each opcode class from the micro-benchmark measured on the same kind of box
+        # (profiles/r02_valu_cycles.json, tools/ubench/valu_cycles.hip); issue cycles needed = sum(count x cost), available =
+        # SIMDs x clock x kernel time of this run. Two readings: "isolated" prices every class at its back-to-back cost (32-bit
+        # operations 2 cycles), "slots" at one 4-cycle issue slot per instruction (what a mixed fp64 stream pays:
+        # MIX_FMA_CND in the micro-benchmark) — the truth lies between them.
         issue = None
-        sfile = os.path.join(ROOT, "profiles", "r01_pmc_sq_summary.json")
-        if (os.path.exists(sfile) and not args.ldpc_only and args.cfg == 8 and F == 4096 and args.iters == 50
+        mfile, cfile = os.path.join(ROOT, "profiles", "r02_instruction_mix.json"), os.path.join(ROOT, "profiles", "r02_valu_cycles.json")
+        if (os.path.exists(mfile) and os.path.exists(cfile) and not args.ldpc_only and args.cfg == 8 and F == 4096 and args.iters == 50
                 and abs(iters_per_launch - 50.0 * F) < 1e-6 * F):
             try:
-                insts = float(json.load(open(sfile))[args.decoder]["SQ_INSTS_VALU"])
-                peak = 256 * 4 * 2.4e9 / 4            # SIMDs x clock / 4 cycles per wave64 instruction (MI355X_MICROARCH.md)
-                issue = {"bound": "valu_issue", "achieved": insts / (dec_ms * 1e-3) / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
-                         "frac": insts / (dec_ms * 1e-3) / peak,
-                         "source": "SQ_INSTS_VALU per launch from profiles/r01_pmc_sq_summary.json (same workload) / kernel time of this run"}
-            except Exception:
-                issue = None
+                mix = json.load(open(mfile))[args.decoder]
+                cyc = {k.split("/")[0]: v["cycles_at_2p4ghz"] for k, v in json.load(open(cfile))["results"].items() if k.endswith("/8w")}
+                fp64 = mix["SQ_INSTS_VALU_ADD_F64"] + mix["SQ_INSTS_VALU_MUL_F64"] + mix["SQ_INSTS_VALU_FMA_F64"]
+                fp32 = mix["SQ_INSTS_VALU_ADD_F32"] + mix["SQ_INSTS_VALU_MUL_F32"] + mix["SQ_INSTS_VALU_FMA_F32"]
+                classes = {"fp64": (fp64, cyc["FMA_F64"]), "trans_f64": (mix["SQ_INSTS_VALU_TRANS_F64"], cyc["RCP_F64"]),
+                           "fp32": (fp32, cyc["FMA_F32"]), "trans_f32": (mix["SQ_INSTS_VALU_TRANS_F32"], cyc["RCP_F32"]),
+                           "int32": (mix["SQ_INSTS_VALU_INT32"], cyc["AND_B32"]), "cvt": (mix["SQ_INSTS_VALU_CVT"], cyc["CVT_F64_I32"]),
+                           "int64": (mix["SQ_INSTS_VALU_INT64"], cyc["LSHL_ADD"])}
+                rest = mix["SQ_INSTS_VALU"] - sum(c for c, _ in classes.values())
+                classes["compare_select_move"] = (rest, 0.5 * (cyc["CMP_U32"] + cyc["MOV_B32"]))
+                isolated = sum(c * w for c, w in classes.values())
+                slots = sum(c * max(w, cyc["FMA_F64"]) for c, w in classes.values())
+                avail = 256 * 4 * 2.4e9 * dec_ms * 1e-3
+                issue = {"bound": "valu_issue", "unit": "SIMD issue cycles per launch", "available": avail,
+                         "needed_isolated_costs": isolated, "frac_isolated": isolated / avail,
+                         "needed_4cycle_slots": slots, "frac_slots": slots / avail, "frac": slots / avail,
+                         "valu_instructions_per_launch": mix["SQ_INSTS_VALU"],
+                         "classes": {k: {"count": c, "cycles_each": w} for k, (c, w) in classes.items()},
+                         "source": "opcode mix: profiles/r02_instruction_mix.json (PMC, same workload); costs: profiles/r02_valu_cycles.json "
+                                   "(micro-benchmark); time: this run"}
+            except Exception as e:                       # a stale profile must not break the bench line
+                issue = {"error": repr(e)}
         line = {
             "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (rx.K, args.iters)) if args.ldpc_only else
                       ("RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters)),
@@ -334,8 +354,7 @@ def main():
                          "secondary": issue,
                          "bytes_per_codeword_iteration": b_iter,
                          "note": "algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are LDS-resident so real HBM "
-                                 "traffic is far lower; the decoder is VALU-issue bound (profiles/r01_pmc_sq_*.csv: SQ_ACTIVE_INST_VALU "
-                                 "x 4 cycles ~95% of SIMD cycles for spa, fp64), not HBM bound"},
+                                 "traffic is far lower; the decoders are bound by vector-instruction issue (see secondary), not by HBM"},
         }
         # the outputs of the last timed step, kept aside before the extras reuse the buffers: the cpu_baseline leg checks them
         S_chk = min(F, args.cpu_sample_per_core * usable_cores())
