@@ -71,6 +71,9 @@ typedef struct mgpu_config {
     float minsum_alpha;   /* normalisation factor for MGPU_DEC_MINSUM (0 -> 0.8) */
     int mfsk_ctrl_mode;   /* 1 = short MFSK control frames (cl_telecom_system::set_mfsk_ctrl_mode, telecom_system.cc:1572);
                              ignored unless cfg is ROBUST_0 / ROBUST_1 */
+    int test_puncture_nBits; /* cl_telecom_system::test_puncture_nBits (telecom_system.h:111, the punctured-LDPC BER-test hook of
+                             main.cc:775): > 0 = demodulated MFSK LLRs from this position on are erasures (telecom_system.cc:1186-1192);
+                             0 = disabled. MFSK modes only, like the reference */
 } mgpu_config;
 
 typedef struct mgpu_info {

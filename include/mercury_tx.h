@@ -10,8 +10,10 @@
  *
  * Parity: pinned. The same composition built from the reference's own objects (oracle/ref_harness.cc:mref_transmit_byte)
  * fixes the CPU restatement bit for bit, and the GPU output must equal it bit for bit (tests/test_transmit_byte.py).
- * Not built: the FIRST/MIDDLE/FLUSH_MESSAGE overlap-save variants (:559-590) that filter across consecutive frames, and
- * pre_equalization_channel (all ones unless a GUI calibration sets it).
+ * The FIRST / MIDDLE / FLUSH_MESSAGE overlap-save variants (:559-590), which filter across consecutive calls through the
+ * 3-frame passband_data_tx_buffer, are batched too: F consecutive calls in one, the buffer kept in the context between
+ * calls (mgpu_transmit_buffer reads or replaces it). Not built: pre_equalization_channel (all ones unless a GUI
+ * calibration sets it).
  */
 #ifndef MERCURY_TX_H
 #define MERCURY_TX_H
@@ -24,6 +26,10 @@
 extern "C" {
 #endif
 
+#define MGPU_FIRST_MESSAGE 0       /* include/common/common_defines.h:197: first call of a stream (telecom_system.cc:559-566); message 0 of the
+                                      batch is the FIRST_MESSAGE call, the following ones MIDDLE_MESSAGE calls (TX_RAND_process_main, :2023-2041) */
+#define MGPU_MIDDLE_MESSAGE 1      /* :198 (telecom_system.cc:568-574) */
+#define MGPU_FLUSH_MESSAGE 2       /* :199 (same path as MIDDLE_MESSAGE) */
 #define MGPU_SINGLE_MESSAGE 3      /* include/common/common_defines.h:200 */
 #define MGPU_NO_FILTER_MESSAGE 4   /* :201 — stop after peak_clip (what the ARQ batch sender asks for, arq_common.cc:2224) */
 #define MGPU_BATCH_MESSAGE 16      /* not a reference constant: the whole signal path of cl_arq_controller::send_batch
@@ -38,7 +44,8 @@ typedef struct mgpu_transmit_config {
     double preamble_papr_cut;   /* physical_config.cc:115: 7 (dB) */
     double data_papr_cut;       /* :116: 10 (dB) */
     uint64_t start_sample;      /* cl_ofdm::passband_start_sample when the call starts: the carrier phase origin (ofdm.cc:2311-2313) */
-    int message_location;       /* MGPU_SINGLE_MESSAGE, MGPU_NO_FILTER_MESSAGE or MGPU_BATCH_MESSAGE */
+    int message_location;       /* MGPU_FIRST / MIDDLE / FLUSH / SINGLE / NO_FILTER / BATCH_MESSAGE; with the first three a call returns,
+                                   per message, what the reference's call returns: the PREVIOUS frame filtered with its neighbours */
     int phase_continuous;       /* 0: every message starts at start_sample (F independent transmitters);
                                    1: message f starts at start_sample + f * (active samples), as F consecutive calls would
                                    (always so for MGPU_BATCH_MESSAGE) */
@@ -56,6 +63,11 @@ int mgpu_transmit_byte_batch(mgpu_ctx* ctx, const uint8_t* payload, int payload_
  * transmit call, so keep one context's calls on one stream); with NULL the context's own stream is used and synchronised */
 int mgpu_transmit_byte_batch_dev(mgpu_ctx* ctx, const void* d_payload, int payload_stride, const void* d_nbytes, int F,
                                  const mgpu_transmit_config* config, void* d_passband, void* stream);
+
+/* data_container.passband_data_tx_buffer (data_container.cc:163): the 3 frames of unfiltered audio the FIRST / MIDDLE / FLUSH_MESSAGE
+ * calls carry from one to the next, [3 * total_frame_size] host doubles. set = 0 copies it out, set = 1 replaces it. A new context
+ * starts with zeros (the reference with uninitialised memory). */
+int mgpu_transmit_buffer(mgpu_ctx* ctx, double* buffer, int set);
 
 /* cl_telecom_system::generate_ack_pattern_passband (pattern 1; telecom_system.cc:1589-1631) and
  * generate_break_pattern_passband (pattern 2; :1659-1689): the 16 known tone symbols the detector of mercury_gpu.h

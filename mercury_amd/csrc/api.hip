@@ -72,6 +72,7 @@ void ctx_alloc(mgpu_ctx* c) {
     d.mfsk_M = t.mfsk_M; d.mfsk_nbits = t.mfsk_nbits; d.mfsk_nstreams = t.mfsk_nstreams; d.mfsk_hop = t.mfsk_hop;
     d.mfsk_off0 = t.mfsk_off[0]; d.mfsk_off1 = t.mfsk_off[1];
     d.active_nsymb = t.active_nsymb; d.active_nbits = t.active_nbits; d.mfsk_amp = t.mfsk_amp;
+    d.puncture_from = (c->cfg.test_puncture_nBits > 0 && c->cfg.test_puncture_nBits < t.active_nbits) ? c->cfg.test_puncture_nBits : t.active_nbits;
     LdpcDev& l = c->ldev;
     l.spack = d.spack; l.svar = d.svar; l.vinfo = d.vinfo; l.sdesc = d.sdesc; l.scrambler = d.scrambler;
     l.cptr = d.cptr; l.cvar = d.cvar;
@@ -337,6 +338,7 @@ int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
     if (cfg->max_iters < 1 || cfg->max_iters > 1000) { g_create_error = "max_iters out of range"; return MGPU_ERR_ARG; }
     if (cfg->decoder < 0 || cfg->decoder > MGPU_DEC_SPA_FAST) { g_create_error = "unknown decoder"; return MGPU_ERR_ARG; }
     if (cfg->max_batch < 1) { g_create_error = "max_batch must be >= 1"; return MGPU_ERR_ARG; }
+    if (cfg->test_puncture_nBits < 0) { g_create_error = "test_puncture_nBits must be >= 0"; return MGPU_ERR_ARG; }
     mgpu_ctx* c = new mgpu_ctx();
     c->cfg = *cfg;
     c->max_batch = cfg->max_batch;

@@ -39,6 +39,7 @@ struct MgpuDev {
     // MFSK modes (mfsk_M == 0 for the OFDM modes)
     int mfsk_M, mfsk_nbits, mfsk_nstreams, mfsk_hop, mfsk_off0, mfsk_off1;
     int active_nsymb, active_nbits;
+    int puncture_from;             // demodulated LLRs from this position on are erasures: min(active_nbits, test_puncture_nBits)
     double mfsk_amp;
 };
 

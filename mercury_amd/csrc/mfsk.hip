@@ -161,6 +161,7 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
             else if (llr > 5.0) llr = 5.0;
             else if (llr < -5.0) llr = -5.0;
             const int idx = s * BPS + st * NB + m;
+            if (idx >= T.puncture_from) llr = 0.0;                  // test_puncture_nBits (telecom_system.cc:1186-1192)
             out[T.llr_dst[idx]] = float(llr);
             if (taps.llr_demod) taps.llr_demod[size_t(f) * T.nBits + idx] = float(llr);
         }

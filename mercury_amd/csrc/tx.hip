@@ -8,6 +8,7 @@
 // Everything is FP64 in the reference's operation order (no FMA contraction in this TU), so the samples equal the
 // reference's bit for bit; the carrier cos/sin and the two pow() constants come from the host libm like the reference's.
 #include <cmath>
+#include <memory>
 #include <map>
 
 #include "ctx.hpp"
@@ -174,6 +175,8 @@ struct TxState {
     int ntaps[2] = {0, 0};
     double* d_cs = nullptr;
     size_t cs_cap = 0;
+    double* d_tx_buffer = nullptr;                      // passband_data_tx_buffer: 3 frames of unfiltered audio carried between the
+                                                        // FIRST / MIDDLE / FLUSH_MESSAGE calls (telecom_system.cc:559-590); zero at first
     void* d_work[3] = {nullptr, nullptr, nullptr};      // data baseband, clipped passband, first filter's output: grown on demand, kept
     size_t work_cap[3] = {0, 0, 0};
     void* work(int i, size_t bytes, hipStream_t s) {
@@ -190,7 +193,7 @@ struct TxState {
     uint64_t cs_start = 0;
     size_t cs_count = 0;
     ~TxState() {
-        (void)hipFree(d_pre_bb); (void)hipFree(d_fir[0]); (void)hipFree(d_fir[1]); (void)hipFree(d_cs);
+        (void)hipFree(d_pre_bb); (void)hipFree(d_fir[0]); (void)hipFree(d_fir[1]); (void)hipFree(d_cs); (void)hipFree(d_tx_buffer);
         for (void* p : d_work) (void)hipFree(p);
     }
 };
@@ -203,15 +206,18 @@ void launch_symbol_mod(mgpu_ctx* c, const double* d_carriers, int n, double* d_o
 
 TxState& tx_state(mgpu_ctx* c, hipStream_t s) {
     if (!c->tx_state) {
-        auto* st = new TxState;
-        c->tx_state = st;
-        c->tx_state_free = free_tx_state;
+        std::unique_ptr<TxState> st(new TxState);            // published in the context only once it is complete
         const auto& t = c->tab;
         DevBuf d_car(t.preamble_carriers.size() * 16);
         HIPCK(hipMemcpyAsync(d_car.p, t.preamble_carriers.data(), t.preamble_carriers.size() * 16, hipMemcpyHostToDevice, s));
         HIPCK(hipMalloc(reinterpret_cast<void**>(&st->d_pre_bb), size_t(t.preamble) * t.Nofdm * 16));
         launch_symbol_mod(c, d_car.as<double>(), t.preamble, st->d_pre_bb, s);
+        const size_t total = size_t(t.Nofdm) * (t.Nsymb + t.preamble) * 4;
+        HIPCK(hipMalloc(reinterpret_cast<void**>(&st->d_tx_buffer), 3 * total * 8));
+        HIPCK(hipMemsetAsync(st->d_tx_buffer, 0, 3 * total * 8, s));
         HIPCK(hipStreamSynchronize(s));
+        c->tx_state = st.release();
+        c->tx_state_free = free_tx_state;
     }
     return *static_cast<TxState*>(c->tx_state);
 }
@@ -245,7 +251,13 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
     const int used = (npre + ndata) * interp;
     TxState& st = tx_state(c, s);
     const bool batch = cfg.message_location == MGPU_BATCH_MESSAGE;
-    const bool filtered = cfg.message_location == MGPU_SINGLE_MESSAGE || batch;
+    // FIRST / MIDDLE / FLUSH_MESSAGE (telecom_system.cc:559-590): call n filters the span that starts half a frame into the 3-frame
+    // buffer [B0, B1 (FIRST: x_n), x_n] and returns its middle frame; the buffer then moves on one frame. Over F consecutive calls
+    // the spans are windows of ONE concatenation cat = [B0, B1 or x_0, x_0, x_1, ..., x_(F-1)] (frame n, n+1, n+2 for call n), and
+    // an output sample sits at least T/2 - 96 samples inside its window, beyond the reach of the two 97-tap filters, so every
+    // sum has exactly the terms, in the order, it has in the reference's per-call filtering: out_n = frame n+1 of FIR2(FIR1(cat)).
+    const bool stream_mode = cfg.message_location >= MGPU_FIRST_MESSAGE && cfg.message_location <= MGPU_FLUSH_MESSAGE;
+    const bool filtered = cfg.message_location == MGPU_SINGLE_MESSAGE || batch || stream_mode;
     const bool continuous = cfg.phase_continuous || batch;
     ensure_carrier_table(st, cfg.carrier_hz, cfg.start_sample, continuous ? size_t(used) * F : size_t(used), s);
     if (filtered && st.carrier != cfg.carrier_hz) {
@@ -270,10 +282,10 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
 
     double* const bb = static_cast<double*>(st.work(0, size_t(F) * t.frame_samples * 16, s));
     // batch form: one padding frame in front of and behind the F frames (arq_common.cc:2236-2240)
-    const size_t pad = batch ? size_t(total) : 0;
+    const size_t pad = batch || stream_mode ? size_t(total) : 0;
     double* const t0 = filtered ? static_cast<double*>(st.work(1, (size_t(F) * total + 2 * pad) * 8, s)) : nullptr;
     double* const t1_all = filtered ? static_cast<double*>(st.work(2, (size_t(F) * total + 2 * pad) * 8, s)) : nullptr;
-    double* clipped = filtered ? t0 + pad : d_out;
+    double* clipped = filtered ? t0 + (stream_mode ? 2 * pad : pad) : d_out;     // stream form: two history frames in front
     for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
         const int n = std::min(F - off, kMaxFramesPerLaunch);
         hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(n), dim3(256), c->lds_tx, s, c->dev, uint64_t(0), uint64_t(0), n, 0.0, -1,
@@ -292,7 +304,7 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
         HIPCK(hipGetLastError());
         hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(n, 2), dim3(256), 0, s, o, total, npre * interp, used, pow_pre, pow_data);
         HIPCK(hipGetLastError());
-        if (filtered && !batch) {
+        if (filtered && !batch && !stream_mode) {
             double* t1 = t1_all + size_t(off) * total;
             for (int w = 0; w < 2; ++w) {
                 double* dst = w ? d_out + size_t(off) * total : t1;
@@ -301,10 +313,19 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
             }
         }
     }
-    if (batch) {        // arq_common.cc:2236-2248: pad with the first / last frame, filter the concatenation, keep the middle
+    if (batch || stream_mode) {
         const size_t ncat = size_t(F + 2) * total;
-        HIPCK(hipMemcpyAsync(t0, t0 + total, size_t(total) * 8, hipMemcpyDeviceToDevice, s));
-        HIPCK(hipMemcpyAsync(t0 + size_t(F + 1) * total, t0 + size_t(F) * total, size_t(total) * 8, hipMemcpyDeviceToDevice, s));
+        if (batch) {    // arq_common.cc:2236-2248: pad with the first / last frame, filter the concatenation, keep the middle
+            HIPCK(hipMemcpyAsync(t0, t0 + total, size_t(total) * 8, hipMemcpyDeviceToDevice, s));
+            HIPCK(hipMemcpyAsync(t0 + size_t(F + 1) * total, t0 + size_t(F) * total, size_t(total) * 8, hipMemcpyDeviceToDevice, s));
+        } else {        // history in front: B0, then B1 (FIRST_MESSAGE: the first frame itself, :559-566)
+            HIPCK(hipMemcpyAsync(t0, st.d_tx_buffer, size_t(total) * 8, hipMemcpyDeviceToDevice, s));
+            HIPCK(hipMemcpyAsync(t0 + total, cfg.message_location == MGPU_FIRST_MESSAGE ? t0 + 2 * size_t(total) : st.d_tx_buffer + total, size_t(total) * 8,
+                                 hipMemcpyDeviceToDevice, s));
+            // the buffer after the last call's shift_left (:584): [frame F, frame F+1, frame F+1] of the concatenation
+            HIPCK(hipMemcpyAsync(st.d_tx_buffer, t0 + size_t(F) * total, 2 * size_t(total) * 8, hipMemcpyDeviceToDevice, s));
+            HIPCK(hipMemcpyAsync(st.d_tx_buffer + 2 * size_t(total), t0 + size_t(F + 1) * total, size_t(total) * 8, hipMemcpyDeviceToDevice, s));
+        }
         hipLaunchKernelGGL(mgpu_fir97_kernel, dim3(unsigned((ncat + FIR97_OUT - 1) / FIR97_OUT), 1), dim3(256), 0, s, t0, int(ncat), st.d_fir[0], t1_all, 0,
                            int(ncat));
         HIPCK(hipGetLastError());
@@ -317,9 +338,10 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
 
 void check_config(const mgpu_ctx* c, const mgpu_transmit_config* cfg, int payload_stride, int F) {
     need(cfg != nullptr && F >= 0, "bad argument");
-    need(cfg->message_location == MGPU_SINGLE_MESSAGE || cfg->message_location == MGPU_NO_FILTER_MESSAGE || cfg->message_location == MGPU_BATCH_MESSAGE,
-         "message_location must be MGPU_SINGLE_MESSAGE, MGPU_NO_FILTER_MESSAGE or MGPU_BATCH_MESSAGE");
-    need(cfg->message_location != MGPU_BATCH_MESSAGE || (size_t(F) + 2) * size_t(mgpu_transmit_frame_samples(const_cast<mgpu_ctx*>(c))) < (size_t(1) << 31),
+    const bool stream_mode = cfg->message_location >= MGPU_FIRST_MESSAGE && cfg->message_location <= MGPU_FLUSH_MESSAGE;
+    need(cfg->message_location == MGPU_SINGLE_MESSAGE || cfg->message_location == MGPU_NO_FILTER_MESSAGE || cfg->message_location == MGPU_BATCH_MESSAGE ||
+             stream_mode, "message_location must be MGPU_FIRST/MIDDLE/FLUSH/SINGLE/NO_FILTER/BATCH_MESSAGE");
+    need(!(cfg->message_location == MGPU_BATCH_MESSAGE || stream_mode) || (size_t(F) + 2) * size_t(mgpu_transmit_frame_samples(const_cast<mgpu_ctx*>(c))) < (size_t(1) << 31),
          "batch too long for one filtering pass (2^31 samples)");
     need(payload_stride >= c->tab.payload_bytes, "payload_stride is shorter than the frame's payload");
     need(cfg->carrier_hz > 0 && cfg->carrier_hz < kSampleRate / 2 && cfg->output_power_watt >= 0, "bad carrier or power");
@@ -362,6 +384,19 @@ int mgpu_transmit_byte_batch(mgpu_ctx* c, const uint8_t* payload, int payload_st
         if (nbytes) HIPCK(hipMemcpyAsync(d_nb.p, nbytes, size_t(F) * 4, hipMemcpyHostToDevice, s));
         transmit_dev(c, d_pl.as<uint8_t>(), payload_stride, nbytes ? d_nb.as<int>() : nullptr, F, *cfg, d_out.as<double>(), s);
         HIPCK(hipMemcpyAsync(passband, d_out.p, size_t(F) * total * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+int mgpu_transmit_buffer(mgpu_ctx* c, double* buffer, int set) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(buffer != nullptr, "bad argument");
+        hipStream_t s = c->stream;
+        TxState& st = tx_state(c, s);
+        const size_t bytes = 3 * size_t(mgpu_transmit_frame_samples(c)) * 8;
+        if (set) HIPCK(hipMemcpyAsync(st.d_tx_buffer, buffer, bytes, hipMemcpyHostToDevice, s));
+        else HIPCK(hipMemcpyAsync(buffer, st.d_tx_buffer, bytes, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
     });
 }

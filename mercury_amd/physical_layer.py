@@ -25,7 +25,7 @@ EST_ZF, EST_LS = 0, 1
 class Config(C.Structure):
     _fields_ = [("cfg", C.c_int), ("max_iters", C.c_int), ("decoder", C.c_int), ("agc", C.c_int),
                 ("variance_source", C.c_int), ("device", C.c_int), ("max_batch", C.c_int),
-                ("minsum_alpha", C.c_float), ("mfsk_ctrl_mode", C.c_int)]
+                ("minsum_alpha", C.c_float), ("mfsk_ctrl_mode", C.c_int), ("test_puncture_nBits", C.c_int)]
 
 
 INFO_FIELDS = ("cfg M bits_per_symbol K P N Nsymb Nc Nfft Ngi Nofdm nData nBits nPilots nVirtual nReal "
@@ -52,6 +52,7 @@ class TransmitConfig(C.Structure):     # include/mercury_tx.h
                 ("message_location", C.c_int), ("phase_continuous", C.c_int)]
 
 
+FIRST_MESSAGE, MIDDLE_MESSAGE, FLUSH_MESSAGE = 0, 1, 2
 SINGLE_MESSAGE, NO_FILTER_MESSAGE, BATCH_MESSAGE = 3, 4, 16
 
 LINK_STATE_DTYPE = np.dtype([("delay_of_last_decoded_message", "<i4"), ("freq_offset_of_last_decoded_message", "<f8"),
@@ -104,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_measure_signal_only",
-    "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
+    "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_transmit_buffer", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
     "mgpu_symbol_demod", "mgpu_automatic_gain_control", "mgpu_channel_estimator", "mgpu_restore_channel_amplitude", "mgpu_channel_equalizer",
     "mgpu_measure_variance", "mgpu_deframer", "mgpu_deinterleaver_c128", "mgpu_deinterleaver_f32", "mgpu_psk_demod",
     "mgpu_bit_energy_dispersal", "mgpu_bit_to_byte", "mgpu_crc16_modbus_rtu",
@@ -149,10 +150,10 @@ class RxPhy:
     """One GPU receive context for one Mercury mode (``load_configuration(cfg)`` equivalent)."""
 
     def __init__(self, cfg, max_iters=50, decoder=DEC_SPA, agc=1, variance_source=1, device=0,
-                 max_batch=4096, minsum_alpha=0.0, mfsk_ctrl_mode=False):
+                 max_batch=4096, minsum_alpha=0.0, mfsk_ctrl_mode=False, test_puncture_nbits=0):
         self.lib = load_library()
         self.h = C.c_void_p()
-        c = Config(cfg, max_iters, decoder, agc, variance_source, device, max_batch, minsum_alpha, 1 if mfsk_ctrl_mode else 0)
+        c = Config(cfg, max_iters, decoder, agc, variance_source, device, max_batch, minsum_alpha, 1 if mfsk_ctrl_mode else 0, test_puncture_nbits)
         rc = self.lib.mgpu_create(C.byref(c), C.byref(self.h))
         if rc != 0:
             raise MgpuError("mgpu_create failed (%d): %s" % (rc, self.lib.mgpu_last_error(None).decode()))
@@ -332,6 +333,20 @@ class RxPhy:
         amp = float(np.sqrt(2.0)) if carrier_amplitude is None else carrier_amplitude
         return TransmitConfig(carrier_hz, amp, output_power_watt, preamble_papr_cut, data_papr_cut, start_sample, message_location,
                               phase_continuous)
+
+    def transmit_buffer(self, buffer=None):
+        """passband_data_tx_buffer of the FIRST / MIDDLE / FLUSH_MESSAGE calls: read it (buffer=None) or replace it."""
+        n = 3 * self.transmit_frame_samples()
+        if buffer is None:
+            out = np.zeros(n)
+            self._ck(self.lib.mgpu_transmit_buffer(self.h, _ptr(out), C.c_int(0)))
+            return out
+        b = np.ascontiguousarray(buffer, np.float64)
+        if b.size != n:
+            raise MgpuError("the transmit buffer is 3 frames = %d samples" % n)
+        self._ck(self.lib.mgpu_transmit_buffer(self.h, _ptr(b), C.c_int(1)))
+        return b
+        return b
 
     def transmit_byte(self, payload, carrier_hz, nbytes=None, **kw):
         """cl_telecom_system::transmit_byte for F messages: payload uint8 [F, >= payload_bytes] -> float64 [F, total_frame_size]."""

@@ -79,6 +79,7 @@ struct morc {
     /* MFSK modes (ROBUST_0..2 = cfg 100..102): mfsk.cc:48-162, telecom_system.cc:2968-2989 */
     int mfsk_M, mfsk_nbits, mfsk_nstreams, mfsk_hop, mfsk_off[4];
     int ctrl_nbits, ctrl_nsymb, active_nbits, active_nsymb;
+    int test_puncture_nbits;   /* cl_telecom_system::test_puncture_nBits, telecom_system.h:111 (0: disabled) */
     int* type;          /* [Nsymb*Nc] */
     cd* pilot_seq;      /* [nPilots] */
     cd* pilot_grid;     /* [Nsymb*Nc] pilot value at pilot cells */
@@ -360,6 +361,7 @@ void morc_set_ctrl_mode(morc* o, int enable) {
     o->active_nsymb = (on && o->ctrl_nsymb > 0) ? o->ctrl_nsymb : o->Nsymb;
     o->active_nbits = (on && o->ctrl_nbits > 0) ? o->ctrl_nbits : o->nBits;
 }
+void morc_set_test_puncture(morc* o, int nBits) { o->test_puncture_nbits = nBits; }
 void morc_get_frame_types(morc* o, int* t) { memcpy(t, o->type, sizeof(int) * o->Nsymb * o->Nc); }
 void morc_get_pilot_seq(morc* o, double* s) { memcpy(s, o->pilot_seq, sizeof(cd) * o->nPilots); }
 void morc_get_scrambler(morc* o, int* s) { memcpy(s, o->scrambler, sizeof(int) * N_MAX); }
@@ -748,7 +750,11 @@ static void rx_mfsk(morc* o, const cd* bb, int flags, morc_rx_out* out) {
     if (out->grid) memcpy(out->grid, o->grid, sizeof(cd) * o->active_nsymb * Nc);
     float dem[N_MAX], dei[N_MAX];
     mfsk_demod(o, o->grid, o->active_nbits, dem);
-    for (int i = o->active_nbits; i < o->nBits; i++) dem[i] = 0.0f;      /* punctured tail, :1183-1191 */
+    {   /* punctured tail, :1183-1191; the BER-test hook test_puncture_nBits moves the cut forward */
+        int puncture_from = o->active_nbits;
+        if (o->test_puncture_nbits > 0 && o->test_puncture_nbits < puncture_from) puncture_from = o->test_puncture_nbits;
+        for (int i = puncture_from; i < o->nBits; i++) dem[i] = 0.0f;
+    }
     if (out->llr_demod) memcpy(out->llr_demod, dem, sizeof(float) * o->nBits);
     il_float(dem, dei, o->nBits, o->bit_blk, 1);
     for (int i = o->P - 1; i >= 0; i--) dei[i + o->nReal + o->nVirtual] = dei[i + o->nReal];
@@ -1117,6 +1123,36 @@ int morc_transmit_batch(morc* o, const int* payloads, int stride, const int* nby
     fir_apply_real(t2c, n2, f1, f2, n);
     memcpy(out, f2 + total, sizeof(double) * (size_t)F * total);
     free(cat); free(f1); free(f2);
+    return F * total;
+}
+
+/* transmit_byte's overlap-save message locations FIRST_MESSAGE (0) / MIDDLE_MESSAGE (1) / FLUSH_MESSAGE (2) — telecom_system.cc:559-590:
+ * F consecutive calls on one 3-frame passband_data_tx_buffer (buffer: [3*total], read and updated); each call puts its clipped,
+ * unfiltered frame into the last third (FIRST_MESSAGE also into the middle third), runs FIR_tx1 and FIR_tx2 over the 2-frame span
+ * that starts half a frame in, returns the middle frame of that span and shifts the buffer left by one frame (misc.cc:26-32).
+ * location 0: call 0 is FIRST_MESSAGE, the rest MIDDLE_MESSAGE (TX_RAND_process_main, :2023-2041). Same composition as
+ * oracle/ref_harness.cc:mref_transmit_stream, which pins it. out: [F][total]. */
+int morc_transmit_stream(morc* o, const int* payloads, int stride, const int* nbytes, int F, const morc_tx_config* c, double* buffer, double* out) {
+    const int interp = 4, total = o->Nofdm * (o->Nsymb + o->preamble) * interp, used = (o->preamble + o->active_nsymb) * o->Nofdm * interp;
+    if (c->message_location < 0 || c->message_location > 2) return -2;
+    double t1c[128], t2c[128];
+    int n1 = morc_tx_fir_taps(c->carrier_hz, 0, t1c), n2 = morc_tx_fir_taps(c->carrier_hz, 1, t2c);
+    double* tx = malloc(sizeof(double) * total);
+    double* f1 = malloc(sizeof(double) * 2 * (size_t)total); double* f2 = malloc(sizeof(double) * 2 * (size_t)total);
+    morc_tx_config cc = *c;
+    cc.message_location = 4;
+    for (int n = 0; n < F; n++) {
+        cc.start_sample = c->start_sample + (unsigned long long)n * used;
+        if (morc_transmit_byte(o, payloads + (size_t)n * stride, nbytes ? nbytes[n] : (o->nReal - 16) / 8, &cc, tx) < 0) { free(tx); free(f1); free(f2); return -1; }
+        int loc = (c->message_location == 0 && n > 0) ? 1 : c->message_location;
+        if (loc == 0) for (int i = 0; i < total; i++) { buffer[total + i] = tx[i]; buffer[2 * total + i] = tx[i]; }
+        else for (int i = 0; i < total; i++) buffer[2 * total + i] = tx[i];
+        fir_apply_real(t1c, n1, buffer + total / 2, f1, 2 * total);
+        fir_apply_real(t2c, n2, f1, f2, 2 * total);
+        memcpy(out + (size_t)n * total, f2 + total / 2, sizeof(double) * total);
+        for (int j = 0; j < 2 * total; j++) buffer[j] = buffer[j + total];
+    }
+    free(tx); free(f1); free(f2);
     return F * total;
 }
 

@@ -71,6 +71,8 @@ morc* morc_create(int cfg, int max_iters, const char* tables_path);
 void morc_destroy(morc*);
 void morc_get_info(morc*, morc_info*);
 void morc_set_ctrl_mode(morc*, int enable);         /* cl_telecom_system::set_mfsk_ctrl_mode, telecom_system.cc:1572 */
+/* cl_telecom_system::test_puncture_nBits (telecom_system.h:111; telecom_system.cc:1186-1192): MFSK LLRs from this position on are erasures */
+void morc_set_test_puncture(morc*, int nBits);
 
 void morc_get_frame_types(morc*, int* types);       /* [Nsymb*Nc] 0=DATA 1=PILOT */
 void morc_get_pilot_seq(morc*, double* seq);        /* [nPilots*2] */
@@ -121,6 +123,9 @@ int morc_tx_fir_taps(double carrier_hz, int which, double* taps);
 /* the signal path of cl_arq_controller::send_batch (arq_common.cc:2224-2248): F messages unfiltered with the carrier running on,
  * the first and last frame repeated as padding, both transmit filters over the concatenation; out: [F][total_frame_size] */
 int morc_transmit_batch(morc*, const int* payloads, int stride, const int* nbytes, int F, const morc_tx_config* cfg, double* out);
+/* FIRST / MIDDLE / FLUSH_MESSAGE (cfg->message_location 0 / 1 / 2; telecom_system.cc:559-590): F consecutive calls on one 3-frame
+ * passband_data_tx_buffer (buffer: [3*total_frame_size], read and updated); out: [F][total_frame_size] */
+int morc_transmit_stream(morc*, const int* payloads, int stride, const int* nbytes, int F, const morc_tx_config* cfg, double* buffer, double* out);
 /* generate_ack_pattern_passband / generate_break_pattern_passband (telecom_system.cc:1589-1631, :1659-1689): which 1 = ACK,
  * 2 = BREAK; out: 16*Nofdm*4 samples; uses carrier_hz, carrier_amplitude, output_power_watt, data_papr_cut, start_sample */
 int morc_generate_ack_pattern_passband(morc*, int which, const morc_tx_config* cfg, double* out_passband);   /* 0 = FIR_tx1 (HPF, Hamming), 1 = FIR_tx2 (LPF, Blackman) */

@@ -81,6 +81,7 @@ struct Ref {
     cl_mfsk ack_mfsk;                // universal ACK / BREAK tone patterns, every mode (telecom_system.cc:3003-3006)
     int ctrl_nBits, ctrl_nsymb;      // telecom_system.cc:2968-2989
     int active_nbits, active_nsymb;  // get_active_nbits / get_active_nsymb, telecom_system.cc:1577-1585
+    int test_puncture_nBits = 0;     // telecom_system.h:111 (0: disabled)
     int cfg, M, bps;
     int Nsymb, Nc, Nfft, Nofdm, nData, nBits, nPilots;
     int nVirtual, nReal;
@@ -243,6 +244,9 @@ void mref_set_ctrl_mode(void* h, int enable) {
     r->active_nbits = (on && r->ctrl_nBits > 0) ? r->ctrl_nBits : r->nBits;
 }
 
+// cl_telecom_system::test_puncture_nBits (telecom_system.h:111, set by main.cc:775; used at telecom_system.cc:1186-1192)
+void mref_set_test_puncture(void* h, int nBits) { ((Ref*)h)->test_puncture_nBits = nBits; }
+
 void mref_destroy(void* h) {
     // The reference's destructors double-free in some orders; leak on purpose (test tool).
     (void)h;
@@ -403,7 +407,11 @@ void mref_rx(void* h, const double* baseband_c128, int flags, mref_rx_out* o) {
         for (int i = 0; i < r->active_nsymb; i++) ofdm.symbol_demod(&bb[i * r->Nofdm], &r->demod_grid[i * r->Nc]);
         if (o->grid) memcpy(o->grid, r->demod_grid, sizeof(cd) * r->active_nsymb * r->Nc);
         r->mfsk.demod(r->demod_grid, r->active_nbits, r->demodulated);
-        for (int i = r->active_nbits; i < r->nBits; i++) r->demodulated[i] = 0.0f;
+        {   // telecom_system.cc:1183-1191: punctured positions are erasures; the BER-test hook test_puncture_nBits moves the cut forward
+            int puncture_from = r->active_nbits;
+            if (r->test_puncture_nBits > 0 && r->test_puncture_nBits < puncture_from) puncture_from = r->test_puncture_nBits;
+            for (int i = puncture_from; i < r->nBits; i++) r->demodulated[i] = 0.0f;
+        }
         o->variance = 0; o->variance_f = 0; o->mean_H = -1.0;
         if (o->llr_demod) memcpy(o->llr_demod, r->demodulated, sizeof(float) * r->nBits);
         deinterleaver(r->demodulated, r->deinterleaved, r->nBits, r->bit_blk);
@@ -650,6 +658,43 @@ int mref_transmit_batch(void* h, const int* payloads, int stride, const int* nby
     f1.apply(cat.data(), t1.data(), n);
     f2.apply(t1.data(), t2.data(), n);
     memcpy(out, &t2[total], sizeof(double) * size_t(F) * total);      // :2283 tx_transfer of frames 1..F
+    return F * total;
+}
+
+// transmit_byte's overlap-save message locations FIRST_MESSAGE (0) / MIDDLE_MESSAGE (1) / FLUSH_MESSAGE (2), telecom_system.cc:559-590,
+// literally: F consecutive calls on one passband_data_tx_buffer of 3 frames (buffer: [3*total], read and updated; the reference
+// allocates it uninitialised, data_container.cc:163 — the caller zero-fills a fresh one), with the reference's FIR objects and
+// shift_left (misc.cc:26-32). location FIRST: call 0 is FIRST_MESSAGE and the following ones MIDDLE_MESSAGE, the way
+// TX_RAND_process_main drives it (:2023-2041). The carrier runs on from call to call (cl_ofdm::passband_start_sample).
+// out: [F][total]: what each call returns (the PREVIOUS frame, filtered with its neighbours as context).
+int mref_transmit_stream(void* h, const int* payloads, int stride, const int* nbytes, int F, const mref_tx_config* c, double* buffer, double* out) {
+    Ref* r = (Ref*)h;
+    const double bandwidth = 48000.0 * 50.0 / 256 / 4, fs = 48000.0;
+    const int interp = 4, total = r->Nofdm * (r->Nsymb + r->preamble_nsymb) * interp, used = (r->preamble_nsymb + r->active_nsymb) * r->Nofdm * interp;
+    if (c->message_location < 0 || c->message_location > 2) return -2;
+    cl_FIR f1, f2;
+    f1.filter_window = HAMMING;  f1.filter_transition_bandwidth = 1000;
+    f1.lpf_filter_cut_frequency = c->carrier_hz + bandwidth / 2;  f1.hpf_filter_cut_frequency = c->carrier_hz - bandwidth / 2;
+    f1.type = HPF;  f1.sampling_frequency = fs;  f1.design();
+    f2.filter_window = BLACKMAN;  f2.filter_transition_bandwidth = 1000;
+    f2.lpf_filter_cut_frequency = c->carrier_hz + bandwidth / 2;  f2.hpf_filter_cut_frequency = c->carrier_hz - bandwidth / 2;
+    f2.type = LPF;  f2.sampling_frequency = fs;  f2.design();
+    std::vector<double> tx(total), t1(2 * size_t(total)), t2(2 * size_t(total));
+    mref_tx_config cc = *c;
+    cc.message_location = NO_FILTER_MESSAGE;
+    for (int n = 0; n < F; n++) {
+        cc.start_sample = c->start_sample + (unsigned long long)n * used;
+        if (mref_transmit_byte(h, payloads + size_t(n) * stride, nbytes ? nbytes[n] : (r->nReal - 16) / 8, &cc, tx.data()) < 0) return -1;
+        const int loc = (c->message_location == FIRST_MESSAGE && n > 0) ? MIDDLE_MESSAGE : c->message_location;
+        if (loc == FIRST_MESSAGE)
+            for (int i = 0; i < total; i++) { buffer[total + i] = tx[i]; buffer[2 * total + i] = tx[i]; }                  // :559-566
+        if (loc == MIDDLE_MESSAGE || loc == FLUSH_MESSAGE)
+            for (int i = 0; i < total; i++) buffer[2 * total + i] = tx[i];                                                 // :568-574
+        f1.apply(&buffer[total / 2], t1.data(), 2 * total);                                                                // :577
+        f2.apply(t1.data(), t2.data(), 2 * total);                                                                         // :578
+        for (int i = 0; i < total; i++) out[size_t(n) * total + i] = t2[total / 2 + i];                                    // :580-583
+        shift_left(buffer, 3 * total, total);                                                                              // :584
+    }
     return F * total;
 }
 

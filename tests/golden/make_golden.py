@@ -197,6 +197,14 @@ def tx_case(lib, cfg):
     # the signal path of cl_arq_controller::send_batch (arq_common.cc:2224-2248): three messages, one of them short
     pl3 = rng.integers(0, 256, (3, nb)).astype(np.int32)
     rec["send_batch"] = digest(lib.transmit_batch(pl3, np.array([nb, 2, nb // 2], np.int32), start_sample=31337))
+    # FIRST / MIDDLE / FLUSH_MESSAGE overlap-save filtering (telecom_system.cc:559-590): four calls starting with FIRST_MESSAGE on a
+    # fresh buffer, then two more as MIDDLE_MESSAGE and one FLUSH_MESSAGE on the buffer they left (one message short)
+    pl7 = rng.integers(0, 256, (7, nb)).astype(np.int32)
+    used = (lib.preamble_nsymb + lib.active_nsymb) * lib.Nofdm * 4
+    y1, buf = lib.transmit_stream(pl7[:4], oraclelib.FIRST_MESSAGE, start_sample=4242)
+    y2, buf = lib.transmit_stream(pl7[4:6], oraclelib.MIDDLE_MESSAGE, buffer=buf, nbytes=np.array([nb, 3], np.int32), start_sample=4242 + 4 * used)
+    y3, buf = lib.transmit_stream(pl7[6:], oraclelib.FLUSH_MESSAGE, buffer=buf, start_sample=4242 + 6 * used)
+    rec["stream"] = [digest(y1), digest(y2), digest(y3), digest(buf), [float(v).hex() for v in y1[1, [0, 1, 777, y1.shape[1] // 2, y1.shape[1] - 1]]]]
     # generate_ack_pattern_passband / generate_break_pattern_passband (telecom_system.cc:1589-1689)
     rec["ack"] = digest(lib.generate_ack_pattern_passband(1))
     rec["break"] = digest(lib.generate_ack_pattern_passband(2, start_sample=10 ** 7 + 1, output_power_watt=0.05, data_papr_cut=3.0))

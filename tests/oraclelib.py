@@ -67,6 +67,10 @@ class _Base:
         self._fn("set_ctrl_mode")(self.h, C.c_int(1 if enable else 0))
         self._init_info()
 
+    def set_test_puncture(self, nbits):
+        """cl_telecom_system::test_puncture_nBits (telecom_system.cc:1186-1192): MFSK LLRs from this position on are erasures."""
+        self._fn("set_test_puncture")(self.h, C.c_int(nbits))
+
     # ---- tables
     def frame_types(self):
         t = np.zeros(self.Nsymb * self.Nc, np.int32)
@@ -271,6 +275,7 @@ CARRIER = BANDWIDTH / 2 + 300                 # physical_config.cc:84 with carri
 AMPLITUDE = float(np.sqrt(2.0))               # telecom_system.cc:69
 
 
+FIRST_MESSAGE, MIDDLE_MESSAGE, FLUSH_MESSAGE = 0, 1, 2     # include/common/common_defines.h:197-199
 SINGLE_MESSAGE, NO_FILTER_MESSAGE = 3, 4        # include/common/common_defines.h:200-201
 
 
@@ -374,6 +379,25 @@ def _sync_methods(cls):
         assert n == out.size, n
         return out
 
+    def transmit_stream(self, payloads, message_location, buffer=None, nbytes=None, carrier=CARRIER, start_sample=0, amplitude=AMPLITUDE,
+                        output_power_watt=0.1, preamble_papr_cut=7.0, data_papr_cut=10.0):
+        """transmit_byte with FIRST_MESSAGE (0) / MIDDLE_MESSAGE (1) / FLUSH_MESSAGE (2), F consecutive calls on one 3-frame
+        passband_data_tx_buffer (`buffer`, float64 [3*total], updated in place; None = a fresh zeroed one).
+        Returns ([F, total_frame_size] audio, buffer)."""
+        pl = np.ascontiguousarray(payloads, np.int32)
+        F, stride = pl.shape
+        nb = None if nbytes is None else np.ascontiguousarray(nbytes, np.int32)
+        total = (self.preamble_nsymb + self.Nsymb) * self.Nofdm * 4
+        buf = np.zeros(3 * total) if buffer is None else buffer
+        assert buf.dtype == np.float64 and buf.size == 3 * total and buf.flags.c_contiguous
+        c = TxConfig(carrier, amplitude, output_power_watt, preamble_papr_cut, data_papr_cut, start_sample, message_location, 0)
+        out = np.zeros((F, total))
+        f = self._fn("transmit_stream")
+        f.restype = C.c_int
+        n = f(self.h, _p(pl), C.c_int(stride), None if nb is None else _p(nb), C.c_int(F), C.byref(c), _p(buf), _p(out))
+        assert n == out.size, n
+        return out, buf
+
     def generate_ack_pattern_passband(self, which=1, carrier=CARRIER, start_sample=0, amplitude=AMPLITUDE, output_power_watt=0.1,
                                       data_papr_cut=10.0):
         """cl_telecom_system::generate_ack_pattern_passband (which=1) / generate_break_pattern_passband (which=2)."""
@@ -385,7 +409,7 @@ def _sync_methods(cls):
         return out
 
     for fn in (preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband, mfsk_pattern, time_sync_mfsk,
-               detect_ack_pattern, transmit_byte, generate_ack_pattern_passband, transmit_batch):
+               detect_ack_pattern, transmit_byte, generate_ack_pattern_passband, transmit_batch, transmit_stream):
         setattr(cls, fn.__name__, fn)
 
 

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     from mercury_amd.physical_layer import Config, Info, TransmitConfig
     assert C.sizeof(TransmitConfig) == 56       # 5 doubles, uint64, 2 ints
     assert STATS_DTYPE.itemsize == 24           # 4 ints + 2 floats
-    assert C.sizeof(Config) == 36               # 7 ints, 1 float, mfsk_ctrl_mode
+    assert C.sizeof(Config) == 40               # 7 ints, 1 float, mfsk_ctrl_mode, test_puncture_nBits
     assert C.sizeof(Info) == 4 * 32
 
 

@@ -149,3 +149,26 @@ def test_mfsk_degenerate_inputs_behave_like_the_reference(cfg):
             assert (st["iterations_done"], st["crc"], st["all_zeros"]) == (ref["iterations"], ref["crc"], ref["all_zeros"]), (cfg, i)
             assert np.array_equal(out["payload"][i], ref["bytes"].astype(np.uint8)), (cfg, i)
     rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,cut", [(100, 1000), (101, 900), (102, 1500), (100, 1599)])
+def test_test_puncture_nbits_hook_matches_oracle(cfg, cut):
+    """cl_telecom_system::test_puncture_nBits (telecom_system.cc:1186-1192, the punctured-LDPC BER-test hook): demodulated LLRs
+    from the cut on are erasures. Decoder-input LLRs, payload, iteration count and CRC must equal the oracle's with the same
+    hook set (the oracle's hook is checked against the compiled reference objects in test_oracle_vs_ref.py)."""
+    from mercury_amd import RxPhy
+    orc = oraclelib.Oracle(cfg, 50)
+    orc.set_test_puncture(cut)
+    F = 4
+    bb = np.stack([orc.gen_frame(SEED, 8100 + i, oraclelib.noise_amp_for(OPERATING_ESN0[cfg] + 2.0))[0] for i in range(F)])
+    rx = RxPhy(cfg, max_batch=F, test_puncture_nbits=cut)
+    out = rx.receive(bb, taps=True)
+    plain = RxPhy(cfg, max_batch=F).receive(bb, taps=True)
+    for f in range(F):
+        ref = orc.rx(bb[f], oraclelib.FLAGS_RECEIVE_BYTE)
+        assert np.array_equal(out["llr_demod"][f], ref["llr_demod"]) and np.array_equal(out["llr_ldpc"][f], ref["llr_ldpc"])
+        assert not out["llr_demod"][f][cut:].any() and np.array_equal(out["llr_demod"][f][:cut], plain["llr_demod"][f][:cut])
+        assert np.array_equal(out["payload"][f], ref["bytes"].astype(np.uint8))
+        assert (out["stats"]["iterations_done"][f], out["stats"]["crc"][f]) == (ref["iterations"], ref["crc"])
+    rx.close()

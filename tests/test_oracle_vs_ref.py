@@ -66,3 +66,20 @@ def test_mfsk_modes_identical(cfg):
                 assert a[k].tobytes() == b[k].tobytes(), (cfg, ctrl, snr, k)
             for k in ("iterations", "crc", "all_zeros", "snr_db"):
                 assert a[k] == b[k], (cfg, ctrl, snr, k)
+
+
+@pytest.mark.parametrize("cfg,cut", [(100, 1000), (101, 900), (102, 1500)])
+def test_test_puncture_nbits_hook_identical(cfg, cut):
+    """cl_telecom_system::test_puncture_nBits (telecom_system.cc:1186-1192): the oracle's hook against the same zeroing done on the
+    compiled reference's demodulated LLRs (oracle/ref_harness.cc), down to the decoder's verdict."""
+    orc, ref = oraclelib.Oracle(cfg, 50), oraclelib.RefLib(cfg, 50)
+    orc.set_test_puncture(cut)
+    ref.set_test_puncture(cut)
+    for i, snr in enumerate((OPERATING_ESN0[cfg] + 2.0, OPERATING_ESN0[cfg] - 1.0)):
+        bb, _ = orc.gen_frame(78, 10 * cfg + i, oraclelib.noise_amp_for(snr))
+        a, b = orc.rx(bb), ref.rx(bb)
+        assert not a["llr_demod"][cut:].any() and a["llr_demod"][:cut].any()
+        for k in ("llr_demod", "llr_ldpc", "bits", "bytes"):
+            assert a[k].tobytes() == b[k].tobytes(), (cfg, snr, k)
+        for k in ("iterations", "crc", "all_zeros"):
+            assert a[k] == b[k], (cfg, snr, k)

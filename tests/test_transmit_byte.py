@@ -110,6 +110,79 @@ def test_gpu_transmit_byte_matches_oracle(cfg):
     assert np.array_equal(got[0], orc.transmit_byte(pls[0].astype(np.int32), carrier=1650.0, **kw))
 
 
+@needs_ref
+@pytest.mark.parametrize("cfg", [3, 8, 13, 102])
+def test_oracle_overlap_save_message_locations_match_reference_objects(cfg):
+    """FIRST / MIDDLE / FLUSH_MESSAGE (telecom_system.cc:559-590) restated literally on the reference's own FIR objects and
+    shift_left (oracle/ref_harness.cc:mref_transmit_stream) against the C restatement: audio of every call and the 3-frame
+    buffer they leave, over a FIRST stream, a MIDDLE continuation on that buffer and a FLUSH on a buffer of noise."""
+    orc, ref = Oracle(cfg), oraclelib.RefLib(cfg)
+    rng = np.random.default_rng(40 + cfg)
+    pls = rng.integers(0, 256, (5, orc.payload_bytes)).astype(np.int32)
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
+    a, ba = orc.transmit_stream(pls[:3], oraclelib.FIRST_MESSAGE, start_sample=99)
+    b, bb = ref.transmit_stream(pls[:3], oraclelib.FIRST_MESSAGE, start_sample=99)
+    assert np.array_equal(a, b) and np.array_equal(ba, bb)
+    a, ba = orc.transmit_stream(pls[3:4], oraclelib.MIDDLE_MESSAGE, buffer=ba, start_sample=99 + 3 * used)
+    b, bb = ref.transmit_stream(pls[3:4], oraclelib.MIDDLE_MESSAGE, buffer=bb, start_sample=99 + 3 * used)
+    assert np.array_equal(a, b) and np.array_equal(ba, bb)
+    noise = rng.standard_normal(ba.size) * 0.01
+    a, ba = orc.transmit_stream(pls[4:], oraclelib.FLUSH_MESSAGE, buffer=noise.copy(), nbytes=np.array([2], np.int32))
+    b, bb = ref.transmit_stream(pls[4:], oraclelib.FLUSH_MESSAGE, buffer=noise.copy(), nbytes=np.array([2], np.int32))
+    assert np.array_equal(a, b) and np.array_equal(ba, bb)
+
+
+def test_oracle_overlap_save_returns_the_previous_frame_filtered_with_its_neighbours():
+    """What the stream form means: call n returns frame n-1 (FIRST_MESSAGE: the frame itself) as it comes out of the two
+    filters run over the whole unfiltered stream; and away from the frame edges that equals SINGLE_MESSAGE filtering."""
+    orc = Oracle(8)
+    rng = np.random.default_rng(3)
+    pls = rng.integers(0, 256, (4, orc.payload_bytes)).astype(np.int32)
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
+    y, buf = orc.transmit_stream(pls, oraclelib.FIRST_MESSAGE, start_sample=0)
+    total = y.shape[1]
+    single = [orc.transmit_byte(pls[i], message_location=SINGLE_MESSAGE, start_sample=i * used) for i in range(4)]
+    raw = [orc.transmit_byte(pls[i], message_location=NO_FILTER_MESSAGE, start_sample=i * used) for i in range(4)]
+    for n, src in ((0, 0), (1, 0), (2, 1), (3, 2)):            # FIRST returns its own frame, every later call the previous one
+        assert np.array_equal(y[n][200: total - 200], single[src][200: total - 200]), n
+    assert not np.array_equal(y[2][:100], single[1][:100])      # the edges see the neighbouring frames instead of silence
+    assert np.array_equal(buf, np.concatenate([raw[2], raw[3], raw[3]]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 8, 11, 16, 100, 102])
+def test_gpu_overlap_save_message_locations_match_oracle(cfg):
+    """mgpu_transmit_byte_batch with MGPU_FIRST / MIDDLE / FLUSH_MESSAGE: the batch stands for F consecutive calls; audio and the
+    buffer carried between calls must equal the oracle's (pinned to the reference's objects above and by golden_tx.json) bit for
+    bit, whether the calls come one by one or batched, from a fresh buffer or from one installed with mgpu_transmit_buffer."""
+    from mercury_amd import RxPhy
+    from mercury_amd.physical_layer import FIRST_MESSAGE, FLUSH_MESSAGE, MIDDLE_MESSAGE
+    orc = Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=8)
+    rng = np.random.default_rng(500 + cfg)
+    pls = rng.integers(0, 256, (6, orc.payload_bytes)).astype(np.uint8)
+    ipl = pls.astype(np.int32)
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
+    assert not rx.transmit_buffer().any()                                              # a new context starts from zeros
+    want, wbuf = orc.transmit_stream(ipl[:4], oraclelib.FIRST_MESSAGE, start_sample=7)
+    got = rx.transmit_byte(pls[:4], CARRIER, message_location=FIRST_MESSAGE, start_sample=7, phase_continuous=1)
+    assert np.array_equal(got, want) and np.array_equal(rx.transmit_buffer(), wbuf)
+    # one call at a time, the way the reference is driven
+    for i in (4, 5):
+        w1, wbuf = orc.transmit_stream(ipl[i: i + 1], oraclelib.MIDDLE_MESSAGE if i == 4 else oraclelib.FLUSH_MESSAGE, buffer=wbuf,
+                                       start_sample=7 + i * used)
+        g1 = rx.transmit_byte(pls[i: i + 1], CARRIER, message_location=MIDDLE_MESSAGE if i == 4 else FLUSH_MESSAGE, start_sample=7 + i * used)
+        assert np.array_equal(g1, w1) and np.array_equal(rx.transmit_buffer(), wbuf), i
+    # an installed buffer, short messages
+    noise = rng.standard_normal(wbuf.size) * 0.01
+    rx.transmit_buffer(noise)
+    nb = np.array([1, orc.payload_bytes, 0], np.int32)
+    w2, wbuf = orc.transmit_stream(ipl[:3], oraclelib.MIDDLE_MESSAGE, buffer=noise.copy(), nbytes=nb, start_sample=0)
+    g2 = rx.transmit_byte(pls[:3], CARRIER, nbytes=nb, message_location=MIDDLE_MESSAGE, start_sample=0, phase_continuous=1)
+    assert np.array_equal(g2, w2) and np.array_equal(rx.transmit_buffer(), wbuf)
+    rx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [8, 100])
 def test_gpu_transmit_byte_phase_continuous_equals_consecutive_calls(cfg):
@@ -284,7 +357,7 @@ def test_gpu_transmit_byte_bad_arguments():
     rx = RxPhy(8, max_batch=4)
     pl = np.zeros((1, rx.payload_bytes), np.uint8)
     with pytest.raises(MgpuError):
-        rx.transmit_byte(pl, CARRIER, message_location=1)                 # FIRST_MESSAGE: not built
+        rx.transmit_byte(pl, CARRIER, message_location=5)                 # no such message location
     with pytest.raises(MgpuError):
         rx.transmit_byte(pl[:, :10], CARRIER)                              # rows shorter than the frame's payload
     with pytest.raises(MgpuError):
