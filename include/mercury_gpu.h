@@ -60,8 +60,25 @@ extern "C" {
 
 typedef struct mgpu_ctx mgpu_ctx;
 
+/* Explicit configuration: any (constellation, LDPC rate, preamble length, channel estimator) combination the
+ * reference's classes accept, not only the 17 rows load_configuration pairs (telecom_system.cc:2506-2624), as a cfg id:
+ *   M: 2, 4, 8, 16 or 32 (MOD_BPSK..MOD_32QAM); rate16: 1, 2, 3, 4, 5, 6, 8 or 14 (sixteenths, ldpc.cc:140-251);
+ *   preamble_nsymb: 1..8; estimator: MGPU_EST_ZF / MGPU_EST_LS.
+ * Everything else is what physical_config.cc:30-122 and init() (telecom_system.cc:1804-1982) set for every mode: Nc 50, Nfft 256,
+ * gi 1/16, pilots Dx 1 / Dy 3 with boost 1.33, LS window 21 x 21, scrambler / pilot seed 0, preamble seed 1; amplitude
+ * restoration for the PSK constellations (:2647-2654). MOD_64QAM is not accepted: the reference sizes its frame at 8 symbols =
+ * 1602 interleaved bits (:1826), which does not fit the N = 1600 codeword (nVirtual = -2), so it cannot run there either.
+ * Evaluates to -1 for an unsupported combination. */
+#define MGPU_CFG_RATE_INDEX_(r) ((r) == 1 ? 0 : (r) == 2 ? 1 : (r) == 3 ? 2 : (r) == 4 ? 3 : (r) == 5 ? 4 : (r) == 6 ? 5 : (r) == 8 ? 6 : (r) == 14 ? 7 : -1)
+#define MGPU_CFG_MOD_INDEX_(m) ((m) == 2 ? 0 : (m) == 4 ? 1 : (m) == 8 ? 2 : (m) == 16 ? 3 : (m) == 32 ? 4 : -1)
+#define MGPU_CFG_EXPLICIT(M, rate16, preamble_nsymb, estimator)                                                                   \
+    ((MGPU_CFG_MOD_INDEX_(M) < 0 || MGPU_CFG_RATE_INDEX_(rate16) < 0 || (preamble_nsymb) < 1 || (preamble_nsymb) > 8 ||           \
+      ((estimator) != 0 && (estimator) != 1))                                                                                       \
+         ? -1                                                                                                                     \
+         : 1000 + (((MGPU_CFG_MOD_INDEX_(M) * 8 + MGPU_CFG_RATE_INDEX_(rate16)) * 8 + ((preamble_nsymb)-1)) * 2 + (estimator)))
+
 typedef struct mgpu_config {
-    int cfg;              /* Mercury CONFIG_0..CONFIG_16, or 100..102 = ROBUST_0..2 (MFSK, common_defines.h:63-65) */
+    int cfg;              /* Mercury CONFIG_0..CONFIG_16, 100..102 = ROBUST_0..2 (MFSK, common_defines.h:63-65), or MGPU_CFG_EXPLICIT(...) */
     int max_iters;        /* nIteration_max, reference default 50 (physical_config.cc:74), CLI 5..50 */
     int decoder;          /* MGPU_DEC_* */
     int agc;              /* 1 = automatic_gain_control before the estimator (receive_byte) */

@@ -331,8 +331,9 @@ extern "C" {
 int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return MGPU_ERR_ARG; }
     *out = nullptr;
-    if (!((cfg->cfg >= 0 && cfg->cfg <= 16) || (cfg->cfg >= 100 && cfg->cfg <= 102))) {
-        g_create_error = "cfg must be 0..16 (OFDM modes) or 100..102 (ROBUST MFSK modes)";
+    int em, er, ep, ee;
+    if (!((cfg->cfg >= 0 && cfg->cfg <= 16) || (cfg->cfg >= 100 && cfg->cfg <= 102) || mgpu::explicit_mode_row(cfg->cfg, &em, &er, &ep, &ee))) {
+        g_create_error = "cfg must be 0..16 (OFDM modes), 100..102 (ROBUST MFSK modes) or an MGPU_CFG_EXPLICIT id";
         return MGPU_ERR_ARG;
     }
     if (cfg->max_iters < 1 || cfg->max_iters > 1000) { g_create_error = "max_iters out of range"; return MGPU_ERR_ARG; }

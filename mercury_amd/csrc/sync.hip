@@ -279,17 +279,19 @@ extern "C" __global__ __launch_bounds__(64 * TS_DWAVES) void mgpu_tsync_metric_d
     vals[size_t(blockIdx.y) * ncand_max + cand] = cc;
 }
 
-// Moose: up to two preamble symbols, each as two 256-point FFTs of a half symbol repeated twice.
+// Moose: pre_half preamble symbols (up to 4: preamble_nSymb / 2 for preambles of up to 8 symbols), each as two 256-point FFTs of a
+// half symbol repeated twice; the four wavefronts take two symbols per round.
 extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(
     const double* __restrict__ bb, int stride, int pre_half, const double* __restrict__ twiddle, double* __restrict__ freq_out) {
     __shared__ c2 v[4][256];
     __shared__ c2 tw[128];
-    __shared__ c2 dep[4][50];
+    __shared__ c2 dep[8][50];
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const c2* in = reinterpret_cast<const c2*>(bb) + size_t(w) * stride;
     if (tid < 128) tw[tid] = {twiddle[2 * tid], twiddle[2 * tid + 1]};
     __syncthreads();
-    const int j = wave >> 1, halfsel = wave & 1;                 // wave -> (symbol j, first/second half)
+    for (int j0 = 0; j0 < pre_half; j0 += 2) {
+    const int j = j0 + (wave >> 1), halfsel = wave & 1;          // wave -> (symbol j, first/second half)
     const bool act = j < pre_half;
     if (act) {
         for (int i = lane; i < 256; i += 64) v[wave][__brev(unsigned(i)) >> 24] = in[j * 272 + (i & 127) + halfsel * 128];
@@ -308,8 +310,9 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(
         }
         if (lane < 50) {
             const int bin = lane < 25 ? lane + 256 - 25 : lane - 25 + 1;
-            dep[wave][lane] = {v[wave][bin].re / 256.0, v[wave][bin].im / 256.0};
+            dep[2 * j + halfsel][lane] = {v[wave][bin].re / 256.0, v[wave][bin].im / 256.0};
         }
+    }
     }
     __syncthreads();
     if (tid == 0) {

@@ -255,11 +255,29 @@ std::vector<double> design_tx_fir(int which, double carrier_hz) {
     return c;
 }
 
+// explicit (M, LDPC rate, preamble length, estimator) combinations outside the 17 rows of load_configuration: cfg id
+// 1000 + (((log2(M) - 1) * 8 + rate_index) * 8 + (preamble_nSymb - 1)) * 2 + estimator, M in {2,4,8,16,32}, rate_index into
+// {1,2,3,4,5,6,8,14}/16, preamble_nSymb 1..8, estimator 0 = ZERO_FORCE / 1 = LEAST_SQUARE; every other parameter as
+// physical_config.cc / init() give it (Nc 50, Nfft 256, gi 1/16, Dx 1, Dy 3, LS window 21, seeds 0 / 1, pilot boost 1.33) (include/mercury_gpu.h: MGPU_CFG_EXPLICIT)
+bool explicit_mode_row(int cfg, int* M, int* rate16, int* preamble, int* estimator) {
+    static const int rates[8] = {1, 2, 3, 4, 5, 6, 8, 14};
+    if (cfg < 1000 || cfg >= 1000 + 5 * 8 * 8 * 2) return false;
+    const int v = cfg - 1000;
+    *estimator = v & 1;
+    *preamble = ((v >> 1) & 7) + 1;
+    *rate16 = rates[(v >> 4) & 7];
+    *M = 2 << (v >> 7);
+    return true;
+}
+
 ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, size_t blob_size) {
     const bool robust = cfg >= 100 && cfg <= 102;                             // common_defines.h:63-65
-    if (!robust && (cfg < 0 || cfg > 16)) throw std::runtime_error("cfg must be 0..16 (OFDM) or 100..102 (ROBUST MFSK)");
+    ModeRow explicit_row = {0, 0, 0, 0};
+    const bool is_explicit = explicit_mode_row(cfg, &explicit_row.M, &explicit_row.rate16, &explicit_row.preamble, &explicit_row.estimator);
+    if (!robust && !is_explicit && (cfg < 0 || cfg > 16))
+        throw std::runtime_error("cfg must be 0..16 (OFDM), 100..102 (ROBUST MFSK) or an MGPU_CFG_EXPLICIT id");
     const ModeRow robust_row = {200 /* MOD_MFSK, mfsk.h:28 */, cfg == 102 ? 4 : 1, 4, 1};   // telecom_system.cc:2625-2645
-    const ModeRow& row = robust ? robust_row : kModeTable[cfg];
+    const ModeRow& row = robust ? robust_row : is_explicit ? explicit_row : kModeTable[cfg];
     ModeTables t;
     t.cfg = cfg;
     t.M = row.M;

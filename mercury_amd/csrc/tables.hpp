@@ -34,6 +34,9 @@ private:
     int f_, r_;
 };
 
+// decodes an MGPU_CFG_EXPLICIT id (include/mercury_gpu.h); false if cfg is not one
+bool explicit_mode_row(int cfg, int* M, int* rate16, int* preamble, int* estimator);
+
 struct LdpcGraph {
     int K = 0, P = 0, N = 1600, E = 0, Cwidth = 0, Vwidth = 0;
     std::vector<uint32_t> cptr;    // [P+1] first edge of each check (edges are check-major, reference row order)

@@ -116,6 +116,14 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+def cfg_explicit(M, rate16, preamble_nsymb, estimator):
+    """MGPU_CFG_EXPLICIT (include/mercury_gpu.h): cfg id of an explicit (constellation, LDPC rate, preamble, estimator) combination."""
+    mods, rates = {2: 0, 4: 1, 8: 2, 16: 3, 32: 4}, {1: 0, 2: 1, 3: 2, 4: 3, 5: 4, 6: 5, 8: 6, 14: 7}
+    if M not in mods or rate16 not in rates or not 1 <= preamble_nsymb <= 8 or estimator not in (0, 1):
+        return -1
+    return 1000 + (((mods[M] * 8 + rates[rate16]) * 8 + (preamble_nsymb - 1)) * 2 + estimator)
+
+
 class MgpuError(RuntimeError):
     pass
 

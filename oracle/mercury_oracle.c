@@ -272,14 +272,33 @@ static const int BREAK_TONES_16[8] = {6, 14, 2, 3, 10, 8, 11, 15};              
 #define ACK_LEN 8
 #define ACK_HOP 7
 #define ACK_OFFSET 17     /* (Nc - 16) / 2: the universal ack_mfsk is M=16, one stream (telecom_system.cc:3006) */
+/* explicit (M, LDPC rate, preamble length, estimator) combinations outside the 17 rows of load_configuration: cfg id
+ * 1000 + (((log2(M) - 1) * 8 + rate_index) * 8 + (preamble_nSymb - 1)) * 2 + estimator, M in {2,4,8,16,32}, rate_index into
+ * {1,2,3,4,5,6,8,14}/16, preamble_nSymb 1..8, estimator 0 = ZERO_FORCE / 1 = LEAST_SQUARE; every other parameter as
+ * physical_config.cc / init() give it (Nc 50, Nfft 256, gi 1/16, Dx 1, Dy 3, LS window 21, seeds 0 / 1, pilot boost 1.33) */
+static int explicit_row(int cfg, int* M, int* rate16, int* preamble, int* est) {
+    static const int rates[8] = {1, 2, 3, 4, 5, 6, 8, 14};
+    if (cfg < 1000 || cfg >= 1000 + 5 * 8 * 8 * 2) return 0;
+    int v = cfg - 1000;
+    *est = (v & 1) ? EST_LS : EST_ZF;
+    *preamble = ((v >> 1) & 7) + 1;
+    *rate16 = rates[(v >> 4) & 7];
+    *M = 2 << (v >> 7);
+    return 1;
+}
+
 morc* morc_create(int cfg, int max_iters, const char* tables_path) {
     int robust = cfg >= 100 && cfg <= 102;                       /* common_defines.h:63-65 */
-    if (!robust && (cfg < 0 || cfg > 16)) return NULL;
+    int eM, erate, epre, eest;
+    int is_explicit = explicit_row(cfg, &eM, &erate, &epre, &eest);
+    if (!robust && !is_explicit && (cfg < 0 || cfg > 16)) return NULL;
     morc* o = calloc(1, sizeof(morc));
     o->cfg = cfg;
     int rate16;
     if (robust) {   /* telecom_system.cc:2625-2645 */
         o->M = MOD_MFSK; o->preamble = 4; o->estimator = EST_LS; rate16 = cfg == 102 ? 4 : 1;
+    } else if (is_explicit) {
+        o->M = eM; o->preamble = epre; o->estimator = eest; rate16 = erate;
     } else {
         o->M = MODES[cfg].M; o->preamble = MODES[cfg].preamble; o->estimator = MODES[cfg].est; rate16 = MODES[cfg].rate16;
     }

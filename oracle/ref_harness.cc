@@ -111,14 +111,31 @@ struct mref_info {
     int mfsk_M, mfsk_nStreams, active_nsymb, active_nbits;
 };
 
+// explicit (M, LDPC rate, preamble length, estimator) combinations outside the 17 rows of load_configuration: cfg id
+// 1000 + (((log2(M) - 1) * 8 + rate_index) * 8 + (preamble_nSymb - 1)) * 2 + estimator, M in {2,4,8,16,32}, rate_index into
+// {1,2,3,4,5,6,8,14}/16, preamble_nSymb 1..8, estimator 0 = ZERO_FORCE / 1 = LEAST_SQUARE; every other parameter as
+// physical_config.cc / init() give it (Nc 50, Nfft 256, gi 1/16, Dx 1, Dy 3, LS window 21, seeds 0 / 1, pilot boost 1.33)
+static bool explicit_row(int cfg, ModeRow* row) {
+    static const int rates[8] = {1, 2, 3, 4, 5, 6, 8, 14}, mods[5] = {MOD_BPSK, MOD_QPSK, MOD_8PSK, MOD_16QAM, MOD_32QAM};
+    if (cfg < 1000 || cfg >= 1000 + 5 * 8 * 8 * 2) return false;
+    const int v = cfg - 1000;
+    row->estimator = (v & 1) ? LEAST_SQUARE : ZERO_FORCE;
+    row->preamble = ((v >> 1) & 7) + 1;
+    row->rate16 = rates[(v >> 4) & 7];
+    row->M = mods[v >> 7];
+    return true;
+}
+
 void* mref_create(int cfg, int max_iters) {
     const bool robust = cfg >= ROBUST_0 && cfg <= ROBUST_2;   // common_defines.h:63-65
-    if (!robust && (cfg < 0 || cfg > 16)) return nullptr;
+    ModeRow explicit_m = {0, 0, 0, 0};
+    const bool is_explicit = explicit_row(cfg, &explicit_m);
+    if (!robust && !is_explicit && (cfg < 0 || cfg > 16)) return nullptr;
     Silence s;
     Ref* r = new Ref();
     // telecom_system.cc:2625-2645: the three MFSK modes
     const ModeRow robust_row = {MOD_MFSK, cfg == ROBUST_2 ? 4 : 1, 4, LEAST_SQUARE};
-    const ModeRow& m = robust ? robust_row : kModes[cfg];
+    const ModeRow& m = robust ? robust_row : is_explicit ? explicit_m : kModes[cfg];
     r->cfg = cfg;
     r->M = m.M;
     // telecom_system.cc:2647-2654

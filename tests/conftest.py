@@ -29,3 +29,7 @@ OPERATING_ESN0 = {0: -8.0, 1: -6.0, 2: -4.5, 3: -3.0, 4: -1.5, 5: -0.5, 6: 1.0, 
                   100: -10.0, 101: -8.0, 102: -5.0}
 MFSK_CFGS = (100, 101, 102)
 SEED = 0x4D455243
+
+# Explicit (constellation, LDPC rate, preamble, estimator) combinations outside load_configuration's 17 rows
+# (include/mercury_gpu.h MGPU_CFG_EXPLICIT), with an Es/N0 at which they decode: (M, rate16, preamble_nsymb, estimator, Es/N0 dB)
+EXPLICIT_COMBOS = [(4, 1, 4, 1, -5.0), (16, 5, 2, 1, 8.0), (32, 8, 1, 0, 20.0), (8, 3, 3, 1, 3.0), (2, 14, 2, 0, 12.0), (4, 4, 8, 1, 1.0)]

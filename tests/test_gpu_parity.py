@@ -74,6 +74,46 @@ def test_all_stages_match_oracle(cfg):
         rx.close()
 
 
+@pytest.mark.parametrize("M,rate16,pre,est,esn0", __import__("conftest").EXPLICIT_COMBOS)
+def test_explicit_configurations_match_oracle(M, rate16, pre, est, esn0):
+    """MGPU_CFG_EXPLICIT: (constellation, LDPC rate, preamble length, estimator) combinations load_configuration does not pair
+    (SURVEY.md §8b "cfg id or explicit"), the whole span against the oracle (pinned to the reference's classes configured the same
+    way, tests/test_oracle_vs_ref.py): same bar as the 17 modes; plus transmit_byte -> receive_byte with the explicit preamble."""
+    from mercury_amd.physical_layer import cfg_explicit
+    cfg = cfg_explicit(M, rate16, pre, est)
+    orc = Oracle(cfg, 50)
+    snrs = [esn0, esn0 + 1.0, esn0 - 2.5, -15.0, 60.0]
+    bb, payloads = _frames(orc, snrs)
+    variants = [(0, 0, FLAGS_BASEBAND_TEST)] if est == 0 else [(1, 1, FLAGS_RECEIVE_BYTE), (0, 0, FLAGS_BASEBAND_TEST)]
+    for agc, vs, flags in variants:
+        rx = _rx(cfg, max_iters=50, agc=agc, variance_source=vs, max_batch=len(snrs))
+        assert (rx.M, rx.K, rx.preamble_nsymb, rx.estimator) == (M, 100 * rate16, pre, est)
+        out = rx.receive(bb, taps=True)
+        for f in range(len(snrs)):
+            ref = orc.rx(bb[f], flags)
+            for key, rtol in (("grid", 0.0), ("eq", 1e-12), ("syms", 1e-12)):
+                assert np.abs(out[key][f] - ref[key]).max() <= rtol * np.abs(ref[key]).max(), (cfg, flags, f, key)
+            assert _llr_close(out["llr_ldpc"][f], ref["llr_ldpc"]).all(), (cfg, flags, f, "llr_ldpc")
+            assert out["stats"]["iterations_done"][f] == ref["iterations"], (cfg, flags, f, "iterations")
+            assert np.array_equal(out["payload"][f], ref["bytes"].astype(np.uint8)), (cfg, flags, f, "payload")
+            assert (out["stats"]["crc"][f], out["stats"]["all_zeros"][f]) == (ref["crc"], ref["all_zeros"]), (cfg, flags, f)
+        assert np.array_equal(out["payload"][0][: orc.payload_bytes], payloads[0].astype(np.uint8))
+        if agc:      # audio round trip through the explicit mode's own preamble and receive_byte
+            msg = np.random.default_rng(cfg).integers(0, 256, (1, rx.payload_bytes), dtype=np.uint8)
+            audio = rx.transmit_byte(msg, oraclelib.CARRIER)
+            want = orc.transmit_byte(msg[0].astype(np.int32))
+            assert np.array_equal(audio[0], want)
+            n = rx.receive_buffer_samples()
+            win = np.random.default_rng(1).standard_normal(n) * 1e-3
+            d = (pre + 3) * rx.Nofdm * 4 + 123           # receive_byte wants the preamble beyond symbol `preamble_nSymb` of the window
+            win[d: d + audio.shape[1]] += 2.0 * audio[0]
+            r = rx.receive_byte(win[None, :], oraclelib.CARRIER)
+            ref_r = orc.receive_byte(win, carrier=oraclelib.CARRIER)
+            assert r["stats"]["message_decoded"][0] == ref_r["message_decoded"] == 1
+            assert np.array_equal(r["payload"][0][: rx.payload_bytes], msg[0]) and r["stats"]["delay"][0] == ref_r["delay"]
+        rx.close()
+
+
 @pytest.mark.parametrize("cfg", [0, 3, 5, 8, 9, 12])
 def test_ldpc_spa_bit_exact_on_identical_llrs(cfg):
     """cl_ldpc::decode parity: same float LLRs in -> same hard bits and iteration count out, including

@@ -83,3 +83,47 @@ def test_test_puncture_nbits_hook_identical(cfg, cut):
             assert a[k].tobytes() == b[k].tobytes(), (cfg, snr, k)
         for k in ("iterations", "crc", "all_zeros"):
             assert a[k] == b[k], (cfg, snr, k)
+
+
+from conftest import EXPLICIT_COMBOS  # noqa: E402
+
+
+@pytest.mark.parametrize("M,rate16,pre,est,esn0", EXPLICIT_COMBOS)
+def test_explicit_configurations_identical(M, rate16, pre, est, esn0):
+    """MGPU_CFG_EXPLICIT ids (explicit M / rate / preamble / estimator instead of a CONFIG row): the reference's
+    classes configured with the combination (oracle/ref_harness.cc) against the C restatement, stage by stage."""
+    from mercury_amd.physical_layer import cfg_explicit
+    cfg = cfg_explicit(M, rate16, pre, est)
+    assert cfg >= 1000
+    orc, ref = oraclelib.Oracle(cfg, 50), oraclelib.RefLib(cfg, 50)
+    for n in oraclelib.INFO_FIELDS:
+        if n != "dwidth":
+            assert getattr(orc, n) == getattr(ref, n), n
+    assert (orc.M, orc.K, orc.preamble_nsymb, orc.estimator) == (M, 100 * rate16, pre, est)
+    for i, snr in enumerate((esn0, esn0 - 2.5, 40.0)):
+        bb, pl = orc.gen_frame(993, 11 * i, oraclelib.noise_amp_for(snr), channel=i % 2)
+        bits = orc.payload_to_bits(pl)
+        assert orc.tx(bits, 1).tobytes() == ref.tx(bits, 1).tobytes()
+        for flags in ((oraclelib.FLAGS_BASEBAND_TEST,) if est == 0 else (oraclelib.FLAGS_BASEBAND_TEST, oraclelib.FLAGS_RECEIVE_BYTE)):
+            a, b = orc.rx(bb, flags), ref.rx(bb, flags)
+            for k in a:
+                if isinstance(a[k], np.ndarray):
+                    assert a[k].tobytes() == b[k].tobytes(), (cfg, snr, flags, k)
+                elif k != "agc_gain":
+                    assert a[k] == b[k] or (np.isnan(a[k]) and np.isnan(b[k])), (cfg, snr, flags, k)
+        if i == 0:
+            assert a["iterations"] <= 50 and np.array_equal(a["bytes"][: orc.payload_bytes], pl)      # and it decodes
+
+
+def test_explicit_configuration_ids():
+    from mercury_amd.physical_layer import cfg_explicit
+    seen = set()
+    for M in (2, 4, 8, 16, 32):
+        for r in (1, 2, 3, 4, 5, 6, 8, 14):
+            for p in range(1, 9):
+                for e in (0, 1):
+                    c = cfg_explicit(M, r, p, e)
+                    assert 1000 <= c < 1640 and c not in seen
+                    seen.add(c)
+    assert cfg_explicit(64, 8, 1, 0) == -1 and cfg_explicit(4, 7, 1, 0) == -1 and cfg_explicit(4, 8, 0, 0) == -1 and cfg_explicit(4, 8, 9, 1) == -1
+    assert oraclelib.Oracle(cfg_explicit(4, 6, 4, 1), 50).K == oraclelib.Oracle(8, 50).K          # cfg 8 is (QPSK, 6/16, 4, LS)
