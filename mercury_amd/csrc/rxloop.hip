@@ -7,7 +7,7 @@
 //
 // Parity: every block is checked against the oracle / the compiled reference on its own; the orchestration is
 // checked against oracle/mercury_oracle.c:morc_receive_byte, whose own parity with telecom_system.cc is UNPINNED
-// (that file cannot be built in this image) — see DESIGN.md. Not built: mfsk_fixed_delay (BER-test hook).
+// (that file cannot be built in this image) — see DESIGN.md. Not built: mfsk_fixed_delay (BER-test / overflow-recapture hook).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -49,10 +49,14 @@ struct Workspace {
     size_t vals_per_window;
     double* h_vals = nullptr;        // page-locked landing area for the synchroniser metrics (tens of MB per call)
     hipStream_t side = nullptr;      // the signal-strength sum (a 92 k-term dependent chain per window) runs beside the synchroniser
+    hipStream_t copy = nullptr;      // brings the capture windows in, slice by slice, under the first kernels
+    std::vector<hipEvent_t> slice_ev;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     ~Workspace() {
         if (h_vals) (void)hipHostFree(h_vals);
         if (side) (void)hipStreamDestroy(side);
+        if (copy) (void)hipStreamDestroy(copy);
+        for (hipEvent_t e : slice_ev) (void)hipEventDestroy(e);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_done) (void)hipEventDestroy(ev_done);
     }
@@ -142,7 +146,17 @@ struct Loop {
         up(d_ic, nc.data(), size_t(n) * 4);
         launch_tsync_metric(d_bbi.as<double>(), buf, d_ib.as<int>(), d_ia.as<int>(), d_ic.as<int>(), ncmax, n, step, pre, ngi_i, nfft_i,
                             d_vals.as<double>(), s);
+        select(n, ncmax, nc, size, loc, step, ntrials, delay, corr);
+    }
+
+    // the reference's peak selection (ofdm.cc:1943-1964) over the candidate metrics of n windows lying in d_vals ([n][ncmax])
+    void select(int n, int ncmax, const std::vector<int>& nc, const std::vector<int>& size, const std::vector<int>& loc, int step, int ntrials,
+                std::vector<int>& delay, std::vector<double>& corr) {
+        delay.assign(n, 0);
+        corr.assign(n, 0.0);
+        if (!n) return;
         if (n >= 32) {   // peak selection where the metrics lie; only (delay, correlation) per window come back
+            up(d_ic, nc.data(), size_t(n) * 4);
             up(d_ia, size.data(), size_t(n) * 4);                    // wins / start are consumed: reuse their index buffers
             up(d_ib, loc.data(), size_t(n) * 4);
             hipLaunchKernelGGL(mgpu_select_peak_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_vals.as<double>(), d_ic.as<int>(), ncmax, step,
@@ -288,13 +302,41 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             r.signal_strength_dbm = -999;
         }
         std::memset(payload, 0, size_t(W) * t.payload_stride);
-        // hipMemcpyDefault: the windows may lie in host memory (the reference's capture buffer) or already in HBM
-        HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyDefault, s));
-
-        pt.mark(s, "upload passband");
-        // ---- :676-696 coarse synchronisation on the FIR_rx_time_sync baseband ----
-        lp.p2b(all, 0);
-        pt.mark(s, "p2b time-sync filter");
+        // ---- upload + :676-696 coarse synchronisation on the FIR_rx_time_sync baseband, pipelined over slices of windows ----
+        // The windows may lie in host memory (the reference's capture buffer; 740 KB each in mode 8, i.e. 13 ms of PCIe time per
+        // 1024) or already in HBM (hipMemcpyDefault). A copy stream brings them over slice by slice; the mixer + time-sync filter
+        // and the Schmidl-Cox metric of a slice run as soon as it has landed, under the copies of the following slices (a copy
+        // from pageable memory holds the host thread, but the kernels of the slices before it are already queued).
+        const int kSlice = 64;
+        const int nsl = (W + kSlice - 1) / kSlice;
+        while (int(lp.ws.slice_ev.size()) < nsl) {
+            hipEvent_t e = nullptr;
+            HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            lp.ws.slice_ev.push_back(e);
+        }
+        if (!lp.ws.copy) HIPCK(hipStreamCreateWithFlags(&lp.ws.copy, hipStreamNonBlocking));
+        lp.up(lp.d_ia, all.data(), size_t(W) * 4);
+        lp.up(lp.d_carrier, lp.carrier.data(), size_t(W) * 8);
+        const double* mix_cs = mixer_table(c, rcp->carrier_hz, size_t(lp.buf), s);        // every window mixes with the call's carrier here
+        HIPCK(hipEventRecord(lp.ws.ev_ready, s));
+        HIPCK(hipStreamWaitEvent(lp.ws.copy, lp.ws.ev_ready, 0));                         // the previous call is done with d_pass
+        const int ntaps_ts = int(t.fir_time_sync.size());
+        const int ncand0 = lp.buf > lp.L ? (lp.buf - lp.L + kCoarseStep - 1) / kCoarseStep : 0;
+        need(size_t(std::max(ncand0, 1)) <= lp.ws.vals_per_window, "search window larger than the workspace");
+        for (int k = 0; k < nsl; ++k) {
+            const int off = k * kSlice, n = std::min(kSlice, W - off);
+            HIPCK(hipMemcpyAsync(lp.d_pass.as<double>() + size_t(off) * lp.buf, passband + size_t(off) * lp.buf, size_t(n) * lp.buf * 8, hipMemcpyDefault, lp.ws.copy));
+            HIPCK(hipEventRecord(lp.ws.slice_ev[k], lp.ws.copy));
+            HIPCK(hipStreamWaitEvent(s, lp.ws.slice_ev[k], 0));
+            hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((lp.buf + 255) / 256, unsigned(n)), dim3(256), size_t(255 + ntaps_ts) * 16, s, lp.d_pass.as<double>(), lp.buf,
+                               lp.d_carrier.as<double>(), nullptr, 0, lp.buf, 1, c->d_fir[0], ntaps_ts, 48000.0, 1.4142135623730951, lp.d_bbi.as<double>(),
+                               lp.d_ia.as<int>() + off, mix_cs);
+            HIPCK(hipGetLastError());
+            if (!lp.mfsk && ncand0 > 0)
+                launch_tsync_metric(lp.d_bbi.as<double>() + size_t(off) * lp.buf * 2, lp.buf, nullptr, nullptr, nullptr, ncand0, n, kCoarseStep, lp.pre, lp.ngi_i,
+                                    lp.nfft_i, lp.d_vals.as<double>() + size_t(off) * ncand0, s);
+        }
+        pt.mark(s, "upload + p2b + coarse metric");
         {   // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order. The sum is a long
             // dependent chain, so it runs on a side stream while the synchroniser works on the same (read-only) baseband; the
             // main stream waits for it before the trial loop overwrites that baseband.
@@ -320,7 +362,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
         } else {
             std::vector<int> zero(W, 0), full(W, lp.buf), d;
             std::vector<double> corr;
-            lp.tsync(all, zero, full, kCoarseStep, zero, 1, d, corr);
+            lp.select(W, ncand0, std::vector<int>(W, ncand0), full, zero, kCoarseStep, 1, d, corr);     // the metrics are already in d_vals
             for (int w = 0; w < W; ++w) { win[w].delay = d[w]; win[w].metric = corr[w]; }
         }
         pt.mark(s, "coarse time sync");
