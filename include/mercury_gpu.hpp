@@ -53,6 +53,7 @@ struct st_receive_stats {
     double freq_offset_of_last_decoded_message = 0;
     double coarse_metric = 0;
     int frame_overflow_symbols = 0;
+    int mfsk_search_raw = 0;      // telecom_system.h:79: MFSK anti-re-decode base search position (symbols); the ARQ layer sets it
 };
 
 namespace detail {
@@ -172,6 +173,8 @@ public:
     int use_last_good_time_sync = YES;
     int use_last_good_freq_offset = YES;
     int coarse_freq_sync_enabled = NO;      // g_gui_state.coarse_freq_sync_enabled (gui_state.h:143)
+    int mfsk_fixed_delay = -1;              // telecom_system.h:110: >= 0 bypasses the time sync once (MFSK modes)
+    int nUnder_processing_events = 0;       // data_container.nUnder_processing_events: symbols consumed since the last decode (:683)
 
     // Samples of one capture window: Nofdm * buffer_Nsymb * frequency_interpolation_rate (data_container.cc:133-143)
     int capture_window_samples() const { return mgpu_receive_buffer_nsymb(ctx_) * info.Nofdm * 4; }
@@ -181,11 +184,17 @@ public:
     // receive_stats; the last good delay / frequency offset carry over to the next call as in the reference.
     st_receive_stats receive_byte(const double* data, int* out) {
         mgpu_receive_config rc{carrier_frequency, time_sync_trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync_enabled};
-        mgpu_link_state ls{receive_stats.delay_of_last_decoded_message, receive_stats.freq_offset_of_last_decoded_message, 0};
+        // the MFSK anti-re-decode offset (telecom_system.cc:683-685) and the one-shot known delay (:663-672)
+        int search_start = receive_stats.mfsk_search_raw - nUnder_processing_events;
+        if (search_start < 0) search_start = 0;
+        mgpu_link_state ls{receive_stats.delay_of_last_decoded_message, receive_stats.freq_offset_of_last_decoded_message, search_start,
+                           (info.mfsk_M > 0 && mfsk_fixed_delay >= 0) ? mfsk_fixed_delay + 1 : 0};
+        mfsk_fixed_delay = -1;
         mgpu_receive_stats r{};
         std::vector<uint8_t> bytes(info.payload_stride);
         detail::check(mgpu_receive_byte_batch(ctx_, data, 1, &rc, &ls, bytes.data(), &r), ctx_, "receive_byte");
-        for (int i = 0; i < info.payload_bytes; ++i) out[i] = bytes[i];
+        if (r.iterations_done != -1)                               // no decode attempted: the reference leaves out[] as it was
+            for (int i = 0; i < info.payload_bytes; ++i) out[i] = bytes[i];
         if (r.iterations_done != -1 || r.message_decoded) {       // a decode was attempted: these members were written
             receive_stats.iterations_done = r.iterations_done; receive_stats.crc = r.crc; receive_stats.all_zeros = r.all_zeros;
         }

@@ -10,7 +10,7 @@
  * PARITY of the control flow is UNPINNED: telecom_system.cc cannot be compiled in the build image (it needs the audio
  * and GUI subsystems), so the gates, recoveries and the retry loop are restated from the source and checked against
  * the repository's own CPU restatement (oracle/mercury_oracle.c:morc_receive_byte). Every DSP block underneath is
- * checked against the compiled reference. Not built: mfsk_fixed_delay (BER-test hook).
+ * checked against the compiled reference.
  */
 #ifndef MERCURY_RXLOOP_H
 #define MERCURY_RXLOOP_H
@@ -36,6 +36,12 @@ typedef struct mgpu_link_state {
     int delay_of_last_decoded_message;             /* -1 = none yet (telecom_system.cc:1972) */
     double freq_offset_of_last_decoded_message;
     int mfsk_search_start;                         /* mfsk_search_raw - nUnder_processing_events, >= 0 (telecom_system.cc:683-685) */
+    int fixed_delay_plus_one;                      /* cl_telecom_system::mfsk_fixed_delay + 1, 0 = none (so a zeroed state means "search"):
+                                                      the known delay of this window in passband samples, as the BER test (:293) and the
+                                                      ARQ overflow recapture (arq_common.cc:2830) set it; the time sync and the signal
+                                                      level are skipped (:663-672) and the field is cleared, as the reference uses it once.
+                                                      MFSK modes only (in the OFDM modes the reference's gates would then read the previous
+                                                      call's baseband); an error elsewhere */
 } mgpu_link_state;
 
 /* st_receive_stats (telecom_system.h:63-82), the fields this function sets */

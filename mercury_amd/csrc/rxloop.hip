@@ -7,7 +7,7 @@
 //
 // Parity: every block is checked against the oracle / the compiled reference on its own; the orchestration is
 // checked against oracle/mercury_oracle.c:morc_receive_byte, whose own parity with telecom_system.cc is UNPINNED
-// (that file cannot be built in this image) — see DESIGN.md. Not built: mfsk_fixed_delay (BER-test / overflow-recapture hook).
+// (that file cannot be built in this image) — see DESIGN.md.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -348,6 +348,8 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
         }
         pt.mark(s, "signal strength");
         std::vector<char> live(W, 1);                             // still on the way to the trial loop
+        std::vector<char> fixed_delay(W, 0);
+        if (state && !lp.mfsk) for (int w = 0; w < W; ++w) need(state[w].fixed_delay_plus_one <= 0, "fixed_delay_plus_one: MFSK modes only");
         if (lp.mfsk) {
             const int nslots = lp.buf / lp.sym;
             DevBuf d_e(size_t(W) * nslots * t.Nc * 8);
@@ -357,8 +359,15 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             HIPCK(hipGetLastError());
             std::vector<double> E(size_t(W) * nslots * t.Nc);
             lp.down(E.data(), d_e, E.size() * 8);
-            for (int w = 0; w < W; ++w)
+            for (int w = 0; w < W; ++w) {
+                if (state && state[w].fixed_delay_plus_one > 0) {      // :663-672 mfsk_fixed_delay: known delay, used once, no signal level
+                    win[w].delay = state[w].fixed_delay_plus_one - 1;
+                    state[w].fixed_delay_plus_one = 0;
+                    fixed_delay[w] = 1;
+                    continue;
+                }
                 win[w].delay = mfsk_sync_from_energies(t, &E[size_t(w) * nslots * t.Nc], nslots, lp.buf, state ? state[w].mfsk_search_start : 0);
+            }
         } else {
             std::vector<int> zero(W, 0), full(W, lp.buf), d;
             std::vector<double> corr;
@@ -408,7 +417,7 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
             HIPCK(hipStreamWaitEvent(s, lp.ws.ev_done, 0));
             std::vector<double> sum(W);
             lp.down(sum.data(), lp.d_freq, size_t(W) * 8);
-            for (int w = 0; w < W; ++w) stats[w].signal_strength_dbm = 10.0 * std::log10((sum[w] / lp.buf) / 0.001);
+            for (int w = 0; w < W; ++w) stats[w].signal_strength_dbm = fixed_delay[w] ? 0.0 : 10.0 * std::log10((sum[w] / lp.buf) / 0.001);
         }
         // ---- :931-1431 the trial loop, one round per trial over the windows still in it ----
         DevBuf& d_stats_k = lp.ws.d_stats_k;

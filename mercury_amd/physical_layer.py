@@ -56,7 +56,7 @@ FIRST_MESSAGE, MIDDLE_MESSAGE, FLUSH_MESSAGE = 0, 1, 2
 SINGLE_MESSAGE, NO_FILTER_MESSAGE, BATCH_MESSAGE = 3, 4, 16
 
 LINK_STATE_DTYPE = np.dtype([("delay_of_last_decoded_message", "<i4"), ("freq_offset_of_last_decoded_message", "<f8"),
-                             ("mfsk_search_start", "<i4")], align=True)
+                             ("mfsk_search_start", "<i4"), ("fixed_delay_plus_one", "<i4")], align=True)
 RECEIVE_STATS_DTYPE = np.dtype([("iterations_done", "<i4"), ("crc", "<i4"), ("all_zeros", "<i4"), ("message_decoded", "<i4"),
                                 ("snr_db", "<f8"), ("delay", "<i4"), ("sync_trials", "<i4"), ("freq_offset", "<f8"),
                                 ("coarse_metric", "<f8"), ("frame_overflow_symbols", "<i4"), ("mean_H", "<f8"),

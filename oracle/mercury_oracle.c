@@ -1368,15 +1368,25 @@ void morc_receive_byte(morc* o, const double* passband, double carrier_hz, int t
     /* receive_stats as init() leaves it (telecom_system.cc:1968-1981) + the per-call resets (:653-655) */
     rs->iterations_done = -1; rs->crc = 0; rs->all_zeros = 0; rs->message_decoded = 0; rs->snr_db = -99.9;
     rs->delay = 0; rs->sync_trials = 0; rs->freq_offset = 0; rs->coarse_metric = 0; rs->frame_overflow_symbols = 0; rs->mean_H = -1.0; rs->signal_strength_dbm = -999;
-    /* :676-696 */
-    morc_passband_to_baseband(o, passband, buf, FS, carrier_hz, CARRIER_AMPLITUDE, 1, FIR_TS, (double*)bbi);
-    {   /* :678 measure_signal_stregth, ofdm.cc:1523-1539 */
+    int fixed = 0;
+    if (o->M == MOD_MFSK && st && st->fixed_delay_plus_one > 0) {
+        /* :663-672 mfsk_fixed_delay >= 0 (BER test, overflow recapture): known delay, no time sync, used once */
+        rs->delay = st->fixed_delay_plus_one - 1;
+        st->fixed_delay_plus_one = 0;
+        rs->signal_strength_dbm = 0;
+        fixed = 1;
+    } else {
+        /* :676-696 */
+        morc_passband_to_baseband(o, passband, buf, FS, carrier_hz, CARRIER_AMPLITUDE, 1, FIR_TS, (double*)bbi);
+        /* :678 measure_signal_stregth, ofdm.cc:1523-1539 */
         double p = 0;
         for (int i = 0; i < buf; i++) p += pow(creal(bbi[i]), 2) + pow(cimag(bbi[i]), 2);
         p /= buf;
         rs->signal_strength_dbm = 10.0 * log10(p / 0.001);
     }
-    if (o->M == MOD_MFSK) {
+    if (fixed) {
+        /* delay already set */
+    } else if (o->M == MOD_MFSK) {
         rs->delay = morc_time_sync_mfsk(o, (const double*)bbi, buf, interp, st ? st->mfsk_search_start : 0);
     } else {
         double corr = 0;

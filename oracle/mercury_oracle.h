@@ -144,6 +144,7 @@ typedef struct morc_link_state {          /* the cross-call members of st_receiv
     int delay_of_last_decoded_message;    /* -1 = none yet (telecom_system.cc:1972) */
     double freq_offset_of_last_decoded_message;
     int mfsk_search_start;                /* receive_stats.mfsk_search_raw - nUnder_processing_events, clamped at 0 (:683-685) */
+    int fixed_delay_plus_one;             /* cl_telecom_system::mfsk_fixed_delay + 1 (0 = none): bypass the time sync once (:663-672); MFSK modes */
 } morc_link_state;
 typedef struct morc_receive_stats {
     int iterations_done, crc, all_zeros, message_decoded;

@@ -209,7 +209,7 @@ class Oracle(_Base):
 
 class LinkState(C.Structure):
     _fields_ = [("delay_of_last_decoded_message", C.c_int), ("freq_offset_of_last_decoded_message", C.c_double),
-                ("mfsk_search_start", C.c_int)]
+                ("mfsk_search_start", C.c_int), ("fixed_delay_plus_one", C.c_int)]
 
 
 class ReceiveStats(C.Structure):

@@ -263,3 +263,38 @@ def test_gpu_measure_signal_only_equals_receive_byte_signal_strength(cfg):
     ref = np.array([orc.receive_byte(wins[w])["signal_strength_dbm"] for w in range(3)])
     assert np.array_equal(dbm, ref)          # shared carrier: the mixer uses the host libm's values, the sum runs in sample order
     assert dbm[1] < -100 and dbm[0] > dbm[1] + 100 and dbm[2] > dbm[1] + 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [100, 102])
+def test_gpu_mfsk_fixed_delay_bypasses_time_sync_once(cfg):
+    """cl_telecom_system::mfsk_fixed_delay (telecom_system.cc:663-672; set by the BER test :293 and the ARQ overflow recapture,
+    arq_common.cc:2830): a window with a known delay skips the time sync and the signal level, the field is used once.
+    GPU vs the oracle's restatement, on windows whose true delay is given, given slightly wrong, and not given."""
+    from mercury_amd import RxPhy
+    from mercury_amd.physical_layer import LINK_STATE_DTYPE
+    orc = Oracle(cfg)
+    wins, pls = make_windows(orc, [("frame", 6 * 1088 + 40, 0.01, 1), ("frame", 9 * 1088, 0.02, 2), ("frame", 12 * 1088 + 7, 0.01, 3)], seed=cfg)
+    true_delay = [6 * 1088 + 40, 9 * 1088, 12 * 1088 + 7]
+    given = [true_delay[0], true_delay[1] + 1088, -1]          # exact, one symbol late (cannot decode), none
+    rx = RxPhy(cfg, max_batch=3)
+    st = np.zeros(3, LINK_STATE_DTYPE)
+    st["delay_of_last_decoded_message"] = -1
+    st["fixed_delay_plus_one"] = [g + 1 for g in given]
+    out = rx.receive_byte(wins, CARRIER, state=st)
+    for w in range(3):
+        s = oraclelib.LinkState(-1, 0.0, 0, given[w] + 1)
+        ref = orc.receive_byte(wins[w], carrier=CARRIER, state=s)
+        r = out["stats"][w]
+        for k in ("iterations_done", "crc", "all_zeros", "message_decoded", "delay", "sync_trials", "frame_overflow_symbols"):
+            assert r[k] == ref[k], (cfg, w, k, r[k], ref[k])
+        assert r["signal_strength_dbm"] == ref["signal_strength_dbm"]
+        assert out["state"][w]["fixed_delay_plus_one"] == 0 and ref["state"].fixed_delay_plus_one == 0      # used once
+        assert np.array_equal(out["payload"][w][: orc.payload_bytes], ref["payload"])
+    assert out["stats"]["delay"][0] == given[0] and out["stats"]["signal_strength_dbm"][0] == 0.0 and out["stats"]["message_decoded"][0] == 1
+    assert out["stats"]["delay"][1] == given[1] and out["stats"]["message_decoded"][1] == 0
+    assert out["stats"]["message_decoded"][2] == 1 and out["stats"]["signal_strength_dbm"][2] != 0.0
+    with pytest.raises(Exception):
+        st2 = np.zeros(1, LINK_STATE_DTYPE); st2["fixed_delay_plus_one"] = 5
+        RxPhy(8, max_batch=1).receive_byte(np.zeros((1, Oracle(8).buffer_samples())), CARRIER, state=st2)      # OFDM mode: refused
+    rx.close()
