@@ -289,10 +289,14 @@ def main():
         ldpc_bytes, _, b_iter = algorithmic_bytes(rx, iters_per_launch, F)
         achieved = ldpc_bytes / (dec_ms * 1e-3)
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
+        # HBM bytes of one decoder launch of this workload from the committed PMC passes (profiles/r02_instruction_mix.json, separate
+        # --pmc runs of this command, tools/collect_pmc_mix.sh): (2 x FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads
+        tfile = os.path.join(ROOT, "profiles", "r02_instruction_mix.json")
+        if os.path.exists(tfile) and not args.ldpc_only and args.cfg == 8 and F == 4096 and args.iters == 50:
             try:
-                traffic = json.load(open(tfile)).get("%s_cfg%d" % (args.decoder, args.cfg))
+                m = json.load(open(tfile))[args.decoder]
+                traffic = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
             except Exception:
                 traffic = None
         # secondary view for the bound the decoders actually hit (vector-instruction issue). The dynamic opcode mix of one

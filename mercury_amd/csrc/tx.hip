@@ -222,12 +222,17 @@ TxState& tx_state(mgpu_ctx* c, hipStream_t s) {
     return *static_cast<TxState*>(c->tx_state);
 }
 
-// carrier table from the host libm, as the reference evaluates it: cos / sin(2*M_PI*fc*(double)n*Ts), n from start_sample
-void ensure_carrier_table(TxState& st, double carrier_hz, uint64_t start_sample, size_t count, hipStream_t s) {
-    if (st.cs_carrier == carrier_hz && st.cs_start == start_sample && st.cs_count >= count) return;
-    std::vector<double> cs(2 * count);
+// carrier table from the host libm, as the reference evaluates it: cos / sin(2*M_PI*fc*(double)n*Ts), n from start_sample.
+// Returns the table entry of start_sample. A request inside the cached range is served from it (a streaming caller that
+// advances start_sample call by call keeps hitting a table built once with head-room); the table is bounded.
+const double* ensure_carrier_table(TxState& st, double carrier_hz, uint64_t start_sample, size_t count, hipStream_t s) {
+    need(count <= (size_t(1) << 27), "carrier table too long: split the batch (at most 2^27 samples of carrier phase per call)");
+    if (st.cs_carrier == carrier_hz && start_sample >= st.cs_start && start_sample + count <= st.cs_start + st.cs_count)
+        return st.d_cs + 2 * (start_sample - st.cs_start);
+    const size_t build = std::max(count, std::min<size_t>(size_t(1) << 22, 8 * count));     // head-room for the calls that follow on
+    std::vector<double> cs(2 * build);
     const double Ts = 1.0 / kSampleRate;
-    for (size_t n = 0; n < count; ++n) {
+    for (size_t n = 0; n < build; ++n) {
         const unsigned long k = static_cast<unsigned long>(start_sample + n);
         // the reference's build evaluates cos and sin of this one phase as a single sincos() call (the compiler
         // merges them); glibc's sincos is not bit-for-bit its cos + sin, so the same call is made here
@@ -236,12 +241,13 @@ void ensure_carrier_table(TxState& st, double carrier_hz, uint64_t start_sample,
     HIPCK(hipStreamSynchronize(s));                      // nothing in flight still reads the old table
     if (st.cs_cap < cs.size()) {
         (void)hipFree(st.d_cs);
-        st.d_cs = nullptr;
+        st.d_cs = nullptr; st.cs_cap = 0; st.cs_count = 0;
         HIPCK(hipMalloc(reinterpret_cast<void**>(&st.d_cs), cs.size() * 8));
         st.cs_cap = cs.size();
     }
     HIPCK(hipMemcpy(st.d_cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
-    st.cs_carrier = carrier_hz; st.cs_start = start_sample; st.cs_count = count;
+    st.cs_carrier = carrier_hz; st.cs_start = start_sample; st.cs_count = build;
+    return st.d_cs;
 }
 
 void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, const int* d_nbytes, int F, const mgpu_transmit_config& cfg,
@@ -259,7 +265,7 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
     const bool stream_mode = cfg.message_location >= MGPU_FIRST_MESSAGE && cfg.message_location <= MGPU_FLUSH_MESSAGE;
     const bool filtered = cfg.message_location == MGPU_SINGLE_MESSAGE || batch || stream_mode;
     const bool continuous = cfg.phase_continuous || batch;
-    ensure_carrier_table(st, cfg.carrier_hz, cfg.start_sample, continuous ? size_t(used) * F : size_t(used), s);
+    const double* const d_cs = ensure_carrier_table(st, cfg.carrier_hz, cfg.start_sample, continuous ? size_t(used) * F : size_t(used), s);
     if (filtered && st.carrier != cfg.carrier_hz) {
         HIPCK(hipStreamSynchronize(s));
         for (int w = 0; w < 2; ++w) {
@@ -299,7 +305,7 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
         double* o = clipped + size_t(off) * total;
         hipLaunchKernelGGL(mgpu_tx_mix_kernel, dim3((total + 255) / 256, n), dim3(256), 0, s, st.d_pre_bb, npre,
                            bb + size_t(off) * t.frame_samples * 2, t.frame_samples, ndata, double(power_normalization), m_pre, m_data,
-                           cfg.carrier_amplitude, st.d_cs + (continuous ? 2 * size_t(used) * off : 0), continuous ? used : 0,
+                           cfg.carrier_amplitude, d_cs + (continuous ? 2 * size_t(used) * off : 0), continuous ? used : 0,
                            o, total);
         HIPCK(hipGetLastError());
         hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(n, 2), dim3(256), 0, s, o, total, npre * interp, used, pow_pre, pow_data);
@@ -418,12 +424,12 @@ int mgpu_generate_ack_pattern_passband(mgpu_ctx* c, int pattern, const mgpu_tran
         DevBuf d_car(car.size() * 16), d_bb(size_t(nbb) * 16), d_out(size_t(total) * 8);
         HIPCK(hipMemcpyAsync(d_car.p, car.data(), car.size() * 16, hipMemcpyHostToDevice, s));
         launch_symbol_mod(c, d_car.as<double>(), kAckNsymb, d_bb.as<double>(), s);
-        ensure_carrier_table(st, cfg->carrier_hz, cfg->start_sample, size_t(total), s);
+        const double* const d_cs = ensure_carrier_table(st, cfg->carrier_hz, cfg->start_sample, size_t(total), s);
         const float power_normalization = std::sqrt(double(t.Nfft * interp));                       // telecom_system.cc:1595
         const double ack_boost = std::sqrt(double(t.Nc) / 1) * std::pow(10.0, -2.0 / 20.0);         // :1611
         const double m = std::sqrt(cfg->output_power_watt) * ack_boost;
         hipLaunchKernelGGL(mgpu_tx_mix_kernel, dim3((total + 255) / 256, 1), dim3(256), 0, s, d_bb.as<double>(), nbb, static_cast<const double*>(nullptr), 0,
-                           0, double(power_normalization), m, 0.0, cfg->carrier_amplitude, st.d_cs, 0, d_out.as<double>(), total);
+                           0, double(power_normalization), m, 0.0, cfg->carrier_amplitude, d_cs, 0, d_out.as<double>(), total);
         HIPCK(hipGetLastError());
         const double p10 = std::pow(10, cfg->data_papr_cut / 10.0);
         hipLaunchKernelGGL(mgpu_peak_clip_kernel, dim3(1, 1), dim3(256), 0, s, d_out.as<double>(), total, total, total, p10, p10);

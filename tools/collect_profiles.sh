@@ -1,34 +1,47 @@
 #!/bin/bash
-# Reproduces the evidence under profiles/ on a GPU box (run from the repo root; writes to gpurun_out/, copy what you
-# want judged into profiles/). Counter passes are separate rocprofv3 runs with --kernel-trace only, as
-# /opt/skills/guides/MI355X_MICROARCH.md prescribes; never combine --pmc with sys/hip/hsa traces on this pool.
-#   tools/collect_profiles.sh            bench lines + kernel stats + PMC (cfg 8, spa and minsum)
-#   tools/collect_profiles.sh sweep      additionally the 20-mode sweep, sync blocks, receive_byte chain
+# Reproduces the evidence under profiles/ on a GPU box (run from the repo root; writes to gpurun_out/r02/, copy what you want judged
+# into profiles/). Counter passes are separate rocprofv3 runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md
+# prescribes; never combine --pmc with sys/hip/hsa traces on this pool.
+#   tools/collect_profiles.sh            bench lines + kernel stats + PMC opcode mix / stall counters (cfg 8: spa, spa_fast, minsum) + opcode costs
+#   tools/collect_profiles.sh sweep      additionally: decoder comparison on all 20 modes, the 20-mode throughput sweep, sync blocks,
+#                                        receive_byte chain, host-buffer path, transmit chain
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out
+OUT=$ROOT/gpurun_out/r02
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for d in spa minsum; do
-  python "$ROOT/bench.py" --decoder $d > "$OUT/bench_${d}_cfg8.json" 2>/dev/null
+[ -x "$ROOT/tools/ubench/valu_cycles" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/valu_cycles" "$ROOT/tools/ubench/valu_cycles.hip"
+"$ROOT/tools/ubench/valu_cycles" > "$OUT/r02_valu_cycles.json"
+for d in spa spa_fast minsum; do
+  python "$ROOT/bench.py" --decoder $d > "$OUT/r02_bench_${d}_cfg8.json" 2>/dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$d" -- python "$ROOT/bench.py" --decoder $d --no-cpu-baseline --no-extras > /dev/null 2>&1
-  cp "$(find "$OUT/prof_$d" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_${d}_cfg8_kernel_stats.csv"
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/pmc_${ctr}_$d" -- python "$ROOT/bench.py" --decoder $d --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
-    cp "$(find "$OUT/pmc_${ctr}_$d" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_${ctr}_${d}_cfg8.csv"
-  done
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --output-format csv \
-    -d "$OUT/pmc_sq_$d" -- python "$ROOT/bench.py" --decoder $d --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1 || true
-  f=$(find "$OUT/pmc_sq_$d" -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/pmc_sq_${d}_cfg8.csv"
+  cp "$(find "$OUT/prof_$d" -name '*kernel_stats.csv' | head -1)" "$OUT/r02_bench_${d}_cfg8_kernel_stats.csv"
+  rm -rf "$OUT/prof_$d"
+  "$ROOT/tools/collect_pmc_mix.sh" $d "$OUT/pmc_mix_$d.json" > /dev/null 2> "$OUT/pmc_mix_$d.err" || true
 done
+python - "$OUT" <<'PY'
+import json, sys, os
+out = sys.argv[1]
+mix = {}
+for d in ("spa", "spa_fast", "minsum"):
+    f = os.path.join(out, "pmc_mix_%s.json" % d)
+    if os.path.exists(f):
+        for k, v in json.load(open(f)).items():
+            if "ldpc" in k:
+                mix[d] = dict(v, kernel=k)
+            elif "frontend" in k:
+                mix["frontend"] = dict(v, kernel=k)
+json.dump(mix, open(os.path.join(out, "r02_instruction_mix.json"), "w"), indent=1)
+PY
 if [ "$1" = "sweep" ]; then
   cd "$ROOT"
-  python tools/sweep_modes.py > "$OUT/mode_sweep.json" 2> "$OUT/mode_sweep.txt"
-  python tools/bench_sync.py > "$OUT/bench_sync_blocks.json"
-  python tests/tools/bench_receive_byte.py 8 1024 > "$OUT/bench_receive_byte_cfg8.json"
-  python tools/bench_tx.py 8 4096 > "$OUT/bench_tx_cfg8.json"
-  python tools/bench_tx.py 100 512 > "$OUT/bench_tx_cfg100.json"
-  python tests/tools/llr_error_table.py > "$OUT/llr_error_by_mode.json" 2>/dev/null || true
+  python tools/compare_decoders.py 4096 > "$OUT/r02_compare_decoders.json" 2> "$OUT/r02_compare_decoders.txt"
+  python tools/sweep_modes.py > "$OUT/r02_mode_sweep.json" 2> "$OUT/r02_mode_sweep.txt"
+  python tools/bench_sync.py > "$OUT/r02_bench_sync_blocks.json"
+  python tests/tools/bench_receive_byte.py 8 1024 > "$OUT/r02_bench_receive_byte_cfg8.json"
+  python tools/bench_host_path.py 8 4096 -15 > "$OUT/r02_bench_host_path_cfg8.json"
+  python tools/bench_tx.py 8 4096 > "$OUT/r02_bench_tx_cfg8.json"
+  python bench.py --cfg 0 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/r02_bench_spa_fast_cfg0.json" 2>/dev/null
+  python bench.py --cfg 0 --decoder spa --no-cpu-baseline --no-extras > "$OUT/r02_bench_spa_cfg0.json" 2>/dev/null
 fi
-python "$ROOT/tools/hbm_traffic_from_pmc.py" "$OUT" "$OUT" || true     # -> $OUT/hbm_traffic.json, r01_pmc_sq_summary.json
 ls -la "$OUT"

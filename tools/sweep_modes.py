@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2]: sweep all 17 OFDM modes (each with the LDPC rate the reference pairs it
-with) and the three MFSK modes (ROBUST_0..2 = cfg 100..102), report per-mode RX throughput for the sum-product (reference) and min-sum decoders, at the
+with) and the three MFSK modes (ROBUST_0..2 = cfg 100..102), report per-mode RX throughput for the sum-product (reference), fp32 sum-product (spa_fast) and min-sum decoders, at the
 worst case (every frame runs all 50 iterations, Es/N0 = -15 dB; -25 dB for the MFSK modes) and at the operating point.
 Writes one JSON document; run on the GPU box:  python tools/sweep_modes.py > gpurun_out/sweep.json
 """
@@ -30,14 +30,15 @@ def main():
     res = {"frames_per_step": frames, "modes": {}}
     for cfg in list(range(17)) + [100, 101, 102]:
         m = {}
-        for dec in ("spa", "minsum"):
+        for dec in ("spa", "spa_fast", "minsum"):
             m[dec + "_50iters"] = run(cfg, dec, -25.0 if cfg >= 100 else -15.0, frames)
             m[dec + "_operating"] = run(cfg, dec, OPERATING_ESN0[cfg] + 1.0, frames)
         res["modes"][str(cfg)] = m
-        print("cfg %3d  spa@50 %9.0f f/s  minsum@50 %9.0f f/s  spa@op %9.0f f/s (%.1f it, %.3f ok)  minsum@op %9.0f f/s (%.3f ok)" % (
-            cfg, m["spa_50iters"]["frames_per_s"], m["minsum_50iters"]["frames_per_s"], m["spa_operating"]["frames_per_s"],
-            m["spa_operating"]["avg_iters"], m["spa_operating"]["decoded_fraction"], m["minsum_operating"]["frames_per_s"],
-            m["minsum_operating"]["decoded_fraction"]), file=sys.stderr)
+        print("cfg %3d  spa@50 %9.0f f/s (%.3f)  spa_fast@50 %9.0f f/s (%.3f)  minsum@50 %9.0f f/s  spa@op %9.0f f/s (%.1f it, %.3f ok)  spa_fast@op %9.0f f/s (%.3f ok)  minsum@op %9.0f f/s (%.3f ok)" % (
+            cfg, m["spa_50iters"]["frames_per_s"], m["spa_50iters"]["roofline_frac"], m["spa_fast_50iters"]["frames_per_s"], m["spa_fast_50iters"]["roofline_frac"],
+            m["minsum_50iters"]["frames_per_s"], m["spa_operating"]["frames_per_s"],
+            m["spa_operating"]["avg_iters"], m["spa_operating"]["decoded_fraction"], m["spa_fast_operating"]["frames_per_s"], m["spa_fast_operating"]["decoded_fraction"],
+            m["minsum_operating"]["frames_per_s"], m["minsum_operating"]["decoded_fraction"]), file=sys.stderr)
     print(json.dumps(res, indent=1))
 
 
