@@ -228,6 +228,9 @@ int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
  * can compare them bit for bit with the libm the reference calls (ldpc_decoder_SPA.cc:145,156).
  * atanh_out[i] is 0 where |in[i]| >= 1. */
 int mgpu_debug_spa_math(mgpu_ctx* ctx, const double* in, int n, double* tanh_out, double* atanh_out);
+/* test hook: the device atan / sincos of csrc/glibc_trig.h (restore_channel_amplitude: misc.cc:34-71; receive mixer: ofdm.cc:2331-2332)
+ * on n host doubles, for bit-for-bit comparison with the reference platform's libm. */
+int mgpu_debug_glibc_trig(mgpu_ctx* ctx, const double* in, int n, double* atan_out, double* sin_out, double* cos_out);
 
 #ifdef __cplusplus
 }

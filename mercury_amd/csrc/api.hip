@@ -726,6 +726,22 @@ int mgpu_debug_spa_math(mgpu_ctx* c, const double* in, int n, double* tanh_out, 
     });
 }
 
+int mgpu_debug_glibc_trig(mgpu_ctx* c, const double* in, int n, double* atan_out, double* sin_out, double* cos_out) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(in && atan_out && sin_out && cos_out && n > 0, "bad argument");
+        DevBuf d_in(size_t(n) * 8), d_a(size_t(n) * 8), d_s(size_t(n) * 8), d_c(size_t(n) * 8);
+        HIPCK(hipMemcpyAsync(d_in.p, in, size_t(n) * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(mgpu_glibc_trig_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_in.as<double>(), d_a.as<double>(), d_s.as<double>(),
+                           d_c.as<double>(), n);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(atan_out, d_a.p, size_t(n) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipMemcpyAsync(sin_out, d_s.p, size_t(n) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipMemcpyAsync(cos_out, d_c.p, size_t(n) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+    });
+}
+
 int mgpu_rx_batch_taps(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, mgpu_frame_stats* stats, const mgpu_stage_taps* taps) {
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {

@@ -44,6 +44,7 @@ extern "C" __global__ void mgpu_decimate_kernel(const double*, int, const int*, 
 #define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
+extern "C" __global__ void mgpu_glibc_trig_probe_kernel(const double*, double*, double*, double*, int);
 using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 #define DECL_MS(NE) extern "C" __global__ void mgpu_ldpc_minsum_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);

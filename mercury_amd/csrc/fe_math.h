@@ -2,6 +2,7 @@
 // stage kernels (stages.hip): the reference's complex division, linear interpolation and angle, operation for operation.
 #pragma once
 #include "fft256.h"   // c2
+#include "glibc_trig.h"   // atan / sincos as the reference platform's libm evaluates them, bit for bit
 
 // libgcc (GCC 11) __divdc3 main path
 __device__ __forceinline__ c2 cdiv(c2 n, c2 d) {
@@ -31,9 +32,9 @@ __device__ __forceinline__ c2 lerp(c2 a, double ax, c2 b, double bx, double x) {
 __device__ __forceinline__ double get_angle(c2 v) {
     double theta = 0;
     if (v.re == 0) theta = M_PI / 2;
-    else if (v.re > 0) theta = atan(v.im / v.re);
-    else if (v.re < 0 && v.im >= 0) theta = atan(v.im / v.re) + M_PI;
-    else if (v.re < 0 && v.im < 0) theta = atan(v.im / v.re) - M_PI;
+    else if (v.re > 0) theta = gl_atan(v.im / v.re);
+    else if (v.re < 0 && v.im >= 0) theta = gl_atan(v.im / v.re) + M_PI;
+    else if (v.re < 0 && v.im < 0) theta = gl_atan(v.im / v.re) - M_PI;
     return theta;
 }
 

@@ -28,14 +28,29 @@
 
 namespace {
 
-// restore_channel_amplitude for one cell (ofdm.cc:1453-1466, set_complex misc.cc:65-71): kept out of line so that the
-// constant tables of atan / cos / sin do not stay live (and spill) across the rest of the front-end kernel
+// restore_channel_amplitude for one cell (ofdm.cc:1453-1466, set_complex misc.cc:65-71), with the reference platform's atan and
+// sincos restated (glibc_trig.h): the unit phasor is bit-identical to the CPU's. Kept out of line so that the constants of the
+// three routines do not stay live (and spill) across the rest of the front-end kernel.
 __device__ __attribute__((noinline)) c2 unit_phasor(c2 h) {
     const double th = get_angle(h);
-    return {cos(th), sin(th)};
+    double s, c;
+    gl_sincos(th, &s, &c);
+    return {1 * c, 1 * s};
 }
 
 }  // namespace
+
+// device probe of glibc_trig.h for tests: atan, sin and cos of n arguments
+extern "C" __global__ void mgpu_glibc_trig_probe_kernel(const double* __restrict__ in, double* __restrict__ out_atan, double* __restrict__ out_sin,
+                                                        double* __restrict__ out_cos, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_atan[i] = gl_atan(in[i]);
+    double s, c;
+    gl_sincos(in[i], &s, &c);
+    out_sin[i] = s;
+    out_cos[i] = c;
+}
 
 // Sum n doubles from LDS in index order with one lane: the additions are a dependent chain by
 // construction (the reference's `+=` loop), so the only thing to hide is the LDS latency: fetch eight

@@ -100,7 +100,7 @@ extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_estimate_ker
 
 extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_restore_amplitude_kernel(MgpuDev T, double* __restrict__ Hio) {
     c2* H = reinterpret_cast<c2*>(Hio) + size_t(blockIdx.x) * T.G;
-    for (int c = threadIdx.x; c < T.G; c += ST_THREADS) { const double th = get_angle(H[c]); H[c] = {cos(th), sin(th)}; }
+    for (int c = threadIdx.x; c < T.G; c += ST_THREADS) { const double th = get_angle(H[c]); double sn, cs; gl_sincos(th, &sn, &cs); H[c] = {1 * cs, 1 * sn}; }
 }
 
 extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_equalize_kernel(MgpuDev T, const double* __restrict__ grid, const double* __restrict__ Hin,

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "glibc_trig.h"
+
 namespace {
 struct c2 { double re, im; };
 __device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -47,7 +49,9 @@ extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
                 v = {a * cs[2 * i], a * cs[2 * i + 1]};
             } else {
                 const double ph = 2 * M_PI * fc * double(i) * Ts;
-                v = {a * cos(ph), a * sin(ph)};
+                double sn, cs1;
+                gl_sincos(ph, &sn, &cs1);            // the reference's sincos() call restated (glibc_trig.h): bit-identical mixer
+                v = {a * cs1, a * sn};
             }
         }
         l[t] = v;

@@ -1561,6 +1561,18 @@ void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* ata
     }
 }
 
+/* the host libm functions exactly as get_angle / set_complex call them (misc.cc:34-71; cos + sin of one angle is one sincos() call
+ * in the reference's build, and in this one: see the relocation in oracle/_ref/obj/misc.o) */
+void morc_libm_atan_sincos(const double* in, int n, double* atan_out, double* sin_out, double* cos_out) {
+    /* through a volatile pointer: left to itself the compiler turns a sincos() whose results go to two arrays into separate sin()
+     * and cos() calls, which on x86-64 are different (FMA multiarch) routines with different last bits */
+    void (*volatile libm_sincos)(double, double*, double*) = sincos;
+    for (int i = 0; i < n; i++) {
+        atan_out[i] = atan(in[i]);
+        libm_sincos(in[i], &sin_out[i], &cos_out[i]);
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* Synthetic workload generator (the repo's own definition; DESIGN.md §"Synthetic inputs") */
 static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }

@@ -162,6 +162,8 @@ void morc_receive_byte(morc*, const double* passband, double carrier_hz, int tim
 
 /* host libm tanh / atanh as the reference's decoder calls them; atanh_out is 0 where |x| >= 1 */
 void morc_libm_tanh_atanh(const double* in, int n, double* tanh_out, double* atanh_out);
+/* host libm atan and sincos as get_angle / set_complex call them (misc.cc:34-71) */
+void morc_libm_atan_sincos(const double* in, int n, double* atan_out, double* sin_out, double* cos_out);
 
 /* cpu_baseline helper: run morc_rx on n frames laid out back to back; returns sum of iterations */
 long morc_rx_many(morc*, const double* baseband_c128, int n, int flags, int* iters_out, int* crc_out,

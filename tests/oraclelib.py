@@ -195,6 +195,12 @@ class Oracle(_Base):
         self.lib.morc_libm_tanh_atanh(_p(xin), C.c_int(xin.size), _p(t), _p(a))
         return t, a
 
+    def libm_atan_sincos(self, x):
+        xin = np.ascontiguousarray(x, np.float64).ravel()
+        a, s, c = np.zeros_like(xin), np.zeros_like(xin), np.zeros_like(xin)
+        self.lib.morc_libm_atan_sincos(_p(xin), C.c_int(xin.size), _p(a), _p(s), _p(c))
+        return a, s, c
+
     def rx_many(self, baseband, flags=FLAGS_RECEIVE_BYTE):
         bb = np.ascontiguousarray(baseband, np.complex128).reshape(-1, self.frame_samples)
         n = bb.shape[0]
