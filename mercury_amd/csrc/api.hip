@@ -125,18 +125,16 @@ void ctx_alloc(mgpu_ctx* c) {
             }
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
-        case MGPU_DEC_SPA_FAST:
+        case MGPU_DEC_SPA_FAST: {
             c->lds_dec = mgpu_spa_fast_lds_bytes(d.S, d.N);
-            switch ((d.S + 1023) / 1024) {
-                case 1: case 2: case 3: case 4: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne4; break;
-                case 5: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne5; break;
-                case 6: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne6; break;
-                case 7: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne7; break;
-                case 8: c->spa_kernel = mgpu_ldpc_spa_fast_kernel_ne8; break;
-                default: throw std::runtime_error("graph too large for the fp32 sum-product kernel");
-            }
+            if (d.S > 8 * 1024) throw std::runtime_error("graph too large for the fp32 sum-product kernel");
+            const char* e = std::getenv("MERCURY_SPA_FAST_THREADS");
+            c->dec_threads = e ? std::atoi(e) : 512;
+            if (c->dec_threads != 512 && c->dec_threads != 1024) throw std::runtime_error("MERCURY_SPA_FAST_THREADS must be 512 or 1024");
+            c->spa_kernel = c->dec_threads == 512 ? mgpu_ldpc_spa_fast_kernel_t512 : mgpu_ldpc_spa_fast_kernel_t1024;
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
+        }
         default: throw std::runtime_error("unknown decoder");
     }
 }
@@ -318,7 +316,7 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
         if (c->cfg.decoder == MGPU_DEC_GBF)
             hipLaunchKernelGGL(mgpu_ldpc_gbf_kernel, dim3(n), dim3(1024), c->lds_dec, s, c->ldev, llr, n, bits, iters, pay, st, var, sv);
         else   // sum-product or min-sum, the variant for this graph's round count
-            hipLaunchKernelGGL(c->spa_kernel, dim3(n), dim3(1024), c->lds_dec, s, c->ldev, llr, n, bits, iters, pay, st, var, sv);
+            hipLaunchKernelGGL(c->spa_kernel, dim3(n), dim3(c->dec_threads), c->lds_dec, s, c->ldev, llr, n, bits, iters, pay, st, var, sv);
         HIPCK(hipGetLastError());
     }
     if (c->timing) { HIPCK(hipEventRecord(c->ev[slot][3], s)); ++c->ev_count; c->ev_fe[c->ev_count % mgpu_ctx::kEvRing] = false; }

@@ -49,8 +49,8 @@ using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8
 extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 #define DECL_MS(NE) extern "C" __global__ void mgpu_ldpc_minsum_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_MS(4) DECL_MS(5) DECL_MS(6) DECL_MS(7) DECL_MS(8)
-#define DECL_SF(NE) extern "C" __global__ void mgpu_ldpc_spa_fast_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-DECL_SF(4) DECL_SF(5) DECL_SF(6) DECL_SF(7) DECL_SF(8)
+#define DECL_SF(T) extern "C" __global__ void mgpu_ldpc_spa_fast_kernel_t##T(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+DECL_SF(1024) DECL_SF(512)
 extern "C" __global__ void mgpu_ldpc_encode_kernel(MgpuDev, const uint8_t*, int, uint8_t*);
 extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*, const uint8_t*, int, const int*, int, int);
 
@@ -123,6 +123,7 @@ struct mgpu_ctx {
     bool ev_fe[kEvRing]{};          // whether the front-end ran in that slot
     size_t lds_fe = 0, lds_dec = 0, lds_tx = 0;
     DecoderKernel spa_kernel = nullptr;
+    int dec_threads = 1024;         // workgroup size of the decoder kernel
 
     template <typename T>
     T* keep(T* p) { owned.push_back(p); return p; }

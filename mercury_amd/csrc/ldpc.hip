@@ -324,13 +324,14 @@ extern "C" size_t mgpu_spa_fast_lds_bytes(int S, int N) {
     return size_t(4) * S + size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64;
 }
 
-template <int NE, int THREADS>
+template <int THREADS>
 __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
                                                 uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
                                                 uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
                                                 const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = T.S, N = T.N;
+    const int NE = (S + THREADS - 1) / THREADS;       // rounds: wave w works on bin w + (THREADS / 64) r in round r
     float* M = reinterpret_cast<float*>(smem);        // R or T per padded edge slot
     float* Lt = M + S;                                // posterior per variable
     float* Li = Lt + N;                               // channel LLR
@@ -461,19 +462,18 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
 }
 
-#define SPA_FAST_KERNEL(NE)                                                                                        \
-    extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_spa_fast_kernel_ne##NE(                   \
+// Two workgroup shapes: 1024 threads (2 workgroups per CU) and 512 threads (4 per CU where LDS allows: 37 KB each in mode 8).
+// The decoder is bound by waits (LDS round trips, the two barriers per iteration), not by instruction issue; smaller workgroups
+// mean barriers over 8 wavefronts instead of 16 and twice as many independent barrier domains per CU.
+#define SPA_FAST_KERNEL(THREADS)                                                                                   \
+    extern "C" __global__ __launch_bounds__(THREADS) void mgpu_ldpc_spa_fast_kernel_t##THREADS(                    \
         LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                        \
         int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,      \
         const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                        \
-        spa_fast_decode<NE, LDPC_THREADS>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in,  \
-                                          snr_variance_in);                                                         \
+        spa_fast_decode<THREADS>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
     }
-SPA_FAST_KERNEL(4)
-SPA_FAST_KERNEL(5)
-SPA_FAST_KERNEL(6)
-SPA_FAST_KERNEL(7)
-SPA_FAST_KERNEL(8)
+SPA_FAST_KERNEL(1024)
+SPA_FAST_KERNEL(512)
 
 // device probe of spa_math.h for tests: out_t[i] = tanh(in[i]); out_a[i] = atanh(in[i]) for |in[i]| < 1 else 0
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double* __restrict__ in, double* __restrict__ out_t,
