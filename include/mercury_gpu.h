@@ -228,6 +228,11 @@ int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
  * can compare them bit for bit with the libm the reference calls (ldpc_decoder_SPA.cc:145,156).
  * atanh_out[i] is 0 where |in[i]| >= 1. */
 int mgpu_debug_spa_math(mgpu_ctx* ctx, const double* in, int n, double* tanh_out, double* atanh_out);
+/* Test hook: the Schmidl-Cox metric of every candidate (time_sync_preamble_with_metric, ofdm.cc:1893-1941, before the peak selection) for W
+ * windows of `size` interpolated baseband samples; vals: [W][ceil((size - preamble_nSymb*Nofdm*4) / step)]. variant: -1 = the library's choice,
+ * 0 = the staged kernel, 1 = the streaming kernel (falls back to the staged one when the geometry does not fit it). */
+int mgpu_debug_tsync_metric(mgpu_ctx* ctx, const double* baseband_interp, int W, int size, int step, int variant, double* vals);
+
 /* test hook: the device atan / sincos of csrc/glibc_trig.h (restore_channel_amplitude: misc.cc:34-71; receive mixer: ofdm.cc:2331-2332)
  * on n host doubles, for bit-for-bit comparison with the reference platform's libm. */
 int mgpu_debug_glibc_trig(mgpu_ctx* ctx, const double* in, int n, double* atan_out, double* sin_out, double* cos_out);

@@ -242,11 +242,46 @@ const double* mixer_table(mgpu_ctx* c, double carrier_hz, size_t count, hipStrea
     return c->d_mix_cs;
 }
 
+// The streaming coarse kernel (sync.hip: mgpu_tsync_metric_stream_kernel) when the geometry fits it and there are enough windows to give
+// every SIMD a wavefront; false = use the staged kernel. MERCURY_TSYNC_STREAM=0 / 1 forces the choice (tests compare the two).
+static bool tsync_stream_launch(const double* d_bb, int stride, const int* d_start, const int* d_widx, const int* d_ncand, int ncand_max, int n, int step,
+                                int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s, int variant) {
+    static const int env = [] { const char* e = getenv("MERCURY_TSYNC_STREAM"); return e ? atoi(e) : -1; }();
+    const int force = variant >= 0 ? variant : env;
+    if (force == 0 || (force < 0 && n < 32)) return false;                   // measured: 16 windows 0.21 vs 0.17 ms staged, 64 windows 0.26 vs 0.34 ms
+    int g[6];
+    mgpu_tsync_stream_geometry(g);
+    if (step != g[0] || ngi_i != g[1] || nfft_i != g[2] || pre_nsymb != g[3]) return false;      // the kernel is built for the reference's coarse search
+    const int K = g[4], ring = g[5];
+    const int sym = ngi_i + nfft_i, half = nfft_i / 2, PS = ngi_i + half, NP = pre_nsymb * PS;
+    const int J = (NP + K - 1) / K;
+    // the span the candidates in flight read, relative to step * (newest candidate): candidate `e` periods older is at pair rho + K*e
+    int lo = 1 << 30, hi = -(1 << 30);
+    for (int rho = 0; rho < K; rho += 4)
+        for (int e = 0; e < J; ++e) {
+            const int np = rho + K * e;
+            if (np >= NP) break;
+            const int l = np / PS, k = np % PS, a = l * sym + k, b = a + (k < ngi_i ? nfft_i : half);
+            lo = std::min(lo, a - step * e);
+            hi = std::max(hi, b + 4 - step * e);
+        }
+    if (hi - lo + 128 > ring) return false;
+    // pieces of the candidate range per window: about one wavefront per SIMD (4 rings of 35 KB fit a CU's LDS), at least J candidates each
+    int pieces = std::max(1, 1024 / n);
+    pieces = std::min(pieces, std::max(1, ncand_max / J));
+    const int cpp = (ncand_max + pieces - 1) / pieces;
+    pieces = (ncand_max + cpp - 1) / cpp;
+    hipLaunchKernelGGL(mgpu_tsync_metric_stream_kernel, dim3(n, pieces), dim3(64), 0, s, d_bb, stride, d_start, d_widx, d_ncand, ncand_max, d_vals, lo, hi, cpp);
+    return true;
+}
+
 void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, const int* d_widx, const int* d_ncand, int ncand_max, int n, int step,
-                         int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s) {
+                         int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s, int variant) {
     if (ngi_i % 64 || (nfft_i / 2) % 64) {    // the staged kernels walk the preamble in chunks of 8 / 64 pairs
         hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncand_max + 63) / 64, n), dim3(64), 0, s, d_bb, stride, d_start, d_widx, d_ncand,
                            ncand_max, step, pre_nsymb, ngi_i, nfft_i, d_vals);
+    } else if (step > 4 && tsync_stream_launch(d_bb, stride, d_start, d_widx, d_ncand, ncand_max, n, step, pre_nsymb, ngi_i, nfft_i, d_vals, s, variant)) {
+        // many windows: one wavefront streams each (piece of a) window through an LDS ring, see sync.hip
     } else {
         // The coarse search re-reads every sample ~44 times (overlapping candidates) and is bound by that traffic. Launching it over
         // 64 windows at a time keeps the windows in flight (95 MB) inside the 256 MB Infinity Cache instead of streaming 1.5 GB per
@@ -568,6 +603,25 @@ int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int 
             select_peak(&cand[size_t(w) * ncand], ncand, step, size, location_to_return, nTrials_max, &delay[w], &corr);
             if (correlation) correlation[w] = corr;
         }
+    });
+}
+
+int mgpu_debug_tsync_metric(mgpu_ctx* c, const double* bb, int W, int size, int step, int variant, double* vals) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        const auto& t = c->tab;
+        const int interp = 4, sym = t.Nofdm * interp, L = t.preamble * sym;
+        need(bb && vals && W > 0 && size > L && step >= 1 && variant >= -1 && variant <= 1, "bad argument");
+        const int ncand = (size - L + step - 1) / step;
+        DevBuf d_in(size_t(W) * size * 16), d_vals(size_t(W) * ncand * 8);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemsetAsync(d_vals.p, 0xff, size_t(W) * ncand * 8, s));
+        HIPCK(hipEventRecord(c->sync_ev[0], s));
+        launch_tsync_metric(d_in.as<double>(), size, nullptr, nullptr, nullptr, ncand, W, step, t.preamble, t.Ngi * interp, t.Nfft * interp, d_vals.as<double>(), s, variant);
+        HIPCK(hipEventRecord(c->sync_ev[1], s));
+        HIPCK(hipMemcpyAsync(vals, d_vals.p, size_t(W) * ncand * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
     });
 }
 

@@ -35,6 +35,8 @@ extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, co
 extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" int mgpu_tsync_coarse_threads();
+extern "C" __global__ void mgpu_tsync_metric_stream_kernel(const double*, int, const int*, const int*, const int*, int, double*, int, int, int);
+extern "C" void mgpu_tsync_stream_geometry(int*);
 extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double*);
 extern "C" __global__ void mgpu_span_energy_kernel(const double*, int, const int*, const int*, int, int, double*, int*);
@@ -173,7 +175,7 @@ const double* mixer_table(mgpu_ctx* c, double carrier_hz, size_t count, hipStrea
 // Schmidl-Cox metrics of n windows (sync.hip): picks the kernel for the step and the segment lengths.
 // d_start / d_widx / d_ncand may be null (search from sample 0, window k = k, ncand_max candidates each).
 void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, const int* d_widx, const int* d_ncand, int ncand_max, int n, int step,
-                         int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s);
+                         int pre_nsymb, int ngi_i, int nfft_i, double* d_vals, hipStream_t s, int variant = -1);
 
 // Every entry point that takes a context runs with the context's device current and puts the caller's device back
 // afterwards, so one host thread can hold contexts on several GPUs (lazy workspaces, per-call buffers, page-locked

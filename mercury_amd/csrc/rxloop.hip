@@ -307,8 +307,11 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
         // 1024) or already in HBM (hipMemcpyDefault). A copy stream brings them over slice by slice; the mixer + time-sync filter
         // and the Schmidl-Cox metric of a slice run as soon as it has landed, under the copies of the following slices (a copy
         // from pageable memory holds the host thread, but the kernels of the slices before it are already queued).
-        const int kSlice = 64;
+        const int kSlice = 64, kCoarseGroup = 2;
         const int nsl = (W + kSlice - 1) / kSlice;
+        hipPointerAttribute_t pattr{};
+        const bool on_device = hipPointerGetAttributes(&pattr, passband) == hipSuccess && pattr.type == hipMemoryTypeDevice;
+        if (!on_device) (void)hipGetLastError();
         while (int(lp.ws.slice_ev.size()) < nsl) {
             hipEvent_t e = nullptr;
             HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -332,9 +335,15 @@ int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mg
                                lp.d_carrier.as<double>(), nullptr, 0, lp.buf, 1, c->d_fir[0], ntaps_ts, 48000.0, 1.4142135623730951, lp.d_bbi.as<double>(),
                                lp.d_ia.as<int>() + off, mix_cs);
             HIPCK(hipGetLastError());
-            if (!lp.mfsk && ncand0 > 0)
-                launch_tsync_metric(lp.d_bbi.as<double>() + size_t(off) * lp.buf * 2, lp.buf, nullptr, nullptr, nullptr, ncand0, n, kCoarseStep, lp.pre, lp.ngi_i,
-                                    lp.nfft_i, lp.d_vals.as<double>() + size_t(off) * ncand0, s);
+            // The coarse search streams each window through LDS with one wavefront per SIMD (sync.hip) and is the more efficient the more
+            // windows a launch has: from host memory it follows the upload in groups of kCoarseGroup slices (the group's search runs under
+            // the next group's copies), windows that already lie in HBM are searched in one launch.
+            const bool group_end = on_device ? k == nsl - 1 : ((k + 1) % kCoarseGroup == 0 || k == nsl - 1);
+            if (!lp.mfsk && ncand0 > 0 && group_end) {
+                const int g0 = on_device ? 0 : (k / kCoarseGroup) * kCoarseGroup * kSlice, gn = off + n - g0;
+                launch_tsync_metric(lp.d_bbi.as<double>() + size_t(g0) * lp.buf * 2, lp.buf, nullptr, nullptr, nullptr, ncand0, gn, kCoarseStep, lp.pre, lp.ngi_i,
+                                    lp.nfft_i, lp.d_vals.as<double>() + size_t(g0) * ncand0, s);
+            }
         }
         pt.mark(s, "upload + p2b + coarse metric");
         {   // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order. The sum is a long

@@ -208,6 +208,144 @@ extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_generic_kerne
     vals[size_t(blockIdx.y) * ncand_max + cand] = cc;
 }
 
+// ---- streaming coarse search (many windows per launch) ----
+// The staged kernel above fetches every sample once per candidate that overlaps it (~44 times: 70 GB of L2 traffic per 1024
+// windows, which is what bounds it). Here one wavefront walks a window once. Lane j of the first J lanes holds candidate
+// q (q mod J == j), and candidate q starts K pair-steps (one "period") after candidate q-1. K is chosen so that the samples a
+// candidate consumes per period (~ K * sym / pairs-per-symbol) match the candidate spacing `step`: all candidates in flight then
+// read within one sliding span of < 2048 samples around step*q, which lives in a wave-private LDS ring that is refilled with 1-2
+// coalesced 64-sample blocks per period. Every sample comes from L2/HBM once per wave; each candidate's three sums still run in
+// the reference's order. Rows of 16 samples are padded to 17 so that lanes 48 samples (3 rows) apart read distinct banks.
+//
+// With one wavefront per SIMD (a ring is 35 KB) the kernel runs at the speed of its instruction stream, so the bookkeeping is
+// kept off the vector unit: the geometry is a template parameter, which makes the places where a candidate of age e (periods
+// since its start) crosses from the guard-interval pairs to the half-symbol pairs or into the next preamble symbol compile-time
+// constants per chunk; the one or two lanes concerned are found with scalar arithmetic and patched under the exec mask. Per chunk
+// of 4 pairs a lane spends 48 fp64 operations, two position increments and two ring-slot computations.
+#define TSS_K 52
+#define TSS_CHUNKS (TSS_K / 4)
+#define TSS_RING 2048
+#define TSS_RING_BYTES ((TSS_RING / 16) * 17 * 16)
+
+namespace {
+__device__ __forceinline__ unsigned tss_slot(unsigned p) { const unsigned r = p & (TSS_RING - 1); return (r + (r >> 4)) << 4; }
+
+template <int STEP, int NGI_, int NFFT_, int PRE_>
+struct TssGeom {
+    static constexpr int STEPV = STEP, NGI = NGI_, NFFT = NFFT_, PRE = PRE_, SYM = NGI_ + NFFT_, HALF = NFFT_ / 2, PS = NGI_ + HALF, NP = PRE_ * PS;
+    static constexpr int J = (NP + TSS_K - 1) / TSS_K;                   // candidates in flight
+    static constexpr int FZP = NP / TSS_K, FZC = (NP % TSS_K) / 4;       // a candidate is complete before chunk FZC of period (its start + FZP)
+    static_assert(STEP % 4 == 0 && NGI % 4 == 0 && HALF % 4 == 0 && J <= 64 && STEP <= 128, "geometry");
+    static_assert(TSS_K == 4 * ((STEP * PS) / (4 * SYM)), "the skew must track the candidate spacing");
+};
+
+// segment changes of the candidates in flight before the chunk with index ch of a period whose starting lane is js
+template <class G>
+__device__ __forceinline__ void tss_segment_events(int ch, int js, int lane, int& pa, int& pb) {
+#pragma unroll
+    for (int e = 0; e < G::J; ++e) {
+        const int n = TSS_K * e + 4 * ch;                            // pair index of the candidate of age e at this chunk
+        const int k = n % G::PS;
+        if (n > 0 && n < G::NP && (k == 0 || k == G::NGI)) {
+            const int le = js - e < 0 ? js - e + G::J : js - e;     // scalar
+            if (k == 0) { if (lane == le) { pa += G::SYM - G::PS; pb += G::SYM - G::PS + G::NFFT - G::HALF; } }
+            else if (lane == le) pb -= G::NFFT - G::HALF;
+        }
+    }
+}
+}  // namespace
+
+// the geometry the kernel is built for: the reference's coarse search (step 100, ofdm.cc:1893) on the x4 interpolated baseband of its
+// Nfft 256 / guard interval 1/16 / 4-symbol-preamble modes; anything else goes to the staged kernel
+typedef TssGeom<100, 64, 1024, 4> TssCoarse;
+extern "C" void mgpu_tsync_stream_geometry(int* g) { g[0] = TssCoarse::STEPV; g[1] = TssCoarse::NGI; g[2] = TssCoarse::NFFT; g[3] = TssCoarse::PRE; g[4] = TSS_K; g[5] = TSS_RING; }
+
+template <class G>
+__device__ __forceinline__ void tss_run(const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
+                                        const int* __restrict__ ncand_w, int ncand_max, double* __restrict__ vals, int lo, int hi, int cpp, char* ring) {
+    // lo / hi: the span [step*q + lo, step*q + hi) holds everything the candidates in flight read during the period that candidate
+    // q starts in (the host enumerates it); cpp: candidates per workgroup (blockIdx.y = piece of the candidate range)
+    const int wsel = widx ? widx[blockIdx.x] : blockIdx.x;
+    const int wstart = start ? start[blockIdx.x] : 0;
+    const int ncand = ncand_w ? ncand_w[blockIdx.x] : ncand_max;
+    const int c0 = blockIdx.y * cpp;
+    if (c0 >= ncand) return;
+    const int nq = min(cpp, ncand - c0);
+    const int lane = threadIdx.x;
+    const int last = stride - wstart - 1;
+    const v2d* winv = reinterpret_cast<const v2d*>(bb) + (size_t(wsel) * stride + wstart);
+    constexpr int step = G::STEPV;
+    int loaded = max(step * c0 + lo, 0) & ~63;
+    for (const int need = step * c0 + hi; loaded < need; loaded += 64)
+        *reinterpret_cast<v2d*>(ring + tss_slot(unsigned(loaded + lane))) = winv[min(loaded + lane, last)];
+    const int nperiods = (nq + G::FZP + (G::FZC ? 1 : 0) + 1) & ~1;  // even: the two register sets below swap roles every chunk, 13 chunks per period
+    int pa = step * c0, pb = pa + G::NFFT;                           // every lane starts somewhere inside the ring; lane 0 is candidate 0
+    double cc = 0, na = 0, nb = 0;
+    int js = 0, jf = 0;                                              // lanes of the candidate starting / finishing in this period
+    // The reads of chunk i+1 are issued before chunk i is accumulated (one wavefront per SIMD: nothing else hides the LDS latency).
+    c2 xa[2][4], xb[2][4];
+    auto fetch = [&](c2* da, c2* db) {
+        const c2* qa = reinterpret_cast<const c2*>(ring + tss_slot(unsigned(pa)));
+        const c2* qb = reinterpret_cast<const c2*>(ring + tss_slot(unsigned(pb)));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { da[m] = qa[m]; db[m] = qb[m]; }
+        pa += 4; pb += 4;
+    };
+    auto period = [&](int p, auto parity) {
+        constexpr int par = decltype(parity)::value;
+        // request what the next period needs beyond `loaded`; it goes into the ring once this period's last chunk has been read
+        const int nblk = (step * (c0 + p + 1) + hi - loaded + 63) >> 6;            // 0..2
+        v2d pf0 = {0, 0}, pf1 = {0, 0};
+        if (nblk > 0) pf0 = winv[min(loaded + lane, last)];
+        if (nblk > 1) pf1 = winv[min(loaded + 64 + lane, last)];
+        const int jz = js;                                           // the lane whose new candidate begins with this period's chunk 0
+#pragma unroll
+        for (int ch = 0; ch < TSS_CHUNKS; ++ch) {
+            const int cur = (ch + par) & 1, nxt = cur ^ 1;
+            if (ch == TSS_CHUNKS - 1) {
+                if (nblk > 0) *reinterpret_cast<v2d*>(ring + tss_slot(unsigned(loaded + lane))) = pf0;
+                if (nblk > 1) *reinterpret_cast<v2d*>(ring + tss_slot(unsigned(loaded + 64 + lane))) = pf1;
+                loaded += nblk * 64;
+                js = js + 1 == G::J ? 0 : js + 1;
+                if (lane == js) { pa = step * (c0 + p + 1); pb = pa + G::NFFT; }    // next period's starter
+                tss_segment_events<G>(0, js, lane, pa, pb);
+            } else {
+                tss_segment_events<G>(ch + 1, js, lane, pa, pb);
+            }
+            // the reads of the next chunk go between the previous chunk's arithmetic and this chunk's: tying their addresses to the sums keeps
+            // the optimiser from collecting a period's reads ahead of its arithmetic (13 chunks of operands do not fit the registers)
+            asm volatile("" : "+v"(pa), "+v"(pb), "+v"(cc), "+v"(na), "+v"(nb));
+            fetch(xa[nxt], xb[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch == G::FZC && p >= G::FZP) {
+                const int q = p - G::FZP;
+                if (q < nq && lane == jf) {
+                    double r = 0.0;
+                    if (!(na < 0.001 || nb < 0.001)) r = cc / sqrt(na * nb);
+                    vals[size_t(blockIdx.x) * ncand_max + c0 + q] = r;
+                }
+                jf = jf + 1 == G::J ? 0 : jf + 1;
+            }
+            if (ch == 0 && lane == jz) { cc = 0; na = 0; nb = 0; }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ts_accumulate(xa[cur][m], xb[cur][m], cc, na, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    fetch(xa[0], xb[0]);
+    for (int p = 0; p < nperiods; p += 2) {
+        period(p, std::integral_constant<int, 0>());
+        period(p + 1, std::integral_constant<int, 1>());
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64) void mgpu_tsync_metric_stream_kernel(
+    const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
+    const int* __restrict__ ncand_w, int ncand_max, double* __restrict__ vals, int lo, int hi, int cpp) {
+    __shared__ __attribute__((aligned(16))) char ring[TSS_RING_BYTES];
+    tss_run<TssCoarse>(bb, stride, start, widx, ncand_w, ncand_max, vals, lo, hi, cpp, ring);
+}
+
 #define TS_DCH 64
 #define TS_DSPAN (63 * 4 + TS_DCH)      // step <= 4
 

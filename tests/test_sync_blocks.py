@@ -279,3 +279,24 @@ def test_gpu_detect_ack_pattern_from_passband_matches_oracle_chain():
     m1, k1 = rx.detect_ack_pattern_from_passband(wins[:1], CARRIER, 1)
     assert k1[0] == 16 and m1[0] > 12.0                                               # the ACK pattern is found in its window
     rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 16])
+def test_gpu_streaming_coarse_metric_equals_staged_kernel_on_every_candidate(cfg):
+    """The many-window coarse search (one wavefront streams a window through an LDS ring, sync.hip) against the staged kernel that the
+    oracle comparisons above pin: every candidate's metric bit-identical, for whole capture windows, short windows (fewer candidates than
+    lanes in flight, one candidate), several windows per launch (pieces of a window per wavefront) and many windows (one piece)."""
+    from mercury_amd import RxPhy
+    rx = RxPhy(cfg, max_batch=1)
+    rng = np.random.default_rng(SEED + cfg)
+    L = rx.preamble_nsymb * rx.Nofdm * 4
+    full = rx.receive_buffer_samples()
+    for W, size in [(3, full), (40, full), (2, L + 1), (2, L + 100 * 7 + 3), (5, L + 100 * 45), (5, L + 100 * 46 + 50), (1100, L + 100 * 60 + 1)]:
+        z = (rng.standard_normal((W, size)) + 1j * rng.standard_normal((W, size))) * np.exp(rng.uniform(-6, 2, (W, 1)))
+        z[0, : size // 3] = 0.0                                        # the "no signal" branch of the metric (sums below 0.001)
+        a = rx.debug_tsync_metric(z, 100, variant=0)
+        b = rx.debug_tsync_metric(z, 100, variant=1)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (cfg, W, size)
+        assert np.array_equal(rx.debug_tsync_metric(z, 100).view(np.uint64), a.view(np.uint64))
+    rx.close()
