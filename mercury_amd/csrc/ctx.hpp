@@ -108,6 +108,9 @@ struct mgpu_ctx {
     void* rxloop_ws = nullptr;      // device workspace of mgpu_receive_byte_batch, kept between calls (rxloop.hip)
     int rxloop_ws_windows = 0;
     void (*rxloop_ws_free)(void*) = nullptr;
+    void* rb_stage = nullptr;       // mgpu_receive_byte_batch from host memory: landing area of the whole call's windows (uploaded by a helper thread)
+    size_t rb_stage_cap = 0;
+    hipStream_t rb_stream = nullptr;
     double* d_mix_cs = nullptr;     // receive mixer: cos / sin of the carrier phase per sample index (host libm) for mix_carrier
     double mix_carrier = -1;
     size_t mix_count = 0, mix_cap = 0;

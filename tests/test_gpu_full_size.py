@@ -117,6 +117,11 @@ def test_audio_loopback_transmit_byte_to_receive_byte_1024_windows():
     assert int(r["stats"]["message_decoded"].sum()) == W
     r_host = rx.receive_byte(wins[:64].cpu().numpy(), carrier)  # same windows from host memory: same answers
     assert np.array_equal(r_host["payload"], r["payload"][:64]) and np.array_equal(r_host["stats"], r["stats"][:64])
+    # 640 and all 1024 windows from host memory: the call is cut into sub-batches (320 + 320, 512 + 512) that a helper thread uploads
+    # while the previous one is being received — same answers, window for window
+    for n_host in (640, W):
+        r_host = rx.receive_byte(wins[:n_host].cpu().numpy(), carrier)
+        assert np.array_equal(r_host["payload"], r["payload"][:n_host]) and np.array_equal(r_host["stats"], r["stats"][:n_host]), n_host
     assert np.array_equal(r["payload"][:, : rx.payload_bytes], msgs.cpu().numpy())
     assert np.abs(r["stats"]["delay"] - delays.cpu().numpy()).max() <= 8 * 4          # within the guard interval's reach
     rx.close()

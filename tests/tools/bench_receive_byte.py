@@ -35,19 +35,27 @@ def main():
     rx = RxPhy(cfg, max_batch=W)
     rx.receive_byte(wins[:8], oraclelib.CARRIER)          # warm-up (kernel load)
     rx.receive_byte(wins, oraclelib.CARRIER)              # and once at full size: the per-batch device buffers are allocated on first use (3.7 ms)
-    t0 = time.perf_counter()
-    out = rx.receive_byte(wins, oraclelib.CARRIER)
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        out = rx.receive_byte(wins, oraclelib.CARRIER)
+        dts.append(time.perf_counter() - t0)
+    print("pageable runs (ms):", [round(x * 1e3, 2) for x in dts], file=sys.stderr)
+    dt = sorted(dts)[len(dts) // 2]
     from mercury_amd.physical_layer import pinned_empty
     pin = pinned_empty(wins.shape, np.float64)             # the same windows in page-locked memory (mgpu_alloc_host)
     pin[...] = wins
-    t0 = time.perf_counter()
-    out_pin = rx.receive_byte(pin, oraclelib.CARRIER)
-    dt_pin = time.perf_counter() - t0
+    dts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out_pin = rx.receive_byte(pin, oraclelib.CARRIER)
+        dts.append(time.perf_counter() - t0)
+    dt_pin = sorted(dts)[1]
     assert np.array_equal(out_pin["payload"], out["payload"])
     import torch
     dwin = torch.from_numpy(wins).to("cuda:0")             # the same windows already resident in HBM
     torch.cuda.synchronize()
+    rx.receive_byte_dev(dwin.data_ptr(), W, oraclelib.CARRIER)    # the workspace grows to W windows on first use (host calls work in sub-batches)
     t0 = time.perf_counter()
     out_dev = rx.receive_byte_dev(dwin.data_ptr(), W, oraclelib.CARRIER)
     dt_dev = time.perf_counter() - t0
@@ -62,7 +70,7 @@ def main():
         same += int(r["message_decoded"] == out["stats"]["message_decoded"][w] and r["delay"] == out["stats"]["delay"][w])
     dc = time.perf_counter() - t0
     print(json.dumps({"cfg": cfg, "windows": W, "window_samples": n, "frame_samples_passband": nframe, "gpu_windows_per_s": W / dt,
-                      "gpu_ms_per_batch": dt * 1e3, "gpu_windows_per_s_pinned_input": W / dt_pin, "gpu_windows_per_s_device_input": W / dt_dev, "decoded": ok, "payload_correct": good, "avg_trials": float(out["stats"]["sync_trials"].mean()),
+                      "gpu_ms_per_batch": dt * 1e3, "timing": "median of 4 calls (host input), 3 (pinned), 1 after warm-up (device)", "gpu_windows_per_s_pinned_input": W / dt_pin, "gpu_windows_per_s_device_input": W / dt_dev, "decoded": ok, "payload_correct": good, "avg_trials": float(out["stats"]["sync_trials"].mean()),
                       "cpu_oracle_windows_per_s_1core": ncpu / dc, "cpu_sample": ncpu, "cpu_gpu_same_decision": same}))
 
 
