@@ -33,7 +33,7 @@ struct MgpuDev {
     int payload_bytes, payload_stride, frame_samples;
     int agc, var_eq, max_iters;
     int staircase;                 // LDPC parity part is the plain IRA staircase (check c holds parity c-1 and c only)
-    int regular_lattice;           // pilots exactly where (row - col) % 3 == 0 (true for all 17 modes)
+    int regular_lattice;           // 1: pilots exactly where (row - col) % 3 == 0 (true for all 17 modes); 2: and the LS window is wide enough for >= 3 pilots per row and residue
     double pilot_boost;
     float minsum_alpha;
     // MFSK modes (mfsk_M == 0 for the OFDM modes)

@@ -76,7 +76,7 @@ __device__ __forceinline__ double serial_sum(const double* red, int n) {
 struct FeCarve { int fft_waves; size_t rsz, work, total; };
 __host__ __device__ inline FeCarve fe_carve(int G, int nPilots, int nBits) {
     FeCarve c;
-    c.rsz = size_t(16) * nPilots > size_t(4) * nBits ? size_t(16) * nPilots : size_t(4) * nBits;
+    c.rsz = size_t(16) * (nPilots + 8) > size_t(4) * nBits ? size_t(16) * (nPilots + 8) : size_t(4) * nBits;   // + 8: zero pad behind the signed pilots (LS row reads)
     c.rsz = (c.rsz + 15) & ~size_t(15);
     const size_t per_wave = size_t(FFT256_STRIDE) * 16;
     size_t w = (size_t(16) * G + c.rsz) / per_wave;
@@ -164,13 +164,17 @@ extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel
     // ---- channel estimate at the pilots -------------------------------------------------------
     const int hw = T.lsw / 2;
     const bool ls_fast = T.estimator != 0 && T.regular_lattice;
+    int ls_rows = 0;     // 1: every window row holds >= 3 pilots and every pilot of the frame is finite -> the branch-free row loop below
     if (ls_fast) {       // x*y for the LS sums: the pilot's sign applied once ((-w)*y == w*(-y) exactly), in pilot order
-        for (int p = tid; p < T.nPilots; p += FE_THREADS) {
+        int finite = 1;
+        for (int p = tid; p < T.nPilots + 8; p += FE_THREADS) {
+            if (p >= T.nPilots) { yp[p] = {0.0, 0.0}; continue; }
             const int q = T.pilot_cell[p];
             const c2 y = grid[q];
             yp[p] = type[q] < 0 ? c2{-y.re, -y.im} : y;
+            finite &= (fabs(y.re) < __builtin_inf()) & (fabs(y.im) < __builtin_inf());
         }
-        __syncthreads();
+        ls_rows = __syncthreads_and(finite) && T.regular_lattice == 2;
     }
     for (int p = tid; p < T.nPilots; p += FE_THREADS) {
         const int c = T.pilot_cell[p], i = c / Nc, j = c - i * Nc;
@@ -198,6 +202,42 @@ extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel
                     for (int k = k0; k <= k1; ++k) { n += r == 0 ? cntr[0] : r == 1 ? cntr[1] : cntr[2]; r = r == 2 ? 0 : r + 1; }
                 }
                 const double w = T.ls_weight[n];
+                if (ls_rows) {
+                    // Rows k0, k0+1, k0+2, k0+3, ... cycle through the three column residues, so a lane's (pilot count, first pilot) pair of a
+                    // row depends only on the row's place in that cycle. A row's first three pilots are always inside the window; pilots
+                    // four to seven are added with the weight w or +0.0: x + (+-0 * y) == x exactly for finite y, and the sums start at +0.0
+                    // and can therefore never be -0.0. Same terms in the same order as the loop below, without its per-term branches.
+                    const int r0 = k0 % 3;
+                    int ptr[3];
+                    double wq[3][4];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int r = r0 + q >= 3 ? r0 + q - 3 : r0 + q;
+                        const int cn = r == 0 ? cntr[0] : r == 1 ? cntr[1] : cntr[2];
+                        ptr[q] = 50 * ((k0 + q) / 3) + (r == 0 ? offr[0] : r == 1 ? offr[1] : offr[2]);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) wq[q][m] = m + 3 < cn ? w : 0.0;
+                    }
+                    auto add_row = [&](int q) {
+                        const c2* row = yp + ptr[q];
+                        const c2 v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3], v4 = row[4], v5 = row[5], v6 = row[6];
+                        hr += w * v0.re; hi += w * v0.im;
+                        hr += w * v1.re; hi += w * v1.im;
+                        hr += w * v2.re; hi += w * v2.im;
+                        hr += wq[q][0] * v3.re; hi += wq[q][0] * v3.im;
+                        hr += wq[q][1] * v4.re; hi += wq[q][1] * v4.im;
+                        hr += wq[q][2] * v5.re; hi += wq[q][2] * v5.im;
+                        hr += wq[q][3] * v6.re; hi += wq[q][3] * v6.im;
+                        ptr[q] += 50;
+                    };
+                    for (int k = k0; k <= k1; k += 3) {
+                        add_row(0);
+                        if (k + 1 <= k1) add_row(1);
+                        if (k + 2 <= k1) add_row(2);
+                    }
+                    H[c] = {hr, hi};
+                    continue;
+                }
                 int km = k0 % 3, rowbase = 50 * (k0 / 3);
                 for (int k = k0; k <= k1; ++k) {
                     const int cnt = km == 0 ? cntr[0] : km == 1 ? cntr[1] : cntr[2];
