@@ -6,10 +6,15 @@
 // positions p and p + 2^(8-st), and bin k ends up at position brev8(k). Every butterfly has the same operands
 // and the same twiddle (index (brev8(p0) & (2^(st-1)-1)) * 2^(8-st)) as the reference's, hence the same
 // roundings. A lane holds four elements and does two stages in registers between LDS transpositions
-// (partners 64, 16, 4 and 1 positions apart in turn): 3 round trips through LDS instead of 8, all of them
-// contiguous or padded (address = p + p/16) so that no access pattern collides on a bank. The work buffer is
-// private to the wavefront and the LDS operations of one wavefront execute in order, so only wave-level
-// scheduling barriers are needed.
+// (partners 64, 16, 4 and 1 positions apart in turn): 3 round trips through LDS instead of 8. A 16-byte LDS
+// access is served 16 lanes (reads: the groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32) or 8
+// consecutive lanes (writes) per cycle, without conflict when those lanes touch distinct 16-byte columns
+// (address / 16 mod 16). Position p is therefore kept at entry (p & ~15) | ((p & 15) ^ X[(p >> 4) & 7]) with
+// X = xor of {4, 1, 14} over the set bits: of all 4x4 bit matrices this one makes every one of the seven access
+// patterns below conflict-free (the earlier padding p + p/16 paid 224 LDS cycles per transform where 144 are
+// needed), and twiddle j lies at entry j ^ (j >> 4) (144 -> 48 cycles: the late stages read 64 different
+// twiddles whose indices are bit-reversed lane numbers). The work buffer is private to the wavefront and the
+// LDS operations of one wavefront execute in order, so only wave-level scheduling barriers are needed.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,7 +22,10 @@ struct c2 { double re, im; };
 
 __device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 
-#define FFT256_STRIDE 272   // c2 entries of wave-private LDS work space: 256 positions + one pad per 16
+#define FFT256_STRIDE 256   // c2 entries of wave-private LDS work space
+
+// entry of twiddle j (0..127) in the LDS table every caller fills: tw[fft256_tw_slot(j)] = exp(-+ 2 pi i j / 256)
+__host__ __device__ __forceinline__ int fft256_tw_slot(int j) { return j ^ (j >> 4); }
 
 __device__ __forceinline__ int brev8(int p) { return int(__brev(unsigned(p)) >> 24); }
 
@@ -33,11 +41,14 @@ __device__ __forceinline__ void wave_fft256(c2& r0, c2& r1, c2& r2, c2& r3, c2* 
     };
     auto bfly = [&](c2& lo, c2& hi, int p0, int st) {
         const int j = brev8(p0) & ((1 << (st - 1)) - 1);
-        bfly_w(lo, hi, tw[j << (8 - st)]);
+        bfly_w(lo, hi, tw[fft256_tw_slot(j << (8 - st))]);
     };
-    auto padded = [](int p) { return p + (p >> 4); };
+    auto padded = [](int p) {       // the entry of position p (see the header of this file)
+        const int h = p >> 4;
+        return (p & ~15) | ((p & 15) ^ ((h & 1 ? 4 : 0) ^ (h & 2 ? 1 : 0) ^ (h & 4 ? 14 : 0)));
+    };
     // stages 1, 2: positions lane + 64k; their twiddle indices are wave-uniform (0, 0, 0 and 64)
-    const c2 w0 = tw[0], w64 = tw[64];
+    const c2 w0 = tw[0], w64 = tw[fft256_tw_slot(64)];
     bfly_w(r0, r2, w0); bfly_w(r1, r3, w0);
     bfly_w(r0, r1, w0); bfly_w(r2, r3, w64);
     v[padded(lane)] = r0; v[padded(lane + 64)] = r1; v[padded(lane + 128)] = r2; v[padded(lane + 192)] = r3;

@@ -112,7 +112,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel
 #define FE_STAMP() do { if (taps.cycles && f == 0 && tid == 0) taps.cycles[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
     FE_STAMP();
 
-    for (int i = tid; i < 128; i += FE_THREADS) tw[i] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
+    for (int i = tid; i < 128; i += FE_THREADS) tw[fft256_tw_slot(i)] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
     for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i] ? (T.pilot_val[i] < 0 ? int8_t(-1) : int8_t(1)) : int8_t(0);
     __syncthreads();
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
     const c2* bb = reinterpret_cast<const c2*>(baseband) + size_t(f) * T.frame_samples;
     float* out = llr_out + size_t(f) * T.N;
 
-    for (int i = tid; i < 128; i += MF_THREADS) tw[i] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
+    for (int i = tid; i < 128; i += MF_THREADS) tw[fft256_tw_slot(i)] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
     if (chunk == 0) {
         // short control frame: the LLRs of the bits that were not sent are 0 (telecom_system.cc:1183-1191)
         for (int i = T.active_nbits + tid; i < T.nBits; i += MF_THREADS) {
@@ -195,7 +195,7 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_slot_energy_kernel
     __shared__ c2 fftb[MF_WAVES * FFT256_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w = blockIdx.y, s = blockIdx.x * MF_WAVES + wave;
-    for (int i = tid; i < 128; i += MF_THREADS) tw[i] = {twiddle[2 * i], twiddle[2 * i + 1]};
+    for (int i = tid; i < 128; i += MF_THREADS) tw[fft256_tw_slot(i)] = {twiddle[2 * i], twiddle[2 * i + 1]};
     __syncthreads();
     if (s >= nslots) return;
     const int offset = s * 272 * interp + 16 * interp;

@@ -25,7 +25,7 @@ extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_symbol_demod
     __shared__ c2 tw[128];
     __shared__ c2 fftb[(ST_THREADS / 64) * FFT256_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 128; i += ST_THREADS) tw[i] = {twiddle[2 * i], twiddle[2 * i + 1]};
+    for (int i = tid; i < 128; i += ST_THREADS) tw[fft256_tw_slot(i)] = {twiddle[2 * i], twiddle[2 * i + 1]};
     __syncthreads();
     const int s = blockIdx.x * (ST_THREADS / 64) + wave;
     if (s >= n) return;

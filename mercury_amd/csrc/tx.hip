@@ -21,7 +21,7 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_symbol_mod_kernel(const d
     __shared__ c2 fftb[4 * FFT256_STRIDE];
     __shared__ c2 tw[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 128; i += 256) tw[i] = {twiddle[2 * i], -twiddle[2 * i + 1]};       // conjugated: IFFT (ofdm.cc:365)
+    for (int i = tid; i < 128; i += 256) tw[fft256_tw_slot(i)] = {twiddle[2 * i], -twiddle[2 * i + 1]};       // conjugated: IFFT (ofdm.cc:365)
     __syncthreads();
     const int s = blockIdx.x * 4 + wave;
     if (s >= n) return;

@@ -67,7 +67,7 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
     // out_stride / out_offset (complex samples): where frame f starts; the transmit path leaves room for the preamble
     c2* out = reinterpret_cast<c2*>(baseband) + size_t(blockIdx.x) * (out_stride ? out_stride : T.frame_samples) + out_offset;
 
-    for (int i = tid; i < 128; i += TX_THREADS) tw[i] = {T.twiddle[2 * i], -T.twiddle[2 * i + 1]};  // conj (ofdm.cc:365)
+    for (int i = tid; i < 128; i += TX_THREADS) tw[fft256_tw_slot(i)] = {T.twiddle[2 * i], -T.twiddle[2 * i + 1]};  // conj (ofdm.cc:365)
     if (payload_in) {                   // transmit_byte: the caller's message, zero-padded to the frame (telecom_system.cc:354-366)
         const int nb = nbytes_in ? nbytes_in[blockIdx.x] : fs;
         for (int j = tid; j < fs; j += TX_THREADS) pay[j] = j < nb ? payload_in[size_t(blockIdx.x) * payload_in_stride + j] : uint8_t(0);
