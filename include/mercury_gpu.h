@@ -228,6 +228,10 @@ int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
  * can compare them bit for bit with the libm the reference calls (ldpc_decoder_SPA.cc:145,156).
  * atanh_out[i] is 0 where |in[i]| >= 1. */
 int mgpu_debug_spa_math(mgpu_ctx* ctx, const double* in, int n, double* tanh_out, double* atanh_out);
+/* Test / tuning hook: workgroups of the front-end kernel (which = 0) that fit one compute unit with this context's LDS carve, as the
+ * runtime's occupancy calculator reports it; -1 on error. */
+int mgpu_debug_occupancy(mgpu_ctx* ctx, int which);
+
 /* Test hook: the Schmidl-Cox metric of every candidate (time_sync_preamble_with_metric, ofdm.cc:1893-1941, before the peak selection) for W
  * windows of `size` interpolated baseband samples; vals: [W][ceil((size - preamble_nSymb*Nofdm*4) / step)]. variant: -1 = the library's choice,
  * 0 = the staged kernel, 1 = the streaming kernel (falls back to the staged one when the geometry does not fit it). */

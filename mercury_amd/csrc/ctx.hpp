@@ -17,7 +17,7 @@
 extern "C" const unsigned char mgpu_ldpc_blob[];
 extern "C" const unsigned long mgpu_ldpc_blob_size;
 
-extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits);
+extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits, int threads);
 extern "C" size_t mgpu_spa_lds_bytes(int E, int N);
 extern "C" size_t mgpu_gbf_lds_bytes(int N);
 extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
@@ -25,6 +25,7 @@ extern "C" size_t mgpu_spa_fast_lds_bytes(int S, int N);
 extern "C" size_t mgpu_txgen_lds_bytes(int G);
 
 extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
+extern "C" __global__ void mgpu_frontend_kernel_t1024(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
 extern "C" __global__ void mgpu_mfsk_frontend_kernel_m32(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
 extern "C" __global__ void mgpu_mfsk_frontend_kernel_m16x2(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
 extern "C" int mgpu_mfsk_syms_per_block();
@@ -127,6 +128,7 @@ struct mgpu_ctx {
     int ev_count = 0;               // launches recorded since timing was enabled (ring of kEvRing)
     bool ev_fe[kEvRing]{};          // whether the front-end ran in that slot
     size_t lds_fe = 0, lds_dec = 0, lds_tx = 0;
+    int fe_threads = 512;           // front-end workgroup size: 1024 when only one workgroup fits a compute unit's LDS anyway (long BPSK frames)
     DecoderKernel spa_kernel = nullptr;
     int dec_threads = 1024;         // workgroup size of the decoder kernel
 

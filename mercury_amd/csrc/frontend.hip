@@ -67,14 +67,15 @@ __device__ __forceinline__ double serial_sum(const double* red, int n) {
     return acc;
 }
 
-#define FE_THREADS 512
-#define FE_WAVES (FE_THREADS / 64)
+// Workgroup size: 512 threads where three (or two) workgroups fit a compute unit's LDS; 1024 for the long BPSK frames (G = 2400 cells,
+// 92 KB of LDS: one workgroup per compute unit either way, so the larger one doubles the wavefronts in flight).
 
 // LDS carve (bytes): grid 16G | work = H 16G + red/yp/llr rsz (the two together are the FFT work area first, later the
-//                    channel / equalised grid and the reduction terms, signed pilots, demapper LLRs) | tw 2048 | type G | scal 64
+//                    channel / equalised grid and the reduction terms, signed pilots, demapper LLRs) | aux = tw 2048 during the FFTs,
+//                    then type G + scal 64 (the cell types are first needed by the estimator)
 // rsz = max(16 nPilots, 4 nBits); the FFT runs on as many waves as work areas fit (4..8). Mode 8: 48 KB -> 3 workgroups/CU.
 struct FeCarve { int fft_waves; size_t rsz, work, total; };
-__host__ __device__ inline FeCarve fe_carve(int G, int nPilots, int nBits) {
+__host__ __device__ inline FeCarve fe_carve(int G, int nPilots, int nBits, int FE_WAVES) {
     FeCarve c;
     c.rsz = size_t(16) * (nPilots + 8) > size_t(4) * nBits ? size_t(16) * (nPilots + 8) : size_t(4) * nBits;   // + 8: zero pad behind the signed pilots (LS row reads)
     c.rsz = (c.rsz + 15) & ~size_t(15);
@@ -82,17 +83,20 @@ __host__ __device__ inline FeCarve fe_carve(int G, int nPilots, int nBits) {
     size_t w = (size_t(16) * G + c.rsz) / per_wave;
     c.fft_waves = int(w < 4 ? 4 : (w > FE_WAVES ? FE_WAVES : w));
     c.work = size_t(16) * G + c.rsz > c.fft_waves * per_wave ? size_t(16) * G + c.rsz : c.fft_waves * per_wave;
-    c.total = size_t(16) * G + c.work + 2048 + ((G + 15) & ~15) + 64;
+    const size_t aux = size_t((G + 15) & ~15) + 64;
+    c.total = size_t(16) * G + c.work + (aux > 2048 ? aux : 2048);
     return c;
 }
-extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits) { return fe_carve(G, nPilots, nBits).total; }
+extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits, int threads) { return fe_carve(G, nPilots, nBits, threads / 64).total; }
 
-extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel(
-    MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
-    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
+template <int FE_THREADS>
+__device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
+                                         float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out,
+                                         const MgpuTapsDev& taps) {
+    constexpr int FE_WAVES = FE_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int G = T.G, Nc = 50, Ns = T.Nsymb;
-    const FeCarve carve = fe_carve(G, T.nPilots, T.nBits);
+    const FeCarve carve = fe_carve(G, T.nPilots, T.nBits, FE_WAVES);
     c2* grid = reinterpret_cast<c2*>(smem);
     c2* H = grid + G;                                               // H and red together are the FFT work area first
     c2* fftb = H;
@@ -100,7 +104,7 @@ extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel
     float* llr = reinterpret_cast<float*>(red);                     // demapper output reuses the reduction area
     c2* yp = reinterpret_cast<c2*>(red);                            // pilots in row-major pilot order, multiplied by their sign
     c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(H) + carve.work);
-    int8_t* type = reinterpret_cast<int8_t*>(tw + 128);             // 0 data, +1 / -1 pilot with that sign
+    int8_t* type = reinterpret_cast<int8_t*>(tw);                   // 0 data, +1 / -1 pilot with that sign; takes the twiddles' place after the FFTs
     double* scal = reinterpret_cast<double*>(type + ((G + 15) & ~15));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +117,6 @@ extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel
     FE_STAMP();
 
     for (int i = tid; i < 128; i += FE_THREADS) tw[fft256_tw_slot(i)] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
-    for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i] ? (T.pilot_val[i] < 0 ? int8_t(-1) : int8_t(1)) : int8_t(0);
     __syncthreads();
 
     // ---- symbol_demod: one wave per symbol (fft256.h), next symbol's samples requested before the butterflies ----
@@ -137,6 +140,8 @@ extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel
         };
         emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
     }
+    __syncthreads();
+    for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i] ? (T.pilot_val[i] < 0 ? int8_t(-1) : int8_t(1)) : int8_t(0);
     __syncthreads();
 
     FE_STAMP();   // 1: FFT done
@@ -389,4 +394,16 @@ extern "C" __global__ __launch_bounds__(FE_THREADS, 6) void mgpu_frontend_kernel
     for (int p = tid; p < T.N; p += FE_THREADS) llr_out[size_t(f) * T.N + p] = llr[T.llr_src[p]];
     FE_STAMP();   // 8: end
 #undef FE_STAMP
+}
+
+extern "C" __global__ __launch_bounds__(512, 6) void mgpu_frontend_kernel(
+    MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
+    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
+    fe_frame<512>(T, baseband, F, llr_out, variance_out, snr_variance_out, eqdata_out, taps);
+}
+
+extern "C" __global__ __launch_bounds__(1024, 4) void mgpu_frontend_kernel_t1024(
+    MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
+    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
+    fe_frame<1024>(T, baseband, F, llr_out, variance_out, snr_variance_out, eqdata_out, taps);
 }
