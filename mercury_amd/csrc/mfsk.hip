@@ -48,7 +48,7 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
     static_assert(M * NS == kBandEnd - kBandStart, "tone band");
     __shared__ c2 tw[128];
     __shared__ c2 fftb[MF_WAVES * FFT256_STRIDE];
-    __shared__ double en[MF_WAVES][64];          // |carrier|^2 of the wave's current symbol, carrier order
+    __shared__ double en[MF_WAVES][128];         // |carrier|^2 of the wave's current pair of symbols, carrier order, 64 per symbol
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f = blockIdx.x / chunks, chunk = blockIdx.x - f * chunks;
@@ -75,52 +75,66 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
     }
     __syncthreads();
 
-    // lane roles in the demapper: lane (st, m) = data tone m of stream st; lanes 0..17 also fetch the out-of-band carriers
-    const int st = lane >= M ? 1 : 0, m = lane & (M - 1);
-    const bool tone_lane = lane < M * NS;
+    // The demapper needs 32 lanes per symbol (M * NS tone lanes), so a wavefront transforms two symbols one after the other and
+    // demaps them side by side: lanes 0-31 the first, lanes 32-63 the second. Lane (st, m) of a half = data tone m of stream st.
+    const int half = lane >> 5, hl = lane & 31;
+    const int st = hl >= M ? 1 : 0, m = hl & (M - 1);
     const int gray_m = m ^ (m >> 1);
     const int tone_off = kBandStart + st * M;
-    const int noise_col = lane < kBandStart ? lane : lane + (kBandEnd - kBandStart);   // 0..8, 41..49 for lanes 0..17
+    double* E = en[wave] + half * 64;                            // |carrier|^2 of this half's symbol, carrier order
 
     c2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
     if (s0 + wave < s1) {
         const c2* in = bb + size_t(s0 + wave) * 272 + 16;            // gi_remover
         n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
     }
-    for (int s = s0 + wave; s < s1; s += MF_WAVES) {
-        c2 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-        if (s + MF_WAVES < s1) {
-            const c2* in = bb + size_t(s + MF_WAVES) * 272 + 16;
-            n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
-        }
-        wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
-        double* E = en[wave];
-        auto emit = [&](const c2& x, int p) {                        // 1/Nfft scale + zero_depadder + energy
-            const int col = carrier_of_bin(brev8(p));
-            if (col < 0) return;
-            const double re = x.re / 256.0, im = x.im / 256.0;
-            E[col] = re * re + im * im;
-            if (taps.grid) {
-                double* g = taps.grid + (size_t(f) * T.G + size_t(s) * Nc + col) * 2;
-                g[0] = re; g[1] = im;
+    for (int sa = s0 + wave; sa < s1; sa += 2 * MF_WAVES) {
+        const int sb = sa + MF_WAVES;                                // the pair's second symbol (may lie past the run's end)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = h ? sb : sa;
+            double* Eo = en[wave] + h * 64;
+            if (s >= s1) {                                           // no second symbol: its half demaps zeros and writes nothing
+                Eo[lane] = 0.0;
+                continue;
             }
-        };
-        emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
+            c2 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+            if (s + MF_WAVES < s1) {
+                const c2* in = bb + size_t(s + MF_WAVES) * 272 + 16;
+                n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
+            }
+            wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
+            auto emit = [&](const c2& x, int p) {                    // 1/Nfft scale + zero_depadder + energy
+                const int col = carrier_of_bin(brev8(p));
+                if (col < 0) return;
+                const double re = x.re / 256.0, im = x.im / 256.0;
+                Eo[col] = re * re + im * im;
+                if (taps.grid) {
+                    double* g = taps.grid + (size_t(f) * T.G + size_t(s) * Nc + col) * 2;
+                    g[0] = re; g[1] = im;
+                }
+            };
+            emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
+        }
         __builtin_amdgcn_wave_barrier();
+        const int s = half ? sb : sa;
 
-        // ---- noise variance: the out-of-band energies added in carrier order (mfsk.cc:303-318) ----
-        const double ev = lane < kNoiseBins ? E[noise_col] : 0.0;
+        // ---- noise variance: the out-of-band energies added in carrier order (mfsk.cc:303-318); every lane adds its half's 18
+        // terms itself (the same address across a half: broadcast reads), so both halves have their sum without an exchange ----
         double noise_sum = 0.0;
         int noise_bins = 0;
-        if (__builtin_amdgcn_ballot_w64(!isfinite(ev)) == 0) {       // the usual case: every term counts
+        {
+            const double ev = hl < kNoiseBins ? E[hl < kBandStart ? hl : hl + (kBandEnd - kBandStart)] : 0.0;
+            if (__builtin_amdgcn_ballot_w64(!isfinite(ev)) == 0) {   // the usual case: every term counts
 #pragma unroll
-            for (int k = 0; k < kNoiseBins; ++k) noise_sum += readlane_f64(ev, k);
-            noise_bins = kNoiseBins;
-        } else {                                                     // NaN / Inf samples: skip those terms
-            for (int k = 0; k < Nc; ++k) {
-                if (k >= kBandStart && k < kBandEnd) continue;
-                const double e = E[k];
-                if (isfinite(e)) { noise_sum += e; ++noise_bins; }
+                for (int k = 0; k < kNoiseBins; ++k) noise_sum += E[k < kBandStart ? k : k + (kBandEnd - kBandStart)];
+                noise_bins = kNoiseBins;
+            } else {                                                 // NaN / Inf samples: skip those terms
+                for (int k = 0; k < Nc; ++k) {
+                    if (k >= kBandStart && k < kBandEnd) continue;
+                    const double e = E[k];
+                    if (isfinite(e)) { noise_sum += e; ++noise_bins; }
+                }
             }
         }
         double noise_var = noise_bins > 0 ? noise_sum / noise_bins : 1e-30;
@@ -132,9 +146,10 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
         // g_j = m_j ^ m_(j+1): the two sets are unions of aligned 2^j-blocks in the pattern 0 1 1 0 | 0 1 1 0 ...
         // Maxima are order-independent, so a butterfly gives the reference's sequential result exactly:
         // blk = max over the lane's aligned 2^j-block (shared tree), then xor 3*2^j and xor 4*2^j, 8*2^j, ... stay
-        // inside the lane's own set, and one exchange at xor 2^j fetches the other set's maximum.
-        double e = -1e30;
-        if (tone_lane) {
+        // inside the lane's own set, and one exchange at xor 2^j fetches the other set's maximum. All exchanges are
+        // at distances below 32, i.e. inside a half.
+        double e;
+        {
             const int hop = (s * HOP) & (M - 1);
             e = E[tone_off + ((m + hop) & (M - 1))];
             if (!isfinite(e)) e = 0.0;
@@ -155,7 +170,7 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
             if (m == NB - 1 - j) diff = max_E0 - max_E1;             // lane m writes bit k = m of its stream
             if (j + 1 < NB) blk = shfl_xor_max(blk, 1 << j);         // next level of the shared tree
         }
-        if (tone_lane && m < NB) {
+        if (s < s1 && m < NB) {
             double llr = diff * llr_scale;
             if (!isfinite(llr)) llr = 0.0;
             else if (llr > 5.0) llr = 5.0;
