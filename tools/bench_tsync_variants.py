@@ -8,7 +8,7 @@ from mercury_amd import RxPhy
 rx = RxPhy(8, max_batch=1)
 n = rx.Nofdm*85*4
 rng = np.random.default_rng(0)
-for W in (16, 64, 256, 1024):
+for W in ([int(sys.argv[1])] if len(sys.argv) > 1 else (16, 64, 256, 1024)):
     z = rng.standard_normal((W, n)) + 1j*rng.standard_normal((W, n))
     out = {}
     for v in (0, 1):
