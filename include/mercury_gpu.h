@@ -228,6 +228,12 @@ int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
  * can compare them bit for bit with the libm the reference calls (ldpc_decoder_SPA.cc:145,156).
  * atanh_out[i] is 0 where |in[i]| >= 1. */
 int mgpu_debug_spa_math(mgpu_ctx* ctx, const double* in, int n, double* tanh_out, double* atanh_out);
+/* Test hook: the device's peak selection (ofdm.cc:1943-1964, the kernel receive_byte uses from 32 windows up) on n rows of candidate metrics
+ * [n][ncand_max] (row w: ncand[w] candidates `step` samples apart in a buffer of size[w] samples, pass loc[w] of nTrials_max), for
+ * comparison with mgpu_host_select_peak. */
+int mgpu_debug_select_peak(mgpu_ctx* ctx, const double* cand_vals, int n, int ncand_max, const int* ncand, const int* size, const int* loc, int step,
+                           int nTrials_max, int* delay, double* corr);
+
 /* Test / tuning hook: workgroups of the front-end kernel (which = 0) that fit one compute unit with this context's LDS carve, as the
  * runtime's occupancy calculator reports it; -1 on error. */
 int mgpu_debug_occupancy(mgpu_ctx* ctx, int which);

@@ -615,6 +615,26 @@ int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int 
     });
 }
 
+int mgpu_debug_select_peak(mgpu_ctx* c, const double* cand_vals, int n, int ncand_max, const int* ncand, const int* size, const int* loc, int step,
+                           int nTrials_max, int* delay, double* corr) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(cand_vals && ncand && size && loc && delay && corr && n > 0 && ncand_max > 0 && step >= 1 && nTrials_max >= 1, "bad argument");
+        DevBuf d_v(size_t(n) * ncand_max * 8), d_nc(size_t(n) * 4), d_sz(size_t(n) * 4), d_lc(size_t(n) * 4), d_d(size_t(n) * 4), d_c(size_t(n) * 8);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_v.p, cand_vals, size_t(n) * ncand_max * 8, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_nc.p, ncand, size_t(n) * 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_sz.p, size, size_t(n) * 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_lc.p, loc, size_t(n) * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(mgpu_select_peak_kernel, dim3(n), dim3(64), 0, s, d_v.as<double>(), d_nc.as<int>(), ncand_max, step, d_sz.as<int>(), d_lc.as<int>(),
+                           nTrials_max, n, d_d.as<int>(), d_c.as<double>());
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(delay, d_d.p, size_t(n) * 4, hipMemcpyDeviceToHost, s));
+        HIPCK(hipMemcpyAsync(corr, d_c.p, size_t(n) * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
 int mgpu_debug_occupancy(mgpu_ctx* c, int which) {
     if (!c) return -1;
     int n = -1;

@@ -163,7 +163,7 @@ struct Loop {
             up(d_ic, nc.data(), size_t(n) * 4);
             up(d_ia, size.data(), size_t(n) * 4);                    // wins / start are consumed: reuse their index buffers
             up(d_ib, loc.data(), size_t(n) * 4);
-            hipLaunchKernelGGL(mgpu_select_peak_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_vals.as<double>(), d_ic.as<int>(), ncmax, step,
+            hipLaunchKernelGGL(mgpu_select_peak_kernel, dim3(n), dim3(64), 0, s, d_vals.as<double>(), d_ic.as<int>(), ncmax, step,
                                d_ia.as<int>(), d_ib.as<int>(), ntrials, n, d_cnt.as<int>(), d_sum.as<double>());
             HIPCK(hipGetLastError());
             HIPCK(hipMemcpyAsync(delay.data(), d_cnt.p, size_t(n) * 4, hipMemcpyDeviceToHost, s));

@@ -300,3 +300,43 @@ def test_gpu_streaming_coarse_metric_equals_staged_kernel_on_every_candidate(cfg
         assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (cfg, W, size)
         assert np.array_equal(rx.debug_tsync_metric(z, 100).view(np.uint64), a.view(np.uint64))
     rx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_peak_selection_kernel_matches_the_reference_selection():
+    """The wavefront-per-window peak selection (sync.hip) against a literal restatement of ofdm.cc:1943-1964 (overwrite, not swap) on rows
+    built to hit its corners: negative maxima (an implicit zero between / behind the candidates wins), exact zeros and ties (the first
+    occurrence wins), later passes, steps 1 / 4 / 100, buffers that end right behind the last candidate or well after it, NaN start entries."""
+    import ctypes as C
+    from mercury_amd import RxPhy
+    from test_host_logic import _reference_selection
+    rx = RxPhy(8, max_batch=1)
+    rng = np.random.default_rng(SEED)
+    pool = np.array([-1.0, -0.25, -0.25, 0.0, 0.0, 0.125, 0.5, 0.5, 0.75, 1.0])
+    for step, ncmax in ((1, 200), (4, 70), (100, 9), (1, 1), (100, 130)):
+        n = 96
+        ncand = rng.integers(1, ncmax + 1, n).astype(np.int32)
+        vals = np.zeros((n, ncmax))
+        size = np.zeros(n, np.int32)
+        loc = rng.integers(0, 4, n).astype(np.int32)
+        ntrials = 3
+        for w in range(n):
+            kind = w % 4
+            row = rng.choice(pool, ncand[w]) if kind < 2 else rng.standard_normal(ncand[w])
+            if kind == 1:
+                row = -np.abs(row) - (w % 3 == 0)                       # all non-positive
+            if kind == 3 and w % 8 == 3:
+                row[0] = np.nan
+            vals[w, : ncand[w]] = row
+            size[w] = (ncand[w] - 1) * step + 1 + (0 if w % 5 == 0 else int(rng.integers(0, 3 * step + 2)))
+        size = np.maximum(size, ntrials).astype(np.int32)
+        delay = np.zeros(n, np.int32)
+        corr = np.zeros(n, np.float64)
+        rc = rx.lib.mgpu_debug_select_peak(rx.h, vals.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(ncmax), ncand.ctypes.data_as(C.c_void_p),
+                                           size.ctypes.data_as(C.c_void_p), loc.ctypes.data_as(C.c_void_p), C.c_int(step), C.c_int(ntrials),
+                                           delay.ctypes.data_as(C.c_void_p), corr.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        for w in range(n):
+            d_ref, c_ref = _reference_selection(vals[w, : ncand[w]].copy(), step, int(size[w]), int(loc[w]), ntrials)
+            assert delay[w] == d_ref and (corr[w] == c_ref or (np.isnan(corr[w]) and np.isnan(c_ref))), (step, w, ncand[w], size[w], loc[w], delay[w], d_ref, corr[w], c_ref)
+    rx.close()
