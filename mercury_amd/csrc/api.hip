@@ -580,7 +580,7 @@ int mgpu_passband_to_baseband(mgpu_ctx* c, const double* passband, int W, int in
         HIPCK(hipEventRecord(c->sync_ev[0], s));
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((count + 255) / 256, W), dim3(256), lds, s, d_in.as<double>(), in_size, d_fc.as<double>(),
                            start ? d_start.as<int>() : nullptr, 0, count, decimation, c->d_fir[filter], ntaps, kSampleRate, kCarrierAmplitude,
-                           d_out.as<double>(), nullptr, cs);
+                           d_out.as<double>(), nullptr, cs, nullptr, 0);
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         HIPCK(hipMemcpyAsync(out_c128, d_out.p, size_t(W) * count * 16, hipMemcpyDeviceToHost, s));
@@ -708,7 +708,7 @@ std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size
         const int ntaps = int(t.fir_data.size());
         const double* cs = mixer_table(c, passband_carrier_hz, size_t(size), s);
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((size + 255) / 256, W), dim3(256), size_t(255 + ntaps) * 16, s, d_pass.as<double>(), size,
-                           d_fc.as<double>(), nullptr, 0, size, 1, c->d_fir[1], ntaps, kSampleRate, kCarrierAmplitude, d_in.as<double>(), nullptr, cs);
+                           d_fc.as<double>(), nullptr, 0, size, 1, c->d_fir[1], ntaps, kSampleRate, kCarrierAmplitude, d_in.as<double>(), nullptr, cs, nullptr, 0);
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(s));          // d_pass / d_fc go out of scope here
     } else {

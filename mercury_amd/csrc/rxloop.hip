@@ -130,7 +130,28 @@ struct Loop {
         const double* cs = shared ? mixer_table(c, carrier[wins[0]], size_t(buf), s) : nullptr;
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((buf + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 + ntaps) * 16, s,
                            d_pass.as<double>(), buf, d_carrier.as<double>(), nullptr, 0, buf, 1, c->d_fir[filter], ntaps, 48000.0,
-                           1.4142135623730951, d_bbi.as<double>(), d_ia.as<int>(), cs);
+                           1.4142135623730951, d_bbi.as<double>(), d_ia.as<int>(), cs, nullptr, 0);
+        HIPCK(hipGetLastError());
+    }
+
+    // FIR_rx_data baseband of the frame at `delay` only, decimated, straight into d_frames (row = slot[j] or j): passband_to_baseband
+    // (ofdm.cc:2316-2339) followed by rational_resampler(DECIMATION) at the delay (:2267-2278) keeps every kInterp-th sample of the
+    // (preamble + Nsymb) * Nofdm * kInterp the frame spans — a tenth of the capture window; each kept sample is the same 33-term sum.
+    void p2b_frames(const std::vector<int>& wins, const std::vector<int>& delay, const int* slot) {
+        if (wins.empty()) return;
+        std::vector<int> st(W, 0);
+        for (size_t j = 0; j < wins.size(); ++j) st[wins[j]] = delay[j];
+        up(d_ia, wins.data(), wins.size() * 4);
+        up(d_ib, st.data(), size_t(W) * 4);
+        if (slot) up(d_ic, slot, wins.size() * 4);
+        up(d_carrier, carrier.data(), size_t(W) * 8);
+        const int ntaps = int(t.fir_data.size());
+        bool shared = true;
+        for (int w : wins) shared = shared && carrier[w] == rc.carrier_hz;
+        const double* cs = shared ? mixer_table(c, carrier[wins[0]], size_t(buf), s) : nullptr;
+        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((frame_n + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 * kInterp + ntaps) * 16, s,
+                           d_pass.as<double>(), buf, d_carrier.as<double>(), d_ib.as<int>(), 0, frame_n, kInterp, c->d_fir[1], ntaps, 48000.0,
+                           1.4142135623730951, d_frames.as<double>(), d_ia.as<int>(), cs, slot ? d_ic.as<int>() : nullptr, 1);
         HIPCK(hipGetLastError());
     }
 
@@ -337,7 +358,7 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             HIPCK(hipStreamWaitEvent(s, lp.ws.slice_ev[k], 0));
             hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((lp.buf + 255) / 256, unsigned(n)), dim3(256), size_t(255 + ntaps_ts) * 16, s, lp.d_pass.as<double>(), lp.buf,
                                lp.d_carrier.as<double>(), nullptr, 0, lp.buf, 1, c->d_fir[0], ntaps_ts, 48000.0, 1.4142135623730951, lp.d_bbi.as<double>(),
-                               lp.d_ia.as<int>() + off, mix_cs);
+                               lp.d_ia.as<int>() + off, mix_cs, nullptr, 0);
             HIPCK(hipGetLastError());
             // The coarse search streams each window through LDS with one wavefront per SIMD (sync.hip) and is the more efficient the more
             // windows a launch has: from host memory it follows the upload in groups of kCoarseGroup slices (the group's search runs under
@@ -544,20 +565,12 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             pt.mark(s, "trial: energy fix");
             // -- :1083-1105 FIR_rx_data baseband at the (coarse-corrected) carrier, frame cut out at `delay`, decimated
             for (int w : act) lp.carrier[w] = rcp->carrier_hz + win[w].coarse_freq_offset;   // effective_carrier_freq, :1074
-            lp.p2b(act, 1);
-            auto extract = [&](const std::vector<int>& wins, const int* slot) {   // rational_resampler DECIMATION at `delay`
-                if (wins.empty()) return;
+            auto frames = [&](const std::vector<int>& wins, const int* slot) {     // data-filter baseband of the frame at `delay`, decimated
                 std::vector<int> dl(wins.size());
                 for (size_t j = 0; j < wins.size(); ++j) dl[j] = win[wins[j]].delay;
-                lp.up(lp.d_ia, wins.data(), wins.size() * 4);
-                lp.up(lp.d_ib, dl.data(), wins.size() * 4);
-                if (slot) lp.up(lp.d_ic, slot, wins.size() * 4);
-                hipLaunchKernelGGL(mgpu_decimate_kernel, dim3((lp.frame_n + 255) / 256, unsigned(wins.size())), dim3(256), 0, s, lp.d_bbi.as<double>(),
-                                   lp.buf, lp.d_ia.as<int>(), lp.d_ib.as<int>(), slot ? lp.d_ic.as<int>() : nullptr, kInterp, lp.frame_n,
-                                   lp.d_frames.as<double>());
-                HIPCK(hipGetLastError());
+                lp.p2b_frames(wins, dl, slot);
             };
-            extract(act, nullptr);
+            frames(act, nullptr);
             pt.mark(s, "trial: p2b data filter + cut");
             // -- :1108-1131 fine frequency offset (Moose) or the last good one on the final trial; re-mix if it matters
             std::vector<double> f(n, 0.0);
@@ -578,8 +591,7 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
                 x.freq = f[k];
                 if (!lp.mfsk && std::fabs(f[k]) > kFreqIgnore) { lp.carrier[act[k]] = rcp->carrier_hz + x.coarse_freq_offset + f[k]; rw.push_back(act[k]); rslot.push_back(k); }
             }
-            lp.p2b(rw, 1);
-            extract(rw, rslot.data());
+            frames(rw, rslot.data());
             pt.mark(s, "trial: Moose + re-mix");
             // -- :1132-1345 the hot path on the data symbols (they start `preamble` symbols into each extracted frame)
             MgpuTapsDev taps{};
@@ -614,6 +626,13 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
                     if (state) state[w].delay_of_last_decoded_message = x.delay;
                 }
                 r.sync_trials = x.sync_trials;
+            }
+            {   // Windows that go on to another trial: in the reference the baseband buffer now holds the FIR_rx_data output of the whole
+                // capture window (:1083-1105 wrote it) and a later trial may read it before refreshing it. p2b_frames computed only the
+                // samples the RX path reads, so the full buffer is produced here — for the windows that did not decode only.
+                std::vector<int> again;
+                for (int w : act) if (win[w].in_loop) again.push_back(w);
+                lp.p2b(again, 1);
             }
         }
         for (int w = 0; w < W; ++w) { stats[w].delay = win[w].delay; stats[w].coarse_metric = win[w].metric; stats[w].sync_trials = win[w].sync_trials; }

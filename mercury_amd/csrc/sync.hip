@@ -21,12 +21,13 @@ __device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.
 
 // One block = 256 consecutive outputs of one window. out[k] = sum_j l[n+h-j]*c[j], n = start + k*decim,
 // l[i] = in[i]*amp*(cos, sin)(2*pi*fc*i*Ts). The (255*decim + ntaps) mixed samples a block needs are formed once in LDS.
+// start_opt (optional) is indexed by the window, like carrier_hz.
 // cs (optional): cos / sin per sample index from the host, for launches whose windows all share one carrier — the reference's
 // own libm values, so the output is then bit-identical to the reference's, and the device evaluates no trigonometry.
 extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
     const double* __restrict__ passband, int in_size, const double* __restrict__ carrier_hz, const int* __restrict__ start_opt,
     int start_all, int count, int decim, const double* __restrict__ taps, int ntaps, double fs, double amplitude,
-    double* __restrict__ out, const int* __restrict__ widx, const double* __restrict__ cs) {
+    double* __restrict__ out, const int* __restrict__ widx, const double* __restrict__ cs, const int* __restrict__ out_row, int row_by_launch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c2* l = reinterpret_cast<c2*>(smem);
     __shared__ double c[P2B_MAXTAPS];
@@ -69,8 +70,10 @@ extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
             ai += v.im * c[j];
         }
     }
-    out[(size_t(w) * count + k) * 2] = ar;
-    out[(size_t(w) * count + k) * 2 + 1] = ai;
+    // output row: the window's own index, or (frames cut out for the RX path) the launch index / an explicit slot
+    const int row = out_row ? out_row[blockIdx.y] : (row_by_launch ? int(blockIdx.y) : w);
+    out[(size_t(row) * count + k) * 2] = ar;
+    out[(size_t(row) * count + k) * 2 + 1] = ai;
 }
 
 // Schmidl-Cox metric (ofdm.cc:1893-1941). One lane per candidate offset i = cand*step; the three accumulators run
