@@ -274,7 +274,7 @@ static bool tsync_stream_launch(const double* d_bb, int stride, const int* d_sta
         }
     if (hi - lo + 128 > ring) return false;
     // pieces of the candidate range per window: about one wavefront per SIMD (4 rings of 35 KB fit a CU's LDS), at least J candidates each
-    int pieces = std::max(1, 1024 / n);
+    int pieces = std::max(1, (1024 + n - 1) / n);               // ceil: 618 windows in two pieces each measured faster than one wavefront per window
     pieces = std::min(pieces, std::max(1, ncand_max / J));
     const int cpp = (ncand_max + pieces - 1) / pieces;
     pieces = (ncand_max + cpp - 1) / cpp;

@@ -54,12 +54,18 @@ struct Workspace {
     double* h_vals = nullptr;        // page-locked landing area for the synchroniser metrics (tens of MB per call)
     hipStream_t side = nullptr;      // the signal-strength sum (a 92 k-term dependent chain per window) runs beside the synchroniser
     hipStream_t copy = nullptr;      // brings the capture windows in, slice by slice, under the first kernels
+    hipStream_t search = nullptr;    // the coarse search of a group of slices, beside the mixer / filter of the next ones
+    std::vector<hipEvent_t> group_ev;
+    hipEvent_t ev_search = nullptr;
     std::vector<hipEvent_t> slice_ev;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     ~Workspace() {
         if (h_vals) (void)hipHostFree(h_vals);
         if (side) (void)hipStreamDestroy(side);
         if (copy) (void)hipStreamDestroy(copy);
+        if (search) (void)hipStreamDestroy(search);
+        for (hipEvent_t e : group_ev) (void)hipEventDestroy(e);
+        if (ev_search) (void)hipEventDestroy(ev_search);
         for (hipEvent_t e : slice_ev) (void)hipEventDestroy(e);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_done) (void)hipEventDestroy(ev_done);
@@ -73,6 +79,7 @@ struct Workspace {
         HIPCK(hipStreamCreate(&side));
         HIPCK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&ev_search, hipEventDisableTiming));
     }
 };
 void free_workspace(void* p) { delete static_cast<Workspace*>(p); }
@@ -87,6 +94,7 @@ struct Loop {
     Workspace& ws;
     DevBuf &d_pass, &d_bbi, &d_frames, &d_carrier, &d_ia, &d_ib, &d_ic, &d_vals, &d_sum, &d_cnt, &d_freq, &d_meanh;
     std::vector<double> carrier;   // per window, as currently applied (carrier + fine offset of the running trial)
+    const double* pass = nullptr;  // the capture windows on the device: the workspace copy, or the caller's buffer when it already lies in HBM
 
     static Workspace& workspace(mgpu_ctx* ctx, int W, int buffer_nsymb) {
         const auto& t = ctx->tab;
@@ -129,7 +137,7 @@ struct Loop {
         for (int w : wins) shared = shared && carrier[w] == rc.carrier_hz;
         const double* cs = shared ? mixer_table(c, carrier[wins[0]], size_t(buf), s) : nullptr;
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((buf + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 + ntaps) * 16, s,
-                           d_pass.as<double>(), buf, d_carrier.as<double>(), nullptr, 0, buf, 1, c->d_fir[filter], ntaps, 48000.0,
+                           pass, buf, d_carrier.as<double>(), nullptr, 0, buf, 1, c->d_fir[filter], ntaps, 48000.0,
                            1.4142135623730951, d_bbi.as<double>(), d_ia.as<int>(), cs, nullptr, 0);
         HIPCK(hipGetLastError());
     }
@@ -150,7 +158,7 @@ struct Loop {
         for (int w : wins) shared = shared && carrier[w] == rc.carrier_hz;
         const double* cs = shared ? mixer_table(c, carrier[wins[0]], size_t(buf), s) : nullptr;
         hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((frame_n + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 * kInterp + ntaps) * 16, s,
-                           d_pass.as<double>(), buf, d_carrier.as<double>(), d_ib.as<int>(), 0, frame_n, kInterp, c->d_fir[1], ntaps, 48000.0,
+                           pass, buf, d_carrier.as<double>(), d_ib.as<int>(), 0, frame_n, kInterp, c->d_fir[1], ntaps, 48000.0,
                            1.4142135623730951, d_frames.as<double>(), d_ia.as<int>(), cs, slot ? d_ic.as<int>() : nullptr, 1);
         HIPCK(hipGetLastError());
     }
@@ -293,6 +301,7 @@ int mgpu_measure_signal_only(mgpu_ctx* c, const double* passband, int W, double 
         std::vector<int> all(W);
         for (int w = 0; w < W; ++w) all[w] = w;
         HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyDefault, s));
+        lp.pass = lp.d_pass.as<double>();
         lp.p2b(all, 0);
         hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_freq.as<double>());
         HIPCK(hipGetLastError());
@@ -351,24 +360,40 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
         const int ntaps_ts = int(t.fir_time_sync.size());
         const int ncand0 = lp.buf > lp.L ? (lp.buf - lp.L + kCoarseStep - 1) / kCoarseStep : 0;
         need(size_t(std::max(ncand0, 1)) <= lp.ws.vals_per_window, "search window larger than the workspace");
+        // Windows that already lie in HBM are read where they are. The coarse search (one wavefront per SIMD, issue-limited: sync.hip)
+        // runs on a stream of its own, group by group, beside the mixer / filter launches of the following slices; from host memory a
+        // group is kCoarseGroup slices (its search runs under the next group's copies), from HBM all of them.
+        lp.pass = on_device ? passband : lp.d_pass.as<double>();
+        if (!lp.ws.search) HIPCK(hipStreamCreateWithFlags(&lp.ws.search, hipStreamNonBlocking));
+        const int group = on_device ? nsl : kCoarseGroup;           // from HBM: one launch (groups of 4 slices beside the filter launches measured 5 % slower)
+        while (int(lp.ws.group_ev.size()) < nsl) {
+            hipEvent_t e = nullptr;
+            HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            lp.ws.group_ev.push_back(e);
+        }
         for (int k = 0; k < nsl; ++k) {
             const int off = k * kSlice, n = std::min(kSlice, W - off);
-            HIPCK(hipMemcpyAsync(lp.d_pass.as<double>() + size_t(off) * lp.buf, passband + size_t(off) * lp.buf, size_t(n) * lp.buf * 8, hipMemcpyDefault, lp.ws.copy));
-            HIPCK(hipEventRecord(lp.ws.slice_ev[k], lp.ws.copy));
-            HIPCK(hipStreamWaitEvent(s, lp.ws.slice_ev[k], 0));
-            hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((lp.buf + 255) / 256, unsigned(n)), dim3(256), size_t(255 + ntaps_ts) * 16, s, lp.d_pass.as<double>(), lp.buf,
+            if (!on_device) {
+                HIPCK(hipMemcpyAsync(lp.d_pass.as<double>() + size_t(off) * lp.buf, passband + size_t(off) * lp.buf, size_t(n) * lp.buf * 8, hipMemcpyDefault, lp.ws.copy));
+                HIPCK(hipEventRecord(lp.ws.slice_ev[k], lp.ws.copy));
+                HIPCK(hipStreamWaitEvent(s, lp.ws.slice_ev[k], 0));
+            }
+            hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((lp.buf + 255) / 256, unsigned(n)), dim3(256), size_t(255 + ntaps_ts) * 16, s, lp.pass, lp.buf,
                                lp.d_carrier.as<double>(), nullptr, 0, lp.buf, 1, c->d_fir[0], ntaps_ts, 48000.0, 1.4142135623730951, lp.d_bbi.as<double>(),
                                lp.d_ia.as<int>() + off, mix_cs, nullptr, 0);
             HIPCK(hipGetLastError());
-            // The coarse search streams each window through LDS with one wavefront per SIMD (sync.hip) and is the more efficient the more
-            // windows a launch has: from host memory it follows the upload in groups of kCoarseGroup slices (the group's search runs under
-            // the next group's copies), windows that already lie in HBM are searched in one launch.
-            const bool group_end = on_device ? k == nsl - 1 : ((k + 1) % kCoarseGroup == 0 || k == nsl - 1);
+            const bool group_end = (k + 1) % group == 0 || k == nsl - 1;
             if (!lp.mfsk && ncand0 > 0 && group_end) {
-                const int g0 = on_device ? 0 : (k / kCoarseGroup) * kCoarseGroup * kSlice, gn = off + n - g0;
+                const int g0 = (k / group) * group * kSlice, gn = off + n - g0;
+                HIPCK(hipEventRecord(lp.ws.group_ev[k], s));
+                HIPCK(hipStreamWaitEvent(lp.ws.search, lp.ws.group_ev[k], 0));
                 launch_tsync_metric(lp.d_bbi.as<double>() + size_t(g0) * lp.buf * 2, lp.buf, nullptr, nullptr, nullptr, ncand0, gn, kCoarseStep, lp.pre, lp.ngi_i,
-                                    lp.nfft_i, lp.d_vals.as<double>() + size_t(g0) * ncand0, s);
+                                    lp.nfft_i, lp.d_vals.as<double>() + size_t(g0) * ncand0, lp.ws.search);
             }
+        }
+        if (!lp.mfsk && ncand0 > 0) {                                // the main stream continues when the last group's search is done
+            HIPCK(hipEventRecord(lp.ws.ev_search, lp.ws.search));
+            HIPCK(hipStreamWaitEvent(s, lp.ws.ev_search, 0));
         }
         pt.mark(s, "upload + p2b + coarse metric");
         {   // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order. The sum is a long
