@@ -240,8 +240,11 @@ int mgpu_debug_occupancy(mgpu_ctx* ctx, int which);
 
 /* Test hook: the Schmidl-Cox metric of every candidate (time_sync_preamble_with_metric, ofdm.cc:1893-1941, before the peak selection) for W
  * windows of `size` interpolated baseband samples; vals: [W][ceil((size - preamble_nSymb*Nofdm*4) / step)]. variant: -1 = the library's choice,
- * 0 = the staged kernel, 1 = the streaming kernel (falls back to the staged one when the geometry does not fit it). */
-int mgpu_debug_tsync_metric(mgpu_ctx* ctx, const double* baseband_interp, int W, int size, int step, int variant, double* vals);
+ * 0 = the staged kernel, 1 = the streaming kernel (falls back to the staged one when the geometry does not fit it). start / sub_size (both or
+ * neither): search only [start[w], start[w] + sub_size[w]) of window w, as receive_byte's recoveries do; entries behind a window's last candidate
+ * keep the fill pattern 0xff. */
+int mgpu_debug_tsync_metric(mgpu_ctx* ctx, const double* baseband_interp, int W, int size, int step, int variant, const int* start, const int* sub_size,
+                            double* vals);
 
 /* test hook: the device atan / sincos of csrc/glibc_trig.h (restore_channel_amplitude: misc.cc:34-71; receive mixer: ofdm.cc:2331-2332)
  * on n host doubles, for bit-for-bit comparison with the reference platform's libm. */

@@ -647,19 +647,32 @@ int mgpu_debug_occupancy(mgpu_ctx* c, int which) {
     return n;
 }
 
-int mgpu_debug_tsync_metric(mgpu_ctx* c, const double* bb, int W, int size, int step, int variant, double* vals) {
+int mgpu_debug_tsync_metric(mgpu_ctx* c, const double* bb, int W, int size, int step, int variant, const int* start, const int* sub_size, double* vals) {
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {
         const auto& t = c->tab;
         const int interp = 4, sym = t.Nofdm * interp, L = t.preamble * sym;
-        need(bb && vals && W > 0 && size > L && step >= 1 && variant >= -1 && variant <= 1, "bad argument");
+        need(bb && vals && W > 0 && size > L && step >= 1 && variant >= -1 && variant <= 1 && (!start == !sub_size), "bad argument");
         const int ncand = (size - L + step - 1) / step;
-        DevBuf d_in(size_t(W) * size * 16), d_vals(size_t(W) * ncand * 8);
+        std::vector<int> nc(W, ncand), st(W, 0), wi(W);
+        for (int w = 0; w < W; ++w) {
+            wi[w] = w;
+            if (start) {
+                need(start[w] >= 0 && sub_size[w] >= 0 && start[w] + sub_size[w] <= size, "sub-window outside the window");
+                st[w] = start[w];
+                nc[w] = sub_size[w] > L ? (sub_size[w] - L + step - 1) / step : 0;
+            }
+        }
+        DevBuf d_in(size_t(W) * size * 16), d_vals(size_t(W) * ncand * 8), d_st(size_t(W) * 4), d_nc(size_t(W) * 4), d_wi(size_t(W) * 4);
         hipStream_t s = c->stream;
         HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_st.p, st.data(), size_t(W) * 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_nc.p, nc.data(), size_t(W) * 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_wi.p, wi.data(), size_t(W) * 4, hipMemcpyHostToDevice, s));
         HIPCK(hipMemsetAsync(d_vals.p, 0xff, size_t(W) * ncand * 8, s));
         HIPCK(hipEventRecord(c->sync_ev[0], s));
-        launch_tsync_metric(d_in.as<double>(), size, nullptr, nullptr, nullptr, ncand, W, step, t.preamble, t.Ngi * interp, t.Nfft * interp, d_vals.as<double>(), s, variant);
+        launch_tsync_metric(d_in.as<double>(), size, start ? d_st.as<int>() : nullptr, start ? d_wi.as<int>() : nullptr, start ? d_nc.as<int>() : nullptr, ncand, W, step,
+                            t.preamble, t.Ngi * interp, t.Nfft * interp, d_vals.as<double>(), s, variant);
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         HIPCK(hipMemcpyAsync(vals, d_vals.p, size_t(W) * ncand * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));

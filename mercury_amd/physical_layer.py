@@ -273,15 +273,19 @@ class RxPhy:
                                                   C.c_int(nTrials_max), _ptr(delay), _ptr(corr)))
         return delay, corr
 
-    def debug_tsync_metric(self, baseband_interp, step, variant=-1):
-        """Test hook: the Schmidl-Cox metric of every candidate, [W][ncand]; variant 0 = staged kernel, 1 = streaming kernel."""
+    def debug_tsync_metric(self, baseband_interp, step, variant=-1, start=None, sub_size=None):
+        """Test hook: the Schmidl-Cox metric of every candidate, [W][ncand]; variant 0 = staged kernel, 1 = streaming kernel;
+        start / sub_size: per-window sub-range to search."""
         z = np.ascontiguousarray(baseband_interp, np.complex128)
         z = z.reshape(1, -1) if z.ndim == 1 else z
         W, size = z.shape
         L = self.preamble_nsymb * self.Nofdm * 4
         ncand = (size - L + step - 1) // step
         vals = np.zeros((W, ncand), np.float64)
-        self._ck(self.lib.mgpu_debug_tsync_metric(self.h, _ptr(z), C.c_int(W), C.c_int(size), C.c_int(step), C.c_int(variant), _ptr(vals)))
+        st = None if start is None else np.ascontiguousarray(start, np.int32)
+        sz = None if sub_size is None else np.ascontiguousarray(sub_size, np.int32)
+        self._ck(self.lib.mgpu_debug_tsync_metric(self.h, _ptr(z), C.c_int(W), C.c_int(size), C.c_int(step), C.c_int(variant),
+                                                  _ptr(st) if st is not None else None, _ptr(sz) if sz is not None else None, _ptr(vals)))
         return vals
 
     def freq_sync(self, baseband):

@@ -299,6 +299,16 @@ def test_gpu_streaming_coarse_metric_equals_staged_kernel_on_every_candidate(cfg
         b = rx.debug_tsync_metric(z, 100, variant=1)
         assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (cfg, W, size)
         assert np.array_equal(rx.debug_tsync_metric(z, 100).view(np.uint64), a.view(np.uint64))
+    # sub-windows with their own start and length, as receive_byte's recoveries search them (some too short for a single candidate)
+    W, size = 70, full
+    z = rng.standard_normal((W, size)) + 1j * rng.standard_normal((W, size))
+    start = rng.integers(0, size // 2, W).astype(np.int32)
+    sub = np.array([int(rng.integers(0, size - start[w] + 1)) for w in range(W)], np.int32)
+    sub[::7] = L                                                    # no candidate at all
+    sub[1::7] = np.minimum(L + 1, size - start[1::7])               # exactly one
+    a = rx.debug_tsync_metric(z, 100, variant=0, start=start, sub_size=sub)
+    b = rx.debug_tsync_metric(z, 100, variant=1, start=start, sub_size=sub)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
     rx.close()
 
 
