@@ -366,6 +366,40 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
     // ---- deframe + time/freq de-interleave + max-log demap -------------------------------------
     const float inv_var = 1 / variance;
     const int M = T.M, bps = T.bps;
+    // cl_psk::demod (psk.cc:278-326): squared distance to every constellation point in double, narrowed to float; per bit the smallest
+    // distance among the points with that bit set / clear; LLR = (d1 - d0) / variance in float. Specialised per constellation size so that
+    // "which of the two minima does point j feed" is a compile-time fact (one v_min_f32 per point and bit) — with M at run time it is a
+    // bit test, two compares and two selects per point and bit, and the 32 points of mode 16 were half of that mode's front-end time.
+    // fminf keeps the running minimum when the new distance is NaN, like the reference's `if (D < d)`.
+    auto demap_all = [&](auto m_tag) {
+        constexpr int MM = decltype(m_tag)::value;
+        constexpr int BPS = MM == 2 ? 1 : MM == 4 ? 2 : MM == 8 ? 3 : MM == 16 ? 4 : 5;
+        for (int k = tid; k < T.nData; k += FE_THREADS) {
+            const c2 s = eq[T.sym_src[k]];
+            if (taps.syms) { taps.syms[(size_t(f) * T.nData + k) * 2] = s.re; taps.syms[(size_t(f) * T.nData + k) * 2 + 1] = s.im; }
+            float d0[BPS], d1[BPS];
+#pragma unroll
+            for (int b = 0; b < BPS; ++b) { d0[b] = __builtin_inff(); d1[b] = __builtin_inff(); }
+#pragma unroll
+            for (int j = 0; j < MM; ++j) {
+                const double dr = s.re - T.constellation[2 * j], di = s.im - T.constellation[2 * j + 1];
+                const float D = float(dr * dr + di * di);
+#pragma unroll
+                for (int b = 0; b < BPS; ++b) {
+                    if ((j >> b) & 1) d1[b] = __builtin_fminf(d1[b], D);
+                    else d0[b] = __builtin_fminf(d0[b], D);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < BPS; ++b) llr[k * BPS + (BPS - 1 - b)] = inv_var * (d1[b] - d0[b]);
+        }
+    };
+    if (M == 2 && bps == 1) demap_all(std::integral_constant<int, 2>());
+    else if (M == 4 && bps == 2) demap_all(std::integral_constant<int, 4>());
+    else if (M == 8 && bps == 3) demap_all(std::integral_constant<int, 8>());
+    else if (M == 16 && bps == 4) demap_all(std::integral_constant<int, 16>());
+    else if (M == 32 && bps == 5) demap_all(std::integral_constant<int, 32>());
+    else
     for (int k = tid; k < T.nData; k += FE_THREADS) {
         const c2 s = eq[T.sym_src[k]];
         if (taps.syms) { taps.syms[(size_t(f) * T.nData + k) * 2] = s.re; taps.syms[(size_t(f) * T.nData + k) * 2 + 1] = s.im; }
