@@ -4,19 +4,18 @@
 #include "fft256.h"   // c2
 #include "glibc_trig.h"   // atan / sincos as the reference platform's libm evaluates them, bit for bit
 
-// libgcc (GCC 11) __divdc3 main path
+// libgcc (GCC 11) __divdc3 main path. The two cases (|c| < |d| or not) are the same five operations on swapped operands, so the
+// operands are selected and the operations done once: lanes of a wavefront take either case at random, and as two branches every
+// wavefront paid for both (six divisions instead of three).
 __device__ __forceinline__ c2 cdiv(c2 n, c2 d) {
     const double a = n.re, b = n.im, c = d.re, dd = d.im;
-    double x, y;
-    if (fabs(c) < fabs(dd)) {
-        const double ratio = c / dd, denom = (c * ratio) + dd;
-        x = ((a * ratio) + b) / denom;
-        y = ((b * ratio) - a) / denom;
-    } else {
-        const double ratio = dd / c, denom = (dd * ratio) + c;
-        x = ((b * ratio) + a) / denom;
-        y = (b - (a * ratio)) / denom;
-    }
+    const bool sw = fabs(c) < fabs(dd);
+    const double p = sw ? c : dd, q = sw ? dd : c;
+    const double ratio = p / q, denom = (p * ratio) + q;        // c / d, (c * ratio) + d   or   d / c, (d * ratio) + c
+    const double u = sw ? a : b, v = sw ? b : a;
+    const double x = ((u * ratio) + v) / denom;                // ((a * ratio) + b) / denom   or   ((b * ratio) + a) / denom
+    const double t = v * ratio;
+    const double y = (sw ? t - a : b - t) / denom;             // ((b * ratio) - a) / denom   or   (b - (a * ratio)) / denom
     return {x, y};
 }
 

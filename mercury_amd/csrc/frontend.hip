@@ -283,17 +283,24 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
     for (int c = tid; c < G; c += FE_THREADS) {
         if (type[c]) continue;
         const int i = c / Nc, j = c - i * Nc;
-        int prev = -1, next = -1;
-        for (int r = i - 1; r >= 0; --r) if (type[r * Nc + j]) { prev = r; break; }
-        for (int r = i + 1; r < Ns; ++r) if (type[r * Nc + j]) { next = r; break; }
         int a, b;
-        if (prev >= 0 && next >= 0) { a = prev; b = next; }
-        else if (prev < 0) {               // above the first pilot: extrapolate from the first two
-            a = next; b = -1;
-            for (int r = next + 1; r < Ns; ++r) if (type[r * Nc + j]) { b = r; break; }
-        } else {                           // below the last pilot: extrapolate from the last two
-            b = prev; a = -1;
-            for (int r = prev - 1; r >= 0; --r) if (type[r * Nc + j]) { a = r; break; }
+        if (T.regular_lattice) {           // column j has its pilots in the rows == j (mod 3): the neighbours follow from (i - j) mod 3
+            const int m = (i - j + 3 * Nc) % 3;                      // 1 or 2 for a data cell
+            a = i - m; b = i + 3 - m;
+            if (a < 0) { a = b; b = a + 3; }                         // above the first pilot: extrapolate from the first two
+            else if (b >= Ns) { b = a; a = b - 3; }                  // below the last pilot: extrapolate from the last two
+        } else {
+            int prev = -1, next = -1;
+            for (int r = i - 1; r >= 0; --r) if (type[r * Nc + j]) { prev = r; break; }
+            for (int r = i + 1; r < Ns; ++r) if (type[r * Nc + j]) { next = r; break; }
+            if (prev >= 0 && next >= 0) { a = prev; b = next; }
+            else if (prev < 0) {               // above the first pilot: extrapolate from the first two
+                a = next; b = -1;
+                for (int r = next + 1; r < Ns; ++r) if (type[r * Nc + j]) { b = r; break; }
+            } else {                           // below the last pilot: extrapolate from the last two
+                b = prev; a = -1;
+                for (int r = prev - 1; r >= 0; --r) if (type[r * Nc + j]) { a = r; break; }
+            }
         }
         H[c] = lerp(H[a * Nc + j], double(a), H[b * Nc + j], double(b), double(i));
     }
