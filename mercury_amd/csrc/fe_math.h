@@ -28,12 +28,13 @@ __device__ __forceinline__ c2 lerp(c2 a, double ax, c2 b, double bx, double x) {
     return {a.re + t.re, a.im + t.im};
 }
 
+// get_angle (misc.cc:34-56): every branch that calls atan calls it on v.im / v.re, so it is evaluated once
 __device__ __forceinline__ double get_angle(c2 v) {
+    const double a = gl_atan(v.im / v.re);
     double theta = 0;
     if (v.re == 0) theta = M_PI / 2;
-    else if (v.re > 0) theta = gl_atan(v.im / v.re);
-    else if (v.re < 0 && v.im >= 0) theta = gl_atan(v.im / v.re) + M_PI;
-    else if (v.re < 0 && v.im < 0) theta = gl_atan(v.im / v.re) - M_PI;
+    else if (v.re > 0) theta = a;
+    else if (v.re < 0 && v.im >= 0) theta = a + M_PI;
+    else if (v.re < 0 && v.im < 0) theta = a - M_PI;
     return theta;
 }
-

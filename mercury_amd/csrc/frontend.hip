@@ -322,12 +322,18 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
             red[p] = dr * dr + di * di;
         }
         __syncthreads();
-        if (tid == 0) {
-            double var = serial_sum(red, T.nPilots);
-            var /= double(T.nPilots);
-            scal[2] = var;
+        // The sum is a chain of nPilots dependent additions for one lane; with three workgroups per compute unit the frame rate is
+        // workgroups in flight / time per frame, so the chain must not sit in front of anything: wavefront 0 adds, the others turn
+        // the channel estimates into unit phasors meanwhile.
+        if (wave == 0) {
+            if (tid == 0) {
+                double var = serial_sum(red, T.nPilots);
+                var /= double(T.nPilots);
+                scal[2] = var;
+            }
+        } else {
+            for (int c = tid - 64; c < G; c += FE_THREADS - 64) H[c] = unit_phasor(H[c]);
         }
-        for (int c = tid; c < G; c += FE_THREADS) H[c] = unit_phasor(H[c]);
         __syncthreads();
     }
     if (taps.H) for (int c = tid; c < G; c += FE_THREADS) { taps.H[(size_t(f) * G + c) * 2] = H[c].re; taps.H[(size_t(f) * G + c) * 2 + 1] = H[c].im; }
@@ -342,26 +348,32 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
         }
     }
     // ---- channel_equalizer (in place over H) ---------------------------------------------------
-    for (int c = tid; c < G; c += FE_THREADS) H[c] = cdiv(grid[c], H[c]);
+    // The pilot cells first: their equalised values are the terms of the variance; then wavefront 0 adds them (the same dependent
+    // chain as above) while the others equalise the data cells.
+    for (int p = tid; p < T.nPilots; p += FE_THREADS) {
+        const int c = T.pilot_cell[p];
+        const c2 e = cdiv(grid[c], H[c]);
+        H[c] = e;
+        if (T.var_eq) {
+            const double dr = e.re - (type[c] < 0 ? -boost : boost), di = e.im - 0.0;
+            red[p] = dr * dr + di * di;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        if (tid == 0) {
+            double var = serial_sum(red, T.nPilots);
+            var /= double(T.nPilots);
+            scal[1] = var;
+        }
+    } else {
+        for (int i = tid - 64; i < T.nData; i += FE_THREADS - 64) { const int c = T.data_cell[i]; H[c] = cdiv(grid[c], H[c]); }
+    }
     __syncthreads();
     c2* eq = H;
     if (taps.eq) for (int c = tid; c < G; c += FE_THREADS) { taps.eq[(size_t(f) * G + c) * 2] = eq[c].re; taps.eq[(size_t(f) * G + c) * 2 + 1] = eq[c].im; }
     if (eqdata_out)   // de-framed equalised symbols, kept for the zero-forcing modes' post-decode SNR (ofdm_deframed_data)
         for (int i = tid; i < T.nData; i += FE_THREADS) { const c2 e = eq[T.data_cell[i]]; eqdata_out[(size_t(f) * T.nData + i) * 2] = e.re; eqdata_out[(size_t(f) * T.nData + i) * 2 + 1] = e.im; }
-    if (T.var_eq) {
-        for (int p = tid; p < T.nPilots; p += FE_THREADS) {
-            const int c = T.pilot_cell[p];
-            const double dr = eq[c].re - (type[c] < 0 ? -boost : boost), di = eq[c].im - 0.0;
-            red[p] = dr * dr + di * di;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        double var = serial_sum(red, T.nPilots);
-        var /= double(T.nPilots);
-        scal[1] = var;
-    }
-    __syncthreads();
     const float variance = float(scal[1]);
     if (tid == 0) {
         variance_out[f] = variance;
