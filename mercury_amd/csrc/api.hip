@@ -120,18 +120,16 @@ void ctx_alloc(mgpu_ctx* c) {
             c->lds_dec = mgpu_gbf_lds_bytes(d.N);
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_gbf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
-        case MGPU_DEC_MINSUM:
+        case MGPU_DEC_MINSUM: {
             c->lds_dec = mgpu_minsum_lds_bytes(d.S, d.N);
-            switch ((d.S + 1023) / 1024) {
-                case 1: case 2: case 3: case 4: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne4; break;
-                case 5: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne5; break;
-                case 6: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne6; break;
-                case 7: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne7; break;
-                case 8: c->spa_kernel = mgpu_ldpc_minsum_kernel_ne8; break;
-                default: throw std::runtime_error("graph too large for the min-sum kernel");
-            }
+            if (d.S > 8 * 1024) throw std::runtime_error("graph too large for the min-sum kernel");
+            const char* e = std::getenv("MERCURY_SPA_FAST_THREADS");
+            c->dec_threads = e ? std::atoi(e) : 512;
+            if (c->dec_threads != 512 && c->dec_threads != 1024) throw std::runtime_error("MERCURY_SPA_FAST_THREADS must be 512 or 1024");
+            c->spa_kernel = c->dec_threads == 512 ? mgpu_ldpc_minsum_kernel_t512 : mgpu_ldpc_minsum_kernel_t1024;
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
+        }
         case MGPU_DEC_SPA_FAST: {
             c->lds_dec = mgpu_spa_fast_lds_bytes(d.S, d.N);
             if (d.S > 8 * 1024) throw std::runtime_error("graph too large for the fp32 sum-product kernel");

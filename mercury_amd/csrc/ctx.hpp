@@ -50,8 +50,8 @@ extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, do
 extern "C" __global__ void mgpu_glibc_trig_probe_kernel(const double*, double*, double*, double*, int);
 using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-#define DECL_MS(NE) extern "C" __global__ void mgpu_ldpc_minsum_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-DECL_MS(4) DECL_MS(5) DECL_MS(6) DECL_MS(7) DECL_MS(8)
+#define DECL_MS(T) extern "C" __global__ void mgpu_ldpc_minsum_kernel_t##T(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+DECL_MS(1024) DECL_MS(512)
 #define DECL_SF(T) extern "C" __global__ void mgpu_ldpc_spa_fast_kernel_t##T(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 DECL_SF(1024) DECL_SF(512)
 extern "C" __global__ void mgpu_ldpc_encode_kernel(MgpuDev, const uint8_t*, int, uint8_t*);

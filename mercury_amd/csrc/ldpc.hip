@@ -475,6 +475,191 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
 SPA_FAST_KERNEL(1024)
 SPA_FAST_KERNEL(512)
 
+extern "C" size_t mgpu_minsum_lds_bytes(int S, int N) {
+    return size_t(4) * S + size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64;
+}
+
+// Normalised min-sum on the skeleton of the fp32 sum-product kernel above (wave-private bins, one in-place message array, scalar
+// prefix-XOR syndrome, descriptors from the shared table, 512-thread workgroups): only the check-node rule differs.
+template <int THREADS>
+__device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
+                                                uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
+                                                uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+                                                const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = T.S, N = T.N;
+    const int NE = (S + THREADS - 1) / THREADS;       // rounds: wave w works on bin w + (THREADS / 64) r in round r
+    float* M = reinterpret_cast<float*>(smem);        // R or T per padded edge slot
+    float* Lt = M + S;                                // posterior per variable
+    float* Li = Lt + N;                               // channel LLR
+    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
+    uint8_t* bytes = hard + ((N + 15) & ~15);
+    int* flag = reinterpret_cast<int*>(bytes + 256);
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (f >= F) return;
+    for (int v = tid; v < N; v += THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; Lt[v] = l; }
+    for (int p = tid; p < S; p += THREADS) M[p] = 0.0f;
+    const uint32_t* __restrict__ sdesc = T.sdesc;
+    const float alpha = T.minsum_alpha;
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    __syncthreads();
+
+    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
+        m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
+        return (m & ends) != 0;
+    };
+    auto syndrome_pass = [&](int p) {
+        bool unsat = false;
+        uint32_t k = sdesc[tid];
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t kn = sdesc[(r + 1) * THREADS + tid];
+            const unsigned long long vmask = __ballot(((k >> 13) & 0x3f) != 0);
+            const float lt = Lt[(k >> 19) & 0x7ff];
+            unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
+            k = kn;
+        }
+        if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
+    };
+    auto cn_pass = [&](bool with_syndrome, int p) {
+        bool unsat = false;
+        uint32_t k = sdesc[tid];
+        uint32_t slot = tid;
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r, slot += THREADS) {
+            const uint32_t kn = sdesc[(r + 1) * THREADS + tid];
+            const uint32_t deg = (k >> 13) & 0x3f;
+            const bool valid = deg != 0;
+            const unsigned long long vmask = __ballot(valid);
+            if (vmask == 0) { k = kn; continue; }
+            float lt;
+            if (valid) lt = Lt[(k >> 19) & 0x7ff];
+            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
+            float q = 0.0f;
+            if (valid) {
+                q = lt - M[slot];                                    // variable-to-check message
+                M[slot] = q;
+            }
+            __builtin_amdgcn_wave_barrier();
+            float rr = 0.0f;
+            if (T.scan_steps > 0) {
+                // high-degree graphs (rate 14/16: 33 edges per check): minimum over the OTHER edges as min(exclusive prefix minimum,
+                // exclusive suffix minimum) with segmented wave scans — a check is a run of consecutive lanes — instead of every lane
+                // scanning all edges of its check: 2 * (log2(deg) + 1) shuffles per bin instead of deg LDS reads. Same values.
+                const int pos = int(slot) - int(k & 0x1fff), rpos = int(deg) - 1 - pos;
+                const float a = valid ? __builtin_fabsf(q) : __builtin_inff();
+                const float inf = __builtin_inff();
+                float pre = __shfl_up(a, 1), suf = __shfl_down(a, 1);
+                pre = pos >= 1 ? pre : inf;
+                suf = rpos >= 1 ? suf : inf;
+                for (int st = 0, d = 1; st < T.scan_steps; ++st, d <<= 1) {
+                    const float tp = __shfl_up(pre, d), ts = __shfl_down(suf, d);
+                    pre = pos >= d ? fminf(pre, tp) : pre;
+                    suf = rpos >= d ? fminf(suf, ts) : suf;
+                }
+                // sign product of the others = parity of the check's negative edges, own edge taken out
+                const unsigned long long neg = __ballot(valid && (__float_as_uint(q) >> 31));
+                const uint32_t l0 = k & 63u;
+                const unsigned long long cm = ((deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << l0);
+                const uint32_t odd = uint32_t(__popcll(neg & cm) & 1) ^ (__float_as_uint(q) >> 31);
+                rr = __uint_as_float(__float_as_uint(fminf(pre, suf) * alpha) | (odd << 31));
+            } else if (valid) {
+                // the two smallest magnitudes and the sign product over ALL edges of the check (every lane of the check runs the same
+                // scan on broadcast reads); the own edge is taken out afterwards: min over the others = (|own| == min1) ? min2 : min1
+                // (a tie leaves min2 == min1).
+                const uint32_t cs = k & 0x1fff;
+                float mn1 = __builtin_inff(), mn2 = __builtin_inff();
+                uint32_t sg = 0;
+                uint32_t j = 0;
+                for (; j + 2 <= deg; j += 2) {
+                    const float x = M[cs + j], y = M[cs + j + 1];
+                    sg ^= __float_as_uint(x) ^ __float_as_uint(y);
+                    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+                    mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, ax);     // second smallest of {mn1, mn2, a}
+                    mn1 = fminf(mn1, ax);
+                    mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, ay);
+                    mn1 = fminf(mn1, ay);
+                }
+                if (j < deg) {
+                    const float x = M[cs + j];
+                    sg ^= __float_as_uint(x);
+                    const float ax = __builtin_fabsf(x);
+                    mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, ax);
+                    mn1 = fminf(mn1, ax);
+                }
+                const float mag = (__builtin_fabsf(q) == mn1) ? mn2 : mn1;
+                rr = __uint_as_float(__float_as_uint(mag * alpha) | ((sg ^ __float_as_uint(q)) & 0x80000000u));
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (valid) M[slot] = rr;
+            k = kn;
+        }
+        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
+    };
+    struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
+    auto load_var = [&](const uint32_t* vinfo, int i) -> VarRec {
+        const uint4 lo = *reinterpret_cast<const uint4*>(vinfo + size_t(i) * 8);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vinfo + size_t(i) * 8 + 4);
+        return VarRec{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+    };
+    auto var_update = [&](const VarRec& q) {
+        const uint32_t v = q.vi & 0x7ff, deg = q.vi >> 11;
+        float s = Li[v];
+        const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
+        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
+        if (deg > 2) {      // rows sorted by degree: wavefronts of degree-2 parity bits skip the rest
+            const float m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
+            s += m2;
+            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
+        }
+        if (deg > 5) {
+            const float m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
+            s += m5;
+            s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
+        }
+        Lt[v] = s;
+    };
+    constexpr int kSpecStart = 8;
+    int iteration = 0;
+    syndrome_pass(0);
+    __syncthreads();
+    if (flag[0]) {
+        for (int it = 1;; ++it) {
+            const bool spec = it - 1 >= kSpecStart;
+            if (it <= T.max_iters) cn_pass(spec, it - 1);
+            else syndrome_pass(it - 1);
+            __syncthreads();
+            if (spec) {
+                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
+                if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
+            }
+            if (tid == 0) flag[it & 1] = 0;
+            for (int i = tid; i < N; i += THREADS) var_update(load_var(T.vinfo, i));
+            __syncthreads();
+            if (it < kSpecStart) {
+                syndrome_pass(it);
+                __syncthreads();
+                if (!flag[it & 1]) { iteration = it; break; }
+                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
+            }
+        }
+    }
+    for (int v = tid; v < N; v += THREADS) hard[v] = Lt[v] < 0;
+    __syncthreads();
+    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}
+
+
+#define MINSUM_KERNEL(THREADS)                                                                                     \
+    extern "C" __global__ __launch_bounds__(THREADS) void mgpu_ldpc_minsum_kernel_t##THREADS(                      \
+        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                        \
+        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,      \
+        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                        \
+        minsum_decode<THREADS>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
+    }
+MINSUM_KERNEL(1024)
+MINSUM_KERNEL(512)
+
 // device probe of spa_math.h for tests: out_t[i] = tanh(in[i]); out_a[i] = atanh(in[i]) for |in[i]| < 1 else 0
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double* __restrict__ in, double* __restrict__ out_t,
                                                       double* __restrict__ out_a, int n) {
@@ -553,212 +738,3 @@ extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_gbf_kernel(
 // min of the other edges' |Q| (each lane scans its check's <= 46 slots, all lanes of a check read
 // the same LDS word per step = broadcast).
 // Up to eight slot descriptors per lane held in named registers; get(r) selects by the wave-uniform round number.
-struct SlotRegs {
-    uint32_t k0, k1, k2, k3, k4, k5, k6, k7;
-    __device__ __forceinline__ uint32_t get(int r) const {
-        uint32_t v = k0;
-        v = (r == 1) ? k1 : v; v = (r == 2) ? k2 : v; v = (r == 3) ? k3 : v; v = (r == 4) ? k4 : v;
-        v = (r == 5) ? k5 : v; v = (r == 6) ? k6 : v; v = (r == 7) ? k7 : v;
-        return v;
-    }
-};
-
-extern "C" size_t mgpu_minsum_lds_bytes(int S, int N) {
-    return size_t(4) * S + size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64;
-}
-
-template <int NE>
-__device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
-                                              uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
-                                              uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
-                                              const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int S = T.S, N = T.N;
-    float* M = reinterpret_cast<float*>(smem);        // Q or R per padded edge slot
-    float* Lt = M + S;                                // posterior per variable
-    float* Li = Lt + N;                               // channel LLR
-    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
-    uint8_t* bytes = hard + ((N + 15) & ~15);
-    int* flag = reinterpret_cast<int*>(bytes + 256);
-    const int tid = threadIdx.x, f = blockIdx.x;
-    if (f >= F) return;
-    const float alpha = T.minsum_alpha;
-    for (int v = tid; v < N; v += LDPC_THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; Lt[v] = l; }
-    auto load_slot = [&](int r) -> uint32_t {
-        const int p = tid + r * LDPC_THREADS;
-        uint32_t k = 0;
-        if (r < NE && p < S) {
-            const uint32_t sp = T.spack[p];
-            if (sp >> 31) k = (sp & 0x7ffffu) | (uint32_t(T.svar[p]) << 19);
-        }
-        return k;
-    };
-    const SlotRegs pk = {load_slot(0), load_slot(1), load_slot(2), load_slot(3), load_slot(4), load_slot(5), load_slot(6), load_slot(7)};
-    struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
-    auto load_var = [&](int i) -> VarRec {
-        if (i >= N) return VarRec{0, 0, 0, 0, 0, 0};
-        const uint32_t* rec = T.vinfo + size_t(i) * 8;
-        return VarRec{rec[0], rec[1], rec[2], rec[3], rec[4], rec[5]};
-    };
-    const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
-    auto var_update = [&](const VarRec& q) {
-        const int v = q.vi & 0x7ff, deg = q.vi >> 11;
-        float s = Li[v];
-        const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
-        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
-        if (deg > 2) {      // rows sorted by degree: wavefronts of degree-2 parity bits skip the rest
-            const float m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
-            s += m2;
-            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
-        }
-        if (deg > 5) {
-            const float m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
-            s += m5;
-            s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
-        }
-        Lt[v] = s;
-    };
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
-    __syncthreads();
-    auto check_parity = [&](uint32_t k, bool neg) -> bool {
-        const unsigned long long m = __ballot(neg);
-        const uint32_t deg = (k >> 13) & 0x3f, l0 = k & 63u;
-        const unsigned long long cm = ((deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << l0);
-        return (__popcll(m & cm) & 1) != 0;
-    };
-    auto syndrome_pass = [&](int p) {
-        bool unsat = false;
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t k = pk.get(r);
-            const bool valid = ((k >> 13) & 0x3f) != 0;
-            const float lt = valid ? Lt[k >> 19] : 0.0f;
-            unsat |= check_parity(k, valid && lt < 0) && valid;
-        }
-        if (unsat) flag[p & 1] = 1;
-    };
-    auto extrinsic_pass = [&](bool first) {            // Q = posterior - R (R == 0 before the first iteration)
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t k = pk.get(r);
-            if (((k >> 13) & 0x3f) != 0) {
-                const int p = tid + r * LDPC_THREADS;
-                M[p] = first ? Li[k >> 19] : Lt[k >> 19] - M[p];
-            }
-        }
-    };
-    auto fused_pass = [&](int p) {
-        bool unsat = false;
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t k = pk.get(r);
-            const bool valid = ((k >> 13) & 0x3f) != 0;
-            const float lt = valid ? Lt[k >> 19] : 0.0f;
-            unsat |= check_parity(k, valid && lt < 0) && valid;
-            if (valid) {
-                const int q = tid + r * LDPC_THREADS;
-                M[q] = lt - M[q];
-            }
-        }
-        if (unsat) flag[p & 1] = 1;
-    };
-    // iteration counts follow the reference's convention: 0 = input already a codeword,
-    // k = converged after k iterations, max+1 = never converged. Exact verdicts for the first kSpecStart passes,
-    // deferred (speculative check update) afterwards — see the sum-product kernel.
-    constexpr int kSpecStart = 8;
-    int iteration = 0;
-    syndrome_pass(0);
-    __syncthreads();
-    if (flag[0]) {
-        extrinsic_pass(true);
-        for (int it = 1;; ++it) {
-            const bool past_end = it > T.max_iters;
-            if (!past_end) {
-#pragma unroll 1
-                for (int r = 0; r < NE; ++r) {
-                    const uint32_t k = pk.get(r);
-                    const int deg = (k >> 13) & 0x3f;
-                    const bool valid = deg != 0;
-                    float rr = 0.0f;
-                    if (T.scan_steps > 0) {
-                        // high-degree graphs (rate 14/16: 33 edges per check): minimum over the OTHER edges as
-                        // min(exclusive prefix minimum, exclusive suffix minimum) with segmented wave scans — a check is
-                        // a run of consecutive lanes — instead of every lane scanning all edges of its check:
-                        // 2 * (log2(deg) + 1) shuffles per bin instead of deg LDS reads. Same values (min is exact).
-                        const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs, rpos = deg - 1 - pos;
-                        const float own = valid ? M[tid + r * LDPC_THREADS] : 0.0f;
-                        const float a = valid ? __builtin_fabsf(own) : __builtin_inff();
-                        const float inf = __builtin_inff();
-                        float pre = __shfl_up(a, 1), suf = __shfl_down(a, 1);
-                        pre = pos >= 1 ? pre : inf;
-                        suf = rpos >= 1 ? suf : inf;
-                        for (int st = 0, d = 1; st < T.scan_steps; ++st, d <<= 1) {
-                            const float tp = __shfl_up(pre, d), ts = __shfl_down(suf, d);
-                            pre = pos >= d ? fminf(pre, tp) : pre;
-                            suf = rpos >= d ? fminf(suf, ts) : suf;
-                        }
-                        // sign product of the others = parity of the check's negative edges, own edge taken out
-                        const unsigned long long neg = __ballot(valid && (__float_as_uint(own) >> 31));
-                        const uint32_t l0 = k & 63u;
-                        const unsigned long long cm = ((deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << l0);
-                        const uint32_t odd = uint32_t(__popcll(neg & cm) & 1) ^ (__float_as_uint(own) >> 31);
-                        rr = __uint_as_float(__float_as_uint(fminf(pre, suf) * alpha) | (odd << 31));
-                    } else if (valid) {
-                        const int cs = k & 0x1fff, pos = tid + r * LDPC_THREADS - cs;
-                        // two smallest magnitudes and the sign product over ALL edges of the check (every lane of the
-                        // check runs the same scan on broadcast reads); the own edge is taken out afterwards:
-                        // min over the others = (|own| == min1) ? min2 : min1  (a tie leaves min2 == min1).
-                        float mn1 = __builtin_inff(), mn2 = __builtin_inff();
-                        uint32_t sg = 0;
-                        for (int j = 0; j < deg; ++j) {
-                            const float m = M[cs + j];
-                            sg ^= __float_as_uint(m);
-                            const float a = __builtin_fabsf(m);
-                            mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);   // second smallest of {mn1, mn2, a}
-                            mn1 = fminf(mn1, a);
-                        }
-                        const float own = M[cs + pos];
-                        const float mag = (__builtin_fabsf(own) == mn1) ? mn2 : mn1;
-                        rr = __uint_as_float(__float_as_uint(mag * alpha) | ((sg ^ __float_as_uint(own)) & 0x80000000u));
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (valid) M[tid + r * LDPC_THREADS] = rr;
-                }
-            }
-            __syncthreads();
-            if (it - 1 >= kSpecStart) {
-                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
-                if (past_end) { iteration = T.max_iters + 1; break; }
-            }
-            if (tid == 0) flag[it & 1] = 0;
-            var_update(va);
-            if (tid + LDPC_THREADS < N) var_update(vb);
-            __syncthreads();
-            if (it < kSpecStart) {
-                syndrome_pass(it);
-                __syncthreads();
-                if (!flag[it & 1]) { iteration = it; break; }
-                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
-                extrinsic_pass(false);
-            } else {
-                fused_pass(it);
-            }
-        }
-    }
-    for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
-    __syncthreads();
-    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
-}
-
-#define MINSUM_KERNEL(NE)                                                                                          \
-    extern "C" __global__ __launch_bounds__(LDPC_THREADS, 8) void mgpu_ldpc_minsum_kernel_ne##NE(                \
-        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                        \
-        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,      \
-        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                        \
-        minsum_decode<NE>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
-    }
-MINSUM_KERNEL(4)
-MINSUM_KERNEL(5)
-MINSUM_KERNEL(6)
-MINSUM_KERNEL(7)
-MINSUM_KERNEL(8)
