@@ -43,8 +43,6 @@ void ctx_alloc(mgpu_ctx* c) {
     d.data_cell = c->keep(upload(t.data_cell));
     d.cptr = c->keep(upload(t.graph.cptr));
     d.cvar = c->keep(upload(t.graph.cvar));
-    d.spack = c->keep(upload(t.graph.spack));
-    d.svar = c->keep(upload(t.graph.svar));
     d.vinfo = c->keep(upload(t.graph.vinfo));
     d.sdesc = c->keep(upload(t.graph.sdesc));
     d.S = t.graph.S;
@@ -75,7 +73,7 @@ void ctx_alloc(mgpu_ctx* c) {
     d.active_nsymb = t.active_nsymb; d.active_nbits = t.active_nbits; d.mfsk_amp = t.mfsk_amp;
     d.puncture_from = (c->cfg.test_puncture_nBits > 0 && c->cfg.test_puncture_nBits < t.active_nbits) ? c->cfg.test_puncture_nBits : t.active_nbits;
     LdpcDev& l = c->ldev;
-    l.spack = d.spack; l.svar = d.svar; l.vinfo = d.vinfo; l.sdesc = d.sdesc; l.scrambler = d.scrambler;
+    l.vinfo = d.vinfo; l.sdesc = d.sdesc; l.scrambler = d.scrambler;
     l.cptr = d.cptr; l.cvar = d.cvar;
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;

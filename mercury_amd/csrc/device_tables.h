@@ -22,8 +22,6 @@ struct MgpuDev {
     // LDPC graph
     const uint32_t* cptr;          // [P+1] check-major edge list in the reference's row order
     const uint16_t* cvar;          // [E]   variable of edge e
-    const uint32_t* spack;         // [S]   wave-private padded layout (see tables.hpp)
-    const uint16_t* svar;          // [S]
     const uint32_t* vinfo;         // [N][6]
     const uint32_t* sdesc;         // [ceil(S/1024)*1024]
     int S;
@@ -46,7 +44,7 @@ struct MgpuDev {
 // Slim argument block for the decoder kernels: only what they touch, so the kernarg does not
 // inflate the SGPR allocation (occupancy on gfx950 drops below 8 waves/SIMD above 80 SGPRs).
 struct LdpcDev {
-    const uint32_t* spack; const uint16_t* svar; const uint32_t* vinfo;   // sum-product / min-sum layout
+    const uint32_t* vinfo;   // sum-product / min-sum layout
     const uint32_t* sdesc;   // [NE*1024] per padded slot: check_start(13) | deg(6)<<13 | variable(11)<<19 | last edge of its check<<31, 0 = padding (zero-filled, one spare round)
     const uint32_t* cptr; const uint16_t* cvar;                           // plain check-major lists (GBF)
     const uint8_t* scrambler;
