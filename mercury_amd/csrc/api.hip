@@ -66,6 +66,8 @@ void ctx_alloc(mgpu_ctx* c) {
     for (int r = 0; r < t.Nsymb; ++r)
         for (int q = 0; q < t.Nc; ++q)
             if ((t.cell_type[size_t(r) * t.Nc + q] != 0) != (((r - q) % 3 + 3) % 3 == 0)) d.regular_lattice = 0;
+    if (t.mfsk_M == 0 && (!d.regular_lattice || t.Nc != 50))
+        throw std::runtime_error("pilot lattice differs from the one the front-end kernel is specialised for (pilots where (row - col) % 3 == 0, 50 carriers)");
     if (d.regular_lattice && std::min(t.lsw / 2 + 1, t.Nc) >= 9) d.regular_lattice = 2;   // and every (clipped) window row holds >= 3 pilots of each column residue
     d.minsum_alpha = c->cfg.minsum_alpha > 0 ? c->cfg.minsum_alpha : 0.8f;
     d.mfsk_M = t.mfsk_M; d.mfsk_nbits = t.mfsk_nbits; d.mfsk_nstreams = t.mfsk_nstreams; d.mfsk_hop = t.mfsk_hop;

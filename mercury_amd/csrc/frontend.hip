@@ -67,24 +67,36 @@ __device__ __forceinline__ double serial_sum(const double* red, int n) {
     return acc;
 }
 
-// Workgroup size: 512 threads where three (or two) workgroups fit a compute unit's LDS; 1024 for the long BPSK frames (G = 2400 cells,
-// 92 KB of LDS: one workgroup per compute unit either way, so the larger one doubles the wavefronts in flight).
+// Workgroup size: 512 threads (three workgroups per compute unit in the QPSK and QAM modes, two in the long BPSK frames); a
+// 1024-thread variant exists for configurations whose LDS carve lets only one workgroup onto a compute unit.
 
-// LDS carve (bytes): grid 16G | work = H 16G + red/yp/llr rsz (the two together are the FFT work area first, later the
-//                    channel / equalised grid and the reduction terms, signed pilots, demapper LLRs) | aux = tw 2048 during the FFTs,
-//                    then type G + scal 64 (the cell types are first needed by the estimator)
-// rsz = max(16 nPilots, 4 nBits); the FFT runs on as many waves as work areas fit (4..8). Mode 8: 48 KB -> 3 workgroups/CU.
+// LDS carve (bytes): grid 16G (the carrier grid, equalised in place at the end) | work = Hp 16 nPilots (channel estimate at the pilots,
+//                    pilot order) + rsz (reduction terms / signed pilots / demapper LLRs), first the FFT work areas | aux = tw 2048
+//                    during the FFTs, then type G + scal 64 (the cell types are first needed by the estimator)
+// The channel estimate of a DATA cell is never stored: interpolation, amplitude restoration and the equaliser are applied to a cell
+// in one go (the interpolated value is a function of two pilot estimates). That keeps the frame at one grid + one pilot-sized
+// array: 40 KB in mode 8, 67 KB in the BPSK modes (92 KB with a second full grid: one workgroup per compute unit).
+// The FFT runs on as many wavefronts as work areas fit next to the grid without costing a workgroup per compute unit.
 struct FeCarve { int fft_waves; size_t rsz, work, total; };
 __host__ __device__ inline FeCarve fe_carve(int G, int nPilots, int nBits, int FE_WAVES) {
     FeCarve c;
     c.rsz = size_t(16) * (nPilots + 8) > size_t(4) * nBits ? size_t(16) * (nPilots + 8) : size_t(4) * nBits;   // + 8: zero pad behind the signed pilots (LS row reads)
     c.rsz = (c.rsz + 15) & ~size_t(15);
-    const size_t per_wave = size_t(FFT256_STRIDE) * 16;
-    size_t w = (size_t(16) * G + c.rsz) / per_wave;
-    c.fft_waves = int(w < 4 ? 4 : (w > FE_WAVES ? FE_WAVES : w));
-    c.work = size_t(16) * G + c.rsz > c.fft_waves * per_wave ? size_t(16) * G + c.rsz : c.fft_waves * per_wave;
-    const size_t aux = size_t((G + 15) & ~15) + 64;
-    c.total = size_t(16) * G + c.work + (aux > 2048 ? aux : 2048);
+    const size_t per_wave = size_t(FFT256_STRIDE) * 16, lds_cu = size_t(160) * 1024;
+    const size_t aux0 = size_t((G + 15) & ~15) + 64, aux = aux0 > 2048 ? aux0 : 2048;
+    const size_t fixed = size_t(16) * G + aux, need = size_t(16) * nPilots + c.rsz;
+    const size_t minimal = fixed + (need > 4 * per_wave ? need : 4 * per_wave);
+    // LDS is handed out in blocks of 1280 bytes (measured: three workgroups of 53,504 bytes run side by side on a compute unit, three of
+    // 54,016 do not — the runtime's occupancy calculator says 3 for both), so a workgroup's share is a whole number of blocks
+    const size_t block = 1280;
+    size_t wgs = lds_cu / ((minimal + block - 1) / block * block);  // workgroups per compute unit by LDS with the fewest FFT work areas
+    const size_t cap = size_t(24 / FE_WAVES) > 0 ? size_t(24 / FE_WAVES) : 1;    // 80 registers per lane: 24 wavefronts per compute unit
+    if (wgs > cap) wgs = cap;
+    if (wgs < 1) wgs = 1;
+    size_t w = (lds_cu / wgs / block * block - fixed) / per_wave;
+    c.fft_waves = int(w < 4 ? 4 : (w > size_t(FE_WAVES) ? size_t(FE_WAVES) : w));
+    c.work = need > c.fft_waves * per_wave ? need : c.fft_waves * per_wave;
+    c.total = fixed + c.work;
     return c;
 }
 extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits, int threads) { return fe_carve(G, nPilots, nBits, threads / 64).total; }
@@ -98,12 +110,12 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
     const int G = T.G, Nc = 50, Ns = T.Nsymb;
     const FeCarve carve = fe_carve(G, T.nPilots, T.nBits, FE_WAVES);
     c2* grid = reinterpret_cast<c2*>(smem);
-    c2* H = grid + G;                                               // H and red together are the FFT work area first
-    c2* fftb = H;
-    double* red = reinterpret_cast<double*>(H + G);                 // nPilots doubles
+    c2* Hp = grid + G;                                              // channel estimate at the pilots, pilot order; Hp and red are the FFT work area first
+    c2* fftb = Hp;
+    double* red = reinterpret_cast<double*>(Hp + T.nPilots);        // nPilots doubles
     float* llr = reinterpret_cast<float*>(red);                     // demapper output reuses the reduction area
     c2* yp = reinterpret_cast<c2*>(red);                            // pilots in row-major pilot order, multiplied by their sign
-    c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(H) + carve.work);
+    c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(Hp) + carve.work);
     int8_t* type = reinterpret_cast<int8_t*>(tw);                   // 0 data, +1 / -1 pilot with that sign; takes the twiddles' place after the FFTs
     double* scal = reinterpret_cast<double*>(type + ((G + 15) & ~15));
 
@@ -185,7 +197,7 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
         const int c = T.pilot_cell[p], i = c / Nc, j = c - i * Nc;
         if (T.estimator == 0) {            // ZF: Y / (x + 0i) reduces to two real divisions in __divdc3
             const double x = type[c] < 0 ? -boost : boost;
-            H[c] = {grid[c].re / x, grid[c].im / x};
+            Hp[p] = {grid[c].re / x, grid[c].im / x};
         } else {                           // LS over the (clipped) 21x21 window, row-major order
             const int k0 = max(i - hw, 0), k1 = min(i + hw, Ns - 1), l0 = max(j - hw, 0), l1 = min(j + hw, Nc - 1);
             double hr = 0, hi = 0;
@@ -240,7 +252,7 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
                         if (k + 1 <= k1) add_row(1);
                         if (k + 2 <= k1) add_row(2);
                     }
-                    H[c] = {hr, hi};
+                    Hp[p] = {hr, hi};
                     continue;
                 }
                 int km = k0 % 3, rowbase = 50 * (k0 / 3);
@@ -274,103 +286,84 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
                         hi += xw * grid[q].im;
                     }
             }
-            H[c] = {hr, hi};
+            Hp[p] = {hr, hi};
         }
     }
     __syncthreads();
     FE_STAMP();   // 3: estimate done
-    // ---- interpolate_linear_col for the data cells --------------------------------------------
-    for (int c = tid; c < G; c += FE_THREADS) {
-        if (type[c]) continue;
-        const int i = c / Nc, j = c - i * Nc;
-        int a, b;
-        if (T.regular_lattice) {           // column j has its pilots in the rows == j (mod 3): the neighbours follow from (i - j) mod 3
-            const int m = (i - j + 3 * Nc) % 3;                      // 1 or 2 for a data cell
-            a = i - m; b = i + 3 - m;
-            if (a < 0) { a = b; b = a + 3; }                         // above the first pilot: extrapolate from the first two
-            else if (b >= Ns) { b = a; a = b - 3; }                  // below the last pilot: extrapolate from the last two
-        } else {
-            int prev = -1, next = -1;
-            for (int r = i - 1; r >= 0; --r) if (type[r * Nc + j]) { prev = r; break; }
-            for (int r = i + 1; r < Ns; ++r) if (type[r * Nc + j]) { next = r; break; }
-            if (prev >= 0 && next >= 0) { a = prev; b = next; }
-            else if (prev < 0) {               // above the first pilot: extrapolate from the first two
-                a = next; b = -1;
-                for (int r = next + 1; r < Ns; ++r) if (type[r * Nc + j]) { b = r; break; }
-            } else {                           // below the last pilot: extrapolate from the last two
-                b = prev; a = -1;
-                for (int r = prev - 1; r >= 0; --r) if (type[r * Nc + j]) { a = r; break; }
-            }
-        }
-        H[c] = lerp(H[a * Nc + j], double(a), H[b * Nc + j], double(b), double(i));
-    }
-    __syncthreads();
-
+    // ---- interpolate_linear_col + restore_channel_amplitude + channel_equalizer, one cell at a time ----------------------
     if (taps.mean_H) {      // mean |H| over the MEASURED (pilot) cells in cell order, telecom_system.cc:1224-1243
-        for (int p = tid; p < T.nPilots; p += FE_THREADS) { const c2 h = H[T.pilot_cell[p]]; red[p] = hypot(h.re, h.im); }
+        for (int p = tid; p < T.nPilots; p += FE_THREADS) { const c2 h = Hp[p]; red[p] = hypot(h.re, h.im); }
         __syncthreads();
         if (tid == 0) taps.mean_H[f] = T.nPilots > 0 ? serial_sum(red, T.nPilots) / T.nPilots : -1.0;
         __syncthreads();
     }
-    FE_STAMP();   // 4: interpolation done
-    // ---- amplitude restoration (PSK modes) + SNR variance on the non-restored equalisation ----
-    if (T.amp_restore) {
-        for (int p = tid; p < T.nPilots; p += FE_THREADS) {      // measure_variance(equalized_data_without_amplitude_restoration)
-            const int c = T.pilot_cell[p];
-            const c2 e = cdiv(grid[c], H[c]);
-            const double dr = e.re - (type[c] < 0 ? -boost : boost), di = e.im - 0.0;
-            red[p] = dr * dr + di * di;
-        }
-        __syncthreads();
-        // The sum is a chain of nPilots dependent additions for one lane; with three workgroups per compute unit the frame rate is
-        // workgroups in flight / time per frame, so the chain must not sit in front of anything: wavefront 0 adds, the others turn
-        // the channel estimates into unit phasors meanwhile.
-        if (wave == 0) {
-            if (tid == 0) {
-                double var = serial_sum(red, T.nPilots);
-                var /= double(T.nPilots);
-                scal[2] = var;
-            }
-        } else {
-            for (int c = tid - 64; c < G; c += FE_THREADS - 64) H[c] = unit_phasor(H[c]);
-        }
-        __syncthreads();
-    }
-    if (taps.H) for (int c = tid; c < G; c += FE_THREADS) { taps.H[(size_t(f) * G + c) * 2] = H[c].re; taps.H[(size_t(f) * G + c) * 2 + 1] = H[c].im; }
-
-    FE_STAMP();   // 5: amplitude restoration done
-    // ---- variance terms from the un-equalised grid (baseband_test_EsN0 variant) ----------------
-    if (!T.var_eq) {
-        for (int p = tid; p < T.nPilots; p += FE_THREADS) {
-            const int c = T.pilot_cell[p];
-            const double dr = grid[c].re - (type[c] < 0 ? -boost : boost), di = grid[c].im - 0.0;
-            red[p] = dr * dr + di * di;
-        }
-    }
-    // ---- channel_equalizer (in place over H) ---------------------------------------------------
-    // The pilot cells first: their equalised values are the terms of the variance; then wavefront 0 adds them (the same dependent
-    // chain as above) while the others equalise the data cells.
+    FE_STAMP();   // 4: (interpolation is part of the equaliser pass below)
+    // A data cell (i, j): column j has its pilots in the rows == j (mod 3) (checked on the host), so the two pilot rows it interpolates
+    // between follow from (i - j) mod 3 (above the first / below the last pilot: extrapolation from the nearest two), and a pilot of
+    // row r, column j has index first_pilot(r) + j / 3 in pilot order (rows hold 17, 17, 16 pilots cyclically). The cell's estimate
+    // = lerp of the two pilot estimates (interpolator.cc:163-254), made a unit phasor in the PSK modes (ofdm.cc:1453-1466), divides the
+    // received cell (ofdm.cc:1637-1647); the equalised value replaces the received one in the grid. Same operations per cell as the
+    // reference's three passes over a full channel grid.
+    auto first_pilot = [](int k) { const int m = k % 3; return 50 * (k / 3) + (m == 0 ? 0 : m == 1 ? 17 : 34); };
+    auto equalise_data = [&](int idx) {
+        const int c = T.data_cell[idx], i = c / Nc, j = c - i * Nc;
+        const int m = (i - j + 3 * Nc) % 3;                          // 1 or 2 for a data cell
+        int a = i - m, b = i + 3 - m;
+        if (a < 0) { a = b; b = a + 3; }                             // above the first pilot: extrapolate from the first two
+        else if (b >= Ns) { b = a; a = b - 3; }                      // below the last pilot: extrapolate from the last two
+        c2 h = lerp(Hp[first_pilot(a) + j / 3], double(a), Hp[first_pilot(b) + j / 3], double(b), double(i));
+        if (T.amp_restore) h = unit_phasor(h);
+        if (taps.H) { taps.H[(size_t(f) * G + c) * 2] = h.re; taps.H[(size_t(f) * G + c) * 2 + 1] = h.im; }
+        grid[c] = cdiv(grid[c], h);
+    };
+    // The pilot cells first, all of them in one pass: the term of the variance before amplitude restoration (PSK modes; SNR report),
+    // the cell's own equalisation, and the term of the variance that scales the LLRs (from the un-equalised cell in the
+    // baseband_test_EsN0 variant). Both variances are sums of nPilots terms in pilot order — dependent chains for one lane — so
+    // wavefront 0 adds them while the other wavefronts equalise the data cells, handed out in runs of 64 from a counter in LDS;
+    // wavefront 0 joins when its sums are done.
+    double* red2 = red + T.nPilots;                                  // second term array (the signed pilots are no longer needed)
+    int* queue = reinterpret_cast<int*>(scal + 3);
+    if (tid == 0) *queue = 0;
     for (int p = tid; p < T.nPilots; p += FE_THREADS) {
         const int c = T.pilot_cell[p];
-        const c2 e = cdiv(grid[c], H[c]);
-        H[c] = e;
-        if (T.var_eq) {
-            const double dr = e.re - (type[c] < 0 ? -boost : boost), di = e.im - 0.0;
+        const c2 g = grid[c];
+        c2 h = Hp[p];
+        const double x = type[c] < 0 ? -boost : boost;
+        if (T.amp_restore) {                                         // measure_variance(equalized_data_without_amplitude_restoration)
+            const c2 e0 = cdiv(g, h);
+            const double dr = e0.re - x, di = e0.im - 0.0;
             red[p] = dr * dr + di * di;
+            h = unit_phasor(h);
         }
+        if (taps.H) { taps.H[(size_t(f) * G + c) * 2] = h.re; taps.H[(size_t(f) * G + c) * 2 + 1] = h.im; }
+        const c2 e = cdiv(g, h);
+        grid[c] = e;
+        const c2 v = T.var_eq ? e : g;
+        const double dr = v.re - x, di = v.im - 0.0;
+        red2[p] = dr * dr + di * di;
     }
     __syncthreads();
-    if (wave == 0) {
-        if (tid == 0) {
+    FE_STAMP();   // 5: pilot cells done
+    if (tid == 0) {
+        if (T.amp_restore) {
             double var = serial_sum(red, T.nPilots);
             var /= double(T.nPilots);
-            scal[1] = var;
+            scal[2] = var;
         }
-    } else {
-        for (int i = tid - 64; i < T.nData; i += FE_THREADS - 64) { const int c = T.data_cell[i]; H[c] = cdiv(grid[c], H[c]); }
+        double var = serial_sum(red2, T.nPilots);
+        var /= double(T.nPilots);
+        scal[1] = var;
+    }
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(queue, 64);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= T.nData) break;
+        if (base + lane < T.nData) equalise_data(base + lane);
     }
     __syncthreads();
-    c2* eq = H;
+    c2* eq = grid;
     if (taps.eq) for (int c = tid; c < G; c += FE_THREADS) { taps.eq[(size_t(f) * G + c) * 2] = eq[c].re; taps.eq[(size_t(f) * G + c) * 2 + 1] = eq[c].im; }
     if (eqdata_out)   // de-framed equalised symbols, kept for the zero-forcing modes' post-decode SNR (ofdm_deframed_data)
         for (int i = tid; i < T.nData; i += FE_THREADS) { const c2 e = eq[T.data_cell[i]]; eqdata_out[(size_t(f) * T.nData + i) * 2] = e.re; eqdata_out[(size_t(f) * T.nData + i) * 2 + 1] = e.im; }

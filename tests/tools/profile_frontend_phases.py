@@ -9,5 +9,5 @@ for cfg in (8,0,16):
     bb=np.tile(bb,(F//8,1))
     out=rx.receive(bb,taps=True); out=rx.receive(bb,taps=True)
     c=out['cycles']; d=np.diff(c[:9])
-    names=['fft','agc','estimate','interp','amp_restore','eq+var','demap','repack']
+    names=['fft','agc','estimate','mean_H tap','pilot cells','variance sums | data cells','demap','repack']
     print(cfg,'total cycles',c[8]-c[0], dict(zip(names,d.tolist())))
