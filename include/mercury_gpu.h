@@ -234,8 +234,9 @@ int mgpu_debug_spa_math(mgpu_ctx* ctx, const double* in, int n, double* tanh_out
 int mgpu_debug_select_peak(mgpu_ctx* ctx, const double* cand_vals, int n, int ncand_max, const int* ncand, const int* size, const int* loc, int step,
                            int nTrials_max, int* delay, double* corr);
 
-/* Test / tuning hook: workgroups of the front-end kernel (which = 0) that fit one compute unit with this context's LDS carve, as the
- * runtime's occupancy calculator reports it; -1 on error. */
+/* Test / tuning hook: which = 0: workgroups of the front-end kernel that fit one compute unit with this context's LDS carve, as the
+ * runtime's occupancy calculator reports it (it does not know that LDS is handed out in 1280-byte blocks); 1 / 2: dynamic LDS bytes of a
+ * front-end / decoder workgroup; 3: threads of a decoder workgroup; -1 on error. */
 int mgpu_debug_occupancy(mgpu_ctx* ctx, int which);
 
 /* Test hook: the Schmidl-Cox metric of every candidate (time_sync_preamble_with_metric, ofdm.cc:1893-1941, before the peak selection) for W

@@ -640,6 +640,9 @@ int mgpu_debug_occupancy(mgpu_ctx* c, int which) {
         const auto& t = c->tab;
         if (which == 0 && t.mfsk_M == 0) HIPCK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, c->fe_threads == 1024 ? mgpu_frontend_kernel_t1024 : mgpu_frontend_kernel, c->fe_threads, c->lds_fe));
         else if (which == 0) HIPCK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, t.mfsk_M == 32 ? mgpu_mfsk_frontend_kernel_m32 : mgpu_mfsk_frontend_kernel_m16x2, 256, 0));
+        else if (which == 1) n = int(c->lds_fe);          // dynamic LDS bytes of the front-end workgroup
+        else if (which == 2) n = int(c->lds_dec);         // ... of the decoder workgroup
+        else if (which == 3) n = c->dec_threads;
         else n = -1;
     });
     return n;
