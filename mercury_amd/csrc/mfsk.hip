@@ -83,11 +83,6 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
     const int tone_off = kBandStart + st * M;
     double* E = en[wave] + half * 64;                            // |carrier|^2 of this half's symbol, carrier order
 
-    c2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
-    if (s0 + wave < s1) {
-        const c2* in = bb + size_t(s0 + wave) * 272 + 16;            // gi_remover
-        n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
-    }
     for (int sa = s0 + wave; sa < s1; sa += 2 * MF_WAVES) {
         const int sb = sa + MF_WAVES;                                // the pair's second symbol (may lie past the run's end)
 #pragma unroll
@@ -98,11 +93,10 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
                 Eo[lane] = 0.0;
                 continue;
             }
-            c2 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-            if (s + MF_WAVES < s1) {
-                const c2* in = bb + size_t(s + MF_WAVES) * 272 + 16;
-                n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
-            }
+            // no prefetch of the following symbol: its 16 registers per lane cost a workgroup per compute unit (94 vs 106: five instead of
+            // four), and five workgroups hide the load latency better than the prefetch did (ROBUST_1: 0.73 -> 0.68 ms per 4096 frames)
+            const c2* in = bb + size_t(s) * 272 + 16;                // gi_remover
+            c2 r0 = in[lane], r1 = in[lane + 64], r2 = in[lane + 128], r3 = in[lane + 192];
             wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
             auto emit = [&](const c2& x, int p) {                    // 1/Nfft scale + zero_depadder + energy
                 const int col = carrier_of_bin(brev8(p));
