@@ -179,6 +179,24 @@ int mgpu_ldpc_batch_dev(mgpu_ctx* ctx, const void* d_llr, int F, void* d_bits_op
 int mgpu_txgen_dev(mgpu_ctx* ctx, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel,
                    void* d_baseband_c128, void* d_payload_opt, void* stream);
 
+/* ---- the reference's self-simulation: cl_telecom_system::baseband_test_EsN0 (telecom_system.cc:96-229) as BER_PLOT_baseband_process_main
+ * drives it (:2393-2480: one call per Es/N0 point, cl_error_rate::check per frame, error_rate.cc:48-70) ------------------------
+ * For every Es/N0 point: frames_per_point frames of random data bits -> encode ... IFFT (the TX chain of the synthetic generator,
+ * DESIGN.md §6) -> AWGN at that Es/N0 (sigma = 10^(-EsN0/20) at the reference's 1/sqrt(Nfft) scale) -> this context's RX path ->
+ * decoded bits compared with the sent ones. All on the device, in batches of at most max_batch frames; blocking. The context's
+ * agc / variance_source choose the RX variant (baseband_test_EsN0 itself is agc = 0, variance_source = 0). The random source is the
+ * generator's Philox stream (seed, frames numbered from frame0 upward, point p uses frames [frame0 + p*frames_per_point, ...)), not
+ * libc rand() as in the reference, so curves agree statistically and — frame for frame — with the CPU oracle fed the same frames. */
+typedef struct mgpu_error_rate {          /* cl_error_rate (error_rate.h) + two extras */
+    double esn0_db;
+    long long Frames_total, Error_frames_total, Bits_total, Error_bits_total;
+    double BER, FER;
+    double avg_iterations;                /* mean of iterations_done */
+    long long crc_ok_frames;              /* frames whose CRC self-check passed (meaningful for payloads that carry one) */
+} mgpu_error_rate;
+int mgpu_baseband_test_esn0(mgpu_ctx* ctx, const double* esn0_db, int npoints, long long frames_per_point, uint64_t seed, uint64_t frame0,
+                            int channel, mgpu_error_rate* out);
+
 /* ---- synchroniser building blocks in front of the path, batched over W capture windows,
  * host buffers, blocking. Sample rate 48 kHz and carrier amplitude sqrt(2) as in the reference
  * (telecom_system.cc:69,1569); FIR designs as load_configuration makes them (physical_config.cc:90-98).

@@ -254,6 +254,17 @@ public:
         detail::check(mgpu_measure_signal_only(ctx_, data, 1, carrier_frequency, &dbm), ctx_, "measure_signal_only");
         return dbm;
     }
+    // cl_error_rate cl_telecom_system::baseband_test_EsN0(float EsN0, int max_frame_no) — telecom_system.h:131, .cc:96-229: the
+    // self-simulation BER_PLOT_baseband_process_main calls once per Es/N0 point (:2408-2414). Frames come from the generator's
+    // Philox stream (seed / first frame below), not libc rand(); the counters are cl_error_rate's (error_rate.h).
+    std::uint64_t ber_seed = 1, ber_next_frame = 0;
+    mgpu_error_rate baseband_test_EsN0(float EsN0, int max_frame_no) {
+        mgpu_error_rate r{};
+        const double e = EsN0;
+        detail::check(mgpu_baseband_test_esn0(ctx_, &e, 1, max_frame_no, ber_seed, ber_next_frame, 0, &r), ctx_, "baseband_test_EsN0");
+        ber_next_frame += std::uint64_t(max_frame_no);
+        return r;
+    }
     // int generate_ack_pattern_passband(double* out) / generate_break_pattern_passband — telecom_system.cc:1589-1631, :1659-1689;
     // returns the number of samples written (ack_pattern_passband_samples)
     int ack_pattern_passband_samples() const { return 16 * info.Nofdm * 4; }

@@ -613,6 +613,51 @@ int mgpu_time_sync_preamble(mgpu_ctx* c, const double* bb, int W, int size, int 
     });
 }
 
+int mgpu_baseband_test_esn0(mgpu_ctx* c, const double* esn0_db, int npoints, long long frames_per_point, uint64_t seed, uint64_t frame0, int channel,
+                            mgpu_error_rate* out) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(esn0_db && out && npoints > 0 && frames_per_point > 0 && (channel == 0 || channel == 1), "bad argument");
+        const auto& t = c->tab;
+        const int B = int(std::min<long long>(frames_per_point, c->max_batch));
+        ensure_workspaces(c, WS_FRONTEND | WS_LLR | WS_OUT);
+        DevBuf d_bb(size_t(B) * t.frame_samples * 16), d_sent(size_t(B) * t.payload_stride), d_acc(4 * 8);
+        hipStream_t s = c->stream;
+        for (int p = 0; p < npoints; ++p) {
+            const double noise_amp = std::pow(10.0, -esn0_db[p] / 20.0) / std::sqrt(2.0);      // per component, telecom_system.cc:100,147
+            HIPCK(hipMemsetAsync(d_acc.p, 0, 32, s));
+            for (long long done = 0; done < frames_per_point; done += B) {
+                const int n = int(std::min<long long>(B, frames_per_point - done));
+                const uint64_t first = frame0 + uint64_t(p) * uint64_t(frames_per_point) + uint64_t(done);
+                for (int off = 0; off < n; off += kMaxFramesPerLaunch) {
+                    const int m = std::min(n - off, kMaxFramesPerLaunch);
+                    hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(m), dim3(256), c->lds_tx, s, c->dev, seed, first + uint64_t(off), m, noise_amp, channel,
+                                       d_bb.as<double>() + size_t(off) * t.frame_samples * 2, d_sent.as<uint8_t>() + size_t(off) * t.payload_stride,
+                                       static_cast<const uint8_t*>(nullptr), 0, static_cast<const int*>(nullptr), 0, 0);
+                    HIPCK(hipGetLastError());
+                }
+                MgpuTapsDev taps{};
+                launch_frontend(c, d_bb.as<double>(), n, c->d_llr, c->d_variance, c->d_snrvar, taps, s);
+                launch_decoder(c, c->d_llr, n, nullptr, nullptr, c->d_payload, c->d_stats, c->d_variance, c->d_snrvar, s);
+                hipLaunchKernelGGL(mgpu_error_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_sent.as<uint8_t>(), c->d_payload, c->d_stats,
+                                   t.payload_stride, t.nReal, n, d_acc.as<unsigned long long>());
+                HIPCK(hipGetLastError());
+            }
+            unsigned long long acc[4];
+            HIPCK(hipMemcpyAsync(acc, d_acc.p, 32, hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            mgpu_error_rate& r = out[p];
+            r.esn0_db = esn0_db[p];
+            r.Frames_total = frames_per_point; r.Error_frames_total = (long long)acc[1];
+            r.Bits_total = frames_per_point * t.nReal; r.Error_bits_total = (long long)acc[0];
+            r.BER = double(r.Error_bits_total) / double(r.Bits_total);
+            r.FER = double(r.Error_frames_total) / double(r.Frames_total);
+            r.avg_iterations = double(acc[2]) / double(frames_per_point);
+            r.crc_ok_frames = (long long)acc[3];
+        }
+    });
+}
+
 int mgpu_debug_select_peak(mgpu_ctx* c, const double* cand_vals, int n, int ncand_max, const int* ncand, const int* size, const int* loc, int step,
                            int nTrials_max, int* delay, double* corr) {
     if (!c) return MGPU_ERR_ARG;

@@ -87,3 +87,30 @@ extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_zf_snr_kernel(
         stats[f].snr_db = float(-10.0 * log10(var));
     }
 }
+
+// cl_error_rate::check (error_rate.cc:48-70) for F frames at once: bits that differ between the sent and the decoded payload
+// (nReal bits per frame, packed LSB first as the payload is; the scrambler is a bijection, so payload bits differ exactly where the
+// reference's data_bit / hd_decoded_data_bit differ), frames with at least one such bit, and the iteration counts, added into
+// acc[0..3] = {bit errors, frame errors, iterations, frames whose CRC self-check passed}. One lane per frame.
+extern "C" __global__ __launch_bounds__(256) void mgpu_error_count_kernel(
+    const uint8_t* __restrict__ sent, const uint8_t* __restrict__ got, const MgpuStatsDev* __restrict__ stats, int stride, int nReal, int F,
+    unsigned long long* __restrict__ acc) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long be = 0, fe = 0, it = 0, ok = 0;
+    if (f < F) {
+        const uint8_t* a = sent + size_t(f) * stride;
+        const uint8_t* b = got + size_t(f) * stride;
+        const int full = nReal >> 3, rem = nReal & 7;
+        unsigned e = 0;
+        for (int i = 0; i < full; ++i) e += __popc(unsigned(a[i] ^ b[i]));
+        if (rem) e += __popc(unsigned((a[full] ^ b[full]) & ((1u << rem) - 1u)));
+        be = e; fe = e != 0; it = unsigned(stats[f].iterations_done); ok = stats[f].message_decoded != 0;
+    }
+    // wave reduction, then one atomic per wave and counter
+    for (int d = 32; d >= 1; d >>= 1) {
+        be += __shfl_xor(be, d); fe += __shfl_xor(fe, d); it += __shfl_xor(it, d); ok += __shfl_xor(ok, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], be); atomicAdd(&acc[1], fe); atomicAdd(&acc[2], it); atomicAdd(&acc[3], ok);
+    }
+}

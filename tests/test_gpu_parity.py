@@ -725,3 +725,39 @@ def test_ldpc_encode_matches_oracle_and_decodes_back(cfg):
     noisy[:, rng.choice(1600, 12, replace=False)] *= -0.25
     bits, iters = rx.ldpc_decode(noisy)
     assert np.array_equal(bits, data) and np.all(iters >= 1) and np.all(iters <= 50)
+
+
+@pytest.mark.parametrize("cfg", [8, 0, 16, 101])
+def test_baseband_test_esn0_counts_match_the_oracle_frame_for_frame(cfg):
+    """mgpu_baseband_test_esn0 (the reference's BER_PLOT_baseband self-simulation, telecom_system.cc:96-229, :2393-2480) against the CPU
+    oracle fed the very same generated frames: bit errors, frame errors and iteration totals per Es/N0 point must be equal, across
+    batch boundaries (max_batch 40, 96 frames per point) and with the points' frame ranges laid end to end."""
+    agc, vs, flags = _variants(cfg)[-1] if cfg < 100 else (1, 1, oraclelib.FLAGS_RECEIVE_BYTE)
+    orc = Oracle(cfg, 50)
+    rx = _rx(cfg, max_batch=40, agc=agc, variance_source=vs)
+    pts = [OPERATING_ESN0[cfg] - 3.0, OPERATING_ESN0[cfg] - 1.5, OPERATING_ESN0[cfg] + 2.0]
+    n, seed, frame0 = 96, 77, 1000
+    res = rx.baseband_test_esn0(pts, n, seed=seed, frame0=frame0)
+    nreal = rx.nReal
+    for p, esn0 in enumerate(pts):
+        be = fe = it = 0
+        for k in range(n):
+            bb, pl = orc.gen_frame(seed, frame0 + p * n + k, noise_amp_for(esn0))
+            ref = orc.rx(bb, flags)
+            crc = 0xffff                                         # CRC16 (Modbus RTU) of the payload, as every frame carries it
+            for byte in pl.astype(np.uint8).tolist():
+                crc ^= byte
+                for _ in range(8):
+                    crc = (crc >> 1) ^ 0xA001 if crc & 1 else crc >> 1
+            full = np.concatenate([pl.astype(np.uint8), np.array([crc & 0xff, crc >> 8], np.uint8), np.zeros(2, np.uint8)])   # spare bits are sent as 0
+            sent = np.unpackbits(full, bitorder="little")[:nreal]
+            got = np.unpackbits(ref["bytes"].astype(np.uint8), bitorder="little")[:nreal]
+            e = int((sent != got).sum())
+            be += e
+            fe += e != 0
+            it += ref["iterations"]
+        r = res[p]
+        assert (r["Error_bits_total"], r["Error_frames_total"], r["Frames_total"], r["Bits_total"]) == (be, fe, n, n * nreal), (cfg, esn0, r, be, fe)
+        assert abs(r["avg_iterations"] * n - it) < 1e-6 and r["BER"] == be / (n * nreal) and r["FER"] == fe / n
+    assert res[0]["Error_frames_total"] > 0 and res[2]["Error_frames_total"] <= res[0]["Error_frames_total"]      # a curve, not a constant
+    rx.close()
