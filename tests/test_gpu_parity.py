@@ -566,6 +566,28 @@ def test_single_frame_graph_path_equals_batched_path():
     rx.close()
 
 
+def test_single_frame_graph_survives_a_larger_batch_in_between():
+    """on a FRESH context the order F = 1 (graph captured), F = max_batch (workspaces grow), F = 1 (graph replayed)
+    must not replay the graph against a freed buffer: the graph owns its one-frame device buffer."""
+    cfg = 8
+    orc = Oracle(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    bb, _ = _frames(orc, [op, op + 1.0, -15.0, op + 3.0, 40.0, op - 1.0, op + 0.5, op + 2.0], seed=99)
+    ref = _rx(cfg, max_batch=len(bb))
+    want = ref.receive(bb)
+    ref.close()
+    rx = _rx(cfg, max_batch=len(bb))
+    first = rx.receive(bb[2:3])                     # captures the graph before any batched workspace exists
+    assert np.array_equal(first["payload"][0], want["payload"][2]) and first["stats"][0] == want["stats"][2]
+    for rep in range(3):
+        big = rx.receive(bb)                        # allocates / reuses the batched buffers
+        assert np.array_equal(big["payload"], want["payload"]) and (big["stats"] == want["stats"]).all()
+        for f in (0, 5, 7):
+            one = rx.receive(bb[f:f + 1])           # replays the graph
+            assert np.array_equal(one["payload"][0], want["payload"][f]) and one["stats"][0] == want["stats"][f], (rep, f)
+    rx.close()
+
+
 def test_generator_and_receiver_are_invariant_to_how_frames_are_sharded():
     """Frame-range sharding: frames are keyed by their global index, so generating / receiving them in one
     call, in two halves or rank by rank (frame_range) gives identical samples, payloads and statistics."""
