@@ -69,6 +69,20 @@ int mgpu_receive_byte_batch(mgpu_ctx* ctx, const double* passband, int W, const 
  * (host or device), signal_strength_dbm: [W] host. */
 int mgpu_measure_signal_only(mgpu_ctx* ctx, const double* passband, int W, double carrier_hz, double* signal_strength_dbm);
 
+/* cl_error_rate cl_telecom_system::passband_test_EsN0(float EsN0, int max_frame_no) (telecom_system.h:130, .cc:231-330), the audio-path
+ * self-simulation (operation mode PLOT_PASSBAND), per Es/N0 point and batched: frames_per_point random payloads -> transmit_byte
+ * (SINGLE_MESSAGE, the physical_config.cc defaults, output_power_watt: 0.1 by default, BER_PLOT_passband_process_main :2442 sets 1) -> cl_awgn::apply_with_delay on the audio (awgn.cc:65-77; the frame starts
+ * ((preamble_nSymb + 2) * Nofdm + 50) * 4 samples into the capture window; sigma as :236-239, for the MFSK modes calibrated from the first
+ * frame's power as :266-279 and with mfsk_fixed_delay set as :293-296) -> receive_byte -> cl_error_rate::check over the payload bits.
+ * Differences from the reference's harness, none of which touches reference arithmetic: payloads and noise come from the library's Philox
+ * streams (the reference: libc rand()); the part of the window behind the frame holds noise (the reference: whatever the previous
+ * iteration left in the buffer); every frame is received with fresh link state (the reference carries receive_stats from frame to
+ * frame, and leaves the previous frame's bytes in hd_decoded_data_byte when no trial of a window reaches the decoder: here such a window
+ * counts as an all-zero payload; a window that reached the decoder counts with its hard decisions, CRC ok or not, as in the reference). windows_out ([npoints * frames_per_point][window] doubles) / sent_out ([...][payload_stride]): optional host copies of what was
+ * received / sent, for tests. Blocking. */
+int mgpu_passband_test_esn0(mgpu_ctx* ctx, const double* esn0_db, int npoints, long long frames_per_point, uint64_t seed, uint64_t frame0,
+                            double carrier_hz, double output_power_watt, mgpu_error_rate* out, double* windows_out, uint8_t* sent_out);
+
 #ifdef __cplusplus
 }
 #endif

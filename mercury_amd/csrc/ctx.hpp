@@ -49,6 +49,8 @@ DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
 extern "C" __global__ void mgpu_glibc_trig_probe_kernel(const double*, double*, double*, double*, int);
 using DecoderKernel = void (*)(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+extern "C" __global__ void mgpu_gen_payload_kernel(uint64_t, uint64_t, int, int, int, uint8_t*);
+extern "C" __global__ void mgpu_passband_channel_kernel(const double*, int, int, int, double, uint64_t, uint64_t, int, double*);
 extern "C" __global__ void mgpu_error_count_kernel(const uint8_t*, const uint8_t*, const MgpuStatsDev*, int, int, int, unsigned long long*);
 extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 #define DECL_MS(T) extern "C" __global__ void mgpu_ldpc_minsum_kernel_t##T(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);

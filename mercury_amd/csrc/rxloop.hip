@@ -20,6 +20,7 @@
 #include <thread>
 
 #include "ctx.hpp"
+#include "../../include/mercury_tx.h"
 
 namespace {
 
@@ -735,3 +736,78 @@ extern "C" int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int 
         if (failed != hipSuccess) throw std::runtime_error(std::string("upload of the capture windows: ") + hipGetErrorString(failed));
     });
 }
+
+// cl_telecom_system::passband_test_EsN0 (telecom_system.cc:231-330) per Es/N0 point, batched: random payloads -> transmit_byte
+// (SINGLE_MESSAGE) -> apply_with_delay (AWGN on the audio, the frame `delay` samples into the capture window) -> receive_byte ->
+// cl_error_rate::check over the payload bits. Everything stays on the device except the per-window results receive_byte returns.
+extern "C" int mgpu_passband_test_esn0(mgpu_ctx* c, const double* esn0_db, int npoints, long long frames_per_point, uint64_t seed, uint64_t frame0,
+                                       double carrier_hz, double output_power_watt, mgpu_error_rate* out, double* windows_out, uint8_t* sent_out) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(esn0_db && out && npoints > 0 && frames_per_point > 0 && output_power_watt > 0, "bad argument");
+        const auto& t = c->tab;
+        const bool mfsk = t.mfsk_M > 0;
+        const int total = mgpu_transmit_frame_samples(c);
+        const int window = t.Nofdm * mgpu_receive_buffer_nsymb(c) * kInterp;
+        const int delay = ((t.preamble + 2) * t.Nofdm + (t.Nfft == 1024 ? 100 : 50)) * kInterp;           // :242-249, :292
+        need(delay + total <= window, "the frame does not fit the capture window behind the test delay");
+        const int B = int(std::min<long long>(frames_per_point, std::min(c->max_batch, 1024)));            // 1024 windows = 0.76 GB of audio
+        const int stride = t.payload_stride, nbytes = t.payload_bytes;
+        DevBuf d_pl(size_t(B) * stride), d_audio(size_t(B) * total * 8), d_win(size_t(B) * window * 8);
+        std::vector<uint8_t> sent(size_t(B) * stride), got(size_t(B) * stride);
+        std::vector<mgpu_receive_stats> st(B);
+        std::vector<mgpu_link_state> ls(B);
+        const mgpu_transmit_config txc = {carrier_hz, 1.4142135623730951, output_power_watt, 7.0, 10.0, 0, MGPU_SINGLE_MESSAGE, 0};   // physical_config.cc defaults
+        const mgpu_receive_config rxc = {carrier_hz, 2, 1, 1, 0};
+        hipStream_t s = c->stream;
+        for (int p = 0; p < npoints; ++p) {
+            // sigma: :236-239 for OFDM; :266-279 calibrates it once per call from the first frame's power for MFSK
+            float sigma = mfsk ? 0.0f : 1.0f / float(std::sqrt(std::pow(10.0f, float(esn0_db[p]) / 10.0f)));
+            bool calibrated = !mfsk;
+            long long be = 0, fe = 0, ok = 0;
+            double iters = 0;
+            for (long long done = 0; done < frames_per_point; done += B) {
+                const int n = int(std::min<long long>(B, frames_per_point - done));
+                const uint64_t first = frame0 + uint64_t(p) * uint64_t(frames_per_point) + uint64_t(done);
+                hipLaunchKernelGGL(mgpu_gen_payload_kernel, dim3(n), dim3(256), 0, s, seed, first, n, nbytes, stride, d_pl.as<uint8_t>());
+                HIPCK(hipGetLastError());
+                if (mgpu_transmit_byte_batch_dev(c, d_pl.p, stride, nullptr, n, &txc, d_audio.p, s) != MGPU_OK) throw std::runtime_error(std::string(c->err));
+                if (!calibrated) {
+                    std::vector<double> a0(total);
+                    HIPCK(hipMemcpyAsync(a0.data(), d_audio.p, size_t(total) * 8, hipMemcpyDeviceToHost, s));
+                    HIPCK(hipStreamSynchronize(s));
+                    double psig = 0;
+                    for (int i = 0; i < total; ++i) psig += a0[i] * a0[i];
+                    psig /= total;
+                    const double bandwidth = 48000.0 * 50.0 / 256 / 4;
+                    sigma = float(std::sqrt(2.0 * psig * (48000.0 / 2.0) / (std::pow(10.0, double(float(esn0_db[p])) / 10.0) * bandwidth)));
+                    calibrated = true;
+                }
+                const double ampl = double(sigma / std::sqrt(2.0f));                                   // awgn.cc:68
+                hipLaunchKernelGGL(mgpu_passband_channel_kernel, dim3((window + 255) / 256, n), dim3(256), 0, s, d_audio.as<double>(), total, delay, window,
+                                   ampl, seed, first, n, d_win.as<double>());
+                HIPCK(hipGetLastError());
+                HIPCK(hipMemcpyAsync(sent.data(), d_pl.p, size_t(n) * stride, hipMemcpyDeviceToHost, s));
+                if (windows_out) HIPCK(hipMemcpyAsync(windows_out + (size_t(p) * frames_per_point + done) * window, d_win.p, size_t(n) * window * 8, hipMemcpyDeviceToHost, s));
+                HIPCK(hipStreamSynchronize(s));
+                if (sent_out) std::memcpy(sent_out + (size_t(p) * frames_per_point + done) * stride, sent.data(), size_t(n) * stride);
+                for (int w = 0; w < n; ++w) ls[w] = mgpu_link_state{-1, 0.0, 0, mfsk ? delay + 1 : 0};      // :293-296 mfsk_fixed_delay
+                receive_byte_impl(c, d_win.as<double>(), n, &rxc, ls.data(), got.data(), st.data());
+                for (int w = 0; w < n; ++w) {
+                    int e = 0;
+                    for (int b = 0; b < nbytes; ++b) e += __builtin_popcount(unsigned(sent[size_t(w) * stride + b] ^ got[size_t(w) * stride + b]));
+                    be += e; fe += e != 0; ok += st[w].message_decoded != 0;
+                    iters += st[w].iterations_done > 0 ? st[w].iterations_done : 0;
+                }
+            }
+            mgpu_error_rate& r = out[p];
+            r.esn0_db = esn0_db[p];
+            r.Frames_total = frames_per_point; r.Error_frames_total = fe;
+            r.Bits_total = frames_per_point * nbytes * 8; r.Error_bits_total = be;
+            r.BER = double(be) / double(r.Bits_total); r.FER = double(fe) / double(frames_per_point);
+            r.avg_iterations = iters / double(frames_per_point);
+            r.crc_ok_frames = ok;
+        }
+    });
+}
+

@@ -256,3 +256,45 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_ldpc_encode_kernel
         for (int c = tid; c < P; c += TX_THREADS) enc[K + c] = pbit[c];
     }
 }
+
+// ---- helpers of the passband self-simulation (cl_telecom_system::passband_test_EsN0, telecom_system.cc:231-330) -----------------
+// the generator's payload bytes of frames frame0 .. frame0+F-1 (the same Philox stream 0 the frame generator above draws them from)
+extern "C" __global__ __launch_bounds__(256) void mgpu_gen_payload_kernel(uint64_t seed, uint64_t frame0, int F, int nbytes, int stride,
+                                                                          uint8_t* __restrict__ out) {
+    const int f = blockIdx.x;
+    if (f >= F) return;
+    const uint64_t fr = frame0 + uint64_t(f);
+    const uint32_t flo = uint32_t(fr), fhi = uint32_t(fr >> 32);
+    for (int j = threadIdx.x; j < stride; j += blockDim.x) {
+        uint8_t v = 0;
+        if (j < nbytes) {
+            uint32_t w[4];
+            philox4x32(seed, uint32_t(j >> 4), 0u, flo, fhi, w);
+            v = uint8_t(w[(j >> 2) & 3] >> (8 * (j & 3)));
+        }
+        out[size_t(f) * stride + j] = v;
+    }
+}
+
+// cl_awgn::apply_with_delay (awgn.cc:65-77) on real audio, one capture window per frame: `delay` samples of randomly picked signal
+// samples + noise, the frame + noise, and — where the reference's buffer keeps whatever an earlier frame left there — noise alone up to
+// the end of the window. Noise = ampl * N(0,1) from Philox stream 3 (counter = sample index, frame).
+extern "C" __global__ __launch_bounds__(256) void mgpu_passband_channel_kernel(const double* __restrict__ audio, int total, int delay, int window,
+                                                                               double ampl, uint64_t seed, uint64_t frame0, int F,
+                                                                               double* __restrict__ out) {
+    const int f = blockIdx.y;
+    if (f >= F) return;
+    const uint64_t fr = frame0 + uint64_t(f);
+    const uint32_t flo = uint32_t(fr), fhi = uint32_t(fr >> 32);
+    const double* a = audio + size_t(f) * total;
+    double* o = out + size_t(f) * window;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < window; i += gridDim.x * blockDim.x) {
+        uint32_t w[4];
+        philox4x32(seed, uint32_t(i), 3u, flo, fhi, w);
+        double x = 0.0;
+        if (i < delay) x = a[w[2] % uint32_t(total)];
+        else if (i < delay + total) x = a[i - delay];
+        o[i] = x + ampl * gauss_bm(w[0], w[1]);
+    }
+}
+

@@ -298,3 +298,54 @@ def test_gpu_mfsk_fixed_delay_bypasses_time_sync_once(cfg):
         st2 = np.zeros(1, LINK_STATE_DTYPE); st2["fixed_delay_plus_one"] = 5
         RxPhy(8, max_batch=1).receive_byte(np.zeros((1, Oracle(8).buffer_samples())), CARRIER, state=st2)      # OFDM mode: refused
     rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,points", [(8, [30.0, 4.0]), (2, [20.0, -4.0]), (100, [10.0, -13.0, -20.0])])
+def test_gpu_passband_test_esn0_counts_match_the_oracle_window_for_window(cfg, points):
+    """mgpu_passband_test_esn0 = cl_telecom_system::passband_test_EsN0 (telecom_system.cc:231-330), the audio-path self-simulation,
+    on the device. The frames it transmitted are the oracle's transmit_byte of the payloads it drew (the noise-free part of the window
+    within float rounding of the channel's noise floor is not separable, so: the clean frame at +200 dB), and its error counters
+    are those cl_error_rate::check gives on the oracle's receive_byte of the very same windows."""
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    nf = 6
+    rx = RxPhy(cfg, max_batch=8)
+    res, wins, sent = rx.passband_test_esn0(points, nf, CARRIER, seed=11, frame0=5, want_windows=True)
+    nb = orc.payload_bytes
+    mfsk = cfg >= 100
+    delay = None
+    for p, pt in enumerate(points):
+        be = fe = ok = 0
+        for f in range(nf):
+            w = p * nf + f
+            if delay is None:                                   # the frame starts ((preamble_nSymb + 2) * Nofdm + 50) * 4 samples in
+                audio = orc.transmit_byte(sent[w][:nb], carrier=CARRIER)
+                delay = _find_delay(wins[w], audio)
+            state = oraclelib.LinkState(-1, 0.0, 0, delay + 1 if mfsk else 0)
+            ref = orc.receive_byte(wins[w], carrier=CARRIER, state=state)
+            e = int(np.unpackbits(ref["payload"] ^ sent[w][:nb]).sum())          # hard decisions count, decoded or not (zeros if no trial ran)
+            be += e; fe += e != 0; ok += int(ref["message_decoded"])
+        r = res[p]
+        assert r["Frames_total"] == nf and r["Bits_total"] == nf * nb * 8
+        assert (r["Error_bits_total"], r["Error_frames_total"], r["crc_ok_frames"]) == (be, fe, ok), (cfg, pt, r, be, fe, ok)
+    assert delay == ((orc.preamble_nsymb + 2) * orc.Nofdm + (100 if orc.Nfft == 1024 else 50)) * 4       # telecom_system.cc:242-249, :292
+    for w in range(len(points) * nf):                                                    # payloads: the generator's stream, frame = frame0 + w
+        assert np.array_equal(sent[w][:nb], orc.gen_payload(11, 5 + w).astype(np.uint8))
+    assert res[0]["Error_bits_total"] == 0 and res[0]["crc_ok_frames"] == nf            # the clean point decodes everything
+    assert res[-1]["Error_frames_total"] > 0                                            # the noisy point does not
+    # the transmitted audio is the oracle's transmit_byte of the drawn payload: at +200 dB the channel adds < 1e-9
+    res2, wins2, sent2 = rx.passband_test_esn0([200.0], 2, CARRIER, seed=11, frame0=5, want_windows=True)
+    assert np.array_equal(sent2[0], sent[0]) and not np.array_equal(sent2[0], sent2[1])   # same (seed, frame) -> same payload
+    for w in range(2):
+        audio = orc.transmit_byte(sent2[w][:nb], carrier=CARRIER)
+        got = wins2[w][delay: delay + audio.size]
+        assert np.max(np.abs(got - audio)) < 1e-6 * max(1.0, np.max(np.abs(audio))), (cfg, w)
+    rx.close()
+
+
+def _find_delay(window, audio):
+    """Offset of the frame in a noisy capture window: peak of the cross-correlation (FFT), test-side only."""
+    n = 1 << int(np.ceil(np.log2(window.size + audio.size)))
+    c = np.fft.irfft(np.fft.rfft(window, n) * np.conj(np.fft.rfft(audio, n)), n)
+    return int(np.argmax(c[: window.size - audio.size + 1]))
