@@ -103,6 +103,12 @@ void ctx_alloc(mgpu_ctx* c) {
     c->lds_tx = mgpu_txgen_lds_bytes(mfsk ? 0 : d.G);
     if (!mfsk) HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->fe_threads == 1024 ? mgpu_frontend_kernel_t1024 : mgpu_frontend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_fe)));
     HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_txgen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_tx)));
+    {
+        int geo[6];
+        mgpu_tsync_fine_geometry(geo);
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_tsync_metric_fine_kernel_r4), hipFuncAttributeMaxDynamicSharedMemorySize, geo[2]));
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_tsync_metric_fine_kernel_r8), hipFuncAttributeMaxDynamicSharedMemorySize, geo[5]));
+    }
     switch (c->cfg.decoder) {
         case MGPU_DEC_SPA:
             c->lds_dec = mgpu_spa_lds_bytes(d.S, d.N);
@@ -285,6 +291,17 @@ void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, con
     if (ngi_i % 64 || (nfft_i / 2) % 64) {    // the staged kernels walk the preamble in chunks of 8 / 64 pairs
         hipLaunchKernelGGL(mgpu_tsync_metric_generic_kernel, dim3((ncand_max + 63) / 64, n), dim3(64), 0, s, d_bb, stride, d_start, d_widx, d_ncand,
                            ncand_max, step, pre_nsymb, ngi_i, nfft_i, d_vals);
+    } else if (step == 1 && ngi_i == 64 * (ngi_i / 64) && (variant > 0 || (variant < 0 && n >= 32))) {
+        // fine search over many windows: R adjacent candidates per lane share every sample's products (sync.hip). variant 1: R = 4, 2: R = 8;
+        // -1 picks by the number of windows (ms per launch of 4352 candidates, dense / R = 4 / R = 8: 16 windows 0.18 / 0.18 / 0.29,
+        // 64: 0.40 / 0.33 / 0.31, 256: 1.24 / 0.81 / 0.84, 1024: 5.13 / 2.91 / 2.71). A few windows keep the dense kernel (one candidate
+        // per lane: four times the wavefronts, a quarter of the latency).
+        if (variant < 0) variant = n >= 512 ? 2 : 1;
+        int geo[6];
+        mgpu_tsync_fine_geometry(geo);                               // the kernels' LDS limits are raised per device in mgpu_create
+        const int g = variant == 2 ? 3 : 0;
+        hipLaunchKernelGGL(variant == 2 ? mgpu_tsync_metric_fine_kernel_r8 : mgpu_tsync_metric_fine_kernel_r4, dim3((ncand_max + geo[g] - 1) / geo[g], n),
+                           dim3(geo[g + 1]), size_t(geo[g + 2]), s, d_bb, stride, d_start, d_widx, d_ncand, ncand_max, pre_nsymb, ngi_i, nfft_i, d_vals);
     } else if (step > 4 && tsync_stream_launch(d_bb, stride, d_start, d_widx, d_ncand, ncand_max, n, step, pre_nsymb, ngi_i, nfft_i, d_vals, s, variant)) {
         // many windows: one wavefront streams each (piece of a) window through an LDS ring, see sync.hip
     } else {
@@ -698,7 +715,7 @@ int mgpu_debug_tsync_metric(mgpu_ctx* c, const double* bb, int W, int size, int 
     return guard(c, [&] {
         const auto& t = c->tab;
         const int interp = 4, sym = t.Nofdm * interp, L = t.preamble * sym;
-        need(bb && vals && W > 0 && size > L && step >= 1 && variant >= -1 && variant <= 1 && (!start == !sub_size), "bad argument");
+        need(bb && vals && W > 0 && size > L && step >= 1 && variant >= -1 && variant <= 2 && (!start == !sub_size), "bad argument");
         const int ncand = (size - L + step - 1) / step;
         std::vector<int> nc(W, ncand), st(W, 0), wi(W);
         for (int w = 0; w < W; ++w) {

@@ -38,6 +38,9 @@ extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, co
 extern "C" int mgpu_tsync_coarse_threads();
 extern "C" __global__ void mgpu_tsync_metric_stream_kernel(const double*, int, const int*, const int*, const int*, int, double*, int, int, int);
 extern "C" void mgpu_tsync_stream_geometry(int*);
+extern "C" __global__ void mgpu_tsync_metric_fine_kernel_r4(const double*, int, const int*, const int*, const int*, int, int, int, int, double*);
+extern "C" __global__ void mgpu_tsync_metric_fine_kernel_r8(const double*, int, const int*, const int*, const int*, int, int, int, int, double*);
+extern "C" int mgpu_tsync_fine_geometry(int*);
 extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double*);
 extern "C" __global__ void mgpu_span_energy_kernel(const double*, int, const int*, const int*, int, int, double*, int*);

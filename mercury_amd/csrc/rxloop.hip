@@ -689,7 +689,8 @@ extern "C" int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int 
         }
         const auto& t = c->tab;
         const size_t buf = size_t(t.Nofdm) * mgpu_receive_buffer_nsymb(c) * kInterp;
-        const int sub = W >= 1024 ? 512 : ((W + 1) / 2 + 63) / 64 * 64;
+        static const int sub_env = getenv("MERCURY_RB_SUB") ? atoi(getenv("MERCURY_RB_SUB")) : 0;
+        const int sub = sub_env >= 64 ? std::min(sub_env, W) : W >= 1024 ? 512 : ((W + 1) / 2 + 63) / 64 * 64;
         const int nsub = (W + sub - 1) / sub;
         if (c->rb_stage_cap < size_t(W) * buf * 8) {
             (void)hipFree(c->rb_stage);

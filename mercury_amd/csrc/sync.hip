@@ -424,6 +424,135 @@ extern "C" __global__ __launch_bounds__(64 * TS_DWAVES) void mgpu_tsync_metric_d
     vals[size_t(blockIdx.y) * ncand_max + cand] = cc;
 }
 
+// The fine search (step 1, ofdm.cc:1893-1941 called from telecom_system.cc:1014-1018 over (preamble + 4) symbols = 4352 candidates of
+// 2304 sample pairs): candidates c and c + 1 read the same samples one pair apart — the pair (x, y) candidate c uses at position m of
+// a segment is (win[a_off + c + m], win[b_off + c + m]) — so the six products a pair contributes (x.re*y.re, x.re*x.re, y.re*y.re and
+// the .im ones) depend on c + m only. A lane therefore owns R *adjacent* candidates and slides a window of R samples' products along
+// the segment: per step one new sample (two 16-byte LDS reads, six multiplications) feeds R candidates (6 additions each, every
+// accumulator in the reference's order). 12 -> 6 + 6/R fp64 operations and 2 -> 2/R LDS reads per candidate pair; the dense kernel
+// above was bound by its LDS reads (two ds_read_b128 per 12 operations: 64 LDS cycles per 48 issue cycles and compute unit).
+// LDS layout: sample i of the wave's span (relative to its first candidate) lies at [i % R][i / R], so the lanes of one read are
+// contiguous; the row length makes the coalesced staging writes (8 consecutive samples = 8 / R columns of every row) conflict-free.
+template <int R>
+struct TfGeom {
+    static constexpr int LOADS = R + 1;                                   // 64 R + 63 samples per chunk of 64 pairs
+    static constexpr int COLS = 64 + 64 / R + 1;
+    static constexpr int ROW = R == 4 ? 82 : 73;                          // >= COLS; = 2 (R = 4) / odd (R = 8) mod 16 columns of 16 bytes
+    static constexpr int WAVES = 1;                                       // nothing is shared between wavefronts: one per workgroup, so the 17 of a 4352-candidate search leave no slot idle
+    static_assert(R == 4 || R == 8, "row length chosen for 4 or 8 candidates per lane");
+    static_assert(ROW >= COLS, "row too short");
+};
+
+template <int R>
+__device__ __forceinline__ void tfine_run(const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
+                                          const int* __restrict__ ncand_w, int ncand_max, int pre_nsymb, int ngi_i, int nfft_i,
+                                          double* __restrict__ vals, c2* lds) {
+    using G = TfGeom<R>;
+    const int wsel = widx ? widx[blockIdx.y] : blockIdx.y;
+    const int wstart = start ? start[blockIdx.y] : 0;
+    const int ncand = ncand_w ? ncand_w[blockIdx.y] : ncand_max;
+    const int size = stride - wstart;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cand0 = (blockIdx.x * G::WAVES + wave) * 64 * R;
+    if (cand0 >= ncand) return;
+    const v2d* winv = reinterpret_cast<const v2d*>(bb) + size_t(wsel) * stride + wstart + cand0;
+    const int last = size - cand0 - 1;                                    // clamp instead of predicating: clamped samples feed discarded candidates only
+    c2* sa = lds + size_t(wave) * 2 * R * G::ROW;
+    c2* sb = sa + R * G::ROW;
+    const int wr = (lane % R) * G::ROW + lane / R;                        // staging: sample j*64 + lane -> row lane % R, column j*(64/R) + lane/R
+    const int nseg = 2 * pre_nsymb;
+    v2d pa[G::LOADS], pb[G::LOADS];
+    double cc[R], na[R], nb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { cc[r] = 0; na[r] = 0; nb[r] = 0; }
+    int q = 0, m0 = 0;
+    {
+        const TsSeg sg = ts_segment(0, ngi_i, nfft_i);
+#pragma unroll
+        for (int j = 0; j < G::LOADS; ++j) {
+            const int t = j * 64 + lane;
+            pa[j] = winv[min(sg.a_off + t, last)];
+            pb[j] = winv[min(sg.b_off + t, last)];
+        }
+    }
+    const int nchunks = pre_nsymb * (ngi_i + nfft_i / 2) / 64;
+    for (int it = 0; it < nchunks; ++it) {
+#pragma unroll
+        for (int j = 0; j < G::LOADS; ++j) {
+            sa[wr + j * (64 / R)] = {pa[j].x, pa[j].y};
+            sb[wr + j * (64 / R)] = {pb[j].x, pb[j].y};
+        }
+        int qn, mn;
+        ts_next_chunk(q, m0, 64, nseg, ngi_i, nfft_i, qn, mn);
+        {
+            const TsSeg sg = ts_segment(qn, ngi_i, nfft_i);
+#pragma unroll
+            for (int j = 0; j < G::LOADS; ++j) {
+                const int t = j * 64 + lane;
+                pa[j] = winv[min(sg.a_off + mn + t, last)];
+                pb[j] = winv[min(sg.b_off + mn + t, last)];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // products of the window's samples: slot k % R holds sample R*lane + k
+        double prr[R], pii[R], xrr[R], xii[R], yrr[R], yii[R];
+        auto rd = [&](int row, int col, c2& x, c2& y) { x = sa[row * G::ROW + lane + col]; y = sb[row * G::ROW + lane + col]; };
+        auto prod = [&](int slot, const c2& x, const c2& y) {
+            prr[slot] = x.re * y.re; xrr[slot] = x.re * x.re; yrr[slot] = y.re * y.re;
+            pii[slot] = x.im * y.im; xii[slot] = x.im * x.im; yii[slot] = y.im * y.im;
+        };
+        c2 nx, ny;                                                        // the sample one step ahead: its LDS read is in flight during the additions
+#pragma unroll
+        for (int k = 0; k < R - 1; ++k) { rd(k, 0, nx, ny); prod(k, nx, ny); }
+        rd(R - 1, 0, nx, ny);
+        for (int u = 0; u < 64 / R; ++u) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                // pair m = R u + t: the new sample is k = m + R - 1 (slot (t + R - 1) % R); the one after it lies at row t, column lane + u + 1
+                // (the last step of a chunk reads one column past the span: inside the wave's rows, never used)
+                prod((t + R - 1) % R, nx, ny);
+                rd(t, u + 1, nx, ny);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int sl = (t + r) % R;
+                    cc[r] += prr[sl]; na[r] += xrr[sl]; nb[r] += yrr[sl];
+                    cc[r] += pii[sl]; na[r] += xii[sl]; nb[r] += yii[sl];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        q = qn; m0 = mn;
+    }
+    double* out = vals + size_t(blockIdx.y) * ncand_max;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int cand = cand0 + R * lane + r;
+        if (cand < ncand) out[cand] = (na[r] < 0.001 || nb[r] < 0.001) ? 0.0 : cc[r] / sqrt(na[r] * nb[r]);
+    }
+}
+
+extern "C" int mgpu_tsync_fine_geometry(int* out) {   // candidates per workgroup, threads, LDS bytes for R = 4 and R = 8
+    out[0] = 64 * 4 * TfGeom<4>::WAVES; out[1] = 64 * TfGeom<4>::WAVES; out[2] = TfGeom<4>::WAVES * 2 * 4 * TfGeom<4>::ROW * 16;
+    out[3] = 64 * 8 * TfGeom<8>::WAVES; out[4] = 64 * TfGeom<8>::WAVES; out[5] = TfGeom<8>::WAVES * 2 * 8 * TfGeom<8>::ROW * 16;
+    return 0;
+}
+
+extern "C" __global__ __launch_bounds__(64 * TfGeom<4>::WAVES) void mgpu_tsync_metric_fine_kernel_r4(
+    const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
+    const int* __restrict__ ncand_w, int ncand_max, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    extern __shared__ __attribute__((aligned(16))) char tf_lds[];
+    tfine_run<4>(bb, stride, start, widx, ncand_w, ncand_max, pre_nsymb, ngi_i, nfft_i, vals, reinterpret_cast<c2*>(tf_lds));
+}
+
+extern "C" __global__ __launch_bounds__(64 * TfGeom<8>::WAVES) void mgpu_tsync_metric_fine_kernel_r8(
+    const double* __restrict__ bb, int stride, const int* __restrict__ start, const int* __restrict__ widx,
+    const int* __restrict__ ncand_w, int ncand_max, int pre_nsymb, int ngi_i, int nfft_i, double* __restrict__ vals) {
+    extern __shared__ __attribute__((aligned(16))) char tf_lds[];
+    tfine_run<8>(bb, stride, start, widx, ncand_w, ncand_max, pre_nsymb, ngi_i, nfft_i, vals, reinterpret_cast<c2*>(tf_lds));
+}
+
 // Moose: pre_half preamble symbols (up to 4: preamble_nSymb / 2 for preambles of up to 8 symbols), each as two 256-point FFTs of a
 // half symbol repeated twice; the four wavefronts take two symbols per round.
 extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(

@@ -283,6 +283,38 @@ def test_gpu_detect_ack_pattern_from_passband_matches_oracle_chain():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [8, 16])
+def test_gpu_fine_search_shared_products_equal_dense_kernel_on_every_candidate(cfg):
+    """The many-window fine search (step 1: a lane owns 4 or 8 adjacent candidates and shares each sample's products between them, sync.hip)
+    against the dense kernel that the oracle comparisons pin: every candidate's metric bit-identical — the search window receive_byte
+    uses ((preamble + 4) symbols), windows whose candidate count is not a multiple of the lanes' share, one candidate, silent stretches,
+    sub-windows with their own start and length."""
+    from mercury_amd import RxPhy
+    rx = RxPhy(cfg, max_batch=1)
+    rng = np.random.default_rng(SEED + 50 + cfg)
+    sym = rx.Nofdm * 4
+    L = rx.preamble_nsymb * sym
+    for W, size in [(3, L + 4 * sym), (40, L + 4 * sym), (2, L + 1), (2, L + 1023), (5, L + 1024), (5, L + 1025), (2, L + 2055), (300, L + 700)]:
+        z = (rng.standard_normal((W, size)) + 1j * rng.standard_normal((W, size))) * np.exp(rng.uniform(-6, 2, (W, 1)))
+        z[0, : size // 3] = 0.0                                        # the "no signal" branch of the metric (sums below 0.001)
+        a = rx.debug_tsync_metric(z, 1, variant=0)
+        for v in (1, 2, -1):
+            b = rx.debug_tsync_metric(z, 1, variant=v)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (cfg, W, size, v)
+    W, size = 40, L + 4 * sym + 300
+    z = rng.standard_normal((W, size)) + 1j * rng.standard_normal((W, size))
+    start = rng.integers(0, 300, W).astype(np.int32)
+    sub = np.array([int(rng.integers(0, size - start[w] + 1)) for w in range(W)], np.int32)
+    sub[::7] = L                                                    # no candidate at all
+    sub[1::7] = L + 1                                               # exactly one
+    a = rx.debug_tsync_metric(z, 1, variant=0, start=start, sub_size=sub)
+    for v in (1, 2):
+        b = rx.debug_tsync_metric(z, 1, variant=v, start=start, sub_size=sub)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), v
+    rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 16])
 def test_gpu_streaming_coarse_metric_equals_staged_kernel_on_every_candidate(cfg):
     """The many-window coarse search (one wavefront streams a window through an LDS ring, sync.hip) against the staged kernel that the
     oracle comparisons above pin: every candidate's metric bit-identical, for whole capture windows, short windows (fewer candidates than

@@ -42,6 +42,8 @@ if [ "$1" = "sweep" ]; then
   python tools/bench_host_path.py 8 4096 -15 > "$OUT/r02_bench_host_path_cfg8.json"
   python tools/bench_tx.py 8 4096 > "$OUT/r02_bench_tx_cfg8.json"
   python tools/bench_tsync_variants.py > "$OUT/r02_bench_tsync_variants.json" 2>/dev/null
+  python tools/bench_tsync_fine.py > "$OUT/r02_bench_tsync_fine.json" 2>/dev/null
+  tools/pmc_any.sh tsync_metric_fine "$OUT/r02_pmc_tsync_fine.json" -- python tools/bench_tsync_fine.py 1024 > /dev/null 2>&1 || true
   tools/pmc_any.sh tsync_metric_stream "$OUT/r02_pmc_tsync_stream.json" -- python tools/bench_tsync_variants.py 1024 > /dev/null 2>&1 || true
   tools/pmc_any.sh mfsk_frontend "$OUT/r02_pmc_mfsk_frontend.json" -- python bench.py --cfg 100 --decoder spa_fast --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frames 2048 > /dev/null 2>&1 || true
   python bench.py --cfg 100 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/r02_bench_spa_fast_cfg100.json" 2>/dev/null
