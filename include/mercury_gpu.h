@@ -242,6 +242,11 @@ int mgpu_enable_timing(mgpu_ctx* ctx, int on);
 int mgpu_kernel_ms_avg(mgpu_ctx* ctx, float ms[2], int* n_launches);
 int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
 
+/* Test hook: the span energies receive_byte's gates and recoveries ask for (telecom_system.cc:758-766, :826-834, :1044-1066: sum of
+ * re^2 + im^2 over len samples from off[j] in window wv[j], clipped at the window end, added in sample order) on W host windows of `size`
+ * complex samples. variant 0: one wavefront per span; 1: one lane per span (what receive_byte launches from 4096 spans up). */
+int mgpu_debug_span_energy(mgpu_ctx* ctx, const double* bb, int W, int size, const int* wv, const int* off, int n, int len, int variant, double* sum,
+                           int* cnt);
 /* test hook: evaluates the decoder's device tanh/atanh (csrc/spa_math.h) on n host doubles so the tests
  * can compare them bit for bit with the libm the reference calls (ldpc_decoder_SPA.cc:145,156).
  * atanh_out[i] is 0 where |in[i]| >= 1. */

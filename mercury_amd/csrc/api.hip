@@ -742,6 +742,31 @@ int mgpu_debug_tsync_metric(mgpu_ctx* c, const double* bb, int W, int size, int 
     });
 }
 
+int mgpu_debug_span_energy(mgpu_ctx* c, const double* bb, int W, int size, const int* wv, const int* off, int n, int len, int variant, double* sum, int* cnt) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(bb && wv && off && sum && cnt && W > 0 && size > 0 && n > 0 && len > 0 && len <= 1088 && (variant == 0 || variant == 1), "bad argument");
+        for (int j = 0; j < n; ++j) need(wv[j] >= 0 && wv[j] < W && off[j] >= 0, "span outside the windows");
+        DevBuf d_in(size_t(W) * size * 16), d_wv(size_t(n) * 4), d_off(size_t(n) * 4), d_sum(size_t(n) * 8), d_cnt(size_t(n) * 4);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_wv.p, wv, size_t(n) * 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(d_off.p, off, size_t(n) * 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipEventRecord(c->sync_ev[0], s));
+        if (variant)
+            hipLaunchKernelGGL(mgpu_span_energy_many_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_in.as<double>(), size, d_wv.as<int>(), d_off.as<int>(), n, len,
+                               d_sum.as<double>(), d_cnt.as<int>());
+        else
+            hipLaunchKernelGGL(mgpu_span_energy_kernel, dim3((n + 3) / 4), dim3(256), 0, s, d_in.as<double>(), size, d_wv.as<int>(), d_off.as<int>(), n, len,
+                               d_sum.as<double>(), d_cnt.as<int>());
+        HIPCK(hipGetLastError());
+        HIPCK(hipEventRecord(c->sync_ev[1], s));
+        HIPCK(hipMemcpyAsync(sum, d_sum.p, size_t(n) * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipMemcpyAsync(cnt, d_cnt.p, size_t(n) * 4, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
 int mgpu_freq_sync(mgpu_ctx* c, const double* bb, int W, int stride, double* freq_offset_hz) {
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {

@@ -44,6 +44,7 @@ extern "C" int mgpu_tsync_fine_geometry(int*);
 extern "C" __global__ void mgpu_tsync_metric_generic_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_fsync_kernel(const double*, int, int, const double*, double*);
 extern "C" __global__ void mgpu_span_energy_kernel(const double*, int, const int*, const int*, int, int, double*, int*);
+extern "C" __global__ void mgpu_span_energy_many_kernel(const double*, int, const int*, const int*, int, int, double*, int*);
 extern "C" __global__ void mgpu_window_energy_kernel(const double*, int, int, double*);
 extern "C" __global__ void mgpu_select_peak_kernel(const double*, const int*, int, int, const int*, const int*, int, int, int*, double*);
 extern "C" __global__ void mgpu_decimate_kernel(const double*, int, const int*, const int*, const int*, int, int, double*);

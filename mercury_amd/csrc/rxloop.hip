@@ -38,6 +38,7 @@ struct PhaseTimer {
 };
 
 constexpr int kInterp = 4, kCoarseStep = 100;
+constexpr int kManySpans = 4096;          // span energies: the lane-per-span kernel from this many spans per launch
 constexpr double kEnergyGate = 0.001, kMetricGate = 0.5, kMeanHGate = 0.3, kFreqIgnore = 0.1;   // telecom_system.cc:843, :854, :1269; physical_config.cc:60
 
 struct Win {                       // one capture window's walk through receive_byte
@@ -53,19 +54,35 @@ struct Workspace {
     DevBuf d_pass, d_bbi, d_frames, d_carrier, d_ia, d_ib, d_ic, d_vals, d_sum, d_cnt, d_freq, d_meanh, d_stats_k, d_payload_k;
     size_t vals_per_window;
     double* h_vals = nullptr;        // page-locked landing area for the synchroniser metrics (tens of MB per call)
+    // page-locked arena for the small index / result arrays of the control rounds: a copy from or to pageable memory holds the calling
+    // thread for ~20-40 us each while the runtime stages it; from here the copies are queued back to back and the host moves on.
+    // Bump-allocated; reset whenever the stream has been synchronised (everything queued before has completed by then).
+    char* h_pin = nullptr;
+    size_t pin_cap = 0, pin_off = 0;
+    struct PendingDown { void* dst; const void* src; size_t bytes; };
+    std::vector<PendingDown> pending;
+    void* pin_take(size_t bytes) {
+        const size_t need = (bytes + 63) & ~size_t(63);
+        if (pin_off + need > pin_cap) return nullptr;
+        void* p = h_pin + pin_off;
+        pin_off += need;
+        return p;
+    }
     hipStream_t side = nullptr;      // the signal-strength sum (a 92 k-term dependent chain per window) runs beside the synchroniser
     hipStream_t copy = nullptr;      // brings the capture windows in, slice by slice, under the first kernels
     hipStream_t search = nullptr;    // the coarse search of a group of slices, beside the mixer / filter of the next ones
-    std::vector<hipEvent_t> group_ev;
+    std::vector<hipEvent_t> group_ev, we_ev;
     hipEvent_t ev_search = nullptr;
     std::vector<hipEvent_t> slice_ev;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     ~Workspace() {
         if (h_vals) (void)hipHostFree(h_vals);
+        if (h_pin) (void)hipHostFree(h_pin);
         if (side) (void)hipStreamDestroy(side);
         if (copy) (void)hipStreamDestroy(copy);
         if (search) (void)hipStreamDestroy(search);
         for (hipEvent_t e : group_ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : we_ev) (void)hipEventDestroy(e);
         if (ev_search) (void)hipEventDestroy(ev_search);
         for (hipEvent_t e : slice_ev) (void)hipEventDestroy(e);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
@@ -77,6 +94,8 @@ struct Workspace {
           d_sum(size_t(W) * 128 * 8), d_cnt(size_t(W) * 128 * 4), d_freq(size_t(W) * 16), d_meanh(size_t(W) * 8),
           d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * payload_stride), vals_per_window(vals_per_window) {
         HIPCK(hipHostMalloc(&h_vals, size_t(W) * vals_per_window * 8, hipHostMallocDefault));
+        pin_cap = std::max<size_t>(size_t(1) << 20, size_t(W) * 128 * 8 * 6);             // a few rounds of the largest index / result arrays
+        HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h_pin), pin_cap, hipHostMallocDefault));
         HIPCK(hipStreamCreate(&side));
         HIPCK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
@@ -121,8 +140,26 @@ struct Loop {
 
     bool in_bounds(int p) const { return p > lower && p < upper; }
 
-    void up(DevBuf& d, const void* h, size_t bytes) { HIPCK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, s)); }
-    void down(void* h, DevBuf& d, size_t bytes) { HIPCK(hipMemcpyAsync(h, d.p, bytes, hipMemcpyDeviceToHost, s)); HIPCK(hipStreamSynchronize(s)); }
+    void up(DevBuf& d, const void* h, size_t bytes) {
+        if (void* p = ws.pin_take(bytes)) { std::memcpy(p, h, bytes); h = p; }
+        HIPCK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, s));
+    }
+    // device -> host without waiting: the bytes are in h after the next down() / settle()
+    void down_async(void* h, DevBuf& d, size_t bytes) {
+        if (void* p = ws.pin_take(bytes)) {
+            HIPCK(hipMemcpyAsync(p, d.p, bytes, hipMemcpyDeviceToHost, s));
+            ws.pending.push_back({h, p, bytes});
+        } else {
+            HIPCK(hipMemcpyAsync(h, d.p, bytes, hipMemcpyDeviceToHost, s));
+        }
+    }
+    void settle() {
+        HIPCK(hipStreamSynchronize(s));
+        for (const auto& q : ws.pending) std::memcpy(q.dst, q.src, q.bytes);
+        ws.pending.clear();
+        ws.pin_off = 0;
+    }
+    void down(void* h, DevBuf& d, size_t bytes) { down_async(h, d, bytes); settle(); }
 
     // passband_to_baseband of the whole buffer for the listed windows, overwriting their interpolated baseband
     void p2b(const std::vector<int>& wins, int filter) {
@@ -196,7 +233,7 @@ struct Loop {
             hipLaunchKernelGGL(mgpu_select_peak_kernel, dim3(n), dim3(64), 0, s, d_vals.as<double>(), d_ic.as<int>(), ncmax, step,
                                d_ia.as<int>(), d_ib.as<int>(), ntrials, n, d_cnt.as<int>(), d_sum.as<double>());
             HIPCK(hipGetLastError());
-            HIPCK(hipMemcpyAsync(delay.data(), d_cnt.p, size_t(n) * 4, hipMemcpyDeviceToHost, s));
+            down_async(delay.data(), d_cnt, size_t(n) * 4);
             down(corr.data(), d_sum, size_t(n) * 8);
         } else {         // a few windows: one lane per window would crawl through its candidates; the host is quicker
             const double* vals = ws.h_vals;
@@ -215,10 +252,15 @@ struct Loop {
             const int m = std::min(n - base, W * 128);
             up(d_ia, wv.data() + base, size_t(m) * 4);
             up(d_ib, off.data() + base, size_t(m) * 4);
-            hipLaunchKernelGGL(mgpu_span_energy_kernel, dim3((m + 3) / 4), dim3(256), 0, s, d_bbi.as<double>(), buf, d_ia.as<int>(), d_ib.as<int>(), m,
-                               len, d_sum.as<double>(), d_cnt.as<int>());
+            // a few spans: a wavefront each (short latency); thousands: a lane each (sync.hip)
+            if (m >= kManySpans)
+                hipLaunchKernelGGL(mgpu_span_energy_many_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d_bbi.as<double>(), buf, d_ia.as<int>(), d_ib.as<int>(), m,
+                                   len, d_sum.as<double>(), d_cnt.as<int>());
+            else
+                hipLaunchKernelGGL(mgpu_span_energy_kernel, dim3((m + 3) / 4), dim3(256), 0, s, d_bbi.as<double>(), buf, d_ia.as<int>(), d_ib.as<int>(), m,
+                                   len, d_sum.as<double>(), d_cnt.as<int>());
             HIPCK(hipGetLastError());
-            HIPCK(hipMemcpyAsync(sum.data() + base, d_sum.p, size_t(m) * 8, hipMemcpyDeviceToHost, s));
+            down_async(sum.data() + base, d_sum, size_t(m) * 8);
             down(cnt.data() + base, d_cnt, size_t(m) * 4);
         }
     }
@@ -304,7 +346,7 @@ int mgpu_measure_signal_only(mgpu_ctx* c, const double* passband, int W, double 
         HIPCK(hipMemcpyAsync(lp.d_pass.p, passband, size_t(W) * lp.buf * 8, hipMemcpyDefault, s));
         lp.pass = lp.d_pass.as<double>();
         lp.p2b(all, 0);
-        hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_freq.as<double>());
+        hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(64), 0, s, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_freq.as<double>());
         HIPCK(hipGetLastError());
         std::vector<double> sum(W);
         lp.down(sum.data(), lp.d_freq, size_t(W) * 8);
@@ -372,6 +414,11 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             lp.ws.group_ev.push_back(e);
         }
+        while (int(lp.ws.we_ev.size()) < nsl) {
+            hipEvent_t e = nullptr;
+            HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            lp.ws.we_ev.push_back(e);
+        }
         for (int k = 0; k < nsl; ++k) {
             const int off = k * kSlice, n = std::min(kSlice, W - off);
             if (!on_device) {
@@ -384,6 +431,17 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
                                lp.d_ia.as<int>() + off, mix_cs, nullptr, 0);
             HIPCK(hipGetLastError());
             const bool group_end = (k + 1) % group == 0 || k == nsl - 1;
+            if (group_end) {
+                // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order, a 92 k-term dependent
+                // chain per window. One wavefront and 4 KB of LDS per window on a side stream, launched ahead of the group's coarse search
+                // so that the two share the compute units (behind the search it added its full latency to the call).
+                const int g0 = (k / group) * group * kSlice, gn = off + n - g0;
+                HIPCK(hipEventRecord(lp.ws.we_ev[k], s));
+                HIPCK(hipStreamWaitEvent(lp.ws.side, lp.ws.we_ev[k], 0));
+                hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(gn), dim3(64), 0, lp.ws.side, lp.d_bbi.as<double>() + size_t(g0) * lp.buf * 2, lp.buf, lp.buf,
+                                   lp.d_freq.as<double>() + g0);
+                HIPCK(hipGetLastError());
+            }
             if (!lp.mfsk && ncand0 > 0 && group_end) {
                 const int g0 = (k / group) * group * kSlice, gn = off + n - g0;
                 HIPCK(hipEventRecord(lp.ws.group_ev[k], s));
@@ -397,15 +455,7 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             HIPCK(hipStreamWaitEvent(s, lp.ws.ev_search, 0));
         }
         pt.mark(s, "upload + p2b + coarse metric");
-        {   // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order. The sum is a long
-            // dependent chain, so it runs on a side stream while the synchroniser works on the same (read-only) baseband; the
-            // main stream waits for it before the trial loop overwrites that baseband.
-            HIPCK(hipEventRecord(lp.ws.ev_ready, s));
-            HIPCK(hipStreamWaitEvent(lp.ws.side, lp.ws.ev_ready, 0));
-            hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(W), dim3(256), 0, lp.ws.side, lp.d_bbi.as<double>(), lp.buf, lp.buf, lp.d_freq.as<double>());
-            HIPCK(hipGetLastError());
-            HIPCK(hipEventRecord(lp.ws.ev_done, lp.ws.side));
-        }
+        HIPCK(hipEventRecord(lp.ws.ev_done, lp.ws.side));            // signal strength: the main stream waits for it before the trial loop overwrites the baseband
         pt.mark(s, "signal strength");
         std::vector<char> live(W, 1);                             // still on the way to the trial loop
         std::vector<char> fixed_delay(W, 0);
@@ -626,8 +676,8 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             launch_decoder(c, c->d_llr, n, nullptr, nullptr, d_payload_k.as<uint8_t>(), d_stats_k.as<MgpuStatsDev>(), c->d_variance, c->d_snrvar, s);
             launch_zf_snr(c, n, d_payload_k.as<uint8_t>(), d_stats_k.as<MgpuStatsDev>(), s);
             std::vector<double> mh(n, 1.0);
-            if (!lp.mfsk) HIPCK(hipMemcpyAsync(mh.data(), lp.d_meanh.p, size_t(n) * 8, hipMemcpyDeviceToHost, s));
-            HIPCK(hipMemcpyAsync(st_k.data(), d_stats_k.p, size_t(n) * sizeof(MgpuStatsDev), hipMemcpyDeviceToHost, s));
+            if (!lp.mfsk) lp.down_async(mh.data(), lp.d_meanh, size_t(n) * 8);
+            lp.down_async(st_k.data(), d_stats_k, size_t(n) * sizeof(MgpuStatsDev));
             lp.down(pay_k.data(), d_payload_k, size_t(n) * t.payload_stride);
             pt.mark(s, "trial: RX path + results");
             for (int k = 0; k < n; ++k) {

@@ -637,6 +637,60 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_span_energy_kernel(
     }
 }
 
+// The same sums for many spans at once (the forward scans of receive_byte's recoveries ask for up to ~80 per window): one *lane* per span.
+// A wavefront owns 64 spans; per chunk of 16 samples it fetches 64 rows of 256 contiguous bytes (16 lanes per row, 4 rows per load), forms
+// the terms and parks them in a wave-private LDS tile (row stride 17: the per-lane reads are conflict-free), then every lane adds its own
+// row's 16 terms in sample order. 64 dependent chains per wavefront instead of one: the wave-per-span kernel above spends its time in a
+// single lane's 1088 additions.
+#define SEM_CH 16
+extern "C" __global__ __launch_bounds__(256) void mgpu_span_energy_many_kernel(
+    const double* __restrict__ bb, int stride, const int* __restrict__ wv, const int* __restrict__ off, int n, int len,
+    double* __restrict__ sum, int* __restrict__ cnt) {
+    __shared__ double tile[4][64][SEM_CH + 1];
+    __shared__ unsigned base_s[4][64];
+    __shared__ int m_s[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = (blockIdx.x * 4 + wave) * 64;
+    if (j0 >= n) return;
+    const int j = min(j0 + lane, n - 1);                          // lanes past the last span repeat it (results discarded)
+    const int o = off[j];
+    int m = stride - o;                                           // terms that exist: i < len && o + i < stride
+    m = m < 0 ? 0 : (m > len ? len : m);
+    base_s[wave][lane] = unsigned(wv[j]) * unsigned(stride) + unsigned(o);        // complex-sample index of the span's first term
+    m_s[wave][lane] = m;
+    __builtin_amdgcn_wave_barrier();
+    const c2* x = reinterpret_cast<const c2*>(bb);
+    const int rsub = lane >> 4, col = lane & 15;                  // staging role: row 4 r + rsub, sample col of the chunk
+    unsigned rbase[16];
+    int rm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rbase[r] = base_s[wave][4 * r + rsub] + unsigned(col); rm[r] = m_s[wave][4 * r + rsub] - col; }
+    double (*t)[SEM_CH + 1] = tile[wave];
+    int mmax = m;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mmax = max(mmax, __shfl_xor(mmax, d));
+    double e = 0.0;
+    c2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = rm[r] > 0 ? x[rbase[r]] : c2{0.0, 0.0};
+    for (int i0 = 0; i0 < mmax; i0 += SEM_CH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[4 * r + rsub][col] = v[r].re * v[r].re + v[r].im * v[r].im;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = rm[r] > i0 + SEM_CH ? x[rbase[r] + unsigned(i0 + SEM_CH)] : c2{0.0, 0.0};      // next chunk in flight
+        const int left = m - i0;
+        if (left >= SEM_CH) {
+#pragma unroll
+            for (int q = 0; q < SEM_CH; ++q) e += t[lane][q];
+        } else {
+            for (int q = 0; q < left; ++q) e += t[lane][q];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (j0 + lane < n) { sum[j0 + lane] = e; cnt[j0 + lane] = m; }
+}
+
 // rational_resampler(..., DECIMATION) (ofdm.cc:2267-2278) from a per-window offset:
 // out[slot[k] or k][i] = bb[widx[k]][delay[k] + i*rate]
 extern "C" __global__ __launch_bounds__(256) void mgpu_decimate_kernel(
@@ -650,28 +704,52 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_decimate_kernel(
 
 // cl_ofdm::measure_signal_stregth (ofdm.cc:1523-1539): sum over a whole window of re^2 + im^2, added in sample order.
 // One workgroup per window: the terms of a chunk are formed in parallel from coalesced loads, one lane adds them.
-#define WE_CHUNK 4096
-extern "C" __global__ __launch_bounds__(256) void mgpu_window_energy_kernel(
+#define WE_CHUNK 512
+#define WE_LOADS (WE_CHUNK / 64)
+extern "C" __global__ __launch_bounds__(64) void mgpu_window_energy_kernel(
     const double* __restrict__ bb, int stride, int n, double* __restrict__ out) {
-    __shared__ double term[WE_CHUNK];
+    // One wavefront and 4 KB of LDS per window, so that the 92 k-term chain can sit beside whatever else fills the compute units
+    // (receive_byte launches it slice by slice under the mixer / filter and the coarse search). The next chunk's samples are in flight
+    // while lane 0 adds the current chunk's terms.
+    __shared__ double term[WE_CHUNK + 8];
     const c2* x = reinterpret_cast<const c2*>(bb) + size_t(blockIdx.x) * stride;
+    const int lane = threadIdx.x;
     double acc = 0.0;
+    c2 v[WE_LOADS];
+#pragma unroll
+    for (int r = 0; r < WE_LOADS; ++r) { const int i = r * 64 + lane; v[r] = i < n ? x[i] : c2{0.0, 0.0}; }
     for (int base = 0; base < n; base += WE_CHUNK) {
         const int m = min(WE_CHUNK, n - base);
-        for (int i = threadIdx.x; i < m; i += 256) { const c2 v = x[base + i]; term[i] = v.re * v.re + v.im * v.im; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
+#pragma unroll
+        for (int r = 0; r < WE_LOADS; ++r) term[r * 64 + lane] = v[r].re * v[r].re + v[r].im * v[r].im;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < WE_LOADS; ++r) { const int i = base + WE_CHUNK + r * 64 + lane; v[r] = i < n ? x[i] : c2{0.0, 0.0}; }
+        if (lane == 0) {
+            // eight terms are read while the eight before them are added: the chain is the additions alone
             int p = 0;
-            for (; p + 8 <= m; p += 8) {
-                const double a0 = term[p], a1 = term[p + 1], a2 = term[p + 2], a3 = term[p + 3];
-                const double a4 = term[p + 4], a5 = term[p + 5], a6 = term[p + 6], a7 = term[p + 7];
-                acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+            double a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = term[q];
+            for (; p + 16 <= m; p += 16) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) b[q] = term[p + 8 + q];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += a[q];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] = term[p + 16 + q];       // the last read of a chunk runs 8 past it: inside the padded array, never added
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += b[q];
+                __builtin_amdgcn_sched_barrier(0);
             }
             for (; p < m; ++p) acc += term[p];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+    if (lane == 0) out[blockIdx.x] = acc;
 }
 
 // The reference's peak selection (ofdm.cc:1943-1964) on the candidate metrics where they lie in HBM, one wavefront per window:

@@ -282,6 +282,36 @@ def test_gpu_detect_ack_pattern_from_passband_matches_oracle_chain():
 
 
 @pytest.mark.gpu
+def test_gpu_span_energies_lane_per_span_equals_wave_per_span_and_the_sequential_sum():
+    """The span energies of receive_byte's gates / recoveries (telecom_system.cc:758-766, :826-834, :1044-1066): both kernels (one
+    wavefront per span; one lane per span, used from 4096 spans per launch) against the sequential sum in sample order — spans anywhere
+    in a window, clipped at its end, starting at or past it (no terms), short and full lengths, a span count that fills no wavefront."""
+    from mercury_amd import RxPhy
+    rx = RxPhy(8, max_batch=1)
+    rng = np.random.default_rng(SEED + 77)
+    W, size = 7, 5000
+    z = (rng.standard_normal((W, size)) + 1j * rng.standard_normal((W, size))) * np.exp(rng.uniform(-8, 3, (W, 1)))
+    for n, length in ((1, 1088), (63, 1088), (64, 17), (700, 1088), (333, 640), (130, 1)):
+        wv = rng.integers(0, W, n).astype(np.int32)
+        off = rng.integers(0, size - 1088, n).astype(np.int32)
+        off[::5] = size - rng.integers(0, 1200, off[::5].size)          # clipped at the window end
+        off[1::11] = size + rng.integers(0, 5, off[1::11].size)          # at / past the end: no terms
+        ref_s = np.zeros(n)
+        ref_c = np.zeros(n, np.int32)
+        for j in range(n):
+            m = int(np.clip(size - off[j], 0, length))
+            x = z[wv[j], off[j]: off[j] + m]
+            terms = x.real * x.real + x.imag * x.imag
+            ref_s[j] = np.cumsum(terms)[-1] if m else 0.0               # cumsum adds in order
+            ref_c[j] = m
+        for variant in (0, 1):
+            s_, c_ = rx.debug_span_energy(z, wv, off, length, variant)
+            assert np.array_equal(c_, ref_c), (n, length, variant)
+            assert np.array_equal(s_.view(np.uint64), ref_s.view(np.uint64)), (n, length, variant)
+    rx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [8, 16])
 def test_gpu_fine_search_shared_products_equal_dense_kernel_on_every_candidate(cfg):
     """The many-window fine search (step 1: a lane owns 4 or 8 adjacent candidates and shares each sample's products between them, sync.hip)

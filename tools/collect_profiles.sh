@@ -39,6 +39,7 @@ if [ "$1" = "sweep" ]; then
   python tools/sweep_modes.py > "$OUT/r02_mode_sweep.json" 2> "$OUT/r02_mode_sweep.txt"
   python tools/bench_sync.py > "$OUT/r02_bench_sync_blocks.json"
   python tests/tools/bench_receive_byte.py 8 1024 > "$OUT/r02_bench_receive_byte_cfg8.json"
+  tools/timeline_receive_byte.sh 8 1024 > "$OUT/r02_receive_byte_timeline.txt" 2>/dev/null || true
   python tools/bench_host_path.py 8 4096 -15 > "$OUT/r02_bench_host_path_cfg8.json"
   python tools/bench_tx.py 8 4096 > "$OUT/r02_bench_tx_cfg8.json"
   python tools/bench_tsync_variants.py > "$OUT/r02_bench_tsync_variants.json" 2>/dev/null
