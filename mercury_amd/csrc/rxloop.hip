@@ -726,8 +726,9 @@ extern "C" int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int 
         // Windows in host memory: bringing 1024 mode-8 windows over PCIe takes 13.5 ms and the synchroniser + decoder another 17 ms.
         // The windows are independent, so the call is cut into sub-batches: a helper thread uploads them one after another into a
         // staging buffer (a copy from pageable memory holds its calling thread), this thread runs the whole receive_byte on each
-        // sub-batch as soon as it has landed. Sub-batches of 512 windows measured best (26.6 -> 23.9 ms per 1024 windows in the steady state;
-        // 256: +1.3 ms, 128: +6 ms — the host-side rounds of the control flow cost the same for any size). MERCURY_NO_PIPELINE=1 disables it.
+        // sub-batch as soon as it has landed. The call then lasts the upload plus the receive_byte of the last sub-batch, so small sub-batches
+        // win until the fixed cost of the control rounds takes over: 1024 windows in 19.0 ms with sub-batches of 512, 17.1 ms with 256,
+        // 19.4 ms with 128 (end of round 2; the upload alone is 13.5 ms). MERCURY_RB_SUB overrides, MERCURY_NO_PIPELINE=1 disables it.
         static const bool no_pipe = getenv("MERCURY_NO_PIPELINE") != nullptr;
         hipPointerAttribute_t pattr{};
         const bool on_device = hipPointerGetAttributes(&pattr, passband) == hipSuccess && pattr.type == hipMemoryTypeDevice;
@@ -740,7 +741,7 @@ extern "C" int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int 
         const auto& t = c->tab;
         const size_t buf = size_t(t.Nofdm) * mgpu_receive_buffer_nsymb(c) * kInterp;
         static const int sub_env = getenv("MERCURY_RB_SUB") ? atoi(getenv("MERCURY_RB_SUB")) : 0;
-        const int sub = sub_env >= 64 ? std::min(sub_env, W) : W >= 1024 ? 512 : ((W + 1) / 2 + 63) / 64 * 64;
+        const int sub = sub_env >= 64 ? std::min(sub_env, W) : 256;
         const int nsub = (W + sub - 1) / sub;
         if (c->rb_stage_cap < size_t(W) * buf * 8) {
             (void)hipFree(c->rb_stage);
