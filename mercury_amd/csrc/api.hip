@@ -323,8 +323,21 @@ void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, con
     HIPCK(hipGetLastError());
 }
 
+static constexpr int kTones32[4] = {4, 20, 12, 28}, kTones16[4] = {2, 10, 6, 14};      // mfsk.cc:82-95
+
+// the same search on the device, for the energies of W windows lying in d_energy ([W][nslots][Nc]); d_search_start: [W] or null
+void launch_mfsk_sync(mgpu_ctx* c, const double* d_energy, int W, int nslots, int size, const int* d_search_start, int* d_delay, hipStream_t s) {
+    const auto& t = c->tab;
+    need(t.preamble >= 1 && t.preamble <= 4 && t.mfsk_nstreams >= 1 && t.mfsk_nstreams <= 4, "MFSK preamble / stream count outside the kernel's tables");
+    MgpuMfskSync P{};
+    P.np = t.preamble; P.nstreams = t.mfsk_nstreams; P.Nc = t.Nc; P.sym_period = t.Nofdm * 4; P.tail = t.Ngi * 4 + t.Nfft * 4;
+    for (int i = 0; i < 4; ++i) P.off[i] = t.mfsk_off[i];
+    for (int p = 0; p < P.np; ++p) P.tones[p] = (t.mfsk_M == 32 ? kTones32 : kTones16)[p % P.np];
+    hipLaunchKernelGGL(mgpu_mfsk_sync_kernel, dim3(W), dim3(256), size_t(P.np) * nslots * 8, s, d_energy, nslots, size, P, d_search_start, d_delay);
+    HIPCK(hipGetLastError());
+}
+
 int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb) {
-    static constexpr int kTones32[4] = {4, 20, 12, 28}, kTones16[4] = {2, 10, 6, 14};      // mfsk.cc:82-95
     const int* tones = t.mfsk_M == 32 ? kTones32 : kTones16;
     const int sym_period = t.Nofdm * 4, np = t.preamble;
     double best_metric = -1;
@@ -797,9 +810,10 @@ constexpr int kInterp = 4;
 // `passband_carrier_hz` >= 0: `bb` is real passband audio ([W][size] doubles) that is first mixed down and filtered with
 // FIR_rx_data on the device (detect_ack_pattern_from_passband, telecom_system.cc:1628-1640); otherwise it is interpolated
 // baseband ([W][size] complex).
-std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size, int nslots, double passband_carrier_hz = -1.0) {
+// d_e ([W][nslots][Nc] doubles on the device) receives the energies; want_host: also returned on the host
+std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size, int nslots, double passband_carrier_hz, DevBuf& d_e, bool want_host) {
     const auto& t = c->tab;
-    DevBuf d_in(size_t(W) * size * 16), d_e(size_t(W) * nslots * t.Nc * 8);
+    DevBuf d_in(size_t(W) * size * 16);
     hipStream_t s = c->stream;
     if (passband_carrier_hz >= 0) {
         DevBuf d_pass(size_t(W) * size * 8), d_fc(size_t(W) * 8);
@@ -821,10 +835,17 @@ std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size
                        c->dev.twiddle, d_e.as<double>());
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(c->sync_ev[1], s));
-    std::vector<double> e(size_t(W) * nslots * t.Nc);
-    HIPCK(hipMemcpyAsync(e.data(), d_e.p, e.size() * 8, hipMemcpyDeviceToHost, s));
-    HIPCK(hipStreamSynchronize(s));
+    std::vector<double> e;
+    if (want_host) {
+        e.resize(size_t(W) * nslots * t.Nc);
+        HIPCK(hipMemcpyAsync(e.data(), d_e.p, e.size() * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIPCK(hipStreamSynchronize(s));              // d_in goes out of scope here
     return e;
+}
+std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size, int nslots, double passband_carrier_hz = -1.0) {
+    DevBuf d_e(size_t(W) * nslots * c->tab.Nc * 8);
+    return slot_energies(c, bb, W, size, nslots, passband_carrier_hz, d_e, true);
 }
 }  // namespace
 }  // extern "C++"
@@ -836,8 +857,18 @@ int mgpu_time_sync_mfsk(mgpu_ctx* c, const double* bb, int W, int size, int sear
         need(t.mfsk_M > 0, "time_sync_mfsk needs an MFSK mode (cfg 100..102)");
         const int sym_period = t.Nofdm * kInterp, nslots = size / sym_period, np = t.preamble;
         need(bb && delay && W > 0 && nslots >= np, "bad argument");
-        const std::vector<double> E = slot_energies(c, bb, W, size, nslots);
-        for (int w = 0; w < W; ++w) delay[w] = mfsk_sync_from_energies(t, &E[size_t(w) * nslots * t.Nc], nslots, size, search_start_symb);
+        if (W == 1) {                                                // one window: 260 KB of energies, the search on the host
+            const std::vector<double> E = slot_energies(c, bb, W, size, nslots);
+            delay[0] = mfsk_sync_from_energies(t, E.data(), nslots, size, search_start_symb);
+            return;
+        }
+        DevBuf d_e(size_t(W) * nslots * t.Nc * 8), d_ss(size_t(W) * 4), d_delay(size_t(W) * 4);
+        slot_energies(c, bb, W, size, nslots, -1.0, d_e, false);
+        const std::vector<int> ss(W, search_start_symb);
+        HIPCK(hipMemcpyAsync(d_ss.p, ss.data(), size_t(W) * 4, hipMemcpyHostToDevice, c->stream));
+        launch_mfsk_sync(c, d_e.as<double>(), W, nslots, size, d_ss.as<int>(), d_delay.as<int>(), c->stream);
+        HIPCK(hipMemcpyAsync(delay, d_delay.p, size_t(W) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
     });
 }
 

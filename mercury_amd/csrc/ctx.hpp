@@ -30,6 +30,7 @@ extern "C" __global__ void mgpu_mfsk_frontend_kernel_m32(MgpuDev, const double*,
 extern "C" __global__ void mgpu_mfsk_frontend_kernel_m16x2(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
 extern "C" int mgpu_mfsk_syms_per_block();
 extern "C" __global__ void mgpu_slot_energy_kernel(const double*, int, int, int, const double*, double*);
+extern "C" __global__ void mgpu_mfsk_sync_kernel(const double*, int, int, MgpuMfskSync, const int*, int*);
 extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
 extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*, const int*, const double*, const int*, int);
@@ -167,6 +168,7 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
 // `location_to_return` after nTrials_max passes
 // the scalar half of cl_ofdm::time_sync_mfsk (ofdm.cc:2004-2060) on the slot energies of one window ([nslots][Nc])
 int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb);
+void launch_mfsk_sync(mgpu_ctx* c, const double* d_energy, int W, int nslots, int size, const int* d_search_start, int* d_delay, hipStream_t s);
 
 void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr);
 

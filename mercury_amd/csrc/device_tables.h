@@ -63,3 +63,7 @@ struct MgpuStatsDev {  // must match mgpu_frame_stats
     int iterations_done, crc, all_zeros, message_decoded;
     float variance, snr_db;
 };
+
+// parameters of mgpu_mfsk_sync_kernel (mfsk.hip): preamble symbols, streams and their carrier offsets, the preamble's tones (mfsk.cc:82-95),
+// carriers per slot, samples per symbol slot, samples a slot's FFT needs behind its start (Ngi + Nfft, interpolated)
+struct MgpuMfskSync { int np, nstreams, off[4], tones[8], Nc, sym_period, tail; };

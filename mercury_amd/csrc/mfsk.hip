@@ -222,3 +222,54 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_slot_energy_kernel
     };
     emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
 }
+
+// The other half of cl_ofdm::time_sync_mfsk (ofdm.cc:2026-2061) where the energies lie: for every start slot s the metric
+// sum_p e_target(s + p) / e_total(s + p) over the np preamble symbols (e_total: the 50 carriers added in carrier order; e_target: the
+// streams' tones of preamble symbol p added in stream order; a slot with e_total <= 0 adds nothing; the sum stops at the first symbol
+// that does not fit the buffer), and the first slot with the largest metric from search_start on (the reference's strict ">"; nothing
+// beats the initial -1 -> slot 0). One workgroup per window; same operations in the same order as mfsk_sync_from_energies (api.hip),
+// which stays as the few-window path and the host-side statement the CPU tests pin. 66 MB of energies per 256 ROBUST_0 windows no
+// longer cross PCIe for a few hundred scalar operations per window.
+extern "C" __global__ __launch_bounds__(256) void mgpu_mfsk_sync_kernel(
+    const double* __restrict__ energy /*[W][nslots][Nc]*/, int nslots, int size, MgpuMfskSync P, const int* __restrict__ search_start /*[W] or null*/,
+    int* __restrict__ delay_out) {
+    extern __shared__ double ratio[];                                // [np][nslots]
+    __shared__ double best_v[256];
+    __shared__ int best_s[256];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const double* E = energy + size_t(w) * nslots * P.Nc;
+    for (int sl = tid; sl < nslots; sl += 256) {
+        const double* e = E + size_t(sl) * P.Nc;
+        double e_total = 0;
+        for (int k = 0; k < P.Nc; ++k) e_total += e[k];
+        for (int p = 0; p < P.np; ++p) {
+            double e_target = 0;
+            for (int st = 0; st < P.nstreams; ++st) e_target += e[P.off[st] + P.tones[p]];
+            ratio[p * nslots + sl] = e_total > 0 ? e_target / e_total : 0.0;       // x + (+0.0) == x: the same as adding nothing
+        }
+    }
+    __syncthreads();
+    const int s0 = search_start ? max(search_start[w], 0) : 0;
+    double bv = -1.0;
+    int bs = 0x7fffffff;
+    for (int s = s0 + tid; s <= nslots - P.np; s += 256) {
+        double metric = 0;
+        for (int p = 0; p < P.np; ++p) {
+            if ((s + p) * P.sym_period + P.tail > size) break;
+            metric += ratio[p * nslots + s + p];
+        }
+        if (metric > bv) { bv = metric; bs = s; }                   // a lane's slots ascend: strict ">" keeps its first maximum
+    }
+    best_v[tid] = bv; best_s[tid] = bs;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (tid < d) {
+            const double ov = best_v[tid + d];
+            const int os = best_s[tid + d];
+            if (os != 0x7fffffff && (best_s[tid] == 0x7fffffff || ov > best_v[tid] || (ov == best_v[tid] && os < best_s[tid]))) { best_v[tid] = ov; best_s[tid] = os; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) delay_out[w] = (best_s[0] == 0x7fffffff ? 0 : best_s[0]) * P.sym_period;
+}
+

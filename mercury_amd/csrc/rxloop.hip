@@ -419,6 +419,9 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             lp.ws.we_ev.push_back(e);
         }
+        // the whole-window signal level (and the MFSK search) is skipped when every window comes with a known delay (the MFSK BER loop)
+        bool need_level = !lp.mfsk || !state;
+        if (!need_level) for (int w = 0; w < W; ++w) if (state[w].fixed_delay_plus_one <= 0) { need_level = true; break; }
         for (int k = 0; k < nsl; ++k) {
             const int off = k * kSlice, n = std::min(kSlice, W - off);
             if (!on_device) {
@@ -431,7 +434,7 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
                                lp.d_ia.as<int>() + off, mix_cs, nullptr, 0);
             HIPCK(hipGetLastError());
             const bool group_end = (k + 1) % group == 0 || k == nsl - 1;
-            if (group_end) {
+            if (group_end && need_level) {
                 // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order, a 92 k-term dependent
                 // chain per window. One wavefront and 4 KB of LDS per window on a side stream, launched ahead of the group's coarse search
                 // so that the two share the compute units (behind the search it added its full latency to the call).
@@ -461,22 +464,30 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
         std::vector<char> fixed_delay(W, 0);
         if (state && !lp.mfsk) for (int w = 0; w < W; ++w) need(state[w].fixed_delay_plus_one <= 0, "fixed_delay_plus_one: MFSK modes only");
         if (lp.mfsk) {
-            const int nslots = lp.buf / lp.sym;
-            DevBuf d_e(size_t(W) * nslots * t.Nc * 8);
-            HIPCK(hipMemsetAsync(d_e.p, 0, size_t(W) * nslots * t.Nc * 8, s));
-            hipLaunchKernelGGL(mgpu_slot_energy_kernel, dim3((nslots + 3) / 4, W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, nslots, kInterp,
-                               c->dev.twiddle, d_e.as<double>());
-            HIPCK(hipGetLastError());
-            std::vector<double> E(size_t(W) * nslots * t.Nc);
-            lp.down(E.data(), d_e, E.size() * 8);
+            // cl_ofdm::time_sync_mfsk (ofdm.cc:2011-2061): slot energies and the preamble-tone search, both where the baseband lies; only the
+            // delays come back. Windows with a known delay (:663-672 mfsk_fixed_delay, used once, no signal level) need neither.
+            std::vector<int> d(W, 0);
+            if (need_level) {
+                const int nslots = lp.buf / lp.sym;
+                DevBuf d_e(size_t(W) * nslots * t.Nc * 8);
+                HIPCK(hipMemsetAsync(d_e.p, 0, size_t(W) * nslots * t.Nc * 8, s));
+                hipLaunchKernelGGL(mgpu_slot_energy_kernel, dim3((nslots + 3) / 4, W), dim3(256), 0, s, lp.d_bbi.as<double>(), lp.buf, nslots, kInterp,
+                                   c->dev.twiddle, d_e.as<double>());
+                HIPCK(hipGetLastError());
+                std::vector<int> ss(W, 0);
+                if (state) for (int w = 0; w < W; ++w) ss[w] = state[w].mfsk_search_start;
+                lp.up(lp.d_ib, ss.data(), size_t(W) * 4);
+                launch_mfsk_sync(c, d_e.as<double>(), W, nslots, lp.buf, lp.d_ib.as<int>(), lp.d_cnt.as<int>(), s);
+                lp.down(d.data(), lp.d_cnt, size_t(W) * 4);
+            }
             for (int w = 0; w < W; ++w) {
-                if (state && state[w].fixed_delay_plus_one > 0) {      // :663-672 mfsk_fixed_delay: known delay, used once, no signal level
+                if (state && state[w].fixed_delay_plus_one > 0) {
                     win[w].delay = state[w].fixed_delay_plus_one - 1;
                     state[w].fixed_delay_plus_one = 0;
                     fixed_delay[w] = 1;
                     continue;
                 }
-                win[w].delay = mfsk_sync_from_energies(t, &E[size_t(w) * nslots * t.Nc], nslots, lp.buf, state ? state[w].mfsk_search_start : 0);
+                win[w].delay = d[w];
             }
         } else {
             std::vector<int> zero(W, 0), full(W, lp.buf), d;
