@@ -242,6 +242,9 @@ int mgpu_enable_timing(mgpu_ctx* ctx, int on);
 int mgpu_kernel_ms_avg(mgpu_ctx* ctx, float ms[2], int* n_launches);
 int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
 
+/* Test hook, process-wide: which passband_to_baseband kernel the library launches. -1 (default): the sliding-tap kernels where they apply
+ * (33 taps, decimation 1 or 4), 0: always the generic one-output-per-lane kernel. Returns the previous setting. */
+int mgpu_debug_p2b_variant(int variant);
 /* Test hook: the span energies receive_byte's gates and recoveries ask for (telecom_system.cc:758-766, :826-834, :1044-1066: sum of
  * re^2 + im^2 over len samples from off[j] in window wv[j], clipped at the window end, added in sample order) on W host windows of `size`
  * complex samples. variant 0: one wavefront per span; 1: one lane per span (what receive_byte launches from 4096 spans up). */

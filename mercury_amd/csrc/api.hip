@@ -7,6 +7,7 @@
 #include <cstring>
 #include <fstream>
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -323,6 +324,29 @@ void launch_tsync_metric(const double* d_bb, int stride, const int* d_start, con
     HIPCK(hipGetLastError());
 }
 
+// -1: pick (sliding-tap kernels where they apply), 0: always the generic kernel, 1: as -1; test hook mgpu_debug_p2b_variant
+static std::atomic<int> g_p2b_variant{-1};
+extern "C" int mgpu_debug_p2b_variant(int v) { const int old = g_p2b_variant.exchange(v); return old; }
+
+void launch_p2b(const double* passband, int in_size, const double* d_carrier, const int* d_start, int start_all, int count, int decim, const double* d_taps,
+                int ntaps, double* out, const int* widx, const double* cs, const int* out_row, int row_by_launch, int nwin, hipStream_t s) {
+    constexpr double kFs = 48000.0, kAmp = 1.4142135623730951;
+    if (g_p2b_variant.load() != 0 && ntaps == 33 && (decim == 1 || decim == 4)) {
+        int geo[6];
+        mgpu_p2b_slide_geometry(geo);
+        const int g = decim == 1 ? 0 : 3;
+        auto kernel = decim == 1 ? (cs ? mgpu_p2b_slide_d1_kernel : mgpu_p2b_slide_d1_sincos_kernel) : (cs ? mgpu_p2b_slide_d4_kernel : mgpu_p2b_slide_d4_sincos_kernel);
+        hipLaunchKernelGGL(kernel, dim3((count + geo[g] - 1) / geo[g], unsigned(nwin)), dim3(geo[g + 1]),
+                           size_t(geo[g + 2]), s, passband, in_size, d_carrier, d_start, start_all, count, d_taps, kFs, kAmp, out, widx, cs, out_row, row_by_launch);
+    } else {
+        const size_t lds = size_t(255 * decim + ntaps) * 16;
+        need(lds <= 64 * 1024 && ntaps <= 64, "decimation too large for the staging buffer");
+        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((count + 255) / 256, unsigned(nwin)), dim3(256), lds, s, passband, in_size, d_carrier, d_start, start_all, count, decim,
+                           d_taps, ntaps, kFs, kAmp, out, widx, cs, out_row, row_by_launch);
+    }
+    HIPCK(hipGetLastError());
+}
+
 static constexpr int kTones32[4] = {4, 20, 12, 28}, kTones16[4] = {2, 10, 6, 14};      // mfsk.cc:82-95
 
 // the same search on the device, for the energies of W windows lying in d_energy ([W][nslots][Nc]); d_search_start: [W] or null
@@ -600,16 +624,12 @@ int mgpu_passband_to_baseband(mgpu_ctx* c, const double* passband, int W, int in
         HIPCK(hipMemcpyAsync(d_fc.p, carrier_hz, size_t(W) * 8, hipMemcpyHostToDevice, s));
         if (start) HIPCK(hipMemcpyAsync(d_start.p, start, size_t(W) * 4, hipMemcpyHostToDevice, s));
         const int ntaps = int(taps.size());
-        const size_t lds = size_t(255 * decimation + ntaps) * 16;
-        need(lds <= 64 * 1024 && ntaps <= 64, "decimation too large for the staging buffer");
         bool shared = true;                                           // one carrier for every window: the host-libm mixer table applies
         for (int w = 1; w < W; ++w) shared = shared && carrier_hz[w] == carrier_hz[0];
         const double* cs = shared ? mixer_table(c, carrier_hz[0], size_t(in_size), s) : nullptr;
         HIPCK(hipEventRecord(c->sync_ev[0], s));
-        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((count + 255) / 256, W), dim3(256), lds, s, d_in.as<double>(), in_size, d_fc.as<double>(),
-                           start ? d_start.as<int>() : nullptr, 0, count, decimation, c->d_fir[filter], ntaps, kSampleRate, kCarrierAmplitude,
-                           d_out.as<double>(), nullptr, cs, nullptr, 0);
-        HIPCK(hipGetLastError());
+        launch_p2b(d_in.as<double>(), in_size, d_fc.as<double>(), start ? d_start.as<int>() : nullptr, 0, count, decimation, c->d_fir[filter], ntaps,
+                   d_out.as<double>(), nullptr, cs, nullptr, 0, W, s);
         HIPCK(hipEventRecord(c->sync_ev[1], s));
         HIPCK(hipMemcpyAsync(out_c128, d_out.p, size_t(W) * count * 16, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
@@ -822,9 +842,7 @@ std::vector<double> slot_energies(mgpu_ctx* c, const double* bb, int W, int size
         HIPCK(hipMemcpyAsync(d_fc.p, fc.data(), size_t(W) * 8, hipMemcpyHostToDevice, s));
         const int ntaps = int(t.fir_data.size());
         const double* cs = mixer_table(c, passband_carrier_hz, size_t(size), s);
-        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((size + 255) / 256, W), dim3(256), size_t(255 + ntaps) * 16, s, d_pass.as<double>(), size,
-                           d_fc.as<double>(), nullptr, 0, size, 1, c->d_fir[1], ntaps, kSampleRate, kCarrierAmplitude, d_in.as<double>(), nullptr, cs, nullptr, 0);
-        HIPCK(hipGetLastError());
+        launch_p2b(d_pass.as<double>(), size, d_fc.as<double>(), nullptr, 0, size, 1, c->d_fir[1], ntaps, d_in.as<double>(), nullptr, cs, nullptr, 0, W, s);
         HIPCK(hipStreamSynchronize(s));          // d_pass / d_fc go out of scope here
     } else {
         HIPCK(hipMemcpyAsync(d_in.p, bb, size_t(W) * size * 16, hipMemcpyHostToDevice, s));

@@ -34,6 +34,11 @@ extern "C" __global__ void mgpu_mfsk_sync_kernel(const double*, int, int, MgpuMf
 extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
 extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*, const int*, const double*, const int*, int);
+extern "C" __global__ void mgpu_p2b_slide_d1_kernel(const double*, int, const double*, const int*, int, int, const double*, double, double, double*, const int*, const double*, const int*, int);
+extern "C" __global__ void mgpu_p2b_slide_d4_kernel(const double*, int, const double*, const int*, int, int, const double*, double, double, double*, const int*, const double*, const int*, int);
+extern "C" __global__ void mgpu_p2b_slide_d1_sincos_kernel(const double*, int, const double*, const int*, int, int, const double*, double, double, double*, const int*, const double*, const int*, int);
+extern "C" __global__ void mgpu_p2b_slide_d4_sincos_kernel(const double*, int, const double*, const int*, int, int, const double*, double, double, double*, const int*, const double*, const int*, int);
+extern "C" int mgpu_p2b_slide_geometry(int*);
 extern "C" __global__ void mgpu_tsync_metric_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" __global__ void mgpu_tsync_metric_dense_kernel(const double*, int, const int*, const int*, const int*, int, int, int, int, int, double*);
 extern "C" int mgpu_tsync_coarse_threads();
@@ -169,6 +174,10 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
 // the scalar half of cl_ofdm::time_sync_mfsk (ofdm.cc:2004-2060) on the slot energies of one window ([nslots][Nc])
 int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslots, int size, int search_start_symb);
 void launch_mfsk_sync(mgpu_ctx* c, const double* d_energy, int W, int nslots, int size, const int* d_search_start, int* d_delay, hipStream_t s);
+// passband_to_baseband launch for nwin windows (grid y) of `count` outputs each: the sliding-tap kernels for the reference's 33-tap filters
+// at decimation 1 / 4, the generic kernel otherwise (api.hip)
+void launch_p2b(const double* passband, int in_size, const double* d_carrier, const int* d_start, int start_all, int count, int decim, const double* d_taps,
+                int ntaps, double* out, const int* widx, const double* cs, const int* out_row, int row_by_launch, int nwin, hipStream_t s);
 
 void select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay, double* corr);
 

@@ -174,10 +174,8 @@ struct Loop {
         bool shared = true;
         for (int w : wins) shared = shared && carrier[w] == rc.carrier_hz;
         const double* cs = shared ? mixer_table(c, carrier[wins[0]], size_t(buf), s) : nullptr;
-        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((buf + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 + ntaps) * 16, s,
-                           pass, buf, d_carrier.as<double>(), nullptr, 0, buf, 1, c->d_fir[filter], ntaps, 48000.0,
-                           1.4142135623730951, d_bbi.as<double>(), d_ia.as<int>(), cs, nullptr, 0);
-        HIPCK(hipGetLastError());
+        launch_p2b(pass, buf, d_carrier.as<double>(), nullptr, 0, buf, 1, c->d_fir[filter], ntaps, d_bbi.as<double>(), d_ia.as<int>(), cs, nullptr, 0,
+                   int(wins.size()), s);
     }
 
     // FIR_rx_data baseband of the frame at `delay` only, decimated, straight into d_frames (row = slot[j] or j): passband_to_baseband
@@ -195,10 +193,8 @@ struct Loop {
         bool shared = true;
         for (int w : wins) shared = shared && carrier[w] == rc.carrier_hz;
         const double* cs = shared ? mixer_table(c, carrier[wins[0]], size_t(buf), s) : nullptr;
-        hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((frame_n + 255) / 256, unsigned(wins.size())), dim3(256), size_t(255 * kInterp + ntaps) * 16, s,
-                           pass, buf, d_carrier.as<double>(), d_ib.as<int>(), 0, frame_n, kInterp, c->d_fir[1], ntaps, 48000.0,
-                           1.4142135623730951, d_frames.as<double>(), d_ia.as<int>(), cs, slot ? d_ic.as<int>() : nullptr, 1);
-        HIPCK(hipGetLastError());
+        launch_p2b(pass, buf, d_carrier.as<double>(), d_ib.as<int>(), 0, frame_n, kInterp, c->d_fir[1], ntaps, d_frames.as<double>(), d_ia.as<int>(), cs,
+                   slot ? d_ic.as<int>() : nullptr, 1, int(wins.size()), s);
     }
 
     // time_sync_preamble[_with_metric] on a sub-window [start, start + size) of each listed window
@@ -429,10 +425,8 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
                 HIPCK(hipEventRecord(lp.ws.slice_ev[k], lp.ws.copy));
                 HIPCK(hipStreamWaitEvent(s, lp.ws.slice_ev[k], 0));
             }
-            hipLaunchKernelGGL(mgpu_p2b_kernel, dim3((lp.buf + 255) / 256, unsigned(n)), dim3(256), size_t(255 + ntaps_ts) * 16, s, lp.pass, lp.buf,
-                               lp.d_carrier.as<double>(), nullptr, 0, lp.buf, 1, c->d_fir[0], ntaps_ts, 48000.0, 1.4142135623730951, lp.d_bbi.as<double>(),
-                               lp.d_ia.as<int>() + off, mix_cs, nullptr, 0);
-            HIPCK(hipGetLastError());
+            launch_p2b(lp.pass, lp.buf, lp.d_carrier.as<double>(), nullptr, 0, lp.buf, 1, c->d_fir[0], ntaps_ts, lp.d_bbi.as<double>(), lp.d_ia.as<int>() + off,
+                       mix_cs, nullptr, 0, n, s);
             const bool group_end = (k + 1) % group == 0 || k == nsl - 1;
             if (group_end && need_level) {
                 // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order, a 92 k-term dependent

@@ -76,6 +76,125 @@ extern "C" __global__ __launch_bounds__(P2B_THREADS) void mgpu_p2b_kernel(
     out[(size_t(row) * count + k) * 2 + 1] = ai;
 }
 
+// The same filter for the reference's 33-tap receive filters with the taps sliding through registers: a lane produces R adjacent outputs
+// (D input samples apart), so a mixed sample read from LDS once feeds every output whose window covers it — out[k + r] takes it with tap
+// j = (k + r) D + h - i, and as the samples are walked downwards every output meets its taps in ascending order, the reference's order of
+// additions. 33 -> (32 + (R - 1) D + 1) / R LDS reads per output (the kernel above spends its time on them: one 16-byte read per two
+// multiply-adds); the taps are uniform and sit in scalar registers. Samples outside the input are staged as zeros: a skipped tap and an
+// added +-0.0 leave the same sum (the accumulators start at +0.0 and can never become -0.0). Sample p of the block's span lies at
+// [p % (R D)][p / (R D)], so the lanes of one read are contiguous and the staging writes conflict-free.
+template <int NTAPS, int D, int R, int THREADS>
+struct P2sGeom {
+    static constexpr int M = R * D;                                  // lane stride in samples = LDS rows
+    static constexpr int SPAN = (THREADS * R - 1) * D + NTAPS;       // mixed samples a block needs
+    static constexpr int COLS = (SPAN + M - 1) / M + 1;
+    static constexpr int ROW = M == 4 ? ((COLS + 13) / 16) * 16 + 2 : (COLS | 1);       // 4 rows: = 2 mod 16; 16 rows: odd
+    static constexpr int STEPS = NTAPS + (R - 1) * D;                // samples a lane walks
+    static_assert(ROW >= COLS, "row too short");
+};
+template <int NTAPS, int D, int R, int THREADS, bool TABLE>
+__device__ __forceinline__ void p2b_slide(
+    const double* __restrict__ passband, int in_size, const double* __restrict__ carrier_hz, const int* __restrict__ start_opt,
+    int start_all, int count, const double* __restrict__ taps, double fs, double amplitude,
+    double* __restrict__ out, const int* __restrict__ widx, const double* __restrict__ cs, const int* __restrict__ out_row, int row_by_launch, c2* l) {
+    using G = P2sGeom<NTAPS, D, R, THREADS>;
+    const int w = widx ? widx[blockIdx.y] : blockIdx.y, tid = threadIdx.x;
+    const int start = start_opt ? start_opt[w] : start_all;
+    const int k0 = blockIdx.x * THREADS * R;
+    constexpr int h = (NTAPS - 1) / 2;
+    const int base = start + k0 * D + h - (NTAPS - 1);               // input index of the span's sample 0
+    const double* in = passband + size_t(w) * in_size;
+    const double fc = carrier_hz[w];
+    const double Ts = 1.0 / fs;
+    for (int t = tid; t < G::SPAN; t += THREADS) {
+        const int i = base + t;
+        c2 v = {0.0, 0.0};
+        if (i >= 0 && i < in_size) {
+            const double a = in[i] * amplitude;
+            if constexpr (TABLE) {       // the launch's windows share one carrier: cos / sin from the host's table (a kernel of its own: the
+                v = {a * cs[2 * i], a * cs[2 * i + 1]};        // inlined sincos would cost this path a third of its wavefronts in registers)
+            } else {
+                const double ph = 2 * M_PI * fc * double(i) * Ts;
+                double sn, cs1;
+                gl_sincos(ph, &sn, &cs1);
+                v = {a * cs1, a * sn};
+            }
+        }
+        l[(t % G::M) * G::ROW + t / G::M] = v;
+    }
+    __syncthreads();
+    const int k = k0 + tid * R;
+    if (k >= count) return;
+    double ar[R], ai[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ar[r] = 0; ai[r] = 0; }
+    // the lane's samples are span positions tid * M + q, q = 0 .. STEPS - 1; output r meets position q with tap j = r D + NTAPS - 1 - q
+    // in groups of four samples, the next group's reads in flight during the current group's multiply-adds. Left to itself the compiler
+    // hoists all 36 reads to the top (150 registers) and then runs the outputs one after another as two dependent chains; the empty asm
+    // ties the lane's LDS position and the accumulators to a point in the program, which pins one group's reads and one group's
+    // arithmetic between two such points.
+    constexpr int GRP = 4, NG = (G::STEPS + GRP - 1) / GRP;
+    c2 cur[GRP], nxt[GRP];
+    int pos = tid;
+    auto fetch = [&](int g, c2* dst) {
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            const int q = G::STEPS - 1 - (g * GRP + u);
+            if (q >= 0) dst[u] = l[(q % G::M) * G::ROW + pos + q / G::M];
+        }
+    };
+    fetch(0, cur);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if constexpr (R == 4)
+            asm volatile("" : "+v"(pos), "+v"(ar[0]), "+v"(ai[0]), "+v"(ar[1]), "+v"(ai[1]), "+v"(ar[2]), "+v"(ai[2]), "+v"(ar[3]), "+v"(ai[3]));
+        else if constexpr (R == 2)
+            asm volatile("" : "+v"(pos), "+v"(ar[0]), "+v"(ai[0]), "+v"(ar[1]), "+v"(ai[1]));
+        if (g + 1 < NG) fetch(g + 1, nxt);
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            const int q = G::STEPS - 1 - (g * GRP + u);
+            if (q < 0) continue;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int j = r * D + NTAPS - 1 - q;
+                if (j >= 0 && j < NTAPS) { ar[r] += cur[u].re * taps[j]; ai[r] += cur[u].im * taps[j]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) cur[u] = nxt[u];
+    }
+    const int row = out_row ? out_row[blockIdx.y] : (row_by_launch ? int(blockIdx.y) : w);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (k + r < count) {
+            out[(size_t(row) * count + k + r) * 2] = ar[r];
+            out[(size_t(row) * count + k + r) * 2 + 1] = ai[r];
+        }
+}
+
+#define P2S_ARGS                                                                                                                              \
+    const double *__restrict__ passband, int in_size, const double *__restrict__ carrier_hz, const int *__restrict__ start_opt, int start_all, \
+        int count, const double *__restrict__ taps, double fs, double amplitude, double *__restrict__ out, const int *__restrict__ widx,        \
+        const double *__restrict__ cs, const int *__restrict__ out_row, int row_by_launch
+// decimation 1 (the whole capture window at the interpolated rate): 256 lanes x 4 outputs; decimation 4 (frames cut out at their delay):
+// 128 lanes x 2 outputs (mixing the 4 input samples per output is most of that kernel: the block keeps 1053 samples for 256 outputs)
+#define P2S_KERNEL(name, D, R, THREADS, TABLE)                                                                                              \
+    extern "C" __global__ __launch_bounds__(THREADS) void name(P2S_ARGS) {                                                                 \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                                               \
+        p2b_slide<33, D, R, THREADS, TABLE>(passband, in_size, carrier_hz, start_opt, start_all, count, taps, fs, amplitude, out, widx, cs, \
+                                            out_row, row_by_launch, reinterpret_cast<c2*>(smem));                                          \
+    }
+P2S_KERNEL(mgpu_p2b_slide_d1_kernel, 1, 4, 256, true)
+P2S_KERNEL(mgpu_p2b_slide_d4_kernel, 4, 2, 128, true)
+P2S_KERNEL(mgpu_p2b_slide_d1_sincos_kernel, 1, 4, 256, false)
+P2S_KERNEL(mgpu_p2b_slide_d4_sincos_kernel, 4, 2, 128, false)
+extern "C" int mgpu_p2b_slide_geometry(int* o) {   // per kernel: outputs per block, threads, LDS bytes
+    o[0] = 256 * 4; o[1] = 256; o[2] = P2sGeom<33, 1, 4, 256>::M * P2sGeom<33, 1, 4, 256>::ROW * 16;
+    o[3] = 128 * 2; o[4] = 128; o[5] = P2sGeom<33, 4, 2, 128>::M * P2sGeom<33, 4, 2, 128>::ROW * 16;
+    return 0;
+}
+
 // Schmidl-Cox metric (ofdm.cc:1893-1941). One lane per candidate offset i = cand*step; the three accumulators run
 // in the reference's order (a dependent chain of 2*(Ngi+Nfft/2)*Nsymb additions each), so the parallelism is
 // across candidates: a wavefront owns 64 consecutive candidates and walks the preamble in chunks of TS_CH pairs.

@@ -282,6 +282,39 @@ def test_gpu_detect_ack_pattern_from_passband_matches_oracle_chain():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 100])
+def test_gpu_p2b_sliding_tap_kernels_equal_generic_kernel_bit_for_bit(cfg):
+    """passband_to_baseband with the taps sliding through registers (4 adjacent outputs per lane, sync.hip) against the generic kernel the
+    oracle comparisons pin: every output bit-identical — whole windows at decimation 1 (both filters), frames cut at a start offset with
+    decimation 4 (counts that fill no block, starts near both ends of the window so that taps fall outside the input), per-window
+    carriers (device sincos) and a shared one (host table), a window shorter than the filter."""
+    from mercury_amd import RxPhy
+    rx = RxPhy(cfg, max_batch=1)
+    rng = np.random.default_rng(SEED + 5 + cfg)
+    n = 20000
+    wins = rng.standard_normal((5, n)) * np.exp(rng.uniform(-4, 2, (5, 1)))
+    cases = []
+    for carriers in (np.full(5, CARRIER), CARRIER + rng.uniform(-20, 20, 5)):
+        for which in (0, 1):
+            cases.append(dict(passband=wins, carrier_hz=carriers, which=which))
+        for count in (1, 255, 256, 257, 1500):
+            cases.append(dict(passband=wins, carrier_hz=carriers, which=1, start=np.array([0, 3, n - 4 * count - 7, max(0, n - 4 * count + 40), 1234], np.int32),
+                              count=count, decimation=4))
+    cases.append(dict(passband=wins[:, :20], carrier_hz=CARRIER, which=0))
+    cases.append(dict(passband=wins[:, :1025], carrier_hz=CARRIER, which=1))
+    try:
+        for kw in cases:
+            rx.debug_p2b_variant(0)
+            a = rx.passband_to_baseband(**kw)
+            rx.debug_p2b_variant(-1)
+            b = rx.passband_to_baseband(**kw)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), {k: v for k, v in kw.items() if k != "passband"}
+    finally:
+        rx.debug_p2b_variant(-1)
+    rx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_span_energies_lane_per_span_equals_wave_per_span_and_the_sequential_sum():
     """The span energies of receive_byte's gates / recoveries (telecom_system.cc:758-766, :826-834, :1044-1066): both kernels (one
     wavefront per span; one lane per span, used from 4096 spans per launch) against the sequential sum in sample order — spans anywhere
