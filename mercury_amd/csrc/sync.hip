@@ -766,7 +766,7 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_span_energy_many_kernel(
     const double* __restrict__ bb, int stride, const int* __restrict__ wv, const int* __restrict__ off, int n, int len,
     double* __restrict__ sum, int* __restrict__ cnt) {
     __shared__ double tile[4][64][SEM_CH + 1];
-    __shared__ unsigned base_s[4][64];
+    __shared__ size_t base_s[4][64];
     __shared__ int m_s[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j0 = (blockIdx.x * 4 + wave) * 64;
@@ -775,15 +775,15 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_span_energy_many_kernel(
     const int o = off[j];
     int m = stride - o;                                           // terms that exist: i < len && o + i < stride
     m = m < 0 ? 0 : (m > len ? len : m);
-    base_s[wave][lane] = unsigned(wv[j]) * unsigned(stride) + unsigned(o);        // complex-sample index of the span's first term
+    base_s[wave][lane] = size_t(wv[j]) * size_t(stride) + size_t(o);              // complex-sample index of the span's first term
     m_s[wave][lane] = m;
     __builtin_amdgcn_wave_barrier();
     const c2* x = reinterpret_cast<const c2*>(bb);
     const int rsub = lane >> 4, col = lane & 15;                  // staging role: row 4 r + rsub, sample col of the chunk
-    unsigned rbase[16];
+    size_t rbase[16];
     int rm[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { rbase[r] = base_s[wave][4 * r + rsub] + unsigned(col); rm[r] = m_s[wave][4 * r + rsub] - col; }
+    for (int r = 0; r < 16; ++r) { rbase[r] = base_s[wave][4 * r + rsub] + size_t(col); rm[r] = m_s[wave][4 * r + rsub] - col; }
     double (*t)[SEM_CH + 1] = tile[wave];
     int mmax = m;
 #pragma unroll
@@ -797,7 +797,7 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_span_energy_many_kernel(
         for (int r = 0; r < 16; ++r) t[4 * r + rsub][col] = v[r].re * v[r].re + v[r].im * v[r].im;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = rm[r] > i0 + SEM_CH ? x[rbase[r] + unsigned(i0 + SEM_CH)] : c2{0.0, 0.0};      // next chunk in flight
+        for (int r = 0; r < 16; ++r) v[r] = rm[r] > i0 + SEM_CH ? x[rbase[r] + size_t(i0 + SEM_CH)] : c2{0.0, 0.0};      // next chunk in flight
         const int left = m - i0;
         if (left >= SEM_CH) {
 #pragma unroll
@@ -828,9 +828,9 @@ extern "C" __global__ __launch_bounds__(256) void mgpu_decimate_kernel(
 extern "C" __global__ __launch_bounds__(64) void mgpu_window_energy_kernel(
     const double* __restrict__ bb, int stride, int n, double* __restrict__ out) {
     // One wavefront and 4 KB of LDS per window, so that the 92 k-term chain can sit beside whatever else fills the compute units
-    // (receive_byte launches it slice by slice under the mixer / filter and the coarse search). The next chunk's samples are in flight
-    // while lane 0 adds the current chunk's terms.
-    __shared__ double term[WE_CHUNK + 8];
+    // (receive_byte launches it ahead of the coarse search). The next chunk's samples are in flight while the current chunk's terms
+    // are added; every lane carries the same sum.
+    __shared__ __attribute__((aligned(16))) double term[WE_CHUNK + 32];
     const c2* x = reinterpret_cast<const c2*>(bb) + size_t(blockIdx.x) * stride;
     const int lane = threadIdx.x;
     double acc = 0.0;
@@ -844,27 +844,34 @@ extern "C" __global__ __launch_bounds__(64) void mgpu_window_energy_kernel(
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < WE_LOADS; ++r) { const int i = base + WE_CHUNK + r * 64 + lane; v[r] = i < n ? x[i] : c2{0.0, 0.0}; }
-        if (lane == 0) {
-            // eight terms are read while the eight before them are added: the chain is the additions alone
-            int p = 0;
-            double a[8], b[8];
+        if (m == WE_CHUNK) {
+            // The chain. A dependent v_add_f64 can issue every 8.25 cycles (tools/ubench/dep_chain.hip: 3.46 ns); a lone wavefront also
+            // spends ~7 cycles of issue on every 16-byte LDS read (two terms), which is what is left to pay: 12 cycles per term when the 16
+            // terms of the next group are already on their way while a group is added. Written as a loop the compiler waits for *all*
+            // outstanding reads at the loop head (22 cycles per term); as straight-line code it counts them exactly. Every lane adds the
+            // same terms (LDS broadcasts): with a single lane enabled a dependent addition takes 10 cycles instead of 8.25. Tried and
+            // slower: one read after every two additions (15.8 cycles per term) and terms spread over the lanes with a v_mov_b64_dpp
+            // row_newbcast per term (the 64-bit move costs two issue passes: 15.8 again; fp64 additions have no DPP form on gfx9).
+            double a[16], b[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = term[q];
-            for (; p + 16 <= m; p += 16) {
+            for (int q = 0; q < 16; ++q) a[q] = term[q];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) b[q] = term[p + 8 + q];
+            for (int g = 0; g < WE_CHUNK / 32; ++g) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) b[q] = term[32 * g + 16 + q];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc += a[q];
+                for (int q = 0; q < 16; ++q) acc += a[q];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) a[q] = term[p + 16 + q];       // the last read of a chunk runs 8 past it: inside the padded array, never added
+                for (int q = 0; q < 16; ++q) a[q] = term[32 * g + 32 + q];   // the last group reads 16 terms past the chunk: inside the array, never added
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc += b[q];
+                for (int q = 0; q < 16; ++q) acc += b[q];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            for (; p < m; ++p) acc += term[p];
+        } else {
+            for (int p = 0; p < m; ++p) acc += term[p];                 // the window's last, partial chunk: every lane reads the same word
         }
         __builtin_amdgcn_wave_barrier();
     }
