@@ -242,6 +242,10 @@ int mgpu_enable_timing(mgpu_ctx* ctx, int on);
 int mgpu_kernel_ms_avg(mgpu_ctx* ctx, float ms[2], int* n_launches);
 int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
 
+/* Test hook: the preamble-tone search of cl_ofdm::time_sync_mfsk (ofdm.cc:2026-2061) on given slot energies [W][nslots][Nc] (host): variant 0
+ * the host statement (what a single-window call uses), 1 the device kernel (what receive_byte and batched calls launch). search_start: [W] or
+ * NULL; delay: [W], interpolated samples. MFSK modes only. */
+int mgpu_debug_mfsk_sync(mgpu_ctx* ctx, const double* energy, int W, int nslots, int size, const int* search_start, int variant, int* delay);
 /* Test hook, process-wide: which passband_to_baseband kernel the library launches. -1 (default): the sliding-tap kernels where they apply
  * (33 taps, decimation 1 or 4), 0: always the generic one-output-per-lane kernel. Returns the previous setting. */
 int mgpu_debug_p2b_variant(int variant);

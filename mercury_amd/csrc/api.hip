@@ -775,6 +775,26 @@ int mgpu_debug_tsync_metric(mgpu_ctx* c, const double* bb, int W, int size, int 
     });
 }
 
+int mgpu_debug_mfsk_sync(mgpu_ctx* c, const double* energy, int W, int nslots, int size, const int* search_start, int variant, int* delay) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        const auto& t = c->tab;
+        need(t.mfsk_M > 0, "MFSK modes only (cfg 100..102)");
+        need(energy && delay && W > 0 && nslots >= t.preamble && size > 0 && (variant == 0 || variant == 1), "bad argument");
+        if (variant == 0) {
+            for (int w = 0; w < W; ++w) delay[w] = mfsk_sync_from_energies(t, energy + size_t(w) * nslots * t.Nc, nslots, size, search_start ? search_start[w] : 0);
+            return;
+        }
+        DevBuf d_e(size_t(W) * nslots * t.Nc * 8), d_ss(size_t(W) * 4), d_delay(size_t(W) * 4);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_e.p, energy, size_t(W) * nslots * t.Nc * 8, hipMemcpyHostToDevice, s));
+        if (search_start) HIPCK(hipMemcpyAsync(d_ss.p, search_start, size_t(W) * 4, hipMemcpyHostToDevice, s));
+        launch_mfsk_sync(c, d_e.as<double>(), W, nslots, size, search_start ? d_ss.as<int>() : nullptr, d_delay.as<int>(), s);
+        HIPCK(hipMemcpyAsync(delay, d_delay.p, size_t(W) * 4, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
 int mgpu_debug_span_energy(mgpu_ctx* c, const double* bb, int W, int size, const int* wv, const int* off, int n, int len, int variant, double* sum, int* cnt) {
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {

@@ -102,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_alloc_host", "mgpu_free_host", "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_host_select_peak", "mgpu_host_fir_taps", "mgpu_host_preamble_carriers",
     "mgpu_ldpc_batch", "mgpu_ldpc_encode_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
-    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_debug_glibc_trig", "mgpu_debug_tsync_metric", "mgpu_debug_occupancy", "mgpu_debug_select_peak", "mgpu_debug_span_energy", "mgpu_debug_p2b_variant", "mgpu_baseband_test_esn0", "mgpu_passband_test_esn0", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
+    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_debug_glibc_trig", "mgpu_debug_tsync_metric", "mgpu_debug_occupancy", "mgpu_debug_select_peak", "mgpu_debug_span_energy", "mgpu_debug_p2b_variant", "mgpu_debug_mfsk_sync", "mgpu_baseband_test_esn0", "mgpu_passband_test_esn0", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_measure_signal_only",
     "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_transmit_buffer", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
@@ -255,6 +255,15 @@ class RxPhy:
         self._ck(self.lib.mgpu_baseband_test_esn0(self.h, _ptr(pts), C.c_int(pts.size), C.c_longlong(frames_per_point), C.c_uint64(seed),
                                                   C.c_uint64(frame0), C.c_int(channel), out))
         return [{n: getattr(r, n) for n, _ in ErrorRate._fields_} for r in out]
+
+    def debug_mfsk_sync(self, energy, size, search_start, variant):
+        """Test hook: cl_ofdm::time_sync_mfsk's search on slot energies [W, nslots, Nc]; variant 0 host, 1 device kernel -> delay [W]."""
+        e = np.ascontiguousarray(energy, np.float64)
+        W, nslots = e.shape[0], e.shape[1]
+        ss = None if search_start is None else np.ascontiguousarray(search_start, np.int32)
+        d = np.zeros(W, np.int32)
+        self._ck(self.lib.mgpu_debug_mfsk_sync(self.h, _ptr(e), C.c_int(W), C.c_int(nslots), C.c_int(size), _ptr(ss), C.c_int(variant), _ptr(d)))
+        return d
 
     def debug_p2b_variant(self, variant):
         """Test hook (process-wide): -1 = sliding-tap passband_to_baseband kernels where they apply, 0 = generic kernel. Returns the old value."""

@@ -282,6 +282,36 @@ def test_gpu_detect_ack_pattern_from_passband_matches_oracle_chain():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [100, 101, 102])
+def test_gpu_mfsk_sync_kernel_equals_host_statement_on_adversarial_energies(cfg):
+    """The device search of time_sync_mfsk (mgpu_mfsk_sync_kernel) against the host statement that the oracle comparisons pin, on slot
+    energies built to hit the corner cases of the arg-max: exact ties between start slots (the first must win), all-zero slots (add
+    nothing), slots whose total is zero / negative zero / NaN / infinite, a search start past every candidate, buffers whose last symbols do
+    not fit (the sum stops early), random energies."""
+    from mercury_amd import RxPhy
+    rx = RxPhy(cfg, max_batch=1)
+    rng = np.random.default_rng(SEED + 9 + cfg)
+    Nc, sym = 50, rx.Nofdm * 4
+    for nslots in (rx.preamble_nsymb, rx.preamble_nsymb + 1, 37, 300, 648):
+        W = 24
+        e = rng.random((W, nslots, Nc)) * np.exp(rng.uniform(-20, 5, (W, nslots, 1)))
+        e[1] = 0.0
+        e[2] = 1.0                                                     # every start slot ties
+        e[3, ::2] = 0.0
+        e[4, nslots // 2] = np.nan
+        e[5, nslots // 3] = np.inf
+        e[6] = np.tile(e[6, :1], (nslots, 1))                          # periodic: many exact ties
+        e[7, :, :] = -0.0
+        e[8] = np.round(e[8] * 4) / 4                                  # coarse values: ties by rounding
+        for size in (nslots * sym, nslots * sym - 1, nslots * sym - sym // 2, (nslots - 1) * sym + 5):
+            for ss in (None, np.zeros(W, np.int32), rng.integers(-3, nslots + 3, W).astype(np.int32)):
+                a = rx.debug_mfsk_sync(e, size, ss, 0)
+                b = rx.debug_mfsk_sync(e, size, ss, 1)
+                assert np.array_equal(a, b), (cfg, nslots, size, None if ss is None else ss.tolist(), a.tolist(), b.tolist())
+    rx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [8, 100])
 def test_gpu_p2b_sliding_tap_kernels_equal_generic_kernel_bit_for_bit(cfg):
     """passband_to_baseband with the taps sliding through registers (4 adjacent outputs per lane, sync.hip) against the generic kernel the
