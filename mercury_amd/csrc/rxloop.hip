@@ -418,6 +418,18 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
         // the whole-window signal level (and the MFSK search) is skipped when every window comes with a known delay (the MFSK BER loop)
         bool need_level = !lp.mfsk || !state;
         if (!need_level) for (int w = 0; w < W; ++w) if (state[w].fixed_delay_plus_one <= 0) { need_level = true; break; }
+        // Windows already in HBM (OFDM): the signal-level chains (one wavefront per window, 0.6 ms of dependent additions) are launched
+        // behind the coarse search instead of ahead of it: they then run beside the gates, their host round trips and the recovery search,
+        // where the GPU has room; beside the coarse search — one latency-bound wavefront per SIMD — they cost it 0.37 ms. (From host memory
+        // the search waits for PCIe anyway; MFSK windows have the longest chain and nothing but the whole call to hide it behind.)
+        const bool defer_level = need_level && on_device && !lp.mfsk;
+        auto launch_level = [&](int g0, int gn, hipEvent_t ev) {
+            HIPCK(hipEventRecord(ev, s));
+            HIPCK(hipStreamWaitEvent(lp.ws.side, ev, 0));
+            hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(gn), dim3(64), 0, lp.ws.side, lp.d_bbi.as<double>() + size_t(g0) * lp.buf * 2, lp.buf, lp.buf,
+                               lp.d_freq.as<double>() + g0);
+            HIPCK(hipGetLastError());
+        };
         for (int k = 0; k < nsl; ++k) {
             const int off = k * kSlice, n = std::min(kSlice, W - off);
             if (!on_device) {
@@ -428,16 +440,12 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             launch_p2b(lp.pass, lp.buf, lp.d_carrier.as<double>(), nullptr, 0, lp.buf, 1, c->d_fir[0], ntaps_ts, lp.d_bbi.as<double>(), lp.d_ia.as<int>() + off,
                        mix_cs, nullptr, 0, n, s);
             const bool group_end = (k + 1) % group == 0 || k == nsl - 1;
-            if (group_end && need_level) {
+            if (group_end && need_level && !defer_level) {
                 // :678 measure_signal_stregth (ofdm.cc:1523-1539): the whole window's |x|^2 added in sample order, a 92 k-term dependent
                 // chain per window. One wavefront and 4 KB of LDS per window on a side stream, launched ahead of the group's coarse search
                 // so that the two share the compute units (behind the search it added its full latency to the call).
-                const int g0 = (k / group) * group * kSlice, gn = off + n - g0;
-                HIPCK(hipEventRecord(lp.ws.we_ev[k], s));
-                HIPCK(hipStreamWaitEvent(lp.ws.side, lp.ws.we_ev[k], 0));
-                hipLaunchKernelGGL(mgpu_window_energy_kernel, dim3(gn), dim3(64), 0, lp.ws.side, lp.d_bbi.as<double>() + size_t(g0) * lp.buf * 2, lp.buf, lp.buf,
-                                   lp.d_freq.as<double>() + g0);
-                HIPCK(hipGetLastError());
+                const int g0 = (k / group) * group * kSlice;
+                launch_level(g0, off + n - g0, lp.ws.we_ev[k]);
             }
             if (!lp.mfsk && ncand0 > 0 && group_end) {
                 const int g0 = (k / group) * group * kSlice, gn = off + n - g0;
@@ -452,6 +460,7 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             HIPCK(hipStreamWaitEvent(s, lp.ws.ev_search, 0));
         }
         pt.mark(s, "upload + p2b + coarse metric");
+        if (defer_level) launch_level(0, W, lp.ws.we_ev[0]);        // behind the coarse search (the event is recorded after the main stream's wait for it)
         HIPCK(hipEventRecord(lp.ws.ev_done, lp.ws.side));            // signal strength: the main stream waits for it before the trial loop overwrites the baseband
         pt.mark(s, "signal strength");
         std::vector<char> live(W, 1);                             // still on the way to the trial loop
