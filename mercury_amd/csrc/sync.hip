@@ -123,8 +123,7 @@ __device__ __forceinline__ void p2b_slide(
         l[(t % G::M) * G::ROW + t / G::M] = v;
     }
     __syncthreads();
-    const int k = k0 + tid * R;
-    if (k >= count) return;
+    const int k = k0 + tid * R;                                       // lanes past the last output filter staged zeros and store nothing
     double ar[R], ai[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { ar[r] = 0; ai[r] = 0; }
@@ -165,12 +164,28 @@ __device__ __forceinline__ void p2b_slide(
         for (int u = 0; u < GRP; ++u) cur[u] = nxt[u];
     }
     const int row = out_row ? out_row[blockIdx.y] : (row_by_launch ? int(blockIdx.y) : w);
+    c2* o = reinterpret_cast<c2*>(out) + size_t(row) * count;
+    if constexpr (D == 1) {
+        // Write-out through LDS: a lane holds R adjacent outputs, so a direct store instruction would touch a 16-byte piece of every
+        // R-th element; in output order a wavefront's stores are contiguous kilobytes (0.21 -> 0.16 ms per 256 windows: two thirds of
+        // the kernel's traffic are these stores). A wavefront's outputs are its own 64 R elements of the block, so once every wavefront
+        // is done with the sample tile it only has to wait for itself. (At decimation 4, two outputs per lane, the round trip costs more
+        // than it saves: 0.051 -> 0.060 ms.)
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (k + r < count) {
-            out[(size_t(row) * count + k + r) * 2] = ar[r];
-            out[(size_t(row) * count + k + r) * 2 + 1] = ai[r];
+        for (int r = 0; r < R; ++r) l[tid * R + r] = {ar[r], ai[r]};
+        __builtin_amdgcn_wave_barrier();
+        const int wave0 = (tid & ~63) * R, lane = tid & 63;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int e = wave0 + j * 64 + lane;
+            if (k0 + e < count) o[k0 + e] = l[e];
         }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (k + r < count) o[k + r] = {ar[r], ai[r]};
+    }
 }
 
 #define P2S_ARGS                                                                                                                              \
