@@ -12,6 +12,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 [ -x "$ROOT/tools/ubench/valu_cycles" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/valu_cycles" "$ROOT/tools/ubench/valu_cycles.hip"
 "$ROOT/tools/ubench/valu_cycles" > "$OUT/r02_valu_cycles.json"
+[ -x "$ROOT/tools/ubench/dep_chain" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/dep_chain" "$ROOT/tools/ubench/dep_chain.hip" 2>/dev/null
+"$ROOT/tools/ubench/dep_chain" > "$OUT/r02_dep_chain.json"
 for d in spa spa_fast minsum; do
   python "$ROOT/bench.py" --decoder $d > "$OUT/r02_bench_${d}_cfg8.json" 2>/dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$d" -- python "$ROOT/bench.py" --decoder $d --no-cpu-baseline --no-extras > /dev/null 2>&1
@@ -45,6 +47,7 @@ if [ "$1" = "sweep" ]; then
   python tools/bench_tsync_variants.py > "$OUT/r02_bench_tsync_variants.json" 2>/dev/null
   python tools/bench_tsync_fine.py > "$OUT/r02_bench_tsync_fine.json" 2>/dev/null
   tools/pmc_any.sh tsync_metric_fine "$OUT/r02_pmc_tsync_fine.json" -- python tools/bench_tsync_fine.py 1024 > /dev/null 2>&1 || true
+  tools/pmc_any.sh p2b_slide_d1_kernel "$OUT/r02_pmc_p2b.json" -- python tools/bench_sync.py > /dev/null 2>&1 || true
   tools/pmc_any.sh tsync_metric_stream "$OUT/r02_pmc_tsync_stream.json" -- python tools/bench_tsync_variants.py 1024 > /dev/null 2>&1 || true
   tools/pmc_any.sh mfsk_frontend "$OUT/r02_pmc_mfsk_frontend.json" -- python bench.py --cfg 100 --decoder spa_fast --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frames 2048 > /dev/null 2>&1 || true
   python bench.py --cfg 100 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/r02_bench_spa_fast_cfg100.json" 2>/dev/null
