@@ -265,6 +265,18 @@ public:
         ber_next_frame += std::uint64_t(max_frame_no);
         return r;
     }
+    // cl_error_rate cl_telecom_system::passband_test_EsN0(float EsN0, int max_frame_no) — telecom_system.h:130, .cc:231-330: the audio-path
+    // self-simulation BER_PLOT_passband_process_main calls once per point (:2451; it sets output_power_Watt = 1 first, :2442) —
+    // transmit_byte, AWGN with delay, receive_byte — with this object's carrier_frequency and output_power_Watt; frames from the same
+    // Philox stream as above.
+    mgpu_error_rate passband_test_EsN0(float EsN0, int max_frame_no) {
+        mgpu_error_rate r{};
+        const double e = EsN0;
+        detail::check(mgpu_passband_test_esn0(ctx_, &e, 1, max_frame_no, ber_seed, ber_next_frame, carrier_frequency, output_power_Watt, &r, nullptr, nullptr), ctx_,
+                      "passband_test_EsN0");
+        ber_next_frame += std::uint64_t(max_frame_no);
+        return r;
+    }
     // int generate_ack_pattern_passband(double* out) / generate_break_pattern_passband — telecom_system.cc:1589-1631, :1659-1689;
     // returns the number of samples written (ack_pattern_passband_samples)
     int ack_pattern_passband_samples() const { return 16 * info.Nofdm * 4; }

@@ -115,6 +115,14 @@ int main(int argc, char** argv) {
             fwrite(sig, sizeof(double), 6, sg);
             fclose(sg);
             if (phy.get_active_nsymb() != data_nsymb) return 7;
+            // 4d) the two BER self-simulations through their mirrors, at points where every frame decodes
+            const mgpu_error_rate eb = phy.baseband_test_EsN0(cfg >= 100 ? 10.0f : 20.0f, 4);
+            const mgpu_error_rate ep = phy.passband_test_EsN0(cfg >= 100 ? 10.0f : 30.0f, 3);
+            const double ber[6] = {double(eb.Frames_total), double(eb.Error_frames_total), double(eb.Bits_total), double(ep.Frames_total),
+                                   double(ep.Error_frames_total), double(ep.crc_ok_frames)};
+            FILE* bf = fopen((std::string(argv[5]) + ".ber").c_str(), "wb");
+            fwrite(ber, sizeof(double), 6, bf);
+            fclose(bf);
         }
         // get_configuration (telecom_system.cc:3036-3108): spot checks on both sides of a few thresholds
         if (mgpu::cl_rx_phy::get_configuration(13.0) != 15 || mgpu::cl_rx_phy::get_configuration(12.5) != 14 || mgpu::cl_rx_phy::get_configuration(0.6) != 8 ||

@@ -129,6 +129,10 @@ def test_cpp_transmit_byte_runs_the_carrier_on_across_calls(tmp_path, cfg):
     assert -40 < dbm < 20
     orc.set_ctrl_mode(1)
     assert (int(data_nsymb), int(ctrl_nsymb)) == (orc.Nsymb, orc.active_nsymb if cfg >= 100 else orc.Nsymb)
+    # baseband_test_EsN0 / passband_test_EsN0 through the C++ mirror: counters of cl_error_rate, every frame of these clean points decodes
+    b_frames, b_err, b_bits, p_frames, p_err, p_ok = np.fromfile(str(tmp_path / "out.bin") + ".ber", np.float64)
+    assert (b_frames, b_err) == (4, 0) and b_bits > 0
+    assert (p_frames, p_err, p_ok) == (3, 0, 3)
 
 
 def _build_stages(tmp_path):
