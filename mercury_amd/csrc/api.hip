@@ -78,6 +78,10 @@ void ctx_alloc(mgpu_ctx* c) {
     LdpcDev& l = c->ldev;
     l.vinfo = d.vinfo; l.sdesc = d.sdesc; l.scrambler = d.scrambler;
     l.cptr = d.cptr; l.cvar = d.cvar;
+    l.sdesc2 = c->keep(upload(t.graph.sdesc2));
+    l.bmask = c->keep(upload(t.graph.bmask));
+    l.vinfo2 = c->keep(upload(t.graph.vinfo2));
+    l.DM = t.graph.DM;
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
     {   // min-sum check update: segmented wave scans pay off once a check has more edges than the scans have steps to hide
@@ -120,6 +124,20 @@ void ctx_alloc(mgpu_ctx* c) {
                 case 7: c->spa_kernel = mgpu_ldpc_spa_kernel_ne7; break;
                 case 8: c->spa_kernel = mgpu_ldpc_spa_kernel_ne8; break;
                 default: throw std::runtime_error("graph too large for the sum-product kernel");
+            }
+            {
+                const char* e = std::getenv("MERCURY_SPA_VARIANT");      // experiment knob: 1 = the round-2 kernel
+                if (!e || std::atoi(e) != 1) {
+                    const int ne = std::max(4, (d.S + 1023) / 1024);
+                    if (t.graph.maxdeg > mgpu_spa2_max_degree(ne)) throw std::runtime_error("check degree exceeds the sum-product kernel's unrolled product walk");
+                    switch (ne) {
+                        case 4: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne4; break;
+                        case 5: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne5; break;
+                        case 6: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne6; break;
+                        case 7: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne7; break;
+                        default: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne8; break;
+                    }
+                }
             }
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;

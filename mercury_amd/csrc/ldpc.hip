@@ -304,6 +304,215 @@ SPA_KERNEL(7)
 SPA_KERNEL(8)
 
 // ---------------------------------------------------------------------------------------------
+// Round-3 form of the same decoder (same arithmetic, same schedule): the vector instructions that were not the
+// reference's fp64 arithmetic are moved to the scalar unit or into the tables.
+//   * descriptor = LDS byte offsets ((check_start*8 | 2) | (variable*8)<<16 | last<<31): one AND / one BFE gives an address,
+//     "valid" is descriptor != 0, and no lane needs its degree or its position inside the check any more;
+//   * the product walk's "does this lane take factor j" is a property of the bin, tabulated on the host (LdpcGraph::bmask):
+//     the wave loads four 64-bit masks with one scalar load and runs v_mul_f64 under them (s_and_b64 exec), so a step
+//     is one LDS broadcast read + one multiplication, no compare; the walk ends at the first all-zero mask;
+//   * variable records carry byte offsets too.
+__device__ __forceinline__ void spa_masked_mul2(double& t, double a0, double a1, uint64_t m0, uint64_t m1) {
+    uint64_t sv;
+    asm volatile(
+        "s_and_saveexec_b64 %1, %4\n\t"
+        "v_mul_f64 %0, %0, %2\n\t"
+        "s_and_b64 exec, %1, %5\n\t"
+        "v_mul_f64 %0, %0, %3\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(t), "=&s"(sv)
+        : "v"(a0), "v"(a1), "s"(m0), "s"(m1)
+        : "scc");
+}
+
+typedef uint32_t spa_u32x4 __attribute__((ext_vector_type(4)));
+// scalar loads the compiler cannot be talked into (every load behind a workgroup barrier counts as clobbered and goes through
+// the vector memory path): issue, and wait separately so that the latency hides behind the arithmetic in between
+__device__ __forceinline__ spa_u32x4 spa_sload4(const uint64_t* p, int byte_off) {
+    spa_u32x4 r;
+    asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(r) : "s"(p), "n"(byte_off));
+    return r;
+}
+__device__ __forceinline__ void spa_swait(spa_u32x4& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
+
+template <int NE, int DMX>
+__device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
+                                            uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
+                                            uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+                                            const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = T.S;
+    constexpr int N = kN;
+    constexpr int kMoff = N * 8;                        // LDS byte offset of the message array
+    double* Lt = reinterpret_cast<double*>(smem);       // LLRtmp per variable
+    double* M = Lt + N;                                 // R or T per padded edge slot
+    float* Li = reinterpret_cast<float*>(M + S);        // channel LLR
+    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
+    uint8_t* bytes = hard + ((N + 15) & ~15);
+    int* flag = reinterpret_cast<int*>(bytes + 256);
+
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (f >= F) return;
+    if (uint32_t(uintptr_t(smem)) != 0) __builtin_trap();
+    const float* lin = llr_in + size_t(f) * N;
+    for (int v = tid; v < N; v += LDPC_THREADS) {
+        const float l = lin[v];
+        Li[v] = l;
+        Lt[v] = l;
+    }
+    for (int p = tid; p < S; p += LDPC_THREADS) M[p] = 0.0;
+    const uint32_t* __restrict__ sdesc = T.sdesc2;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
+    auto load_var = [&](const uint32_t* vinfo, int i) -> VarRec {
+        if (i >= N) return VarRec{0, 0, 0, 0, 0, 0};
+        const uint4 lo = *reinterpret_cast<const uint4*>(vinfo + size_t(i) * 8);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vinfo + size_t(i) * 8 + 4);
+        return VarRec{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+    };
+    // LDS accessed by integer byte offset: the kernel has no static LDS, so the dynamic block starts at address 0 (checked
+    // below), and an address formed from an integer spares the "+ base" addition per access the symbol would cost
+    typedef __attribute__((address_space(3))) double lds_f64;
+    auto ldsd = [](uint32_t byte_off) -> lds_f64* { return reinterpret_cast<lds_f64*>(byte_off); };
+    auto Mb = [&](uint32_t byte_off) -> double { return *ldsd(kMoff + byte_off); };
+    auto var_update = [&](const VarRec& q) {
+        const uint32_t v = q.vi & 0x7ff;
+        uint32_t deg = q.vi >> 11;
+        asm volatile("" : "+v"(deg));
+        double s = Li[v];
+        if (deg > 0) { s += Mb(q.w0 & 0xffff); SPA_KEEP(s); }
+        if (deg > 1) { s += Mb(q.w0 >> 16); SPA_KEEP(s); }
+        if (deg > 2) {
+            s += Mb(q.w1 & 0xffff); SPA_KEEP(s);
+            if (deg > 3) { s += Mb(q.w1 >> 16); SPA_KEEP(s); }
+            if (deg > 4) { s += Mb(q.w2 & 0xffff); SPA_KEEP(s); }
+            if (deg > 5) {
+                s += Mb(q.w2 >> 16); SPA_KEEP(s);
+                if (deg > 6) { s += Mb(q.w3 & 0xffff); SPA_KEEP(s); }
+                if (deg > 7) { s += Mb(q.w3 >> 16); SPA_KEEP(s); }
+                if (deg > 8) { s += Mb(q.w4 & 0xffff); SPA_KEEP(s); }
+            }
+        }
+        Lt[v] = s;
+    };
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    __syncthreads();
+
+    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
+        m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
+        return (m & ends) != 0;
+    };
+    auto lt_of = [&](uint32_t k) -> double { return *ldsd((k >> 16) & 0x3fff); };
+
+    auto syndrome_pass = [&](int p) {
+        bool unsat = false;
+        uint32_t k = sdesc[tid];
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t kn = sdesc[(r + 1) * LDPC_THREADS + tid];
+            const unsigned long long vmask = __ballot(k != 0);
+            const double lt = lt_of(k);                                // padding reads variable 0; masked out below
+            unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
+            k = kn;
+        }
+        if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
+    };
+    auto cn_pass = [&](bool with_syndrome, int p) {
+        bool unsat = false;
+        uint32_t k = sdesc[tid];
+        const uint32_t* __restrict__ sd = sdesc + LDPC_THREADS;         // next round's descriptors (scalar base + lane offset)
+        uint32_t own = kMoff + tid * 8;                                // LDS address of this lane's slot in round r
+        const uint64_t* __restrict__ bm = T.bmask + size_t(wave) * T.DM;
+        const size_t bm_step = size_t(16) * T.DM;
+#pragma unroll 1
+        for (int r = 0; r < NE; ++r, own += LDPC_THREADS * 8, bm += bm_step, sd += LDPC_THREADS) {
+            const uint32_t kn = sd[tid];
+            const bool valid = k != 0;
+            const unsigned long long vmask = __ballot(valid);
+            if (vmask == 0) { k = kn; continue; }                    // an empty bin (only in the last round)
+            spa_u32x4 mk = spa_sload4(bm, 0);                        // masks of walk steps 0 and 1; waited for after the tanh
+            double lt;
+            if (valid) lt = lt_of(k);
+            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
+            if (valid) *ldsd(own) = spa_tanh_half(lt - *ldsd(own));
+            __builtin_amdgcn_wave_barrier();
+            // Product of the check's OTHER T values in slot order, starting from 1.0 (the reference's temp *= ...):
+            // every lane of a check reads the check's slots in order (a broadcast) and multiplies under the bin's
+            // tabulated mask for that step (own slot, slots past the check's degree and padding lanes excluded).
+            // Uniform control flow: the masks come through scalar loads, padding lanes read slot 0 and never multiply.
+            double temp = 1;
+            {
+                uint32_t chk = kMoff + (k & 0xfff8u);
+                asm volatile("" : "+v"(chk));                        // one address register; the steps are ds_read2 offsets
+                spa_swait(mk);
+#pragma unroll
+                for (int c = 0; c < DMX / 2; ++c) {
+                    const uint64_t m0 = mk.x | uint64_t(mk.y) << 32, m1 = mk.z | uint64_t(mk.w) << 32;
+                    if (m0 == 0) break;
+                    spa_u32x4 nx;
+                    if (c + 1 < DMX / 2) nx = spa_sload4(bm, (c + 1) * 16);          // the next two steps' masks, behind this pair
+                    const double a0 = ldsd(chk)[2 * c], a1 = ldsd(chk)[2 * c + 1];
+                    spa_masked_mul2(temp, a0, a1, m0, m1);
+                    if (c + 1 < DMX / 2) { spa_swait(nx); mk = nx; }
+                }
+            }
+            double rr;
+            if (valid) rr = spa_atanh_x2(temp);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) *ldsd(own) = rr;
+            k = kn;
+        }
+        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
+    };
+    constexpr int kSpecStart = 8;
+    int iteration = 0;
+    syndrome_pass(0);
+    __syncthreads();
+    if (flag[0]) {
+        for (int it = 1;; ++it) {
+            const bool spec = it - 1 >= kSpecStart;
+            if (it <= T.max_iters) cn_pass(spec, it - 1);
+            else syndrome_pass(it - 1);
+            const uint32_t* vinfo = T.vinfo2;
+            asm volatile("" : "+s"(vinfo));
+            const VarRec va = load_var(vinfo, tid), vb = load_var(vinfo, tid + LDPC_THREADS);
+            __syncthreads();
+            if (spec) {
+                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
+                if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
+            }
+            if (tid == 0) flag[it & 1] = 0;
+            var_update(va);
+            if (tid + LDPC_THREADS < N) var_update(vb);
+            __syncthreads();
+            if (it < kSpecStart) {
+                syndrome_pass(it);
+                __syncthreads();
+                if (!flag[it & 1]) { iteration = it; break; }
+                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
+            }
+        }
+    }
+    for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
+    __syncthreads();
+    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}
+
+#define SPA2_KERNEL(NE, DMX)                                                                                    \
+    extern "C" __global__ __launch_bounds__(LDPC_THREADS, 8) void mgpu_ldpc_spa2_kernel_ne##NE(               \
+        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                     \
+        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,   \
+        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                     \
+        spa2_decode<NE, DMX>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
+    }
+SPA2_KERNEL(4, 16)
+SPA2_KERNEL(5, 16)
+SPA2_KERNEL(6, 16)
+SPA2_KERNEL(7, 16)
+SPA2_KERNEL(8, 48)
+extern "C" int mgpu_spa2_max_degree(int ne) { return ne == 8 ? 48 : 16; }
+
+// ---------------------------------------------------------------------------------------------
 // Sum-product, single precision ("spa_fast"; BASELINE.json north_star's fast variant, SURVEY.md §7.3-1: "SPA-equivalent
 // check node in FP32"). NOT the reference's arithmetic: the same flooding schedule, the same tanh rule
 // R = 2*atanh(prod_others tanh(Q/2)) and the same iteration/early-exit convention as ldpc_decoder_SPA.cc:25-218, evaluated

@@ -170,7 +170,8 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         if (g.S >= 8192) throw std::runtime_error("padded edge count exceeds the 13-bit slot field");
         g.spack.assign(g.S, 0u);
         g.svar.assign(g.S, 0);
-        g.sdesc.assign(size_t((g.S + 1023) / 1024 + 1) * 1024, 0u);    // one extra all-padding round: the kernels always prefetch round r+1
+        // one extra all-padding round: the kernels always prefetch round r+1; never fewer than the 4 rounds of the smallest kernel instance
+        g.sdesc.assign(size_t(std::max(4, (g.S + 1023) / 1024) + 1) * 1024, 0u);
         std::vector<uint32_t> slot_of_edge(E);
         for (size_t b = 0; b < members.size(); ++b) {
             uint32_t p = uint32_t(b) * 64;
@@ -198,6 +199,34 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
                 const uint32_t slot = slot_of_edge[g.vedge[g.vptr[v] + j]];
                 g.vinfo[size_t(i) * 8 + 1 + j / 2] |= slot << (16 * (j & 1));
             }
+        }
+        // ---- the fp64 sum-product kernel's view: byte offsets and tabulated walk masks ----------
+        {
+            int maxdeg = 0;
+            for (uint32_t c = 0; c < P; ++c) maxdeg = std::max(maxdeg, int(cdeg[c]));
+            g.maxdeg = maxdeg;
+            g.DM = ((maxdeg + 1) & ~1) + 2;      // pairs of steps, and one all-zero pair that ends the walk
+            const size_t rounds = size_t(std::max(4, (g.S + 1023) / 1024));    // the smallest kernel instance runs 4 rounds
+            g.sdesc2.assign((rounds + 1) * 1024, 0u);
+            g.bmask.assign(rounds * 16 * size_t(g.DM), 0ull);
+            for (size_t b = 0; b < members.size(); ++b) {
+                uint32_t p = uint32_t(b) * 64;
+                for (uint32_t c : members[b]) {
+                    const uint32_t cs = p, d = cdeg[c];
+                    for (uint32_t j = 0; j < d; ++j, ++p) {
+                        const uint32_t eo = g.cptr[c] + j;
+                        g.sdesc2[p] = (cs * 8u) | 2u | (uint32_t(g.cvar[eo]) * 8u) << 16 | (j + 1 == d ? 0x80000000u : 0u);
+                        for (uint32_t s2 = 0; s2 < d; ++s2)
+                            if (s2 != j) g.bmask[b * size_t(g.DM) + s2] |= 1ull << (p & 63);
+                    }
+                }
+            }
+            g.vinfo2 = g.vinfo;
+            for (uint32_t i = 0; i < N; ++i)
+                for (int w = 1; w <= 5; ++w) {
+                    const uint32_t x = g.vinfo[size_t(i) * 8 + w];
+                    g.vinfo2[size_t(i) * 8 + w] = ((x & 0xffffu) * 8u) | ((x >> 16) * 8u) << 16;
+                }
         }
         return g;
     }

@@ -50,6 +50,13 @@ struct LdpcGraph {
     std::vector<uint16_t> svar;    // [S] variable of the slot's edge (0 for padding)
     std::vector<uint32_t> sdesc;   // [(ceil(S/1024)+1)*1024] what the decoders read per slot: check_start | deg<<13 | variable<<19 | last-edge-of-check<<31, 0 for padding
     std::vector<uint32_t> vinfo;   // [N][8] (6 used) variable | deg<<11, then 10 u16 padded-slot indices; rows sorted by degree (descending)
+    // the fp64 sum-product kernel's own tables (ldpc.hip, spa_decode): LDS byte offsets instead of indices, and the
+    // product walk's execution masks tabulated per bin and step instead of compared per lane
+    int maxdeg = 0;                // largest check degree
+    int DM = 0;                    // mask row length: the largest check degree rounded up to a pair of steps, plus one all-zero pair (ends the walk)
+    std::vector<uint32_t> sdesc2;  // [(ceil(S/1024)+1)*1024] (check_start*8 | 2) | (variable*8)<<16 | last-edge-of-check<<31, 0 for padding
+    std::vector<uint64_t> bmask;   // [ceil(S/1024)*16 bins][DM] lanes of the bin that multiply factor j in: position != j and degree > j (0 past the bin's largest degree)
+    std::vector<uint32_t> vinfo2;  // [N][8] like vinfo with byte offsets (slot*8) in the 10 u16 fields
 };
 
 struct ModeTables {
