@@ -78,7 +78,8 @@ void ctx_alloc(mgpu_ctx* c) {
     LdpcDev& l = c->ldev;
     l.vinfo = d.vinfo; l.sdesc = d.sdesc; l.scrambler = d.scrambler;
     l.cptr = d.cptr; l.cvar = d.cvar;
-    l.sdesc2 = c->keep(upload(t.graph.sdesc2));
+    l.sadr = c->keep(upload(t.graph.sadr));
+    l.bhead = c->keep(upload(t.graph.bhead));
     l.bmask = c->keep(upload(t.graph.bmask));
     l.vinfo2 = c->keep(upload(t.graph.vinfo2));
     l.DM = t.graph.DM;

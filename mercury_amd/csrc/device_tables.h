@@ -48,8 +48,9 @@ struct LdpcDev {
     const uint32_t* sdesc;   // [NE*1024] per padded slot: check_start(13) | deg(6)<<13 | variable(11)<<19 | last edge of its check<<31, 0 = padding (zero-filled, one spare round)
     const uint32_t* cptr; const uint16_t* cvar;                           // plain check-major lists (GBF)
     const uint8_t* scrambler;
-    // fp64 sum-product kernel (tables.hpp: LdpcGraph::sdesc2 / bmask / vinfo2)
-    const uint32_t* sdesc2;  // [(NE+1)*1024] (check_start*8 | 2) | (variable*8)<<16 | last edge of its check<<31, 0 = padding
+    // fp64 sum-product kernel (tables.hpp: LdpcGraph::sadr / bhead / bmask / vinfo2)
+    const uint32_t* sadr;    // [(NE+1)*1024][2] LDS byte offset of the slot's posterior, LDS byte address of the first message of the slot's check
+    const uint64_t* bhead;   // [(NE+1)*16][2] per bin: lanes in use, lanes holding the last edge of a check
     const uint64_t* bmask;   // [NE*16][DM] execution mask of product-walk step j of a bin
     const uint32_t* vinfo2;  // vinfo with LDS byte offsets
     int DM;

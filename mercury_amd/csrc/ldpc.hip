@@ -326,14 +326,38 @@ __device__ __forceinline__ void spa_masked_mul2(double& t, double a0, double a1,
 }
 
 typedef uint32_t spa_u32x4 __attribute__((ext_vector_type(4)));
-// scalar loads the compiler cannot be talked into (every load behind a workgroup barrier counts as clobbered and goes through
-// the vector memory path): issue, and wait separately so that the latency hides behind the arithmetic in between
-__device__ __forceinline__ spa_u32x4 spa_sload4(const uint64_t* p, int byte_off) {
-    spa_u32x4 r;
-    asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(r) : "s"(p), "n"(byte_off));
-    return r;
+typedef uint32_t spa_u32x2 __attribute__((ext_vector_type(2)));
+// The bin tables are read through constant-address-space pointers: a uniform load from there is a scalar load whatever
+// barriers the loop contains (through a global pointer every load behind a workgroup barrier counts as clobbered and takes
+// the vector memory path), and the compiler keeps track of the outstanding loads itself.
+typedef const uint64_t __attribute__((address_space(4))) * spa_cptr64;
+
+// Steps 2C and 2C+1 of the product walk and, recursively, the rest (unrolled by construction: every step's LDS offset is an
+// immediate): masks m0 / m1 belong to this pair, the next pair's are fetched behind it; an all-zero mask ends the walk.
+template <int C, int CMAX>
+__device__ __forceinline__ void spa_walk(double& temp, uint32_t achk, spa_cptr64 bm, uint64_t m0, uint64_t m1) {
+    typedef __attribute__((address_space(3))) double lds_f64;
+    if (m0 == 0) return;
+    uint64_t n0 = 0, n1 = 0;
+    if constexpr (C + 1 < CMAX) { n0 = bm[2 * C + 2]; n1 = bm[2 * C + 3]; }
+    const lds_f64* chk = reinterpret_cast<const lds_f64*>(achk);
+    const double a0 = chk[2 * C], a1 = chk[2 * C + 1];
+    spa_masked_mul2(temp, a0, a1, m0, m1);
+    if constexpr (C + 1 < CMAX) spa_walk<C + 1, CMAX>(temp, achk, bm, n0, n1);
 }
-__device__ __forceinline__ void spa_swait(spa_u32x4& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
+// The same in groups of four steps (the high-degree graphs: half as many load round trips per check)
+template <int C, int CMAX>
+__device__ __forceinline__ void spa_walk4(double& temp, uint32_t achk, spa_cptr64 bm, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
+    typedef __attribute__((address_space(3))) double lds_f64;
+    if (m0 == 0) return;
+    uint64_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    if constexpr (C + 1 < CMAX) { n0 = bm[4 * C + 4]; n1 = bm[4 * C + 5]; n2 = bm[4 * C + 6]; n3 = bm[4 * C + 7]; }
+    const lds_f64* chk = reinterpret_cast<const lds_f64*>(achk);
+    const double a0 = chk[4 * C], a1 = chk[4 * C + 1], a2 = chk[4 * C + 2], a3 = chk[4 * C + 3];
+    spa_masked_mul2(temp, a0, a1, m0, m1);
+    if (m2 != 0) spa_masked_mul2(temp, a2, a3, m2, m3);
+    if constexpr (C + 1 < CMAX) spa_walk4<C + 1, CMAX>(temp, achk, bm, n0, n1, n2, n3);
+}
 
 template <int NE, int DMX>
 __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
@@ -361,13 +385,12 @@ __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __res
         Lt[v] = l;
     }
     for (int p = tid; p < S; p += LDPC_THREADS) M[p] = 0.0;
-    const uint32_t* __restrict__ sdesc = T.sdesc2;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
-    auto load_var = [&](const uint32_t* vinfo, int i) -> VarRec {
-        if (i >= N) return VarRec{0, 0, 0, 0, 0, 0};
-        const uint4 lo = *reinterpret_cast<const uint4*>(vinfo + size_t(i) * 8);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vinfo + size_t(i) * 8 + 4);
+    const __amdgpu_buffer_rsrc_t vrec = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.vinfo2), 0, N * 32, 0x00020000);
+    auto load_var = [&](int i) -> VarRec {          // rows past N read as zeros (the buffer's bounds check): degree 0
+        const spa_u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(vrec, i * 32, 0, 0);
+        const spa_u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(vrec, i * 32, 16, 0);
         return VarRec{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
     };
     // LDS accessed by integer byte offset: the kernel has no static LDS, so the dynamic block starts at address 0 (checked
@@ -402,38 +425,49 @@ __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __res
         m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
         return (m & ends) != 0;
     };
-    auto lt_of = [&](uint32_t k) -> double { return *ldsd((k >> 16) & 0x3fff); };
+    // Per-slot addresses come straight from a table (no field extraction): the LDS offset of the slot's posterior and the
+    // LDS address of its check's first message, one buffer load per round (lane offset in a register, round offset in a
+    // scalar). What is uniform over a bin comes through scalar loads: the lanes in use and the lanes ending a check (bhead),
+    // the walk masks (bmask); "valid" is the bin's lane mask applied as exec.
+    const __amdgpu_buffer_rsrc_t sadr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.sadr), 0, 0x7fffffff, 0x00020000);
+    constexpr int kRound = LDPC_THREADS * 8;                       // bytes of address table per round
+    const spa_cptr64 bhead0 = (spa_cptr64)(T.bhead) + size_t(wave) * 2;
 
     auto syndrome_pass = [&](int p) {
         bool unsat = false;
-        uint32_t k = sdesc[tid];
+        spa_cptr64 bh = bhead0;
+        uint32_t alt = __builtin_amdgcn_raw_buffer_load_b32(sadr, tid * 8, 0, 0);
 #pragma unroll 1
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t kn = sdesc[(r + 1) * LDPC_THREADS + tid];
-            const unsigned long long vmask = __ballot(k != 0);
-            const double lt = lt_of(k);                                // padding reads variable 0; masked out below
-            unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
-            k = kn;
+        for (int r = 0; r < NE; ++r, bh += 32) {
+            const uint32_t altn = __builtin_amdgcn_raw_buffer_load_b32(sadr, tid * 8, (r + 1) * kRound, 0);
+            const unsigned long long vmask = bh[0], ends = bh[1];
+            const double lt = *ldsd(alt);                              // padding reads variable 0; masked out below
+            unsat |= bin_unsat(__ballot(lt < 0) & vmask, ends);
+            alt = altn;
         }
         if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
     auto cn_pass = [&](bool with_syndrome, int p) {
         bool unsat = false;
-        uint32_t k = sdesc[tid];
-        const uint32_t* __restrict__ sd = sdesc + LDPC_THREADS;         // next round's descriptors (scalar base + lane offset)
+        spa_u32x2 ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, tid * 8, 0, 0);
         uint32_t own = kMoff + tid * 8;                                // LDS address of this lane's slot in round r
-        const uint64_t* __restrict__ bm = T.bmask + size_t(wave) * T.DM;
+        spa_cptr64 bm = (spa_cptr64)(T.bmask) + size_t(wave) * T.DM;
         const size_t bm_step = size_t(16) * T.DM;
+        spa_cptr64 bh = bhead0;
+        unsigned long long vmask = bh[0], ends = bh[1];
 #pragma unroll 1
-        for (int r = 0; r < NE; ++r, own += LDPC_THREADS * 8, bm += bm_step, sd += LDPC_THREADS) {
-            const uint32_t kn = sd[tid];
-            const bool valid = k != 0;
-            const unsigned long long vmask = __ballot(valid);
-            if (vmask == 0) { k = kn; continue; }                    // an empty bin (only in the last round)
-            spa_u32x4 mk = spa_sload4(bm, 0);                        // masks of walk steps 0 and 1; waited for after the tanh
+        for (int r = 0; r < NE; ++r, own += LDPC_THREADS * 8, bm += bm_step) {
+            const uint32_t alt = ad.x, achk = ad.y;
+            const unsigned long long vm = vmask, en = ends;
+            bh += 32;
+            vmask = bh[0]; ends = bh[1];                              // next round's bin (the table has one spare round)
+            if (vm == 0) continue;                                    // an empty bin: only in the last round, nothing follows it
+            uint64_t m0 = bm[0], m1 = bm[1], m2 = 0, m3 = 0;           // masks of the first walk steps, behind the tanh
+            if constexpr (DMX > 16) { m2 = bm[2]; m3 = bm[3]; }
+            const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
             double lt;
-            if (valid) lt = lt_of(k);
-            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
+            if (valid) lt = *ldsd(alt);
+            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0) & vm, en);
             if (valid) *ldsd(own) = spa_tanh_half(lt - *ldsd(own));
             __builtin_amdgcn_wave_barrier();
             // Product of the check's OTHER T values in slot order, starting from 1.0 (the reference's temp *= ...):
@@ -441,26 +475,14 @@ __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __res
             // tabulated mask for that step (own slot, slots past the check's degree and padding lanes excluded).
             // Uniform control flow: the masks come through scalar loads, padding lanes read slot 0 and never multiply.
             double temp = 1;
-            {
-                uint32_t chk = kMoff + (k & 0xfff8u);
-                asm volatile("" : "+v"(chk));                        // one address register; the steps are ds_read2 offsets
-                spa_swait(mk);
-#pragma unroll
-                for (int c = 0; c < DMX / 2; ++c) {
-                    const uint64_t m0 = mk.x | uint64_t(mk.y) << 32, m1 = mk.z | uint64_t(mk.w) << 32;
-                    if (m0 == 0) break;
-                    spa_u32x4 nx;
-                    if (c + 1 < DMX / 2) nx = spa_sload4(bm, (c + 1) * 16);          // the next two steps' masks, behind this pair
-                    const double a0 = ldsd(chk)[2 * c], a1 = ldsd(chk)[2 * c + 1];
-                    spa_masked_mul2(temp, a0, a1, m0, m1);
-                    if (c + 1 < DMX / 2) { spa_swait(nx); mk = nx; }
-                }
-            }
+            if constexpr (DMX > 16) spa_walk4<0, DMX / 4>(temp, achk, bm, m0, m1, m2, m3);
+            else spa_walk<0, DMX / 2>(temp, achk, bm, m0, m1);
+            // the next round's addresses land in the registers this round is done with, behind the atanh (the table has a spare round)
+            ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, tid * 8, (r + 1) * kRound, 0);
             double rr;
             if (valid) rr = spa_atanh_x2(temp);
             __builtin_amdgcn_wave_barrier();
             if (valid) *ldsd(own) = rr;
-            k = kn;
         }
         if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
@@ -473,9 +495,7 @@ __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __res
             const bool spec = it - 1 >= kSpecStart;
             if (it <= T.max_iters) cn_pass(spec, it - 1);
             else syndrome_pass(it - 1);
-            const uint32_t* vinfo = T.vinfo2;
-            asm volatile("" : "+s"(vinfo));
-            const VarRec va = load_var(vinfo, tid), vb = load_var(vinfo, tid + LDPC_THREADS);
+            const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
             __syncthreads();
             if (spec) {
                 if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }

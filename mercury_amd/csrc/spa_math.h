@@ -46,6 +46,7 @@
 #define SPA_MAKE(hi, lo) __hiloint2double(int(hi), int(lo))
 #define SPA_LO(x) uint32_t(__double2loint(x))
 #define SPA_KEEP(x) asm volatile("" : "+v"(x))
+#define SPA_UNDEF(x) asm volatile("" : "=v"(x))      /* a definition without an instruction */
 SPA_FN double spa_recip(double d) {          // 1/d to within an ulp, d normal
     const double r = __builtin_amdgcn_rcp(d);
     const double e = __builtin_fma(-d, r, 1.0);
@@ -67,6 +68,7 @@ static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_
 #define SPA_LO(x) spa_bits_lo_(x)
 #define SPA_MAKE(hi, lo) spa_make_(hi, lo)
 #define SPA_KEEP(x) (void)(x)
+#define SPA_UNDEF(x) (x) = 0
 SPA_FN double spa_recip(double d) { return d; }
 SPA_FN double spa_div_r(double n, double d, double) { return n / d; }
 #endif
@@ -163,8 +165,8 @@ SPA_FN double spa_atanh_x2(double x) {
                  Lp7 = 1.479819860511658591e-01;
     if (__builtin_expect(spa_fabs(x) == 1.0, 0)) {
         x = SPA_MAKE((SPA_BITS_HI(x) & 0x80000000u) | 0x3fefffffu, 0xca501acbu);      // +-0.9999999
-        SPA_KEEP(x);
     }
+    SPA_KEEP(x);                       // the clamp rewrites x itself; |x| below stays a source modifier, never a register pair of its own
     const uint32_t jx = SPA_BITS_HI(x);
     const double xa = spa_fabs(x);
     const double t2 = xa + xa;
@@ -182,14 +184,29 @@ SPA_FN double spa_atanh_x2(double x) {
     double f, l;
     const bool direct = int32_t(SPA_BITS_HI(y)) < 0x3FDA827A;
     const double u = 1.0 + y;
-    const uint32_t hu0 = SPA_BITS_HI(u), hu = hu0 & 0x000fffffu;
-    const bool lowhalf = hu < 0x6a09eu;
-    if (direct) {
-        f = y;
+    // s_log1p.c normalises u = 1 + y to [sqrt(2)/2, sqrt(2)): k = exponent, + 1 when the top 20 mantissa bits are >= 0x6a09e.
+    // Adding 0x100000 - 0x6a09e to the high word carries into the exponent field in exactly that case, so one addition
+    // gives k ((hadd >> 20) - 1023), the normalised high word ((hadd & 0xfffff) + 0x3fe6a09e = hu | 0x3ff00000 resp.
+    // hu | 0x3fe00000) and the |f| < 2^-20 test (hu == 0 resp. (0x100000 - hu) >> 2 == 0 <=> (hadd & 0xfffff) in 0x95f5f..0x95f62)
+    const uint32_t hadd = SPA_BITS_HI(u) + 0x95f62u, hm = hadd & 0x000fffffu;
+    // The normalised lanes finish with y first (the correction term c = (1 + y - u)/u, exactly as s_log1p.c forms it) and
+    // then turn it into f in place; the direct lanes' f is y itself - no lane copies a register pair.
+    double c;
+    SPA_UNDEF(c);
+    f = y;
+    if (!direct) {
+        // not direct => y >= 0.41421 => u >= 1.41421: the unadjusted exponent is > 0 exactly when u >= 2
+        if (u >= 2.0) {
+            c = 1.0 - (u - y);
+            SPA_KEEP(c);
+        } else {
+            c = y - (u - 1.0);
+            SPA_KEEP(c);
+        }
+        c = spa_div_r(c, u, spa_recip(u));
+        f = SPA_MAKE(hm + 0x3fe6a09eu, SPA_LO(u)) - 1.0;
         SPA_KEEP(f);
-    } else {
-        f = SPA_MAKE(hu | (lowhalf ? 0x3ff00000u : 0x3fe00000u), SPA_LO(u)) - 1.0;
-        SPA_KEEP(f);
+        SPA_KEEP(c);
     }
     const double hfsq = 0.5 * f * f;
     const double d3 = 2.0 + f;
@@ -205,22 +222,8 @@ SPA_FN double spa_atanh_x2(double x) {
         l = f - (hfsq - sr);
         SPA_KEEP(l);
     } else {
-        // not direct => y >= 0.41421 => u >= 1.41421 => the biased exponent of u is 0x3ff (k = 0, mantissa in the upper half,
-        // normalised to u/2: k = 1) or larger (k > 0)
-        int32_t k = int32_t(hu0 >> 20) - 1023;
-        double c;
-        if (k > 0) {
-            c = 1.0 - (u - y);
-            SPA_KEEP(c);
-        } else {
-            c = y - (u - 1.0);
-            SPA_KEEP(c);
-        }
-        c = spa_div_r(c, u, spa_recip(u));
-        k = lowhalf ? k : k + 1;
-        const double dk = double(k);
-        // |f| < 2^-20 <=> the normalised mantissa word is 0 (lower half) or within 3 of 2^20 (upper half, (2^20 - hu) >> 2 == 0)
-        if (__builtin_expect(((hu + 3u) & 0x000fffffu) < 4u, 0)) {
+        const double dk = double(int32_t(hadd >> 20) - 1023);
+        if (__builtin_expect(hm - 0x95f5fu < 4u, 0)) {
             if (f == 0.0) {
                 l = dk * ln2_hi + (c + dk * ln2_lo);
             } else {
@@ -232,7 +235,7 @@ SPA_FN double spa_atanh_x2(double x) {
         }
         SPA_KEEP(l);
     }
-    double res = SPA_MAKE(SPA_BITS_HI(l) ^ (jx & 0x80000000u), SPA_LO(l));     // 2 * (+-0.5 * l)
+    double res = SPA_MAKE((SPA_BITS_HI(l) & 0x7fffffffu) | (jx & 0x80000000u), SPA_LO(l));     // l > 0: 2 * (+-0.5 * l) is one bit-field insert
     if (__builtin_expect(xa < 0x1.0p-28, 0)) res = x + x;
     return res;
 }

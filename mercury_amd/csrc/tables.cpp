@@ -205,9 +205,10 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
             int maxdeg = 0;
             for (uint32_t c = 0; c < P; ++c) maxdeg = std::max(maxdeg, int(cdeg[c]));
             g.maxdeg = maxdeg;
-            g.DM = ((maxdeg + 1) & ~1) + 2;      // pairs of steps, and one all-zero pair that ends the walk
+            g.DM = ((maxdeg + 3) & ~3) + 4;      // groups of (two or) four steps, and one all-zero group that ends the walk
             const size_t rounds = size_t(std::max(4, (g.S + 1023) / 1024));    // the smallest kernel instance runs 4 rounds
-            g.sdesc2.assign((rounds + 1) * 1024, 0u);
+            g.sadr.assign((rounds + 1) * 1024 * 2, 0u);
+            g.bhead.assign((rounds + 1) * 16 * 2, 0ull);
             g.bmask.assign(rounds * 16 * size_t(g.DM), 0ull);
             for (size_t b = 0; b < members.size(); ++b) {
                 uint32_t p = uint32_t(b) * 64;
@@ -215,7 +216,10 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
                     const uint32_t cs = p, d = cdeg[c];
                     for (uint32_t j = 0; j < d; ++j, ++p) {
                         const uint32_t eo = g.cptr[c] + j;
-                        g.sdesc2[p] = (cs * 8u) | 2u | (uint32_t(g.cvar[eo]) * 8u) << 16 | (j + 1 == d ? 0x80000000u : 0u);
+                        g.sadr[size_t(p) * 2] = g.cvar[eo] * 8u;
+                        g.sadr[size_t(p) * 2 + 1] = 8u * N + cs * 8u;
+                        g.bhead[b * 2] |= 1ull << (p & 63);
+                        if (j + 1 == d) g.bhead[b * 2 + 1] |= 1ull << (p & 63);
                         for (uint32_t s2 = 0; s2 < d; ++s2)
                             if (s2 != j) g.bmask[b * size_t(g.DM) + s2] |= 1ull << (p & 63);
                     }

@@ -54,8 +54,9 @@ struct LdpcGraph {
     // product walk's execution masks tabulated per bin and step instead of compared per lane
     int maxdeg = 0;                // largest check degree
     int DM = 0;                    // mask row length: the largest check degree rounded up to a pair of steps, plus one all-zero pair (ends the walk)
-    std::vector<uint32_t> sdesc2;  // [(ceil(S/1024)+1)*1024] (check_start*8 | 2) | (variable*8)<<16 | last-edge-of-check<<31, 0 for padding
-    std::vector<uint64_t> bmask;   // [ceil(S/1024)*16 bins][DM] lanes of the bin that multiply factor j in: position != j and degree > j (0 past the bin's largest degree)
+    std::vector<uint32_t> sadr;    // [(rounds+1)*1024][2] per padded slot: LDS byte offset of its variable's posterior (variable*8), LDS byte address of its check's first message (8*N + check_start*8); 0 for padding
+    std::vector<uint64_t> bhead;   // [(rounds+1)*16 bins][2] lanes in use, lanes holding the last edge of a check
+    std::vector<uint64_t> bmask;   // [rounds*16 bins][DM] lanes of the bin that multiply factor j in: position != j and degree > j (0 past the bin's largest degree)
     std::vector<uint32_t> vinfo2;  // [N][8] like vinfo with byte offsets (slot*8) in the 10 u16 fields
 };
 
