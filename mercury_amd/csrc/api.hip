@@ -118,26 +118,16 @@ void ctx_alloc(mgpu_ctx* c) {
     switch (c->cfg.decoder) {
         case MGPU_DEC_SPA:
             c->lds_dec = mgpu_spa_lds_bytes(d.S, d.N);
-            switch ((d.S + 1023) / 1024) {
-                case 1: case 2: case 3: case 4: c->spa_kernel = mgpu_ldpc_spa_kernel_ne4; break;
-                case 5: c->spa_kernel = mgpu_ldpc_spa_kernel_ne5; break;
-                case 6: c->spa_kernel = mgpu_ldpc_spa_kernel_ne6; break;
-                case 7: c->spa_kernel = mgpu_ldpc_spa_kernel_ne7; break;
-                case 8: c->spa_kernel = mgpu_ldpc_spa_kernel_ne8; break;
-                default: throw std::runtime_error("graph too large for the sum-product kernel");
-            }
             {
-                const char* e = std::getenv("MERCURY_SPA_VARIANT");      // experiment knob: 1 = the round-2 kernel
-                if (!e || std::atoi(e) != 1) {
-                    const int ne = std::max(4, (d.S + 1023) / 1024);
-                    if (t.graph.maxdeg > mgpu_spa2_max_degree(ne)) throw std::runtime_error("check degree exceeds the sum-product kernel's unrolled product walk");
-                    switch (ne) {
-                        case 4: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne4; break;
-                        case 5: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne5; break;
-                        case 6: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne6; break;
-                        case 7: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne7; break;
-                        default: c->spa_kernel = mgpu_ldpc_spa2_kernel_ne8; break;
-                    }
+                const int ne = std::max(4, (d.S + 1023) / 1024);      // rounds of 16 bins; the smallest instance runs 4 (tables sized to match)
+                if (ne > 8) throw std::runtime_error("graph too large for the sum-product kernel");
+                if (t.graph.maxdeg > mgpu_spa_max_degree(ne)) throw std::runtime_error("check degree exceeds the sum-product kernel's unrolled product walk");
+                switch (ne) {
+                    case 4: c->spa_kernel = mgpu_ldpc_spa_kernel_ne4; break;
+                    case 5: c->spa_kernel = mgpu_ldpc_spa_kernel_ne5; break;
+                    case 6: c->spa_kernel = mgpu_ldpc_spa_kernel_ne6; break;
+                    case 7: c->spa_kernel = mgpu_ldpc_spa_kernel_ne7; break;
+                    default: c->spa_kernel = mgpu_ldpc_spa_kernel_ne8; break;
                 }
             }
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
@@ -149,9 +139,9 @@ void ctx_alloc(mgpu_ctx* c) {
         case MGPU_DEC_MINSUM: {
             c->lds_dec = mgpu_minsum_lds_bytes(d.S, d.N);
             if (d.S > 8 * 1024) throw std::runtime_error("graph too large for the min-sum kernel");
-            const char* e = std::getenv("MERCURY_SPA_FAST_THREADS");
+            const char* e = std::getenv("MERCURY_MINSUM_THREADS");
             c->dec_threads = e ? std::atoi(e) : 512;
-            if (c->dec_threads != 512 && c->dec_threads != 1024) throw std::runtime_error("MERCURY_SPA_FAST_THREADS must be 512 or 1024");
+            if (c->dec_threads != 512 && c->dec_threads != 1024) throw std::runtime_error("MERCURY_MINSUM_THREADS must be 512 or 1024");
             c->spa_kernel = c->dec_threads == 512 ? mgpu_ldpc_minsum_kernel_t512 : mgpu_ldpc_minsum_kernel_t1024;
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
@@ -1132,11 +1122,12 @@ static void rx_batch_pipelined(mgpu_ctx* c, const double* bb, int F, uint8_t* pa
     // chunk size: a decoder launch keeps the whole chip busy only from 2 workgroups per CU upwards (512 codewords on 256 CUs; a
     // smaller launch takes just as long), and a copy should carry a few MB; so chunks are multiples of that wave of workgroups
     // and a batch that is not larger than one chunk goes through in one piece.
-    static const int wave_of_wgs = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return 2 * (cus > 0 ? cus : 256);
-    }();
+    if (c->wave_of_wgs == 0) {           // per context: the devices of a pool need not be alike
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device);
+        c->wave_of_wgs = 2 * (cus > 0 ? cus : 256);
+    }
+    const int wave_of_wgs = c->wave_of_wgs;
     int chunk = wave_of_wgs;
     while (size_t(chunk) * frame_bytes < (size_t(8) << 20)) chunk += wave_of_wgs;
     if (const char* e = std::getenv("MERCURY_RX_CHUNK")) chunk = std::max(1, std::atoi(e));

@@ -54,9 +54,8 @@ extern "C" __global__ void mgpu_span_energy_many_kernel(const double*, int, cons
 extern "C" __global__ void mgpu_window_energy_kernel(const double*, int, int, double*);
 extern "C" __global__ void mgpu_select_peak_kernel(const double*, const int*, int, int, const int*, const int*, int, int, int*, double*);
 extern "C" __global__ void mgpu_decimate_kernel(const double*, int, const int*, const int*, const int*, int, int, double*);
-#define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*); \
-    extern "C" __global__ void mgpu_ldpc_spa2_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-extern "C" int mgpu_spa2_max_degree(int ne);
+#define DECL_SPA(NE) extern "C" __global__ void mgpu_ldpc_spa_kernel_ne##NE(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
+extern "C" int mgpu_spa_max_degree(int ne);     // largest check degree the ne-round instance's unrolled product walk covers
 DECL_SPA(4) DECL_SPA(5) DECL_SPA(6) DECL_SPA(7) DECL_SPA(8)
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double*, double*, double*, int);
 extern "C" __global__ void mgpu_glibc_trig_probe_kernel(const double*, double*, double*, double*, int);
@@ -146,6 +145,7 @@ struct mgpu_ctx {
     int fe_threads = 512;           // front-end workgroup size: 1024 when only one workgroup fits a compute unit's LDS anyway (long BPSK frames)
     DecoderKernel spa_kernel = nullptr;
     int dec_threads = 1024;         // workgroup size of the decoder kernel
+    int wave_of_wgs = 0;            // decoder workgroups that fill the device once (2 per compute unit); 0 = not asked yet
 
     template <typename T>
     T* keep(T* p) { owned.push_back(p); return p; }

@@ -95,223 +95,22 @@ extern "C" size_t mgpu_spa_lds_bytes(int S, int N) {
 // The syndrome costs nothing extra: in that pass every lane holds the posterior of its edge's
 // variable, one 64-bit ballot of the sign bits gives every check its parity.
 // Per iteration: [syndrome +] tanh + check update | barrier | variable update | barrier [| syndrome | barrier | verdict].
-// Slot descriptors (check start, degree, variable: one word per slot, T.sdesc) are shared by every
-// codeword; a wave fetches the word of its next bin while it works on the current one (one coalesced
-// cached load per bin), so no descriptor lives in registers or scratch across the loop.
 //
-// Instruction budget (profiles/r02_valu_cycles.json, r02_spa_instruction_mix.json): the kernel is bound by
-// vector-instruction issue; an fp64 operation costs 4 cycles per wavefront, v_rcp_f64 16, a 32-bit
-// integer/select operation 2-4. Per edge and iteration the reference's arithmetic needs ~105 fp64
-// operations + 5 reciprocal seeds (spa_math.h); everything else in the loop is kept to a few dozen
-// 32-bit operations: padding lanes and fdlibm's case distinctions are execution-mask branches (scalar
-// instructions only), not selects.
+// Instruction budget (profiles/r03_instruction_mix.json, r02_valu_cycles.json): a wavefront alone keeps its SIMD busy about a
+// quarter of the time and eight of them reach 81 %, so every instruction of the loop counts, scalar ones included. Per edge and
+// iteration the reference's arithmetic needs ~105 fp64 operations + 5 reciprocal seeds (spa_math.h). Round 3 moved what was not
+// that arithmetic out of the vector unit (174 -> 157 vector instructions per 64-slot bin-iteration, 2.89 G per headline launch):
+//   * per-slot addresses come from a table (LdpcGraph::sadr: LDS offset of the slot's posterior, LDS address of its check's first
+//     message), one buffer load per round with the round offset in a scalar: no field extraction, no lane needs its degree or its
+//     position inside the check;
+//   * what is uniform over a bin comes through scalar loads from constant-address-space pointers: the lanes in use and the lanes
+//     ending a check (bhead) and, per product-walk step, the lanes that multiply that factor in (bmask: position != step and
+//     degree > step, tabulated on the host). "valid" is the bin's lane mask applied as exec (inverse ballot); a walk step is one
+//     LDS broadcast read + one v_mul_f64 under s_and_b64 exec - no compare; the walk ends at the first all-zero mask;
+//   * padding lanes and fdlibm's case distinctions are execution-mask branches (scalar instructions only), not selects;
+//   * variable records carry LDS byte offsets and come through buffer loads (rows past N read as zeros = degree 0).
 constexpr int kN = 1600;             // every Mercury code has N = 1600 (checked on the host); fixes the LDS layout below
 
-template <int NE>
-__device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
-                                           uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
-                                           uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
-                                           const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int S = T.S;
-    constexpr int N = kN;
-    // LLRtmp first, at a compile-time offset, then the messages: every LDS address in the loop is one shift/mask of a
-    // descriptor field plus an immediate offset
-    double* Lt = reinterpret_cast<double*>(smem);     // LLRtmp per variable
-    double* M = Lt + N;                               // R or T per padded edge slot
-    float* Li = reinterpret_cast<float*>(M + S);      // channel LLR
-    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
-    uint8_t* bytes = hard + ((N + 15) & ~15);
-    int* flag = reinterpret_cast<int*>(bytes + 256);
-
-    const int tid = threadIdx.x, f = blockIdx.x;
-    if (f >= F) return;
-    const float* lin = llr_in + size_t(f) * N;
-    for (int v = tid; v < N; v += LDPC_THREADS) {
-        const float l = lin[v];
-        Li[v] = l;
-        Lt[v] = l;
-    }
-    for (int p = tid; p < S; p += LDPC_THREADS) M[p] = 0.0;     // R = 0 before the first iteration (:106-122)
-    // slot descriptor (T.sdesc, NE+1 rounds of 1024 words, zero = padding):
-    //   check_start(13) | deg(6)<<13 | variable(11)<<19 | last-edge-of-its-check<<31 ; deg == 0 marks padding.
-    // The slot's position inside its check is p - check_start.
-    const uint32_t* __restrict__ sdesc = T.sdesc;
-    // variable records (variable | deg<<11, then 10 u16 slot indices in the reference's slot order)
-    struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
-    // The records are fetched again in every iteration (two cached loads per lane, issued ahead of the barrier they hide
-    // behind) rather than held in 12 registers across the check-node pass, which needs all 64 of them.
-    auto load_var = [&](const uint32_t* vinfo, int i) -> VarRec {
-        if (i >= N) return VarRec{0, 0, 0, 0, 0, 0};
-        const uint4 lo = *reinterpret_cast<const uint4*>(vinfo + size_t(i) * 8);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vinfo + size_t(i) * 8 + 4);
-        return VarRec{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
-    };
-    // LLRtmp = LLR + R[slot 0] + R[slot 1] + ... in slot order (:162-170). Every "does this variable have a slot j" test is
-    // a branch on the execution mask (the rows are sorted by degree, so most wavefronts agree and skip whole blocks);
-    // deg is made opaque so that the nine lane masks are recomputed (one compare each) instead of being kept alive
-    // across the whole decode, where they do not fit the scalar register file.
-    auto var_update = [&](const VarRec& q) {
-        const uint32_t v = q.vi & 0x7ff;
-        uint32_t deg = q.vi >> 11;
-        asm volatile("" : "+v"(deg));
-        double s = Li[v];
-        if (deg > 0) { s += M[q.w0 & 0xffff]; SPA_KEEP(s); }
-        if (deg > 1) { s += M[q.w0 >> 16]; SPA_KEEP(s); }
-        if (deg > 2) {
-            s += M[q.w1 & 0xffff]; SPA_KEEP(s);
-            if (deg > 3) { s += M[q.w1 >> 16]; SPA_KEEP(s); }
-            if (deg > 4) { s += M[q.w2 & 0xffff]; SPA_KEEP(s); }
-            if (deg > 5) {
-                s += M[q.w2 >> 16]; SPA_KEEP(s);
-                if (deg > 6) { s += M[q.w3 & 0xffff]; SPA_KEEP(s); }
-                if (deg > 7) { s += M[q.w3 >> 16]; SPA_KEEP(s); }
-                if (deg > 8) { s += M[q.w4 & 0xffff]; SPA_KEEP(s); }
-            }
-        }
-        Lt[v] = s;
-    };
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
-    __syncthreads();
-
-    // Does any check of this wave's bin have odd parity? m = sign bits of the posteriors of the bin's 64 edges (a check
-    // is a run of consecutive lanes, padding lanes contribute 0), ends = the lanes holding the last edge of a check.
-    // With px = prefix XOR of m, check i spanning lanes (e[i-1], e[i]] has parity px[e[i]] ^ px[e[i-1]], so all
-    // parities are even <=> px is 0 at every check end. Scalar instructions only (ballots are wave-uniform).
-    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
-        m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
-        return (m & ends) != 0;
-    };
-
-    // Pass p (0 = channel values, 1..max = after iteration p) leaves its syndrome verdict in flag[p & 1].
-    auto syndrome_pass = [&](int p) {
-        bool unsat = false;
-        uint32_t k = sdesc[tid];
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t kn = sdesc[(r + 1) * LDPC_THREADS + tid];
-            const unsigned long long vmask = __ballot(((k >> 13) & 0x3f) != 0);
-            const double lt = Lt[(k >> 19) & 0x7ff];                 // padding reads variable 0; masked out below
-            unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
-            k = kn;
-        }
-        if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
-    };
-    // cn_pass: Q = LLRtmp - R (:193-209) -> T = tanh(0.5*Q) (:145) -> product of the others, clamp, R = 2*atanh (:129-160),
-    // all inside the wavefront that owns the bin; with_syndrome additionally judges the posteriors it reads (pass p)
-    auto cn_pass = [&](bool with_syndrome, int p) {
-        bool unsat = false;
-        uint32_t k = sdesc[tid];
-        uint32_t slot = tid;
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r, slot += LDPC_THREADS) {
-            const uint32_t kn = sdesc[(r + 1) * LDPC_THREADS + tid];
-            const uint32_t deg = (k >> 13) & 0x3f;
-            const bool valid = deg != 0;
-            const unsigned long long vmask = __ballot(valid);
-            if (vmask == 0) { k = kn; continue; }                    // an empty bin (only in the last round)
-            double lt;
-            if (valid) lt = Lt[(k >> 19) & 0x7ff];
-            if (with_syndrome) unsat |= bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
-            if (valid) M[slot] = spa_tanh_half(lt - M[slot]);
-            __builtin_amdgcn_wave_barrier();        // every lane's T is written (LDS operations of a wave complete in order)
-            double rr;
-            if (valid) {
-                // Product of the check's OTHER T values in slot order, starting from 1.0, as the reference multiplies them.
-                // Every lane of a check walks the check's slots in order (all read the same word: a broadcast) and the lane
-                // whose own slot comes up sits that step out under the execution mask; the wave runs to the largest degree
-                // in the bin (its first check: bins are filled in order of decreasing degree) and lanes of shorter checks
-                // drop out at their own degree, a test only needed from the smallest degree in the bin (its last check) on.
-                const double* chk = M + (k & 0x1fff);
-                const uint32_t pos = slot - (k & 0x1fff);
-                const uint32_t dmax = __builtin_amdgcn_readfirstlane(deg);
-                const uint32_t dmin = __builtin_amdgcn_readlane(deg, 63 - __builtin_clzll(vmask));
-                double temp = 1;
-                auto step = [&](uint32_t j) {
-                    const double a = chk[j];
-                    bool use = j != pos;
-                    if (j >= dmin) use = use && j < deg;
-                    if (use) { temp *= a; SPA_KEEP(temp); }
-                };
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) {
-                    if (j >= dmax) break;
-                    step(j);
-                }
-#pragma unroll 1
-                for (uint32_t j = 8; j < dmax; ++j) step(j);
-                rr = spa_atanh_x2(temp);              // clamps +-1 to +-0.9999999 first (:150-155)
-            }
-            __builtin_amdgcn_wave_barrier();        // every lane of this wave has read its check's T values
-            if (valid) M[slot] = rr;
-            k = kn;
-        }
-        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
-    };
-    // The first kSpecStart passes are judged exactly: syndrome | barrier | verdict, and only unconverged frames
-    // pay for the next tanh + check update (at the operating SNRs most frames stop within a few iterations, so
-    // nothing is computed in vain). From then on a frame is likely to run long and the syndrome rides along with
-    // the next check-node pass (which reads the same posteriors); its verdict is read behind the barrier that
-    // follows. On convergence that speculative pass is simply dropped: it never touches the posteriors.
-    // That saves one barrier and one sweep over the edges per iteration where iterations are many.
-    constexpr int kSpecStart = 8;
-    int iteration = 0;
-    syndrome_pass(0);                                   // initial syndrome (ldpc_decoder_SPA.cc:62-76)
-    __syncthreads();
-    if (flag[0]) {
-        for (int it = 1;; ++it) {
-            const bool spec = it - 1 >= kSpecStart;     // this pass carries the syndrome of pass it-1
-            if (it <= T.max_iters) cn_pass(spec, it - 1);
-            else syndrome_pass(it - 1);                 // only reachable with spec: the last verdict is still open
-            const uint32_t* vinfo = T.vinfo;
-            asm volatile("" : "+s"(vinfo));             // a fresh fetch per iteration, not 12 registers kept (and spilled) across the loop
-            const VarRec va = load_var(vinfo, tid), vb = load_var(vinfo, tid + LDPC_THREADS);
-            __syncthreads();
-            if (spec) {
-                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
-                if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
-            }
-            if (tid == 0) flag[it & 1] = 0;
-            // variable update (:162-170): variables sorted by degree so a wave's lanes run the same trip count;
-            // each lane owns variables tid and tid+1024 of that order
-            var_update(va);
-            if (tid + LDPC_THREADS < N) var_update(vb);
-            __syncthreads();
-            if (it < kSpecStart) {
-                syndrome_pass(it);                      // (:173-190)
-                __syncthreads();
-                if (!flag[it & 1]) { iteration = it; break; }
-                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
-            }
-        }
-    }
-    for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
-    __syncthreads();
-    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
-}
-
-#define SPA_KERNEL(NE)                                                                                          \
-    extern "C" __global__ __launch_bounds__(LDPC_THREADS, 8) void mgpu_ldpc_spa_kernel_ne##NE(                \
-        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                     \
-        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,   \
-        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                     \
-        spa_decode<NE>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
-    }
-SPA_KERNEL(4)
-SPA_KERNEL(5)
-SPA_KERNEL(6)
-SPA_KERNEL(7)
-SPA_KERNEL(8)
-
-// ---------------------------------------------------------------------------------------------
-// Round-3 form of the same decoder (same arithmetic, same schedule): the vector instructions that were not the
-// reference's fp64 arithmetic are moved to the scalar unit or into the tables.
-//   * descriptor = LDS byte offsets ((check_start*8 | 2) | (variable*8)<<16 | last<<31): one AND / one BFE gives an address,
-//     "valid" is descriptor != 0, and no lane needs its degree or its position inside the check any more;
-//   * the product walk's "does this lane take factor j" is a property of the bin, tabulated on the host (LdpcGraph::bmask):
-//     the wave loads four 64-bit masks with one scalar load and runs v_mul_f64 under them (s_and_b64 exec), so a step
-//     is one LDS broadcast read + one multiplication, no compare; the walk ends at the first all-zero mask;
-//   * variable records carry byte offsets too.
 __device__ __forceinline__ void spa_masked_mul2(double& t, double a0, double a1, uint64_t m0, uint64_t m1) {
     uint64_t sv;
     asm volatile(
@@ -360,7 +159,7 @@ __device__ __forceinline__ void spa_walk4(double& temp, uint32_t achk, spa_cptr6
 }
 
 template <int NE, int DMX>
-__device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
+__device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
                                             uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
                                             uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
                                             const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
@@ -431,14 +230,14 @@ __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __res
     // the walk masks (bmask); "valid" is the bin's lane mask applied as exec.
     const __amdgpu_buffer_rsrc_t sadr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.sadr), 0, 0x7fffffff, 0x00020000);
     constexpr int kRound = LDPC_THREADS * 8;                       // bytes of address table per round
-    const spa_cptr64 bhead0 = (spa_cptr64)(T.bhead) + size_t(wave) * 2;
+    const spa_cptr64 bhead0 = (spa_cptr64)(T.bhead) + size_t(wave) * 4;
 
     auto syndrome_pass = [&](int p) {
         bool unsat = false;
         spa_cptr64 bh = bhead0;
         uint32_t alt = __builtin_amdgcn_raw_buffer_load_b32(sadr, tid * 8, 0, 0);
 #pragma unroll 1
-        for (int r = 0; r < NE; ++r, bh += 32) {
+        for (int r = 0; r < NE; ++r, bh += 64) {
             const uint32_t altn = __builtin_amdgcn_raw_buffer_load_b32(sadr, tid * 8, (r + 1) * kRound, 0);
             const unsigned long long vmask = bh[0], ends = bh[1];
             const double lt = *ldsd(alt);                              // padding reads variable 0; masked out below
@@ -459,11 +258,9 @@ __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __res
         for (int r = 0; r < NE; ++r, own += LDPC_THREADS * 8, bm += bm_step) {
             const uint32_t alt = ad.x, achk = ad.y;
             const unsigned long long vm = vmask, en = ends;
-            bh += 32;
+            bh += 64;
             vmask = bh[0]; ends = bh[1];                              // next round's bin (the table has one spare round)
             if (vm == 0) continue;                                    // an empty bin: only in the last round, nothing follows it
-            uint64_t m0 = bm[0], m1 = bm[1], m2 = 0, m3 = 0;           // masks of the first walk steps, behind the tanh
-            if constexpr (DMX > 16) { m2 = bm[2]; m3 = bm[3]; }
             const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
             double lt;
             if (valid) lt = *ldsd(alt);
@@ -475,8 +272,8 @@ __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __res
             // tabulated mask for that step (own slot, slots past the check's degree and padding lanes excluded).
             // Uniform control flow: the masks come through scalar loads, padding lanes read slot 0 and never multiply.
             double temp = 1;
-            if constexpr (DMX > 16) spa_walk4<0, DMX / 4>(temp, achk, bm, m0, m1, m2, m3);
-            else spa_walk<0, DMX / 2>(temp, achk, bm, m0, m1);
+            if constexpr (DMX > 16) spa_walk4<0, DMX / 4>(temp, achk, bm, bm[0], bm[1], bm[2], bm[3]);
+            else spa_walk<0, DMX / 2>(temp, achk, bm, bm[0], bm[1]);
             // the next round's addresses land in the registers this round is done with, behind the atanh (the table has a spare round)
             ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, tid * 8, (r + 1) * kRound, 0);
             double rr;
@@ -518,19 +315,19 @@ __device__ __forceinline__ void spa2_decode(const LdpcDev& T, const float* __res
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
 }
 
-#define SPA2_KERNEL(NE, DMX)                                                                                    \
-    extern "C" __global__ __launch_bounds__(LDPC_THREADS, 8) void mgpu_ldpc_spa2_kernel_ne##NE(               \
+#define SPA_KERNEL(NE, DMX)                                                                                    \
+    extern "C" __global__ __launch_bounds__(LDPC_THREADS, 8) void mgpu_ldpc_spa_kernel_ne##NE(               \
         LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                     \
         int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,   \
         const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                     \
-        spa2_decode<NE, DMX>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
+        spa_decode<NE, DMX>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
     }
-SPA2_KERNEL(4, 16)
-SPA2_KERNEL(5, 16)
-SPA2_KERNEL(6, 16)
-SPA2_KERNEL(7, 16)
-SPA2_KERNEL(8, 48)
-extern "C" int mgpu_spa2_max_degree(int ne) { return ne == 8 ? 48 : 16; }
+SPA_KERNEL(4, 16)
+SPA_KERNEL(5, 16)
+SPA_KERNEL(6, 16)
+SPA_KERNEL(7, 16)
+SPA_KERNEL(8, 48)
+extern "C" int mgpu_spa_max_degree(int ne) { return ne == 8 ? 48 : 16; }
 
 // ---------------------------------------------------------------------------------------------
 // Sum-product, single precision ("spa_fast"; BASELINE.json north_star's fast variant, SURVEY.md §7.3-1: "SPA-equivalent

@@ -136,7 +136,11 @@ struct Loop {
           upper(buffer_nsymb - (t.Nsymb + t.preamble)), ngi_i(t.Ngi * kInterp), nfft_i(t.Nfft * kInterp), L(t.preamble * t.Nofdm * kInterp),
           mfsk(t.mfsk_M > 0), s(ctx->stream), rc(rc_), ws(workspace(ctx, W_, buffer_nsymb)),
           d_pass(ws.d_pass), d_bbi(ws.d_bbi), d_frames(ws.d_frames), d_carrier(ws.d_carrier), d_ia(ws.d_ia), d_ib(ws.d_ib), d_ic(ws.d_ic),
-          d_vals(ws.d_vals), d_sum(ws.d_sum), d_cnt(ws.d_cnt), d_freq(ws.d_freq), d_meanh(ws.d_meanh), carrier(W_, rc_.carrier_hz) {}
+          d_vals(ws.d_vals), d_sum(ws.d_sum), d_cnt(ws.d_cnt), d_freq(ws.d_freq), d_meanh(ws.d_meanh), carrier(W_, rc_.carrier_hz) {
+        // a call that threw between down_async() and settle() leaves entries whose destinations were its stack vectors: never replay them
+        ws.pending.clear();
+        ws.pin_off = 0;
+    }
 
     bool in_bounds(int p) const { return p > lower && p < upper; }
 
@@ -465,7 +469,6 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
         pt.mark(s, "signal strength");
         std::vector<char> live(W, 1);                             // still on the way to the trial loop
         std::vector<char> fixed_delay(W, 0);
-        if (state && !lp.mfsk) for (int w = 0; w < W; ++w) need(state[w].fixed_delay_plus_one <= 0, "fixed_delay_plus_one: MFSK modes only");
         if (lp.mfsk) {
             // cl_ofdm::time_sync_mfsk (ofdm.cc:2011-2061): slot energies and the preamble-tone search, both where the baseband lies; only the
             // delays come back. Windows with a known delay (:663-672 mfsk_fixed_delay, used once, no signal level) need neither.
@@ -737,6 +740,8 @@ extern "C" int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int 
         need(passband && rcp && payload && stats && W > 0 && W <= c->max_batch, "bad argument (W must be 1..max_batch)");
         need(rcp->time_sync_trials_max >= 1 && rcp->time_sync_trials_max < 64,
              "time_sync_trials_max must be 1..63 (0 makes the reference index its peak table at -1)");
+        // every argument is judged before the first copy or kernel is queued: an error return leaves nothing in flight and no state[] entry touched
+        if (state && c->tab.mfsk_M == 0) for (int w = 0; w < W; ++w) need(state[w].fixed_delay_plus_one <= 0, "fixed_delay_plus_one: MFSK modes only");
         // Windows in host memory: bringing 1024 mode-8 windows over PCIe takes 13.5 ms and the synchroniser + decoder another 17 ms.
         // The windows are independent, so the call is cut into sub-batches: a helper thread uploads them one after another into a
         // staging buffer (a copy from pageable memory holds its calling thread), this thread runs the whole receive_byte on each

@@ -168,8 +168,6 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         }
         g.S = int(fill.size()) * 64;
         if (g.S >= 8192) throw std::runtime_error("padded edge count exceeds the 13-bit slot field");
-        g.spack.assign(g.S, 0u);
-        g.svar.assign(g.S, 0);
         // one extra all-padding round: the kernels always prefetch round r+1; never fewer than the 4 rounds of the smallest kernel instance
         g.sdesc.assign(size_t(std::max(4, (g.S + 1023) / 1024) + 1) * 1024, 0u);
         std::vector<uint32_t> slot_of_edge(E);
@@ -179,8 +177,6 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
                 const uint32_t cs = p, d = cdeg[c];
                 for (uint32_t j = 0; j < d; ++j, ++p) {
                     const uint32_t eo = g.cptr[c] + j;
-                    g.spack[p] = cs | (d << 13) | (j << 19) | 0x80000000u;
-                    g.svar[p] = g.cvar[eo];
                     g.sdesc[p] = cs | (d << 13) | (uint32_t(g.cvar[eo]) << 19) | (j + 1 == d ? 0x80000000u : 0u);
                     slot_of_edge[eo] = p;
                 }
@@ -205,10 +201,10 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
             int maxdeg = 0;
             for (uint32_t c = 0; c < P; ++c) maxdeg = std::max(maxdeg, int(cdeg[c]));
             g.maxdeg = maxdeg;
-            g.DM = ((maxdeg + 3) & ~3) + 4;      // groups of (two or) four steps, and one all-zero group that ends the walk
+            g.DM = ((maxdeg + 7) & ~7) + 8;      // the walk runs in groups of (two, four or) eight steps; an all-zero group ends it
             const size_t rounds = size_t(std::max(4, (g.S + 1023) / 1024));    // the smallest kernel instance runs 4 rounds
             g.sadr.assign((rounds + 1) * 1024 * 2, 0u);
-            g.bhead.assign((rounds + 1) * 16 * 2, 0ull);
+            g.bhead.assign((rounds + 1) * 16 * 4, 0ull);
             g.bmask.assign(rounds * 16 * size_t(g.DM), 0ull);
             for (size_t b = 0; b < members.size(); ++b) {
                 uint32_t p = uint32_t(b) * 64;
@@ -218,8 +214,9 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
                         const uint32_t eo = g.cptr[c] + j;
                         g.sadr[size_t(p) * 2] = g.cvar[eo] * 8u;
                         g.sadr[size_t(p) * 2 + 1] = 8u * N + cs * 8u;
-                        g.bhead[b * 2] |= 1ull << (p & 63);
-                        if (j + 1 == d) g.bhead[b * 2 + 1] |= 1ull << (p & 63);
+                        g.bhead[b * 4] |= 1ull << (p & 63);
+                        if (j + 1 == d) g.bhead[b * 4 + 1] |= 1ull << (p & 63);
+                        g.bhead[b * 4 + 2] = std::max<uint64_t>(g.bhead[b * 4 + 2], d);
                         for (uint32_t s2 = 0; s2 < d; ++s2)
                             if (s2 != j) g.bmask[b * size_t(g.DM) + s2] |= 1ull << (p & 63);
                     }

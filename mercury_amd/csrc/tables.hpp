@@ -46,16 +46,14 @@ struct LdpcGraph {
     // wave-private layout for the sum-product kernel: whole checks bin-packed (first-fit decreasing)
     // into 64-slot bins so that one wavefront owns every edge of the checks it updates
     int S = 0;                     // padded slot count = 64 * bins
-    std::vector<uint32_t> spack;   // [S] check_start_slot | deg<<13 | pos<<19 | valid<<31 (0 for padding)
-    std::vector<uint16_t> svar;    // [S] variable of the slot's edge (0 for padding)
     std::vector<uint32_t> sdesc;   // [(ceil(S/1024)+1)*1024] what the decoders read per slot: check_start | deg<<13 | variable<<19 | last-edge-of-check<<31, 0 for padding
     std::vector<uint32_t> vinfo;   // [N][8] (6 used) variable | deg<<11, then 10 u16 padded-slot indices; rows sorted by degree (descending)
     // the fp64 sum-product kernel's own tables (ldpc.hip, spa_decode): LDS byte offsets instead of indices, and the
     // product walk's execution masks tabulated per bin and step instead of compared per lane
     int maxdeg = 0;                // largest check degree
-    int DM = 0;                    // mask row length: the largest check degree rounded up to a pair of steps, plus one all-zero pair (ends the walk)
+    int DM = 0;                    // mask row length: the largest check degree rounded up to a multiple of 8 (the walk's group size)
     std::vector<uint32_t> sadr;    // [(rounds+1)*1024][2] per padded slot: LDS byte offset of its variable's posterior (variable*8), LDS byte address of its check's first message (8*N + check_start*8); 0 for padding
-    std::vector<uint64_t> bhead;   // [(rounds+1)*16 bins][2] lanes in use, lanes holding the last edge of a check
+    std::vector<uint64_t> bhead;   // [(rounds+1)*16 bins][4] lanes in use, lanes holding the last edge of a check, largest check degree in the bin, 0
     std::vector<uint64_t> bmask;   // [rounds*16 bins][DM] lanes of the bin that multiply factor j in: position != j and degree > j (0 past the bin's largest degree)
     std::vector<uint32_t> vinfo2;  // [N][8] like vinfo with byte offsets (slot*8) in the 10 u16 fields
 };

@@ -367,6 +367,10 @@ int mgpu_transmit_byte_batch_dev(mgpu_ctx* c, const void* d_payload, int payload
     return guard(c, [&] {
         check_config(c, cfg, payload_stride, F);
         need(d_payload && d_passband, "bad argument");
+        // the FIRST / MIDDLE / FLUSH messages of a stream share the context's three-frame history: calls on different streams would
+        // race on it, so a stream call of the overlap-save kind must run on the context's own stream (stream == NULL)
+        need(!stream || cfg->message_location == MGPU_SINGLE_MESSAGE || cfg->message_location == MGPU_NO_FILTER_MESSAGE,
+             "FIRST / MIDDLE / FLUSH messages carry state between calls: pass stream = NULL (the context's stream)");
         if (F == 0) return;
         transmit_dev(c, static_cast<const uint8_t*>(d_payload), payload_stride, static_cast<const int*>(d_nbytes), F, *cfg,
                      static_cast<double*>(d_passband), stream ? static_cast<hipStream_t>(stream) : c->stream);

@@ -415,7 +415,6 @@ class RxPhy:
             raise MgpuError("the transmit buffer is 3 frames = %d samples" % n)
         self._ck(self.lib.mgpu_transmit_buffer(self.h, _ptr(b), C.c_int(1)))
         return b
-        return b
 
     def transmit_byte(self, payload, carrier_hz, nbytes=None, **kw):
         """cl_telecom_system::transmit_byte for F messages: payload uint8 [F, >= payload_bytes] -> float64 [F, total_frame_size]."""

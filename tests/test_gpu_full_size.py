@@ -49,6 +49,19 @@ def test_configs3_mode16_one_million_frames_multipath_round_trip():
     rx.receive_dev(bb[F // 2:].data_ptr(), F // 2, got2.data_ptr(), stats2.data_ptr(), stream=s)
     torch.cuda.synchronize()
     assert torch.equal(got2, got[F // 2:]) and torch.equal(stats2[:, :4], stats[F // 2:, :4])
+    # and the CPU oracle on a sample of the very same frames (first / middle / last + one frame that did not decode, if any):
+    # payload bytes, iteration count, CRC and all-zeros flag identical
+    import oraclelib
+    orc = oraclelib.Oracle(cfg, 50)
+    sample = [0, F // 2, F - 1]
+    failed = torch.nonzero(~decoded)
+    if failed.numel():
+        sample.append(int(failed[0].item()))
+    for f in sample:
+        ref = orc.rx(bb[f].cpu().numpy().view(np.complex128).reshape(-1), oraclelib.FLAGS_BASEBAND_TEST)
+        assert np.array_equal(got[f].cpu().numpy(), ref["bytes"].astype(np.uint8)), (cfg, f)
+        st = stats[f].cpu().numpy()
+        assert (int(st[0]), int(st[1]), int(st[2])) == (ref["iterations"], ref["crc"], ref["all_zeros"]), (cfg, f)
     del bb
     rx.close()
 
@@ -83,6 +96,13 @@ def test_configs4_ldpc_soak_share_of_one_gpu(iters):
         sums.append((int(bits.to(torch.int64).sum().item()), int((bits.view(torch.int64) if rx.K % 8 == 0 else bits.to(torch.int64)).sum().item())))
     assert sums[0] == sums[-1]
     assert 0.45 < sums[0][0] / (F * rx.K) < 0.55                                          # hard decisions of noise: about half ones
+    # the CPU oracle's decoder on the first / middle / last codeword of the very same buffer: hard bits and iteration count identical
+    import oraclelib
+    orc = oraclelib.Oracle(cfg, iters)
+    for f in (0, F // 2, F - 1):
+        ref_bits, ref_it = orc.ldpc_decode(llr[f].cpu().numpy())
+        assert int(its[f].item()) == ref_it, (iters, f)
+        assert np.array_equal(bits[f].cpu().numpy(), ref_bits.astype(np.uint8)), (iters, f)
     del llr
     rx.close()
 
