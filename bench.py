@@ -34,7 +34,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from mercury_amd import DEC_GBF, DEC_MINSUM, DEC_SPA, DEC_SPA_FAST, RxPhy
+from mercury_amd import DEC_GBF, DEC_MINSUM, DEC_SPA, DEC_SPA_FAST, RxPhy, RxPool, STATS_DTYPE
 
 DECODERS = {"spa": DEC_SPA, "minsum": DEC_MINSUM, "gbf": DEC_GBF, "spa_fast": DEC_SPA_FAST}
 from mercury_amd.sharding import frame_range
@@ -51,6 +51,57 @@ def algorithmic_bytes(rx, iters_exec_sum, frames):
     ldpc = frames * (4 * rx.N + b_out) + iters_exec_sum * b_iter       # what the decoder kernel itself moves
     total = frames * (b_in + 4 * rx.N + b_out) + iters_exec_sum * b_iter
     return ldpc, total, b_iter
+
+
+def profile_mix(decoder, args, F):
+    """The committed PMC passes of one decoder launch of the headline workload (tools/collect_pmc_mix.sh), or None when they
+    were taken from another build of the decoder kernels than the one being timed (stamp = mercury_amd.build.decoder_digest())."""
+    if args.ldpc_only or args.cfg != 8 or F != 4096 or args.iters != 50:
+        return None, "no profile for this workload"
+    path = os.path.join(ROOT, "profiles", "r03_instruction_mix.json")
+    try:
+        from mercury_amd.build import decoder_digest
+        prof = json.load(open(path))
+        if prof.get("decoder_digest") != decoder_digest():
+            return None, "profiles/r03_instruction_mix.json was taken from another build of the decoder kernels (stamp %s, library %s)" % (
+                prof.get("decoder_digest"), decoder_digest())
+        return prof[decoder], "profiles/r03_instruction_mix.json (PMC, same workload, same decoder build %s)" % prof["decoder_digest"]
+    except Exception as e:
+        return None, "profile unreadable: %r" % (e,)
+
+
+def issue_view(decoder, dec_ms, args, F, iters_per_launch):
+    """Secondary view for the bound the decoders actually hit (vector-instruction issue). The dynamic opcode mix of one launch of
+    THIS workload comes from the committed PMC passes, the issue cost of each opcode class from the micro-benchmark measured on the
+    same kind of box (profiles/r02_valu_cycles.json, tools/ubench/valu_cycles.hip); issue cycles needed = sum(count x cost),
+    available = SIMDs x clock x kernel time of this run. Two readings: "isolated" prices every class at its back-to-back cost
+    (32-bit operations 2 cycles), "slots" at one 4-cycle issue slot per instruction (what a mixed fp64 stream pays: MIX_FMA_CND in
+    the micro-benchmark) - the truth lies between them."""
+    mix, src = profile_mix(decoder, args, F)
+    cfile = os.path.join(ROOT, "profiles", "r02_valu_cycles.json")
+    if mix is None or not os.path.exists(cfile) or abs(iters_per_launch - 50.0 * F) > 1e-6 * F:
+        return {"unavailable": src if mix is None else "not the all-50-iterations workload the profile was taken on"}
+    try:
+        cyc = {k.split("/")[0]: v["cycles_at_2p4ghz"] for k, v in json.load(open(cfile))["results"].items() if k.endswith("/8w")}
+        fp64 = mix["SQ_INSTS_VALU_ADD_F64"] + mix["SQ_INSTS_VALU_MUL_F64"] + mix["SQ_INSTS_VALU_FMA_F64"]
+        fp32 = mix["SQ_INSTS_VALU_ADD_F32"] + mix["SQ_INSTS_VALU_MUL_F32"] + mix["SQ_INSTS_VALU_FMA_F32"]
+        classes = {"fp64": (fp64, cyc["FMA_F64"]), "trans_f64": (mix["SQ_INSTS_VALU_TRANS_F64"], cyc["RCP_F64"]),
+                   "fp32": (fp32, cyc["FMA_F32"]), "trans_f32": (mix["SQ_INSTS_VALU_TRANS_F32"], cyc["RCP_F32"]),
+                   "int32": (mix["SQ_INSTS_VALU_INT32"], cyc["AND_B32"]), "cvt": (mix["SQ_INSTS_VALU_CVT"], cyc["CVT_F64_I32"]),
+                   "int64": (mix["SQ_INSTS_VALU_INT64"], cyc["LSHL_ADD"])}
+        rest = mix["SQ_INSTS_VALU"] - sum(c for c, _ in classes.values())
+        classes["compare_select_move"] = (rest, 0.5 * (cyc["CMP_U32"] + cyc["MOV_B32"]))
+        isolated = sum(c * w for c, w in classes.values())
+        slots = sum(c * max(w, cyc["FMA_F64"]) for c, w in classes.values())
+        avail = 256 * 4 * 2.4e9 * dec_ms * 1e-3
+        return {"bound": "valu_issue", "unit": "SIMD issue cycles per launch", "available": avail,
+                "needed_isolated_costs": isolated, "frac_isolated": isolated / avail,
+                "needed_4cycle_slots": slots, "frac_slots": slots / avail, "frac": slots / avail,
+                "valu_instructions_per_launch": mix["SQ_INSTS_VALU"],
+                "classes": {k: {"count": c, "cycles_each": w} for k, (c, w) in classes.items()},
+                "source": "opcode mix: %s; costs: profiles/r02_valu_cycles.json (micro-benchmark); time: this run" % src}
+    except Exception as e:                       # a stale profile must not break the bench line
+        return {"error": repr(e)}
 
 
 def usable_cores():
@@ -123,7 +174,7 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
     from conftest import OPERATING_ESN0
     out = {}
 
-    def timed(phy, inputs, steps=3):
+    def timed(phy, inputs, steps=10):
         for i in range(2):
             phy.receive_dev(inputs[i % len(inputs)].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
         torch.cuda.synchronize()
@@ -144,8 +195,12 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
     for other in [d for d in ("spa", "spa_fast", "minsum") if d != args.decoder]:
         rx2 = RxPhy(args.cfg, max_iters=args.iters, decoder=DECODERS[other], agc=agc, variance_source=vs, device=dev.index, max_batch=F)
         m = timed(rx2, bufs)
-        ldpc_bytes, _, _ = algorithmic_bytes(rx2, m["avg_iters"] * F, F)
-        m["roofline_frac_algorithmic"] = ldpc_bytes / (m["ldpc_ms"] * 1e-3) / HBM_PEAK
+        # these kernels keep their messages in LDS: pricing them against HBM says nothing (the model fraction exceeds 1 on some
+        # modes). What bounds them is vector-instruction issue: the fraction of the SIMDs' issue cycles their PMC opcode mix needs.
+        sec = issue_view(other, m["ldpc_ms"], args, F, m["avg_iters"] * F)
+        if sec and "frac" in sec:
+            m["roofline_frac"] = sec["frac_isolated"]
+            m["roofline_bound"] = "valu_issue (isolated opcode costs; %s)" % sec["source"]
         out["same_inputs_decoder_" + other] = m
         others[other] = rx2
     op = OPERATING_ESN0[args.cfg] + 1.0
@@ -198,6 +253,115 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
     return out
 
 
+def run_pool(args):
+    """The same measurement with the host side the reference would have: ONE process (the C / C++ caller's shape,
+    RX_SHM_process_main telecom_system.cc:2266-2390) driving N devices through include/mercury_pool.h - a context and a host worker
+    thread per device, every device's shard resident in its own memory, no collectives. Weak scaling like the torchrun form: every
+    device owns --frames frames per step. A step is one blocking mgpu_pool_rx_batch_dev call (all devices, including the read-back
+    of the 24-byte stats records the merged counters are made from)."""
+    N, F = args.gpus, args.frames
+    devices = [0] * N if args.share_device else list(range(N))
+    decoder = DECODERS[args.decoder]
+    agc, vs = (1, 1) if args.variant == "receive_byte" else (0, 0)
+    pool = RxPool(args.cfg, devices, max_iters=args.iters, decoder=decoder, agc=agc, variance_source=vs, max_batch=F)
+    one = RxPhy(args.cfg, max_iters=args.iters, decoder=decoder, agc=agc, variance_source=vs, device=devices[0], max_batch=1)   # mode constants
+    counts = [F] * N
+    noise_amp = float(10.0 ** (-args.esn0 / 20.0) / np.sqrt(2.0))
+    nbuf = max(1, args.nbuf)
+    fs, ps = pool.frame_samples, pool.payload_stride
+    d_in = []
+    for b in range(nbuf):
+        if args.ldpc_only:
+            bufs = []
+            for g in range(N):
+                gen = torch.Generator(device="cuda:%d" % devices[g])
+                gen.manual_seed(SEED + (b * N + g) * F)
+                bufs.append(2.0 * torch.randn((F, pool.N), generator=gen, dtype=torch.float32, device="cuda:%d" % devices[g]))
+            d_in.append(bufs)
+        else:
+            ptrs = [pool.device_malloc(g, F * fs * 16) for g in range(N)]
+            pool.txgen_dev(SEED, b * F * N, counts, noise_amp, ptrs, None, channel=args.channel)
+            d_in.append(ptrs)
+    for g in range(N):
+        torch.cuda.synchronize(devices[g])
+    d_pay = [pool.device_malloc(g, F * ps) for g in range(N)]
+    d_st = [pool.device_malloc(g, F * 24) for g in range(N)]
+    d_it = [pool.device_malloc(g, F * 4) for g in range(N)]
+
+    def step(i):
+        src = d_in[i % nbuf]
+        if args.ldpc_only:
+            pool.ldpc_decode_dev([t.data_ptr() for t in src], counts, None, d_it)
+        else:
+            pool.receive_dev(src, counts, d_pay, d_st)
+        return pool.counters()
+
+    for i in range(max(args.warmup, 0)):
+        step(i)
+    pool.enable_timing(True)
+    iters_total = decoded_total = 0
+    dev_ms = np.zeros(N)
+    for g in range(N):
+        torch.cuda.synchronize(devices[g])
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        k = step(i)                               # blocking: returns when every device has finished its shard
+        iters_total += k["ldpc_iterations"]
+        decoded_total += k["decoded"]
+        dev_ms += np.array(k["device_ms"])
+    for g in range(N):
+        torch.cuda.synchronize(devices[g])
+    dt = time.perf_counter() - t0
+    fe_ms, dec_ms, nl = pool.kernel_ms(0)
+    pool.enable_timing(False)
+    frames_total = F * N * args.steps
+    iters_per_launch = iters_total / (args.steps * N)
+    ldpc_bytes, _, b_iter = algorithmic_bytes(one, iters_per_launch, F)
+    achieved = ldpc_bytes / (dec_ms * 1e-3)
+    mix, mix_src = profile_mix(args.decoder, args, F)
+    line = {
+        "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (pool.K, args.iters)) if args.ldpc_only else
+                  ("RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters)),
+        "value": frames_total / dt, "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if args.decoder == "spa" else "f32", "data": "synthetic",
+        "config": {"workload": ("BASELINE.json configs[4]-style decoder-only soak: %d rate-%d/1600 codewords per GPU per step, noise-only LLRs, "
+                                "decoder=%s, max %d iterations" % (F, pool.K, args.decoder, args.iters)) if args.ldpc_only else
+                               ("BASELINE.json configs[1]: %d mode-%d frames per GPU per step through %s at Es/N0 %+.1f dB, "
+                                "%s variant, decoder=%s, max %d iterations" % (F, args.cfg, "2-path+AWGN" if args.channel else "AWGN",
+                                                                               args.esn0, args.variant, args.decoder, args.iters)),
+                   "frames_per_step_per_gpu": F, "cfg": args.cfg, "esn0_db": args.esn0, "decoder": args.decoder,
+                   "parallelism": "pool x%d: one process, one context + host thread per device (include/mercury_pool.h), device-resident "
+                                  "shards, no collectives%s" % (N, " [all contexts on GPU 0: --share-device]" if args.share_device else "")},
+        "ldpc_iters_per_s": iters_total / dt, "avg_iters_per_frame": iters_total / frames_total,
+        "decoded_fraction": decoded_total / frames_total,
+        "kernel_ms": {"frontend": fe_ms, "ldpc": dec_ms, "launches_averaged": nl, "device": 0},
+        "pool_device_ms_per_step": [float(x) / args.steps for x in dev_ms],
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                     "traffic": (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None, "traffic_source": mix_src,
+                     "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
+                     "secondary": issue_view(args.decoder, dec_ms, args, F, iters_per_launch),
+                     "bytes_per_codeword_iteration": b_iter,
+                     "note": "device 0's decoder launch; algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are "
+                             "LDS-resident so real HBM traffic is far lower; the decoders are bound by vector-instruction issue"},
+    }
+    if N == 1 and not args.no_cpu_baseline and not args.ldpc_only:
+        import oraclelib
+        cores = usable_cores()
+        S = min(F, args.cpu_sample_per_core * cores)
+        last = (args.steps - 1) % nbuf
+        bb_h = pool.copy_to_host(0, np.zeros((S, fs), np.complex128), d_in[last][0])
+        pay = pool.copy_to_host(0, np.zeros((S, ps), np.uint8), d_pay[0])
+        st = pool.copy_to_host(0, np.zeros(S, STATS_DTYPE), d_st[0])
+        st6 = np.stack([st["iterations_done"], st["crc"], st["all_zeros"], st["message_decoded"]], axis=1)
+        flags = oraclelib.FLAGS_RECEIVE_BYTE if args.variant == "receive_byte" else oraclelib.FLAGS_BASEBAND_TEST
+        line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, pay, st6)
+        line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line), flush=True)
+    pool.close()
+    one.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,7 +382,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary per-GPU measurements (min-sum, operating point)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--pool", action="store_true",
+                    help="one process drives the --gpus devices through the C-ABI pool (include/mercury_pool.h: one context + one host "
+                         "thread per device), device-resident shards; also what `python bench.py --gpus N` does when not under torchrun")
     args = ap.parse_args()
+    if args.pool or (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus > 1):
+        return run_pool(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -314,51 +483,12 @@ def main():
         iters_per_launch = float(iters_acc.item()) / args.steps
         ldpc_bytes, _, b_iter = algorithmic_bytes(rx, iters_per_launch, F)
         achieved = ldpc_bytes / (dec_ms * 1e-3)
-        traffic = None
-        # HBM bytes of one decoder launch of this workload from the committed PMC passes (profiles/r02_instruction_mix.json, separate
-        # --pmc runs of this command, tools/collect_pmc_mix.sh): (2 x FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE doubled as
-        # MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads
-        tfile = os.path.join(ROOT, "profiles", "r02_instruction_mix.json")
-        if os.path.exists(tfile) and not args.ldpc_only and args.cfg == 8 and F == 4096 and args.iters == 50:
-            try:
-                m = json.load(open(tfile))[args.decoder]
-                traffic = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
-            except Exception:
-                traffic = None
-        # secondary view for the bound the decoders actually hit (vector-instruction issue). The dynamic opcode mix of one
-        # launch of THIS workload comes from the committed PMC passes (profiles/r02_instruction_mix.json, tools/collect_pmc_mix.sh),
-        # the issue cost of each opcode class from the micro-benchmark measured on the same kind of box
-        # (profiles/r02_valu_cycles.json, tools/ubench/valu_cycles.hip); issue cycles needed = sum(count x cost), available =
-        # SIMDs x clock x kernel time of this run. Two readings: "isolated" prices every class at its back-to-back cost (32-bit
-        # operations 2 cycles), "slots" at one 4-cycle issue slot per instruction (what a mixed fp64 stream pays:
-        # MIX_FMA_CND in the micro-benchmark) — the truth lies between them.
-        issue = None
-        mfile, cfile = os.path.join(ROOT, "profiles", "r02_instruction_mix.json"), os.path.join(ROOT, "profiles", "r02_valu_cycles.json")
-        if (os.path.exists(mfile) and os.path.exists(cfile) and not args.ldpc_only and args.cfg == 8 and F == 4096 and args.iters == 50
-                and abs(iters_per_launch - 50.0 * F) < 1e-6 * F):
-            try:
-                mix = json.load(open(mfile))[args.decoder]
-                cyc = {k.split("/")[0]: v["cycles_at_2p4ghz"] for k, v in json.load(open(cfile))["results"].items() if k.endswith("/8w")}
-                fp64 = mix["SQ_INSTS_VALU_ADD_F64"] + mix["SQ_INSTS_VALU_MUL_F64"] + mix["SQ_INSTS_VALU_FMA_F64"]
-                fp32 = mix["SQ_INSTS_VALU_ADD_F32"] + mix["SQ_INSTS_VALU_MUL_F32"] + mix["SQ_INSTS_VALU_FMA_F32"]
-                classes = {"fp64": (fp64, cyc["FMA_F64"]), "trans_f64": (mix["SQ_INSTS_VALU_TRANS_F64"], cyc["RCP_F64"]),
-                           "fp32": (fp32, cyc["FMA_F32"]), "trans_f32": (mix["SQ_INSTS_VALU_TRANS_F32"], cyc["RCP_F32"]),
-                           "int32": (mix["SQ_INSTS_VALU_INT32"], cyc["AND_B32"]), "cvt": (mix["SQ_INSTS_VALU_CVT"], cyc["CVT_F64_I32"]),
-                           "int64": (mix["SQ_INSTS_VALU_INT64"], cyc["LSHL_ADD"])}
-                rest = mix["SQ_INSTS_VALU"] - sum(c for c, _ in classes.values())
-                classes["compare_select_move"] = (rest, 0.5 * (cyc["CMP_U32"] + cyc["MOV_B32"]))
-                isolated = sum(c * w for c, w in classes.values())
-                slots = sum(c * max(w, cyc["FMA_F64"]) for c, w in classes.values())
-                avail = 256 * 4 * 2.4e9 * dec_ms * 1e-3
-                issue = {"bound": "valu_issue", "unit": "SIMD issue cycles per launch", "available": avail,
-                         "needed_isolated_costs": isolated, "frac_isolated": isolated / avail,
-                         "needed_4cycle_slots": slots, "frac_slots": slots / avail, "frac": slots / avail,
-                         "valu_instructions_per_launch": mix["SQ_INSTS_VALU"],
-                         "classes": {k: {"count": c, "cycles_each": w} for k, (c, w) in classes.items()},
-                         "source": "opcode mix: profiles/r02_instruction_mix.json (PMC, same workload); costs: profiles/r02_valu_cycles.json "
-                                   "(micro-benchmark); time: this run"}
-            except Exception as e:                       # a stale profile must not break the bench line
-                issue = {"error": repr(e)}
+        # HBM bytes of one decoder launch of this workload from the committed PMC passes (separate --pmc runs of this command,
+        # tools/collect_pmc_mix.sh): (2 x FETCH_SIZE + WRITE_SIZE) KB - FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+        # gfx950's wide coalesced reads. Quoted only when the profile's stamp matches the decoder build being timed.
+        mix, mix_src = profile_mix(args.decoder, args, F)
+        traffic = (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None
+        issue = issue_view(args.decoder, dec_ms, args, F, iters_per_launch)
         line = {
             "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (rx.K, args.iters)) if args.ldpc_only else
                       ("RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters)),
@@ -379,7 +509,7 @@ def main():
             "decoded_fraction": decoded_total / frames_total,
             "kernel_ms": {"frontend": fe_ms, "ldpc": dec_ms, "launches_averaged": nl},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": mix_src,
                          "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
                          "secondary": issue,
                          "bytes_per_codeword_iteration": b_iter,
@@ -416,6 +546,9 @@ def main():
                     ts.append(time.perf_counter() - t0)
                 return F / sorted(ts)[reps // 2], out
             line["pcie_inclusive_frames_per_s"], out_h = median_rate(bb_all)
+            hp = rx.host_path_last()       # device events of the last call: the pipeline's fill (first chunk's copy) and drain (after the last input byte)
+            line["pcie_inclusive_pipeline"] = dict(hp, note="frames/s = F / (fill + steady chunks + drain); at F = %d in chunks of %d the "
+                                                   "fill and drain are a fixed %.1f of the call's %.1f ms" % (F, hp["chunk_frames"], hp["fill_ms"] + hp["drain_ms"], hp["total_ms"]))
             line["pcie_inclusive_equals_device_path"] = bool(np.array_equal(out_h["payload"][:S_chk], payload_chk) and
                                                              out_h["stats"][:S_chk].tobytes() == stats_chk.tobytes())
             from mercury_amd.physical_layer import pinned_empty

@@ -175,6 +175,14 @@ int mgpu_frontend_dev(mgpu_ctx* ctx, const void* d_baseband_c128, int F, void* d
                       void* stream);
 int mgpu_ldpc_batch_dev(mgpu_ctx* ctx, const void* d_llr, int F, void* d_bits_opt, void* d_iters,
                         void* d_payload_opt, void* d_stats_opt, const void* d_variance_f_opt, void* stream);
+/* For host programs that do not link the HIP runtime themselves (plain C / C++ callers of this C-ABI, the pool in
+ * mercury_pool.h): device memory on the context's device, the context's own stream, and blocking copies ordered behind it. */
+void* mgpu_device_malloc(mgpu_ctx* ctx, size_t bytes);            /* NULL on failure (mgpu_last_error) */
+void mgpu_device_free(mgpu_ctx* ctx, void* d_ptr);
+void* mgpu_context_stream(mgpu_ctx* ctx);                          /* the hipStream_t the host-buffer entry points work on */
+int mgpu_synchronize(mgpu_ctx* ctx, void* stream_or_null);         /* waits for `stream` (NULL: the context's own stream) */
+int mgpu_copy_to_host(mgpu_ctx* ctx, void* dst, const void* d_src, size_t bytes, void* stream_or_null);      /* ordered behind the stream, blocking */
+int mgpu_copy_to_device(mgpu_ctx* ctx, void* d_dst, const void* src, size_t bytes, void* stream_or_null);    /* ordered behind the stream, blocking */
 /* synthetic workload: frames frame0..frame0+F-1 of the Philox-keyed generator */
 int mgpu_txgen_dev(mgpu_ctx* ctx, uint64_t seed, uint64_t frame0, int F, double noise_amp, int channel,
                    void* d_baseband_c128, void* d_payload_opt, void* stream);
@@ -240,6 +248,10 @@ int mgpu_last_sync_kernel_ms(mgpu_ctx* ctx, float* ms);
  * [1]=LDPC decoder kernel (incl. fused tail). Synchronises on the recorded events. */
 int mgpu_enable_timing(mgpu_ctx* ctx, int on);
 int mgpu_kernel_ms_avg(mgpu_ctx* ctx, float ms[2], int* n_launches);
+/* Profile of the most recent mgpu_rx_batch call that went through the chunked host-buffer pipeline (F > 1): frames per chunk,
+ * number of chunks, and from device events: fill = the first chunk's host-to-device copy (nothing can compute before it has
+ * landed), drain = from the last input byte landing to the last result copied back, total = first copy start to that point. */
+int mgpu_host_path_last(mgpu_ctx* ctx, int* chunk_frames, int* n_chunks, float* fill_ms, float* drain_ms, float* total_ms);
 int mgpu_last_kernel_ms(mgpu_ctx* ctx, float ms[2]);
 
 /* Test hook: the preamble-tone search of cl_ofdm::time_sync_mfsk (ofdm.cc:2026-2061) on given slot energies [W][nslots][Nc] (host): variant 0

@@ -34,8 +34,9 @@ typedef struct mgpu_pool mgpu_pool;
 typedef struct mgpu_pool_counters {
     int n_devices;
     long long frames;                 /* frames (or windows) processed */
-    long long decoded;                /* message_decoded != 0 */
-    long long ldpc_iterations;        /* iterations executed, max_iters for frames that never converged (iterations_done clipped) */
+    long long decoded;                /* message_decoded != 0; counted from the stats array: 0 when the call was given stats == NULL */
+    long long ldpc_iterations;        /* iterations executed, max_iters for frames that never converged (iterations_done clipped);
+                                         counted from the stats / iters array: 0 when the call was given none */
     double wall_ms;                   /* the call, host clock */
     int device_frames[MGPU_POOL_MAX_DEVICES];
     double device_ms[MGPU_POOL_MAX_DEVICES];   /* each worker's own wall time for its shard */
@@ -58,6 +59,20 @@ int mgpu_pool_rx_batch(mgpu_pool* pool, const double* baseband_c128, int F, uint
 int mgpu_pool_ldpc_batch(mgpu_pool* pool, const float* llr, int F, uint8_t* bits, int* iters);
 int mgpu_pool_receive_byte_batch(mgpu_pool* pool, const double* passband, int W, const mgpu_receive_config* config,
                                  mgpu_link_state* state, uint8_t* payload, mgpu_receive_stats* stats);
+
+/* ---- device-resident shards: every device's part of the batch already lies in that device's own memory ----------------------
+ * The arrays have one entry per pool device, in pool order: counts[g] frames (<= max_batch; mgpu_pool_shard gives the split the
+ * host-buffer calls use, any other split is as good), d_in[g] / d_out[g] device pointers ON pool device g (mgpu_device_malloc on
+ * mgpu_pool_context(pool, g), or the caller's own HIP allocations). Every device runs its shard on its context's stream; the call
+ * returns when all of them have finished. Outputs stay on the devices; only what the merged counters need (24 bytes of stats
+ * resp. 4 bytes of iteration count per frame) is read back. Layouts are those of mgpu_rx_batch_dev / mgpu_ldpc_batch_dev.
+ * mgpu_pool_txgen_dev fills the shards with the synthetic generator's frames frame0, frame0 + 1, ... numbered across the devices
+ * in pool order (device g starts at frame0 + counts[0] + ... + counts[g-1]), so that a pool of any size sees the same frames. */
+int mgpu_pool_rx_batch_dev(mgpu_pool* pool, const void* const* d_baseband_c128, const int* counts, void* const* d_payload,
+                           void* const* d_stats);
+int mgpu_pool_ldpc_batch_dev(mgpu_pool* pool, const void* const* d_llr, const int* counts, void* const* d_bits_opt, void* const* d_iters);
+int mgpu_pool_txgen_dev(mgpu_pool* pool, uint64_t seed, uint64_t frame0, const int* counts, double noise_amp, int channel,
+                        void* const* d_baseband_c128, void* const* d_payload_opt);
 
 #ifdef __cplusplus
 }

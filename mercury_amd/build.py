@@ -45,6 +45,17 @@ def _sources_digest():
     return h.hexdigest()
 
 
+def decoder_digest():
+    """Digest of what the LDPC decoder kernels are compiled from (sources + flags): profiles/ stamps its PMC passes with it and
+    bench.py only quotes a profile whose stamp matches the library it is timing."""
+    h = hashlib.sha256()
+    for name in ("ldpc.hip", "spa_math.h", "device_tables.h"):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _write_blob_c(path):
     with open(TABLES, "rb") as f:
         data = f.read()

@@ -495,6 +495,7 @@ void mgpu_destroy(mgpu_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto& q : c->ev) for (auto& e : q) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->sync_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->hp_ev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->d_one_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
     for (auto& p : c->pipe) {
@@ -599,6 +600,39 @@ int mgpu_rx_batch_dev(mgpu_ctx* c, const void* d_bb, int F, void* d_payload, voi
         launch_decoder(c, llr, F, nullptr, nullptr, static_cast<uint8_t*>(d_payload), static_cast<MgpuStatsDev*>(d_stats),
                        c->d_variance, c->d_snrvar, s);
         launch_zf_snr(c, F, static_cast<uint8_t*>(d_payload), static_cast<MgpuStatsDev*>(d_stats), s);
+    });
+}
+
+void* mgpu_device_malloc(mgpu_ctx* c, size_t bytes) {
+    if (!c) return nullptr;
+    void* p = nullptr;
+    const int rc = guard(c, [&] { HIPCK(hipMalloc(&p, bytes ? bytes : 1)); });
+    return rc == MGPU_OK ? p : nullptr;
+}
+void mgpu_device_free(mgpu_ctx* c, void* d_ptr) {
+    if (c && d_ptr) (void)guard(c, [&] { HIPCK(hipFree(d_ptr)); });
+}
+void* mgpu_context_stream(mgpu_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+int mgpu_synchronize(mgpu_ctx* c, void* stream) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] { HIPCK(hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : c->stream)); });
+}
+int mgpu_copy_to_host(mgpu_ctx* c, void* dst, const void* d_src, size_t bytes, void* stream) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need((dst && d_src) || bytes == 0, "bad argument");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+        if (bytes) HIPCK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+int mgpu_copy_to_device(mgpu_ctx* c, void* d_dst, const void* src, size_t bytes, void* stream) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need((d_dst && src) || bytes == 0, "bad argument");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+        if (bytes) HIPCK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s));
+        HIPCK(hipStreamSynchronize(s));
     });
 }
 
@@ -1162,13 +1196,18 @@ static void rx_batch_pipelined(mgpu_ctx* c, const double* bb, int F, uint8_t* pa
     hipPointerAttribute_t attr{};
     const bool pinned = hipPointerGetAttributes(&attr, bb) == hipSuccess && attr.type == hipMemoryTypeHost;
     if (!pinned) (void)hipGetLastError();
+    for (auto& e : c->hp_ev) if (!e) HIPCK(hipEventCreate(&e));
+    const int nchunks = (F + chunk - 1) / chunk;
     int k = 0;
     for (int off = 0; off < F; off += chunk, ++k) {
         auto& p = c->pipe[k % mgpu_ctx::kPipes];                     // input buffer of this chunk
         hipStream_t cs = pinned ? c->pipe[0].stream : p.stream, ks = pinned ? c->pipe[1].stream : p.stream;
         const int n = std::min(chunk, F - off);
         if (pinned && k >= mgpu_ctx::kPipes) HIPCK(hipStreamWaitEvent(cs, p.done, 0));          // the front-end of chunk k-2 has consumed it
+        if (k == 0) HIPCK(hipEventRecord(c->hp_ev[0], cs));
         HIPCK(hipMemcpyAsync(p.d_in, reinterpret_cast<const char*>(bb) + size_t(off) * frame_bytes, size_t(n) * frame_bytes, hipMemcpyHostToDevice, cs));
+        if (k == 0) HIPCK(hipEventRecord(c->hp_ev[1], cs));          // fill: nothing can compute before the first chunk has landed
+        if (k == nchunks - 1) HIPCK(hipEventRecord(c->hp_ev[2], cs)); // drain: what is left when the last input byte has landed
         if (pinned) {
             HIPCK(hipEventRecord(p.copied, cs));
             HIPCK(hipStreamWaitEvent(ks, p.copied, 0));
@@ -1181,10 +1220,25 @@ static void rx_batch_pipelined(mgpu_ctx* c, const double* bb, int F, uint8_t* pa
         if (payload) HIPCK(hipMemcpyAsync(h_payload + size_t(off) * t.payload_stride, c->d_payload + size_t(off) * t.payload_stride,
                                           size_t(n) * t.payload_stride, hipMemcpyDeviceToHost, ks));
         if (stats) HIPCK(hipMemcpyAsync(h_stats + off, c->d_stats + off, size_t(n) * sizeof(MgpuStatsDev), hipMemcpyDeviceToHost, ks));
+        if (k == nchunks - 1) HIPCK(hipEventRecord(c->hp_ev[3], ks));
     }
     for (auto& p : c->pipe) HIPCK(hipStreamSynchronize(p.stream));
+    c->hp_chunk = chunk; c->hp_nchunks = nchunks;
+    (void)hipEventElapsedTime(&c->hp_fill_ms, c->hp_ev[0], c->hp_ev[1]);
+    (void)hipEventElapsedTime(&c->hp_drain_ms, c->hp_ev[2], c->hp_ev[3]);
+    (void)hipEventElapsedTime(&c->hp_total_ms, c->hp_ev[0], c->hp_ev[3]);
     if (payload) std::memcpy(payload, h_payload, size_t(F) * t.payload_stride);
     if (stats) std::memcpy(stats, h_stats, size_t(F) * sizeof(MgpuStatsDev));
+}
+
+int mgpu_host_path_last(mgpu_ctx* c, int* chunk_frames, int* n_chunks, float* fill_ms, float* drain_ms, float* total_ms) {
+    if (!c) return MGPU_ERR_ARG;
+    if (chunk_frames) *chunk_frames = c->hp_chunk;
+    if (n_chunks) *n_chunks = c->hp_nchunks;
+    if (fill_ms) *fill_ms = c->hp_fill_ms;
+    if (drain_ms) *drain_ms = c->hp_drain_ms;
+    if (total_ms) *total_ms = c->hp_total_ms;
+    return MGPU_OK;
 }
 
 int mgpu_rx_batch(mgpu_ctx* c, const double* bb, int F, uint8_t* payload, mgpu_frame_stats* stats, float* llr_opt) {

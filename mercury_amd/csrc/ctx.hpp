@@ -136,6 +136,9 @@ struct mgpu_ctx {
     void* h_out = nullptr;          // page-locked staging for the payloads + stats of a pipelined call ([max_batch])
     static constexpr int kPipes = 2;
     Pipe pipe[kPipes];                   // the two chunk pipelines of the blocking host-buffer entry points (api.hip rx_batch_pipelined)
+    hipEvent_t hp_ev[4]{};               // call start, first chunk copied, last chunk copied, all done (host-path profile)
+    int hp_chunk = 0, hp_nchunks = 0;    // the last pipelined call: frames per chunk, chunks
+    float hp_fill_ms = 0, hp_drain_ms = 0, hp_total_ms = 0;
     static constexpr int kEvRing = 64;
     hipEvent_t ev[kEvRing][4]{};    // per launch: front-end start/stop, decoder start/stop
     bool timing = false;

@@ -14,7 +14,7 @@
 
 namespace {
 
-std::string g_pool_create_error;
+thread_local std::string g_pool_create_error;     // what mgpu_pool_last_error(NULL) reports: the calling thread's last failed create
 
 struct Worker {
     mgpu_ctx* ctx = nullptr;
@@ -67,17 +67,21 @@ struct mgpu_pool {
 
 namespace {
 
-// run shard(g, first, count) on every worker that has frames; merge return codes (first failure wins) and timings
-int run_sharded(mgpu_pool* p, int F, const std::function<int(mgpu_ctx*, int, int)>& shard) {
+// run shard(ctx, g, first, count) on every worker that has frames; merge return codes (first failure wins) and timings.
+// counts == nullptr: the contiguous split of F frames (mgpu_pool_shard); otherwise the caller's own per-device counts.
+int run_sharded(mgpu_pool* p, int F, const std::function<int(mgpu_ctx*, int, int, int)>& shard, const int* counts = nullptr) {
     const int G = int(p->w.size());
     const auto t0 = std::chrono::steady_clock::now();
+    p->err.clear();                 // mgpu_pool_last_error describes this call, not an earlier one
     std::vector<int> first(G), count(G);
+    int at = 0;
     for (int g = 0; g < G; ++g) {
-        mgpu_pool_shard(F, G, g, &first[g], &count[g]);
+        if (counts) { first[g] = at; count[g] = counts[g]; at += counts[g]; }
+        else mgpu_pool_shard(F, G, g, &first[g], &count[g]);
         if (count[g] > 0) {
             mgpu_ctx* ctx = p->w[g]->ctx;
             const int f0 = first[g], n = count[g];
-            p->w[g]->submit([=, &shard] { return shard(ctx, f0, n); });
+            p->w[g]->submit([=, &shard] { return shard(ctx, g, f0, n); });
         }
     }
     int rc = MGPU_OK;
@@ -164,7 +168,7 @@ int mgpu_pool_rx_batch(mgpu_pool* p, const double* bb, int F, uint8_t* payload, 
     mgpu_get_info(p->w[0]->ctx, &info);
     if ((long long)F > (long long)p->cfg.max_batch * (long long)p->w.size()) { p->err = "F exceeds n_devices * max_batch"; return MGPU_ERR_ARG; }
     const size_t frame = size_t(info.frame_samples) * 2, stride = size_t(info.payload_stride);
-    const int rc = run_sharded(p, F, [&](mgpu_ctx* ctx, int f0, int n) {
+    const int rc = run_sharded(p, F, [&](mgpu_ctx* ctx, int, int f0, int n) {
         return mgpu_rx_batch(ctx, bb + size_t(f0) * frame, n, payload ? payload + size_t(f0) * stride : nullptr, stats ? stats + f0 : nullptr, nullptr);
     });
     if (rc == MGPU_OK && stats)
@@ -181,12 +185,86 @@ int mgpu_pool_ldpc_batch(mgpu_pool* p, const float* llr, int F, uint8_t* bits, i
     mgpu_info info{};
     mgpu_get_info(p->w[0]->ctx, &info);
     if ((long long)F > (long long)p->cfg.max_batch * (long long)p->w.size()) { p->err = "F exceeds n_devices * max_batch"; return MGPU_ERR_ARG; }
-    const int rc = run_sharded(p, F, [&](mgpu_ctx* ctx, int f0, int n) {
+    const int rc = run_sharded(p, F, [&](mgpu_ctx* ctx, int, int f0, int n) {
         return mgpu_ldpc_batch(ctx, llr + size_t(f0) * info.N, n, bits ? bits + size_t(f0) * info.K : nullptr, iters ? iters + f0 : nullptr);
     });
     if (rc == MGPU_OK && iters)
         for (int f = 0; f < F; ++f) p->last.ldpc_iterations += iters[f] > p->cfg.max_iters ? p->cfg.max_iters : iters[f];
     return rc;
+}
+
+static bool counts_ok(mgpu_pool* p, const int* counts, long long* total) {
+    long long F = 0;
+    for (size_t g = 0; g < p->w.size(); ++g) {
+        if (counts[g] < 0 || counts[g] > p->cfg.max_batch) { p->err = "counts[g] must be 0..max_batch"; return false; }
+        F += counts[g];
+    }
+    *total = F;
+    return true;
+}
+
+int mgpu_pool_rx_batch_dev(mgpu_pool* p, const void* const* d_bb, const int* counts, void* const* d_payload, void* const* d_stats) {
+    if (!p || !d_bb || !counts || !d_payload || !d_stats) return MGPU_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->call);
+    long long F = 0;
+    if (!counts_ok(p, counts, &F)) return MGPU_ERR_ARG;
+    const int G = int(p->w.size());
+    std::vector<long long> dec(G, 0), its(G, 0);
+    const int max_iters = p->cfg.max_iters;
+    const int rc = run_sharded(p, int(F), [&](mgpu_ctx* ctx, int g, int f0, int n) {
+        (void)f0;
+        void* s = mgpu_context_stream(ctx);
+        int r = mgpu_rx_batch_dev(ctx, d_bb[g], n, d_payload[g], d_stats[g], nullptr, s);
+        if (r != MGPU_OK) return r;
+        std::vector<mgpu_frame_stats> st(n);
+        r = mgpu_copy_to_host(ctx, st.data(), d_stats[g], size_t(n) * sizeof(mgpu_frame_stats), s);       // waits for the shard, too
+        if (r != MGPU_OK) return r;
+        for (int f = 0; f < n; ++f) {
+            dec[g] += st[f].message_decoded != 0;
+            its[g] += st[f].iterations_done > max_iters ? max_iters : st[f].iterations_done;
+        }
+        return int(MGPU_OK);
+    }, counts);
+    for (int g = 0; g < G; ++g) { p->last.decoded += dec[g]; p->last.ldpc_iterations += its[g]; }
+    return rc;
+}
+
+int mgpu_pool_ldpc_batch_dev(mgpu_pool* p, const void* const* d_llr, const int* counts, void* const* d_bits_opt, void* const* d_iters) {
+    if (!p || !d_llr || !counts || !d_iters) return MGPU_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->call);
+    long long F = 0;
+    if (!counts_ok(p, counts, &F)) return MGPU_ERR_ARG;
+    const int G = int(p->w.size());
+    std::vector<long long> its(G, 0);
+    const int max_iters = p->cfg.max_iters;
+    const int rc = run_sharded(p, int(F), [&](mgpu_ctx* ctx, int g, int f0, int n) {
+        (void)f0;
+        void* s = mgpu_context_stream(ctx);
+        int r = mgpu_ldpc_batch_dev(ctx, d_llr[g], n, d_bits_opt ? d_bits_opt[g] : nullptr, d_iters[g], nullptr, nullptr, nullptr, s);
+        if (r != MGPU_OK) return r;
+        std::vector<int> it(n);
+        r = mgpu_copy_to_host(ctx, it.data(), d_iters[g], size_t(n) * sizeof(int), s);
+        if (r != MGPU_OK) return r;
+        for (int f = 0; f < n; ++f) its[g] += it[f] > max_iters ? max_iters : it[f];
+        return int(MGPU_OK);
+    }, counts);
+    for (int g = 0; g < G; ++g) p->last.ldpc_iterations += its[g];
+    return rc;
+}
+
+int mgpu_pool_txgen_dev(mgpu_pool* p, uint64_t seed, uint64_t frame0, const int* counts, double noise_amp, int channel,
+                        void* const* d_bb, void* const* d_payload_opt) {
+    if (!p || !counts || !d_bb) return MGPU_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->call);
+    long long F = 0;
+    if (!counts_ok(p, counts, &F)) return MGPU_ERR_ARG;
+    const int G = int(p->w.size());
+    return run_sharded(p, int(F), [&](mgpu_ctx* ctx, int g, int f0, int n) {
+        (void)f0;
+        void* s = mgpu_context_stream(ctx);
+        const int r = mgpu_txgen_dev(ctx, seed, frame0 + uint64_t(f0), n, noise_amp, channel, d_bb[g], d_payload_opt ? d_payload_opt[g] : nullptr, s);
+        return r != MGPU_OK ? r : mgpu_synchronize(ctx, s);
+    }, counts);
 }
 
 int mgpu_pool_receive_byte_batch(mgpu_pool* p, const double* passband, int W, const mgpu_receive_config* config, mgpu_link_state* state,
@@ -197,7 +275,7 @@ int mgpu_pool_receive_byte_batch(mgpu_pool* p, const double* passband, int W, co
     mgpu_get_info(p->w[0]->ctx, &info);
     if ((long long)W > (long long)p->cfg.max_batch * (long long)p->w.size()) { p->err = "W exceeds n_devices * max_batch"; return MGPU_ERR_ARG; }
     const size_t window = size_t(mgpu_receive_buffer_nsymb(p->w[0]->ctx)) * info.Nofdm * 4, stride = size_t(info.payload_stride);
-    const int rc = run_sharded(p, W, [&](mgpu_ctx* ctx, int f0, int n) {
+    const int rc = run_sharded(p, W, [&](mgpu_ctx* ctx, int, int f0, int n) {
         return mgpu_receive_byte_batch(ctx, passband + size_t(f0) * window, n, config, state ? state + f0 : nullptr,
                                        payload ? payload + size_t(f0) * stride : nullptr, stats ? stats + f0 : nullptr);
     });

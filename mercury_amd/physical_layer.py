@@ -102,6 +102,8 @@ EXPORTED_SYMBOLS = [
     "mgpu_alloc_host", "mgpu_free_host", "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_host_select_peak", "mgpu_host_fir_taps", "mgpu_host_preamble_carriers",
     "mgpu_ldpc_batch", "mgpu_ldpc_encode_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
+    "mgpu_host_path_last", "mgpu_device_malloc", "mgpu_device_free", "mgpu_context_stream", "mgpu_synchronize", "mgpu_copy_to_host", "mgpu_copy_to_device",
+    "mgpu_pool_rx_batch_dev", "mgpu_pool_ldpc_batch_dev", "mgpu_pool_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_debug_glibc_trig", "mgpu_debug_tsync_metric", "mgpu_debug_occupancy", "mgpu_debug_select_peak", "mgpu_debug_span_energy", "mgpu_debug_p2b_variant", "mgpu_debug_mfsk_sync", "mgpu_baseband_test_esn0", "mgpu_passband_test_esn0", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_measure_signal_only",
@@ -492,6 +494,13 @@ class RxPhy:
     def enable_timing(self, on=True):
         self._ck(self.lib.mgpu_enable_timing(self.h, C.c_int(1 if on else 0)))
 
+    def host_path_last(self):
+        """Profile of the last chunked mgpu_rx_batch call: dict(chunk_frames, n_chunks, fill_ms, drain_ms, total_ms)."""
+        a, b = C.c_int(), C.c_int()
+        f, d, t = C.c_float(), C.c_float(), C.c_float()
+        self._ck(self.lib.mgpu_host_path_last(self.h, C.byref(a), C.byref(b), C.byref(f), C.byref(d), C.byref(t)))
+        return {"chunk_frames": a.value, "n_chunks": b.value, "fill_ms": f.value, "drain_ms": d.value, "total_ms": t.value}
+
     def kernel_ms_avg(self):
         """(front-end ms, decoder ms, launches) averaged over the launches since enable_timing()."""
         ms = (C.c_float * 2)()
@@ -583,6 +592,76 @@ class RxPool:
         iters = np.zeros(F, np.int32)
         self._ck(self.lib.mgpu_pool_ldpc_batch(self.h, _ptr(l), C.c_int(F), _ptr(bits), _ptr(iters)))
         return bits, iters
+
+    # ---- device-resident shards: one pointer and one count per pool device (mercury_pool.h) ----
+    @staticmethod
+    def _ptrs(ptrs, n):
+        if ptrs is None:
+            return None
+        assert len(ptrs) == n
+        return (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ptrs])
+
+    def shard(self, F):
+        """The split the host-buffer calls use: [(first, count)] per device."""
+        out = []
+        for g in range(self.n_devices):
+            a, b = C.c_int(), C.c_int()
+            self.lib.mgpu_pool_shard(C.c_int(F), C.c_int(self.n_devices), C.c_int(g), C.byref(a), C.byref(b))
+            out.append((a.value, b.value))
+        return out
+
+    def device_malloc(self, g, nbytes):
+        self.lib.mgpu_device_malloc.restype = C.c_void_p
+        ctx = C.c_void_p(self.lib.mgpu_pool_context(self.h, g))
+        p = self.lib.mgpu_device_malloc(ctx, C.c_size_t(nbytes))
+        if not p:
+            raise MgpuError("mgpu_device_malloc(%d bytes) failed on pool device %d" % (nbytes, g))
+        return p
+
+    def device_free(self, g, ptr):
+        self.lib.mgpu_device_free(C.c_void_p(self.lib.mgpu_pool_context(self.h, g)), C.c_void_p(ptr))
+
+    def copy_to_host(self, g, dst, d_src):
+        """dst: a numpy array; blocking copy from pool device g."""
+        ctx = C.c_void_p(self.lib.mgpu_pool_context(self.h, g))
+        rc = self.lib.mgpu_copy_to_host(ctx, _ptr(dst), C.c_void_p(d_src), C.c_size_t(dst.nbytes), None)
+        if rc != 0:
+            raise MgpuError("mgpu_copy_to_host failed (%d)" % rc)
+        return dst
+
+    def copy_to_device(self, g, d_dst, src):
+        src = np.ascontiguousarray(src)
+        ctx = C.c_void_p(self.lib.mgpu_pool_context(self.h, g))
+        rc = self.lib.mgpu_copy_to_device(ctx, C.c_void_p(d_dst), _ptr(src), C.c_size_t(src.nbytes), None)
+        if rc != 0:
+            raise MgpuError("mgpu_copy_to_device failed (%d)" % rc)
+
+    def txgen_dev(self, seed, frame0, counts, noise_amp, d_bb, d_payload=None, channel=0):
+        n = self.n_devices
+        cnt = (C.c_int * n)(*counts)
+        self._ck(self.lib.mgpu_pool_txgen_dev(self.h, C.c_uint64(seed), C.c_uint64(frame0), cnt, C.c_double(noise_amp), C.c_int(channel),
+                                              self._ptrs(d_bb, n), self._ptrs(d_payload, n)))
+
+    def receive_dev(self, d_bb, counts, d_payload, d_stats):
+        n = self.n_devices
+        cnt = (C.c_int * n)(*counts)
+        self._ck(self.lib.mgpu_pool_rx_batch_dev(self.h, self._ptrs(d_bb, n), cnt, self._ptrs(d_payload, n), self._ptrs(d_stats, n)))
+
+    def ldpc_decode_dev(self, d_llr, counts, d_bits, d_iters):
+        n = self.n_devices
+        cnt = (C.c_int * n)(*counts)
+        self._ck(self.lib.mgpu_pool_ldpc_batch_dev(self.h, self._ptrs(d_llr, n), cnt, self._ptrs(d_bits, n), self._ptrs(d_iters, n)))
+
+    def enable_timing(self, on=True):
+        for g in range(self.n_devices):
+            self.lib.mgpu_enable_timing(C.c_void_p(self.lib.mgpu_pool_context(self.h, g)), C.c_int(1 if on else 0))
+
+    def kernel_ms(self, g):
+        """(front-end ms, decoder ms, launches) averaged since enable_timing on pool device g."""
+        ms = (C.c_float * 2)()
+        n = C.c_int()
+        self.lib.mgpu_kernel_ms_avg(C.c_void_p(self.lib.mgpu_pool_context(self.h, g)), ms, C.byref(n))
+        return float(ms[0]), float(ms[1]), n.value
 
     def receive_buffer_samples(self):
         return int(self.lib.mgpu_receive_buffer_nsymb(self._ctx0)) * self.Nofdm * 4

@@ -38,6 +38,41 @@ int main(int argc, char** argv) {
         frames += n;
     }
     if (frames != F || k.frames != F) { std::fprintf(stderr, "counters\n"); return 1; }
+    // the same frames again as device-resident shards (mgpu_pool_rx_batch_dev): this program does not link HIP - memory, copies and
+    // ordering all go through the C-ABI - and the bytes that come back must be the ones the host-buffer call returned
+    {
+        const int G = k.n_devices;
+        std::vector<const void*> d_in(G);
+        std::vector<void*> d_pay(G), d_st(G);
+        std::vector<int> cnt(G), first(G);
+        for (int g = 0; g < G; ++g) {
+            mgpu_pool_shard(F, G, g, &first[g], &cnt[g]);
+            mgpu_ctx* ctx = mgpu_pool_context(pool, g);
+            const size_t n = size_t(cnt[g] > 0 ? cnt[g] : 1);
+            void* in = mgpu_device_malloc(ctx, n * info.frame_samples * 16);
+            d_pay[g] = mgpu_device_malloc(ctx, n * info.payload_stride);
+            d_st[g] = mgpu_device_malloc(ctx, n * sizeof(mgpu_frame_stats));
+            if (!in || !d_pay[g] || !d_st[g]) { std::fprintf(stderr, "device_malloc: %s\n", mgpu_last_error(ctx)); return 1; }
+            if (mgpu_copy_to_device(ctx, in, bb.data() + size_t(first[g]) * info.frame_samples * 2, size_t(cnt[g]) * info.frame_samples * 16, nullptr) != MGPU_OK) return 1;
+            d_in[g] = in;
+        }
+        if (mgpu_pool_rx_batch_dev(pool, d_in.data(), cnt.data(), d_pay.data(), d_st.data()) != MGPU_OK) { std::fprintf(stderr, "rx_dev: %s\n", mgpu_pool_last_error(pool)); return 1; }
+        mgpu_pool_counters kd;
+        mgpu_pool_last_counters(pool, &kd);
+        if (kd.decoded != k.decoded || kd.ldpc_iterations != k.ldpc_iterations || kd.frames != F) { std::fprintf(stderr, "dev counters\n"); return 1; }
+        std::vector<uint8_t> pd(pay.size());
+        std::vector<mgpu_frame_stats> sd(F);
+        for (int g = 0; g < G; ++g) {
+            mgpu_ctx* ctx = mgpu_pool_context(pool, g);
+            if (mgpu_copy_to_host(ctx, pd.data() + size_t(first[g]) * info.payload_stride, d_pay[g], size_t(cnt[g]) * info.payload_stride, nullptr) != MGPU_OK) return 1;
+            if (mgpu_copy_to_host(ctx, sd.data() + first[g], d_st[g], size_t(cnt[g]) * sizeof(mgpu_frame_stats), nullptr) != MGPU_OK) return 1;
+            mgpu_device_free(ctx, const_cast<void*>(d_in[g])); mgpu_device_free(ctx, d_pay[g]); mgpu_device_free(ctx, d_st[g]);
+        }
+        if (std::memcmp(pd.data(), pay.data(), pay.size()) != 0 || std::memcmp(sd.data(), st.data(), sizeof(mgpu_frame_stats) * F) != 0) {
+            std::fprintf(stderr, "device-resident shards differ from the host-buffer call\n");
+            return 1;
+        }
+    }
     mgpu_pool_destroy(pool);
     mgpu_ctx* one = nullptr;
     if (mgpu_create(&c, &one) != MGPU_OK) { std::fprintf(stderr, "create: %s\n", mgpu_last_error(nullptr)); return 1; }

@@ -434,6 +434,39 @@ def test_bench_two_ranks_on_one_gpu():
     assert "roofline" in j and "cpu_baseline" not in j
 
 
+def test_bench_pool_two_contexts_on_one_gpu():
+    """bench.py --pool: ONE process drives the devices through the C-ABI pool (include/mercury_pool.h), shards resident in each
+    device's memory - the host shape of the reference's RX_SHM loop (telecom_system.cc:2266-2390). Two contexts sharing GPU 0
+    here; `python bench.py --gpus N` (no torchrun) runs the same code on N GPUs. Also the decoder-only soak form."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--ldpc-only", "--iters", "5"]):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--pool", "--share-device", "--steps", "2", "--warmup", "1",
+               "--frames", "256", "--esn0", "2.5", "--no-extras"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["unit"] == "frames/s" and j["config"]["parallelism"].startswith("pool x2")
+        assert abs(j["value"] - 2 * 256 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-6 * j["value"]
+        assert "roofline" in j and len(j["pool_device_ms_per_step"]) == 2
+        if extra:
+            assert j["avg_iters_per_frame"] == 5.0           # noise-only LLRs: every codeword runs all 5 iterations
+        else:
+            assert j["decoded_fraction"] > 0.97               # both devices' frames decode (disjoint frame numbers, same seed)
+    # one device through the pool: the CPU leg cross-checks the very frames the pool decoded
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--pool", "--steps", "2", "--warmup", "1", "--frames", "128",
+           "--esn0", "2.5", "--cpu-sample-per-core", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["cpu_baseline"]["gpu_vs_cpu_mismatches"] == 0 and j["n_gpus"] == 1
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 12])
 def test_decoder_only_all_eight_rates_bpsk_llrs(cfg):
     """every LDPC rate with BPSK LLRs llr = 2y/sigma^2 around the waterfall, so that the

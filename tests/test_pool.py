@@ -116,6 +116,65 @@ def test_python_pool_rx_ldpc_and_receive_byte_equal_single_context():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg,F,devices", [(8, 37, [0, 0]), (16, 10, [0, 0, 0]), (8, 3, [0, 0, 0, 0])])
+def test_pool_device_resident_shards_equal_single_context(cfg, F, devices):
+    """mgpu_pool_rx_batch_dev / mgpu_pool_ldpc_batch_dev / mgpu_pool_txgen_dev: every device's shard lies in its
+    own memory (allocated through the C-ABI, no torch involved), outputs stay there. A pool of contexts on device 0 must give, shard
+    by shard, exactly the bytes one context gives for the whole batch - generated frames, payload, stats, hard bits and iterations -
+    and the merged counters must add up."""
+    from mercury_amd import RxPhy, RxPool, STATS_DTYPE
+    agc, vs = (0, 0) if cfg in (15, 16) else (1, 1)
+    one = RxPhy(cfg, max_batch=F, agc=agc, variance_source=vs)
+    pool = RxPool(cfg, devices, max_batch=F, agc=agc, variance_source=vs)
+    G = len(devices)
+    shards = pool.shard(F)
+    counts = [n for _, n in shards]
+    assert sum(counts) == F
+    fs, ps = one.frame_samples, one.payload_stride
+    d_bb = [pool.device_malloc(g, max(1, counts[g]) * fs * 16) for g in range(G)]
+    d_sent = [pool.device_malloc(g, max(1, counts[g]) * ps) for g in range(G)]
+    d_pay = [pool.device_malloc(g, max(1, counts[g]) * ps) for g in range(G)]
+    d_st = [pool.device_malloc(g, max(1, counts[g]) * 24) for g in range(G)]
+    amp = oraclelib.noise_amp_for(OPERATING_ESN0[cfg] + 0.5)
+    pool.txgen_dev(SEED, 9000, counts, amp, d_bb, d_sent)
+    pool.receive_dev(d_bb, counts, d_pay, d_st)
+    k = pool.counters()
+    bb = np.concatenate([pool.copy_to_host(g, np.zeros((counts[g], fs), np.complex128), d_bb[g]) for g in range(G) if counts[g]])
+    pay = np.concatenate([pool.copy_to_host(g, np.zeros((counts[g], ps), np.uint8), d_pay[g]) for g in range(G) if counts[g]])
+    st = np.concatenate([pool.copy_to_host(g, np.zeros(counts[g], STATS_DTYPE), d_st[g]) for g in range(G) if counts[g]])
+    # the single context on the same frames: generated on the device from the same (seed, frame numbers), received from host memory
+    orc = oraclelib.Oracle(cfg, 50)
+    sent = np.concatenate([pool.copy_to_host(g, np.zeros((counts[g], ps), np.uint8), d_sent[g]) for g in range(G) if counts[g]])
+    for f in (0, F // 2, F - 1):                                      # frame numbering runs across the devices (samples: up to libm ulps in the noise)
+        ref_bb, ref_pl = orc.gen_frame(SEED, 9000 + f, amp)
+        assert np.array_equal(sent[f][: orc.payload_bytes], ref_pl.astype(np.uint8))
+        assert np.abs(bb[f] - ref_bb).max() <= 1e-9 * np.abs(ref_bb).max()
+    ref = one.receive(bb, want_llr=True)
+    assert np.array_equal(pay, ref["payload"]) and st.tobytes() == ref["stats"].tobytes()
+    assert k["frames"] == F and k["device_frames"] == counts and k["decoded"] == int((ref["stats"]["message_decoded"] != 0).sum())
+    assert k["ldpc_iterations"] == int(np.minimum(ref["stats"]["iterations_done"], 50).sum())
+    assert k["decoded"] >= F // 2
+    # decoder only, LLRs uploaded shard by shard
+    d_llr = [pool.device_malloc(g, max(1, counts[g]) * 1600 * 4) for g in range(G)]
+    d_bits = [pool.device_malloc(g, max(1, counts[g]) * one.K) for g in range(G)]
+    d_it = [pool.device_malloc(g, max(1, counts[g]) * 4) for g in range(G)]
+    for g, (a, n) in enumerate(shards):
+        if n:
+            pool.copy_to_device(g, d_llr[g], ref["llr_ldpc"][a: a + n])
+    pool.ldpc_decode_dev(d_llr, counts, d_bits, d_it)
+    bits = np.concatenate([pool.copy_to_host(g, np.zeros((counts[g], one.K), np.uint8), d_bits[g]) for g in range(G) if counts[g]])
+    its = np.concatenate([pool.copy_to_host(g, np.zeros(counts[g], np.int32), d_it[g]) for g in range(G) if counts[g]])
+    b1, i1 = one.ldpc_decode(ref["llr_ldpc"])
+    assert np.array_equal(bits, b1) and np.array_equal(its, i1)
+    assert pool.counters()["ldpc_iterations"] == int(np.minimum(i1, 50).sum())
+    for g in range(G):
+        for p in (d_bb[g], d_sent[g], d_pay[g], d_st[g], d_llr[g], d_bits[g], d_it[g]):
+            pool.device_free(g, p)
+    one.close()
+    pool.close()
+
+
+@pytest.mark.gpu
 def test_one_thread_two_contexts_graph_order_and_device_scope():
     """(high) the single-frame hipGraph must survive a larger batch reallocating the context's input buffer
     (order F=1, F=max, F=1 on a fresh context); (medium) every entry point runs on the context's own device whatever the

@@ -1,30 +1,32 @@
 #!/bin/bash
-# Reproduces the evidence under profiles/ on a GPU box (run from the repo root; writes to gpurun_out/r02/, copy what you want judged
-# into profiles/). Counter passes are separate rocprofv3 runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md
+# Reproduces the evidence under profiles/ on a GPU box (run from the repo root; writes to gpurun_out/$R/ with R = the round prefix,
+# default r03; copy what you want judged into profiles/). Counter passes are separate rocprofv3 runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md
 # prescribes; never combine --pmc with sys/hip/hsa traces on this pool.
 #   tools/collect_profiles.sh            bench lines + kernel stats + PMC opcode mix / stall counters (cfg 8: spa, spa_fast, minsum) + opcode costs
 #   tools/collect_profiles.sh sweep      additionally: decoder comparison on all 20 modes, the 20-mode throughput sweep, sync blocks,
 #                                        receive_byte chain, host-buffer path, transmit chain
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/r02
+R=${R:-r03}
+OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 [ -x "$ROOT/tools/ubench/valu_cycles" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/valu_cycles" "$ROOT/tools/ubench/valu_cycles.hip"
-"$ROOT/tools/ubench/valu_cycles" > "$OUT/r02_valu_cycles.json"
+"$ROOT/tools/ubench/valu_cycles" > "$OUT/${R}_valu_cycles.json"
 [ -x "$ROOT/tools/ubench/dep_chain" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/dep_chain" "$ROOT/tools/ubench/dep_chain.hip" 2>/dev/null
-"$ROOT/tools/ubench/dep_chain" > "$OUT/r02_dep_chain.json"
+"$ROOT/tools/ubench/dep_chain" > "$OUT/${R}_dep_chain.json"
 for d in spa spa_fast minsum; do
-  python "$ROOT/bench.py" --decoder $d > "$OUT/r02_bench_${d}_cfg8.json" 2>/dev/null
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$d" -- python "$ROOT/bench.py" --decoder $d --no-cpu-baseline --no-extras > /dev/null 2>&1
-  cp "$(find "$OUT/prof_$d" -name '*kernel_stats.csv' | head -1)" "$OUT/r02_bench_${d}_cfg8_kernel_stats.csv"
-  rm -rf "$OUT/prof_$d"
   "$ROOT/tools/collect_pmc_mix.sh" $d "$OUT/pmc_mix_$d.json" > /dev/null 2> "$OUT/pmc_mix_$d.err" || true
 done
-python - "$OUT" <<'PY'
+"$ROOT/tools/collect_pmc_mix.sh" spa "$OUT/pmc_mix_spa_cfg16.json" --cfg 16 > /dev/null 2> "$OUT/pmc_mix_spa_cfg16.err" || true
+python - "$OUT" "$ROOT" "$R" <<'PY'
 import json, sys, os
-out = sys.argv[1]
-mix = {}
+out, root, R = sys.argv[1:4]
+sys.path.insert(0, root)
+from mercury_amd.build import decoder_digest
+mix = {"decoder_digest": decoder_digest(),
+       "note": "average per launch of the headline workload (bench.py defaults: 4096 mode-8 frames, 50 iterations each); separate rocprofv3 --pmc "
+               "passes (tools/collect_pmc_mix.sh); bench.py quotes this file only while decoder_digest matches mercury_amd.build.decoder_digest()"}
 for d in ("spa", "spa_fast", "minsum"):
     f = os.path.join(out, "pmc_mix_%s.json" % d)
     if os.path.exists(f):
@@ -33,25 +35,44 @@ for d in ("spa", "spa_fast", "minsum"):
                 mix[d] = dict(v, kernel=k)
             elif "frontend" in k:
                 mix["frontend"] = dict(v, kernel=k)
-json.dump(mix, open(os.path.join(out, "r02_instruction_mix.json"), "w"), indent=1)
+f = os.path.join(out, "pmc_mix_spa_cfg16.json")
+if os.path.exists(f):
+    for k, v in json.load(open(f)).items():
+        if "ldpc" in k:
+            mix["spa_cfg16"] = dict(v, kernel=k)
+json.dump(mix, open(os.path.join(out, "%s_instruction_mix.json" % R), "w"), indent=1)
+json.dump(mix, open(os.path.join(root, "profiles", "%s_instruction_mix.json" % R), "w"), indent=1)     # where bench.py looks for it
 PY
+for d in spa spa_fast minsum; do
+  python "$ROOT/bench.py" --decoder $d > "$OUT/${R}_bench_${d}_cfg8.json" 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$d" -- python "$ROOT/bench.py" --decoder $d --no-cpu-baseline --no-extras > /dev/null 2>&1
+  cp "$(find "$OUT/prof_$d" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_bench_${d}_cfg8_kernel_stats.csv"
+  rm -rf "$OUT/prof_$d"
+done
+# the high-degree graph (rate 14/16: modes 12, 14, 15, 16; BASELINE.json configs[3])
+python "$ROOT/bench.py" --cfg 16 --variant baseband_test --no-extras > "$OUT/${R}_bench_spa_cfg16.json" 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_16" -- python "$ROOT/bench.py" --cfg 16 --variant baseband_test --no-cpu-baseline --no-extras > /dev/null 2>&1
+cp "$(find "$OUT/prof_16" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_bench_spa_cfg16_kernel_stats.csv"
+rm -rf "$OUT/prof_16"
+python "$ROOT/bench.py" --cfg 16 --variant baseband_test --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_fast_cfg16.json" 2>/dev/null
+python "$ROOT/bench.py" --gpus 1 --pool --no-extras > "$OUT/${R}_bench_spa_cfg8_pool.json" 2>/dev/null
 if [ "$1" = "sweep" ]; then
   cd "$ROOT"
-  python tools/compare_decoders.py 4096 > "$OUT/r02_compare_decoders.json" 2> "$OUT/r02_compare_decoders.txt"
-  python tools/sweep_modes.py > "$OUT/r02_mode_sweep.json" 2> "$OUT/r02_mode_sweep.txt"
-  python tools/bench_sync.py > "$OUT/r02_bench_sync_blocks.json"
-  python tests/tools/bench_receive_byte.py 8 1024 > "$OUT/r02_bench_receive_byte_cfg8.json"
-  tools/timeline_receive_byte.sh 8 1024 > "$OUT/r02_receive_byte_timeline.txt" 2>/dev/null || true
-  python tools/bench_host_path.py 8 4096 -15 > "$OUT/r02_bench_host_path_cfg8.json"
-  python tools/bench_tx.py 8 4096 > "$OUT/r02_bench_tx_cfg8.json"
-  python tools/bench_tsync_variants.py > "$OUT/r02_bench_tsync_variants.json" 2>/dev/null
-  python tools/bench_tsync_fine.py > "$OUT/r02_bench_tsync_fine.json" 2>/dev/null
-  tools/pmc_any.sh tsync_metric_fine "$OUT/r02_pmc_tsync_fine.json" -- python tools/bench_tsync_fine.py 1024 > /dev/null 2>&1 || true
-  tools/pmc_any.sh p2b_slide_d1_kernel "$OUT/r02_pmc_p2b.json" -- python tools/bench_sync.py > /dev/null 2>&1 || true
-  tools/pmc_any.sh tsync_metric_stream "$OUT/r02_pmc_tsync_stream.json" -- python tools/bench_tsync_variants.py 1024 > /dev/null 2>&1 || true
-  tools/pmc_any.sh mfsk_frontend "$OUT/r02_pmc_mfsk_frontend.json" -- python bench.py --cfg 100 --decoder spa_fast --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frames 2048 > /dev/null 2>&1 || true
-  python bench.py --cfg 100 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/r02_bench_spa_fast_cfg100.json" 2>/dev/null
-  python bench.py --cfg 0 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/r02_bench_spa_fast_cfg0.json" 2>/dev/null
-  python bench.py --cfg 0 --decoder spa --no-cpu-baseline --no-extras > "$OUT/r02_bench_spa_cfg0.json" 2>/dev/null
+  python tools/compare_decoders.py 4096 > "$OUT/${R}_compare_decoders.json" 2> "$OUT/${R}_compare_decoders.txt"
+  python tools/sweep_modes.py > "$OUT/${R}_mode_sweep.json" 2> "$OUT/${R}_mode_sweep.txt"
+  python tools/bench_sync.py > "$OUT/${R}_bench_sync_blocks.json"
+  python tests/tools/bench_receive_byte.py 8 1024 > "$OUT/${R}_bench_receive_byte_cfg8.json"
+  tools/timeline_receive_byte.sh 8 1024 > "$OUT/${R}_receive_byte_timeline.txt" 2>/dev/null || true
+  python tools/bench_host_path.py 8 4096 -15 > "$OUT/${R}_bench_host_path_cfg8.json"
+  python tools/bench_tx.py 8 4096 > "$OUT/${R}_bench_tx_cfg8.json"
+  python tools/bench_tsync_variants.py > "$OUT/${R}_bench_tsync_variants.json" 2>/dev/null
+  python tools/bench_tsync_fine.py > "$OUT/${R}_bench_tsync_fine.json" 2>/dev/null
+  tools/pmc_any.sh tsync_metric_fine "$OUT/${R}_pmc_tsync_fine.json" -- python tools/bench_tsync_fine.py 1024 > /dev/null 2>&1 || true
+  tools/pmc_any.sh p2b_slide_d1_kernel "$OUT/${R}_pmc_p2b.json" -- python tools/bench_sync.py > /dev/null 2>&1 || true
+  tools/pmc_any.sh tsync_metric_stream "$OUT/${R}_pmc_tsync_stream.json" -- python tools/bench_tsync_variants.py 1024 > /dev/null 2>&1 || true
+  tools/pmc_any.sh mfsk_frontend "$OUT/${R}_pmc_mfsk_frontend.json" -- python bench.py --cfg 100 --decoder spa_fast --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frames 2048 > /dev/null 2>&1 || true
+  python bench.py --cfg 100 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_fast_cfg100.json" 2>/dev/null
+  python bench.py --cfg 0 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_fast_cfg0.json" 2>/dev/null
+  python bench.py --cfg 0 --decoder spa --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_cfg0.json" 2>/dev/null
 fi
 ls -la "$OUT"
