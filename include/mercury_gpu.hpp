@@ -140,13 +140,36 @@ public:
     ~cl_rx_phy() { release(); }
 
     // telecom_system.cc:2487 — re-initialises everything the mode owns; a no-op for the current mode
+    int last_configuration = -1;      // telecom_system.h: last_configuration (CONFIG_NONE)
     void load_configuration(int configuration) {
         if (configuration == current_configuration && ctx_) return;
         if (!((configuration >= 0 && configuration <= 16) || (configuration >= 100 && configuration <= 102))) return;   // the reference returns silently too (:2494-2497)
         release();
+        last_configuration = current_configuration < 0 ? configuration : current_configuration;     // telecom_system.cc:2671-2680
         current_configuration = configuration;
         mfsk_ctrl_mode = false;               // load_configuration leaves control-frame mode (telecom_system.cc:2990)
         select(0);
+        // init() measures the filter chain whenever the modulation or the preamble length changed (telecom_system.cc:1954-1958, :2682-2691);
+        // the table depends on the modulation, the pilot count and the carrier only, so measuring it on every load gives the same table
+        if (configuration < 100) get_pre_equalization_channel();
+    }
+    // void cl_telecom_system::return_to_last_configuration() — telecom_system.cc:3027-3034
+    void return_to_last_configuration() {
+        const int now = current_configuration, back = last_configuration;
+        load_configuration(back);
+        last_configuration = back;
+        current_configuration = now;
+        std::swap(last_configuration, current_configuration);
+    }
+    // void cl_telecom_system::get_pre_equalization_channel() — telecom_system.cc:3108-3145: measured for carrier_frequency and installed;
+    // transmit_bit / transmit_byte multiply the preamble and data grids with it (:474-494). The OFDM modes only (:1954).
+    std::vector<std::complex<double>> pre_equalization_channel;
+    void get_pre_equalization_channel() {
+        pre_equalization_channel.assign(info.Nc, std::complex<double>(0, 0));
+        if (mgpu_host_pre_equalization_channel(current_configuration, carrier_frequency, reinterpret_cast<double*>(pre_equalization_channel.data())) != MGPU_OK)
+            throw std::runtime_error("get_pre_equalization_channel: the OFDM modes only");
+        detail::check(mgpu_set_pre_equalization_channel(ctx_, reinterpret_cast<const double*>(pre_equalization_channel.data())), ctx_,
+                      "get_pre_equalization_channel");
     }
     // void cl_telecom_system::set_mfsk_ctrl_mode(bool) (telecom_system.cc:1572-1584): short control frames in the MFSK modes.
     // The frame geometry is part of a context's tables, so the mirror keeps one context per setting and switches between them.
@@ -227,6 +250,44 @@ public:
         detail::check(mgpu_transmit_byte_batch(ctx_, bytes.data(), info.payload_bytes, &nBytes, 1, &tc, out), ctx_, "transmit_byte");
         passband_start_sample += static_cast<unsigned long>(info.preamble_nsymb + info.active_nsymb) * info.Nofdm * 4;
         return true;
+    }
+
+    // void cl_telecom_system::transmit_bit(int* data, double* out, int message_location) — telecom_system.h:138, .cc:384-556: the
+    // get_frame_size_bits() + 16 = nReal data bits as they are (transmit_byte has appended the CRC and the padding by then).
+    void transmit_bit(const int* data, double* out, int message_location) {
+        std::vector<uint8_t> bits(info.nReal);
+        for (int i = 0; i < info.nReal; ++i) bits[i] = uint8_t(data[i] & 1);
+        const mgpu_transmit_config tc{carrier_frequency, carrier_amplitude, output_power_Watt, preamble_papr_cut, data_papr_cut,
+                                      passband_start_sample, message_location, 0};
+        detail::check(mgpu_transmit_bit_batch(ctx_, bits.data(), 1, &tc, out), ctx_, "transmit_bit");
+        passband_start_sample += static_cast<unsigned long>(info.preamble_nsymb + info.active_nsymb) * info.Nofdm * 4;
+    }
+    // st_receive_stats cl_telecom_system::receive_bit(double* data, int* out) — telecom_system.h:139, .cc:636-644: receive_byte into the
+    // decoder's byte buffer, then byte_to_bit over nReal / 8 bytes (misc.cc:93-105, LSB first): out receives (nReal / 8) * 8 ints, the
+    // de-scrambled decoded bits CRC included. (Like receive_byte, nothing is written when no decode was attempted.)
+    st_receive_stats receive_bit(const double* data, int* out) {
+        mgpu_receive_config rc{carrier_frequency, time_sync_trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync_enabled};
+        int search_start = receive_stats.mfsk_search_raw - nUnder_processing_events;
+        if (search_start < 0) search_start = 0;
+        mgpu_link_state ls{receive_stats.delay_of_last_decoded_message, receive_stats.freq_offset_of_last_decoded_message, search_start,
+                           (info.mfsk_M > 0 && mfsk_fixed_delay >= 0) ? mfsk_fixed_delay + 1 : 0};
+        mfsk_fixed_delay = -1;
+        mgpu_receive_stats r{};
+        std::vector<uint8_t> bytes(info.payload_stride);
+        detail::check(mgpu_receive_byte_batch(ctx_, data, 1, &rc, &ls, bytes.data(), &r), ctx_, "receive_bit");
+        if (r.iterations_done != -1)
+            for (int i = 0; i < info.nReal / 8; ++i)
+                for (int j = 0; j < 8; ++j) out[i * 8 + j] = (bytes[i] >> j) & 1;
+        if (r.iterations_done != -1 || r.message_decoded) {
+            receive_stats.iterations_done = r.iterations_done; receive_stats.crc = r.crc; receive_stats.all_zeros = r.all_zeros;
+        }
+        receive_stats.message_decoded = r.message_decoded; receive_stats.SNR = r.snr_db;
+        receive_stats.delay = r.delay; receive_stats.sync_trials = r.sync_trials; receive_stats.coarse_metric = r.coarse_metric;
+        receive_stats.frame_overflow_symbols = r.frame_overflow_symbols;
+        if (r.message_decoded) receive_stats.freq_offset = r.freq_offset;
+        receive_stats.delay_of_last_decoded_message = ls.delay_of_last_decoded_message;
+        receive_stats.freq_offset_of_last_decoded_message = ls.freq_offset_of_last_decoded_message;
+        return receive_stats;
     }
 
     // One synchronised frame: `baseband` points at the first data symbol, i.e. what receive_byte passes to

@@ -12,8 +12,16 @@
  * fixes the CPU restatement bit for bit, and the GPU output must equal it bit for bit (tests/test_transmit_byte.py).
  * The FIRST / MIDDLE / FLUSH_MESSAGE overlap-save variants (:559-590), which filter across consecutive calls through the
  * 3-frame passband_data_tx_buffer, are batched too: F consecutive calls in one, the buffer kept in the context between
- * calls (mgpu_transmit_buffer reads or replaces it). Not built: pre_equalization_channel (all ones unless a GUI
- * calibration sets it).
+ * calls (mgpu_transmit_buffer reads or replaces it).
+ *
+ * pre_equalization_channel (telecom_system.h:186): init() measures the transmit / receive filter chain once per loaded modulation
+ * (get_pre_equalization_channel, telecom_system.cc:1954-1958, :3108-3145: 1000 random symbols through symbol_mod, the mixer, FIR_tx1,
+ * FIR_tx2, the receive mixer + FIR_rx_data and symbol_demod; mean of sent / received per carrier) and transmit_bit multiplies the
+ * preamble and data grids with it (:474-494). mgpu_host_pre_equalization_channel computes that table for a freshly loaded
+ * configuration and a carrier (on the host: it is an init-time table like the filters), mgpu_set_pre_equalization_channel installs
+ * it in a context; a new context has none installed (= all ones), the C++ mirror installs it in its constructor like init() does.
+ * Pinned like the rest: the table and the audio with it equal oracle/ref_harness.cc's composition of the reference's objects bit
+ * for bit (tests/test_transmit_byte.py, tests/golden/golden_tx.json).
  */
 #ifndef MERCURY_TX_H
 #define MERCURY_TX_H
@@ -51,6 +59,13 @@ typedef struct mgpu_transmit_config {
                                    (always so for MGPU_BATCH_MESSAGE) */
 } mgpu_transmit_config;
 
+/* cl_telecom_system::get_pre_equalization_channel for a process that has loaded configuration `cfg` (0..16 or an MGPU_CFG_EXPLICIT id)
+ * with carrier_frequency = carrier_hz: channel_c128 [Nc = 50] complex128. Host only (no GPU needed), about 0.2 s. */
+int mgpu_host_pre_equalization_channel(int cfg, double carrier_hz, double* channel_c128);
+/* installs the table transmit_bit multiplies the carrier grids with (telecom_system.cc:474-494) in this context, [Nc] complex128;
+ * NULL removes it (all ones). Synchronises the context's stream. The MFSK modes have none (telecom_system.cc:474). */
+int mgpu_set_pre_equalization_channel(mgpu_ctx* ctx, const double* channel_c128);
+
 /* total_frame_size = Nofdm * (Nsymb + preamble_nSymb) * 4 (data_container.cc:159): samples written per message */
 int mgpu_transmit_frame_samples(mgpu_ctx* ctx);
 
@@ -59,6 +74,10 @@ int mgpu_transmit_frame_samples(mgpu_ctx* ctx);
  * control frame the row is zero. Host buffers, blocking. */
 int mgpu_transmit_byte_batch(mgpu_ctx* ctx, const uint8_t* payload, int payload_stride, const int* nbytes, int F,
                              const mgpu_transmit_config* config, double* passband);
+/* void cl_telecom_system::transmit_bit(int* data, double* out, int message_location) (telecom_system.h:138, .cc:384-556) for F frames:
+ * bits [F][nReal] (mgpu_info.nReal), one byte per data bit, sent as they are - no CRC, no padding (transmit_byte makes those and calls
+ * this). Everything else as mgpu_transmit_byte_batch. */
+int mgpu_transmit_bit_batch(mgpu_ctx* ctx, const uint8_t* bits, int F, const mgpu_transmit_config* config, double* passband);
 /* the same on device buffers: asynchronous on `stream` when one is given (the context's work buffers are reused by its next
  * transmit call, so keep one context's calls on one stream); with NULL the context's own stream is used and synchronised */
 int mgpu_transmit_byte_batch_dev(mgpu_ctx* ctx, const void* d_payload, int payload_stride, const void* d_nbytes, int F,

@@ -130,6 +130,9 @@ struct mgpu_ctx {
     double mix_carrier = -1;
     size_t mix_count = 0, mix_cap = 0;
     void* tx_state = nullptr;       // transmit path: preamble baseband, filter taps, carrier table (tx.hip)
+    std::vector<double> pre_eq;     // [Nc][2] installed pre_equalization_channel (empty: none); dev.pre_eq is its device copy
+    double* d_pre_eq_buf = nullptr; // device copy of pre_eq (owned through keep())
+    int pre_eq_version = 0;         // bumped by mgpu_set_pre_equalization_channel: the transmit state rebuilds its preamble
     void (*tx_state_free)(void*) = nullptr;
     hipStream_t stream = nullptr;   // private stream for the host-buffer entry points
     struct Pipe { hipStream_t stream = nullptr; hipEvent_t done = nullptr, copied = nullptr; double* d_in = nullptr; size_t cap = 0; };

@@ -10,6 +10,7 @@ struct MgpuDev {
     const uint16_t* pilot_cell;    // [nPilots] row-major list of pilot cells
     const double* constellation;   // [M][2]
     const double* twiddle;         // [128][2]
+    const double* pre_eq;          // [Nc][2] pre_equalization_channel the transmit path multiplies the carrier grid with, or NULL (none)
     const uint16_t* sym_src;       // [nData]
     const uint16_t* llr_src;       // [1600]
     const double* ls_weight;       // [lsw*lsw+1]

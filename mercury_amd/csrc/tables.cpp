@@ -2,6 +2,7 @@
 #include "tables.hpp"
 
 #include <algorithm>
+#include <complex>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -283,6 +284,115 @@ std::vector<double> design_tx_fir(int which, double carrier_hz) {
         for (int i = 0; i < n; ++i) c[i] *= 0.42 - 0.5 * std::cos(2.0 * M_PI * double(i) / n) + 0.08 * std::cos(4.0 * M_PI * double(i) / n);
     }
     return c;
+}
+
+// cl_telecom_system::get_pre_equalization_channel (telecom_system.cc:3108-3145) as init() reaches it (:1954-1958) in a process that
+// has loaded this one configuration. An init-time table like the filters above, so it is computed on the host, statement by statement:
+// 1000 x [Nc random symbols (the PRNG continues where cl_ofdm::init left it: __srandom(pilot seed 0), one draw per pilot, ofdm.cc:112-113,
+// :940-951) -> psk.mod -> symbol_mod -> baseband_to_passband (phase origin 0, ofdm.cc:2293-2315) -> FIR_tx1 -> FIR_tx2 (fir_filter.cc:189-210)
+// -> passband_to_baseband (FIR_rx_data, decimation 4, ofdm.cc:2316-2339) -> symbol_demod], mean of sent / received per carrier.
+std::vector<Cplx> pre_equalization_channel(const ModeTables& t, double carrier_hz) {
+    if (t.mfsk_M > 0) throw std::runtime_error("pre_equalization_channel: the OFDM modes only (telecom_system.cc:1954)");
+    typedef std::complex<double> cd;
+    const double fs = 48000.0, amplitude = std::sqrt(2.0), Ts = 1.0 / fs;       // carrier_amplitude: telecom_system.cc:69
+    const int interp = 4, Nofdm = t.Nofdm, Nc = t.Nc, n = Nofdm * interp, nTries = 1000;
+    const std::vector<double> f1 = design_tx_fir(0, carrier_hz), f2 = design_tx_fir(1, carrier_hz);
+    const std::vector<double>& frx = t.fir_data;
+    int bitrev[256];
+    for (int i = 0; i < 256; ++i) { int r = 0; for (int b = 0; b < 8; ++b) if (i & (1 << b)) r |= 1 << (7 - b); bitrev[i] = r; }
+    auto cmul = [](cd a, cd b) { return cd(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real()); };
+    auto fft256 = [&](cd* v, bool inverse) {                                     // _fft_fast / _ifft_fast, ofdm.cc:310-377
+        for (int i = 0; i < 256; ++i) if (i < bitrev[i]) std::swap(v[i], v[bitrev[i]]);
+        for (int size = 2; size <= 256; size *= 2) {
+            const int half = size / 2, step = 256 / size;
+            for (int i = 0; i < 256; i += size)
+                for (int j = 0; j < half; ++j) {
+                    cd w(t.twiddle[j * step].re, t.twiddle[j * step].im);
+                    if (inverse) w = std::conj(w);
+                    const cd x = cmul(w, v[i + j + half]);
+                    v[i + j + half] = v[i + j] - x;
+                    v[i + j] = v[i + j] + x;
+                }
+        }
+    };
+    // std::complex operator/ in the reference's build = libgcc's __divdc3 (Smith's method; operands finite and normal here). Spelled out:
+    // this file is compiled by clang, whose runtime divides complex numbers by another method that differs in the last ulp.
+    auto cdiv = [](cd x, cd y) {
+        const double a = x.real(), b = x.imag(), c = y.real(), d = y.imag();
+        if (std::fabs(c) < std::fabs(d)) {
+            const double ratio = c / d, denom = (c * ratio) + d;
+            return cd(((a * ratio) + b) / denom, ((b * ratio) - a) / denom);
+        }
+        const double ratio = d / c, denom = (d * ratio) + c;
+        return cd(((b * ratio) + a) / denom, (b - (a * ratio)) / denom);
+    };
+    auto lerp = [](cd a, double ax, cd b, double bx, double x) {                 // interpolate_linear, interpolator.cc:43-50
+        const cd d = b - a;
+        const double m = x - ax, q = bx - ax;
+        cd r(d.real() * m, d.imag() * m);
+        r = cd(r.real() / q, r.imag() / q);
+        return a + r;
+    };
+    auto fir_real = [](const std::vector<double>& c, const double* in, double* out, int len) {   // cl_FIR::apply(double*), fir_filter.cc:189-210
+        const int nt = int(c.size()), h = (nt - 1) / 2;
+        for (int i = 0; i < len + nt - 1; ++i) {
+            double acc = 0;
+            for (int j = 0; j < nt; ++j) if (i - j >= 0 && i - j < len) acc += in[i - j] * c[j];
+            if (i >= h && i < len + h) out[i - h] = acc;
+        }
+    };
+    GlibcRandom rng(0);
+    for (int i = 0; i < t.nPilots; ++i) (void)rng.next();
+    std::vector<cd> acc(Nc, cd(0, 0)), mod(Nc), sym(Nofdm), bb(Nofdm), dem(Nc), mixed(n);
+    std::vector<double> pb(n), t1(n), t2(n), cs(2 * size_t(n));
+    // the carrier phases are the same in every try (phase origin 0 both ways). The reference's build evaluates cos and sin of one phase
+    // as a single sincos() call (the compiler merges the pair); glibc's sincos is not bit-for-bit its cos + sin, so the same call here
+    for (int i = 0; i < n; ++i) ::sincos(2 * M_PI * carrier_hz * double(i) * Ts, &cs[2 * i + 1], &cs[2 * i]);
+    for (int tr = 0; tr < nTries; ++tr) {
+        for (int i = 0; i < Nc; ++i) {                                           // psk.mod, psk.cc:259-272
+            unsigned loc = 0;
+            for (int j = 0; j < t.bps; ++j) { loc += unsigned(rng.next() % 2); loc <<= 1; }
+            loc >>= 1;
+            mod[i] = cd(t.constellation[loc].re, t.constellation[loc].im);
+        }
+        cd z[256];                                                               // symbol_mod, ofdm.cc:855-860
+        for (auto& v : z) v = cd(0, 0);
+        for (int j = 0; j < 25; ++j) z[j + 256 - 25] = mod[j];
+        for (int j = 25; j < 50; ++j) z[j - 25 + 1] = mod[j];
+        fft256(z, true);
+        for (int j = 0; j < 256; ++j) sym[j + 16] = z[j];
+        for (int j = 0; j < 16; ++j) sym[j] = z[j + 256 - 16];
+        for (int i = 0; i < Nofdm; ++i)                                          // rational_resampler INTERPOLATION + mixer
+            for (int j = 0; j < interp; ++j) {
+                const cd v = i < Nofdm - 1 ? lerp(sym[i], 0, sym[i + 1], interp, j) : lerp(sym[Nofdm - 2], 0, sym[Nofdm - 1], interp, interp + j);
+                const int k = i * interp + j;
+                pb[k] = v.real() * amplitude * cs[2 * k];
+                pb[k] += v.imag() * amplitude * cs[2 * k + 1];
+            }
+        fir_real(f1, pb.data(), t1.data(), n);
+        fir_real(f2, t1.data(), t2.data(), n);
+        for (int i = 0; i < n; ++i) mixed[i] = cd(t2[i] * amplitude * cs[2 * i], t2[i] * amplitude * cs[2 * i + 1]);
+        {                                                                        // cl_FIR::apply(complex) fir_filter.cc:164-187 + DECIMATION ofdm.cc:2267-2278
+            const int nt = int(frx.size()), h = (nt - 1) / 2;
+            int index = 0;
+            for (int m = 0; m < n; m += interp) {
+                double ar = 0, ai = 0;
+                const int i = m + h;
+                for (int j = 0; j < nt; ++j)
+                    if (i - j >= 0 && i - j < n) { ar += mixed[i - j].real() * frx[j]; ai += mixed[i - j].imag() * frx[j]; }
+                bb[index++] = cd(ar, ai);
+            }
+        }
+        for (int j = 0; j < 256; ++j) z[j] = bb[j + 16];                         // symbol_demod, ofdm.cc:862-867
+        fft256(z, false);
+        for (int j = 0; j < 256; ++j) z[j] = cd(z[j].real() / 256.0, z[j].imag() / 256.0);
+        for (int j = 0; j < 25; ++j) dem[j] = z[j + 256 - 25];
+        for (int j = 25; j < 50; ++j) dem[j] = z[j - 25 + 1];
+        for (int i = 0; i < Nc; ++i) acc[i] += cdiv(mod[i], dem[i]);
+    }
+    std::vector<Cplx> out(Nc);
+    for (int i = 0; i < Nc; ++i) out[i] = {acc[i].real() / double(nTries), acc[i].imag() / double(nTries)};
+    return out;
 }
 
 // explicit (M, LDPC rate, preamble length, estimator) combinations outside the 17 rows of load_configuration: cfg id

@@ -94,6 +94,9 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* ldpc_bl
 
 uint16_t crc16_modbus(const uint8_t* bytes, int n);
 
+// pre_equalization_channel of a freshly loaded configuration for a given carrier (telecom_system.cc:3108-3145): [Nc]
+std::vector<Cplx> pre_equalization_channel(const ModeTables& t, double carrier_hz);
+
 // transmit filters for a given carrier: which 0 = FIR_tx1 (HPF, Hamming), 1 = FIR_tx2 (LPF, Blackman); physical_config.cc:103-113
 std::vector<double> design_tx_fir(int which, double carrier_hz);
 

@@ -8,6 +8,7 @@
 // Everything is FP64 in the reference's operation order (no FMA contraction in this TU), so the samples equal the
 // reference's bit for bit; the carrier cos/sin and the two pow() constants come from the host libm like the reference's.
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <map>
 
@@ -175,6 +176,7 @@ struct TxState {
     int ntaps[2] = {0, 0};
     double* d_cs = nullptr;
     size_t cs_cap = 0;
+    int pre_eq_version = 0;                             // the context's pre_eq_version d_pre_bb was built with
     double* d_tx_buffer = nullptr;                      // passband_data_tx_buffer: 3 frames of unfiltered audio carried between the
                                                         // FIRST / MIDDLE / FLUSH_MESSAGE calls (telecom_system.cc:559-590); zero at first
     void* d_work[3] = {nullptr, nullptr, nullptr};      // data baseband, clipped passband, first filter's output: grown on demand, kept
@@ -204,14 +206,30 @@ void launch_symbol_mod(mgpu_ctx* c, const double* d_carriers, int n, double* d_o
     HIPCK(hipGetLastError());
 }
 
+// the preamble's baseband (symbol_mod of the preamble carriers, with the installed pre_equalization_channel: telecom_system.cc:477-484)
+void build_preamble_baseband(mgpu_ctx* c, TxState* st, hipStream_t s) {
+    const auto& t = c->tab;
+    std::vector<mgpu::Cplx> car = t.preamble_carriers;
+    if (!c->pre_eq.empty() && t.mfsk_M == 0)
+        for (size_t i = 0; i < car.size(); ++i) {
+            const double hr = c->pre_eq[2 * (i % t.Nc)], hi = c->pre_eq[2 * (i % t.Nc) + 1], gr = car[i].re, gi = car[i].im;
+            car[i] = {gr * hr - gi * hi, gr * hi + gi * hr};
+        }
+    DevBuf d_car(car.size() * 16);
+    HIPCK(hipMemcpyAsync(d_car.p, car.data(), car.size() * 16, hipMemcpyHostToDevice, s));
+    launch_symbol_mod(c, d_car.as<double>(), t.preamble, st->d_pre_bb, s);
+    HIPCK(hipStreamSynchronize(s));
+    st->pre_eq_version = c->pre_eq_version;
+}
+
 TxState& tx_state(mgpu_ctx* c, hipStream_t s) {
+    if (c->tx_state && static_cast<TxState*>(c->tx_state)->pre_eq_version != c->pre_eq_version)
+        build_preamble_baseband(c, static_cast<TxState*>(c->tx_state), s);
     if (!c->tx_state) {
         std::unique_ptr<TxState> st(new TxState);            // published in the context only once it is complete
         const auto& t = c->tab;
-        DevBuf d_car(t.preamble_carriers.size() * 16);
-        HIPCK(hipMemcpyAsync(d_car.p, t.preamble_carriers.data(), t.preamble_carriers.size() * 16, hipMemcpyHostToDevice, s));
         HIPCK(hipMalloc(reinterpret_cast<void**>(&st->d_pre_bb), size_t(t.preamble) * t.Nofdm * 16));
-        launch_symbol_mod(c, d_car.as<double>(), t.preamble, st->d_pre_bb, s);
+        build_preamble_baseband(c, st.get(), s);
         const size_t total = size_t(t.Nofdm) * (t.Nsymb + t.preamble) * 4;
         HIPCK(hipMalloc(reinterpret_cast<void**>(&st->d_tx_buffer), 3 * total * 8));
         HIPCK(hipMemsetAsync(st->d_tx_buffer, 0, 3 * total * 8, s));
@@ -296,7 +314,7 @@ void transmit_dev(mgpu_ctx* c, const uint8_t* d_payload, int payload_stride, con
         const int n = std::min(F - off, kMaxFramesPerLaunch);
         hipLaunchKernelGGL(mgpu_txgen_kernel, dim3(n), dim3(256), c->lds_tx, s, c->dev, uint64_t(0), uint64_t(0), n, 0.0, -1,
                            bb + size_t(off) * t.frame_samples * 2, static_cast<uint8_t*>(nullptr),
-                           d_payload + size_t(off) * payload_stride, payload_stride, at(d_nbytes, size_t(off)), 0, 0);
+                           d_payload + size_t(off) * size_t(payload_stride < 0 ? -payload_stride : payload_stride), payload_stride, at(d_nbytes, size_t(off)), 0, 0);
         HIPCK(hipGetLastError());
     }
     const int kMaxY = 32768;                                   // gridDim.y limit is 65535
@@ -349,13 +367,41 @@ void check_config(const mgpu_ctx* c, const mgpu_transmit_config* cfg, int payloa
              stream_mode, "message_location must be MGPU_FIRST/MIDDLE/FLUSH/SINGLE/NO_FILTER/BATCH_MESSAGE");
     need(!(cfg->message_location == MGPU_BATCH_MESSAGE || stream_mode) || (size_t(F) + 2) * size_t(mgpu_transmit_frame_samples(const_cast<mgpu_ctx*>(c))) < (size_t(1) << 31),
          "batch too long for one filtering pass (2^31 samples)");
-    need(payload_stride >= c->tab.payload_bytes, "payload_stride is shorter than the frame's payload");
+    need(payload_stride >= c->tab.payload_bytes || payload_stride <= -c->tab.nReal, "payload_stride is shorter than the frame's payload");     // negative: rows of data bits (transmit_bit)
     need(cfg->carrier_hz > 0 && cfg->carrier_hz < kSampleRate / 2 && cfg->output_power_watt >= 0, "bad carrier or power");
 }
 
 }  // namespace
 
 extern "C" {
+
+int mgpu_host_pre_equalization_channel(int cfg, double carrier_hz, double* channel_c128) {
+    if (!channel_c128) return MGPU_ERR_ARG;
+    try {
+        const mgpu::ModeTables m = mgpu::build_mode_tables(cfg, 0, mgpu_ldpc_blob, mgpu_ldpc_blob_size);
+        const std::vector<mgpu::Cplx> h = mgpu::pre_equalization_channel(m, carrier_hz);
+        std::memcpy(channel_c128, h.data(), h.size() * 16);
+        return MGPU_OK;
+    } catch (const std::exception&) { return MGPU_ERR_ARG; }
+}
+
+int mgpu_set_pre_equalization_channel(mgpu_ctx* c, const double* channel_c128) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(c->tab.mfsk_M == 0 || !channel_c128, "pre_equalization_channel: the OFDM modes only (telecom_system.cc:474-494)");
+        HIPCK(hipStreamSynchronize(c->stream));                  // no transmit call of this context still reads the old table
+        if (channel_c128) {
+            c->pre_eq.assign(channel_c128, channel_c128 + 2 * size_t(c->tab.Nc));
+            if (!c->d_pre_eq_buf) c->d_pre_eq_buf = c->keep(upload(c->pre_eq));
+            else HIPCK(hipMemcpy(c->d_pre_eq_buf, c->pre_eq.data(), c->pre_eq.size() * 8, hipMemcpyHostToDevice));
+            c->dev.pre_eq = c->d_pre_eq_buf;
+        } else {
+            c->pre_eq.clear();
+            c->dev.pre_eq = nullptr;                              // the device buffer stays with the context for the next table
+        }
+        ++c->pre_eq_version;
+    });
+}
 
 int mgpu_transmit_frame_samples(mgpu_ctx* c) {
     return c ? c->tab.Nofdm * (c->tab.Nsymb + c->tab.preamble) * 4 : MGPU_ERR_ARG;
@@ -393,6 +439,23 @@ int mgpu_transmit_byte_batch(mgpu_ctx* c, const uint8_t* payload, int payload_st
         HIPCK(hipMemcpyAsync(d_pl.p, payload, size_t(F) * payload_stride, hipMemcpyHostToDevice, s));
         if (nbytes) HIPCK(hipMemcpyAsync(d_nb.p, nbytes, size_t(F) * 4, hipMemcpyHostToDevice, s));
         transmit_dev(c, d_pl.as<uint8_t>(), payload_stride, nbytes ? d_nb.as<int>() : nullptr, F, *cfg, d_out.as<double>(), s);
+        HIPCK(hipMemcpyAsync(passband, d_out.p, size_t(F) * total * 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+    });
+}
+
+int mgpu_transmit_bit_batch(mgpu_ctx* c, const uint8_t* bits, int F, const mgpu_transmit_config* cfg, double* passband) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        const int nReal = c->tab.nReal;
+        check_config(c, cfg, -nReal, F);
+        need(bits && passband, "bad argument");
+        if (F == 0) return;
+        const size_t total = size_t(mgpu_transmit_frame_samples(c));
+        DevBuf d_bits(size_t(F) * nReal), d_out(size_t(F) * total * 8);
+        hipStream_t s = c->stream;
+        HIPCK(hipMemcpyAsync(d_bits.p, bits, size_t(F) * nReal, hipMemcpyHostToDevice, s));
+        transmit_dev(c, d_bits.as<uint8_t>(), -nReal, nullptr, F, *cfg, d_out.as<double>(), s);      // negative stride: rows of data bits
         HIPCK(hipMemcpyAsync(passband, d_out.p, size_t(F) * total * 8, hipMemcpyDeviceToHost, s));
         HIPCK(hipStreamSynchronize(s));
     });

@@ -68,6 +68,19 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
     c2* out = reinterpret_cast<c2*>(baseband) + size_t(blockIdx.x) * (out_stride ? out_stride : T.frame_samples) + out_offset;
 
     for (int i = tid; i < 128; i += TX_THREADS) tw[fft256_tw_slot(i)] = {T.twiddle[2 * i], -T.twiddle[2 * i + 1]};  // conj (ofdm.cc:365)
+    const bool raw_bits = payload_in && payload_in_stride < 0;   // transmit_bit: the caller's nReal data bits, one byte each, rows of -stride
+    if (raw_bits) {                     // telecom_system.cc:384-396: no CRC, no padding - the bits as they are
+        const uint8_t* in = payload_in + size_t(blockIdx.x) * size_t(-payload_in_stride);
+        for (int j = tid; j < 200; j += TX_THREADS) pay[j] = 0;
+        __syncthreads();
+        for (int i = tid; i < nReal; i += TX_THREADS) bits[i] = (in[i] & 1) ^ T.scrambler[i];   // bit_energy_dispersal
+        if (tid < (nReal + 7) / 8) {                                                              // the expected RX bytes, LSB first
+            uint8_t v = 0;
+            for (int k = 0; k < 8 && tid * 8 + k < nReal; ++k) v |= uint8_t(in[tid * 8 + k] & 1) << k;
+            pay[tid] = v;
+        }
+        __syncthreads();
+    } else {
     if (payload_in) {                   // transmit_byte: the caller's message, zero-padded to the frame (telecom_system.cc:354-366)
         const int nb = nbytes_in ? nbytes_in[blockIdx.x] : fs;
         for (int j = tid; j < fs; j += TX_THREADS) pay[j] = j < nb ? payload_in[size_t(blockIdx.x) * payload_in_stride + j] : uint8_t(0);
@@ -94,10 +107,11 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
         const uint8_t b = byte < fs + 2 ? uint8_t((pay[byte] >> (i & 7)) & 1) : uint8_t(0);
         bits[i] = b ^ T.scrambler[i];   // bit_energy_dispersal
     }
+    }
     if (payload_out)
         for (int b = tid; b < T.payload_stride; b += TX_THREADS) {
             // expected RX bytes: the nReal (un-scrambled) data bits packed LSB first
-            uint8_t v = b < fs + 2 ? pay[b] : uint8_t(0);
+            uint8_t v = (raw_bits || b < fs + 2) ? pay[b] : uint8_t(0);
             if ((b + 1) * 8 > nReal) v &= uint8_t((1u << (nReal - b * 8)) - 1);
             payload_out[size_t(blockIdx.x) * T.payload_stride + b] = v;
         }
@@ -150,6 +164,13 @@ extern "C" __global__ __launch_bounds__(TX_THREADS) void mgpu_txgen_kernel(
             unsigned loc = 0;
             for (int j = 0; j < T.bps; ++j) loc = (loc << 1) | inter[k * T.bps + j];
             grid[T.sym_src[k]] = {T.constellation[2 * loc], T.constellation[2 * loc + 1]};
+        }
+        if (channel < 0 && T.pre_eq) {      // transmit_bit only (telecom_system.cc:486-493): ofdm_framed_data[i*Nc+j] *= pre_equalization_channel[j]
+            __syncthreads();
+            for (int c = tid; c < T.G; c += TX_THREADS) {
+                const c2 g = grid[c], h = {T.pre_eq[2 * (c % 50)], T.pre_eq[2 * (c % 50) + 1]};
+                grid[c] = {g.re * h.re - g.im * h.im, g.re * h.im + g.im * h.re};      // std::complex operator*= on finite values
+            }
         }
     }
     __syncthreads();

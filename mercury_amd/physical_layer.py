@@ -107,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_debug_glibc_trig", "mgpu_debug_tsync_metric", "mgpu_debug_occupancy", "mgpu_debug_select_peak", "mgpu_debug_span_energy", "mgpu_debug_p2b_variant", "mgpu_debug_mfsk_sync", "mgpu_baseband_test_esn0", "mgpu_passband_test_esn0", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_measure_signal_only",
-    "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_transmit_buffer", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
+    "mgpu_host_pre_equalization_channel", "mgpu_set_pre_equalization_channel", "mgpu_transmit_bit_batch", "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_transmit_buffer", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
     "mgpu_symbol_demod", "mgpu_automatic_gain_control", "mgpu_channel_estimator", "mgpu_restore_channel_amplitude", "mgpu_channel_equalizer",
     "mgpu_measure_variance", "mgpu_deframer", "mgpu_deinterleaver_c128", "mgpu_deinterleaver_f32", "mgpu_psk_demod",
     "mgpu_bit_energy_dispersal", "mgpu_bit_to_byte", "mgpu_crc16_modbus_rtu",
@@ -418,6 +418,23 @@ class RxPhy:
         self._ck(self.lib.mgpu_transmit_buffer(self.h, _ptr(b), C.c_int(1)))
         return b
 
+    def pre_equalization_channel(self, carrier_hz):
+        """cl_telecom_system::get_pre_equalization_channel for this mode and carrier (host computation): complex128 [Nc]."""
+        out = np.zeros(self.Nc, np.complex128)
+        rc = self.lib.mgpu_host_pre_equalization_channel(C.c_int(self.cfg), C.c_double(carrier_hz), _ptr(out))
+        if rc != 0:
+            raise MgpuError("mgpu_host_pre_equalization_channel failed (%d)" % rc)
+        return out
+
+    def set_pre_equalization_channel(self, channel):
+        """Install (complex128 [Nc]) or remove (None) the table transmit_bit multiplies the carrier grids with."""
+        if channel is None:
+            self._ck(self.lib.mgpu_set_pre_equalization_channel(self.h, None))
+        else:
+            ch = np.ascontiguousarray(channel, np.complex128)
+            assert ch.size == self.Nc
+            self._ck(self.lib.mgpu_set_pre_equalization_channel(self.h, _ptr(ch)))
+
     def transmit_byte(self, payload, carrier_hz, nbytes=None, **kw):
         """cl_telecom_system::transmit_byte for F messages: payload uint8 [F, >= payload_bytes] -> float64 [F, total_frame_size]."""
         pl = np.ascontiguousarray(payload, np.uint8)
@@ -428,6 +445,14 @@ class RxPhy:
         out = np.zeros((F, self.transmit_frame_samples()), np.float64)
         self._ck(self.lib.mgpu_transmit_byte_batch(self.h, _ptr(pl), C.c_int(stride), None if nb is None else _ptr(nb), C.c_int(F), C.byref(cfg),
                                                    _ptr(out)))
+        return out
+
+    def transmit_bit(self, bits, carrier_hz, **kw):
+        """cl_telecom_system::transmit_bit for F frames: uint8 [F, nReal] data bits -> float64 [F, total_frame_size]."""
+        b = np.ascontiguousarray(bits, np.uint8).reshape(-1, self.nReal)
+        cfg = self.transmit_config(carrier_hz, **kw)
+        out = np.zeros((b.shape[0], self.transmit_frame_samples()), np.float64)
+        self._ck(self.lib.mgpu_transmit_bit_batch(self.h, _ptr(b), C.c_int(b.shape[0]), C.byref(cfg), _ptr(out)))
         return out
 
     def transmit_byte_dev(self, d_payload, payload_stride, F, d_passband, carrier_hz, d_nbytes=None, stream=None, **kw):

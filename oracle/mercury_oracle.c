@@ -88,6 +88,7 @@ struct morc {
     cd tw[128];
     int bitrev[256];
     double fir_ts[64], fir_data[64]; int fir_ntaps;   /* FIR_rx_time_sync / FIR_rx_data */
+    cd pre_eq[50]; double pre_eq_carrier; int apply_pre_eq;   /* pre_equalization_channel (telecom_system.h:186), for pre_eq_carrier; applied by morc_tx when set */
     cd* preamble_vals;  /* [preamble*Nc] preamble carrier values */
     /* LDPC graph, reference layout (padded with -1) */
     int *C, *V, *Vdeg, *Cdeg;
@@ -477,6 +478,8 @@ void morc_tx(morc* o, const int* bits, int scramble, double* out_c128) {
         if (o->type[c] == DATA) o->framed[c] = o->tfi[di++];
         else o->framed[c] = o->pilot_seq[pi++];
     }
+    if (o->apply_pre_eq)                                         /* telecom_system.cc:486-493 */
+        for (int c = 0; c < o->Nsymb * o->Nc; c++) o->framed[c] = cmul(o->framed[c], o->pre_eq[c % o->Nc]);
     }
     cd* out = (cd*)out_c128;
     for (int s = 0; s < nsymb; s++) {                            /* symbol_mod ofdm.cc:855-860 */
@@ -1041,6 +1044,11 @@ static int tx_passband_impl(morc* o, const int* bits, double fs, double carrier_
         cd z[256];
         memset(z, 0, sizeof z);
         const cd* in = o->M == MOD_MFSK ? &mfsk_pre[s * 50] : &o->preamble_vals[s * o->Nc];
+        cd eq_in[50];
+        if (o->apply_pre_eq && o->M != MOD_MFSK) {                 /* telecom_system.cc:477-484 */
+            for (int j = 0; j < 50; j++) eq_in[j] = cmul(in[j], o->pre_eq[j]);
+            in = eq_in;
+        }
         for (int j = 0; j < 25; j++) z[j + 256 - 25] = in[j];
         for (int j = 25; j < 50; j++) z[j - 25 + 1] = in[j];
         fft256(o, z, 1);
@@ -1197,9 +1205,59 @@ int morc_generate_ack_pattern_passband(morc* o, int which, const morc_tx_config*
 
 /* cl_telecom_system::transmit_byte + transmit_bit — telecom_system.cc:342-556, message_location 3 = SINGLE_MESSAGE (both
  * transmit filters) or 4 = NO_FILTER_MESSAGE; same composition as oracle/ref_harness.cc:mref_transmit_byte, which pins it. */
+static void symbol_mod(const morc* o, const cd* in, cd* y);
+
+/* cl_telecom_system::get_pre_equalization_channel — telecom_system.cc:3108-3145, as init() reaches it (:1954-1958) in a process
+ * that has loaded this one configuration: 1000 random symbols through symbol_mod, baseband_to_passband (phase origin 0), FIR_tx1,
+ * FIR_tx2, passband_to_baseband (FIR_rx_data, decimation 4), symbol_demod; the mean of sent / received per carrier. The random
+ * bits continue the stream cl_ofdm::init left behind: __srandom(pilot seed = 0) and one draw per pilot (ofdm.cc:112-113, :940-951).
+ * carrier_amplitude sqrt(2) (telecom_system.cc:69), 48 kHz. out: [Nc] complex128. OFDM modes only. */
+int morc_get_pre_equalization_channel(morc* o, double carrier_hz, double* out_c128) {
+    if (o->M == MOD_MFSK) return -1;
+    const double fs = 48000.0, amplitude = sqrt(2.0);
+    const int interp = 4, n = o->Nofdm * interp, nTries = 1000;
+    double t1c[128], t2c[128];
+    int n1 = morc_tx_fir_taps(carrier_hz, 0, t1c), n2 = morc_tx_fir_taps(carrier_hz, 1, t2c);
+    prng_t rng;
+    prng_seed(&rng, 0);
+    for (int i = 0; i < o->nPilots; i++) (void)prng_next(&rng);
+    cd acc[50], mod[50], dem[50];
+    cd* sym = malloc(sizeof(cd) * o->Nofdm * 2);
+    cd* bb = sym + o->Nofdm;
+    double* pb = malloc(sizeof(double) * n * 3);
+    double *f1 = pb + n, *f2 = pb + 2 * n;
+    for (int i = 0; i < o->Nc; i++) acc[i] = 0;
+    for (int t = 0; t < nTries; t++) {
+        for (int i = 0; i < o->Nc; i++) {                          /* psk.cc:259-272 on Nc * log2(M) fresh bits */
+            unsigned loc = 0;
+            for (int j = 0; j < o->bps; j++) { loc += (unsigned)(prng_next(&rng) % 2); loc <<= 1; }
+            loc >>= 1;
+            mod[i] = o->constellation[loc];
+        }
+        symbol_mod(o, mod, sym);
+        unsigned long start = 0;
+        b2p(sym, o->Nofdm, pb, fs, carrier_hz, amplitude, &start);
+        fir_apply_real(t1c, n1, pb, f1, n);
+        fir_apply_real(t2c, n2, f1, f2, n);
+        morc_passband_to_baseband(o, f2, n, fs, carrier_hz, amplitude, interp, 1, (double*)bb);
+        symbol_demod(o, bb, dem);
+        for (int i = 0; i < o->Nc; i++) acc[i] += mod[i] / dem[i];       /* std::complex operator/ = libgcc's __divdc3, as here */
+    }
+    for (int i = 0; i < o->Nc; i++) acc[i] = (creal(acc[i]) / (double)nTries) + (cimag(acc[i]) / (double)nTries) * I;
+    memcpy(out_c128, acc, sizeof(cd) * o->Nc);
+    free(sym); free(pb);
+    return o->Nc;
+}
+
 int morc_transmit_byte(morc* o, const int* payload, int nBytes, const morc_tx_config* c, double* out) {
     const int interp = 4, total = o->Nofdm * (o->Nsymb + o->preamble) * interp;
     if (nBytes > (o->nReal - 16) / 8) return -1;
+    /* reserved = 1: with the pre-equalisation transmit_bit applies (telecom_system.cc:474-494), computed for this carrier as init() does */
+    o->apply_pre_eq = c->reserved == 1 && o->M != MOD_MFSK;
+    if (o->apply_pre_eq && o->pre_eq_carrier != c->carrier_hz) {
+        morc_get_pre_equalization_channel(o, c->carrier_hz, (double*)o->pre_eq);
+        o->pre_eq_carrier = c->carrier_hz;
+    }
     int bits[N_MAX];
     morc_payload_to_bits(o, payload, nBytes, bits);
     double* tx = calloc(total, sizeof(double));
@@ -1207,6 +1265,7 @@ int morc_transmit_byte(morc* o, const int* payload, int nBytes, const morc_tx_co
     int npre = o->Nofdm * o->preamble * interp;
     peak_clip(tx, npre, c->preamble_papr_cut);
     peak_clip(tx + npre, used - npre, c->data_papr_cut);
+    o->apply_pre_eq = 0;
     if (c->message_location == 4) { memcpy(out, tx, sizeof(double) * total); free(tx); return total; }
     if (c->message_location != 3) { free(tx); return -2; }
     double t1c[128], t2c[128];

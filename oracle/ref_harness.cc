@@ -94,6 +94,10 @@ struct Ref {
     cd *demod_grid, *eq, *eq_noamp, *deframed, *tf_deinter;
     float demodulated[N_MAX], deinterleaved[N_MAX];
     int hd_bits[N_MAX], hd_bytes[N_MAX];
+    // pre_equalization_channel (telecom_system.h:186): computed for pre_eq_carrier on demand, applied by mref_tx when apply_pre_eq
+    std::vector<cd> pre_eq;
+    double pre_eq_carrier = -1;
+    bool apply_pre_eq = false;
 };
 
 }  // namespace
@@ -369,6 +373,9 @@ void mref_tx(void* h, const int* bits, int scramble, double* out_c128) {
     r->psk.mod(r->bit_inter, r->nBits, r->modulated);
     interleaver(r->modulated, r->tf_inter, r->nData, r->tf_blk);
     r->ofdm.framer(r->tf_inter, r->framed);
+    if (r->apply_pre_eq)                                               // telecom_system.cc:486-493
+        for (int i = 0; i < r->Nsymb; i++)
+            for (int j = 0; j < r->Nc; j++) r->framed[i * r->Nc + j] *= r->pre_eq[j];
     for (int i = 0; i < r->Nsymb; i++)
         r->ofdm.symbol_mod(&r->framed[i * r->Nc], &r->symbol_mod[i * r->Nofdm]);
     memcpy(out_c128, r->symbol_mod, sizeof(cd) * r->Nofdm * r->Nsymb);
@@ -594,6 +601,9 @@ static int tx_passband_impl(Ref* r, const int* bits, double fs, double carrier_h
         mfsk_boost = sqrt((double)r->Nc / r->mfsk.nStreams) * pow(10.0, -2.0 / 20.0);
     } else {
         for (int i = 0; i < pre * r->Nc; i++) pre_data[i] = r->ofdm.ofdm_preamble[i].value;   // telecom_system.cc:466-472
+        if (r->apply_pre_eq)                                                                   // telecom_system.cc:477-484
+            for (int i = 0; i < pre; i++)
+                for (int j = 0; j < r->Nc; j++) pre_data[i * r->Nc + j] *= r->pre_eq[j];
     }
     for (int i = 0; i < pre; i++) r->ofdm.symbol_mod(&pre_data[i * r->Nc], &pre_mod[i * r->Nofdm]);
     cd* data = (cd*)frame.data();
@@ -621,8 +631,62 @@ struct mref_tx_config {
     unsigned long long start_sample;       // cl_ofdm::passband_start_sample when the call starts
     int message_location, reserved;
 };
+static void design_tx_firs(cl_FIR& f1, cl_FIR& f2, double carrier_hz) {     // physical_config.cc:103-113, telecom_system.cc:2856-2866, :1924-1935
+    const double bandwidth = 48000.0 * 50.0 / 256 / 4, fs = 48000.0;
+    f1.filter_window = HAMMING;  f1.filter_transition_bandwidth = 1000;
+    f1.lpf_filter_cut_frequency = carrier_hz + bandwidth / 2;  f1.hpf_filter_cut_frequency = carrier_hz - bandwidth / 2;
+    f1.type = HPF;  f1.sampling_frequency = fs;  f1.design();
+    f2.filter_window = BLACKMAN;  f2.filter_transition_bandwidth = 1000;
+    f2.lpf_filter_cut_frequency = carrier_hz + bandwidth / 2;  f2.hpf_filter_cut_frequency = carrier_hz - bandwidth / 2;
+    f2.type = LPF;  f2.sampling_frequency = fs;  f2.design();
+}
+
+// cl_telecom_system::get_pre_equalization_channel (telecom_system.cc:3108-3145) statement by statement on the reference's own
+// objects, as cl_telecom_system::init() reaches it (:1954-1958) in a process that has loaded this one configuration: the PRNG is
+// where cl_ofdm::init left it (ofdm.cc:112-113: the preamble sequence first, then __srandom(pilot seed) and one draw per pilot,
+// ofdm.cc:940-951; nothing between there and :1957 draws from it). carrier_amplitude sqrt(2) (telecom_system.cc:69), 48 kHz.
+// out: [Nc] complex128. The OFDM modes only (M != MOD_MFSK, :1954).
+int mref_get_pre_equalization_channel(void* h, double carrier_hz, double* out_c128) {
+    Ref* r = (Ref*)h;
+    if (r->M == MOD_MFSK) return -1;
+    Silence s;
+    const double fs = 48000.0, amplitude = sqrt(2.0);
+    const int interp = 4, n = r->Nofdm * interp;
+    cl_FIR f1, f2;
+    design_tx_firs(f1, f2, carrier_hz);
+    __srandom(r->ofdm.pilot_configurator.seed);
+    for (int i = 0; i < r->ofdm.pilot_configurator.nPilots; i++) (void)__random();
+    std::vector<cd> acc(r->Nc, cd(0, 0)), mod(r->Nc), sym(r->Nofdm), bb(r->Nofdm), dem(r->Nc);
+    std::vector<int> bits(N_MAX);
+    std::vector<double> pb(n), t1(n), t2(n);
+    const int nTries = 1000;
+    for (int j = 0; j < nTries; j++) {
+        for (int i = 0; i < r->Nc * log2(r->M); i++) bits[i] = __random() % 2;
+        r->psk.mod(bits.data(), r->Nc * log2(r->M), mod.data());
+        r->ofdm.symbol_mod(mod.data(), sym.data());
+        r->ofdm.passband_start_sample = 0;
+        r->ofdm.baseband_to_passband(sym.data(), r->Nofdm, pb.data(), fs, carrier_hz, amplitude, interp);
+        f1.apply(pb.data(), t1.data(), n);
+        f2.apply(t1.data(), t2.data(), n);
+        r->ofdm.passband_to_baseband(t2.data(), n, bb.data(), fs, carrier_hz, amplitude, interp, &r->ofdm.FIR_rx_data);
+        r->ofdm.symbol_demod(bb.data(), dem.data());
+        for (int i = 0; i < r->Nc; i++) acc[i] += mod[i] / dem[i];
+    }
+    for (int i = 0; i < r->Nc; i++) acc[i] /= nTries;
+    memcpy(out_c128, acc.data(), sizeof(cd) * r->Nc);
+    return r->Nc;
+}
+
 int mref_transmit_byte(void* h, const int* payload, int nBytes, const mref_tx_config* c, double* out) {
     Ref* r = (Ref*)h;
+    // reserved = 1: with the pre-equalisation transmit_bit applies (telecom_system.cc:474-494), computed for this carrier as init() does
+    r->apply_pre_eq = c->reserved == 1 && r->M != MOD_MFSK;
+    if (r->apply_pre_eq && r->pre_eq_carrier != c->carrier_hz) {
+        r->pre_eq.assign(r->Nc, cd(0, 0));
+        mref_get_pre_equalization_channel(h, c->carrier_hz, (double*)r->pre_eq.data());
+        r->pre_eq_carrier = c->carrier_hz;
+    }
+    struct Off { Ref* r; ~Off() { r->apply_pre_eq = false; } } off{r};
     const double bandwidth = 48000.0 * 50.0 / 256 / 4, fs = 48000.0;
     const int interp = 4, total = r->Nofdm * (r->Nsymb + r->preamble_nsymb) * interp;
     if (nBytes > (r->nReal - 16) / 8) return -1;                       // "message too long.. not sent."

@@ -94,7 +94,42 @@ int main(int argc, char** argv) {
                 if (!phy.transmit_byte(&msgs[size_t(m) * pb], m == 1 ? pb / 2 : pb, audio.data(), m == 3 ? MGPU_NO_FILTER_MESSAGE : MGPU_SINGLE_MESSAGE)) return 4;
                 fwrite(audio.data(), sizeof(double), total, tx);
             }
+            // transmit_bit (telecom_system.cc:384): the frame's data bits as they are — the bits transmit_byte would have made of message 0
+            // (CRC appended, computed here the way :365-372 does) must give message 0's audio again, the carrier running on
+            {
+                const int nReal = phy.info.nReal;
+                std::vector<int> bits(nReal, 0);
+                unsigned crc = 0xffff;
+                for (int j = 0; j < pb; ++j) {
+                    crc ^= unsigned(msgs[j]) & 0xff;
+                    for (int i = 0; i < 8; ++i) crc = (crc & 1) ? ((crc >> 1) ^ 0xA001) : (crc >> 1);
+                }
+                for (int j = 0; j < pb; ++j) for (int i = 0; i < 8; ++i) bits[j * 8 + i] = (msgs[j] >> i) & 1;
+                for (int i = 0; i < 8; ++i) { bits[pb * 8 + i] = (crc >> i) & 1; bits[(pb + 1) * 8 + i] = (crc >> (8 + i)) & 1; }
+                phy.transmit_bit(bits.data(), audio.data(), MGPU_SINGLE_MESSAGE);
+                fwrite(audio.data(), sizeof(double), total, tx);
+            }
             fclose(tx);
+            // receive_bit (telecom_system.cc:636): the first capture window again, bits instead of bytes
+            if (argc >= 8 && atoi(argv[7]) > 0) {
+                const int n = phy.capture_window_samples();
+                auto pass = slurp<double>(argv[6], size_t(n));
+                std::vector<int> rbits((phy.info.nReal / 8) * 8, -1);
+                mgpu::cl_rx_phy fresh;                    // a receiver without the history of the calls above
+                fresh.load_configuration(cfg);
+                const mgpu::st_receive_stats st = fresh.receive_bit(pass.data(), rbits.data());
+                FILE* rb = fopen((std::string(argv[5]) + ".rbits").c_str(), "wb");
+                const int dec = st.message_decoded;
+                fwrite(&dec, sizeof(int), 1, rb);
+                fwrite(rbits.data(), sizeof(int), rbits.size(), rb);
+                fclose(rb);
+                // return_to_last_configuration (telecom_system.cc:3027-3034): back and forth between two modes
+                const int other = cfg >= 100 ? 101 : 5;
+                fresh.load_configuration(other);
+                if (fresh.current_configuration != other || fresh.last_configuration != cfg) return 9;
+                fresh.return_to_last_configuration();
+                if (fresh.current_configuration != cfg || fresh.last_configuration != other || fresh.info.cfg != cfg) return 10;
+            }
             std::vector<int> too_long(pb + 1, 0);
             if (phy.transmit_byte(too_long.data(), pb + 1, audio.data(), MGPU_SINGLE_MESSAGE)) return 5;     // "message too long.. not sent."
             // 4c) the signalling calls the ARQ layer makes: ACK pattern out and back in, signal level, control-frame mode

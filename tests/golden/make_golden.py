@@ -189,6 +189,16 @@ def tx_case(lib, cfg):
     for name, m, kw in cases:
         y = lib.transmit_byte(m, **kw)
         rec[name] = [digest(y), [float(v).hex() for v in y[[0, 1, 777, y.size // 2, y.size - 1]]]]
+    if cfg < 100:
+        # pre_equalization_channel as init() computes it (telecom_system.cc:1954-1958, :3108-3145) for two carriers, and the audio
+        # transmit_bit makes with it (:474-494)
+        for tag, fc in (("pre_eq", oraclelib.CARRIER), ("pre_eq_1650", 1650.0)):
+            h = lib.get_pre_equalization_channel(fc)
+            rec[tag] = [digest(h), [float(v).hex() for v in h.view(np.float64)[[0, 1, 50, 51, 98, 99]]]]
+        y = lib.transmit_byte(msg, message_location=oraclelib.SINGLE_MESSAGE, pre_equalize=True)
+        rec["filtered_pre_eq"] = [digest(y), [float(v).hex() for v in y[[0, 1, 777, y.size // 2, y.size - 1]]]]
+        y = lib.transmit_byte(msg[: nb // 3], message_location=oraclelib.NO_FILTER_MESSAGE, carrier=1650.0, start_sample=99, pre_equalize=True)
+        rec["unfiltered_pre_eq_1650"] = [digest(y), [float(v).hex() for v in y[[0, 1, 777, y.size // 2, y.size - 1]]]]
     if cfg >= 100:
         lib.set_ctrl_mode(1)
         y = lib.transmit_byte(msg, message_location=oraclelib.SINGLE_MESSAGE)

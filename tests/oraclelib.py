@@ -357,11 +357,21 @@ def _sync_methods(cls):
         m = f(self.h, _p(z), C.c_int(z.size), C.c_int(interp), C.c_int(which), C.byref(matched))
         return float(m), int(matched.value)
 
+    def get_pre_equalization_channel(self, carrier=CARRIER):
+        """cl_telecom_system::get_pre_equalization_channel (telecom_system.cc:3108-3145) for a process that loaded this configuration:
+        complex128 [Nc]."""
+        out = np.zeros(self.Nc, np.complex128)
+        f = self._fn("get_pre_equalization_channel")
+        f.restype = C.c_int
+        assert f(self.h, C.c_double(carrier), _p(out)) == self.Nc
+        return out
+
     def transmit_byte(self, payload, carrier=CARRIER, message_location=SINGLE_MESSAGE, start_sample=0, amplitude=AMPLITUDE,
-                      output_power_watt=0.1, preamble_papr_cut=7.0, data_papr_cut=10.0):
-        """cl_telecom_system::transmit_byte: payload bytes -> total_frame_size passband samples (None = message too long)."""
+                      output_power_watt=0.1, preamble_papr_cut=7.0, data_papr_cut=10.0, pre_equalize=False):
+        """cl_telecom_system::transmit_byte: payload bytes -> total_frame_size passband samples (None = message too long).
+        pre_equalize: with the pre-equalisation of transmit_bit (telecom_system.cc:474-494; the table init() computes for `carrier`)."""
         pl = np.ascontiguousarray(payload, np.int32)
-        c = TxConfig(carrier, amplitude, output_power_watt, preamble_papr_cut, data_papr_cut, start_sample, message_location, 0)
+        c = TxConfig(carrier, amplitude, output_power_watt, preamble_papr_cut, data_papr_cut, start_sample, message_location, 1 if pre_equalize else 0)
         out = np.zeros((self.preamble_nsymb + self.Nsymb) * self.Nofdm * 4)
         f = self._fn("transmit_byte")
         f.restype = C.c_int
@@ -414,7 +424,7 @@ def _sync_methods(cls):
         assert f(self.h, C.c_int(which), C.byref(c), _p(out)) == out.size
         return out
 
-    for fn in (preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband, mfsk_pattern, time_sync_mfsk,
+    for fn in (get_pre_equalization_channel, preamble, fir_taps, passband_to_baseband, time_sync_preamble, freq_sync, tx_passband, mfsk_pattern, time_sync_mfsk,
                detect_ack_pattern, transmit_byte, generate_ack_pattern_passband, transmit_batch, transmit_stream):
         setattr(cls, fn.__name__, fn)
 

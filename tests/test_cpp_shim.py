@@ -110,18 +110,29 @@ def test_cpp_transmit_byte_runs_the_carrier_on_across_calls(tmp_path, cfg):
     msgs = np.random.default_rng(cfg).integers(0, 256, (4, pb)).astype(np.int32)
     (tmp_path / "bb.bin").write_bytes(np.zeros((1, orc.frame_samples), np.complex128).tobytes())
     (tmp_path / "llr.bin").write_bytes(np.zeros((1, 1600), np.float32).tobytes())
-    (tmp_path / "pass.bin").write_bytes(np.zeros(orc.buffer_samples()).tobytes())
+    win = np.random.default_rng(5).standard_normal(orc.buffer_samples()) * 1e-3      # message 0 in a capture window, receiver gain 2
+    pb0 = orc.transmit_byte(msgs[0])
+    d0 = 9 * orc.Nofdm * 4 + 77
+    win[d0: d0 + pb0.size] += 2.0 * pb0
+    (tmp_path / "pass.bin").write_bytes(win.tobytes())
     (tmp_path / "msgs.bin").write_bytes(msgs.tobytes())
     r = subprocess.run([str(exe), str(cfg), "1", str(tmp_path / "bb.bin"), str(tmp_path / "llr.bin"), str(tmp_path / "out.bin"),
                         str(tmp_path / "pass.bin"), "1", str(tmp_path / "msgs.bin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     total = (orc.preamble_nsymb + orc.Nsymb) * orc.Nofdm * 4
     used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
-    audio = np.fromfile(str(tmp_path / "out.bin") + ".tx", np.float64).reshape(4, total)
+    audio = np.fromfile(str(tmp_path / "out.bin") + ".tx", np.float64).reshape(5, total)
+    pre_eq = cfg < 100            # load_configuration measures and installs pre_equalization_channel like init() does (OFDM modes)
     for m in range(4):
         want = orc.transmit_byte(msgs[m, : pb // 2] if m == 1 else msgs[m], start_sample=m * used,
-                                 message_location=oraclelib.NO_FILTER_MESSAGE if m == 3 else oraclelib.SINGLE_MESSAGE)
+                                 message_location=oraclelib.NO_FILTER_MESSAGE if m == 3 else oraclelib.SINGLE_MESSAGE, pre_equalize=pre_eq)
         assert np.array_equal(audio[m], want), m
+    # transmit_bit on the bits transmit_byte makes of message 0: the same frame, four frames further along the carrier
+    assert np.array_equal(audio[4], orc.transmit_byte(msgs[0], start_sample=4 * used, pre_equalize=pre_eq))
+    # receive_bit on a window that holds message 0: the de-scrambled decoded bits, CRC included, LSB first
+    rb = np.fromfile(str(tmp_path / "out.bin") + ".rbits", np.int32)
+    assert rb[0] == 1
+    assert np.array_equal(rb[1:], orc.payload_to_bits(msgs[0])[: (orc.nReal // 8) * 8])
     # the signalling calls: the ACK pattern it generates is the one it detects (and not BREAK), the level of a buffer that holds only
     # that pattern, and the control-frame switch (MFSK modes only)
     metric, m_ack, m_brk, dbm, data_nsymb, ctrl_nsymb = np.fromfile(str(tmp_path / "out.bin") + ".sig", np.float64)

@@ -110,6 +110,67 @@ def test_gpu_transmit_byte_matches_oracle(cfg):
     assert np.array_equal(got[0], orc.transmit_byte(pls[0].astype(np.int32), carrier=1650.0, **kw))
 
 
+@pytest.mark.parametrize("cfg", [c for c in MG.TX_CFGS if c < 100])
+def test_library_pre_equalization_channel_matches_the_reference_fixture(cfg):
+    """cl_telecom_system::get_pre_equalization_channel (telecom_system.cc:3108-3145): the library computes the table on the host
+    (mgpu_host_pre_equalization_channel, no GPU needed); it must be the reference's, bit for bit, for both carriers of the fixture
+    (tests/golden/golden_tx.json, generated from the reference's objects), and the oracle's."""
+    import ctypes as C
+    from mercury_amd import load_library
+    lib = load_library()
+    want = json.load(open(os.path.join(HERE, "golden", "golden_tx.json")))[str(cfg)]
+    orc = Oracle(cfg)
+    for tag, fc in (("pre_eq", CARRIER), ("pre_eq_1650", 1650.0)):
+        h = np.zeros(50, np.complex128)
+        assert lib.mgpu_host_pre_equalization_channel(C.c_int(cfg), C.c_double(fc), h.ctypes.data_as(C.c_void_p)) == 0
+        assert MG.digest(h) == want[tag][0], (cfg, tag)
+        assert np.array_equal(h, orc.get_pre_equalization_channel(fc))
+        assert 1.0 < np.abs(h).min() and np.abs(h).max() < 6.0           # far from "all ones": the band edges need 4.8x
+    assert lib.mgpu_host_pre_equalization_channel(C.c_int(100), C.c_double(CARRIER), h.ctypes.data_as(C.c_void_p)) == 1      # MFSK: none
+    assert lib.mgpu_host_pre_equalization_channel(C.c_int(8), C.c_double(CARRIER), None) == 1
+
+
+@needs_ref
+@pytest.mark.parametrize("cfg", [1, 5, 9, 12, 15])
+def test_oracle_pre_equalization_matches_reference_build_on_the_other_modes(cfg):
+    orc, ref = Oracle(cfg), oraclelib.RefLib(cfg)
+    for fc in (CARRIER, 1234.5):
+        assert np.array_equal(orc.get_pre_equalization_channel(fc), ref.get_pre_equalization_channel(fc))
+    msg = np.random.default_rng(cfg).integers(0, 256, orc.payload_bytes).astype(np.int32)
+    for loc in (SINGLE_MESSAGE, NO_FILTER_MESSAGE):
+        assert np.array_equal(orc.transmit_byte(msg, message_location=loc, start_sample=5, pre_equalize=True),
+                              ref.transmit_byte(msg, message_location=loc, start_sample=5, pre_equalize=True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 8, 11, 13, 16])
+def test_gpu_transmit_byte_with_pre_equalization_matches_oracle(cfg):
+    """transmit_bit's pre-equalisation (telecom_system.cc:474-494): with the table installed the audio equals the oracle's (pinned
+    to the reference's objects by the fixture above), for the filtered / unfiltered / stream forms and another carrier; removing
+    the table gives the plain audio again."""
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    F = 3
+    rx = RxPhy(cfg, max_batch=F)
+    rng = np.random.default_rng(900 + cfg)
+    pls = rng.integers(0, 256, (F, rx.payload_stride)).astype(np.uint8)
+    plain = rx.transmit_byte(pls, CARRIER, message_location=SINGLE_MESSAGE)
+    for fc in (CARRIER, 1650.0):
+        h = rx.pre_equalization_channel(fc)
+        assert np.array_equal(h, orc.get_pre_equalization_channel(fc))
+        rx.set_pre_equalization_channel(h)
+        for loc, start in ((SINGLE_MESSAGE, 0), (NO_FILTER_MESSAGE, 2 ** 33 + 5)):
+            got = rx.transmit_byte(pls, fc, message_location=loc, start_sample=start)
+            for f in range(F):
+                want = orc.transmit_byte(pls[f, : orc.payload_bytes].astype(np.int32), carrier=fc, message_location=loc, start_sample=start,
+                                         pre_equalize=True)
+                assert np.array_equal(got[f], want), (cfg, fc, loc, f)
+    assert not np.array_equal(got[0], plain[0])
+    rx.set_pre_equalization_channel(None)
+    assert np.array_equal(rx.transmit_byte(pls, CARRIER, message_location=SINGLE_MESSAGE), plain)
+    rx.close()
+
+
 @needs_ref
 @pytest.mark.parametrize("cfg", [3, 8, 13, 102])
 def test_oracle_overlap_save_message_locations_match_reference_objects(cfg):
