@@ -44,8 +44,6 @@ void ctx_alloc(mgpu_ctx* c) {
     d.data_cell = c->keep(upload(t.data_cell));
     d.cptr = c->keep(upload(t.graph.cptr));
     d.cvar = c->keep(upload(t.graph.cvar));
-    d.vinfo = c->keep(upload(t.graph.vinfo));
-    d.sdesc = c->keep(upload(t.graph.sdesc));
     d.S = t.graph.S;
     d.M = t.M; d.bps = t.bps; d.K = t.K; d.P = t.P; d.N = t.N; d.E = t.graph.E;
     d.Nsymb = t.Nsymb; d.G = t.Nsymb * t.Nc; d.nData = t.nData; d.nBits = t.nBits; d.nPilots = t.nPilots;
@@ -76,8 +74,12 @@ void ctx_alloc(mgpu_ctx* c) {
     d.active_nsymb = t.active_nsymb; d.active_nbits = t.active_nbits; d.mfsk_amp = t.mfsk_amp;
     d.puncture_from = (c->cfg.test_puncture_nBits > 0 && c->cfg.test_puncture_nBits < t.active_nbits) ? c->cfg.test_puncture_nBits : t.active_nbits;
     LdpcDev& l = c->ldev;
-    l.vinfo = d.vinfo; l.sdesc = d.sdesc; l.scrambler = d.scrambler;
+    l.scrambler = d.scrambler;
     l.cptr = d.cptr; l.cvar = d.cvar;
+    l.gdesc = c->keep(upload(t.graph.gdesc));
+    l.gkind = c->keep(upload(t.graph.gkind));
+    l.vinfo_g = c->keep(upload(t.graph.vinfo_g));
+    l.Sg = t.graph.Sg;
     l.sadr = c->keep(upload(t.graph.sadr));
     l.bhead = c->keep(upload(t.graph.bhead));
     l.bmask = c->keep(upload(t.graph.bmask));
@@ -85,15 +87,6 @@ void ctx_alloc(mgpu_ctx* c) {
     l.DM = t.graph.DM;
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
-    {   // min-sum check update: segmented wave scans pay off once a check has more edges than the scans have steps to hide
-        int maxdeg = 0;
-        for (int q = 0; q < t.P; ++q) maxdeg = std::max(maxdeg, int(t.graph.cptr[q + 1] - t.graph.cptr[q]));
-        int steps = 0;
-        while ((1 << steps) < maxdeg - 1) ++steps;      // exclusive scans cover deg - 1 other edges
-        const char* force = std::getenv("MERCURY_MINSUM_SCAN");
-        l.scan_steps = (force ? std::atoi(force) != 0 : maxdeg > 16) ? steps : 0;
-    }
-
     HIPCK(hipStreamCreate(&c->stream));
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));
     for (auto& e : c->sync_ev) HIPCK(hipEventCreate(&e));
@@ -137,22 +130,16 @@ void ctx_alloc(mgpu_ctx* c) {
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_gbf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
         case MGPU_DEC_MINSUM: {
-            c->lds_dec = mgpu_minsum_lds_bytes(d.S, d.N);
-            if (d.S > 8 * 1024) throw std::runtime_error("graph too large for the min-sum kernel");
-            const char* e = std::getenv("MERCURY_MINSUM_THREADS");
-            c->dec_threads = e ? std::atoi(e) : 512;
-            if (c->dec_threads != 512 && c->dec_threads != 1024) throw std::runtime_error("MERCURY_MINSUM_THREADS must be 512 or 1024");
-            c->spa_kernel = c->dec_threads == 512 ? mgpu_ldpc_minsum_kernel_t512 : mgpu_ldpc_minsum_kernel_t1024;
+            c->lds_dec = mgpu_spa_fast_lds_bytes(c->ldev.Sg, d.N);
+            c->dec_threads = 512;
+            c->spa_kernel = mgpu_ldpc_minsum_kernel_t512;
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
         }
         case MGPU_DEC_SPA_FAST: {
-            c->lds_dec = mgpu_spa_fast_lds_bytes(d.S, d.N);
-            if (d.S > 8 * 1024) throw std::runtime_error("graph too large for the fp32 sum-product kernel");
-            const char* e = std::getenv("MERCURY_SPA_FAST_THREADS");
-            c->dec_threads = e ? std::atoi(e) : 512;
-            if (c->dec_threads != 512 && c->dec_threads != 1024) throw std::runtime_error("MERCURY_SPA_FAST_THREADS must be 512 or 1024");
-            c->spa_kernel = c->dec_threads == 512 ? mgpu_ldpc_spa_fast_kernel_t512 : mgpu_ldpc_spa_fast_kernel_t1024;
+            c->lds_dec = mgpu_spa_fast_lds_bytes(c->ldev.Sg, d.N);
+            c->dec_threads = 512;            // 8 wavefronts per barrier domain: the kernel is bound by waits, not by issue (1024 threads: 1.4x slower)
+            c->spa_kernel = mgpu_ldpc_spa_fast_kernel_t512;
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->spa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
         }

@@ -20,8 +20,7 @@ extern "C" const unsigned long mgpu_ldpc_blob_size;
 extern "C" size_t mgpu_frontend_lds_bytes(int G, int nPilots, int nBits, int threads);
 extern "C" size_t mgpu_spa_lds_bytes(int E, int N);
 extern "C" size_t mgpu_gbf_lds_bytes(int N);
-extern "C" size_t mgpu_minsum_lds_bytes(int E, int N);
-extern "C" size_t mgpu_spa_fast_lds_bytes(int S, int N);
+extern "C" size_t mgpu_spa_fast_lds_bytes(int Sg, int N);
 extern "C" size_t mgpu_txgen_lds_bytes(int G);
 
 extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
@@ -65,9 +64,9 @@ extern "C" __global__ void mgpu_passband_channel_kernel(const double*, int, int,
 extern "C" __global__ void mgpu_error_count_kernel(const uint8_t*, const uint8_t*, const MgpuStatsDev*, int, int, int, unsigned long long*);
 extern "C" __global__ void mgpu_ldpc_gbf_kernel(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
 #define DECL_MS(T) extern "C" __global__ void mgpu_ldpc_minsum_kernel_t##T(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-DECL_MS(1024) DECL_MS(512)
+DECL_MS(512)
 #define DECL_SF(T) extern "C" __global__ void mgpu_ldpc_spa_fast_kernel_t##T(LdpcDev, const float*, int, uint8_t*, int*, uint8_t*, MgpuStatsDev*, const float*, const float*);
-DECL_SF(1024) DECL_SF(512)
+DECL_SF(512)
 extern "C" __global__ void mgpu_ldpc_encode_kernel(MgpuDev, const uint8_t*, int, uint8_t*);
 extern "C" __global__ void mgpu_txgen_kernel(MgpuDev, uint64_t, uint64_t, int, double, int, double*, uint8_t*, const uint8_t*, int, const int*, int, int);
 

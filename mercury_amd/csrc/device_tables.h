@@ -23,8 +23,6 @@ struct MgpuDev {
     // LDPC graph
     const uint32_t* cptr;          // [P+1] check-major edge list in the reference's row order
     const uint16_t* cvar;          // [E]   variable of edge e
-    const uint32_t* vinfo;         // [N][6]
-    const uint32_t* sdesc;         // [ceil(S/1024)*1024]
     int S;
     int M, bps, K, P, N, E;
     int Nsymb, G, nData, nBits, nPilots, nVirtual, nReal;
@@ -45,10 +43,11 @@ struct MgpuDev {
 // Slim argument block for the decoder kernels: only what they touch, so the kernarg does not
 // inflate the SGPR allocation (occupancy on gfx950 drops below 8 waves/SIMD above 80 SGPRs).
 struct LdpcDev {
-    const uint32_t* vinfo;   // sum-product / min-sum layout
-    const uint32_t* sdesc;   // [NE*1024] per padded slot: check_start(13) | deg(6)<<13 | variable(11)<<19 | last edge of its check<<31, 0 = padding (zero-filled, one spare round)
     const uint32_t* cptr; const uint16_t* cvar;                           // plain check-major lists (GBF)
     const uint8_t* scrambler;
+    // fp32 decoders (sum-product and min-sum), grouped layout (tables.hpp: LdpcGraph::gdesc / gkind / vinfo_g)
+    const uint32_t* gdesc; const uint32_t* gkind; const uint32_t* vinfo_g;
+    int Sg;
     // fp64 sum-product kernel (tables.hpp: LdpcGraph::sadr / bhead / bmask / vinfo2)
     const uint32_t* sadr;    // [(NE+1)*1024][2] LDS byte offset of the slot's posterior, LDS byte address of the first message of the slot's check
     const uint64_t* bhead;   // [(NE+1)*16][2] per bin: lanes in use, lanes holding the last edge of a check
@@ -57,7 +56,6 @@ struct LdpcDev {
     int DM;
     int S, N, P, K, E, nReal, payload_stride, max_iters;
     float minsum_alpha;
-    int scan_steps;   // min-sum: 0 = every lane scans its check's edges; > 0 = segmented wave scans with this many doubling steps
 };
 
 struct MgpuTapsDev {

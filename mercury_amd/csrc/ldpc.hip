@@ -334,318 +334,165 @@ extern "C" int mgpu_spa_max_degree(int ne) { return ne == 8 ? 48 : 16; }
 // ---------------------------------------------------------------------------------------------
 // Sum-product, single precision ("spa_fast"; BASELINE.json north_star's fast variant, SURVEY.md §7.3-1: "SPA-equivalent
 // check node in FP32"). NOT the reference's arithmetic: the same flooding schedule, the same tanh rule
-// R = 2*atanh(prod_others tanh(Q/2)) and the same iteration/early-exit convention as ldpc_decoder_SPA.cc:25-218, evaluated
-// in fp32 with the hardware's exp2/log2/rcp. Parity for this decoder is therefore defined the way the reference's own
-// alternative decoder (GBF) relates to SPA: same codeword whenever both decode, decode rate within 0.5 % of the fp64
-// decoder at the operating points of all 20 modes (tests/test_gpu_parity.py::test_spa_fast_*).
-//
-// Same skeleton as the fp64 kernel (wave-private 64-slot bins, one in-place message array, scalar prefix-XOR syndrome,
-// descriptors from the shared table, two barriers per iteration), with what fp32 allows on top:
-//   * T = tanh(Q/2) = (1 - e)/(1 + e), e = exp(-|Q|): one v_exp_f32 + one v_rcp_f32; |T| is kept inside
-//     [2^-30, 1 - 2^-24] so that a product never contains an exact zero or one;
-//   * the check product is taken over ALL edges of the check (every lane of the check reads the same LDS words = broadcast
-//     reads, no own-edge skipping logic) and the own factor is divided out again: prod_others = P / T_own (exact zero
-//     excluded above; an underflowing P means every extrinsic of that check is < 1e-30 anyway);
-//   * R = 2*atanh(p) = ln2 * log2((1 + p)/(1 - p)): one v_rcp_f32 + one v_log_f32; 1 - |p| is exact (Sterbenz) and >= 2^-24,
-//     which caps |R| at 17.3 (the fp64 decoder's own clamp of +-1 to +-0.9999999 caps it at 16.8).
-extern "C" size_t mgpu_spa_fast_lds_bytes(int S, int N) {
-    return size_t(4) * S + size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64;
+// R = 2*atanh(prod_others tanh(Q/2)) and the same iteration / early-exit convention as ldpc_decoder_SPA.cc:25-218, evaluated
+// in fp32 with the hardware's exp2 / log2 / rcp:
+//   * T = tanh(Q/2) = (1 - e)/(1 + e), e = exp(-|Q|): one v_exp_f32 + one v_rcp_f32; |T| is kept inside [2^-30, 1 - 2^-24] so that
+//     a product never contains an exact zero or one;
+//   * R = 2*atanh(p) = ln2 * log2((1 + p)/(1 - p)): one v_rcp_f32 + one v_log_f32; 1 - |p| is exact (Sterbenz) and >= 2^-24, which
+//     caps |R| at 17.3 (the fp64 decoder's own clamp of +-1 to +-0.9999999 caps it at 16.8).
+// Round 3: the GROUPED layout (LdpcGraph::gdesc / gkind / vinfo_g) replaced the bin-packed one this decoder shared with the fp64
+// kernel (rate 14/16: 6.36 -> 3.0 ms per 4096 x 50; rate 6/16: 2.14 -> 1.98). A check occupies an aligned group of
+// 2^k lanes (k = 1..6), a bin holds groups of one size. The product over a check's edges is then an all-reduce inside the wavefront -
+// lane ^ 1, lane ^ 2 (quad permutes), half-row mirror, row mirror (DPP), and for 32 / 64 lanes the four row products through scalar
+// registers - instead of a walk through LDS: T never leaves the registers, M holds only R, and nothing between the tanh and the atanh
+// waits for memory. The own factor is divided out of the check's total (|T| is kept inside [2^-30, 1 - 2^-24], so never zero); padding
+// lanes contribute 1. The order of the multiplications differs from the reference's; this decoder's parity is statistical (same decode
+// rate and payloads as the fp64 decoder, tests/test_gpu_parity.py::test_spa_fast_*), unlike the fp64 kernel's.
+// The syndrome is the parity of the sign bits of each group: a fold of the ballot by the group size (2 log2(g) scalar instructions).
+template <int CTRL>
+__device__ __forceinline__ float spag_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+extern "C" size_t mgpu_spa_fast_lds_bytes(int Sg, int N) {
+    return size_t(4) * Sg + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
 }
 
-__device__ __forceinline__ void spaf_masked_mul2(float& t, float a0, float a1, uint64_t m0, uint64_t m1) {
-    uint64_t sv;
-    asm volatile(
-        "s_and_saveexec_b64 %1, %4\n\t"
-        "v_mul_f32 %0, %0, %2\n\t"
-        "s_and_b64 exec, %1, %5\n\t"
-        "v_mul_f32 %0, %0, %3\n\t"
-        "s_mov_b64 exec, %1"
-        : "+v"(t), "=&s"(sv)
-        : "v"(a0), "v"(a1), "s"(m0), "s"(m1)
-        : "scc");
-}
-// Product walk of the fp32 decoder, four steps per group (two LDS reads, one scalar load of masks, fetched one group ahead);
-// an all-zero mask ends the walk. Groups of eight were slower (7.0 vs 6.65 ms per 4096 x 50 on mode 16, 1.68 vs 1.60 on mode 0).
-template <int C, int CMAX>
-__device__ __forceinline__ void spaf_walk4(float& temp, uint32_t achk, spa_cptr64 bm, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
-    typedef __attribute__((address_space(3))) float lds_f32;
-    if (m0 == 0) return;
-    uint64_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    if constexpr (C + 1 < CMAX) { n0 = bm[4 * C + 4]; n1 = bm[4 * C + 5]; n2 = bm[4 * C + 6]; n3 = bm[4 * C + 7]; }
-    const lds_f32* chk = reinterpret_cast<const lds_f32*>(achk);
-    const float a0 = chk[4 * C], a1 = chk[4 * C + 1], a2 = chk[4 * C + 2], a3 = chk[4 * C + 3];
-    spaf_masked_mul2(temp, a0, a1, m0, m1);
-    if (m2 != 0) spaf_masked_mul2(temp, a2, a3, m2, m3);
-    if constexpr (C + 1 < CMAX) spaf_walk4<C + 1, CMAX>(temp, achk, bm, n0, n1, n2, n3);
-}
-
-template <int THREADS>
+template <int THREADS, int RULE>     // RULE 0: sum-product ("spa_fast"), 1: normalised min-sum
 __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
-                                                uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
-                                                uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
-                                                const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+                                                 uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
+                                                 uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+                                                 const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    static_assert(THREADS == 512, "the grouped tables are laid out in rounds of 8 bins");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int S = T.S, N = T.N;
-    const int NE = (S + THREADS - 1) / THREADS;       // rounds: wave w works on bin w + (THREADS / 64) r in round r
-    float* M = reinterpret_cast<float*>(smem);        // R or T per padded edge slot
+    const int S = T.Sg, N = T.N;
+    const int NE = (S + THREADS - 1) / THREADS;       // rounds: wave w works on bin w + 8 r in round r
+    float* M = reinterpret_cast<float*>(smem);        // R per slot
     float* Lt = M + S;                                // posterior per variable
-    float* Li = Lt + N;                               // channel LLR
-    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
+    uint8_t* hard = reinterpret_cast<uint8_t*>(Lt + N);
     uint8_t* bytes = hard + ((N + 15) & ~15);
     int* flag = reinterpret_cast<int*>(bytes + 256);
-    const int tid = threadIdx.x, f = blockIdx.x;
+    const int tid = threadIdx.x, f = blockIdx.x, lane = tid & 63;
     if (f >= F) return;
-    for (int v = tid; v < N; v += THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; Lt[v] = l; }
+    constexpr int kRows = (kN + THREADS - 1) / THREADS;      // channel LLRs in registers: row i of the variable records belongs to one lane
+    float li[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const int i = tid + k * THREADS;
+        li[k] = 0.0f;
+        if (i < N) {
+            const uint32_t v = T.vinfo_g[size_t(i) * 8] & 0x7ff;
+            li[k] = llr_in[size_t(f) * N + v];
+            Lt[v] = li[k];
+        }
+    }
     for (int p = tid; p < S; p += THREADS) M[p] = 0.0f;
-    const uint32_t* __restrict__ sdesc = T.sdesc;
+    const uint32_t* __restrict__ gdesc = T.gdesc;
+    typedef const uint32_t __attribute__((address_space(4))) * cptr32;
+    const cptr32 gkind = (cptr32)(T.gkind) + __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
 
-    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
-        m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
-        return (m & ends) != 0;
+    // any group of 2^kind lanes with an odd number of set bits? fold the ballot onto each group's lowest lane
+    auto groups_unsat = [&](unsigned long long m, uint32_t kind) -> bool {
+        m ^= m >> 1;
+        unsigned long long lead = 0x5555555555555555ull;
+        if (kind >= 2) { m ^= m >> 2; lead = 0x1111111111111111ull; }
+        if (kind >= 3) { m ^= m >> 4; lead = 0x0101010101010101ull; }
+        if (kind >= 4) { m ^= m >> 8; lead = 0x0001000100010001ull; }
+        if (kind >= 5) { m ^= m >> 16; lead = 0x0000000100000001ull; }
+        if (kind >= 6) { m ^= m >> 32; lead = 1ull; }
+        return (m & lead) != 0;
     };
     auto syndrome_pass = [&](int p) {
         bool unsat = false;
-        uint32_t k = sdesc[tid];
+        uint32_t k = gdesc[tid];
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
-            const uint32_t kn = sdesc[(r + 1) * THREADS + tid];
-            const unsigned long long vmask = __ballot(((k >> 13) & 0x3f) != 0);
-            const float lt = Lt[(k >> 19) & 0x7ff];
-            if (!unsat) unsat = bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
+            const uint32_t kn = gdesc[(r + 1) * THREADS + tid];
+            const uint32_t kind = gkind[r * 8];
+            const float lt = Lt[k & 0x7ff];
+            if (!unsat && kind) unsat = groups_unsat(__ballot(lt < 0 && int32_t(k) < 0), kind);
             k = kn;
         }
-        if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
+        if (unsat && lane == 0) flag[p & 1] = 1;
     };
     auto cn_pass = [&](bool with_syndrome, int p) {
         bool unsat = false;
-        uint32_t k = sdesc[tid];
-        uint32_t slot = tid;
-        spa_cptr64 bm = (spa_cptr64)(T.bmask) + size_t(__builtin_amdgcn_readfirstlane(tid >> 6)) * T.DM;     // bin = wave + (THREADS / 64) * round
-        const size_t bm_step = size_t(THREADS / 64) * T.DM;
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r, slot += THREADS, bm += bm_step) {
-            const uint32_t kn = sdesc[(r + 1) * THREADS + tid];
-            const uint32_t deg = (k >> 13) & 0x3f;
-            const bool valid = deg != 0;
-            const unsigned long long vmask = __ballot(valid);
-            if (vmask == 0) { k = kn; continue; }
-            float lt;
-            if (valid) lt = Lt[(k >> 19) & 0x7ff];
-            if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
-            float t = 1.0f;
-            if (valid) {
-                const float q = lt - M[slot];
-                const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * __builtin_fabsf(q));
-                float a = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-                a = __builtin_amdgcn_fmed3f(a, 0x1.0p-30f, 0x1.fffffep-1f);
-                t = __builtin_copysignf(a, q);
-                M[slot] = t;
-            }
-            __builtin_amdgcn_wave_barrier();
-            // product over the check's OTHER edges, in slot order, under the bin's tabulated step masks (LdpcGraph::bmask, the
-            // fp64 kernel's table): uniform control flow, four factors per pair of LDS reads, no own factor to divide out again
-            float prod = 1.0f;
-            spaf_walk4<0, 12>(prod, (k & 0x1fff) * 4, bm, bm[0], bm[1], bm[2], bm[3]);
-            float rr = 0.0f;
-            if (valid) {
-                const float pa = fminf(__builtin_fabsf(prod), 0x1.fffffep-1f);
-                const float l2 = __builtin_amdgcn_logf((1.0f + pa) * __builtin_amdgcn_rcpf(1.0f - pa));
-                rr = __builtin_copysignf(0.693147180559945309f * l2, prod);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (valid) M[slot] = rr;
-            k = kn;
-        }
-        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
-    };
-    struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
-    auto load_var = [&](const uint32_t* vinfo, int i) -> VarRec {
-        const uint4 lo = *reinterpret_cast<const uint4*>(vinfo + size_t(i) * 8);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vinfo + size_t(i) * 8 + 4);
-        return VarRec{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
-    };
-    auto var_update = [&](const VarRec& q) {
-        const uint32_t v = q.vi & 0x7ff, deg = q.vi >> 11;
-        float s = Li[v];
-        const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
-        s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
-        if (deg > 2) {      // rows sorted by degree: wavefronts of degree-2 parity bits skip the rest
-            const float m2 = M[q.w1 & 0xffff], m3 = M[q.w1 >> 16], m4 = M[q.w2 & 0xffff];
-            s += m2;
-            s = deg > 3 ? s + m3 : s; s = deg > 4 ? s + m4 : s;
-        }
-        if (deg > 5) {
-            const float m5 = M[q.w2 >> 16], m6 = M[q.w3 & 0xffff], m7 = M[q.w3 >> 16], m8 = M[q.w4 & 0xffff];
-            s += m5;
-            s = deg > 6 ? s + m6 : s; s = deg > 7 ? s + m7 : s; s = deg > 8 ? s + m8 : s;
-        }
-        Lt[v] = s;
-    };
-    constexpr int kSpecStart = 8;
-    int iteration = 0;
-    syndrome_pass(0);
-    __syncthreads();
-    if (flag[0]) {
-        for (int it = 1;; ++it) {
-            const bool spec = it - 1 >= kSpecStart;
-            if (it <= T.max_iters) cn_pass(spec, it - 1);
-            else syndrome_pass(it - 1);
-            __syncthreads();
-            if (spec) {
-                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
-                if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
-            }
-            if (tid == 0) flag[it & 1] = 0;
-            for (int i = tid; i < N; i += THREADS) var_update(load_var(T.vinfo, i));
-            __syncthreads();
-            if (it < kSpecStart) {
-                syndrome_pass(it);
-                __syncthreads();
-                if (!flag[it & 1]) { iteration = it; break; }
-                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
-            }
-        }
-    }
-    for (int v = tid; v < N; v += THREADS) hard[v] = Lt[v] < 0;
-    __syncthreads();
-    decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
-}
-
-// Two workgroup shapes: 1024 threads (2 workgroups per CU) and 512 threads (4 per CU where LDS allows: 37 KB each in mode 8).
-// The decoder is bound by waits (LDS round trips, the two barriers per iteration), not by instruction issue; smaller workgroups
-// mean barriers over 8 wavefronts instead of 16 and twice as many independent barrier domains per CU.
-#define SPA_FAST_KERNEL(THREADS)                                                                                   \
-    extern "C" __global__ __launch_bounds__(THREADS) void mgpu_ldpc_spa_fast_kernel_t##THREADS(                    \
-        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                        \
-        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,      \
-        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                        \
-        spa_fast_decode<THREADS>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
-    }
-SPA_FAST_KERNEL(1024)
-SPA_FAST_KERNEL(512)
-
-extern "C" size_t mgpu_minsum_lds_bytes(int S, int N) {
-    return size_t(4) * S + size_t(4) * N * 2 + ((N + 15) & ~15) + 256 + 64;
-}
-
-// Normalised min-sum on the skeleton of the fp32 sum-product kernel above (wave-private bins, one in-place message array, scalar
-// prefix-XOR syndrome, descriptors from the shared table, 512-thread workgroups): only the check-node rule differs.
-template <int THREADS>
-__device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
-                                                uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
-                                                uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
-                                                const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int S = T.S, N = T.N;
-    const int NE = (S + THREADS - 1) / THREADS;       // rounds: wave w works on bin w + (THREADS / 64) r in round r
-    float* M = reinterpret_cast<float*>(smem);        // R or T per padded edge slot
-    float* Lt = M + S;                                // posterior per variable
-    float* Li = Lt + N;                               // channel LLR
-    uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
-    uint8_t* bytes = hard + ((N + 15) & ~15);
-    int* flag = reinterpret_cast<int*>(bytes + 256);
-    const int tid = threadIdx.x, f = blockIdx.x;
-    if (f >= F) return;
-    for (int v = tid; v < N; v += THREADS) { const float l = llr_in[size_t(f) * N + v]; Li[v] = l; Lt[v] = l; }
-    for (int p = tid; p < S; p += THREADS) M[p] = 0.0f;
-    const uint32_t* __restrict__ sdesc = T.sdesc;
-    const float alpha = T.minsum_alpha;
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
-    __syncthreads();
-
-    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
-        m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
-        return (m & ends) != 0;
-    };
-    auto syndrome_pass = [&](int p) {
-        bool unsat = false;
-        uint32_t k = sdesc[tid];
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t kn = sdesc[(r + 1) * THREADS + tid];
-            const unsigned long long vmask = __ballot(((k >> 13) & 0x3f) != 0);
-            const float lt = Lt[(k >> 19) & 0x7ff];
-            if (!unsat) unsat = bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
-            k = kn;
-        }
-        if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
-    };
-    auto cn_pass = [&](bool with_syndrome, int p) {
-        bool unsat = false;
-        uint32_t k = sdesc[tid];
+        uint32_t k = gdesc[tid];
         uint32_t slot = tid;
 #pragma unroll 1
         for (int r = 0; r < NE; ++r, slot += THREADS) {
-            const uint32_t kn = sdesc[(r + 1) * THREADS + tid];
-            const uint32_t deg = (k >> 13) & 0x3f;
-            const bool valid = deg != 0;
-            const unsigned long long vmask = __ballot(valid);
-            if (vmask == 0) { k = kn; continue; }
-            float lt;
-            if (valid) lt = Lt[(k >> 19) & 0x7ff];
-            if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vmask, __ballot(int32_t(k) < 0));
-            float q = 0.0f;
-            if (valid) {
-                q = lt - M[slot];                                    // variable-to-check message
-                M[slot] = q;
+            const uint32_t kn = gdesc[(r + 1) * THREADS + tid];
+            const uint32_t kind = gkind[r * 8];
+            if (kind == 0) { k = kn; continue; }                     // an empty bin (only in the last round)
+            const bool valid = int32_t(k) < 0;
+            const float lt = Lt[k & 0x7ff];                          // padding lanes read variable 0
+            if (with_syndrome && !unsat) unsat = groups_unsat(__ballot(lt < 0 && valid), kind);
+            const float q = lt - M[slot];
+            if constexpr (RULE == 0) {
+            const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * __builtin_fabsf(q));
+            float a = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+            a = __builtin_amdgcn_fmed3f(a, 0x1.0p-30f, 0x1.fffffep-1f);
+            const float t = valid ? __builtin_copysignf(a, q) : 1.0f;
+            // the check's total: all-reduce over its aligned group
+            float x = t * spag_dpp<0xB1>(t);                                          // lane ^ 1  (quad_perm [1,0,3,2])
+            if (kind >= 2) x *= spag_dpp<0x4E>(x);                                    // lane ^ 2  (quad_perm [2,3,0,1])
+            if (kind >= 3) x *= spag_dpp<0x141>(x);                                   // row_half_mirror: the other quad of the 8
+            if (kind >= 4) x *= spag_dpp<0x140>(x);                                   // row_mirror: the other half of the 16
+            if (kind >= 5) {
+                const int xi = __builtin_bit_cast(int, x);                            // the four row products, through scalar registers
+                const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+                const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+                const float pa = r0 * r1, pb = r2 * r3;
+                x = kind == 6 ? pa * pb : (lane < 32 ? pa : pb);
             }
-            __builtin_amdgcn_wave_barrier();
-            float rr = 0.0f;
-            if (T.scan_steps > 0) {
-                // high-degree graphs (rate 14/16: 33 edges per check): minimum over the OTHER edges as min(exclusive prefix minimum,
-                // exclusive suffix minimum) with segmented wave scans — a check is a run of consecutive lanes — instead of every lane
-                // scanning all edges of its check: 2 * (log2(deg) + 1) shuffles per bin instead of deg LDS reads. Same values.
-                const int pos = int(slot) - int(k & 0x1fff), rpos = int(deg) - 1 - pos;
-                const float a = valid ? __builtin_fabsf(q) : __builtin_inff();
-                const float inf = __builtin_inff();
-                float pre = __shfl_up(a, 1), suf = __shfl_down(a, 1);
-                pre = pos >= 1 ? pre : inf;
-                suf = rpos >= 1 ? suf : inf;
-                for (int st = 0, d = 1; st < T.scan_steps; ++st, d <<= 1) {
-                    const float tp = __shfl_up(pre, d), ts = __shfl_down(suf, d);
-                    pre = pos >= d ? fminf(pre, tp) : pre;
-                    suf = rpos >= d ? fminf(suf, ts) : suf;
-                }
-                // sign product of the others = parity of the check's negative edges, own edge taken out
-                const unsigned long long neg = __ballot(valid && (__float_as_uint(q) >> 31));
-                const uint32_t l0 = k & 63u;
-                const unsigned long long cm = ((deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << l0);
-                const uint32_t odd = uint32_t(__popcll(neg & cm) & 1) ^ (__float_as_uint(q) >> 31);
-                rr = __uint_as_float(__float_as_uint(fminf(pre, suf) * alpha) | (odd << 31));
-            } else if (valid) {
-                // the two smallest magnitudes and the sign product over ALL edges of the check (every lane of the check runs the same
-                // scan on broadcast reads); the own edge is taken out afterwards: min over the others = (|own| == min1) ? min2 : min1
-                // (a tie leaves min2 == min1).
-                const uint32_t cs = k & 0x1fff;
-                float mn1 = __builtin_inff(), mn2 = __builtin_inff();
-                uint32_t sg = 0;
-                uint32_t j = 0;
-                for (; j + 2 <= deg; j += 2) {
-                    const float x = M[cs + j], y = M[cs + j + 1];
-                    sg ^= __float_as_uint(x) ^ __float_as_uint(y);
-                    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-                    mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, ax);     // second smallest of {mn1, mn2, a}
-                    mn1 = fminf(mn1, ax);
-                    mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, ay);
-                    mn1 = fminf(mn1, ay);
-                }
-                if (j < deg) {
-                    const float x = M[cs + j];
-                    sg ^= __float_as_uint(x);
-                    const float ax = __builtin_fabsf(x);
-                    mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, ax);
-                    mn1 = fminf(mn1, ax);
-                }
-                const float mag = (__builtin_fabsf(q) == mn1) ? mn2 : mn1;
-                rr = __uint_as_float(__float_as_uint(mag * alpha) | ((sg ^ __float_as_uint(q)) & 0x80000000u));
+            const float pe = x * __builtin_amdgcn_rcpf(t);                            // product over the other edges
+            const float pa = fminf(__builtin_fabsf(pe), 0x1.fffffep-1f);
+            const float l2 = __builtin_amdgcn_logf((1.0f + pa) * __builtin_amdgcn_rcpf(1.0f - pa));
+            if (valid) M[slot] = __builtin_copysignf(0.693147180559945309f * l2, pe);
+            } else {
+            // normalised min-sum: R = alpha * (smallest |Q| among the check's other edges) with the sign parity of the others. The two
+            // smallest magnitudes (m1 <= m2) and the sign parity of the whole check by the same all-reduce; the own edge is taken out
+            // afterwards: min over the others = (|own| == m1) ? m2 : m1 (a tie leaves m2 == m1).
+            const float a = valid ? __builtin_fabsf(q) : __builtin_inff();
+            float m1 = a, m2 = __builtin_inff();
+            uint32_t sg = valid ? __float_as_uint(q) & 0x80000000u : 0u;
+            auto join = [&](float p1, float p2, uint32_t ps) {
+                const float hi = fmaxf(m1, p1);
+                m1 = fminf(m1, p1);
+                m2 = fminf(hi, fminf(m2, p2));
+                sg ^= ps;
+            };
+            auto step = [&](auto ctrl) {
+                constexpr int C = decltype(ctrl)::value;
+                join(spag_dpp<C>(m1), spag_dpp<C>(m2), uint32_t(__builtin_amdgcn_update_dpp(0, int(sg), C, 0xf, 0xf, false)));
+            };
+            step(std::integral_constant<int, 0xB1>());
+            if (kind >= 2) step(std::integral_constant<int, 0x4E>());
+            if (kind >= 3) step(std::integral_constant<int, 0x141>());
+            if (kind >= 4) step(std::integral_constant<int, 0x140>());
+            if (kind >= 5) {
+                auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+                auto rs = [](uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); };
+                // rows 0|1 and 2|3 (and, for 64 lanes, both pairs): the same join on the rows' representatives
+                const float a1 = rl(m1, 0), a2 = rl(m2, 0), b1 = rl(m1, 16), b2 = rl(m2, 16), c1 = rl(m1, 32), c2 = rl(m2, 32), d1 = rl(m1, 48), d2 = rl(m2, 48);
+                const uint32_t sa = rs(sg, 0) ^ rs(sg, 16), sc = rs(sg, 32) ^ rs(sg, 48);
+                auto join2 = [](float x1, float x2, float y1, float y2, float& o1, float& o2) {
+                    o1 = fminf(x1, y1);
+                    o2 = fminf(fmaxf(x1, y1), fminf(x2, y2));
+                };
+                float ab1, ab2, cd1, cd2;
+                join2(a1, a2, b1, b2, ab1, ab2);
+                join2(c1, c2, d1, d2, cd1, cd2);
+                if (kind == 6) { join2(ab1, ab2, cd1, cd2, m1, m2); sg = sa ^ sc; }
+                else { m1 = lane < 32 ? ab1 : cd1; m2 = lane < 32 ? ab2 : cd2; sg = lane < 32 ? sa : sc; }
             }
-            __builtin_amdgcn_wave_barrier();
-            if (valid) M[slot] = rr;
+            const float mag = (a == m1) ? m2 : m1;
+            if (valid) M[slot] = __uint_as_float(__float_as_uint(mag * T.minsum_alpha) | ((sg ^ __float_as_uint(q)) & 0x80000000u));
+            }
             k = kn;
         }
-        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
+        if (with_syndrome && unsat && lane == 0) flag[p & 1] = 1;
     };
     struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
     auto load_var = [&](const uint32_t* vinfo, int i) -> VarRec {
@@ -653,9 +500,8 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
         const uint2 hi = *reinterpret_cast<const uint2*>(vinfo + size_t(i) * 8 + 4);
         return VarRec{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
     };
-    auto var_update = [&](const VarRec& q) {
+    auto var_update = [&](const VarRec& q, float s) {       // s: the variable's channel LLR
         const uint32_t v = q.vi & 0x7ff, deg = q.vi >> 11;
-        float s = Li[v];
         const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
         s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
         if (deg > 2) {      // rows sorted by degree: wavefronts of degree-2 parity bits skip the rest
@@ -685,7 +531,8 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
                 if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
             }
             if (tid == 0) flag[it & 1] = 0;
-            for (int i = tid; i < N; i += THREADS) var_update(load_var(T.vinfo, i));
+#pragma unroll
+            for (int k = 0; k < kRows; ++k) { const int i = tid + k * THREADS; if (i < N) var_update(load_var(T.vinfo_g, i), li[k]); }
             __syncthreads();
             if (it < kSpecStart) {
                 syndrome_pass(it);
@@ -699,17 +546,19 @@ __device__ __forceinline__ void minsum_decode(const LdpcDev& T, const float* __r
     __syncthreads();
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
 }
-
-
-#define MINSUM_KERNEL(THREADS)                                                                                     \
-    extern "C" __global__ __launch_bounds__(THREADS) void mgpu_ldpc_minsum_kernel_t##THREADS(                      \
-        LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,                        \
-        int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,      \
-        const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {                        \
-        minsum_decode<THREADS>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in); \
-    }
-MINSUM_KERNEL(1024)
-MINSUM_KERNEL(512)
+extern "C" __global__ __launch_bounds__(512, 2) void mgpu_ldpc_spa_fast_kernel_t512(
+    LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
+    int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+    const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    spa_fast_decode<512, 0>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}
+// Normalised min-sum (BASELINE.json's north_star names it; alpha = mgpu_config.minsum_alpha, default 0.8) on the same skeleton.
+extern "C" __global__ __launch_bounds__(512, 2) void mgpu_ldpc_minsum_kernel_t512(
+    LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
+    int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
+    const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
+    spa_fast_decode<512, 1>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+}
 
 // device probe of spa_math.h for tests: out_t[i] = tanh(in[i]); out_a[i] = atanh(in[i]) for |in[i]| < 1 else 0
 extern "C" __global__ void mgpu_spa_math_probe_kernel(const double* __restrict__ in, double* __restrict__ out_t,

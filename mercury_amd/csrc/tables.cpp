@@ -169,18 +169,12 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         }
         g.S = int(fill.size()) * 64;
         if (g.S >= 8192) throw std::runtime_error("padded edge count exceeds the 13-bit slot field");
-        // one extra all-padding round: the kernels always prefetch round r+1; never fewer than the 4 rounds of the smallest kernel instance
-        g.sdesc.assign(size_t(std::max(4, (g.S + 1023) / 1024) + 1) * 1024, 0u);
         std::vector<uint32_t> slot_of_edge(E);
         for (size_t b = 0; b < members.size(); ++b) {
             uint32_t p = uint32_t(b) * 64;
             for (uint32_t c : members[b]) {
-                const uint32_t cs = p, d = cdeg[c];
-                for (uint32_t j = 0; j < d; ++j, ++p) {
-                    const uint32_t eo = g.cptr[c] + j;
-                    g.sdesc[p] = cs | (d << 13) | (uint32_t(g.cvar[eo]) << 19) | (j + 1 == d ? 0x80000000u : 0u);
-                    slot_of_edge[eo] = p;
-                }
+                const uint32_t d = cdeg[c];
+                for (uint32_t j = 0; j < d; ++j, ++p) slot_of_edge[g.cptr[c] + j] = p;
             }
         }
         // variable update order: by degree (descending) so the lanes of a wavefront share a trip count
@@ -195,6 +189,51 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
             for (uint32_t j = 0; j < d; ++j) {
                 const uint32_t slot = slot_of_edge[g.vedge[g.vptr[v] + j]];
                 g.vinfo[size_t(i) * 8 + 1 + j / 2] |= slot << (16 * (j & 1));
+            }
+        }
+        // ---- grouped layout for the fp32 sum-product kernel ---------------------------------------
+        {
+            std::vector<std::vector<uint32_t>> by_kind(7);           // checks per group-size exponent
+            for (uint32_t c : order) {
+                int k = 1;
+                while ((1 << k) < int(cdeg[c])) ++k;
+                by_kind[k].push_back(c);
+            }
+            std::vector<uint32_t> kinds;                              // per bin
+            std::vector<std::vector<uint32_t>> bin_checks;
+            for (int k = 6; k >= 1; --k) {
+                const size_t per = size_t(64) >> k;
+                for (size_t i = 0; i < by_kind[k].size(); i += per) {
+                    kinds.push_back(uint32_t(k));
+                    bin_checks.emplace_back(by_kind[k].begin() + i, by_kind[k].begin() + std::min(by_kind[k].size(), i + per));
+                }
+            }
+            const size_t bins = kinds.size(), rounds = (bins + 7) / 8;
+            g.Sg = int(bins) * 64;
+            if (g.Sg >= 65536) throw std::runtime_error("grouped layout exceeds the 16-bit slot index of the variable records");
+            g.gdesc.assign((rounds + 1) * 512, 0u);
+            g.gkind.assign((rounds + 1) * 8, 0u);
+            std::vector<uint32_t> gslot_of_edge(E);
+            for (size_t b = 0; b < bins; ++b) {
+                g.gkind[b] = kinds[b];
+                const uint32_t gsz = 1u << kinds[b];
+                for (size_t q = 0; q < bin_checks[b].size(); ++q) {
+                    const uint32_t c = bin_checks[b][q], base = uint32_t(b) * 64 + uint32_t(q) * gsz;
+                    for (uint32_t j = 0; j < cdeg[c]; ++j) {
+                        const uint32_t eo = g.cptr[c] + j;
+                        g.gdesc[base + j] = 0x80000000u | uint32_t(g.cvar[eo]);
+                        gslot_of_edge[eo] = base + j;
+                    }
+                }
+            }
+            g.vinfo_g.assign(size_t(N) * 8, 0u);
+            for (uint32_t i = 0; i < N; ++i) {
+                const uint32_t v = vorder[i], d = vdeg[v];
+                g.vinfo_g[size_t(i) * 8] = v | (d << 11);
+                for (uint32_t j = 0; j < d; ++j) {
+                    const uint32_t slot = gslot_of_edge[g.vedge[g.vptr[v] + j]];
+                    g.vinfo_g[size_t(i) * 8 + 1 + j / 2] |= slot << (16 * (j & 1));
+                }
             }
         }
         // ---- the fp64 sum-product kernel's view: byte offsets and tabulated walk masks ----------

@@ -46,8 +46,14 @@ struct LdpcGraph {
     // wave-private layout for the sum-product kernel: whole checks bin-packed (first-fit decreasing)
     // into 64-slot bins so that one wavefront owns every edge of the checks it updates
     int S = 0;                     // padded slot count = 64 * bins
-    std::vector<uint32_t> sdesc;   // [(ceil(S/1024)+1)*1024] what the decoders read per slot: check_start | deg<<13 | variable<<19 | last-edge-of-check<<31, 0 for padding
-    std::vector<uint32_t> vinfo;   // [N][8] (6 used) variable | deg<<11, then 10 u16 padded-slot indices; rows sorted by degree (descending)
+    std::vector<uint32_t> vinfo;   // [N][8] (6 used) variable | deg<<11, then 10 u16 padded-slot indices; rows sorted by degree (descending); host only: vinfo2 is its device form
+    // grouped layout of the fp32 sum-product kernel (ldpc.hip, spa_fast): every check sits in an ALIGNED group of 2, 4, 8, 16, 32 or 64 lanes
+    // (its degree rounded up to a power of two), a bin holds groups of one size, so the product over a check is a handful of DPP
+    // steps inside the wavefront instead of a walk through LDS
+    int Sg = 0;                    // slots = 64 * bins
+    std::vector<uint32_t> gdesc;   // [(rounds+1)*512] per slot: 0x80000000 | variable, 0 for padding lanes (rounds of 8 bins: 512-thread workgroups)
+    std::vector<uint32_t> gkind;   // [(rounds+1)*8] per bin: log2 of its group size (1..6), 0 for an empty bin
+    std::vector<uint32_t> vinfo_g; // [N][8] like vinfo, slot indices in the grouped layout
     // the fp64 sum-product kernel's own tables (ldpc.hip, spa_decode): LDS byte offsets instead of indices, and the
     // product walk's execution masks tabulated per bin and step instead of compared per lane
     int maxdeg = 0;                // largest check degree
