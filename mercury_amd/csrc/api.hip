@@ -15,6 +15,9 @@
 
 #include "ctx.hpp"
 
+typedef void (*fe_kernel_t)(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
+static fe_kernel_t fe_kernel(int threads) { return threads == 1024 ? mgpu_frontend_kernel_t1024 : threads == 384 ? mgpu_frontend_kernel_t384 : mgpu_frontend_kernel; }
+
 thread_local std::string g_create_error;
 
 namespace mgpu_detail {
@@ -96,11 +99,11 @@ void ctx_alloc(mgpu_ctx* c) {
         const char* e = getenv("MERCURY_FE_THREADS");
         const size_t lds512 = mfsk ? 0 : mgpu_frontend_lds_bytes(d.G, d.nPilots, d.nBits, 512);
         c->fe_threads = e ? atoi(e) : (lds512 > size_t(160) * 1024 / 2 ? 1024 : 512);
-        if (c->fe_threads != 512 && c->fe_threads != 1024) throw std::invalid_argument("MERCURY_FE_THREADS must be 512 or 1024");
+        if (c->fe_threads != 384 && c->fe_threads != 512 && c->fe_threads != 1024) throw std::invalid_argument("MERCURY_FE_THREADS must be 384, 512 or 1024");
         c->lds_fe = mfsk ? 0 : mgpu_frontend_lds_bytes(d.G, d.nPilots, d.nBits, c->fe_threads);
     }
     c->lds_tx = mgpu_txgen_lds_bytes(mfsk ? 0 : d.G);
-    if (!mfsk) HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(c->fe_threads == 1024 ? mgpu_frontend_kernel_t1024 : mgpu_frontend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_fe)));
+    if (!mfsk) HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(fe_kernel(c->fe_threads)), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_fe)));
     HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_txgen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_tx)));
     {
         int geo[6];
@@ -199,7 +202,7 @@ void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float
         const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
         if (off && (taps.grid || taps.H || taps.eq || taps.syms || taps.llr_demod || taps.variance || taps.agc_gain || taps.mean_H))
             throw std::invalid_argument("stage taps are limited to 2^21 frames per call");
-        hipLaunchKernelGGL(c->fe_threads == 1024 ? mgpu_frontend_kernel_t1024 : mgpu_frontend_kernel, dim3(n), dim3(c->fe_threads), c->lds_fe, s, dev, d_bb + size_t(off) * stride * 2, n,
+        hipLaunchKernelGGL(fe_kernel(c->fe_threads), dim3(n), dim3(c->fe_threads), c->lds_fe, s, dev, d_bb + size_t(off) * stride * 2, n,
                            d_llr + size_t(off) * t.N, d_var + off, at(d_snrvar, off), at(c->d_eqdata, (size_t(frame0) + off) * t.nData * 2), taps);
         HIPCK(hipGetLastError());
     }
@@ -763,7 +766,7 @@ int mgpu_debug_occupancy(mgpu_ctx* c, int which) {
     int n = -1;
     guard(c, [&] {
         const auto& t = c->tab;
-        if (which == 0 && t.mfsk_M == 0) HIPCK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, c->fe_threads == 1024 ? mgpu_frontend_kernel_t1024 : mgpu_frontend_kernel, c->fe_threads, c->lds_fe));
+        if (which == 0 && t.mfsk_M == 0) HIPCK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fe_kernel(c->fe_threads), c->fe_threads, c->lds_fe));
         else if (which == 0) HIPCK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, t.mfsk_M == 32 ? mgpu_mfsk_frontend_kernel_m32 : mgpu_mfsk_frontend_kernel_m16x2, 256, 0));
         else if (which == 1) n = int(c->lds_fe);          // dynamic LDS bytes of the front-end workgroup
         else if (which == 2) n = int(c->lds_dec);         // ... of the decoder workgroup

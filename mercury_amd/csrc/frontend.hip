@@ -448,6 +448,12 @@ extern "C" __global__ __launch_bounds__(512, 6) void mgpu_frontend_kernel(
     fe_frame<512>(T, baseband, F, llr_out, variance_out, snr_variance_out, eqdata_out, taps);
 }
 
+extern "C" __global__ __launch_bounds__(384, 6) void mgpu_frontend_kernel_t384(
+    MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
+    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
+    fe_frame<384>(T, baseband, F, llr_out, variance_out, snr_variance_out, eqdata_out, taps);
+}
+
 extern "C" __global__ __launch_bounds__(1024, 4) void mgpu_frontend_kernel_t1024(
     MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
     float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
