@@ -79,6 +79,20 @@ void ctx_alloc(mgpu_ctx* c) {
     LdpcDev& l = c->ldev;
     l.scrambler = d.scrambler;
     l.cptr = d.cptr; l.cvar = d.cvar;
+    {   // the CRC as a sum of per-bit constants (crc16_modbus_rtu.cc:25-45 is linear over GF(2) up to the register's initial value)
+        const int full = d.nReal / 8;
+        std::vector<uint8_t> msg(size_t(full > 0 ? full : 1), 0);
+        const uint16_t zero = mgpu::crc16_modbus(msg.data(), full);
+        std::vector<uint16_t> tab(size_t(full > 0 ? full : 1) * 8, 0);
+        for (int b = 0; b < full; ++b)
+            for (int j = 0; j < 8; ++j) {
+                msg[b] = uint8_t(1u << j);
+                tab[size_t(b) * 8 + j] = uint16_t(mgpu::crc16_modbus(msg.data(), full) ^ zero);
+                msg[b] = 0;
+            }
+        l.crc_tab = c->keep(upload(tab));
+        l.crc_init = zero;
+    }
     l.gdesc = c->keep(upload(t.graph.gdesc));
     l.gkind = c->keep(upload(t.graph.gkind));
     l.vinfo_g = c->keep(upload(t.graph.vinfo_g));

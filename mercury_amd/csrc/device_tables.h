@@ -45,6 +45,8 @@ struct MgpuDev {
 struct LdpcDev {
     const uint32_t* cptr; const uint16_t* cvar;                           // plain check-major lists (GBF)
     const uint8_t* scrambler;
+    const uint16_t* crc_tab;   // [nReal/8][8] what message bit 8b+j set contributes to the CRC register after nReal/8 bytes (ldpc.hip: decode_tail)
+    uint32_t crc_init;         // the register after nReal/8 zero bytes
     // fp32 decoders (sum-product and min-sum), grouped layout (tables.hpp: LdpcGraph::gdesc / gkind / vinfo_g)
     const uint32_t* gdesc; const uint32_t* gkind; const uint32_t* vinfo_g;
     int Sg;

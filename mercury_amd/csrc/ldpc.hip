@@ -26,10 +26,18 @@
 #include "spa_math.h"
 
 #define LDPC_THREADS 1024
+#ifndef SPA_SPEC_START
+#define SPA_SPEC_START 8
+#endif
 
 namespace {
 
-// Epilogue shared by all decoders: hard[] (N bytes in LDS) -> bits / payload / stats.
+// Epilogue shared by all decoders: hard[] (N bytes in LDS) -> bits / payload / stats. bytes_lds: 256 bytes + 16 ints of scratch.
+// The CRC (crc16_modbus_rtu.cc:25-45 over the first nReal/8 bytes, telecom_system.cc:1319-1345) is linear over GF(2): the register
+// after the message = the register after an all-zero message of that length (crc_init) xor the contributions of the message's set
+// bits, each a constant of the bit's position (crc_tab, built on the host by running the bitwise algorithm on single-bit messages).
+// Every byte's lane looks up its eight constants, a wavefront xor-reduces them: a dozen instructions instead of one lane's
+// 600 dependent shift steps (10 us per frame, a third of a frame's decode time at the operating points).
 __device__ void decode_tail(const LdpcDev& T, int f, const uint8_t* hard, uint8_t* bytes_lds, int iterations,
                             uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
                             uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
@@ -38,29 +46,33 @@ __device__ void decode_tail(const LdpcDev& T, int f, const uint8_t* hard, uint8_
     if (bits_out) for (int i = tid; i < T.K; i += blockDim.x) bits_out[size_t(f) * T.K + i] = hard[i];
     if (iters_out && tid == 0) iters_out[f] = iterations;
     if (!payload_out && !stats_out) return;
-    const int nb = T.nReal, nbytes = (nb + 7) / 8;
+    const int nb = T.nReal, nbytes = (nb + 7) / 8, full = nb / 8;
+    unsigned x = 0, nz = 0;
     for (int b = tid; b < nbytes; b += blockDim.x) {
         unsigned v = 0;
         for (int j = 0; j < 8; ++j) {
             const int i = b * 8 + j;
             if (i < nb) v |= unsigned(hard[i] ^ T.scrambler[i]) << j;
         }
-        bytes_lds[b] = uint8_t(v);
         if (payload_out) payload_out[size_t(f) * T.payload_stride + b] = uint8_t(v);
-    }
-    __syncthreads();
-    if (stats_out && tid == 0) {
-        const int full = nb / 8;
-        int all_zeros = 1;
-        for (int i = 0; i < full; ++i) if (bytes_lds[i]) { all_zeros = 0; break; }
-        unsigned crc = 0;
-        if (!all_zeros) {
-            crc = 0xffff;
-            for (int j = 0; j < full; ++j) {
-                crc ^= bytes_lds[j];
-                for (int i = 0; i < 8; ++i) crc = (crc & 1) ? ((crc >> 1) ^ 0xA001) : (crc >> 1);
-            }
+        if (b < full) {
+            nz |= v;
+            const uint4 t = reinterpret_cast<const uint4*>(T.crc_tab)[b];
+            x ^= (v & 1 ? t.x & 0xffffu : 0u) ^ (v & 2 ? t.x >> 16 : 0u) ^ (v & 4 ? t.y & 0xffffu : 0u) ^ (v & 8 ? t.y >> 16 : 0u)
+               ^ (v & 16 ? t.z & 0xffffu : 0u) ^ (v & 32 ? t.z >> 16 : 0u) ^ (v & 64 ? t.w & 0xffffu : 0u) ^ (v & 128 ? t.w >> 16 : 0u);
         }
+    }
+    if (!stats_out) return;
+    int* scratch = reinterpret_cast<int*>(bytes_lds + 256);           // one word per wavefront (the decoders' flags are done with)
+    for (int o = 32; o; o >>= 1) x ^= unsigned(__shfl_xor(int(x), o));
+    x |= __any(nz != 0) ? 0x10000u : 0u;
+    if ((tid & 63) == 0) scratch[tid >> 6] = int(x);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0;
+        for (int w = 0; w < int(blockDim.x >> 6); ++w) { const unsigned y = unsigned(scratch[w]); acc = ((acc ^ y) & 0xffffu) | ((acc | y) & 0x10000u); }
+        const int all_zeros = !(acc & 0x10000u);
+        const unsigned crc = all_zeros ? 0u : ((acc & 0xffffu) ^ T.crc_init);
         MgpuStatsDev s;
         s.iterations_done = iterations;
         s.crc = int(crc);
@@ -285,7 +297,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         }
         if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
-    constexpr int kSpecStart = 8;
+    constexpr int kSpecStart = SPA_SPEC_START;
     int iteration = 0;
     syndrome_pass(0);
     __syncthreads();
@@ -374,23 +386,21 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     const int tid = threadIdx.x, f = blockIdx.x, lane = tid & 63;
     if (f >= F) return;
     constexpr int kRows = (kN + THREADS - 1) / THREADS;      // channel LLRs in registers: row i of the variable records belongs to one lane
-    float li[kRows];
+    uint32_t vrow[kRows];
 #pragma unroll
-    for (int k = 0; k < kRows; ++k) {
+    for (int k = 0; k < kRows; ++k) {                        // the frame's LLRs: coalesced; each lane then picks its rows' variables from LDS
         const int i = tid + k * THREADS;
-        li[k] = 0.0f;
-        if (i < N) {
-            const uint32_t v = T.vinfo_g[size_t(i) * 8] & 0x7ff;
-            li[k] = llr_in[size_t(f) * N + v];
-            Lt[v] = li[k];
-        }
+        vrow[k] = i < N ? T.vinfo_g[size_t(i) * 8] & 0x7ff : 0u;
+        if (i < N) Lt[i] = llr_in[size_t(f) * N + i];
     }
-    for (int p = tid; p < S; p += THREADS) M[p] = 0.0f;
     const uint32_t* __restrict__ gdesc = T.gdesc;
     typedef const uint32_t __attribute__((address_space(4))) * cptr32;
     const cptr32 gkind = (cptr32)(T.gkind) + __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
+    float li[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) li[k] = Lt[vrow[k]];
 
     // any group of 2^kind lanes with an odd number of set bits? fold the ballot onto each group's lowest lane
     auto groups_unsat = [&](unsigned long long m, uint32_t kind) -> bool {
@@ -416,7 +426,10 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         }
         if (unsat && lane == 0) flag[p & 1] = 1;
     };
-    auto cn_pass = [&](bool with_syndrome, int p) {
+    // Every pass tests the syndrome of the posteriors it starts from (the first one: of the channel LLRs), so a frame costs one check
+    // pass more than it has iterations and no syndrome-only passes; the messages start as zeros that are never stored (first).
+    auto cn_pass = [&](int p, bool first) {
+        constexpr bool with_syndrome = true;
         bool unsat = false;
         uint32_t k = gdesc[tid];
         uint32_t slot = tid;
@@ -428,7 +441,7 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
             const bool valid = int32_t(k) < 0;
             const float lt = Lt[k & 0x7ff];                          // padding lanes read variable 0
             if (with_syndrome && !unsat) unsat = groups_unsat(__ballot(lt < 0 && valid), kind);
-            const float q = lt - M[slot];
+            const float q = first ? lt : lt - M[slot];
             if constexpr (RULE == 0) {
             const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * __builtin_fabsf(q));
             float a = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
@@ -516,31 +529,17 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         }
         Lt[v] = s;
     };
-    constexpr int kSpecStart = 8;
     int iteration = 0;
-    syndrome_pass(0);
-    __syncthreads();
-    if (flag[0]) {
-        for (int it = 1;; ++it) {
-            const bool spec = it - 1 >= kSpecStart;
-            if (it <= T.max_iters) cn_pass(spec, it - 1);
-            else syndrome_pass(it - 1);
-            __syncthreads();
-            if (spec) {
-                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
-                if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
-            }
-            if (tid == 0) flag[it & 1] = 0;
+    for (int it = 1;; ++it) {
+        if (it <= T.max_iters) cn_pass(it - 1, it == 1);
+        else syndrome_pass(it - 1);
+        __syncthreads();
+        if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
+        if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
+        if (tid == 0) flag[it & 1] = 0;
 #pragma unroll
-            for (int k = 0; k < kRows; ++k) { const int i = tid + k * THREADS; if (i < N) var_update(load_var(T.vinfo_g, i), li[k]); }
-            __syncthreads();
-            if (it < kSpecStart) {
-                syndrome_pass(it);
-                __syncthreads();
-                if (!flag[it & 1]) { iteration = it; break; }
-                if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
-            }
-        }
+        for (int k = 0; k < kRows; ++k) { const int i = tid + k * THREADS; if (i < N) var_update(load_var(T.vinfo_g, i), li[k]); }
+        __syncthreads();
     }
     for (int v = tid; v < N; v += THREADS) hard[v] = Lt[v] < 0;
     __syncthreads();
@@ -629,12 +628,3 @@ extern "C" __global__ __launch_bounds__(LDPC_THREADS) void mgpu_ldpc_gbf_kernel(
     __syncthreads();
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
 }
-
-// ---------------------------------------------------------------------------------------------
-// Normalised min-sum, fp32, flooding schedule (BASELINE.json north_star variant; not in the
-// reference). Same skeleton as the sum-product kernel: wave-private 64-slot bins, one message array
-// updated in place (Q -> R -> Q), slot descriptors in registers, ballot syndrome, two barriers per
-// iteration. Check update per edge: sign = product of the other edges' signs, magnitude = alpha *
-// min of the other edges' |Q| (each lane scans its check's <= 46 slots, all lanes of a check read
-// the same LDS word per step = broadcast).
-// Up to eight slot descriptors per lane held in named registers; get(r) selects by the wave-uniform round number.
