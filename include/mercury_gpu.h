@@ -127,7 +127,7 @@ typedef struct mgpu_stage_taps {
     float* llr_ldpc;    /* [F][1600]         decoder input (bit de-interleaved, re-packed) */
     double* variance;   /* [F]               measure_variance as double */
     double* agc_gain;   /* [F] */
-    long long* cycles;  /* [16] shader-clock stamps at the front-end's phase boundaries for frame 0 (profiling aid) */
+    long long* cycles;  /* [16] shader-clock stamps at the front-end's phase boundaries for a frame from the middle of the batch (profiling aid) */
 } mgpu_stage_taps;
 
 int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out);

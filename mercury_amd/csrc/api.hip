@@ -16,7 +16,7 @@
 #include "ctx.hpp"
 
 typedef void (*fe_kernel_t)(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
-static fe_kernel_t fe_kernel(int threads) { return threads == 1024 ? mgpu_frontend_kernel_t1024 : threads == 384 ? mgpu_frontend_kernel_t384 : mgpu_frontend_kernel; }
+static fe_kernel_t fe_kernel(int threads) { return threads == 1024 ? mgpu_frontend_kernel_t1024 : mgpu_frontend_kernel; }
 
 thread_local std::string g_create_error;
 
@@ -113,7 +113,7 @@ void ctx_alloc(mgpu_ctx* c) {
         const char* e = getenv("MERCURY_FE_THREADS");
         const size_t lds512 = mfsk ? 0 : mgpu_frontend_lds_bytes(d.G, d.nPilots, d.nBits, 512);
         c->fe_threads = e ? atoi(e) : (lds512 > size_t(160) * 1024 / 2 ? 1024 : 512);
-        if (c->fe_threads != 384 && c->fe_threads != 512 && c->fe_threads != 1024) throw std::invalid_argument("MERCURY_FE_THREADS must be 384, 512 or 1024");
+        if (c->fe_threads != 512 && c->fe_threads != 1024) throw std::invalid_argument("MERCURY_FE_THREADS must be 512 or 1024");
         c->lds_fe = mfsk ? 0 : mgpu_frontend_lds_bytes(d.G, d.nPilots, d.nBits, c->fe_threads);
     }
     c->lds_tx = mgpu_txgen_lds_bytes(mfsk ? 0 : d.G);

@@ -25,7 +25,6 @@ extern "C" size_t mgpu_txgen_lds_bytes(int G);
 
 extern "C" __global__ void mgpu_frontend_kernel(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
 extern "C" __global__ void mgpu_frontend_kernel_t1024(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
-extern "C" __global__ void mgpu_frontend_kernel_t384(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
 extern "C" __global__ void mgpu_mfsk_frontend_kernel_m32(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
 extern "C" __global__ void mgpu_mfsk_frontend_kernel_m16x2(MgpuDev, const double*, int, int, float*, float*, float*, MgpuTapsDev);
 extern "C" int mgpu_mfsk_syms_per_block();

@@ -62,7 +62,7 @@ struct LdpcDev {
 
 struct MgpuTapsDev {
     double* grid; double* H; double* eq; double* syms; float* llr_demod; double* variance; double* agc_gain;
-    long long* cycles;   // optional: s_memtime stamps at the phase boundaries of frame 0 (profiling aid)
+    long long* cycles;   // optional: s_memtime stamps at the phase boundaries of a frame from the middle of the batch (profiling aid)
     double* mean_H;      // optional: mean |H| over the pilot cells after the estimator (receive_byte's gate, telecom_system.cc:1224-1243)
 };
 

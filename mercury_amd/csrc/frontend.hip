@@ -125,7 +125,7 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
     const c2* bb = reinterpret_cast<const c2*>(baseband) + size_t(f) * T.frame_samples;
     const double boost = T.pilot_boost;
     int stamp_i = 0;
-#define FE_STAMP() do { if (taps.cycles && f == 0 && tid == 0) taps.cycles[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
+#define FE_STAMP() do { if (taps.cycles && f == (F >> 1) && tid == 0) taps.cycles[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)    /* a frame from the middle of the launch: the compute unit is in its steady mix of phases */
     FE_STAMP();
 
     for (int i = tid; i < 128; i += FE_THREADS) tw[fft256_tw_slot(i)] = {T.twiddle[2 * i], T.twiddle[2 * i + 1]};
@@ -446,12 +446,6 @@ extern "C" __global__ __launch_bounds__(512, 6) void mgpu_frontend_kernel(
     MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
     float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
     fe_frame<512>(T, baseband, F, llr_out, variance_out, snr_variance_out, eqdata_out, taps);
-}
-
-extern "C" __global__ __launch_bounds__(384, 6) void mgpu_frontend_kernel_t384(
-    MgpuDev T, const double* __restrict__ baseband, int F, float* __restrict__ llr_out,
-    float* __restrict__ variance_out, float* __restrict__ snr_variance_out, double* __restrict__ eqdata_out, MgpuTapsDev taps) {
-    fe_frame<384>(T, baseband, F, llr_out, variance_out, snr_variance_out, eqdata_out, taps);
 }
 
 extern "C" __global__ __launch_bounds__(1024, 4) void mgpu_frontend_kernel_t1024(
