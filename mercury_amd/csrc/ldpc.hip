@@ -529,6 +529,11 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         }
         Lt[v] = s;
     };
+    // a lane's variable records (four rows, which slots hold the variable's messages) stay in registers: loaded per iteration they put an
+    // L2 round trip behind every barrier
+    VarRec vr[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) { const int i = tid + k * THREADS; vr[k] = i < N ? load_var(T.vinfo_g, i) : VarRec{0, 0, 0, 0, 0, 0}; }
     int iteration = 0;
     for (int it = 1;; ++it) {
         if (it <= T.max_iters) cn_pass(it - 1, it == 1);
@@ -538,21 +543,21 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
         if (tid == 0) flag[it & 1] = 0;
 #pragma unroll
-        for (int k = 0; k < kRows; ++k) { const int i = tid + k * THREADS; if (i < N) var_update(load_var(T.vinfo_g, i), li[k]); }
+        for (int k = 0; k < kRows; ++k) { const int i = tid + k * THREADS; if (i < N) var_update(vr[k], li[k]); }
         __syncthreads();
     }
     for (int v = tid; v < N; v += THREADS) hard[v] = Lt[v] < 0;
     __syncthreads();
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
 }
-extern "C" __global__ __launch_bounds__(512, 2) void mgpu_ldpc_spa_fast_kernel_t512(
+extern "C" __global__ __launch_bounds__(512, 8) void mgpu_ldpc_spa_fast_kernel_t512(
     LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
     int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
     const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
     spa_fast_decode<512, 0>(T, llr_in, F, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
 }
 // Normalised min-sum (BASELINE.json's north_star names it; alpha = mgpu_config.minsum_alpha, default 0.8) on the same skeleton.
-extern "C" __global__ __launch_bounds__(512, 2) void mgpu_ldpc_minsum_kernel_t512(
+extern "C" __global__ __launch_bounds__(512, 8) void mgpu_ldpc_minsum_kernel_t512(
     LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,
     int* __restrict__ iters_out, uint8_t* __restrict__ payload_out, MgpuStatsDev* __restrict__ stats_out,
     const float* __restrict__ variance_in, const float* __restrict__ snr_variance_in) {
