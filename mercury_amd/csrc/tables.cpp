@@ -229,6 +229,8 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
             g.vinfo_g.assign(size_t(N) * 8, 0u);
             for (uint32_t i = 0; i < N; ++i) {
                 const uint32_t v = vorder[i], d = vdeg[v];
+                // the fp32 decoders keep a lane's records (rows i, i + 512, ...) in 6 + 4 + 3 + 2 registers
+                if (d > (i < 512 ? 9u : i < 1024 ? 6u : i < 1536 ? 4u : 2u)) throw std::runtime_error("variable degrees exceed the fp32 decoders' register layout");
                 g.vinfo_g[size_t(i) * 8] = v | (d << 11);
                 for (uint32_t j = 0; j < d; ++j) {
                     const uint32_t slot = gslot_of_edge[g.vedge[g.vptr[v] + j]];
