@@ -29,6 +29,9 @@
 #ifndef SPA_SPEC_START
 #define SPA_SPEC_START 8
 #endif
+#ifndef SPA_VR_RESIDENT
+#define SPA_VR_RESIDENT 1
+#endif
 
 namespace {
 
@@ -229,6 +232,19 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         }
         Lt[v] = s;
     };
+    auto var_update4 = [&](uint32_t vi, uint32_t w0, uint32_t w1) {      // rows from 1024 on: at most four edges (checked on the host)
+        const uint32_t v = vi & 0x7ff;
+        uint32_t deg = vi >> 11;
+        asm volatile("" : "+v"(deg));
+        double s = Li[v];
+        if (deg > 0) { s += Mb(w0 & 0xffff); SPA_KEEP(s); }
+        if (deg > 1) { s += Mb(w0 >> 16); SPA_KEEP(s); }
+        if (deg > 2) {
+            s += Mb(w1 & 0xffff); SPA_KEEP(s);
+            if (deg > 3) { s += Mb(w1 >> 16); SPA_KEEP(s); }
+        }
+        Lt[v] = s;
+    };
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
 
@@ -297,6 +313,11 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         }
         if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
+#if SPA_VR_RESIDENT
+    // the lane's two variable records stay in registers (6 + 3): loaded per iteration, their L2 round trip sat behind the barrier
+    const VarRec va = load_var(tid);
+    const spa_u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(vrec, (tid + LDPC_THREADS) * 32, 0, 0);
+#endif
     constexpr int kSpecStart = SPA_SPEC_START;
     int iteration = 0;
     syndrome_pass(0);
@@ -306,7 +327,9 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             const bool spec = it - 1 >= kSpecStart;
             if (it <= T.max_iters) cn_pass(spec, it - 1);
             else syndrome_pass(it - 1);
+#if !SPA_VR_RESIDENT
             const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
+#endif
             __syncthreads();
             if (spec) {
                 if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
@@ -314,7 +337,11 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             }
             if (tid == 0) flag[it & 1] = 0;
             var_update(va);
+#if SPA_VR_RESIDENT
+            if (tid + LDPC_THREADS < N) var_update4(vb.x, vb.y, vb.z);
+#else
             if (tid + LDPC_THREADS < N) var_update(vb);
+#endif
             __syncthreads();
             if (it < kSpecStart) {
                 syndrome_pass(it);

@@ -185,6 +185,7 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         for (uint32_t i = 0; i < N; ++i) {
             const uint32_t v = vorder[i], d = vdeg[v];
             if (d > 9) throw std::runtime_error("variable degree exceeds the unrolled update");
+            if (i >= 1024 && d > 4) throw std::runtime_error("variable degrees exceed the fp64 decoder's register layout (rows from 1024 on: at most 4 edges)");
             g.vinfo[size_t(i) * 8] = v | (d << 11);
             for (uint32_t j = 0; j < d; ++j) {
                 const uint32_t slot = slot_of_edge[g.vedge[g.vptr[v] + j]];
