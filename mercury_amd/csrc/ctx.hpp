@@ -244,11 +244,12 @@ inline int guard(mgpu_ctx* c, const std::function<void()>& fn) {
 inline void need(bool ok, const char* what) { if (!ok) throw std::invalid_argument(what); }
 struct DevBuf {
     void* p = nullptr;
+    void* view = nullptr;       // when set: page-locked host memory holding the buffer's current content, which kernels read in place
     explicit DevBuf(size_t bytes) { HIPCK(hipMalloc(&p, bytes ? bytes : 16)); }
     ~DevBuf() { (void)hipFree(p); }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    template <typename T> T* as() { return static_cast<T*>(p); }
+    template <typename T> T* as() { return static_cast<T*>(view ? view : p); }
 };
 // mfsk.cc:82-95, :120-126, :149-155; the universal ACK/BREAK patterns use M = 16, one stream centred in Nc = 50
 // (telecom_system.cc:3006), hop step 7, 8 tones sent twice.

@@ -140,12 +140,23 @@ struct Loop {
         // a call that threw between down_async() and settle() leaves entries whose destinations were its stack vectors: never replay them
         ws.pending.clear();
         ws.pin_off = 0;
+        d_ia.view = d_ib.view = d_ic.view = d_carrier.view = nullptr;
     }
+    const bool zero_copy = []{ const char* e = std::getenv("MERCURY_RB_ZEROCOPY"); return !e || atoi(e) != 0; }();
 
     bool in_bounds(int p) const { return p > lower && p < upper; }
 
+    // Host -> device for the control rounds' small index arrays (window lists, start offsets, carriers: a few KB). They are placed in the
+    // page-locked staging area and the kernels read them THERE (the buffer's view): a 4 KB hipMemcpyAsync is a 5 us blit kernel plus the
+    // gaps around it on the stream, and a call of 1024 windows made 400 of them (a fifth of its device time). A staging slot is reused
+    // only after settle() has waited for the stream, so every kernel launched with a view has read it by then.
     void up(DevBuf& d, const void* h, size_t bytes) {
-        if (void* p = ws.pin_take(bytes)) { std::memcpy(p, h, bytes); h = p; }
+        d.view = nullptr;
+        if (void* p = ws.pin_take(bytes)) {
+            std::memcpy(p, h, bytes);
+            if (zero_copy) { d.view = p; return; }
+            h = p;
+        }
         HIPCK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, s));
     }
     // device -> host without waiting: the bytes are in h after the next down() / settle()
