@@ -260,18 +260,25 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     constexpr int kRound = LDPC_THREADS * 8;                       // bytes of address table per round
     const spa_cptr64 bhead0 = (spa_cptr64)(T.bhead) + size_t(wave) * 4;
 
+    // Syndrome only (before the first iteration and, in a frame's first eight iterations, after every variable update): all rounds'
+    // addresses, masks and posteriors are requested before the first is used, so the pass waits for one L2 and one LDS round trip
+    // instead of one per round — it is pure latency, and at a mode's operating point there is one of these per iteration.
     auto syndrome_pass = [&](int p) {
+        uint32_t alt[NE];
+        unsigned long long vmask[NE], ends[NE];
+        double lt[NE];
+#pragma unroll
+        for (int r = 0; r < NE; ++r) alt[r] = __builtin_amdgcn_raw_buffer_load_b32(sadr, tid * 8, r * kRound, 0);
+#pragma unroll
+        for (int r = 0; r < NE; ++r) { vmask[r] = bhead0[r * 64]; ends[r] = bhead0[r * 64 + 1]; }
+#pragma unroll
+        for (int r = 0; r < NE; ++r) lt[r] = *ldsd(alt[r]);                // padding reads variable 0; masked out below
+#pragma unroll
+        for (int r = 0; r < NE; ++r) SPA_KEEP(lt[r]);                      // all of them here: the optimiser would sink each load to its (conditional) use
         bool unsat = false;
-        spa_cptr64 bh = bhead0;
-        uint32_t alt = __builtin_amdgcn_raw_buffer_load_b32(sadr, tid * 8, 0, 0);
-#pragma unroll 1
-        for (int r = 0; r < NE; ++r, bh += 64) {
-            const uint32_t altn = __builtin_amdgcn_raw_buffer_load_b32(sadr, tid * 8, (r + 1) * kRound, 0);
-            const unsigned long long vmask = bh[0], ends = bh[1];
-            const double lt = *ldsd(alt);                              // padding reads variable 0; masked out below
-            if (!unsat) unsat = bin_unsat(__ballot(lt < 0) & vmask, ends);
-            alt = altn;
-        }
+#pragma unroll
+        for (int r = 0; r < NE; ++r)
+            if (!unsat) unsat = bin_unsat(__ballot(lt[r] < 0) & vmask[r], ends[r]);
         if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
     auto cn_pass = [&](bool with_syndrome, int p) {
