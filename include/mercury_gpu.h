@@ -65,7 +65,8 @@ typedef struct mgpu_ctx mgpu_ctx;
  *   M: 2, 4, 8, 16 or 32 (MOD_BPSK..MOD_32QAM); rate16: 1, 2, 3, 4, 5, 6, 8 or 14 (sixteenths, ldpc.cc:140-251);
  *   preamble_nsymb: 1..8; estimator: MGPU_EST_ZF / MGPU_EST_LS.
  * Everything else is what physical_config.cc:30-122 and init() (telecom_system.cc:1804-1982) set for every mode: Nc 50, Nfft 256,
- * gi 1/16, pilots Dx 1 / Dy 3 with boost 1.33, LS window 21 x 21, scrambler / pilot seed 0, preamble seed 1; amplitude
+ * gi 1/16, pilots Dx 1 / Dy 3 with boost 1.33, LS window 21 x 21, scrambler / pilot seed 0, preamble seed 1 (boost, LS window and
+ * the seeds can be overridden per context: mgpu_create_explicit below); amplitude
  * restoration for the PSK constellations (:2647-2654). MOD_64QAM is not accepted: the reference sizes its frame at 8 symbols =
  * 1602 interleaved bits (:1826), which does not fit the N = 1600 codeword (nVirtual = -2), so it cannot run there either.
  * Evaluates to -1 for an unsupported combination. */
@@ -131,6 +132,23 @@ typedef struct mgpu_stage_taps {
 } mgpu_stage_taps;
 
 int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out);
+
+/* The rest of SURVEY.md §8b's explicit configuration: the parameters physical_config.cc:30-65 gives every mode and
+ * cl_telecom_system::load_configuration copies into the DSP objects (telecom_system.cc:2772-2811). A zero field keeps the reference's
+ * value. Honoured: pilot_boost (ofdm_pilot_configurator_pilot_boost, a float: 1.33), ls_window (ofdm_LS_window_width = _hight: 20; an
+ * even value is incremented as telecom_system.cc:2802-2809 does; 1..21 cells — the front-end reads at most 7 pilots of a window
+ * row) and, when seeds_set != 0, the three PRNG seeds (ofdm_pilot_configurator_seed 0, bit_energy_dispersal_seed 0,
+ * ofdm_preamble_configurator_seed 1; seed 0 means 1 to __srandom, os_interop.cc:251). They act on the RX path, the synthetic
+ * generator and the transmit chain alike. Nc / Nfft / Dx / Dy must be 0 or the reference's 50 / 256 / 1 / 3: the kernels are
+ * specialised for that carrier geometry and pilot lattice (MGPU_ERR_UNSUPPORTED otherwise). params == NULL: mgpu_create. */
+typedef struct mgpu_explicit_params {
+    float pilot_boost;
+    int ls_window;
+    int seeds_set;
+    unsigned pilot_seed, scrambler_seed, preamble_seed;
+    int Nc, Nfft, Dx, Dy;
+} mgpu_explicit_params;
+int mgpu_create_explicit(const mgpu_config* cfg, const mgpu_explicit_params* params, mgpu_ctx** out);
 void mgpu_destroy(mgpu_ctx* ctx);
 const char* mgpu_last_error(mgpu_ctx* ctx);   /* ctx may be NULL: error of the last failed mgpu_create */
 int mgpu_get_info(mgpu_ctx* ctx, mgpu_info* info);

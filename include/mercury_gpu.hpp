@@ -136,6 +136,14 @@ public:
     int device = 0;
     st_receive_stats receive_stats;
     mgpu_info info{};
+    // cl_telecom_system::default_configurations_telecom_system (cl_configuration_telecom_system, physical_config.cc:30-65): the values
+    // load_configuration copies into the DSP objects for every mode (telecom_system.cc:2772-2811). Change them BEFORE load_configuration,
+    // as the reference's callers do. (Nc, Nfft, Dx, Dy are fixed: the kernels are specialised for the reference's geometry.)
+    struct {
+        float ofdm_pilot_configurator_pilot_boost = 1.33f;
+        int ofdm_LS_window_width = 20;            // = ofdm_LS_window_hight
+        unsigned ofdm_pilot_configurator_seed = 0, bit_energy_dispersal_seed = 0, ofdm_preamble_configurator_seed = 1;
+    } default_configurations_telecom_system;
 
     ~cl_rx_phy() { release(); }
 
@@ -166,8 +174,8 @@ public:
     std::vector<std::complex<double>> pre_equalization_channel;
     void get_pre_equalization_channel() {
         pre_equalization_channel.assign(info.Nc, std::complex<double>(0, 0));
-        if (mgpu_host_pre_equalization_channel(current_configuration, carrier_frequency, reinterpret_cast<double*>(pre_equalization_channel.data())) != MGPU_OK)
-            throw std::runtime_error("get_pre_equalization_channel: the OFDM modes only");
+        detail::check(mgpu_context_pre_equalization_channel(ctx_, carrier_frequency, reinterpret_cast<double*>(pre_equalization_channel.data())), ctx_,
+                      "get_pre_equalization_channel");
         detail::check(mgpu_set_pre_equalization_channel(ctx_, reinterpret_cast<const double*>(pre_equalization_channel.data())), ctx_,
                       "get_pre_equalization_channel");
     }
@@ -369,7 +377,14 @@ private:
             mgpu_config c{};
             c.cfg = current_configuration; c.max_iters = ldpc_nIteration_max; c.decoder = ldpc_decoding_algorithm;
             c.agc = 1; c.variance_source = 1; c.device = device; c.max_batch = max_batch; c.mfsk_ctrl_mode = which;
-            detail::check(mgpu_create(&c, &ctxs_[which]), nullptr, "load_configuration");
+            mgpu_explicit_params x{};
+            x.pilot_boost = default_configurations_telecom_system.ofdm_pilot_configurator_pilot_boost;
+            x.ls_window = default_configurations_telecom_system.ofdm_LS_window_width;
+            x.seeds_set = 1;
+            x.pilot_seed = default_configurations_telecom_system.ofdm_pilot_configurator_seed;
+            x.scrambler_seed = default_configurations_telecom_system.bit_energy_dispersal_seed;
+            x.preamble_seed = default_configurations_telecom_system.ofdm_preamble_configurator_seed;
+            detail::check(mgpu_create_explicit(&c, &x, &ctxs_[which]), nullptr, "load_configuration");
         }
         ctx_ = ctxs_[which];
         detail::check(mgpu_get_info(ctx_, &info), ctx_, "load_configuration");

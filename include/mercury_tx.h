@@ -62,6 +62,9 @@ typedef struct mgpu_transmit_config {
 /* cl_telecom_system::get_pre_equalization_channel for a process that has loaded configuration `cfg` (0..16 or an MGPU_CFG_EXPLICIT id)
  * with carrier_frequency = carrier_hz: channel_c128 [Nc = 50] complex128. Host only (no GPU needed), about 0.2 s. */
 int mgpu_host_pre_equalization_channel(int cfg, double carrier_hz, double* channel_c128);
+/* the same for the configuration a context holds, explicit parameters included (mgpu_create_explicit: the measurement's random symbols
+ * continue the PRNG stream the pilot seed started) */
+int mgpu_context_pre_equalization_channel(mgpu_ctx* ctx, double carrier_hz, double* channel_c128);
 /* installs the table transmit_bit multiplies the carrier grids with (telecom_system.cc:474-494) in this context, [Nc] complex128;
  * NULL removes it (all ones). Synchronises the context's stream. The MFSK modes have none (telecom_system.cc:474). */
 int mgpu_set_pre_equalization_channel(mgpu_ctx* ctx, const double* channel_c128);

@@ -433,9 +433,25 @@ void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int
 
 extern "C" {
 
-int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
+int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) { return mgpu_create_explicit(cfg, nullptr, out); }
+
+int mgpu_create_explicit(const mgpu_config* cfg, const mgpu_explicit_params* xp_in, mgpu_ctx** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return MGPU_ERR_ARG; }
     *out = nullptr;
+    mgpu::ExplicitParams xp;
+    if (xp_in) {
+        // the kernels are specialised for the reference's carrier geometry and pilot lattice: those fields only confirm it
+        if ((xp_in->Nc != 0 && xp_in->Nc != 50) || (xp_in->Nfft != 0 && xp_in->Nfft != 256) || (xp_in->Dx != 0 && xp_in->Dx != 1) ||
+            (xp_in->Dy != 0 && xp_in->Dy != 3)) {
+            g_create_error = "explicit parameters: Nc / Nfft / Dx / Dy other than 50 / 256 / 1 / 3 are not supported (the kernels are specialised for the reference's geometry)";
+            return MGPU_ERR_UNSUPPORTED;
+        }
+        if (xp_in->pilot_boost != 0.0f) xp.pilot_boost = xp_in->pilot_boost;
+        if (xp_in->ls_window != 0) xp.ls_window = xp_in->ls_window;
+        if (xp_in->ls_window < 0 || xp_in->ls_window > 21) { g_create_error = "explicit parameters: ls_window must be 1..21 (0 = the reference's 20)"; return MGPU_ERR_ARG; }
+        if (!(xp.pilot_boost > 0.0f) || !(xp.pilot_boost < 1e6f)) { g_create_error = "explicit parameters: pilot_boost must be positive and finite (0 = the reference's 1.33)"; return MGPU_ERR_ARG; }
+        if (xp_in->seeds_set) { xp.pilot_seed = xp_in->pilot_seed; xp.scrambler_seed = xp_in->scrambler_seed; xp.preamble_seed = xp_in->preamble_seed; }
+    }
     int em, er, ep, ee;
     if (!((cfg->cfg >= 0 && cfg->cfg <= 16) || (cfg->cfg >= 100 && cfg->cfg <= 102) || mgpu::explicit_mode_row(cfg->cfg, &em, &er, &ep, &ee))) {
         g_create_error = "cfg must be 0..16 (OFDM modes), 100..102 (ROBUST MFSK modes) or an MGPU_CFG_EXPLICIT id";
@@ -460,7 +476,7 @@ int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out) {
             blob_size = file_blob.size();
         }
         try {
-            c->tab = mgpu::build_mode_tables(cfg->cfg, cfg->mfsk_ctrl_mode, blob, blob_size);
+            c->tab = mgpu::build_mode_tables(cfg->cfg, cfg->mfsk_ctrl_mode, blob, blob_size, xp);
         } catch (const std::exception& e) {
             g_create_error = e.what();
             delete c;

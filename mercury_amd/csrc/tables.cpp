@@ -383,7 +383,7 @@ std::vector<Cplx> pre_equalization_channel(const ModeTables& t, double carrier_h
             if (i >= h && i < len + h) out[i - h] = acc;
         }
     };
-    GlibcRandom rng(0);
+    GlibcRandom rng(t.xp.pilot_seed);
     for (int i = 0; i < t.nPilots; ++i) (void)rng.next();
     std::vector<cd> acc(Nc, cd(0, 0)), mod(Nc), sym(Nofdm), bb(Nofdm), dem(Nc), mixed(n);
     std::vector<double> pb(n), t1(n), t2(n), cs(2 * size_t(n));
@@ -452,7 +452,7 @@ bool explicit_mode_row(int cfg, int* M, int* rate16, int* preamble, int* estimat
     return true;
 }
 
-ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, size_t blob_size) {
+ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, size_t blob_size, const ExplicitParams& xp) {
     const bool robust = cfg >= 100 && cfg <= 102;                             // common_defines.h:63-65
     ModeRow explicit_row = {0, 0, 0, 0};
     const bool is_explicit = explicit_mode_row(cfg, &explicit_row.M, &explicit_row.rate16, &explicit_row.preamble, &explicit_row.estimator);
@@ -461,6 +461,10 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
     const ModeRow robust_row = {200 /* MOD_MFSK, mfsk.h:28 */, cfg == 102 ? 4 : 1, 4, 1};   // telecom_system.cc:2625-2645
     const ModeRow& row = robust ? robust_row : is_explicit ? explicit_row : kModeTable[cfg];
     ModeTables t;
+    t.xp = xp;
+    t.lsw = xp.ls_window % 2 == 0 ? xp.ls_window + 1 : xp.ls_window;        // telecom_system.cc:2802-2809
+    if (!(xp.pilot_boost > 0.0f) || !(xp.pilot_boost < 1e6f)) throw std::runtime_error("pilot_boost must be a positive finite number");
+    if (t.lsw < 1 || t.lsw > 21) throw std::runtime_error("LS window must be 1..21 cells wide (the front-end reads at most 7 pilots of a window row)");
     t.cfg = cfg;
     t.M = row.M;
     t.preamble = row.preamble;
@@ -490,10 +494,10 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
     }
     const int G = t.Nsymb * t.Nc;
     t.cell_type = robust ? std::vector<uint8_t>(G, 0) : make_pilot_lattice(t.Nsymb, t.Nc);   // MFSK frames carry no pilots
-    t.pilot_boost = static_cast<double>(1.33f);                               // physical_config.h:53 (float)
+    t.pilot_boost = static_cast<double>(xp.pilot_boost);                      // physical_config.h:53 (float)
     t.pilot_val.assign(G, 0.0);
     if (!robust) {   // DBPSK pilot sequence, ofdm.cc:940-951
-        GlibcRandom rng(0);
+        GlibcRandom rng(xp.pilot_seed);
         int last = 0;
         for (int c = 0; c < G; ++c) {
             if (!t.cell_type[c]) continue;
@@ -519,7 +523,7 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
     t.frame_samples = t.active_nsymb * t.Nofdm;
     if (!robust) t.constellation = make_constellation(t.M);
     {   // telecom_system.cc:1961-1966
-        GlibcRandom rng(0);
+        GlibcRandom rng(xp.scrambler_seed);
         t.scrambler.resize(t.N);
         for (int i = 0; i < t.N; ++i) t.scrambler[i] = uint8_t(rng.next() % 2);
     }
@@ -580,7 +584,7 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
         for (int s = 0; s < t.preamble; ++s)
             for (int st = 0; st < t.mfsk_nstreams; ++st) t.preamble_carriers[size_t(s) * t.Nc + t.mfsk_off[st] + tones[s % 4]] = Cplx{t.mfsk_amp, 0.0};
     } else {                            // cl_preamble_configurator::configure + init, ofdm.cc:1127-1232 (QPSK, seed 1, telecom_system.cc:2837-2841)
-        GlibcRandom rng(1);
+        GlibcRandom rng(xp.preamble_seed);
         const double s2 = std::sqrt(2.0);
         for (int i = 0; i < t.preamble; ++i)
             for (int j = 0; j < t.Nc; ++j) {

@@ -64,7 +64,18 @@ struct LdpcGraph {
     std::vector<uint32_t> vinfo2;  // [N][8] like vinfo with byte offsets (slot*8) in the 10 u16 fields
 };
 
+// The parameters physical_config.cc:30-65 gives every mode and telecom_system.cc:2772-2811 copies into the DSP objects; a context may
+// override them (include/mercury_gpu.h: mgpu_explicit_params). Defaults = the reference's.
+struct ExplicitParams {
+    float pilot_boost = 1.33f;     // ofdm_pilot_configurator_pilot_boost (physical_config.h:53: float)
+    int ls_window = 20;            // ofdm_LS_window_width = _hight; an even value is incremented (telecom_system.cc:2802-2809)
+    unsigned pilot_seed = 0;       // ofdm_pilot_configurator_seed
+    unsigned scrambler_seed = 0;   // bit_energy_dispersal_seed
+    unsigned preamble_seed = 1;    // ofdm_preamble_configurator_seed
+};
+
 struct ModeTables {
+    ExplicitParams xp;
     int cfg = 0, M = 0, bps = 0, K = 0, P = 0, N = 1600;
     int Nsymb = 0, Nc = 50, Nfft = 256, Ngi = 16, Nofdm = 272;
     int nData = 0, nBits = 0, nPilots = 0, nVirtual = 0, nReal = 0;
@@ -96,7 +107,7 @@ struct ModeTables {
 };
 
 // Throws std::runtime_error on a bad cfg or unreadable/corrupt table blob.
-ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* ldpc_blob, size_t ldpc_blob_size);
+ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* ldpc_blob, size_t ldpc_blob_size, const ExplicitParams& xp = ExplicitParams());
 
 uint16_t crc16_modbus(const uint8_t* bytes, int n);
 

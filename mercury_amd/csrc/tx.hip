@@ -385,6 +385,15 @@ int mgpu_host_pre_equalization_channel(int cfg, double carrier_hz, double* chann
     } catch (const std::exception&) { return MGPU_ERR_ARG; }
 }
 
+int mgpu_context_pre_equalization_channel(mgpu_ctx* c, double carrier_hz, double* channel_c128) {
+    if (!c || !channel_c128) return MGPU_ERR_ARG;
+    return guard(c, [&] {
+        need(c->tab.mfsk_M == 0, "pre_equalization_channel: the OFDM modes only (telecom_system.cc:474-494)");
+        const std::vector<mgpu::Cplx> h = mgpu::pre_equalization_channel(c->tab, carrier_hz);     // the context's own tables (explicit parameters included)
+        std::memcpy(channel_c128, h.data(), h.size() * 16);
+    });
+}
+
 int mgpu_set_pre_equalization_channel(mgpu_ctx* c, const double* channel_c128) {
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {

@@ -33,6 +33,11 @@ INFO_FIELDS = ("cfg M bits_per_symbol K P N Nsymb Nc Nfft Ngi Nofdm nData nBits 
                "payload_bytes payload_stride frame_samples mfsk_M mfsk_nStreams active_nsymb active_nbits").split()
 
 
+class ExplicitParams(C.Structure):    # mgpu_explicit_params
+    _fields_ = [("pilot_boost", C.c_float), ("ls_window", C.c_int), ("seeds_set", C.c_int), ("pilot_seed", C.c_uint),
+                ("scrambler_seed", C.c_uint), ("preamble_seed", C.c_uint), ("Nc", C.c_int), ("Nfft", C.c_int), ("Dx", C.c_int), ("Dy", C.c_int)]
+
+
 class Info(C.Structure):
     _fields_ = [(n, C.c_int) for n in INFO_FIELDS]
 
@@ -107,13 +112,13 @@ EXPORTED_SYMBOLS = [
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_debug_glibc_trig", "mgpu_debug_tsync_metric", "mgpu_debug_occupancy", "mgpu_debug_select_peak", "mgpu_debug_span_energy", "mgpu_debug_p2b_variant", "mgpu_debug_mfsk_sync", "mgpu_baseband_test_esn0", "mgpu_passband_test_esn0", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_measure_signal_only",
-    "mgpu_host_pre_equalization_channel", "mgpu_set_pre_equalization_channel", "mgpu_transmit_bit_batch", "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_transmit_buffer", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
+    "mgpu_host_pre_equalization_channel", "mgpu_context_pre_equalization_channel", "mgpu_set_pre_equalization_channel", "mgpu_transmit_bit_batch", "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_transmit_buffer", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
     "mgpu_symbol_demod", "mgpu_automatic_gain_control", "mgpu_channel_estimator", "mgpu_restore_channel_amplitude", "mgpu_channel_equalizer",
     "mgpu_measure_variance", "mgpu_deframer", "mgpu_deinterleaver_c128", "mgpu_deinterleaver_f32", "mgpu_psk_demod",
     "mgpu_bit_energy_dispersal", "mgpu_bit_to_byte", "mgpu_crc16_modbus_rtu",
     "mgpu_shm_create", "mgpu_shm_connect", "mgpu_shm_close", "mgpu_shm_destroy", "mgpu_shm_used", "mgpu_shm_free", "mgpu_shm_capacity",
     "mgpu_shm_clear", "mgpu_shm_write", "mgpu_shm_read", "mgpu_shm_read_all", "mgpu_shm_publish_decoded",
-    "mgpu_pool_create", "mgpu_pool_destroy", "mgpu_pool_size", "mgpu_pool_context", "mgpu_pool_last_error", "mgpu_pool_last_counters",
+    "mgpu_create_explicit", "mgpu_pool_create", "mgpu_pool_destroy", "mgpu_pool_size", "mgpu_pool_context", "mgpu_pool_last_error", "mgpu_pool_last_counters",
     "mgpu_pool_shard", "mgpu_pool_rx_batch", "mgpu_pool_ldpc_batch", "mgpu_pool_receive_byte_batch",
 ]
 
@@ -160,11 +165,20 @@ class RxPhy:
     """One GPU receive context for one Mercury mode (``load_configuration(cfg)`` equivalent)."""
 
     def __init__(self, cfg, max_iters=50, decoder=DEC_SPA, agc=1, variance_source=1, device=0,
-                 max_batch=4096, minsum_alpha=0.0, mfsk_ctrl_mode=False, test_puncture_nbits=0):
+                 max_batch=4096, minsum_alpha=0.0, mfsk_ctrl_mode=False, test_puncture_nbits=0, explicit=None):
+        """explicit: dict with any of pilot_boost, ls_window, pilot_seed, scrambler_seed, preamble_seed (and Nc, Nfft, Dx, Dy, which must
+        be the reference's) -> mgpu_create_explicit (include/mercury_gpu.h); the seeds override the reference's 0 / 0 / 1 together."""
         self.lib = load_library()
         self.h = C.c_void_p()
         c = Config(cfg, max_iters, decoder, agc, variance_source, device, max_batch, minsum_alpha, 1 if mfsk_ctrl_mode else 0, test_puncture_nbits)
-        rc = self.lib.mgpu_create(C.byref(c), C.byref(self.h))
+        if explicit:
+            seeds = any(k in explicit for k in ("pilot_seed", "scrambler_seed", "preamble_seed"))
+            xp = ExplicitParams(float(explicit.get("pilot_boost", 0.0)), int(explicit.get("ls_window", 0)), 1 if seeds else 0,
+                                int(explicit.get("pilot_seed", 0)), int(explicit.get("scrambler_seed", 0)), int(explicit.get("preamble_seed", 1)),
+                                int(explicit.get("Nc", 0)), int(explicit.get("Nfft", 0)), int(explicit.get("Dx", 0)), int(explicit.get("Dy", 0)))
+            rc = self.lib.mgpu_create_explicit(C.byref(c), C.byref(xp), C.byref(self.h))
+        else:
+            rc = self.lib.mgpu_create(C.byref(c), C.byref(self.h))
         if rc != 0:
             raise MgpuError("mgpu_create failed (%d): %s" % (rc, self.lib.mgpu_last_error(None).decode()))
         self.config = c
@@ -421,9 +435,7 @@ class RxPhy:
     def pre_equalization_channel(self, carrier_hz):
         """cl_telecom_system::get_pre_equalization_channel for this mode and carrier (host computation): complex128 [Nc]."""
         out = np.zeros(self.Nc, np.complex128)
-        rc = self.lib.mgpu_host_pre_equalization_channel(C.c_int(self.cfg), C.c_double(carrier_hz), _ptr(out))
-        if rc != 0:
-            raise MgpuError("mgpu_host_pre_equalization_channel failed (%d)" % rc)
+        self._ck(self.lib.mgpu_context_pre_equalization_channel(self.h, C.c_double(carrier_hz), _ptr(out)))
         return out
 
     def set_pre_equalization_channel(self, channel):

@@ -75,6 +75,9 @@ struct morc {
     int cfg, M, bps, K, P, N, max_iters;
     int Nsymb, Nc, Nfft, Ngi, Nofdm, nData, nBits, nPilots, nVirtual, nReal;
     int bit_blk, tf_blk, preamble, estimator, amp_restore, lsw;
+    /* physical_config.cc:30-65 values a caller may override (morc_create_explicit); defaults are the reference's */
+    float boostf;                                  /* ofdm_pilot_configurator_pilot_boost (a float, physical_config.h:53) */
+    unsigned pilot_seed, scrambler_seed, preamble_seed;
     int Cwidth, Vwidth;
     /* MFSK modes (ROBUST_0..2 = cfg 100..102): mfsk.cc:48-162, telecom_system.cc:2968-2989 */
     int mfsk_M, mfsk_nbits, mfsk_nstreams, mfsk_hop, mfsk_off[4];
@@ -161,10 +164,10 @@ static void build_pilots(morc* o) {
     o->nData = Ns * Nc - o->nPilots;
     free(vc);
     /* DBPSK pilot sequence — ofdm.cc:940-951; boost is float 1.33 widened (physical_config.h:53) */
-    float boostf = 1.33;
+    float boostf = o->boostf;
     double boost = boostf;
     o->pilot_seq = malloc(sizeof(cd) * o->nPilots);
-    prng_t p; prng_seed(&p, 0);
+    prng_t p; prng_seed(&p, o->pilot_seed);
     int last = 0;
     for (int i = 0; i < o->nPilots; i++) {
         int pv = (prng_next(&p) % 2) ^ last;
@@ -204,7 +207,7 @@ static void build_preamble(morc* o) {
     for (int j = 25; j < 50; j++) z[j] = zero_bin[j - 25 + 1];
     o->preamble_vals = calloc((size_t)np * Nc, sizeof(cd));
     cd* seq = malloc(sizeof(cd) * np * Nc);
-    prng_t p; prng_seed(&p, 1);
+    prng_t p; prng_seed(&p, o->preamble_seed);
     for (int i = 0; i < np * Nc; i++) {
         /* std::complex<double>(2*(__random()%2)-1, 2*(__random()%2)-1): g++ evaluates the second argument first */
         int b = 2 * (prng_next(&p) % 2) - 1;
@@ -289,6 +292,13 @@ static int explicit_row(int cfg, int* M, int* rate16, int* preamble, int* est) {
 }
 
 morc* morc_create(int cfg, int max_iters, const char* tables_path) {
+    return morc_create_explicit(cfg, max_iters, tables_path, 1.33f, 20, 0u, 0u, 1u);
+}
+
+/* the same with the parameters physical_config.cc:35-65 gives every mode spelled out: pilot boost (float), LS window width = height
+ * (an even value is incremented, telecom_system.cc:2802-2809), pilot / bit-energy-dispersal / preamble PRNG seeds */
+morc* morc_create_explicit(int cfg, int max_iters, const char* tables_path, float pilot_boost, int ls_window, unsigned pilot_seed,
+                           unsigned scrambler_seed, unsigned preamble_seed) {
     int robust = cfg >= 100 && cfg <= 102;                       /* common_defines.h:63-65 */
     int eM, erate, epre, eest;
     int is_explicit = explicit_row(cfg, &eM, &erate, &epre, &eest);
@@ -311,7 +321,8 @@ morc* morc_create(int cfg, int max_iters, const char* tables_path) {
     o->Nc = 50; o->Nfft = 256; o->Ngi = 16; o->Nofdm = 272;
     o->Nsymb = o->M == 2 ? 48 : o->M == 4 ? 24 : o->M == 8 ? 16 : o->M == 16 ? 12 : 9;
     o->bps = o->M == 2 ? 1 : o->M == 4 ? 2 : o->M == 8 ? 3 : o->M == 16 ? 4 : 5;
-    o->lsw = 21;
+    o->lsw = ls_window % 2 == 0 ? ls_window + 1 : ls_window;     /* telecom_system.cc:2802-2809 */
+    o->boostf = pilot_boost; o->pilot_seed = pilot_seed; o->scrambler_seed = scrambler_seed; o->preamble_seed = preamble_seed;
     if (robust) {   /* cl_mfsk::init mfsk.cc:48-78 as called from telecom_system.cc:2900-2907 */
         o->mfsk_M = cfg == 100 ? 32 : 16;
         o->mfsk_nstreams = cfg == 100 ? 1 : 2;
@@ -333,7 +344,7 @@ morc* morc_create(int cfg, int max_iters, const char* tables_path) {
     o->nReal = o->nBits - o->P;
     o->bit_blk = o->nBits / 10; o->tf_blk = o->nData / 10;       /* telecom_system.cc:2910-2911 */
     o->active_nbits = o->nBits;
-    prng_t p; prng_seed(&p, 0);                                  /* telecom_system.cc:1961-1966 */
+    prng_t p; prng_seed(&p, o->scrambler_seed);                  /* telecom_system.cc:1961-1966 */
     for (int i = 0; i < o->N; i++) o->scrambler[i] = prng_next(&p) % 2;
     for (int k = 0; k < 128; k++) {                              /* ofdm.cc:266-271 */
         double angle = -2.0 * M_PI * k / 256;
@@ -812,7 +823,7 @@ void morc_rx(morc* o, const double* baseband_c128, int flags, morc_rx_out* out) 
             amp += sqrt(creal(o->grid[c]) * creal(o->grid[c]) + cimag(o->grid[c]) * cimag(o->grid[c])); n++;
         }
         amp /= n;
-        float boostf = 1.33; double boost = boostf;
+        float boostf = o->boostf; double boost = boostf;
         double agc = boost / amp;
         for (int c = 0; c < G; c++) o->grid[c] = (creal(o->grid[c]) * agc) + (cimag(o->grid[c]) * agc) * I;
         out->agc_gain = agc;
@@ -1219,7 +1230,7 @@ int morc_get_pre_equalization_channel(morc* o, double carrier_hz, double* out_c1
     double t1c[128], t2c[128];
     int n1 = morc_tx_fir_taps(carrier_hz, 0, t1c), n2 = morc_tx_fir_taps(carrier_hz, 1, t2c);
     prng_t rng;
-    prng_seed(&rng, 0);
+    prng_seed(&rng, o->pilot_seed);
     for (int i = 0; i < o->nPilots; i++) (void)prng_next(&rng);
     cd acc[50], mod[50], dem[50];
     cd* sym = malloc(sizeof(cd) * o->Nofdm * 2);

@@ -68,6 +68,9 @@ typedef struct morc_rx_out {
 
 /* tables_path: mercury_ldpc_tables.bin (derived data, see oracle/gen_ldpc_tables.py) */
 morc* morc_create(int cfg, int max_iters, const char* tables_path);
+/* with the parameters physical_config.cc:35-65 gives every mode spelled out (morc_create: 1.33f, 20, 0, 0, 1) */
+morc* morc_create_explicit(int cfg, int max_iters, const char* tables_path, float pilot_boost, int ls_window, unsigned pilot_seed,
+                           unsigned scrambler_seed, unsigned preamble_seed);
 void morc_destroy(morc*);
 void morc_get_info(morc*, morc_info*);
 void morc_set_ctrl_mode(morc*, int enable);         /* cl_telecom_system::set_mfsk_ctrl_mode, telecom_system.cc:1572 */

@@ -130,7 +130,14 @@ static bool explicit_row(int cfg, ModeRow* row) {
     return true;
 }
 
-void* mref_create(int cfg, int max_iters) {
+void* mref_create_explicit(int cfg, int max_iters, float pilot_boost, int ls_window, unsigned pilot_seed, unsigned scrambler_seed,
+                           unsigned preamble_seed);
+void* mref_create(int cfg, int max_iters) { return mref_create_explicit(cfg, max_iters, 1.33f, 20, 0u, 0u, 1u); }
+
+// the same with the values physical_config.cc:35-65 holds for every mode passed in (what load_configuration copies from
+// default_configurations_telecom_system, telecom_system.cc:2772-2811)
+void* mref_create_explicit(int cfg, int max_iters, float pilot_boost, int ls_window, unsigned pilot_seed, unsigned scrambler_seed,
+                           unsigned preamble_seed) {
     const bool robust = cfg >= ROBUST_0 && cfg <= ROBUST_2;   // common_defines.h:63-65
     ModeRow explicit_m = {0, 0, 0, 0};
     const bool is_explicit = explicit_row(cfg, &explicit_m);
@@ -173,20 +180,22 @@ void* mref_create(int cfg, int max_iters) {
     r->ofdm.pilot_configurator.first_col = DATA;
     r->ofdm.pilot_configurator.second_col = DATA;
     r->ofdm.pilot_configurator.last_col = AUTO_SELLECT;
-    float boost = 1.33;  // physical_config.h:53 declares it float
+    float boost = pilot_boost;  // physical_config.h:53 declares it float
     r->ofdm.pilot_configurator.boost = boost;
-    r->ofdm.pilot_configurator.seed = 0;
+    r->ofdm.pilot_configurator.seed = pilot_seed;
     r->ofdm.pilot_configurator.pilot_density = HIGH_DENSITY;
     r->ofdm.preamble_configurator.nIdentical_sections = 2;
     r->ofdm.preamble_configurator.modulation = MOD_QPSK;
     r->ofdm.preamble_configurator.boost = sqrt(2);
-    r->ofdm.preamble_configurator.seed = 1;
+    r->ofdm.preamble_configurator.seed = preamble_seed;
     r->ofdm.freq_offset_ignore_limit = 0.1;
     r->ofdm.start_shift = 1;
     r->ofdm.preamble_papr_cut = 7;
     r->ofdm.data_papr_cut = 10;
-    r->ofdm.LS_window_width = 20 + 1;  // telecom_system.cc:2802-2809 (even -> +1)
-    r->ofdm.LS_window_hight = 20 + 1;
+    r->ofdm.LS_window_width = ls_window;   // telecom_system.cc:2799-2809 (even -> +1)
+    r->ofdm.LS_window_hight = ls_window;
+    if (r->ofdm.LS_window_width % 2 == 0) r->ofdm.LS_window_width++;
+    if (r->ofdm.LS_window_hight % 2 == 0) r->ofdm.LS_window_hight++;
     r->ldpc.standard = MERCURY;
     r->ldpc.framesize = MERCURY_NORMAL;
     r->ldpc.decoding_algorithm = SPA;
@@ -231,7 +240,7 @@ void* mref_create(int cfg, int max_iters) {
     r->nBits = r->nData * r->bps;
     r->preamble_nsymb = m.preamble;
     // telecom_system.cc:1961-1966
-    __srandom(0);
+    __srandom(scrambler_seed);
     for (int i = 0; i < r->ldpc.N; i++) r->scrambler[i] = __random() % 2;
     // telecom_system.cc:2910-2911
     r->bit_blk = r->nBits / 10;

@@ -238,8 +238,51 @@ def main_sync():
     print("wrote golden_sync.json")
 
 
+# Explicit parameter sets (mgpu_create_explicit / morc_create_explicit): values physical_config.cc:35-65 holds for every mode, varied.
+EXPLICIT_CASES = [
+    # (cfg, parameters)
+    (8, dict(pilot_boost=1.7, ls_window=9, pilot_seed=5, scrambler_seed=7, preamble_seed=3)),
+    (0, dict(pilot_boost=1.0, ls_window=4, pilot_seed=11, scrambler_seed=0, preamble_seed=1)),
+    (13, dict(pilot_boost=1.33, ls_window=14, pilot_seed=0, scrambler_seed=123456, preamble_seed=99)),
+    (16, dict(pilot_boost=2.5, ls_window=20, pilot_seed=77, scrambler_seed=1, preamble_seed=2)),      # ZF estimator: the window is unused
+    (4, dict(pilot_boost=0.8, ls_window=1, pilot_seed=3, scrambler_seed=9, preamble_seed=4)),          # a window of one cell
+]
+
+
+def explicit_case(lib, cfg, x, idx):
+    """One explicit parameter set through `lib` (RefLib or Oracle): tables, the RX chain's outputs on two frames, one transmitted frame."""
+    gen = oraclelib.Oracle(cfg, 50, explicit=x)      # input generator (its frames carry the set's pilots / scrambler)
+    o = lib(cfg, 50, explicit=x)
+    rec = {"cfg": cfg, "params": x, "ls_window": o.ls_window, "pilot_seq": digest(o.pilot_seq()), "scrambler": digest(o.scrambler().astype(np.uint8)),
+           "frames": []}
+    op = OPERATING_ESN0[cfg]
+    for k, snr in enumerate((op + 1.0, 40.0)):
+        bb, pl = gen.gen_frame(SEED, 5000 + 10 * idx + k, oraclelib.noise_amp_for(snr), 0)
+        fr = {"frame": 5000 + 10 * idx + k, "esn0_db": snr, "input_sha256": digest(bb), "variants": {}}
+        for vname, flags in (("baseband_test", oraclelib.FLAGS_BASEBAND_TEST), ("receive_byte", oraclelib.FLAGS_RECEIVE_BYTE)):
+            r = o.rx(bb, flags)
+            fr["variants"][vname] = {"iterations": int(r["iterations"]), "crc": int(r["crc"]), "variance_f": float(r["variance_f"]).hex(),
+                                     "sha256": {q: digest(r[q]) for q in ("grid", "H", "eq", "syms", "llr_demod", "llr_ldpc", "bytes")}}
+        if k == 0:
+            fr["tx_sha256"] = digest(o.tx(o.payload_to_bits(pl), 1))
+        rec["frames"].append(fr)
+    if cfg != 16:
+        rec["pre_equalization_channel"] = digest(o.get_pre_equalization_channel(oraclelib.CARRIER))
+    return rec
+
+
+def main_explicit():
+    assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
+    out = [explicit_case(oraclelib.RefLib, cfg, x, i) for i, (cfg, x) in enumerate(EXPLICIT_CASES)]
+    with open(os.path.join(HERE, "golden_explicit.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote golden_explicit.json")
+
+
 if __name__ == "__main__":
-    if "--tx" in sys.argv:
+    if "--explicit" in sys.argv:
+        main_explicit() # explicit parameter sets (SURVEY.md §8b: boost, LS window, seeds)
+    elif "--tx" in sys.argv:
         main_tx()       # transmit_byte (SURVEY.md §8 row f4, the TX mirror up to the audio samples)
     elif "--sync" in sys.argv:
         main_sync()     # synchroniser blocks (SURVEY.md §8 row f1) and the MFSK sync / ACK detector

@@ -145,15 +145,23 @@ class _Base:
         return res
 
 
+# physical_config.cc:35-65: what every mode gets unless a context overrides it (mgpu_create_explicit / morc_create_explicit)
+EXPLICIT_DEFAULTS = dict(pilot_boost=1.33, ls_window=20, pilot_seed=0, scrambler_seed=0, preamble_seed=1)
+
+
 class Oracle(_Base):
     prefix = "morc_"
 
-    def __init__(self, cfg, max_iters=50):
+    def __init__(self, cfg, max_iters=50, explicit=None):
+        """explicit: dict(pilot_boost, ls_window, pilot_seed, scrambler_seed, preamble_seed) overriding physical_config.cc:35-65"""
         if not os.path.exists(ORACLE_SO):
             build_oracle()
         self.lib = C.CDLL(ORACLE_SO)
-        self.lib.morc_create.restype = C.c_void_p
-        h = self.lib.morc_create(C.c_int(cfg), C.c_int(max_iters), TABLES.encode())
+        self.lib.morc_create_explicit.restype = C.c_void_p
+        x = dict(EXPLICIT_DEFAULTS)
+        x.update(explicit or {})
+        h = self.lib.morc_create_explicit(C.c_int(cfg), C.c_int(max_iters), TABLES.encode(), C.c_float(x["pilot_boost"]), C.c_int(x["ls_window"]),
+                                          C.c_uint(x["pilot_seed"]), C.c_uint(x["scrambler_seed"]), C.c_uint(x["preamble_seed"]))
         if not h:
             raise RuntimeError("morc_create failed")
         self.h = C.c_void_p(h)
@@ -255,10 +263,13 @@ class RefLib(_Base):
     def available():
         return os.path.exists(REF_SO)
 
-    def __init__(self, cfg, max_iters=50):
+    def __init__(self, cfg, max_iters=50, explicit=None):
         self.lib = C.CDLL(REF_SO)
-        self.lib.mref_create.restype = C.c_void_p
-        self.h = C.c_void_p(self.lib.mref_create(C.c_int(cfg), C.c_int(max_iters)))
+        self.lib.mref_create_explicit.restype = C.c_void_p
+        x = dict(EXPLICIT_DEFAULTS)
+        x.update(explicit or {})
+        self.h = C.c_void_p(self.lib.mref_create_explicit(C.c_int(cfg), C.c_int(max_iters), C.c_float(x["pilot_boost"]), C.c_int(x["ls_window"]),
+                                                          C.c_uint(x["pilot_seed"]), C.c_uint(x["scrambler_seed"]), C.c_uint(x["preamble_seed"])))
         self.max_iters = max_iters
         self._init_info()
 

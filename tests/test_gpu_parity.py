@@ -3,6 +3,8 @@
 Bar (BASELINE.json north_star): bit-exact interleaver indexing / hard decisions / CRC / payload;
 soft LLRs within 1e-5 (absolute, scaled by max(1,|LLR|) as SURVEY.md §7.3-2 specifies).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -130,6 +132,70 @@ def test_explicit_configurations_match_oracle(M, rate16, pre, est, esn0):
             assert r["stats"]["message_decoded"][0] == ref_r["message_decoded"] == 1
             assert np.array_equal(r["payload"][0][: rx.payload_bytes], msg[0]) and r["stats"]["delay"][0] == ref_r["delay"]
         rx.close()
+
+
+def _explicit_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg.EXPLICIT_CASES
+
+
+@pytest.mark.parametrize("cfg,x", _explicit_cases())
+def test_explicit_parameters_match_oracle(cfg, x):
+    """mgpu_create_explicit (pilot boost, LS window, PRNG seeds of physical_config.cc:35-65 varied): every stage of the span,
+    the synthetic generator, the transmit chain and the pre-equalization channel against the oracle configured the same way, which
+    tests/golden/golden_explicit.json pins to the reference's classes (tests/test_oracle_golden.py)."""
+    orc = Oracle(cfg, 50, explicit=x)
+    op = OPERATING_ESN0[cfg]
+    snrs = [op, op + 1.0, op - 1.5, -15.0, 60.0]
+    bb, payloads = _frames(orc, snrs)
+    for agc, vs, flags in _variants(cfg):
+        rx = _rx(cfg, max_iters=50, agc=agc, variance_source=vs, max_batch=len(snrs), explicit=x)
+        assert rx.ls_window == orc.ls_window
+        out = rx.receive(bb, taps=True)
+        exact = EXACT_TRIG or not orc.amp_restore
+        for f in range(len(snrs)):
+            ref = orc.rx(bb[f], flags)
+            for key in ("grid", "H", "eq", "syms"):
+                d, scale = np.abs(out[key][f] - ref[key]).max(), np.abs(ref[key]).max()
+                assert d <= (0.0 if exact or key == "grid" else 1e-12) * scale, (cfg, flags, f, key, d, scale)
+            if exact and np.isfinite(ref["variance"]):
+                assert out["variance"][f] == ref["variance"], (cfg, f)
+                assert np.array_equal(out["llr_ldpc"][f], ref["llr_ldpc"], equal_nan=True), (cfg, flags, f, "llr_ldpc")
+            assert _llr_close(out["llr_ldpc"][f], ref["llr_ldpc"]).all(), (cfg, flags, f, "llr_ldpc")
+            assert out["stats"]["iterations_done"][f] == ref["iterations"], (cfg, flags, f, "iterations")
+            assert np.array_equal(out["payload"][f], ref["bytes"].astype(np.uint8)), (cfg, flags, f, "payload")
+            assert (out["stats"]["crc"][f], out["stats"]["all_zeros"][f]) == (ref["crc"], ref["all_zeros"]), (cfg, flags, f)
+        assert np.array_equal(out["payload"][4][: orc.payload_bytes], payloads[4].astype(np.uint8))      # the noiseless frame comes back
+        if agc:
+            import torch
+            # the device generator builds frames with this set's pilots and scrambler
+            dbb = torch.empty((2, rx.frame_samples, 2), dtype=torch.float64, device="cuda:0")
+            dpl = torch.empty((2, rx.payload_stride), dtype=torch.uint8, device="cuda:0")
+            rx.txgen_dev(SEED, 40, 2, noise_amp_for(op + 1.0), dbb.data_ptr(), dpl.data_ptr())
+            torch.cuda.synchronize()
+            for k in range(2):
+                want_bb, want_pl = orc.gen_frame(SEED, 40 + k, noise_amp_for(op + 1.0), 0)
+                got = dbb[k].cpu().numpy().view(np.complex128).reshape(-1)
+                assert np.abs(got - want_bb).max() <= 1e-9 * np.abs(want_bb).max()
+                assert np.array_equal(dpl[k].cpu().numpy()[: orc.payload_bytes], want_pl.astype(np.uint8))
+            # transmit_byte: this set's preamble, pilots, scrambler and pre-equalization channel, down to the audio samples
+            assert rx.pre_equalization_channel(oraclelib.CARRIER).tobytes() == orc.get_pre_equalization_channel(oraclelib.CARRIER).tobytes()
+            msg = np.random.default_rng(cfg).integers(0, 256, (1, rx.payload_bytes), dtype=np.uint8)
+            assert np.array_equal(rx.transmit_byte(msg, oraclelib.CARRIER)[0], orc.transmit_byte(msg[0].astype(np.int32)))
+        rx.close()
+
+
+def test_explicit_parameters_are_checked():
+    from mercury_amd.physical_layer import MgpuError
+    for bad in (dict(Nc=64), dict(Nfft=512), dict(Dy=4), dict(ls_window=23), dict(pilot_boost=-1.0)):
+        with pytest.raises(MgpuError):
+            _rx(8, explicit=bad)
+    rx = _rx(8, explicit=dict(Nc=50, Nfft=256, Dx=1, Dy=3))       # the reference's geometry spelled out = the defaults
+    assert rx.ls_window == 21
+    rx.close()
 
 
 @pytest.mark.parametrize("cfg", [0, 3, 5, 8, 9, 12])

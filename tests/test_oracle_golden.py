@@ -141,3 +141,18 @@ def test_sync_blocks_match_reference_vectors(cfg):
     want = json.load(open(os.path.join(HERE, "golden", "golden_sync.json")))[str(cfg)]
     got = json.loads(json.dumps(mg.sync_case(oraclelib.Oracle(cfg), cfg)))          # same code path, the oracle as `lib`
     assert got == want
+
+
+# ---- explicit parameter sets (physical_config.cc:35-65 varied): fixtures from tests/golden/make_golden.py --explicit -------------
+def test_explicit_parameter_sets_match_reference_vectors():
+    """morc_create_explicit against the compiled reference configured the same way (pilot boost, LS window, pilot / scrambler /
+    preamble seeds): tables, every RX stage in both variants, a transmitted frame, the pre-equalization channel."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(HERE, "golden", "golden_explicit.json")))
+    assert len(want) == len(mg.EXPLICIT_CASES)
+    for i, (cfg, x) in enumerate(mg.EXPLICIT_CASES):
+        got = json.loads(json.dumps(mg.explicit_case(oraclelib.Oracle, cfg, x, i), sort_keys=True))
+        assert got == want[i], (cfg, [k for k in got if got[k] != want[i].get(k)])
