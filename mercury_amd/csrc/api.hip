@@ -94,7 +94,7 @@ void ctx_alloc(mgpu_ctx* c) {
         l.crc_init = zero;
     }
     l.gdesc = c->keep(upload(t.graph.gdesc));
-    l.gkind = c->keep(upload(t.graph.gkind));
+    l.gkpack = c->keep(upload(t.graph.gkpack));
     l.vinfo_g = c->keep(upload(t.graph.vinfo_g));
     l.Sg = t.graph.Sg;
     l.sadr = c->keep(upload(t.graph.sadr));

@@ -47,8 +47,8 @@ struct LdpcDev {
     const uint8_t* scrambler;
     const uint16_t* crc_tab;   // [nReal/8][8] what message bit 8b+j set contributes to the CRC register after nReal/8 bytes (ldpc.hip: decode_tail)
     uint32_t crc_init;         // the register after nReal/8 zero bytes
-    // fp32 decoders (sum-product and min-sum), grouped layout (tables.hpp: LdpcGraph::gdesc / gkind / vinfo_g)
-    const uint32_t* gdesc; const uint32_t* gkind; const uint32_t* vinfo_g;
+    // fp32 decoders (sum-product and min-sum), grouped layout (tables.hpp: LdpcGraph::gdesc / gkpack / vinfo_g)
+    const uint32_t* gdesc; const uint64_t* gkpack; const uint32_t* vinfo_g;
     int Sg;
     // fp64 sum-product kernel (tables.hpp: LdpcGraph::sadr / bhead / bmask / vinfo2)
     const uint32_t* sadr;    // [(NE+1)*1024][2] LDS byte offset of the slot's posterior, LDS byte address of the first message of the slot's check

@@ -428,8 +428,10 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         if (i < N) Lt[i] = llr_in[size_t(f) * N + i];
     }
     const uint32_t* __restrict__ gdesc = T.gdesc;
-    typedef const uint32_t __attribute__((address_space(4))) * cptr32;
-    const cptr32 gkind = (cptr32)(T.gkind) + __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the group sizes of the wavefront's bins, 3 bits per round, in one scalar register pair (a scalar load per round put its latency
+    // at the head of every bin)
+    typedef const uint64_t __attribute__((address_space(4))) * cptr64;
+    const uint64_t kpack = ((cptr64)(T.gkpack))[__builtin_amdgcn_readfirstlane(tid >> 6)];
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
     float li[kRows];
@@ -453,7 +455,7 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
 #pragma unroll 1
         for (int r = 0; r < NE; ++r) {
             const uint32_t kn = gdesc[(r + 1) * THREADS + tid];
-            const uint32_t kind = gkind[r * 8];
+            const uint32_t kind = uint32_t(kpack >> (3 * r)) & 7u;
             const float lt = Lt[k & 0x7ff];
             if (!unsat && kind) unsat = groups_unsat(__ballot(lt < 0 && int32_t(k) < 0), kind);
             k = kn;
@@ -470,7 +472,7 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
 #pragma unroll 1
         for (int r = 0; r < NE; ++r, slot += THREADS) {
             const uint32_t kn = gdesc[(r + 1) * THREADS + tid];
-            const uint32_t kind = gkind[r * 8];
+            const uint32_t kind = uint32_t(kpack >> (3 * r)) & 7u;
             if (kind == 0) { k = kn; continue; }                     // an empty bin (only in the last round)
             const bool valid = int32_t(k) < 0;
             const float lt = Lt[k & 0x7ff];                          // padding lanes read variable 0

@@ -212,11 +212,14 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
             const size_t bins = kinds.size(), rounds = (bins + 7) / 8;
             g.Sg = int(bins) * 64;
             if (g.Sg >= 65536) throw std::runtime_error("grouped layout exceeds the 16-bit slot index of the variable records");
+            if (rounds > 21) throw std::runtime_error("grouped layout exceeds the 21 rounds whose group sizes fit one 64-bit word per wavefront");
             g.gdesc.assign((rounds + 1) * 512, 0u);
             g.gkind.assign((rounds + 1) * 8, 0u);
+            g.gkpack.assign(8, 0ull);
             std::vector<uint32_t> gslot_of_edge(E);
             for (size_t b = 0; b < bins; ++b) {
                 g.gkind[b] = kinds[b];
+                g.gkpack[b & 7] |= uint64_t(kinds[b]) << (3 * (b >> 3));
                 const uint32_t gsz = 1u << kinds[b];
                 for (size_t q = 0; q < bin_checks[b].size(); ++q) {
                     const uint32_t c = bin_checks[b][q], base = uint32_t(b) * 64 + uint32_t(q) * gsz;

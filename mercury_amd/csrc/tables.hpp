@@ -53,6 +53,7 @@ struct LdpcGraph {
     int Sg = 0;                    // slots = 64 * bins
     std::vector<uint32_t> gdesc;   // [(rounds+1)*512] per slot: 0x80000000 | variable, 0 for padding lanes (rounds of 8 bins: 512-thread workgroups)
     std::vector<uint32_t> gkind;   // [(rounds+1)*8] per bin: log2 of its group size (1..6), 0 for an empty bin
+    std::vector<uint64_t> gkpack;  // [8] per wavefront w: gkind[w + 8 r] in bits 3r .. 3r+2 (at most 21 rounds): one scalar register pair per wavefront
     std::vector<uint32_t> vinfo_g; // [N][8] like vinfo, slot indices in the grouped layout
     // the fp64 sum-product kernel's own tables (ldpc.hip, spa_decode): LDS byte offsets instead of indices, and the
     // product walk's execution masks tabulated per bin and step instead of compared per lane
