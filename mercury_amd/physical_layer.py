@@ -704,15 +704,20 @@ class RxPool:
         return int(self.lib.mgpu_receive_buffer_nsymb(self._ctx0)) * self.Nofdm * 4
 
     def receive_byte(self, passband, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1, state=None,
-                     coarse_freq_sync=0):
-        x = np.ascontiguousarray(passband, np.float64)
-        x = x.reshape(1, -1) if x.ndim == 1 else x
-        W = x.shape[0]
+                     coarse_freq_sync=0, W=None):
+        """passband: float64 [W, buffer samples] in host memory, or (with W given) a raw device pointer when every context of the pool
+        sits on the device that holds the windows (contexts time-sharing one GPU)."""
+        if W is None:
+            x = np.ascontiguousarray(passband, np.float64)
+            x = x.reshape(1, -1) if x.ndim == 1 else x
+            W, src = x.shape[0], _ptr(x)
+        else:
+            src = C.c_void_p(passband)
         cfg = ReceiveConfig(carrier_hz, trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync)
         st = np.zeros(W, LINK_STATE_DTYPE) if state is None else np.ascontiguousarray(state, LINK_STATE_DTYPE)
         if state is None:
             st["delay_of_last_decoded_message"] = -1
         payload = np.zeros((W, self.payload_stride), np.uint8)
         stats = np.zeros(W, RECEIVE_STATS_DTYPE)
-        self._ck(self.lib.mgpu_pool_receive_byte_batch(self.h, _ptr(x), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
+        self._ck(self.lib.mgpu_pool_receive_byte_batch(self.h, src, C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
         return {"payload": payload, "stats": stats, "state": st}
