@@ -132,6 +132,32 @@ int main(int argc, char** argv) {
             }
             std::vector<int> too_long(pb + 1, 0);
             if (phy.transmit_byte(too_long.data(), pb + 1, audio.data(), MGPU_SINGLE_MESSAGE)) return 5;     // "message too long.. not sent."
+            // default_configurations_telecom_system (physical_config.cc:35-65), set before load_configuration like the reference's callers do:
+            // another pilot boost / LS window / seeds give another waveform, and a receiver configured the same way takes it back
+            if (cfg < 100 && argc >= 8 && atoi(argv[7]) > 0) {
+                mgpu::cl_rx_phy other;
+                other.default_configurations_telecom_system.ofdm_pilot_configurator_pilot_boost = 1.7f;
+                other.default_configurations_telecom_system.ofdm_LS_window_width = 10;
+                other.default_configurations_telecom_system.ofdm_pilot_configurator_seed = 5;
+                other.default_configurations_telecom_system.bit_energy_dispersal_seed = 7;
+                other.default_configurations_telecom_system.ofdm_preamble_configurator_seed = 3;
+                other.load_configuration(cfg);
+                if (other.info.ls_window != 11) return 11;
+                std::vector<double> a2(total);
+                if (!other.transmit_byte(&msgs[0], pb, a2.data(), MGPU_SINGLE_MESSAGE)) return 12;
+                std::vector<double> a1(total);
+                if (!phy.transmit_byte(&msgs[0], pb, a1.data(), MGPU_SINGLE_MESSAGE)) return 12;
+                if (a1 == a2) return 13;
+                const int nw = other.capture_window_samples();
+                std::vector<double> win(nw, 0.0);
+                for (int i = 0; i < total && 20000 + i < nw; ++i) win[20000 + i] = a2[i];
+                std::vector<int> got(pb, -1);
+                const mgpu::st_receive_stats st2 = other.receive_byte(win.data(), got.data());
+                if (!st2.message_decoded) return 14;
+                for (int j = 0; j < pb; ++j) if (got[j] != (msgs[j] & 0xff)) return 15;
+                const mgpu::st_receive_stats st1 = phy.receive_byte(win.data(), got.data());     // the default receiver must not take it
+                if (st1.message_decoded) return 16;
+            }
             // 4c) the signalling calls the ARQ layer makes: ACK pattern out and back in, signal level, control-frame mode
             const int n = phy.capture_window_samples(), na = phy.ack_pattern_passband_samples();
             std::vector<double> buf(n, 0.0), ack(na);
