@@ -290,6 +290,46 @@ def test_spa_fast_agrees_with_oracle_where_both_converge(cfg):
     assert both >= ref_ok - 1 and both >= 8
 
 
+@pytest.mark.parametrize("max_iters", [1, 2, 5, 50])
+def test_fast_decoders_keep_the_iteration_count_convention(max_iters):
+    """cl_ldpc::decode's return value (ldpc_decoder_SPA.cc:25-218): 0 = the input already was a codeword, k = converged after k iterations,
+    max+1 = never. The fp32 decoders test the syndrome inside every check pass (one pass more than iterations, no syndrome-only pass): at
+    every max_iters their counts must stay in 0..max+1, be the fp64 decoder's on almost every frame (the arithmetic differs, so a frame
+    may converge one iteration earlier or later), and a frame they report as converged must carry a CRC-clean payload as often as the
+    reference decoder's does."""
+    import torch
+    from mercury_amd import DEC_MINSUM, DEC_SPA, DEC_SPA_FAST
+    cfg, F = 8, 1024
+    rx = {n: _rx(cfg, decoder=d, max_iters=max_iters, max_batch=F) for n, d in (("spa", DEC_SPA), ("fast", DEC_SPA_FAST), ("minsum", DEC_MINSUM))}
+    st = torch.cuda.current_stream().cuda_stream
+    bb = torch.empty((F, rx["spa"].frame_samples, 2), dtype=torch.float64, device="cuda")
+    for esn0 in (OPERATING_ESN0[cfg] + 1.0, 40.0):
+        rx["spa"].txgen_dev(SEED, 99 << 20, F, noise_amp_for(esn0), bb.data_ptr(), None, stream=st)
+        torch.cuda.synchronize()
+        res = {}
+        for n, phy in rx.items():
+            payload = torch.zeros((F, phy.payload_stride), dtype=torch.uint8, device="cuda")
+            stats = torch.zeros((F, 6), dtype=torch.int32, device="cuda")
+            phy.receive_dev(bb.data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=st)
+            torch.cuda.synchronize()
+            res[n] = stats.cpu().numpy()
+        it_ref = res["spa"][:, 0]
+        assert it_ref.min() >= 0 and it_ref.max() <= max_iters + 1
+        if esn0 == 40.0:
+            assert (it_ref == 0).all()                              # noiseless: already a codeword
+        for n in ("fast", "minsum"):
+            it = res[n][:, 0]
+            assert it.min() >= 0 and it.max() <= max_iters + 1, (n, max_iters)
+            if esn0 == 40.0:
+                assert (it == 0).all(), (n, max_iters)
+            if n == "fast":
+                assert (np.abs(it - it_ref) <= 1).mean() >= 0.99 and (it == it_ref).mean() >= 0.9, (max_iters, esn0, (it == it_ref).mean())
+            conv = it <= max_iters
+            assert (res[n][conv, 3] != 0).all(), (n, max_iters)    # converged on a codeword: the CRC of a mode-8 frame at this SNR holds
+    for phy in rx.values():
+        phy.close()
+
+
 @pytest.mark.parametrize("cfg", list(range(17)) + [100, 101, 102])
 def test_spa_fast_decode_rate_matches_reference_decoder(cfg):
     """on every mode, at its operating point and 1.5 dB below (inside the waterfall), the fp32
