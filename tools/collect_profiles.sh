@@ -74,5 +74,10 @@ if [ "$1" = "sweep" ]; then
   python bench.py --cfg 100 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_fast_cfg100.json" 2>/dev/null
   python bench.py --cfg 0 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_fast_cfg0.json" 2>/dev/null
   python bench.py --cfg 0 --decoder spa --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_cfg0.json" 2>/dev/null
+  # BASELINE.json configs[4] on one GPU: decoder-only, rate 8/16 (mode 13's code), noise-only LLRs so that every codeword runs all its iterations
+  : > "$OUT/${R}_bench_ldpc_only_rate8.jsonl"
+  for dec in spa spa_fast minsum; do for it in 5 20 50; do
+    python bench.py --ldpc-only --cfg 13 --iters $it --decoder $dec --no-cpu-baseline --no-extras --steps 20 2>/dev/null | tail -1 >> "$OUT/${R}_bench_ldpc_only_rate8.jsonl"
+  done; done
 fi
 ls -la "$OUT"
