@@ -245,7 +245,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         }
         Lt[v] = s;
     };
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = LDPC_THREADS / 64; flag[3] = LDPC_THREADS / 64; }
     __syncthreads();
 
     auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
@@ -281,21 +281,27 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             if (!unsat) unsat = bin_unsat(__ballot(lt[r] < 0) & vmask[r], ends[r]);
         if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
+    // The check pass. Bins are handed out on demand: wavefront w starts with bin w, every further bin goes to whoever asks first (a counter
+    // in LDS, asked for while the current bin is being worked on). The hardware issues the oldest wavefront of a SIMD first, so with a
+    // fixed split (bin w + 16 r in round r: rounds 1-2) the first wavefronts of a workgroup finish long before the last ones and wait at the
+    // barrier: -0.4 % at rate 6/16 (89 bins), -3.6 % at rate 14/16 (116 bins: 7.25 per wavefront). Which wavefront works a bin does not
+    // change a bit of its arithmetic.
     auto cn_pass = [&](bool with_syndrome, int p) {
         bool unsat = false;
-        spa_u32x2 ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, tid * 8, 0, 0);
-        uint32_t own = kMoff + tid * 8;                                // LDS address of this lane's slot in round r
-        spa_cptr64 bm = (spa_cptr64)(T.bmask) + size_t(wave) * T.DM;
-        const size_t bm_step = size_t(16) * T.DM;
-        spa_cptr64 bh = bhead0;
-        unsigned long long vmask = bh[0], ends = bh[1];
+        const int nbins = T.S >> 6;
+        const uint32_t lane8 = (tid & 63) * 8;
+        int b = wave;
+        spa_u32x2 ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, lane8, b * 512, 0);
+        int* ctr = &flag[2 + (p & 1)];
 #pragma unroll 1
-        for (int r = 0; r < NE; ++r, own += LDPC_THREADS * 8, bm += bm_step) {
+        while (b < nbins) {
+            int nxt = 0;
+            if ((tid & 63) == 0) nxt = atomicAdd(ctr, 1);
             const uint32_t alt = ad.x, achk = ad.y;
-            const unsigned long long vm = vmask, en = ends;
-            bh += 64;
-            vmask = bh[0]; ends = bh[1];                              // next round's bin (the table has one spare round)
-            if (vm == 0) continue;                                    // an empty bin: only in the last round, nothing follows it
+            const uint32_t own = kMoff + lane8 + uint32_t(b) * 512u;
+            spa_cptr64 bh = (spa_cptr64)(T.bhead) + size_t(b) * 4;
+            spa_cptr64 bm = (spa_cptr64)(T.bmask) + size_t(b) * T.DM;
+            const unsigned long long vm = bh[0], en = bh[1];
             const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
             double lt;
             if (valid) lt = *ldsd(alt);
@@ -311,12 +317,14 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             double temp = 1;
             if constexpr (DMX > 16) spa_walk4<0, DMX / 4>(temp, achk, bm, bm[0], bm[1], bm[2], bm[3]);
             else spa_walk<0, DMX / 2>(temp, achk, bm, bm[0], bm[1]);
-            // the next round's addresses land in the registers this round is done with, behind the atanh (the table has a spare round)
-            ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, tid * 8, (r + 1) * kRound, 0);
+            // the next bin's addresses land in the registers this one is done with, behind the atanh
+            nxt = __builtin_amdgcn_readfirstlane(nxt);
+            ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, lane8, (nxt < nbins ? nxt : nbins) * 512, 0);      // (the table has a spare round)
             double rr;
             if (valid) rr = spa_atanh_x2(temp);
             __builtin_amdgcn_wave_barrier();
             if (valid) *ldsd(own) = rr;
+            b = nxt;
         }
         if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
@@ -342,7 +350,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
                 if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
                 if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
             }
-            if (tid == 0) flag[it & 1] = 0;
+            if (tid == 0) { flag[it & 1] = 0; flag[2 + (it & 1)] = LDPC_THREADS / 64; }
             var_update(va);
 #if SPA_VR_RESIDENT
             if (tid + LDPC_THREADS < N) var_update4(vb.x, vb.y, vb.z);
