@@ -24,7 +24,11 @@ HEADERS = ["device_tables.h", "tables.hpp", "spa_math.h", "fft256.h", "fe_math.h
 
 # -ffp-contract=off: the reference runs without FMA contraction (baseline x86-64); the FP64 front-end
 # and the sum-product decoder reproduce its roundings exactly, which an fma() would break.
+# -amdgpu-atomic-optimizer-strategy=None: the kernels' few LDS atomics are issued by one lane of a wavefront (the decoder's bin counter,
+# the front-end's work queue); the optimiser's wave-reduction around them (mbcnt, bcnt, readfirstlane, add and a wait right behind the
+# atomic) is eight vector instructions and an exposed LDS round trip per call for nothing.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
                "-Wno-unused-result", "-Wno-deprecated-declarations"]
 
 

@@ -293,18 +293,19 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         int b = wave;
         spa_u32x2 ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, lane8, b * 512, 0);
         int* ctr = &flag[2 + (p & 1)];
+        const spa_cptr64 bh0 = (spa_cptr64)(T.bhead);
+        unsigned long long vm = bh0[size_t(b) * 4], en = bh0[size_t(b) * 4 + 1];
 #pragma unroll 1
         while (b < nbins) {
-            int nxt = 0;
-            if ((tid & 63) == 0) nxt = atomicAdd(ctr, 1);
             const uint32_t alt = ad.x, achk = ad.y;
             const uint32_t own = kMoff + lane8 + uint32_t(b) * 512u;
-            spa_cptr64 bh = (spa_cptr64)(T.bhead) + size_t(b) * 4;
             spa_cptr64 bm = (spa_cptr64)(T.bmask) + size_t(b) * T.DM;
-            const unsigned long long vm = bh[0], en = bh[1];
             const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
             double lt;
             if (valid) lt = *ldsd(alt);
+            int nxt;                                                   // the next bin, asked for behind this bin's first read
+            SPA_UNDEF(nxt);                                            // (only lane 0's value is ever looked at)
+            if ((tid & 63) == 0) nxt = atomicAdd(ctr, 1);
             // one odd check settles the pass, so the wave's later bins skip the test: the ballot -> prefix-XOR chain is a dependent run of
             // scalar instructions on the bin's critical path (6.27 -> 6.06 ms per 4096 x 50 on the headline, where the first bin settles it)
             if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vm, en);
@@ -317,9 +318,11 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             double temp = 1;
             if constexpr (DMX > 16) spa_walk4<0, DMX / 4>(temp, achk, bm, bm[0], bm[1], bm[2], bm[3]);
             else spa_walk<0, DMX / 2>(temp, achk, bm, bm[0], bm[1]);
-            // the next bin's addresses land in the registers this one is done with, behind the atanh
+            // the next bin's addresses and lane masks land in the registers this one is done with, behind the atanh (the tables have a spare round)
             nxt = __builtin_amdgcn_readfirstlane(nxt);
-            ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, lane8, (nxt < nbins ? nxt : nbins) * 512, 0);      // (the table has a spare round)
+            const int nb = nxt < nbins ? nxt : nbins;
+            ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, lane8, nb * 512, 0);
+            vm = bh0[size_t(nb) * 4]; en = bh0[size_t(nb) * 4 + 1];
             double rr;
             if (valid) rr = spa_atanh_x2(temp);
             __builtin_amdgcn_wave_barrier();

@@ -9,7 +9,7 @@ mkdir -p mercury_amd/_variants
 B=mercury_amd/_build
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Wno-deprecated-declarations $flags -I mercury_amd/csrc -c mercury_amd/csrc/ldpc.hip -o $B/ldpc.$name.o &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None -Wno-unused-result -Wno-deprecated-declarations $flags -I mercury_amd/csrc -c mercury_amd/csrc/ldpc.hip -o $B/ldpc.$name.o &
 done
 wait
 for spec in "$@"; do
