@@ -139,14 +139,17 @@ int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out);
  * even value is incremented as telecom_system.cc:2802-2809 does; 1..21 cells — the front-end reads at most 7 pilots of a window
  * row) and, when seeds_set != 0, the three PRNG seeds (ofdm_pilot_configurator_seed 0, bit_energy_dispersal_seed 0,
  * ofdm_preamble_configurator_seed 1; seed 0 means 1 to __srandom, os_interop.cc:251). They act on the RX path, the synthetic
- * generator and the transmit chain alike. Nc / Nfft / Dx / Dy must be 0 or the reference's 50 / 256 / 1 / 3: the kernels are
- * specialised for that carrier geometry and pilot lattice (MGPU_ERR_UNSUPPORTED otherwise). params == NULL: mgpu_create. */
+ * generator and the transmit chain alike.
+ * FIXED, not parameters: the carrier geometry Nc = 50, Nfft = 256 (Ngi = 16, Nofdm = 272) and the pilot lattice Dx = 1, Dy = 3 —
+ * physical_config.cc:35-65 gives all 17 modes these values and the kernels are specialised for them. The four fields exist only so
+ * that a caller holding the reference's configuration can have it confirmed: 0 or exactly 50 / 256 / 1 / 3 is accepted, anything
+ * else returns MGPU_ERR_UNSUPPORTED before any device work. params == NULL: mgpu_create. */
 typedef struct mgpu_explicit_params {
     float pilot_boost;
     int ls_window;
     int seeds_set;
     unsigned pilot_seed, scrambler_seed, preamble_seed;
-    int Nc, Nfft, Dx, Dy;
+    int Nc, Nfft, Dx, Dy;      /* fixed at 50 / 256 / 1 / 3 (0 = unspecified); see above */
 } mgpu_explicit_params;
 int mgpu_create_explicit(const mgpu_config* cfg, const mgpu_explicit_params* params, mgpu_ctx** out);
 void mgpu_destroy(mgpu_ctx* ctx);
@@ -176,11 +179,14 @@ int mgpu_ldpc_batch(mgpu_ctx* ctx, const float* llr, int F, uint8_t* bits, int* 
  *   which only every `step`-th is a candidate metric) on the candidate metrics alone, as the synchroniser entry points use it.
  * mgpu_host_fir_taps: the filters the library designs (cl_FIR::design, fir_filter.cc:45-162): which 0 = FIR_rx_time_sync,
  *   1 = FIR_rx_data, 2 = FIR_tx1, 3 = FIR_tx2 (the transmit filters depend on the carrier). taps: room for 128 doubles.
- * mgpu_host_preamble_carriers: the mode's preamble symbols in the carrier domain, [n_symbols][50] complex128. */
+ * mgpu_host_preamble_carriers: the mode's preamble symbols in the carrier domain, [n_symbols][50] complex128.
+ * mgpu_host_mode_info: what mgpu_get_info reports for a mode — cl_telecom_system::load_configuration's row and the sizes init()
+ *   derives from it (telecom_system.cc:2487-3025, :1818-1826, :2910-2911) — from the same host-side table builder mgpu_create runs. */
 int mgpu_host_select_peak(const double* cand_vals, int ncand, int step, int size, int location_to_return, int nTrials_max, int* delay,
                           double* correlation);
 int mgpu_host_fir_taps(int which, double carrier_hz, double* taps, int* ntaps);
 int mgpu_host_preamble_carriers(int cfg, double* carriers_c128, int* n_symbols);
+int mgpu_host_mode_info(int cfg, int mfsk_ctrl_mode, mgpu_info* info);
 
 /* void cl_ldpc::encode(const int* data, int* encoded_data) (ldpc.h:82, ldpc.cc:111-132) for F words: bits [F][K], one byte per bit
  * -> encoded [F][N] = the data followed by the P parity bits. */

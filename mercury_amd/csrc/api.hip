@@ -536,9 +536,7 @@ void mgpu_free_host(void* p) { if (p) (void)hipHostFree(p); }
 
 const char* mgpu_last_error(mgpu_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
-int mgpu_get_info(mgpu_ctx* c, mgpu_info* i) {
-    if (!c || !i) return MGPU_ERR_ARG;
-    const auto& t = c->tab;
+static void fill_info(const mgpu::ModeTables& t, mgpu_info* i) {
     i->cfg = t.cfg; i->M = t.M; i->bits_per_symbol = t.bps; i->K = t.K; i->P = t.P; i->N = t.N;
     i->Nsymb = t.Nsymb; i->Nc = t.Nc; i->Nfft = t.Nfft; i->Ngi = t.Ngi; i->Nofdm = t.Nofdm;
     i->nData = t.nData; i->nBits = t.nBits; i->nPilots = t.nPilots; i->nVirtual = t.nVirtual; i->nReal = t.nReal;
@@ -547,7 +545,23 @@ int mgpu_get_info(mgpu_ctx* c, mgpu_info* i) {
     i->Cwidth = t.graph.Cwidth; i->Vwidth = t.graph.Vwidth; i->E = t.graph.E;
     i->payload_bytes = t.payload_bytes; i->payload_stride = t.payload_stride; i->frame_samples = t.frame_samples;
     i->mfsk_M = t.mfsk_M; i->mfsk_nStreams = t.mfsk_nstreams; i->active_nsymb = t.active_nsymb; i->active_nbits = t.active_nbits;
+}
+
+int mgpu_get_info(mgpu_ctx* c, mgpu_info* i) {
+    if (!c || !i) return MGPU_ERR_ARG;
+    fill_info(c->tab, i);
     return MGPU_OK;
+}
+
+// load_configuration's mode row + derived sizes (telecom_system.cc:2487-3025, :1818-1826, :2910-2911) without a device: the same table builder
+// mgpu_create runs, so the CPU test suite can hold it against the reference's printed values (tests/golden/survey_mode_table.json)
+int mgpu_host_mode_info(int cfg, int mfsk_ctrl_mode, mgpu_info* i) {
+    if (!i) return MGPU_ERR_ARG;
+    try {
+        const mgpu::ModeTables m = mgpu::build_mode_tables(cfg, mfsk_ctrl_mode, mgpu_ldpc_blob, mgpu_ldpc_blob_size);
+        fill_info(m, i);
+        return MGPU_OK;
+    } catch (const std::exception& e) { g_create_error = e.what(); return MGPU_ERR_ARG; }
 }
 
 int mgpu_enable_timing(mgpu_ctx* c, int on) {

@@ -26,6 +26,26 @@
 #include "spa_math.h"
 
 #define LDPC_THREADS 1024
+
+// Profiling aid (variant builds only: tools/build_variants.sh name:"-DSPA_STAMPS=1"): lane 0 of every wavefront of eight workgroups spread
+// over the launch appends (code << 56 | s_memrealtime: 100 MHz ticks) at the decoder's phase boundaries; tools/spa_stamps.py reads them back
+// through mgpu_debug_spa_stamps. The product build carries none of it.
+#ifdef SPA_STAMPS
+#define SPA_STAMP_WGS 8
+#define SPA_STAMP_MAX 192
+__device__ unsigned long long g_spa_stamps[SPA_STAMP_WGS * 16 * SPA_STAMP_MAX];
+#define SPA_STAMP_DECL(F_) int stamp_n = 0; const int stamp_wg = (blockIdx.x % ((F_) / SPA_STAMP_WGS > 0 ? (F_) / SPA_STAMP_WGS : 1)) == ((F_) / (2 * SPA_STAMP_WGS)) ? int(blockIdx.x / ((F_) / SPA_STAMP_WGS > 0 ? (F_) / SPA_STAMP_WGS : 1)) : -1
+#define SPA_STAMP(code) do { if (stamp_wg >= 0 && stamp_wg < SPA_STAMP_WGS && (threadIdx.x & 63) == 0 && stamp_n < SPA_STAMP_MAX) { \
+    g_spa_stamps[(stamp_wg * 16 + (threadIdx.x >> 6)) * SPA_STAMP_MAX + stamp_n] = (static_cast<unsigned long long>(code) << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull); } ++stamp_n; } while (0)
+extern "C" int mgpu_debug_spa_stamps(unsigned long long* out, int clear) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spa_stamps), sizeof(g_spa_stamps)) != hipSuccess) return -1;
+    if (clear) { static unsigned long long z[SPA_STAMP_WGS * 16 * SPA_STAMP_MAX]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_spa_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return SPA_STAMP_WGS * 16 * SPA_STAMP_MAX;
+}
+#else
+#define SPA_STAMP_DECL(F_) do {} while (0)
+#define SPA_STAMP(code) do {} while (0)
+#endif
 #ifndef SPA_SPEC_START
 #define SPA_SPEC_START 8
 #endif
@@ -192,6 +212,8 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     const int tid = threadIdx.x, f = blockIdx.x;
     if (f >= F) return;
     if (uint32_t(uintptr_t(smem)) != 0) __builtin_trap();
+    SPA_STAMP_DECL(F);
+    SPA_STAMP(1);                                   // 1: start
     const float* lin = llr_in + size_t(f) * N;
     for (int v = tid; v < N; v += LDPC_THREADS) {
         const float l = lin[v];
@@ -338,8 +360,11 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
 #endif
     constexpr int kSpecStart = SPA_SPEC_START;
     int iteration = 0;
+    SPA_STAMP(2);                                   // 2: inputs in LDS, tables requested
     syndrome_pass(0);
+    SPA_STAMP(3);                                   // 3: syndrome pass done (before its barrier)
     __syncthreads();
+    SPA_STAMP(4);                                   // 4: behind the barrier
     if (flag[0]) {
         for (int it = 1;; ++it) {
             const bool spec = it - 1 >= kSpecStart;
@@ -348,7 +373,9 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
 #if !SPA_VR_RESIDENT
             const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
 #endif
+            SPA_STAMP(5);                           // 5: check pass done
             __syncthreads();
+            SPA_STAMP(6);                           // 6: behind its barrier
             if (spec) {
                 if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
                 if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
@@ -360,18 +387,24 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
 #else
             if (tid + LDPC_THREADS < N) var_update(vb);
 #endif
+            SPA_STAMP(7);                           // 7: variable update done
             __syncthreads();
+            SPA_STAMP(8);                           // 8: behind its barrier
             if (it < kSpecStart) {
                 syndrome_pass(it);
+                SPA_STAMP(3);
                 __syncthreads();
+                SPA_STAMP(4);
                 if (!flag[it & 1]) { iteration = it; break; }
                 if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
             }
         }
     }
+    SPA_STAMP(9);                                   // 9: loop left
     for (int v = tid; v < N; v += LDPC_THREADS) hard[v] = Lt[v] < 0;
     __syncthreads();
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+    SPA_STAMP(10);                                  // 10: tail done
 }
 
 #define SPA_KERNEL(NE, DMX)                                                                                    \
@@ -430,6 +463,8 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     int* flag = reinterpret_cast<int*>(bytes + 256);
     const int tid = threadIdx.x, f = blockIdx.x, lane = tid & 63;
     if (f >= F) return;
+    SPA_STAMP_DECL(F);
+    SPA_STAMP(1);
     constexpr int kRows = (kN + THREADS - 1) / THREADS;      // channel LLRs in registers: row i of the variable records belongs to one lane
     uint32_t vrow[kRows];
 #pragma unroll
@@ -602,10 +637,13 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     const std::integral_constant<int, 9> s9; const std::integral_constant<int, 6> s6; const std::integral_constant<int, 4> s4; const std::integral_constant<int, 2> s2;
     const VarRec vr0 = load_var(s9, tid), vr1 = load_var(s6, tid + THREADS), vr2 = load_var(s4, tid + 2 * THREADS), vr3 = load_var(s2, tid + 3 * THREADS);
     int iteration = 0;
+    SPA_STAMP(2);
     for (int it = 1;; ++it) {
         if (it <= T.max_iters) cn_pass(it - 1, it == 1);
         else syndrome_pass(it - 1);
+        SPA_STAMP(5);
         __syncthreads();
+        SPA_STAMP(6);
         if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
         if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
         if (tid == 0) flag[it & 1] = 0;
@@ -613,11 +651,15 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         var_update(s6, vr1, li[1]);
         var_update(s4, vr2, li[2]);
         if (tid + 3 * THREADS < N) var_update(s2, vr3, li[3]);
+        SPA_STAMP(7);
         __syncthreads();
+        SPA_STAMP(8);
     }
+    SPA_STAMP(9);
     for (int v = tid; v < N; v += THREADS) hard[v] = Lt[v] < 0;
     __syncthreads();
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
+    SPA_STAMP(10);
 }
 extern "C" __global__ __launch_bounds__(512, 8) void mgpu_ldpc_spa_fast_kernel_t512(
     LdpcDev T, const float* __restrict__ llr_in, int F, uint8_t* __restrict__ bits_out,

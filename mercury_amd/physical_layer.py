@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmercury_gpu.so")
+# MERCURY_GPU_LIB: another build of the same HIP library (kernel experiments: tools/build_variants.sh); never a CPU path
+LIB_PATH = os.environ.get("MERCURY_GPU_LIB") or os.path.join(HERE, "libmercury_gpu.so")
 
 DEC_GBF, DEC_SPA, DEC_MINSUM, DEC_SPA_FAST = 0, 1, 2, 3
 EST_ZF, EST_LS = 0, 1
@@ -105,7 +106,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "mgpu_alloc_host", "mgpu_free_host", "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
-    "mgpu_host_select_peak", "mgpu_host_fir_taps", "mgpu_host_preamble_carriers",
+    "mgpu_host_select_peak", "mgpu_host_fir_taps", "mgpu_host_preamble_carriers", "mgpu_host_mode_info",
     "mgpu_ldpc_batch", "mgpu_ldpc_encode_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_host_path_last", "mgpu_device_malloc", "mgpu_device_free", "mgpu_context_stream", "mgpu_synchronize", "mgpu_copy_to_host", "mgpu_copy_to_device",
     "mgpu_pool_rx_batch_dev", "mgpu_pool_ldpc_batch_dev", "mgpu_pool_txgen_dev",

@@ -162,8 +162,8 @@ def test_cpp_per_method_mirror_compiles(tmp_path):
 @pytest.mark.parametrize("cfg", [0, 8, 10, 13, 16])
 def test_cpp_per_method_sequence_matches_oracle(tmp_path, cfg):
     """receive_byte's front half written method by method (mgpu::cl_ofdm / cl_psk / deinterleaver, tests/cpp/stages_test.cpp)
-    gives, stage by stage, what the oracle's receive_byte variant gives: carrier grid bit-exact, channel / equalised grid to
-    the last-ulp differences of the device atan/cos/sin, LLRs to 1e-5."""
+    gives, stage by stage, what the oracle's receive_byte variant gives, bit for bit (carrier grid, channel grid, equalised grid,
+    float variance, symbols, LLRs) like the fused path."""
     exe = _build_stages(tmp_path)
     orc = oraclelib.Oracle(cfg, 50)
     bb, _ = orc.gen_frame(SEED, 4000 + cfg, oraclelib.noise_amp_for(OPERATING_ESN0[cfg] + 2.0))
@@ -185,14 +185,25 @@ def test_cpp_per_method_sequence_matches_oracle(tmp_path, cfg):
     variance = take(1, np.float32)[0]
     syms, llr_demod, llr_deint = take(nData, np.complex128), take(nBits, np.float32), take(nBits, np.float32)
     assert grid.tobytes() == ref["grid"].tobytes()
-    assert np.abs(H - ref["H"]).max() <= 1e-12 * np.abs(ref["H"]).max()
-    assert np.abs(eq - ref["eq"]).max() <= 1e-12 * np.abs(ref["eq"]).max()
+    # stages.hip uses the same restated libm (csrc/glibc_trig.h) and the same operation order as the fused front-end: the per-method
+    # path is held to the same bar - BIT-IDENTICAL wherever the host runs the libm build that was restated (tests/test_gpu_parity.py:
+    # EXACT_TRIG), last-ulp phasor differences otherwise in the modes that restore the amplitude
+    from test_gpu_parity import EXACT_TRIG
+    exact = EXACT_TRIG or not orc.amp_restore
+    rel = 0.0 if exact else 1e-12
+    assert np.abs(H - ref["H"]).max() <= rel * np.abs(ref["H"]).max()
+    assert np.abs(eq - ref["eq"]).max() <= rel * np.abs(ref["eq"]).max()
     if cfg < 15:     # the ZF modes' equalised-pilot variance is rounding noise (~1e-33) in this variant: not comparable
+        nreal = orc.nReal
+        if exact:
+            assert np.float32(variance) == np.float32(ref["variance_f"])
+            assert syms.tobytes() == ref["syms"].tobytes()
+            assert np.array_equal(llr_demod, ref["llr_demod"], equal_nan=True)
+            assert np.array_equal(llr_deint[:nreal], ref["llr_ldpc"][:nreal], equal_nan=True)
         assert abs(variance - ref["variance_f"]) <= 2e-7 * ref["variance_f"]
         assert np.abs(syms - ref["syms"]).max() <= 1e-12 * np.abs(ref["syms"]).max()
         tol = 1e-5 * np.maximum(1.0, np.abs(ref["llr_demod"]))
         assert (np.abs(llr_demod - ref["llr_demod"]) <= tol).all()
-        nreal = orc.nReal
         assert (np.abs(llr_deint[:nreal] - ref["llr_ldpc"][:nreal]) <= 1e-5 * np.maximum(1.0, np.abs(ref["llr_ldpc"][:nreal]))).all()
     # integer tail: bit-exact
     nreal = orc.nReal

@@ -71,7 +71,7 @@ def test_all_stages_match_oracle(cfg):
             # (csrc/glibc_trig.h) -> every stage BIT-IDENTICAL where the host runs the libm build that was restated
             # (FMA-capable x86-64, see tests/test_glibc_trig.py); elsewhere the PSK modes' phasors may differ in the last ulp
             exact = EXACT_TRIG or not orc.amp_restore
-            for key in ("grid", "eq", "syms"):
+            for key in ("grid", "H", "eq", "syms"):        # H: the channel grid after estimate + interpolation + amplitude restoration (rows a4-a7)
                 d = np.abs(out[key][f] - ref[key]).max()
                 scale = np.abs(ref[key]).max()
                 assert d <= (0.0 if exact or key == "grid" else 1e-12) * scale, (cfg, flags, f, key, d, scale)
@@ -91,6 +91,18 @@ def test_all_stages_match_oracle(cfg):
             assert out["stats"]["all_zeros"][f] == ref["all_zeros"], (cfg, flags, f)
             if ref["iterations"] <= 50 and snrs[f] > 0 or snrs[f] == 60.0:
                 assert np.array_equal(out["payload"][f][: orc.payload_bytes], payloads[f].astype(np.uint8))
+        rx.close()
+
+
+def test_live_contexts_report_the_reference_mode_table():
+    """mgpu_get_info of a context on the device equals what the compiled reference printed after the real
+    load_configuration(cfg) (transcribed into tests/golden/survey_mode_table.json) for all 17 modes."""
+    import json
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "survey_mode_table.json")))
+    for cfg in range(17):
+        rx = _rx(cfg, max_batch=1)
+        for k, v in dict(tab["modes"][str(cfg)], **tab["fixed"]).items():
+            assert getattr(rx, k) == v, (cfg, k, getattr(rx, k), v)
         rx.close()
 
 

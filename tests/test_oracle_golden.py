@@ -45,6 +45,32 @@ def test_tables_and_mode_parameters(cfg):
     assert abs(abs(orc.pilot_seq()[0]) - 1.3300000429153442) == 0.0
 
 
+def test_mode_table_equals_what_the_compiled_reference_printed():
+    """SURVEY.md §8 row a22, pinned independently of oracle/ref_harness.cc (which restates the 17 mode rows because telecom_system.cc
+    cannot be linked here): the oracle AND the library's host-side table builder (mgpu_host_mode_info: the code mgpu_create runs) report
+    the numbers the surveyor printed from the compiled reference after the real load_configuration(cfg) — SURVEY.md §0, transcribed by
+    tests/golden/make_survey_mode_table.py."""
+    import ctypes as C
+    from mercury_amd import load_library
+    from mercury_amd.physical_layer import Info
+    tab = json.load(open(os.path.join(HERE, "golden", "survey_mode_table.json")))
+    assert sorted(tab["modes"], key=int) == [str(c) for c in range(17)]
+    lib = load_library()
+    for cfg in range(17):
+        want = dict(tab["modes"][str(cfg)], **tab["fixed"])
+        orc = oraclelib.Oracle(cfg)
+        info = Info()
+        assert lib.mgpu_host_mode_info(C.c_int(cfg), C.c_int(0), C.byref(info)) == 0
+        for k, v in want.items():
+            if k != "E":                                   # the oracle's info carries the table widths, not the edge count
+                assert getattr(orc, k) == v, ("oracle", cfg, k, getattr(orc, k), v)
+            assert getattr(info, k) == v, ("library", cfg, k, getattr(info, k), v)
+        assert info.payload_bytes == (want["nBits"] - want["P"] - 16) // 8 == orc.payload_bytes      # telecom_system.cc:332-340
+        assert info.frame_samples == want["Nsymb"] * want["Nofdm"]
+    bad = Info()
+    assert lib.mgpu_host_mode_info(C.c_int(55), C.c_int(0), C.byref(bad)) != 0
+
+
 @pytest.mark.parametrize("cfg", list(range(17)))
 def test_rx_chain_matches_reference_vectors(cfg):
     orc = oraclelib.Oracle(cfg, 50)
