@@ -53,34 +53,46 @@ def algorithmic_bytes(rx, iters_exec_sum, frames):
     return ldpc, total, b_iter
 
 
-def profile_mix(decoder, args, F):
-    """The committed PMC passes of one decoder launch of the headline workload (tools/collect_pmc_mix.sh), or None when they
-    were taken from another build of the decoder kernels than the one being timed (stamp = mercury_amd.build.decoder_digest())."""
-    if args.ldpc_only or args.cfg != 8 or F != 4096 or args.iters != 50:
+PROFILE_ROUND = "r04"          # profiles/<round>_instruction_mix.json (PMC passes) and <round>_valu_cycles.json (opcode issue costs)
+
+
+def machine_of(device_index):
+    """Compute units, SIMDs and engine clock of the device being timed, from the HIP runtime (mgpu_device_props_get), so that the issue-cycle
+    budget below is this box's and not a constant; also what the pool's placement uses (PCI address, NUMA node)."""
+    from mercury_amd import device_props
+    p = device_props(device_index)
+    return {"name": p["name"], "gcn_arch": p["gcn_arch"], "compute_units": p["compute_units"], "simds": 4 * p["compute_units"],
+            "clock_hz": 1e3 * p["clock_khz"], "pci_bus_id": p["pci_bus_id"], "numa_node": p["numa_node"]}
+
+
+def profile_mix(key, workload_ok=True):
+    """The committed PMC passes of one kernel launch (tools/collect_pmc_mix.sh; key "spa" / "spa_fast" / "minsum" = the decoder on the
+    headline workload, "<decoder>_op" = on the operating-point workload, "frontend"), or None when they were taken from another build of
+    the decoder kernels than the one being timed (stamp = mercury_amd.build.decoder_digest())."""
+    name = "profiles/%s_instruction_mix.json" % PROFILE_ROUND
+    if not workload_ok:
         return None, "no profile for this workload"
-    path = os.path.join(ROOT, "profiles", "r03_instruction_mix.json")
     try:
         from mercury_amd.build import decoder_digest
-        prof = json.load(open(path))
+        prof = json.load(open(os.path.join(ROOT, name)))
         if prof.get("decoder_digest") != decoder_digest():
-            return None, "profiles/r03_instruction_mix.json was taken from another build of the decoder kernels (stamp %s, library %s)" % (
-                prof.get("decoder_digest"), decoder_digest())
-        return prof[decoder], "profiles/r03_instruction_mix.json (PMC, same workload, same decoder build %s)" % prof["decoder_digest"]
+            return None, "%s was taken from another build of the decoder kernels (stamp %s, library %s)" % (name, prof.get("decoder_digest"), decoder_digest())
+        return prof[key], "%s[%s] (PMC, same workload, same decoder build %s)" % (name, key, prof["decoder_digest"])
     except Exception as e:
         return None, "profile unreadable: %r" % (e,)
 
 
-def issue_view(decoder, dec_ms, args, F, iters_per_launch):
-    """Secondary view for the bound the decoders actually hit (vector-instruction issue). The dynamic opcode mix of one launch of
-    THIS workload comes from the committed PMC passes, the issue cost of each opcode class from the micro-benchmark measured on the
-    same kind of box (profiles/r02_valu_cycles.json, tools/ubench/valu_cycles.hip); issue cycles needed = sum(count x cost),
-    available = SIMDs x clock x kernel time of this run. Two readings: "isolated" prices every class at its back-to-back cost
-    (32-bit operations 2 cycles), "slots" at one 4-cycle issue slot per instruction (what a mixed fp64 stream pays: MIX_FMA_CND in
+def issue_view(mix, src, kernel_ms, machine, sclk=None):
+    """Secondary view for the bound these kernels actually hit (vector-instruction issue). The dynamic opcode mix of one launch comes from
+    the committed PMC passes of THAT workload, the issue cost of each opcode class from the micro-benchmark measured on the same kind of
+    box (profiles/<round>_valu_cycles.json, tools/ubench/valu_cycles.hip); issue cycles needed = sum(count x cost), available = the
+    device's SIMDs x engine clock (HIP runtime) x kernel time of this run. Two readings: "isolated" prices every class at its back-to-back
+    cost (32-bit operations 2 cycles), "slots" at one 4-cycle issue slot per instruction (what a mixed fp64 stream pays: MIX_FMA_CND in
     the micro-benchmark) - the truth lies between them."""
-    mix, src = profile_mix(decoder, args, F)
-    cfile = os.path.join(ROOT, "profiles", "r02_valu_cycles.json")
-    if mix is None or not os.path.exists(cfile) or abs(iters_per_launch - 50.0 * F) > 1e-6 * F:
-        return {"unavailable": src if mix is None else "not the all-50-iterations workload the profile was taken on"}
+    cname = "profiles/%s_valu_cycles.json" % PROFILE_ROUND
+    cfile = os.path.join(ROOT, cname)
+    if mix is None or not os.path.exists(cfile):
+        return {"unavailable": src if mix is None else cname + " missing"}
     try:
         cyc = {k.split("/")[0]: v["cycles_at_2p4ghz"] for k, v in json.load(open(cfile))["results"].items() if k.endswith("/8w")}
         fp64 = mix["SQ_INSTS_VALU_ADD_F64"] + mix["SQ_INSTS_VALU_MUL_F64"] + mix["SQ_INSTS_VALU_FMA_F64"]
@@ -93,15 +105,55 @@ def issue_view(decoder, dec_ms, args, F, iters_per_launch):
         classes["compare_select_move"] = (rest, 0.5 * (cyc["CMP_U32"] + cyc["MOV_B32"]))
         isolated = sum(c * w for c, w in classes.values())
         slots = sum(c * max(w, cyc["FMA_F64"]) for c, w in classes.values())
-        avail = 256 * 4 * 2.4e9 * dec_ms * 1e-3
+        # the engine clock the device actually held while this kernel was timed (hwmon samples) when there are any; else the runtime's maximum
+        clock_hz = 1e6 * sclk["median"] if sclk and sclk.get("median") else machine["clock_hz"]
+        avail = machine["simds"] * clock_hz * kernel_ms * 1e-3
         return {"bound": "valu_issue", "unit": "SIMD issue cycles per launch", "available": avail,
                 "needed_isolated_costs": isolated, "frac_isolated": isolated / avail,
                 "needed_4cycle_slots": slots, "frac_slots": slots / avail, "frac": slots / avail,
+                "clock_hz_used": clock_hz, "clock_source": "hwmon freq1_input, median over the timed region" if clock_hz != machine["clock_hz"] else "hipDeviceProp clockRate (maximum)",
                 "valu_instructions_per_launch": mix["SQ_INSTS_VALU"],
+                "valu_busy_measured": 4.0 * mix["SQ_ACTIVE_INST_VALU"] / (mix["GRBM_GUI_ACTIVE"] / 8.0 * machine["simds"]) if mix.get("GRBM_GUI_ACTIVE") else None,
+                "machine": {k: machine[k] for k in ("compute_units", "simds", "clock_hz")},
                 "classes": {k: {"count": c, "cycles_each": w} for k, (c, w) in classes.items()},
-                "source": "opcode mix: %s; costs: profiles/r02_valu_cycles.json (micro-benchmark); time: this run" % src}
+                "source": "opcode mix: %s; costs: %s (micro-benchmark); SIMDs and clock: hipDeviceProp; time: this run" % (src, cname)}
     except Exception as e:                       # a stale profile must not break the bench line
         return {"error": repr(e)}
+
+
+class ClockSampler(threading.Thread):
+    """Engine clock (and board power) of the device while the timed region runs, from the amdgpu hwmon files of its PCI address: a clock
+    drop (power cap, thermal) then shows in the bench line instead of silently moving the roofline fraction."""
+
+    def __init__(self, pci_bus_id, period=0.01):
+        super().__init__(daemon=True)
+        import glob
+        base = "/sys/bus/pci/devices/%s" % pci_bus_id.lower()
+        self.freq = (glob.glob(base + "/hwmon/hwmon*/freq1_input") or [None])[0]
+        self.power = (glob.glob(base + "/hwmon/hwmon*/power1_average") + glob.glob(base + "/hwmon/hwmon*/power1_input") or [None])[0]
+        self.period, self.mhz, self.watt, self.stop_flag = period, [], [], threading.Event()
+
+    def run(self):
+        while not self.stop_flag.is_set():
+            try:
+                if self.freq:
+                    self.mhz.append(int(open(self.freq).read()) / 1e6)
+                if self.power:
+                    self.watt.append(int(open(self.power).read()) / 1e6)
+            except Exception:
+                pass
+            self.stop_flag.wait(self.period)
+
+    def summary(self):
+        self.stop_flag.set()
+        self.join(timeout=1.0)
+        if not self.mhz:
+            return None
+        m = sorted(self.mhz)
+        out = {"min": m[0], "median": m[len(m) // 2], "max": m[-1], "samples": len(m), "source": "hwmon freq1_input"}
+        if self.watt:
+            out["power_w_median"] = sorted(self.watt)[len(self.watt) // 2]
+        return out
 
 
 def usable_cores():
@@ -168,9 +220,36 @@ def cpu_baseline(cfg, max_iters, bb_sample, flags, gpu_payload, gpu_stats):
     return out
 
 
-def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
-    """Secondary measurements on rank 0's GPU, outside the contract's timed region: the other decoder on the same
-    inputs, and the same decoder at the mode's operating point (threshold + 3 dB) where early termination works."""
+def headline_workload(args, F):
+    return (not args.ldpc_only) and args.cfg == 8 and F == 4096 and args.iters == 50 and args.variant == "receive_byte" and args.channel == 0
+
+
+def operating_point_roofline(rx, decoder, m, F, machine, profiled, sclk=None):
+    """Rooflines of the two kernels of one operating-point step (SURVEY.md §8d C2's second point): the front-end is a streaming kernel
+    - its input samples against HBM - and also priced against vector issue from its PMC mix; the decoder (LDS-resident messages) against
+    vector issue from a PMC pass of THIS launch (profiles/<round>_instruction_mix.json["<decoder>_op"]), with the §8d HBM-model figure
+    beside it for comparison with the headline."""
+    b_in = 16 * rx.Nsymb * rx.Nofdm
+    fe = {"kernel": "mgpu_frontend_kernel", "bound": "hbm", "achieved": F * b_in / (m["frontend_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+          "bytes_per_frame": b_in}
+    fe["frac"] = fe["achieved"] / fe["peak"]
+    mix, src = profile_mix("frontend", profiled)
+    fe["traffic"] = (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None
+    fe["secondary"] = issue_view(mix, src, m["frontend_ms"], machine, sclk)
+    ldpc_bytes, _, b_iter = algorithmic_bytes(rx, m["avg_iters"] * F, F)
+    mix, src = profile_mix(decoder + "_op", profiled)
+    dec = {"kernel": "mgpu_ldpc_%s_kernel" % decoder, "bound": "valu_issue", "secondary": issue_view(mix, src, m["ldpc_ms"], machine, sclk),
+           "hbm_model": {"achieved": ldpc_bytes / (m["ldpc_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": ldpc_bytes / (m["ldpc_ms"] * 1e-3) / HBM_PEAK, "bytes_per_codeword_iteration": b_iter},
+           "traffic": (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None, "traffic_source": src}
+    if "frac" in dec["secondary"]:
+        dec["frac"] = dec["secondary"]["frac_isolated"] if decoder != "spa" else dec["secondary"]["frac_slots"]
+    return {"frontend": fe, "decoder": dec}
+
+
+def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp, machine):
+    """Secondary measurements on rank 0's GPU, outside the contract's timed region: the other decoders on the same
+    inputs, and every decoder at the mode's operating point (threshold + 3 dB) where early termination works."""
     from conftest import OPERATING_ESN0
     out = {}
 
@@ -179,25 +258,31 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
             phy.receive_dev(inputs[i % len(inputs)].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         phy.enable_timing(True)
+        sampler = ClockSampler(machine["pci_bus_id"], period=0.002)
+        sampler.start()
         t0 = time.perf_counter()
         for i in range(steps):
             phy.receive_dev(inputs[i % len(inputs)].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        sclk = sampler.summary()
         fe, dec, _ = phy.kernel_ms_avg()
         phy.enable_timing(False)
         it = float(stats[:, 0].clamp(max=args.iters).sum().item()) / F
         ok = float(stats[:, 3].sum().item()) / F
-        return {"frames_per_s": F * steps / dt, "frontend_ms": fe, "ldpc_ms": dec, "avg_iters": it, "decoded_fraction": ok}
+        return {"frames_per_s": F * steps / dt, "ms_per_step": dt / steps * 1e3, "frontend_ms": fe, "ldpc_ms": dec, "avg_iters": it, "decoded_fraction": ok,
+                "sclk_mhz": sclk}
 
     agc, vs = (1, 1) if args.variant == "receive_byte" else (0, 0)
+    profiled = headline_workload(args, F)
     others = {}
     for other in [d for d in ("spa", "spa_fast", "minsum") if d != args.decoder]:
         rx2 = RxPhy(args.cfg, max_iters=args.iters, decoder=DECODERS[other], agc=agc, variance_source=vs, device=dev.index, max_batch=F)
         m = timed(rx2, bufs)
         # these kernels keep their messages in LDS: pricing them against HBM says nothing (the model fraction exceeds 1 on some
         # modes). What bounds them is vector-instruction issue: the fraction of the SIMDs' issue cycles their PMC opcode mix needs.
-        sec = issue_view(other, m["ldpc_ms"], args, F, m["avg_iters"] * F)
+        mix, src = profile_mix(other, profiled and abs(m["avg_iters"] - 50.0) < 1e-6)
+        sec = issue_view(mix, src, m["ldpc_ms"], machine, m["sclk_mhz"])
         if sec and "frac" in sec:
             m["roofline_frac"] = sec["frac_isolated"]
             m["roofline_bound"] = "valu_issue (isolated opcode costs; %s)" % sec["source"]
@@ -209,8 +294,9 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp):
     rx.txgen_dev(SEED, 1 << 40, F, amp, bb.data_ptr(), None, channel=args.channel, stream=stream)
     torch.cuda.synchronize()
     for name, phy in [(args.decoder, rx)] + list(others.items()):
-        r = timed(phy, [bb])
+        r = timed(phy, [bb], steps=20)
         r["esn0_db"] = op
+        r["roofline"] = operating_point_roofline(rx, name, r, F, machine, profiled, r["sclk_mhz"])
         out["operating_point_decoder_" + name] = r
     # one frame per call through the blocking host-buffer entry point (mgpu_rx_batch, F = 1): what a receive_byte
     # patched as in INTEGRATION.md §1.2 waits for, PCIe copies and launch overheads included
@@ -318,7 +404,8 @@ def run_pool(args):
     iters_per_launch = iters_total / (args.steps * N)
     ldpc_bytes, _, b_iter = algorithmic_bytes(one, iters_per_launch, F)
     achieved = ldpc_bytes / (dec_ms * 1e-3)
-    mix, mix_src = profile_mix(args.decoder, args, F)
+    machine = machine_of(devices[0])
+    mix, mix_src = profile_mix(args.decoder, headline_workload(args, F) and abs(iters_per_launch - 50.0 * F) <= 1e-6 * F)
     line = {
         "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (pool.K, args.iters)) if args.ldpc_only else
                   ("RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters)),
@@ -340,7 +427,7 @@ def run_pool(args):
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      "traffic": (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None, "traffic_source": mix_src,
                      "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
-                     "secondary": issue_view(args.decoder, dec_ms, args, F, iters_per_launch),
+                     "secondary": issue_view(mix, mix_src, dec_ms, machine),
                      "bytes_per_codeword_iteration": b_iter,
                      "note": "device 0's decoder launch; algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are "
                              "LDS-resident so real HBM traffic is far lower; the decoders are bound by vector-instruction issue"},
@@ -357,6 +444,7 @@ def run_pool(args):
         flags = oraclelib.FLAGS_RECEIVE_BYTE if args.variant == "receive_byte" else oraclelib.FLAGS_BASEBAND_TEST
         line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, pay, st6)
         line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    line["placement"] = {"devices": devices, "numa_nodes": pool.numa_nodes(), "worker_threads": "bound to their device's NUMA node (MERCURY_POOL_AFFINITY=0 to disable)"}
     print(json.dumps(line), flush=True)
     pool.close()
     one.close()
@@ -382,10 +470,18 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary per-GPU measurements (min-sum, operating point)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing only: create the process group (and run the barrier / MAX / SUM reductions) even with one rank - the RCCL code path of the "
+                         "driver's 8-GPU run on a one-GPU box")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the shard map of `--gpus N` (rank -> device, NUMA node when known, global frame ranges per input batch) as one JSON line and "
+                         "exit; touches no GPU")
     ap.add_argument("--pool", action="store_true",
                     help="one process drives the --gpus devices through the C-ABI pool (include/mercury_pool.h: one context + one host "
                          "thread per device), device-resident shards; also what `python bench.py --gpus N` does when not under torchrun")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
     if args.pool or (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus > 1):
         return run_pool(args)
 
@@ -396,8 +492,12 @@ def main():
         local_rank = 0
     elif torch.cuda.device_count() > 0:
         local_rank %= torch.cuda.device_count()       # e.g. a launcher that exposes one device per rank
-    if world > 1:
+    collective = world > 1 or args.force_dist
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -452,8 +552,12 @@ def main():
     if args.warmup == 0:  # torch loads its reduction kernels lazily; keep that one-off out of the timed region
         (stats[:, 0].clamp(max=args.iters).sum() + stats[:, 3].sum()).item()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
+    machine = machine_of(local_rank)
+    sampler = ClockSampler(machine["pci_bus_id"]) if rank == 0 else None
+    if sampler:
+        sampler.start()
     rx.enable_timing(True)
     iters_acc.zero_()
     decoded_acc.zero_()
@@ -462,16 +566,17 @@ def main():
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sclk = sampler.summary() if sampler else None
     fe_ms, dec_ms, nl = rx.kernel_ms_avg()
     rx.enable_timing(False)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     sums = torch.stack([iters_acc, decoded_acc]).to(torch.float64).to(rdev)
-    if world > 1:
+    if collective:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
@@ -486,9 +591,9 @@ def main():
         # HBM bytes of one decoder launch of this workload from the committed PMC passes (separate --pmc runs of this command,
         # tools/collect_pmc_mix.sh): (2 x FETCH_SIZE + WRITE_SIZE) KB - FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
         # gfx950's wide coalesced reads. Quoted only when the profile's stamp matches the decoder build being timed.
-        mix, mix_src = profile_mix(args.decoder, args, F)
+        mix, mix_src = profile_mix(args.decoder, headline_workload(args, F) and abs(iters_per_launch - 50.0 * F) <= 1e-6 * F)
         traffic = (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None
-        issue = issue_view(args.decoder, dec_ms, args, F, iters_per_launch)
+        issue = issue_view(mix, mix_src, dec_ms, machine, sclk)
         line = {
             "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (rx.K, args.iters)) if args.ldpc_only else
                       ("RX frames/s (mode %d, max %d LDPC iters)" % (args.cfg, args.iters)),
@@ -508,6 +613,8 @@ def main():
             "avg_iters_per_frame": iters_total / frames_total,
             "decoded_fraction": decoded_total / frames_total,
             "kernel_ms": {"frontend": fe_ms, "ldpc": dec_ms, "launches_averaged": nl},
+            "sclk_mhz_during_run": sclk,
+            "machine": machine,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": mix_src,
                          "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
@@ -520,7 +627,16 @@ def main():
         S_chk = min(F, args.cpu_sample_per_core * usable_cores())
         payload_chk, stats_chk = payload[:S_chk].cpu().numpy().copy(), stats[:S_chk].cpu().numpy().copy()
         if not args.no_extras and not args.ldpc_only:
-            line["extras_per_gpu"] = extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp)
+            line["extras_per_gpu"] = extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp, machine)
+            # SURVEY.md §8d C2 names two points for this metric: the all-iterations one above is `value`; the realistic one (Es/N0 = threshold
+            # + 3 dB, early termination at work) is this second record, same decoder, same frames per step, with its own rooflines
+            opr = line["extras_per_gpu"].get("operating_point_decoder_" + args.decoder)
+            if opr:
+                line["operating_point"] = {"metric": "RX frames/s (mode %d at Es/N0 %+.1f dB, max %d LDPC iters, early termination)" % (args.cfg, opr["esn0_db"], args.iters),
+                                           "value": opr["frames_per_s"], "unit": "frames/s", "ms_per_step": opr["ms_per_step"], "esn0_db": opr["esn0_db"],
+                                           "avg_iters_per_frame": opr["avg_iters"], "ldpc_iters_per_s": opr["avg_iters"] * opr["frames_per_s"],
+                                           "decoded_fraction": opr["decoded_fraction"], "kernel_ms": {"frontend": opr["frontend_ms"], "ldpc": opr["ldpc_ms"]},
+                                           "decoder": args.decoder, "roofline": opr["roofline"]}
         if world == 1 and not args.no_cpu_baseline and not args.ldpc_only:
             cores = usable_cores()
             S = min(F, args.cpu_sample_per_core * cores)
@@ -528,10 +644,8 @@ def main():
             bb_h = bufs[last][:S].cpu().numpy().view(np.complex128).reshape(S, -1)
             import oraclelib
             flags = oraclelib.FLAGS_RECEIVE_BYTE if args.variant == "receive_byte" else oraclelib.FLAGS_BASEBAND_TEST
-            if args.decoder == "spa":
-                line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload_chk, stats_chk)
-            else:
-                line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload_chk, stats_chk)
+            line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, payload_chk, stats_chk)
+            if args.decoder != "spa":
                 line["cpu_baseline"]["note"] = "CPU runs the reference's sum-product decoder; mismatches vs %s are expected on non-converged frames" % args.decoder
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
             # the same call through the host-buffer entry point (pageable host memory -> H2D, kernels, D2H): never `value`
@@ -557,8 +671,32 @@ def main():
             line["pcie_inclusive_pinned_frames_per_s"], _ = median_rate(pin)
             line["pcie_bound_frames_per_s_at_55GBps"] = 55e9 / (rx.frame_samples * 16)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
+
+
+def dry_run(args):
+    """The shard map of `bench.py --gpus N` without touching a GPU: which device every rank takes (the LOCAL_RANK rule of main(), or the pool's
+    device list), that device's NUMA node when sysfs knows the amdgpu devices, and the global frame indices each rank generates and decodes
+    per input batch (frame_range: SURVEY.md §8e, frame f -> rank floor(f * N / F_total))."""
+    import glob
+    N, F = args.gpus, args.frames
+    nodes = []
+    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if os.path.basename(os.path.realpath(os.path.join(d, "driver"))) == "amdgpu":
+                nodes.append({"pci_bus_id": os.path.basename(os.path.realpath(d)), "numa_node": int(open(os.path.join(d, "numa_node")).read())})
+        except Exception:
+            pass
+    ranks = []
+    for r in range(N):
+        lo, hi = frame_range(r, N, F * N)
+        dev = 0 if args.share_device else (r % len(nodes) if nodes else r)
+        ranks.append({"rank": r, "device": dev, "placement": nodes[dev] if dev < len(nodes) else None,
+                      "frames_per_step": hi - lo, "global_frames_by_input_batch": [[b * F * N + lo, b * F * N + hi] for b in range(max(1, args.nbuf))]})
+    print(json.dumps({"dry_run": True, "n_gpus": N, "mode": "pool (one process, one worker thread per device)" if args.pool or N > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
+                      else "ranks (torch.distributed.run, one process per GPU)", "collectives_on_the_data_path": 0,
+                      "frames_per_step_total": F * N, "scaling": "weak", "amdgpu_devices_visible_in_sysfs": len(nodes), "ranks": ranks}), flush=True)
 
 
 if __name__ == "__main__":

@@ -162,6 +162,27 @@ int mgpu_get_info(mgpu_ctx* ctx, mgpu_info* info);
 void* mgpu_alloc_host(size_t bytes);
 void mgpu_free_host(void* p);
 
+/* ---- placement on a multi-GPU host (SURVEY.md §8 row e) ---------------------------------------------------------------
+ * mgpu_device_props_get: what the benchmark's roofline arithmetic and the pool's placement need to know about device `device`
+ *   (HIP runtime + sysfs): compute units, engine / memory clock, LDS per compute unit, HBM size, PCI address, and the NUMA node the
+ *   device hangs off (-1: the platform reports none). MGPU_ERR_DEVICE without a visible device.
+ * mgpu_alloc_host_near: mgpu_alloc_host with the pages taken from `device`'s NUMA node when the platform names one (the calling
+ *   thread's memory policy is set to prefer that node for the duration of the call); a context's own staging buffers are
+ *   allocated the same way. Free with mgpu_free_host.
+ * mgpu_host_numa_node_of_pci / mgpu_host_numa_cpus: the sysfs lookups behind it (no GPU needed): node of a PCI address
+ *   ("0000:c1:00.0"), CPUs of a node (returns how many there are; writes at most `max`). */
+typedef struct mgpu_device_props {
+    int compute_units, clock_khz, memory_clock_khz, lds_bytes_per_cu, wavefront_size, numa_node;
+    unsigned long long hbm_bytes;
+    char name[64];
+    char gcn_arch[32];
+    char pci_bus_id[32];
+} mgpu_device_props;
+int mgpu_device_props_get(int device, mgpu_device_props* out);
+void* mgpu_alloc_host_near(int device, size_t bytes);
+int mgpu_host_numa_node_of_pci(const char* pci_bus_id);
+int mgpu_host_numa_cpus(int node, int* cpus, int max);
+
 /* ---- host-buffer entry points (blocking; copy in, run, copy out) -------------------- */
 /* baseband_c128: [F][Nsymb*Nofdm] complex<double>, data symbols only (preamble already
  * stripped, i.e. the pointer receive_byte passes to symbol_demod at telecom_system.cc:1137).

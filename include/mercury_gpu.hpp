@@ -157,21 +157,40 @@ public:
         current_configuration = configuration;
         mfsk_ctrl_mode = false;               // load_configuration leaves control-frame mode (telecom_system.cc:2990)
         select(0);
-        // init() measures the filter chain whenever the modulation or the preamble length changed (telecom_system.cc:1954-1958, :2682-2691);
-        // the table depends on the modulation, the pilot count and the carrier only, so measuring it on every load gives the same table
-        if (configuration < 100) get_pre_equalization_channel();
+        // init() measures the filter chain only when the modulation or the preamble length changed (telecom_system.cc:1954-1958, :2682-2691).
+        // The measurement is ~0.2 s of host work (1000 symbols through three filters), so the mirror does the same: a gear shift between
+        // modes of one modulation and preamble length re-installs the table it has (every load makes a new context) instead of re-measuring.
+        if (configuration < 100) {
+            const auto& d = default_configurations_telecom_system;
+            const PreEqKey key{info.M, info.preamble_nsymb, carrier_frequency, d.ofdm_pilot_configurator_pilot_boost, d.ofdm_pilot_configurator_seed,
+                               d.ofdm_preamble_configurator_seed};
+            if (key == pre_eq_key_ && int(pre_equalization_channel.size()) == info.Nc)
+                detail::check(mgpu_set_pre_equalization_channel(ctx_, reinterpret_cast<const double*>(pre_equalization_channel.data())), ctx_,
+                              "load_configuration");
+            else { get_pre_equalization_channel(); pre_eq_key_ = key; }
+        }
     }
-    // void cl_telecom_system::return_to_last_configuration() — telecom_system.cc:3027-3034
+    // void cl_telecom_system::return_to_last_configuration() — telecom_system.cc:3027-3034, statement for statement. Note what the reference's
+    // bookkeeping amounts to: load_configuration(last) already moves current -> last and last -> current, and the swap that follows moves
+    // them back, so afterwards current_configuration / last_configuration read as BEFORE the call while the mode actually loaded (info.cfg,
+    // every buffer size) is the former last_configuration. The mirror reproduces that state exactly (the reference's ARQ layer keeps its own
+    // bookkeeping, arq_common.cc:783-794, and never calls this member); load_configuration's "already current" test reads
+    // current_configuration, as the reference's does (:2489-2492).
     void return_to_last_configuration() {
-        const int now = current_configuration, back = last_configuration;
-        load_configuration(back);
-        last_configuration = back;
-        current_configuration = now;
-        std::swap(last_configuration, current_configuration);
+        load_configuration(last_configuration);
+        const int tmp = last_configuration;
+        last_configuration = current_configuration;
+        current_configuration = tmp;
     }
     // void cl_telecom_system::get_pre_equalization_channel() — telecom_system.cc:3108-3145: measured for carrier_frequency and installed;
     // transmit_bit / transmit_byte multiply the preamble and data grids with it (:474-494). The OFDM modes only (:1954).
     std::vector<std::complex<double>> pre_equalization_channel;
+    struct PreEqKey {
+        int M = -1, preamble = -1; double carrier = 0; float boost = 0; unsigned pilot_seed = 0, preamble_seed = 0;
+        bool operator==(const PreEqKey& o) const {
+            return M == o.M && preamble == o.preamble && carrier == o.carrier && boost == o.boost && pilot_seed == o.pilot_seed && preamble_seed == o.preamble_seed;
+        }
+    } pre_eq_key_;
     void get_pre_equalization_channel() {
         pre_equalization_channel.assign(info.Nc, std::complex<double>(0, 0));
         detail::check(mgpu_context_pre_equalization_channel(ctx_, carrier_frequency, reinterpret_cast<double*>(pre_equalization_channel.data())), ctx_,

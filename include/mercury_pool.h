@@ -47,6 +47,11 @@ typedef struct mgpu_pool_counters {
 int mgpu_pool_create(const mgpu_config* cfg, const int* devices, int n_devices, mgpu_pool** out);
 void mgpu_pool_destroy(mgpu_pool* pool);
 int mgpu_pool_size(const mgpu_pool* pool);
+/* Placement: every worker thread binds itself to the CPUs of its device's NUMA node (sysfs numa_node of the device's PCI address) and
+ * its context allocates its page-locked staging there, so that on a two-socket host eight devices' DMA streams read memory next to
+ * their own root complex (set MERCURY_POOL_AFFINITY=0 to leave the threads unbound). Returns that node, -1 when the platform names none.
+ * Caller-owned input arrays are the caller's to place: mgpu_alloc_host_near(device, bytes) (mercury_gpu.h). */
+int mgpu_pool_device_numa_node(mgpu_pool* pool, int i);
 mgpu_ctx* mgpu_pool_context(mgpu_pool* pool, int i);      /* the i-th device's context (for mgpu_get_info and the like) */
 const char* mgpu_pool_last_error(mgpu_pool* pool);
 int mgpu_pool_last_counters(mgpu_pool* pool, mgpu_pool_counters* out);

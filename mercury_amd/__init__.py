@@ -6,9 +6,9 @@ declared in ``include/mercury_gpu.h``), ``data/`` (the LDPC graphs as compact de
 shared-memory ring decoded payloads are published through, ``include/mercury_shm.h``).
 """
 from .physical_layer import (DEC_GBF, DEC_MINSUM, DEC_SPA, DEC_SPA_FAST, EXPORTED_SYMBOLS, LIB_PATH, MgpuError, RxPhy,
-                             RxPool, STATS_DTYPE, load_library, pool_shard)
+                             RxPool, STATS_DTYPE, device_props, load_library, pool_shard)
 
 from .shm import ShmRing  # noqa: E402
 
 __all__ = ["ShmRing", "RxPhy", "RxPool", "pool_shard", "MgpuError", "DEC_GBF", "DEC_SPA", "DEC_MINSUM", "DEC_SPA_FAST", "STATS_DTYPE", "load_library",
-           "LIB_PATH", "EXPORTED_SYMBOLS"]
+           "LIB_PATH", "EXPORTED_SYMBOLS", "device_props"]

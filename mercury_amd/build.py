@@ -17,8 +17,8 @@ LIB = os.path.join(HERE, "libmercury_gpu.so")
 TABLES = os.path.join(HERE, "data", "mercury_ldpc_tables.bin")
 
 HIP_SOURCES = ["api.hip", "rxloop.hip", "stages_api.hip", "stages.hip", "frontend.hip", "mfsk.hip", "ldpc.hip", "txgen.hip", "tx.hip", "stats.hip", "sync.hip"]
-CXX_SOURCES = ["tables.cpp", "shm_transport.cpp", "pool.cpp"]
-HEADERS = ["device_tables.h", "tables.hpp", "spa_math.h", "fft256.h", "fe_math.h", "glibc_trig.h", "glibc_trig_tables.h", "ctx.hpp", os.path.join(ROOT, "include", "mercury_gpu.h"),
+CXX_SOURCES = ["tables.cpp", "shm_transport.cpp", "pool.cpp", "numa.cpp"]
+HEADERS = ["device_tables.h", "tables.hpp", "numa.hpp", "spa_math.h", "fft256.h", "fe_math.h", "glibc_trig.h", "glibc_trig_tables.h", "ctx.hpp", os.path.join(ROOT, "include", "mercury_gpu.h"),
            os.path.join(ROOT, "include", "mercury_shm.h"), os.path.join(ROOT, "include", "mercury_rxloop.h"), os.path.join(ROOT, "include", "mercury_stages.h"),
            os.path.join(ROOT, "include", "mercury_tx.h"), os.path.join(ROOT, "include", "mercury_pool.h")]
 

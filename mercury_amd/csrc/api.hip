@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "numa.hpp"
 
 typedef void (*fe_kernel_t)(MgpuDev, const double*, int, float*, float*, float*, double*, MgpuTapsDev);
 static fe_kernel_t fe_kernel(int threads) { return threads == 1024 ? mgpu_frontend_kernel_t1024 : mgpu_frontend_kernel; }
@@ -127,6 +128,7 @@ void ctx_alloc(mgpu_ctx* c) {
     }
     switch (c->cfg.decoder) {
         case MGPU_DEC_SPA:
+            if (!t.graph.fp64_limit.empty()) throw std::runtime_error(t.graph.fp64_limit);
             c->lds_dec = mgpu_spa_lds_bytes(d.S, d.N);
             {
                 const int ne = std::max(4, (d.S + 1023) / 1024);      // rounds of 16 bins; the smallest instance runs 4 (tables sized to match)
@@ -147,6 +149,7 @@ void ctx_alloc(mgpu_ctx* c) {
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(mgpu_ldpc_gbf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_dec)));
             break;
         case MGPU_DEC_MINSUM: {
+            if (!t.graph.fp32_limit.empty()) throw std::runtime_error(t.graph.fp32_limit);
             c->lds_dec = mgpu_spa_fast_lds_bytes(c->ldev.Sg, d.N);
             c->dec_threads = 512;
             c->spa_kernel = mgpu_ldpc_minsum_kernel_t512;
@@ -154,6 +157,7 @@ void ctx_alloc(mgpu_ctx* c) {
             break;
         }
         case MGPU_DEC_SPA_FAST: {
+            if (!t.graph.fp32_limit.empty()) throw std::runtime_error(t.graph.fp32_limit);
             c->lds_dec = mgpu_spa_fast_lds_bytes(c->ldev.Sg, d.N);
             c->dec_threads = 512;            // 8 wavefronts per barrier domain: the kernel is bound by waits, not by issue (1024 threads: 1.4x slower)
             c->spa_kernel = mgpu_ldpc_spa_fast_kernel_t512;
@@ -486,6 +490,7 @@ int mgpu_create_explicit(const mgpu_config* cfg, const mgpu_explicit_params* xp_
         HIPCK(hipGetDeviceCount(&ndev));
         if (ndev < 1) throw HipError("no HIP device visible (the MI355X path has no CPU fallback)");
         HIPCK(hipSetDevice(cfg->device));
+        c->numa_node = mgpu_detail::device_numa_node(cfg->device);      // where the context's page-locked staging lives (-1: anywhere)
         mgpu_detail::ctx_alloc(c);
     } catch (const std::exception& e) {
         g_create_error = e.what();
@@ -531,6 +536,52 @@ void mgpu_destroy(mgpu_ctx* c) {
 void* mgpu_alloc_host(size_t bytes) {
     void* p = nullptr;
     return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+int mgpu_device_props_get(int device, mgpu_device_props* out) {
+    if (!out) return MGPU_ERR_ARG;
+    std::memset(out, 0, sizeof(*out));
+    out->numa_node = -1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return MGPU_ERR_DEVICE;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return MGPU_ERR_DEVICE;
+    out->compute_units = p.multiProcessorCount;
+    out->clock_khz = p.clockRate;
+    out->memory_clock_khz = p.memoryClockRate;
+    out->lds_bytes_per_cu = int(p.maxSharedMemoryPerMultiProcessor);
+    out->wavefront_size = p.warpSize;
+    out->hbm_bytes = p.totalGlobalMem;
+    std::snprintf(out->name, sizeof(out->name), "%s", p.name);
+    std::snprintf(out->gcn_arch, sizeof(out->gcn_arch), "%s", p.gcnArchName);
+    if (hipDeviceGetPCIBusId(out->pci_bus_id, int(sizeof(out->pci_bus_id)), device) != hipSuccess) out->pci_bus_id[0] = 0;
+    out->numa_node = mgpu_host_numa_node_of_pci(out->pci_bus_id);
+    return MGPU_OK;
+}
+
+extern "C++" {
+namespace mgpu_detail {
+// page-locked host memory on `node` (the GPU's NUMA node) when there is one: hipHostMallocNumaUser makes the runtime honour the calling
+// thread's memory policy, which prefers that node while the allocation (and the page-locking first touch) runs
+hipError_t host_alloc_on_node(void** p, size_t bytes, int node) {
+    if (node >= 0) {
+        mgpu_numa::PreferNode scope(node);
+        if (scope.active() && hipHostMalloc(p, bytes, hipHostMallocNumaUser) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+    }
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+int device_numa_node(int device) {
+    char id[32] = {0};
+    if (hipDeviceGetPCIBusId(id, int(sizeof(id)), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return mgpu_host_numa_node_of_pci(id);
+}
+}  // namespace mgpu_detail
+}  // extern "C++"
+
+void* mgpu_alloc_host_near(int device, size_t bytes) {
+    void* p = nullptr;
+    return mgpu_detail::host_alloc_on_node(&p, bytes ? bytes : 16, mgpu_detail::device_numa_node(device)) == hipSuccess ? p : nullptr;
 }
 void mgpu_free_host(void* p) { if (p) (void)hipHostFree(p); }
 
@@ -1145,8 +1196,8 @@ static int rx_one_frame(mgpu_ctx* c, const double* bb, uint8_t* payload, mgpu_fr
             // that live as long as the context (d_baseband may be reallocated by a larger batch later; the max_batch-sized
             // workspaces never are). Nothing is published in the context until the whole graph exists.
             if (!c->d_one_in) HIPCK(hipMalloc(&c->d_one_in, in_bytes));
-            if (!c->h_one_in) HIPCK(hipHostMalloc(&c->h_one_in, in_bytes, hipHostMallocDefault));
-            if (!c->h_one_out) HIPCK(hipHostMalloc(&c->h_one_out, out_bytes, hipHostMallocDefault));
+            if (!c->h_one_in) HIPCK(host_alloc_on_node(&c->h_one_in, in_bytes, c->numa_node));
+            if (!c->h_one_out) HIPCK(host_alloc_on_node(&c->h_one_out, out_bytes, c->numa_node));
             hipGraph_t graph = nullptr;
             HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             try {
@@ -1216,7 +1267,7 @@ static void rx_batch_pipelined(mgpu_ctx* c, const double* bb, int F, uint8_t* pa
     // arrays would block the host until the chunk's kernels have finished, i.e. before the next chunk's input copy could even
     // be queued, and nothing would overlap.
     const size_t out_bytes = size_t(c->max_batch) * (t.payload_stride + sizeof(MgpuStatsDev));
-    if (!c->h_out) HIPCK(hipHostMalloc(&c->h_out, out_bytes + 16, hipHostMallocDefault));
+    if (!c->h_out) HIPCK(host_alloc_on_node(&c->h_out, out_bytes + 16, c->numa_node));
     uint8_t* h_payload = static_cast<uint8_t*>(c->h_out);
     MgpuStatsDev* h_stats = reinterpret_cast<MgpuStatsDev*>(h_payload + ((size_t(c->max_batch) * t.payload_stride + 15) & ~size_t(15)));
     MgpuTapsDev none{};

@@ -89,6 +89,9 @@ T* upload(const std::vector<T>& v) {
     return d;
 }
 
+hipError_t host_alloc_on_node(void** p, size_t bytes, int node);   // api.hip
+int device_numa_node(int device);
+
 }  // namespace mgpu_detail
 using namespace mgpu_detail;
 
@@ -100,6 +103,7 @@ struct mgpu_ctx {
     std::vector<void*> owned;       // device allocations freed in destroy
     std::string err;
     int max_batch = 0;
+    int numa_node = -1;             // the device's NUMA node (sysfs), -1 when the platform names none: page-locked staging is allocated there
     // workspaces (device)
     double* d_baseband = nullptr;   // lazily sized for the host-buffer entry points
     size_t baseband_cap = 0;

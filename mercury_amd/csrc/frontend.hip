@@ -93,7 +93,8 @@ __host__ __device__ inline FeCarve fe_carve(int G, int nPilots, int nBits, int F
     const size_t cap = size_t(24 / FE_WAVES) > 0 ? size_t(24 / FE_WAVES) : 1;    // 80 registers per lane: 24 wavefronts per compute unit
     if (wgs > cap) wgs = cap;
     if (wgs < 1) wgs = 1;
-    size_t w = (lds_cu / wgs / block * block - fixed) / per_wave;
+    // ... less 256 bytes: round 4 measured three workgroups of 53,504 bytes resident and three of 53,760 (42 blocks exactly) not
+    size_t w = (lds_cu / wgs / block * block - 256 - fixed) / per_wave;
     c.fft_waves = int(w < 4 ? 4 : (w > size_t(FE_WAVES) ? size_t(FE_WAVES) : w));
     c.work = need > c.fft_waves * per_wave ? need : c.fft_waves * per_wave;
     c.total = fixed + c.work;

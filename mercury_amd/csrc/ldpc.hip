@@ -282,27 +282,37 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     constexpr int kRound = LDPC_THREADS * 8;                       // bytes of address table per round
     const spa_cptr64 bhead0 = (spa_cptr64)(T.bhead) + size_t(wave) * 4;
 
-    // Syndrome only (before the first iteration and, in a frame's first eight iterations, after every variable update): all rounds'
-    // addresses, masks and posteriors are requested before the first is used, so the pass waits for one L2 and one LDS round trip
-    // instead of one per round — it is pure latency, and at a mode's operating point there is one of these per iteration.
-    auto syndrome_pass = [&](int p) {
-        uint32_t alt[NE];
-        unsigned long long vmask[NE], ends[NE];
+    // Syndrome only (before the first iteration and, in a frame's first eight iterations, after every variable update): pure latency — one L2
+    // round trip for the rounds' addresses and lane masks, one LDS round trip for the posteriors, a dependent run of scalar instructions —
+    // and at a mode's operating point there is one of these per iteration. It comes in two halves: syn_fetch requests all rounds' addresses
+    // and masks (issued in FRONT of the work that precedes the pass, the variable update, so the L2 round trip is over when the barrier
+    // opens: round 4), syn_judge reads the posteriors and forms the parities.
+    struct SynPre { uint32_t alt[NE]; unsigned long long vmask[NE], ends[NE]; };
+    auto syn_fetch = [&](SynPre& q) {
+        uint32_t off = tid * 8;
+        asm volatile("" : "+v"(off));                  // a fetch per pass: hoisted out of the iteration loop these would be 6 + 24 registers to spill
+#pragma unroll
+        for (int r = 0; r < NE; ++r) q.alt[r] = __builtin_amdgcn_raw_buffer_load_b32(sadr, off, r * kRound, 0);
+#pragma unroll
+        for (int r = 0; r < NE; ++r) { q.vmask[r] = bhead0[r * 64]; q.ends[r] = bhead0[r * 64 + 1]; }
+    };
+    auto syn_pin = [&](SynPre& q) {                    // keeps the requests above where they were written (ahead of a barrier)
+#pragma unroll
+        for (int r = 0; r < NE; ++r) asm volatile("" : "+v"(q.alt[r]));
+    };
+    auto syn_judge = [&](const SynPre& q, int p) {
         double lt[NE];
 #pragma unroll
-        for (int r = 0; r < NE; ++r) alt[r] = __builtin_amdgcn_raw_buffer_load_b32(sadr, tid * 8, r * kRound, 0);
-#pragma unroll
-        for (int r = 0; r < NE; ++r) { vmask[r] = bhead0[r * 64]; ends[r] = bhead0[r * 64 + 1]; }
-#pragma unroll
-        for (int r = 0; r < NE; ++r) lt[r] = *ldsd(alt[r]);                // padding reads variable 0; masked out below
+        for (int r = 0; r < NE; ++r) lt[r] = *ldsd(q.alt[r]);              // padding reads variable 0; masked out below
 #pragma unroll
         for (int r = 0; r < NE; ++r) SPA_KEEP(lt[r]);                      // all of them here: the optimiser would sink each load to its (conditional) use
         bool unsat = false;
 #pragma unroll
         for (int r = 0; r < NE; ++r)
-            if (!unsat) unsat = bin_unsat(__ballot(lt[r] < 0) & vmask[r], ends[r]);
+            if (!unsat) unsat = bin_unsat(__ballot(lt[r] < 0) & q.vmask[r], q.ends[r]);
         if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
+    auto syndrome_pass = [&](int p) { SynPre q; syn_fetch(q); syn_judge(q, p); };
     // The check pass. Bins are handed out on demand: wavefront w starts with bin w, every further bin goes to whoever asks first (a counter
     // in LDS, asked for while the current bin is being worked on). The hardware issues the oldest wavefront of a SIMD first, so with a
     // fixed split (bin w + 16 r in round r: rounds 1-2) the first wavefronts of a workgroup finish long before the last ones and wait at the
@@ -381,17 +391,26 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
                 if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
             }
             if (tid == 0) { flag[it & 1] = 0; flag[2 + (it & 1)] = LDPC_THREADS / 64; }
-            var_update(va);
+            SynPre pre;
+            if (it < kSpecStart) syn_fetch(pre);
 #if SPA_VR_RESIDENT
-            if (tid + LDPC_THREADS < N) var_update4(vb.x, vb.y, vb.z);
+            // the records' fields are unpacked here, every iteration: unpacked once in front of the loop (what the optimiser prefers) they are
+            // thirteen more values to keep across the check pass, i.e. spills
+            VarRec qa = va;
+            spa_u32x4 qb = vb;
+            asm volatile("" : "+v"(qa.vi), "+v"(qa.w0), "+v"(qa.w1), "+v"(qa.w2), "+v"(qa.w3), "+v"(qa.w4), "+v"(qb));
+            var_update(qa);
+            if (tid + LDPC_THREADS < N) var_update4(qb.x, qb.y, qb.z);
 #else
+            var_update(va);
             if (tid + LDPC_THREADS < N) var_update(vb);
 #endif
+            if (it < kSpecStart) syn_pin(pre);
             SPA_STAMP(7);                           // 7: variable update done
             __syncthreads();
             SPA_STAMP(8);                           // 8: behind its barrier
             if (it < kSpecStart) {
-                syndrome_pass(it);
+                syn_judge(pre, it);
                 SPA_STAMP(3);
                 __syncthreads();
                 SPA_STAMP(4);

@@ -3,6 +3,7 @@
 // behaves exactly like G independent contexts driven from G threads.
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -11,6 +12,7 @@
 #include <vector>
 
 #include "../../include/mercury_pool.h"
+#include "numa.hpp"
 
 namespace {
 
@@ -19,6 +21,8 @@ thread_local std::string g_pool_create_error;     // what mgpu_pool_last_error(N
 struct Worker {
     mgpu_ctx* ctx = nullptr;
     int device = 0;
+    int numa_node = -1;             // the device's NUMA node (sysfs); the worker thread runs on that node's CPUs when there is one
+    bool bound = false;
     std::thread th;
     std::mutex m;
     std::condition_variable cv;
@@ -28,6 +32,10 @@ struct Worker {
     double ms = 0;
 
     void loop() {
+        // launches, waits and — on the host-buffer entry points — the staging copies of this device happen on this thread: keep it next to
+        // the device's root complex (MERCURY_POOL_AFFINITY=0 leaves the thread where the scheduler puts it)
+        const char* e = std::getenv("MERCURY_POOL_AFFINITY");
+        if (!(e && e[0] == '0')) bound = mgpu_numa::bind_thread_to_node(numa_node);
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             cv.wait(lk, [&] { return has_job || quit; });
@@ -133,6 +141,10 @@ int mgpu_pool_create(const mgpu_config* cfg, const int* devices, int n_devices, 
         Worker* w = new Worker();
         w->ctx = ctx;
         w->device = devices[g];
+        {
+            mgpu_device_props dp;
+            w->numa_node = mgpu_device_props_get(devices[g], &dp) == MGPU_OK ? dp.numa_node : -1;
+        }
         w->th = std::thread([w] { w->loop(); });
         p->w.push_back(w);
     }
@@ -152,6 +164,7 @@ void mgpu_pool_destroy(mgpu_pool* p) {
 }
 
 int mgpu_pool_size(const mgpu_pool* p) { return p ? int(p->w.size()) : 0; }
+int mgpu_pool_device_numa_node(mgpu_pool* p, int i) { return (p && i >= 0 && i < int(p->w.size())) ? p->w[i]->numa_node : -1; }
 mgpu_ctx* mgpu_pool_context(mgpu_pool* p, int i) { return (p && i >= 0 && i < int(p->w.size())) ? p->w[i]->ctx : nullptr; }
 const char* mgpu_pool_last_error(mgpu_pool* p) { return p ? p->err.c_str() : g_pool_create_error.c_str(); }
 

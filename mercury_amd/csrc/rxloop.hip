@@ -88,14 +88,14 @@ struct Workspace {
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_done) (void)hipEventDestroy(ev_done);
     }
-    Workspace(int W, int buf, int frame_n, size_t vals_per_window, int payload_stride)
+    Workspace(int W, int buf, int frame_n, size_t vals_per_window, int payload_stride, int numa_node)
         : d_pass(size_t(W) * buf * 8), d_bbi(size_t(W) * buf * 16), d_frames(size_t(W) * frame_n * 16), d_carrier(size_t(W) * 8),
           d_ia(size_t(W) * 128 * 4), d_ib(size_t(W) * 128 * 4), d_ic(size_t(W) * 4), d_vals(size_t(W) * vals_per_window * 8),
           d_sum(size_t(W) * 128 * 8), d_cnt(size_t(W) * 128 * 4), d_freq(size_t(W) * 16), d_meanh(size_t(W) * 8),
           d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * payload_stride), vals_per_window(vals_per_window) {
-        HIPCK(hipHostMalloc(&h_vals, size_t(W) * vals_per_window * 8, hipHostMallocDefault));
+        HIPCK(host_alloc_on_node(reinterpret_cast<void**>(&h_vals), size_t(W) * vals_per_window * 8, numa_node));      // control rounds' results: on the GPU's NUMA node
         pin_cap = std::max<size_t>(size_t(1) << 20, size_t(W) * 128 * 8 * 6);             // a few rounds of the largest index / result arrays
-        HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h_pin), pin_cap, hipHostMallocDefault));
+        HIPCK(host_alloc_on_node(reinterpret_cast<void**>(&h_pin), pin_cap, numa_node));
         HIPCK(hipStreamCreate(&side));
         HIPCK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
@@ -123,7 +123,7 @@ struct Loop {
             ctx->rxloop_ws = nullptr;
             const int buf = t.Nofdm * buffer_nsymb * kInterp, sym = t.Nofdm * kInterp;
             const size_t vals = size_t(std::max(buf / kCoarseStep + 2, 4 * sym + 2));       // coarse / fine candidate counts
-            ctx->rxloop_ws = new Workspace(W, buf, t.Nofdm * (t.Nsymb + t.preamble), vals, t.payload_stride);
+            ctx->rxloop_ws = new Workspace(W, buf, t.Nofdm * (t.Nsymb + t.preamble), vals, t.payload_stride, ctx->numa_node);
             ctx->rxloop_ws_windows = W;
             ctx->rxloop_ws_free = free_workspace;
         }
@@ -150,6 +150,9 @@ struct Loop {
     // page-locked staging area and the kernels read them THERE (the buffer's view): a 4 KB hipMemcpyAsync is a 5 us blit kernel plus the
     // gaps around it on the stream, and a call of 1024 windows made 400 of them (a fifth of its device time). A staging slot is reused
     // only after settle() has waited for the stream, so every kernel launched with a view has read it by then.
+    // INVARIANT: a buffer with a view may only be consumed by kernels launched on stream `s` — settle() waits for `s` alone, so a kernel on
+    // the side stream reading a view could still be running when its slot is handed out again. The side stream's kernels (signal level,
+    // upload slices) take device buffers only; keep it that way or give them their own settle().
     void up(DevBuf& d, const void* h, size_t bytes) {
         d.view = nullptr;
         if (void* p = ws.pin_take(bytes)) {

@@ -185,7 +185,7 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         for (uint32_t i = 0; i < N; ++i) {
             const uint32_t v = vorder[i], d = vdeg[v];
             if (d > 9) throw std::runtime_error("variable degree exceeds the unrolled update");
-            if (i >= 1024 && d > 4) throw std::runtime_error("variable degrees exceed the fp64 decoder's register layout (rows from 1024 on: at most 4 edges)");
+            if (i >= 1024 && d > 4) g.fp64_limit = "variable degrees exceed the fp64 decoder's register layout (rows from 1024 on: at most 4 edges)";
             g.vinfo[size_t(i) * 8] = v | (d << 11);
             for (uint32_t j = 0; j < d; ++j) {
                 const uint32_t slot = slot_of_edge[g.vedge[g.vptr[v] + j]];
@@ -234,7 +234,7 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
             for (uint32_t i = 0; i < N; ++i) {
                 const uint32_t v = vorder[i], d = vdeg[v];
                 // the fp32 decoders keep a lane's records (rows i, i + 512, ...) in 6 + 4 + 3 + 2 registers
-                if (d > (i < 512 ? 9u : i < 1024 ? 6u : i < 1536 ? 4u : 2u)) throw std::runtime_error("variable degrees exceed the fp32 decoders' register layout");
+                if (d > (i < 512 ? 9u : i < 1024 ? 6u : i < 1536 ? 4u : 2u)) g.fp32_limit = "variable degrees exceed the fp32 decoders' register layout (rows of 512: 9 / 6 / 4 / 2 edges)";
                 g.vinfo_g[size_t(i) * 8] = v | (d << 11);
                 for (uint32_t j = 0; j < d; ++j) {
                     const uint32_t slot = gslot_of_edge[g.vedge[g.vptr[v] + j]];

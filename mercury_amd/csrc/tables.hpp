@@ -57,6 +57,9 @@ struct LdpcGraph {
     std::vector<uint32_t> vinfo_g; // [N][8] like vinfo, slot indices in the grouped layout
     // the fp64 sum-product kernel's own tables (ldpc.hip, spa_decode): LDS byte offsets instead of indices, and the
     // product walk's execution masks tabulated per bin and step instead of compared per lane
+    // register-layout limits of individual kernels, recorded here and enforced where a context selects its decoder (api.hip: ctx_alloc), so
+    // that a graph one decoder cannot hold still loads for the others (GBF walks the plain lists and has no such limit)
+    std::string fp64_limit, fp32_limit;   // empty = fits; otherwise what the fp64 / the fp32 sum-product + min-sum kernels cannot hold
     int maxdeg = 0;                // largest check degree
     int DM = 0;                    // mask row length: the largest check degree rounded up to a multiple of 8 (the walk's group size)
     std::vector<uint32_t> sadr;    // [(rounds+1)*1024][2] per padded slot: LDS byte offset of its variable's posterior (variable*8), LDS byte address of its check's first message (8*N + check_start*8); 0 for padding

@@ -398,7 +398,10 @@ int mgpu_set_pre_equalization_channel(mgpu_ctx* c, const double* channel_c128) {
     if (!c) return MGPU_ERR_ARG;
     return guard(c, [&] {
         need(c->tab.mfsk_M == 0 || !channel_c128, "pre_equalization_channel: the OFDM modes only (telecom_system.cc:474-494)");
-        HIPCK(hipStreamSynchronize(c->stream));                  // no transmit call of this context still reads the old table
+        // No transmit call of this context may still be reading the old table or the preamble baseband made from it: such calls can run on
+        // a caller's stream (mgpu_transmit_byte_batch_dev, SINGLE / NO_FILTER / BATCH), which this context cannot name, so the whole device
+        // is drained — the table changes when a mode is loaded, not per frame.
+        HIPCK(hipDeviceSynchronize());
         if (channel_c128) {
             c->pre_eq.assign(channel_c128, channel_c128 + 2 * size_t(c->tab.Nc));
             if (!c->d_pre_eq_buf) c->d_pre_eq_buf = c->keep(upload(c->pre_eq));
@@ -424,8 +427,9 @@ int mgpu_transmit_byte_batch_dev(mgpu_ctx* c, const void* d_payload, int payload
         need(d_payload && d_passband, "bad argument");
         // the FIRST / MIDDLE / FLUSH messages of a stream share the context's three-frame history: calls on different streams would
         // race on it, so a stream call of the overlap-save kind must run on the context's own stream (stream == NULL)
-        need(!stream || cfg->message_location == MGPU_SINGLE_MESSAGE || cfg->message_location == MGPU_NO_FILTER_MESSAGE,
-             "FIRST / MIDDLE / FLUSH messages carry state between calls: pass stream = NULL (the context's stream)");
+        const bool stream_mode = cfg->message_location == MGPU_FIRST_MESSAGE || cfg->message_location == MGPU_MIDDLE_MESSAGE ||
+                                 cfg->message_location == MGPU_FLUSH_MESSAGE;       // SINGLE, NO_FILTER and BATCH keep nothing between calls
+        need(!stream || !stream_mode, "FIRST / MIDDLE / FLUSH messages carry state between calls: pass stream = NULL (the context's stream)");
         if (F == 0) return;
         transmit_dev(c, static_cast<const uint8_t*>(d_payload), payload_stride, static_cast<const int*>(d_nbytes), F, *cfg,
                      static_cast<double*>(d_passband), stream ? static_cast<hipStream_t>(stream) : c->stream);

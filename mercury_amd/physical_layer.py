@@ -107,6 +107,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mgpu_alloc_host", "mgpu_free_host", "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
     "mgpu_host_select_peak", "mgpu_host_fir_taps", "mgpu_host_preamble_carriers", "mgpu_host_mode_info",
+    "mgpu_device_props_get", "mgpu_alloc_host_near", "mgpu_host_numa_node_of_pci", "mgpu_host_numa_cpus", "mgpu_pool_device_numa_node",
     "mgpu_ldpc_batch", "mgpu_ldpc_encode_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_host_path_last", "mgpu_device_malloc", "mgpu_device_free", "mgpu_context_stream", "mgpu_synchronize", "mgpu_copy_to_host", "mgpu_copy_to_device",
     "mgpu_pool_rx_batch_dev", "mgpu_pool_ldpc_batch_dev", "mgpu_pool_txgen_dev",
@@ -136,16 +137,34 @@ class MgpuError(RuntimeError):
     pass
 
 
-def pinned_empty(shape, dtype):
-    """numpy array over page-locked host memory from mgpu_alloc_host (keep the array alive while it is in use; the
-    memory is released when the returned array's base object is collected)."""
+class DeviceProps(C.Structure):    # mgpu_device_props
+    _fields_ = [("compute_units", C.c_int), ("clock_khz", C.c_int), ("memory_clock_khz", C.c_int), ("lds_bytes_per_cu", C.c_int),
+                ("wavefront_size", C.c_int), ("numa_node", C.c_int), ("hbm_bytes", C.c_ulonglong),
+                ("name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("pci_bus_id", C.c_char * 32)]
+
+
+def device_props(device=0):
+    """mgpu_device_props_get: compute units, clocks, LDS per compute unit, PCI address and NUMA node of a device, as a dict."""
+    lib = load_library()
+    p = DeviceProps()
+    rc = lib.mgpu_device_props_get(C.c_int(device), C.byref(p))
+    if rc != 0:
+        raise MgpuError("mgpu_device_props_get(%d) failed (%d): no such device" % (device, rc))
+    return {n: (getattr(p, n).decode() if isinstance(getattr(p, n), bytes) else getattr(p, n)) for n, _ in DeviceProps._fields_}
+
+
+def pinned_empty(shape, dtype, device=None):
+    """numpy array over page-locked host memory from mgpu_alloc_host — or, with ``device``, from mgpu_alloc_host_near (pages on that
+    GPU's NUMA node). Keep the array alive while it is in use; the memory is released when the returned array's base object is collected."""
     lib = load_library()
     lib.mgpu_alloc_host.restype = C.c_void_p
     lib.mgpu_alloc_host.argtypes = [C.c_size_t]
+    lib.mgpu_alloc_host_near.restype = C.c_void_p
+    lib.mgpu_alloc_host_near.argtypes = [C.c_int, C.c_size_t]
     lib.mgpu_free_host.argtypes = [C.c_void_p]
     dt = np.dtype(dtype)
     n = int(np.prod(shape))
-    ptr = lib.mgpu_alloc_host(n * dt.itemsize)
+    ptr = lib.mgpu_alloc_host(n * dt.itemsize) if device is None else lib.mgpu_alloc_host_near(int(device), n * dt.itemsize)
     if not ptr:
         raise MgpuError("mgpu_alloc_host failed")
 
@@ -593,6 +612,10 @@ class RxPool:
         for n in INFO_FIELDS:
             setattr(self, n, getattr(i, n))
         self._ctx0 = ctx0
+
+    def numa_nodes(self):
+        """NUMA node of every context's device (mgpu_pool_device_numa_node; -1: the platform names none)."""
+        return [int(self.lib.mgpu_pool_device_numa_node(self.h, C.c_int(g))) for g in range(self.n_devices)]
 
     def _ck(self, rc):
         if rc != 0:

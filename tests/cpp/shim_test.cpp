@@ -128,7 +128,8 @@ int main(int argc, char** argv) {
                 fresh.load_configuration(other);
                 if (fresh.current_configuration != other || fresh.last_configuration != cfg) return 9;
                 fresh.return_to_last_configuration();
-                if (fresh.current_configuration != cfg || fresh.last_configuration != other || fresh.info.cfg != cfg) return 10;
+                // the reference's own bookkeeping (telecom_system.cc:3027-3034): the two members read as before the call, the loaded mode is the former last
+                if (fresh.current_configuration != other || fresh.last_configuration != cfg || fresh.info.cfg != cfg) return 10;
             }
             std::vector<int> too_long(pb + 1, 0);
             if (phy.transmit_byte(too_long.data(), pb + 1, audio.data(), MGPU_SINGLE_MESSAGE)) return 5;     // "message too long.. not sent."

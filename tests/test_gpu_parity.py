@@ -302,6 +302,31 @@ def test_spa_fast_agrees_with_oracle_where_both_converge(cfg):
     assert both >= ref_ok - 1 and both >= 8
 
 
+@pytest.mark.parametrize("cfg", [0, 8, 13, 16])
+def test_fp32_decoders_track_the_fp64_posteriors_iteration_by_iteration(cfg):
+    """The deterministic leg of the fp32 decoders' parity (their arithmetic is not the reference's, so bit-identity is not defined): on the
+    SAME decoder-input LLRs, stopped after exactly k flooding iterations (max_iters = k, frames below the waterfall so that nothing
+    converges earlier), the sign of every information bit's posterior must agree with the bit-exact fp64 decoder's on >= 99.9 % of the bits
+    for the fp32 sum-product decoder (same rule, fp32 rounding: only posteriors within rounding of zero may differ) and >= 90 % for
+    normalised min-sum (a different check-node rule: 95.8 % after one iteration on the rate-1/16 code, more on the others). Same inputs, same schedule, k = 1, 2, 5, 10."""
+    from mercury_amd import DEC_MINSUM, DEC_SPA, DEC_SPA_FAST
+    orc = Oracle(cfg, 50)
+    F = 64
+    bb, _ = _frames(orc, [OPERATING_ESN0[cfg] - 2.5] * F, seed=31)
+    flags = FLAGS_BASEBAND_TEST if cfg in (15, 16) else oraclelib.FLAGS_RECEIVE_BYTE
+    llr = np.stack([orc.rx(b, flags | oraclelib.FLAG_NO_LDPC)["llr_ldpc"] for b in bb])
+    for k in (1, 2, 5, 10):
+        ref_bits, ref_it = _rx(cfg, max_iters=k, decoder=DEC_SPA, max_batch=F).ldpc_decode(llr)
+        open_frames = ref_it == k + 1                        # the frames that ran all k iterations in the reference decoder
+        assert open_frames.sum() >= F // 2, (cfg, k, int(open_frames.sum()))
+        for dec, floor in ((DEC_SPA_FAST, 0.999), (DEC_MINSUM, 0.90)):
+            bits, it = _rx(cfg, max_iters=k, decoder=dec, max_batch=F).ldpc_decode(llr)
+            both = open_frames & (it == k + 1)
+            agree = float((bits[both] == ref_bits[both]).mean())
+            assert agree >= floor, (cfg, k, dec, agree)
+            assert both.sum() >= open_frames.sum() - 2, (cfg, k, dec)       # and it leaves (almost) the same frames open
+
+
 @pytest.mark.parametrize("max_iters", [1, 2, 5, 50])
 def test_fast_decoders_keep_the_iteration_count_convention(max_iters):
     """cl_ldpc::decode's return value (ldpc_decoder_SPA.cc:25-218): 0 = the input already was a codeword, k = converged after k iterations,
@@ -550,6 +575,34 @@ def test_bench_two_ranks_on_one_gpu():
     assert j["decoded_fraction"] > 0.97            # both ranks' frames decode (disjoint frame ranges, same seed)
     assert abs(j["value"] - 2 * 256 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-6 * j["value"]
     assert "roofline" in j and "cpu_baseline" not in j
+
+
+def test_bench_collective_path_over_rccl_and_two_ranks_share_one_gpu_fairly():
+    """8-GPU readiness on a one-GPU box. (1) The collective code path of bench.py over RCCL itself (backend nccl: process group on the
+    device, barrier, MAX / SUM all-reduces of device tensors) with one rank - RCCL refuses two ranks on one device, so the two-rank run
+    stays on gloo. (2) Two ranks time-sharing GPU 0 (gloo) process together what one rank processes alone, within 10 %: sharding adds
+    nothing but the barrier (the per-rank share of the N = 2 line is half of the N = 1 line)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "6", "--warmup", "2", "--frames", "2048", "--esn0", "-15", "--no-extras", "--no-cpu-baseline"]
+
+    def line(cmd, env=None):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ls = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(ls) == 1, r.stdout
+        return json.loads(ls[0])
+
+    one = line([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl"] + common,
+               env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert one["n_gpus"] == 1 and one["avg_iters_per_frame"] == 50.0 and one["machine"]["compute_units"] == 256
+    two = line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29643",
+                os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device"] + common)
+    assert two["n_gpus"] == 2 and two["avg_iters_per_frame"] == 50.0
+    assert abs(two["value"] / one["value"] - 1.0) < 0.10, (one["value"], two["value"])
 
 
 def test_bench_pool_two_contexts_on_one_gpu():

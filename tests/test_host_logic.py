@@ -160,3 +160,54 @@ def test_host_filter_designs_and_preamble_match_the_oracle():
         assert lib.mgpu_host_preamble_carriers(C.c_int(cfg), out.ctypes.data_as(C.c_void_p), C.byref(ns)) == 0
         assert ns.value == o.preamble_nsymb and np.array_equal(out[: ns.value].ravel(), o.preamble())
     assert lib.mgpu_host_preamble_carriers(C.c_int(55), out.ctypes.data_as(C.c_void_p), C.byref(ns)) != 0
+
+
+def test_numa_placement_lookups_without_a_gpu(tmp_path, monkeypatch):
+    """SURVEY.md §8 row e, host side: the sysfs lookups behind mgpu_alloc_host_near / the pool's worker placement — NUMA node of a PCI
+    address, CPUs of a node — against a fabricated sysfs tree; without a device mgpu_device_props_get reports MGPU_ERR_DEVICE."""
+    import ctypes as C
+    from mercury_amd import load_library
+    from mercury_amd.physical_layer import DeviceProps
+    lib = load_library()
+    lib.mgpu_host_numa_node_of_pci.argtypes = [C.c_char_p]
+    root = tmp_path / "sys"
+    (root / "bus/pci/devices/0000:c1:00.0").mkdir(parents=True)
+    (root / "bus/pci/devices/0000:c1:00.0/numa_node").write_text("1\n")
+    (root / "bus/pci/devices/0000:05:00.0").mkdir(parents=True)
+    (root / "bus/pci/devices/0000:05:00.0/numa_node").write_text("-1\n")
+    (root / "devices/system/node/node1").mkdir(parents=True)
+    (root / "devices/system/node/node1/cpulist").write_text("16-19,48-49,63\n")
+    monkeypatch.setenv("MERCURY_SYSFS_ROOT", str(root))
+    assert lib.mgpu_host_numa_node_of_pci(b"0000:C1:00.0") == 1          # HIP spells the address in upper case, sysfs in lower case
+    assert lib.mgpu_host_numa_node_of_pci(b"0000:05:00.0") == -1         # the platform reports no affinity
+    assert lib.mgpu_host_numa_node_of_pci(b"0000:ff:00.0") == -1         # no such device
+    cpus = (C.c_int * 16)()
+    n = lib.mgpu_host_numa_cpus(C.c_int(1), cpus, C.c_int(16))
+    assert n == 7 and list(cpus[:7]) == [16, 17, 18, 19, 48, 49, 63]
+    assert lib.mgpu_host_numa_cpus(C.c_int(5), cpus, C.c_int(16)) == 0
+    import torch
+    if not torch.cuda.is_available():
+        p = DeviceProps()
+        assert lib.mgpu_device_props_get(C.c_int(0), C.byref(p)) == 2   # MGPU_ERR_DEVICE
+
+
+def test_bench_dry_run_prints_the_shard_map_without_a_gpu():
+    """`bench.py --gpus 8 --dry-run`: the driver's 8-GPU launch, as a shard map - disjoint, contiguous, complete global frame ranges per rank
+    and input batch - produced without touching a device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--frames", "4096", "--dry-run"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["dry_run"] and j["n_gpus"] == 8 and j["collectives_on_the_data_path"] == 0 and j["frames_per_step_total"] == 8 * 4096
+    assert [k["rank"] for k in j["ranks"]] == list(range(8)) and len({k["device"] for k in j["ranks"]}) == 8
+    for b in range(2):
+        at = b * 8 * 4096
+        for k in j["ranks"]:
+            lo, hi = k["global_frames_by_input_batch"][b]
+            assert lo == at and hi - lo == 4096 == k["frames_per_step"]
+            at = hi

@@ -227,3 +227,35 @@ def test_pipelined_host_entry_point_equals_one_launch(cfg, monkeypatch):
     assert np.array_equal(out["payload"], ref["payload"]) and out["stats"].tobytes() == ref["stats"].tobytes()
     assert int((ref["stats"]["message_decoded"] != 0).sum()) >= F // 2
     rx.close()
+
+
+@pytest.mark.gpu
+def test_device_props_and_numa_placed_staging():
+    """SURVEY.md §8 row e, placement: the device's properties come from the HIP runtime (what bench.py prices the vector unit with), its
+    NUMA node from sysfs; page-locked memory allocated near the device works like any other input buffer, and a pool reports the same
+    node for its contexts' devices (its workers bind themselves there, its contexts' staging is allocated there)."""
+    from mercury_amd import RxPhy, RxPool, device_props
+    from mercury_amd.physical_layer import pinned_empty
+    p = device_props(0)
+    assert p["compute_units"] == 256 and p["wavefront_size"] == 64 and p["gcn_arch"].startswith("gfx950")
+    assert p["lds_bytes_per_cu"] == 160 * 1024 and p["hbm_bytes"] > 200e9 and 1_000_000 < p["clock_khz"] < 3_000_000
+    assert len(p["pci_bus_id"]) >= 7 and p["numa_node"] >= -1
+    lib = RxPhy(8, max_batch=1).lib
+    lib.mgpu_host_numa_node_of_pci.argtypes = [C.c_char_p]
+    assert lib.mgpu_host_numa_node_of_pci(p["pci_bus_id"].encode()) == p["numa_node"]
+    orc = oraclelib.Oracle(8, 50)
+    frames = [orc.gen_frame(SEED, 900 + f, oraclelib.noise_amp_for(OPERATING_ESN0[8] + 1.0)) for f in range(6)]
+    bb = np.stack([f[0] for f in frames])
+    near = pinned_empty(bb.shape, np.complex128, device=0)
+    near[...] = bb
+    rx = RxPhy(8, max_batch=8)
+    a, b = rx.receive(bb), rx.receive(near)
+    assert np.array_equal(a["payload"], b["payload"]) and a["stats"].tobytes() == b["stats"].tobytes()
+    for f in range(6):
+        assert np.array_equal(a["payload"][f][: orc.payload_bytes], frames[f][1].astype(np.uint8))
+    rx.close()
+    pool = RxPool(8, [0, 0], max_batch=8)
+    assert pool.numa_nodes() == [p["numa_node"]] * 2
+    out = pool.receive(near)
+    assert np.array_equal(out["payload"], a["payload"])
+    pool.close()

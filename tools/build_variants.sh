@@ -18,7 +18,7 @@ wait
 for spec in "$@"; do
   head=${spec%%:*}
   name=${head%%@*}; unit=ldpc.hip; [ "$head" != "$name" ] && unit=${head#*@}
-  objs=$(ls $B/*.o | grep -v "/variant\." | grep -v "/ldpc\.[a-zA-Z0-9_]*\.o$" | grep -v "/$unit.o$")
+  objs=$(ls $B/*.o | grep -v "/variant\." | grep -v "/$unit.o$")
   hipcc --offload-arch=gfx950 -shared -fPIC -o mercury_amd/_variants/lib_$name.so $objs $B/variant.$name.o -lpthread -lrt
   echo built mercury_amd/_variants/lib_$name.so
 done
