@@ -485,12 +485,17 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     SPA_STAMP_DECL(F);
     SPA_STAMP(1);
     constexpr int kRows = (kN + THREADS - 1) / THREADS;      // channel LLRs in registers: row i of the variable records belongs to one lane
+    // A posterior lives at its variable's ROW (LdpcGraph::vinfo_g's order), not at the variable's number: the variable update's stores are
+    // then consecutive, and the host orders the rows so that the 32 posteriors a half-wavefront of the check pass gathers lie in 32
+    // different LDS banks (tables.cpp, "bank-aware placement"). The frame's LLRs are fetched by variable number, once.
     uint32_t vrow[kRows];
+    float li[kRows];
 #pragma unroll
-    for (int k = 0; k < kRows; ++k) {                        // the frame's LLRs: coalesced; each lane then picks its rows' variables from LDS
+    for (int k = 0; k < kRows; ++k) {
         const int i = tid + k * THREADS;
         vrow[k] = i < N ? T.vinfo_g[size_t(i) * 8] & 0x7ff : 0u;
-        if (i < N) Lt[i] = llr_in[size_t(f) * N + i];
+        li[k] = i < N ? llr_in[size_t(f) * N + vrow[k]] : 0.0f;
+        if (i < N) Lt[i] = li[k];
     }
     const uint32_t* __restrict__ gdesc = T.gdesc;
     // the group sizes of the wavefront's bins, 3 bits per round, in one scalar register pair (a scalar load per round put its latency
@@ -499,9 +504,6 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     const uint64_t kpack = ((cptr64)(T.gkpack))[__builtin_amdgcn_readfirstlane(tid >> 6)];
     if (tid == 0) { flag[0] = 0; flag[1] = 0; }
     __syncthreads();
-    float li[kRows];
-#pragma unroll
-    for (int k = 0; k < kRows; ++k) li[k] = Lt[vrow[k]];
 
     // any group of 2^kind lanes with an odd number of set bits? fold the ballot onto each group's lowest lane
     auto groups_unsat = [&](unsigned long long m, uint32_t kind) -> bool {
@@ -627,9 +629,9 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         }
         return q;
     };
-    auto var_update = [&](auto maxs_tag, const VarRec& q, float s) {       // s: the variable's channel LLR
+    auto var_update = [&](auto maxs_tag, const VarRec& q, float s, int row) {       // s: the variable's channel LLR
         constexpr int MAXS = decltype(maxs_tag)::value;
-        const uint32_t v = q.vi & 0x7ff, deg = q.vi >> 11;
+        const uint32_t deg = q.vi >> 11;
         const float m0 = M[q.w0 & 0xffff], m1 = M[q.w0 >> 16];
         s = deg > 0 ? s + m0 : s; s = deg > 1 ? s + m1 : s;
         if constexpr (MAXS > 2) {
@@ -650,7 +652,7 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
                 }
             }
         }
-        Lt[v] = s;
+        Lt[row] = s;
     };
     static_assert(kRows == 4, "the variable records are specialised for four rows of 512");
     const std::integral_constant<int, 9> s9; const std::integral_constant<int, 6> s6; const std::integral_constant<int, 4> s4; const std::integral_constant<int, 2> s2;
@@ -666,16 +668,18 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
         if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
         if (tid == 0) flag[it & 1] = 0;
-        var_update(s9, vr0, li[0]);
-        var_update(s6, vr1, li[1]);
-        var_update(s4, vr2, li[2]);
-        if (tid + 3 * THREADS < N) var_update(s2, vr3, li[3]);
+        var_update(s9, vr0, li[0], tid);
+        var_update(s6, vr1, li[1], tid + THREADS);
+        var_update(s4, vr2, li[2], tid + 2 * THREADS);
+        if (tid + 3 * THREADS < N) var_update(s2, vr3, li[3], tid + 3 * THREADS);
         SPA_STAMP(7);
         __syncthreads();
         SPA_STAMP(8);
     }
     SPA_STAMP(9);
-    for (int v = tid; v < N; v += THREADS) hard[v] = Lt[v] < 0;
+#pragma unroll
+    for (int k = 0; k < kRows; ++k)
+        if (tid + k * THREADS < N) hard[vrow[k]] = Lt[tid + k * THREADS] < 0;       // hard decisions by variable number
     __syncthreads();
     decode_tail(T, f, hard, bytes, iteration, bits_out, iters_out, payload_out, stats_out, variance_in, snr_variance_in);
     SPA_STAMP(10);

@@ -5,6 +5,8 @@
 #include <complex>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 
 namespace mgpu {
@@ -109,7 +111,7 @@ std::vector<uint8_t> make_pilot_lattice(int Nsymb, int Nc) {
     return t;
 }
 
-LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
+static LdpcGraph load_graph_uncached(int K, const uint8_t* blob, size_t size) {
     auto rd32 = [&](size_t off) { uint32_t x; if (off + 4 > size) throw std::runtime_error("LDPC table blob truncated"); std::memcpy(&x, blob + off, 4); return x; };
     if (size < 12 || std::memcmp(blob, "MLDP", 4) != 0 || rd32(4) != 1) throw std::runtime_error("LDPC table blob: bad magic/version");
     const uint32_t nrates = rd32(8);
@@ -216,23 +218,152 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
             g.gdesc.assign((rounds + 1) * 512, 0u);
             g.gkind.assign((rounds + 1) * 8, 0u);
             g.gkpack.assign(8, 0ull);
-            std::vector<uint32_t> gslot_of_edge(E);
+            // ---- bank-aware placement (round 4) --------------------------------------------------------------------------------------
+            // The two scattered LDS accesses of these kernels are 4-byte gathers: the check pass reads the posterior of every slot's variable,
+            // the variable update reads the messages of every row's edges. A wave64 ds_read_b32 is served as two groups of 32 lanes, one cycle
+            // each when the 32 addresses fall into 32 different banks ((address / 4) mod 32) and one more per extra address on a bank; with
+            // variables and slots where the graph happens to put them that is ~3.5 cycles per group (PMC round 3: two conflict cycles per LDS
+            // instruction, a fifth of the kernels' time). Two things are free to choose, and neither changes any arithmetic:
+            //  (A) where a variable's posterior lives. It is stored at its ROW (the order the variable update walks, sorted by degree) instead
+            //      of at its number, which makes the update's own stores consecutive, and inside every run of 32 rows the variables are
+            //      permuted so that the 32 variables a half-wavefront of the check pass gathers lie in different banks;
+            //  (B) which lane of its check's group an edge sits on (the product over a group is an all-reduce: any order). The edges are
+            //      permuted inside their group - never across the two halves of a bin - so that the j-th messages of 32 consecutive rows lie in
+            //      different banks.
+            // Both are descents on sum(count^2) over (access, bank) by pairwise swaps: deterministic, a few milliseconds per graph.
+            std::vector<uint32_t> lane_of_edge(E), bin_of_edge(E), group_of_edge(E), gsize_of_edge(E);
             for (size_t b = 0; b < bins; ++b) {
                 g.gkind[b] = kinds[b];
                 g.gkpack[b & 7] |= uint64_t(kinds[b]) << (3 * (b >> 3));
                 const uint32_t gsz = 1u << kinds[b];
                 for (size_t q = 0; q < bin_checks[b].size(); ++q) {
-                    const uint32_t c = bin_checks[b][q], base = uint32_t(b) * 64 + uint32_t(q) * gsz;
+                    const uint32_t c = bin_checks[b][q];
                     for (uint32_t j = 0; j < cdeg[c]; ++j) {
                         const uint32_t eo = g.cptr[c] + j;
-                        g.gdesc[base + j] = 0x80000000u | uint32_t(g.cvar[eo]);
-                        gslot_of_edge[eo] = base + j;
+                        lane_of_edge[eo] = uint32_t(q) * gsz + j;
+                        bin_of_edge[eo] = uint32_t(b);
+                        group_of_edge[eo] = c;
+                        gsize_of_edge[eo] = gsz;
                     }
                 }
             }
+            // (A) rows: the degree order, permuted inside runs of 32
+            std::vector<uint32_t> vorder_g = vorder, row_of(N);
+            {
+                // distinct variables per half-bin (two checks of a bin may share a variable: one address, a broadcast, no conflict)
+                std::vector<std::vector<uint32_t>> halves_of_var(N);
+                for (uint32_t c = 0; c < P; ++c)
+                    for (uint32_t j = 0; j < cdeg[c]; ++j) {
+                        const uint32_t eo = g.cptr[c] + j, h = bin_of_edge[eo] * 2 + (lane_of_edge[eo] >= 32 ? 1u : 0u);
+                        auto& hv = halves_of_var[g.cvar[eo]];
+                        if (std::find(hv.begin(), hv.end(), h) == hv.end()) hv.push_back(h);
+                    }
+                std::vector<int> cnt(bins * 2 * 32, 0);
+                auto bump = [&](uint32_t v, uint32_t bank, int d) { long long delta = 0; for (uint32_t h : halves_of_var[v]) { int& x = cnt[size_t(h) * 32 + bank]; delta += d > 0 ? 2 * x + 1 : 1 - 2 * x; x += d; } return delta; };
+                for (uint32_t i = 0; i < N; ++i) bump(vorder_g[i], i & 31, +1);
+                uint32_t lcg = 12345u;                                   // sideways moves (no change of the objective) are taken on a fixed coin
+                auto coin = [&] { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 16) & 1u; };
+                // two rows may trade places when that keeps the update's register layout and its wavefront-uniform early exits: inside a run of 32
+                // rows always, across runs when the degrees are equal and both rows belong to the same block of 512
+                auto try_swap = [&](uint32_t ia, uint32_t ib) {
+                    const uint32_t va = vorder_g[ia], vb = vorder_g[ib];
+                    if ((ia & 31) == (ib & 31)) return false;
+                    const long long d = bump(va, ia & 31, -1) + bump(vb, ib & 31, -1) + bump(va, ib & 31, +1) + bump(vb, ia & 31, +1);
+                    if (d < 0 || (d == 0 && coin())) { std::swap(vorder_g[ia], vorder_g[ib]); return d < 0; }
+                    bump(va, ib & 31, -1); bump(vb, ia & 31, -1); bump(va, ia & 31, +1); bump(vb, ib & 31, +1);
+                    return false;
+                };
+                for (int sweep = 0, idle = 0; sweep < 200 && idle < 6; ++sweep) {
+                    bool improved = false;
+                    for (uint32_t ia = 0; ia < N; ++ia) {
+                        const uint32_t lo = ia & ~31u, hi = std::min<uint32_t>(lo + 32, N);
+                        for (uint32_t ib = ia + 1; ib < hi; ++ib) improved |= try_swap(ia, ib);
+                        // same degree, same block of 512, another run
+                        for (uint32_t ib = hi; ib < N && ib / 512 == ia / 512 && vdeg[vorder_g[ib]] == vdeg[vorder_g[ia]]; ++ib) improved |= try_swap(ia, ib);
+                    }
+                    idle = improved ? 0 : idle + 1;
+                }
+                for (uint32_t i = 0; i < N; ++i) row_of[vorder_g[i]] = i;
+            }
+            // (B) lanes: which access an edge belongs to = (run of 32 rows of its variable, its index in the variable's slot order)
+            {
+                std::vector<uint32_t> access_of_edge(E);
+                for (uint32_t v = 0; v < N; ++v)
+                    for (uint32_t j = 0; j < vdeg[v]; ++j) access_of_edge[g.vedge[g.vptr[v] + j]] = (row_of[v] / 32) * 9 + j;
+                std::vector<int> cnt(size_t((N + 31) / 32) * 9 * 32, 0);
+                auto at = [&](uint32_t e, uint32_t lane) -> int& { return cnt[size_t(access_of_edge[e]) * 32 + (lane & 31)]; };
+                for (uint32_t e2 = 0; e2 < E; ++e2) ++at(e2, lane_of_edge[e2]);
+                uint32_t lcg = 54321u;
+                auto coin = [&] { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 16) & 1u; };
+                for (int sweep = 0, idle = 0; sweep < 200 && idle < 6; ++sweep) {
+                    bool improved = false;
+                    for (uint32_t c = 0; c < P; ++c) {
+                        const uint32_t e0 = g.cptr[c], d = cdeg[c];
+                        if (d == 0) continue;
+                        const uint32_t gsz = gsize_of_edge[e0], gbase = lane_of_edge[e0] - (lane_of_edge[e0] % gsz);
+                        // the lanes of the group, used or free; an edge may move to any lane of its group inside its half of the bin
+                        std::vector<int> edge_at(gsz, -1);
+                        for (uint32_t j = 0; j < d; ++j) edge_at[lane_of_edge[e0 + j] - gbase] = int(e0 + j);
+                        for (uint32_t a = 0; a < gsz; ++a)
+                            for (uint32_t b2 = a + 1; b2 < gsz; ++b2) {
+                                if (((gbase + a) ^ (gbase + b2)) & 32) continue;
+                                const int ea = edge_at[a], eb = edge_at[b2];
+                                if (ea < 0 && eb < 0) continue;
+                                long long dlt = 0;
+                                auto mv = [&](int e2, uint32_t from, uint32_t to) { if (e2 < 0) return; int& x = at(uint32_t(e2), from); dlt += 1 - 2 * x; --x; int& y = at(uint32_t(e2), to); dlt += 2 * y + 1; ++y; };
+                                mv(ea, gbase + a, gbase + b2); mv(eb, gbase + b2, gbase + a);
+                                if (dlt < 0 || (dlt == 0 && coin())) {
+                                    if (ea >= 0) lane_of_edge[ea] = gbase + b2;
+                                    if (eb >= 0) lane_of_edge[eb] = gbase + a;
+                                    std::swap(edge_at[a], edge_at[b2]);
+                                    improved |= dlt < 0;
+                                } else { mv(ea, gbase + b2, gbase + a); mv(eb, gbase + a, gbase + b2); }
+                            }
+                    }
+                    // ... and two groups of a bin may trade places inside their half (a group of 8 lanes reaches only 8 of the 32 banks: when more
+                    // than 8 of an access's edges sit in groups at the same offset, no order inside the groups separates them)
+                    for (size_t b = 0; b < bins; ++b) {
+                        const uint32_t gsz = 1u << kinds[b];
+                        if (gsz >= 32) continue;
+                        const uint32_t per_half = 32 / gsz;
+                        std::vector<std::vector<uint32_t>> members(64 / gsz);          // edges per group position
+                        for (uint32_t c : bin_checks[b])
+                            for (uint32_t j = 0; j < cdeg[c]; ++j) members[lane_of_edge[g.cptr[c] + j] / gsz].push_back(g.cptr[c] + j);
+                        for (uint32_t half = 0; half < 2; ++half)
+                            for (uint32_t pa = 0; pa < per_half; ++pa)
+                                for (uint32_t pb = pa + 1; pb < per_half; ++pb) {
+                                    const uint32_t ga = half * per_half + pa, gb = half * per_half + pb;
+                                    if (members[ga].empty() && members[gb].empty()) continue;
+                                    const int shift = int(gb - ga) * int(gsz);
+                                    long long dlt = 0;
+                                    auto mvg = [&](const std::vector<uint32_t>& es, int sh) {
+                                        for (uint32_t e2 : es) { int& x = at(e2, lane_of_edge[e2]); dlt += 1 - 2 * x; --x; }
+                                        for (uint32_t e2 : es) { int& y = at(e2, uint32_t(int(lane_of_edge[e2]) + sh)); dlt += 2 * y + 1; ++y; }
+                                    };
+                                    mvg(members[ga], shift); mvg(members[gb], -shift);
+                                    if (dlt < 0 || (dlt == 0 && coin())) {
+                                        for (uint32_t e2 : members[ga]) lane_of_edge[e2] = uint32_t(int(lane_of_edge[e2]) + shift);
+                                        for (uint32_t e2 : members[gb]) lane_of_edge[e2] = uint32_t(int(lane_of_edge[e2]) - shift);
+                                        std::swap(members[ga], members[gb]);
+                                        improved |= dlt < 0;
+                                    } else {
+                                        // undo the counts (the lanes were not changed)
+                                        for (uint32_t e2 : members[ga]) { --at(e2, uint32_t(int(lane_of_edge[e2]) + shift)); ++at(e2, lane_of_edge[e2]); }
+                                        for (uint32_t e2 : members[gb]) { --at(e2, uint32_t(int(lane_of_edge[e2]) - shift)); ++at(e2, lane_of_edge[e2]); }
+                                    }
+                                }
+                    }
+                    idle = improved ? 0 : idle + 1;
+                }
+            }
+            std::vector<uint32_t> gslot_of_edge(E);
+            for (uint32_t eo = 0; eo < E; ++eo) {
+                gslot_of_edge[eo] = bin_of_edge[eo] * 64 + lane_of_edge[eo];
+                g.gdesc[gslot_of_edge[eo]] = 0x80000000u | row_of[g.cvar[eo]];          // the posterior's index = the variable's row
+            }
             g.vinfo_g.assign(size_t(N) * 8, 0u);
             for (uint32_t i = 0; i < N; ++i) {
-                const uint32_t v = vorder[i], d = vdeg[v];
+                const uint32_t v = vorder_g[i], d = vdeg[v];
                 // the fp32 decoders keep a lane's records (rows i, i + 512, ...) in 6 + 4 + 3 + 2 registers
                 if (d > (i < 512 ? 9u : i < 1024 ? 6u : i < 1536 ? 4u : 2u)) g.fp32_limit = "variable degrees exceed the fp32 decoders' register layout (rows of 512: 9 / 6 / 4 / 2 edges)";
                 g.vinfo_g[size_t(i) * 8] = v | (d << 11);
@@ -278,6 +409,19 @@ LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
         return g;
     }
     throw std::runtime_error("LDPC table blob has no graph for this rate");
+}
+
+// The layouts are functions of the blob alone and take a few hundred milliseconds to place (the bank-aware descent above): contexts of one
+// process share them (a gear-shifting caller re-creates contexts of the same eight codes over and over).
+LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
+    static std::mutex m;
+    static std::map<std::pair<uint64_t, int>, LdpcGraph> cache;
+    uint64_t h = 1469598103934665603ull;                         // FNV-1a of the blob: a file-supplied table set (MERCURY_LDPC_TABLES) gets its own entries
+    for (size_t i = 0; i < size; ++i) { h ^= blob[i]; h *= 1099511628211ull; }
+    std::lock_guard<std::mutex> lk(m);
+    auto it = cache.find({h ^ size, K});
+    if (it == cache.end()) it = cache.emplace(std::make_pair(h ^ size, K), load_graph_uncached(K, blob, size)).first;
+    return it->second;
 }
 
 }  // namespace

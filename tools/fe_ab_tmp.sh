@@ -1,15 +1,9 @@
 cd /root/repo
-for v in base fe7 base fe7; do
-  lib=""; [ "$v" != base ] && lib=$PWD/mercury_amd/_variants/lib_$v.so
-  MERCURY_GPU_LIB=$lib python bench.py --decoder spa_fast --esn0 3.5 --no-extras --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$v frontend %.4f ms' % (d['kernel_ms']['frontend']))"
-done
-for v in base fe7; do
-  lib=""; [ "$v" != base ] && lib=$PWD/mercury_amd/_variants/lib_$v.so
-  echo "== $v"; MERCURY_GPU_LIB=$lib python tools/fe_phases.py 8 4096 3.5 2>/dev/null
-  MERCURY_GPU_LIB=$lib python -c "
-import sys; sys.path.insert(0,'.')
-from mercury_amd import RxPhy
-rx=RxPhy(8,max_batch=8)
-print('occupancy calc', rx.lib.mgpu_debug_occupancy(rx.h,0), 'lds', rx.lib.mgpu_debug_occupancy(rx.h,1))"
-done
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fast or minsum or fp32 or mfsk" 2>&1 | tail -3
+tools/r04_ab.sh "base old" "spa_fast minsum" "-15 3.5" 2>&1
+tools/r04_ab.sh "base old" "spa_fast" "-15 20" 16 2>&1
+tools/r04_ab.sh "base old" "spa_fast" "-15 -7" 0 2>&1 | tail -4
+tools/pmc_any.sh ldpc gpurun_out/pmc_lds_new.json -- python bench.py --decoder spa_fast --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+python -c "
+import json; d=json.load(open('gpurun_out/pmc_lds_new.json'))
+for k,v in d.items(): print(k, {c:round(v[c]) for c in ('SQ_INSTS_LDS','SQ_LDS_BANK_CONFLICT','SQ_LDS_IDX_ACTIVE','SQ_ACTIVE_INST_LDS','SQ_WAIT_INST_LDS') if c in v})"
