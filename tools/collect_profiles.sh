@@ -1,13 +1,13 @@
 #!/bin/bash
 # Reproduces the evidence under profiles/ on a GPU box (run from the repo root; writes to gpurun_out/$R/ with R = the round prefix,
-# default r03; copy what you want judged into profiles/). Counter passes are separate rocprofv3 runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md
+# default r04; copy what you want judged into profiles/). Counter passes are separate rocprofv3 runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md
 # prescribes; never combine --pmc with sys/hip/hsa traces on this pool.
 #   tools/collect_profiles.sh            bench lines + kernel stats + PMC opcode mix / stall counters (cfg 8: spa, spa_fast, minsum) + opcode costs
 #   tools/collect_profiles.sh sweep      additionally: decoder comparison on all 20 modes, the 20-mode throughput sweep, sync blocks,
 #                                        receive_byte chain, host-buffer path, transmit chain
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-R=${R:-r03}
+R=${R:-r04}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -19,13 +19,18 @@ for d in spa spa_fast minsum; do
   "$ROOT/tools/collect_pmc_mix.sh" $d "$OUT/pmc_mix_$d.json" > /dev/null 2> "$OUT/pmc_mix_$d.err" || true
 done
 "$ROOT/tools/collect_pmc_mix.sh" spa "$OUT/pmc_mix_spa_cfg16.json" --cfg 16 > /dev/null 2> "$OUT/pmc_mix_spa_cfg16.err" || true
+# the operating-point launch (mode 8 at Es/N0 3.5 dB, 3.75 iterations per frame: SURVEY.md 8d C2's second point) gets PMC passes of its own
+OPES=${OPES:-3.5}
+for d in spa spa_fast minsum; do
+  "$ROOT/tools/collect_pmc_mix.sh" $d "$OUT/pmc_mix_${d}_op.json" --esn0 $OPES > /dev/null 2> "$OUT/pmc_mix_${d}_op.err" || true
+done
 python - "$OUT" "$ROOT" "$R" <<'PY'
 import json, sys, os
 out, root, R = sys.argv[1:4]
 sys.path.insert(0, root)
 from mercury_amd.build import decoder_digest
 mix = {"decoder_digest": decoder_digest(),
-       "note": "average per launch of the headline workload (bench.py defaults: 4096 mode-8 frames, 50 iterations each); separate rocprofv3 --pmc "
+       "note": "average per launch of the headline workload (bench.py defaults: 4096 mode-8 frames, 50 iterations each; keys ending in _op: the same frames count at Es/N0 3.5 dB, 3.75 iterations per frame); separate rocprofv3 --pmc "
                "passes (tools/collect_pmc_mix.sh); bench.py quotes this file only while decoder_digest matches mercury_amd.build.decoder_digest()"}
 for d in ("spa", "spa_fast", "minsum"):
     f = os.path.join(out, "pmc_mix_%s.json" % d)
@@ -35,6 +40,14 @@ for d in ("spa", "spa_fast", "minsum"):
                 mix[d] = dict(v, kernel=k)
             elif "frontend" in k:
                 mix["frontend"] = dict(v, kernel=k)
+for d in ("spa", "spa_fast", "minsum"):
+    f = os.path.join(out, "pmc_mix_%s_op.json" % d)
+    if os.path.exists(f):
+        for k, v in json.load(open(f)).items():
+            if "ldpc" in k:
+                mix[d + "_op"] = dict(v, kernel=k, workload="mode 8 at Es/N0 3.5 dB (operating point)")
+            elif "frontend" in k:
+                mix["frontend_op"] = dict(v, kernel=k)
 f = os.path.join(out, "pmc_mix_spa_cfg16.json")
 if os.path.exists(f):
     for k, v in json.load(open(f)).items():
@@ -49,6 +62,15 @@ for d in spa spa_fast minsum; do
   cp "$(find "$OUT/prof_$d" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_bench_${d}_cfg8_kernel_stats.csv"
   rm -rf "$OUT/prof_$d"
 done
+# the operating point: kernel stats of the launch bench.py reports as `operating_point`, the front-end's phase stamps, the decoders' phase stamps
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_op" -- python "$ROOT/bench.py" --esn0 $OPES --no-cpu-baseline --no-extras --steps 30 > /dev/null 2>&1
+cp "$(find "$OUT/prof_op" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_op_spa_cfg8_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/prof_op"
+( cd "$ROOT" && python tools/fe_phases.py 8 4096 $OPES > "$OUT/${R}_op_frontend_phases_cfg8.txt" 2>/dev/null; python tools/fe_phases.py 0 4096 -7 > "$OUT/${R}_op_frontend_phases_cfg0.txt" 2>/dev/null
+  if [ -f mercury_amd/_variants/lib_stamps.so ]; then
+    for spec in "spa $OPES" "spa_fast $OPES" "spa -15"; do set -- $spec
+      MERCURY_GPU_LIB=$ROOT/mercury_amd/_variants/lib_stamps.so python tools/spa_stamps.py $1 8 4096 $2 2>/dev/null | grep -v "^{" > "$OUT/${R}_decoder_phases_${1}_es${2}.txt"
+    done
+  fi )
 # the high-degree graph (rate 14/16: modes 12, 14, 15, 16; BASELINE.json configs[3])
 python "$ROOT/bench.py" --cfg 16 --variant baseband_test --no-extras > "$OUT/${R}_bench_spa_cfg16.json" 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_16" -- python "$ROOT/bench.py" --cfg 16 --variant baseband_test --no-cpu-baseline --no-extras > /dev/null 2>&1
