@@ -113,7 +113,9 @@ def issue_view(mix, src, kernel_ms, machine, sclk=None):
                 "needed_4cycle_slots": slots, "frac_slots": slots / avail, "frac": slots / avail,
                 "clock_hz_used": clock_hz, "clock_source": "hwmon freq1_input, median over the timed region" if clock_hz != machine["clock_hz"] else "hipDeviceProp clockRate (maximum)",
                 "valu_instructions_per_launch": mix["SQ_INSTS_VALU"],
-                "valu_busy_measured": 4.0 * mix["SQ_ACTIVE_INST_VALU"] / (mix["GRBM_GUI_ACTIVE"] / 8.0 * machine["simds"]) if mix.get("GRBM_GUI_ACTIVE") else None,
+                # PMC only, clock-free: SQ_ACTIVE_INST_VALU counts issue quanta; x4 turns them into SIMD cycles for fp64 streams (an over-estimate for 32-bit
+                # operations, which issue in about 2.3 cycles: the fp32 decoders can read above 1), GRBM_GUI_ACTIVE / 8 XCDs are the launch's cycles
+                "valu_busy_pmc": 4.0 * mix["SQ_ACTIVE_INST_VALU"] / (mix["GRBM_GUI_ACTIVE"] / 8.0 * machine["simds"]) if mix.get("GRBM_GUI_ACTIVE") else None,
                 "machine": {k: machine[k] for k in ("compute_units", "simds", "clock_hz")},
                 "classes": {k: {"count": c, "cycles_each": w} for k, (c, w) in classes.items()},
                 "source": "opcode mix: %s; costs: %s (micro-benchmark); SIMDs and clock: hipDeviceProp; time: this run" % (src, cname)}

@@ -13,6 +13,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 [ -x "$ROOT/tools/ubench/valu_cycles" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/valu_cycles" "$ROOT/tools/ubench/valu_cycles.hip"
 "$ROOT/tools/ubench/valu_cycles" > "$OUT/${R}_valu_cycles.json"
+cp "$OUT/${R}_valu_cycles.json" "$ROOT/profiles/${R}_valu_cycles.json"       # where bench.py looks for the opcode costs
 [ -x "$ROOT/tools/ubench/dep_chain" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/dep_chain" "$ROOT/tools/ubench/dep_chain.hip" 2>/dev/null
 "$ROOT/tools/ubench/dep_chain" > "$OUT/${R}_dep_chain.json"
 for d in spa spa_fast minsum; do
