@@ -208,6 +208,9 @@ int mgpu_host_select_peak(const double* cand_vals, int ncand, int step, int size
 int mgpu_host_fir_taps(int which, double carrier_hz, double* taps, int* ntaps);
 int mgpu_host_preamble_carriers(int cfg, double* carriers_c128, int* n_symbols);
 int mgpu_host_mode_info(int cfg, int mfsk_ctrl_mode, mgpu_info* info);
+/* test / documentation hook: the fp32 decoders' LDS placement as modelled on the host — out[0], out[1]: LDS cycles per 32-lane gather
+ * group (1.0 = conflict-free) of the check pass's posterior reads and the variable update's message reads; out[2] bins; out[3] occupancy */
+int mgpu_host_layout_stats(int cfg, double out[4]);
 
 /* void cl_ldpc::encode(const int* data, int* encoded_data) (ldpc.h:82, ldpc.cc:111-132) for F words: bits [F][K], one byte per bit
  * -> encoded [F][N] = the data followed by the P parity bits. */

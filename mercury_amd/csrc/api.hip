@@ -615,6 +615,18 @@ int mgpu_host_mode_info(int cfg, int mfsk_ctrl_mode, mgpu_info* i) {
     } catch (const std::exception& e) { g_create_error = e.what(); return MGPU_ERR_ARG; }
 }
 
+// the fp32 decoders' bank-aware placement, as modelled on the host (tables.cpp): LDS cycles per 32-lane gather group, 1.0 = conflict-free;
+// out[0] the check pass's posterior reads, out[1] the variable update's message reads, out[2] bins, out[3] slots in use / slots
+int mgpu_host_layout_stats(int cfg, double out[4]) {
+    if (!out) return MGPU_ERR_ARG;
+    try {
+        const mgpu::ModeTables m = mgpu::build_mode_tables(cfg, 0, mgpu_ldpc_blob, mgpu_ldpc_blob_size);
+        out[0] = m.graph.bank_model[0]; out[1] = m.graph.bank_model[1];
+        out[2] = m.graph.Sg / 64; out[3] = m.graph.Sg ? double(m.graph.E) / m.graph.Sg : 0;
+        return MGPU_OK;
+    } catch (const std::exception& e) { g_create_error = e.what(); return MGPU_ERR_ARG; }
+}
+
 int mgpu_enable_timing(mgpu_ctx* c, int on) {
     if (!c) return MGPU_ERR_ARG;
     c->timing = on != 0;

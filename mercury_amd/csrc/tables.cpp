@@ -361,6 +361,32 @@ static LdpcGraph load_graph_uncached(int K, const uint8_t* blob, size_t size) {
                 gslot_of_edge[eo] = bin_of_edge[eo] * 64 + lane_of_edge[eo];
                 g.gdesc[gslot_of_edge[eo]] = 0x80000000u | row_of[g.cvar[eo]];          // the posterior's index = the variable's row
             }
+            {   // what the placement achieved, by the rule of the LDS (a 32-lane group costs one cycle + one per extra address on a bank)
+                auto group_cycles = [](std::vector<uint32_t>& addr) {
+                    std::sort(addr.begin(), addr.end());
+                    addr.erase(std::unique(addr.begin(), addr.end()), addr.end());
+                    int cnt[32] = {0}, m = 1;
+                    for (uint32_t a : addr) m = std::max(m, ++cnt[a & 31]);
+                    return m;
+                };
+                long cyc = 0, groups = 0;
+                for (size_t b = 0; b < bins; ++b)
+                    for (uint32_t half = 0; half < 2; ++half) {
+                        std::vector<uint32_t> addr;
+                        for (uint32_t l = 0; l < 32; ++l) { const uint32_t d = g.gdesc[b * 64 + half * 32 + l]; addr.push_back(d & 0x80000000u ? d & 0x7ffu : 0u); }
+                        cyc += group_cycles(addr); ++groups;
+                    }
+                g.bank_model[0] = groups ? double(cyc) / groups : 0;
+                cyc = groups = 0;
+                for (uint32_t base = 0; base < N; base += 32)
+                    for (uint32_t j = 0; j < 9; ++j) {
+                        std::vector<uint32_t> addr;
+                        for (uint32_t i = base; i < std::min<uint32_t>(base + 32, N); ++i)
+                            if (j < vdeg[vorder_g[i]]) addr.push_back(gslot_of_edge[g.vedge[g.vptr[vorder_g[i]] + j]]);
+                        if (!addr.empty()) { cyc += group_cycles(addr); ++groups; }
+                    }
+                g.bank_model[1] = groups ? double(cyc) / groups : 0;
+            }
             g.vinfo_g.assign(size_t(N) * 8, 0u);
             for (uint32_t i = 0; i < N; ++i) {
                 const uint32_t v = vorder_g[i], d = vdeg[v];

@@ -54,7 +54,8 @@ struct LdpcGraph {
     std::vector<uint32_t> gdesc;   // [(rounds+1)*512] per slot: 0x80000000 | variable, 0 for padding lanes (rounds of 8 bins: 512-thread workgroups)
     std::vector<uint32_t> gkind;   // [(rounds+1)*8] per bin: log2 of its group size (1..6), 0 for an empty bin
     std::vector<uint64_t> gkpack;  // [8] per wavefront w: gkind[w + 8 r] in bits 3r .. 3r+2 (at most 21 rounds): one scalar register pair per wavefront
-    std::vector<uint32_t> vinfo_g; // [N][8] like vinfo, slot indices in the grouped layout
+    std::vector<uint32_t> vinfo_g; // [N][8] like vinfo, slot indices in the grouped layout; the rows' order is the grouped layout's own (bank-aware, tables.cpp)
+    double bank_model[2] = {0, 0}; // modelled LDS cycles per 32-lane gather group (1.0 = conflict-free) of the check pass's posterior reads / the variable update's message reads
     // the fp64 sum-product kernel's own tables (ldpc.hip, spa_decode): LDS byte offsets instead of indices, and the
     // product walk's execution masks tabulated per bin and step instead of compared per lane
     // register-layout limits of individual kernels, recorded here and enforced where a context selects its decoder (api.hip: ctx_alloc), so

@@ -211,3 +211,18 @@ def test_bench_dry_run_prints_the_shard_map_without_a_gpu():
             lo, hi = k["global_frames_by_input_batch"][b]
             assert lo == at and hi - lo == 4096 == k["frames_per_step"]
             at = hi
+
+
+def test_fp32_decoder_placement_keeps_its_gathers_off_each_others_banks():
+    """The bank-aware placement of the fp32 decoders' posteriors and edges (tables.cpp; round 4) by the LDS's own rule — a 32-lane group of a
+    4-byte gather costs one cycle plus one per extra address on a bank: a random placement costs about 2.8 (check pass) and 4-7 (variable
+    update) cycles per group, the placed tables must stay below 2.0 / 2.2 on every rate, and the rate-14/16 graph's large groups reach 1.0."""
+    import ctypes as C
+    from mercury_amd import load_library
+    lib = load_library()
+    out = (C.c_double * 4)()
+    for cfg in (0, 1, 2, 3, 4, 8, 13, 16):
+        assert lib.mgpu_host_layout_stats(C.c_int(cfg), out) == 0
+        assert 1.0 <= out[0] < 2.0 and 1.0 <= out[1] < 2.2, (cfg, list(out))
+        assert 0.6 < out[3] <= 1.0
+    assert lib.mgpu_host_layout_stats(C.c_int(16), out) == 0 and out[1] == 1.0
