@@ -214,13 +214,17 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     if (uint32_t(uintptr_t(smem)) != 0) __builtin_trap();
     SPA_STAMP_DECL(F);
     SPA_STAMP(1);                                   // 1: start
+    // Before the first iteration every R is zero, so Q = posterior - R is the channel LLR on every edge of a variable and T = tanh(Q/2) is
+    // one value per VARIABLE (1600) where the check pass would compute it per EDGE (3574 - 6604): it is computed here, once per variable,
+    // and the first check pass takes it from the posterior array instead of evaluating tanh (x - 0.0 == x exactly, so the value is the
+    // one the pass would have computed; tanh keeps the sign, so the syndrome of the channel LLRs reads the same hard decisions). The
+    // messages are never zeroed: nothing reads them before the first pass has written them. Round 4: -6 % at a mode's operating point.
     const float* lin = llr_in + size_t(f) * N;
     for (int v = tid; v < N; v += LDPC_THREADS) {
         const float l = lin[v];
         Li[v] = l;
-        Lt[v] = l;
+        Lt[v] = spa_tanh_half(double(l));
     }
-    for (int p = tid; p < S; p += LDPC_THREADS) M[p] = 0.0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
     const __amdgpu_buffer_rsrc_t vrec = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.vinfo2), 0, N * 32, 0x00020000);
@@ -318,7 +322,9 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     // fixed split (bin w + 16 r in round r: rounds 1-2) the first wavefronts of a workgroup finish long before the last ones and wait at the
     // barrier: -0.4 % at rate 6/16 (89 bins), -3.6 % at rate 14/16 (116 bins: 7.25 per wavefront). Which wavefront works a bin does not
     // change a bit of its arithmetic.
-    auto cn_pass = [&](bool with_syndrome, int p) {
+    auto cn_pass = [&](bool with_syndrome, int p, auto first_tag) {
+        constexpr bool first = decltype(first_tag)::value;      // the first pass is a copy of the loop of its own: the steady-state loop carries no test for it
+                                                                // (measured: the test as a run-time flag costs the headline 1.6 %; a copy per syndrome mode as well costs 0.7 %)
         bool unsat = false;
         const int nbins = T.S >> 6;
         const uint32_t lane8 = (tid & 63) * 8;
@@ -341,7 +347,12 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             // one odd check settles the pass, so the wave's later bins skip the test: the ballot -> prefix-XOR chain is a dependent run of
             // scalar instructions on the bin's critical path (6.27 -> 6.06 ms per 4096 x 50 on the headline, where the first bin settles it)
             if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vm, en);
-            if (valid) *ldsd(own) = spa_tanh_half(lt - *ldsd(own));
+            if (valid) {
+                double t;
+                if constexpr (first) t = lt;                           // the posterior array holds T itself (see the top of the kernel)
+                else t = spa_tanh_half(lt - *ldsd(own));
+                *ldsd(own) = t;
+            }
             __builtin_amdgcn_wave_barrier();
             // Product of the check's OTHER T values in slot order, starting from 1.0 (the reference's temp *= ...):
             // every lane of a check reads the check's slots in order (a broadcast) and multiplies under the bin's
@@ -378,7 +389,8 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     if (flag[0]) {
         for (int it = 1;; ++it) {
             const bool spec = it - 1 >= kSpecStart;
-            if (it <= T.max_iters) cn_pass(spec, it - 1);
+            if (it == 1) cn_pass(spec, 0, std::true_type());
+            else if (it <= T.max_iters) cn_pass(spec, it - 1, std::false_type());
             else syndrome_pass(it - 1);
 #if !SPA_VR_RESIDENT
             const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
@@ -466,6 +478,14 @@ extern "C" size_t mgpu_spa_fast_lds_bytes(int Sg, int N) {
     return size_t(4) * Sg + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
 }
 
+// tanh(q/2) of the fp32 sum-product decoder: (1 - e)/(1 + e), e = exp(-|q|), magnitude kept inside [2^-30, 1 - 2^-24]
+__device__ __forceinline__ float spaf_tanh_half(float q) {
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * __builtin_fabsf(q));
+    float a = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    a = __builtin_amdgcn_fmed3f(a, 0x1.0p-30f, 0x1.fffffep-1f);
+    return __builtin_copysignf(a, q);
+}
+
 template <int THREADS, int RULE>     // RULE 0: sum-product ("spa_fast"), 1: normalised min-sum
 __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* __restrict__ llr_in, int F,
                                                  uint8_t* __restrict__ bits_out, int* __restrict__ iters_out,
@@ -495,7 +515,10 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         const int i = tid + k * THREADS;
         vrow[k] = i < N ? T.vinfo_g[size_t(i) * 8] & 0x7ff : 0u;
         li[k] = i < N ? llr_in[size_t(f) * N + vrow[k]] : 0.0f;
-        if (i < N) Lt[i] = li[k];
+        // sum-product: before the first iteration Q is the channel LLR on every edge of a variable, so T = tanh(Q/2) is computed here once per
+        // variable and the first check pass takes it from the posterior array (same expression, same value; the sign - all the syndrome and
+        // the hard decisions read - is the LLR's)
+        if (i < N) Lt[i] = RULE == 0 ? spaf_tanh_half(li[k]) : li[k];
     }
     const uint32_t* __restrict__ gdesc = T.gdesc;
     // the group sizes of the wavefront's bins, 3 bits per round, in one scalar register pair (a scalar load per round put its latency
@@ -531,7 +554,8 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     };
     // Every pass tests the syndrome of the posteriors it starts from (the first one: of the channel LLRs), so a frame costs one check
     // pass more than it has iterations and no syndrome-only passes; the messages start as zeros that are never stored (first).
-    auto cn_pass = [&](int p, bool first) {
+    auto cn_pass = [&](int p, auto first_tag) {
+        constexpr bool first = decltype(first_tag)::value;       // the first pass is a loop of its own (no message reads; sum-product: no tanh)
         constexpr bool with_syndrome = true;
         bool unsat = false;
         uint32_t k = gdesc[tid];
@@ -544,12 +568,12 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
             const bool valid = int32_t(k) < 0;
             const float lt = Lt[k & 0x7ff];                          // padding lanes read variable 0
             if (with_syndrome && !unsat) unsat = groups_unsat(__ballot(lt < 0 && valid), kind);
-            const float q = first ? lt : lt - M[slot];
+            float q;
+            if constexpr (first) q = lt; else q = lt - M[slot];
             if constexpr (RULE == 0) {
-            const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * __builtin_fabsf(q));
-            float a = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-            a = __builtin_amdgcn_fmed3f(a, 0x1.0p-30f, 0x1.fffffep-1f);
-            const float t = valid ? __builtin_copysignf(a, q) : 1.0f;
+            float t;
+            if constexpr (first) t = valid ? lt : 1.0f;                // the posterior array holds T itself (see the top of the kernel)
+            else t = valid ? spaf_tanh_half(q) : 1.0f;
             // the check's total: all-reduce over its aligned group
             float x = t * spag_dpp<0xB1>(t);                                          // lane ^ 1  (quad_perm [1,0,3,2])
             if (kind >= 2) x *= spag_dpp<0x4E>(x);                                    // lane ^ 2  (quad_perm [2,3,0,1])
@@ -660,7 +684,8 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
     int iteration = 0;
     SPA_STAMP(2);
     for (int it = 1;; ++it) {
-        if (it <= T.max_iters) cn_pass(it - 1, it == 1);
+        if (it == 1) cn_pass(0, std::true_type());
+        else if (it <= T.max_iters) cn_pass(it - 1, std::false_type());
         else syndrome_pass(it - 1);
         SPA_STAMP(5);
         __syncthreads();
