@@ -153,6 +153,7 @@ SPA_FN double spa_tanh_half(double q) {
     if (__builtin_expect(iq < 0x3c900000u || iq >= 0x40460000u, 0)) {
         const double one = SPA_MAKE(0x3ff00000u | (jq & 0x80000000u), 0u);
         res = (iq >= 0x40460000u) ? one : 0.5 * q;
+        if (q != q) res = q;                                 // s_tanh.c: one/x + one for a NaN is that NaN (the posterior array holds T before the first pass: a NaN must stay one)
     }
     return res;
 }
