@@ -726,6 +726,38 @@ def test_ragged_batch_sizes(F):
     assert (out["stats"]["message_decoded"] == 1).mean() > 0.9
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_path_in_several_chunks_equals_one_piece(pinned, monkeypatch):
+    """mgpu_rx_batch's double-buffered host path (api.hip: input chunks on a copy stream, kernels on another, results through page-locked
+    staging) cut into many chunks with a ragged tail - pageable and page-locked input take different stream schedules - returns what
+    the same call in one piece returns, frame for frame (payload bytes, stats records, LLRs), and what the oracle returns."""
+    from mercury_amd.physical_layer import pinned_empty
+    cfg, F = 11, 203
+    orc = Oracle(cfg, 50)
+    op = OPERATING_ESN0[cfg]
+    bb, _ = _frames(orc, [op + (i % 4) - 1.0 for i in range(F)], seed=515)
+    if pinned:
+        buf = pinned_empty(bb.shape, np.complex128)
+        buf[...] = bb
+        bb = buf
+    rx = _rx(cfg, max_batch=256)
+    monkeypatch.delenv("MERCURY_RX_CHUNK", raising=False)
+    whole = rx.receive(bb, want_llr=True)
+    for chunk in ("16", "37", "64"):
+        monkeypatch.setenv("MERCURY_RX_CHUNK", chunk)
+        for rep in range(2):
+            cut = rx.receive(bb, want_llr=True)
+            assert np.array_equal(cut["payload"], whole["payload"]), (chunk, rep)
+            assert (cut["stats"] == whole["stats"]).all(), (chunk, rep)
+            assert np.array_equal(cut["llr_ldpc"].view(np.uint32), whole["llr_ldpc"].view(np.uint32)), (chunk, rep)
+    monkeypatch.delenv("MERCURY_RX_CHUNK", raising=False)
+    for f in (0, 15, 16, 36, 37, 63, 64, 127, 128, 192, F - 1):
+        ref = orc.rx(np.asarray(bb[f]), FLAGS_RECEIVE_BYTE)
+        assert whole["stats"]["iterations_done"][f] == ref["iterations"] and whole["stats"]["crc"][f] == ref["crc"], f
+        assert np.array_equal(whole["payload"][f], ref["bytes"].astype(np.uint8)), f
+    rx.close()
+
+
 def test_descrambler_crc_and_stats_fields():
     """bit_energy_dispersal / bit_to_byte / CRC16 / all_zeros / SNR against the oracle for decoded, failed and
     all-zero outcomes (telecom_system.cc:1313-1372)."""
