@@ -110,6 +110,25 @@ def test_gpu_transmit_byte_matches_oracle(cfg):
     assert np.array_equal(got[0], orc.transmit_byte(pls[0].astype(np.int32), carrier=1650.0, **kw))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 8, 13, 16, 100])
+def test_gpu_transmit_bit_is_what_transmit_byte_calls(cfg):
+    """cl_telecom_system::transmit_bit (telecom_system.cc:384-556; mgpu_transmit_bit_batch): transmit_byte packs the message bytes LSB first,
+    appends the CRC16 and calls it (telecom_system.cc:343-383) - the same data bits handed to transmit_bit directly give the same audio."""
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    rx = RxPhy(cfg, max_batch=4)
+    rng = np.random.default_rng(1900 + cfg)
+    pls = rng.integers(0, 256, (3, orc.payload_bytes)).astype(np.uint8)
+    bits = np.stack([orc.payload_to_bits(pls[f].astype(np.int32)) for f in range(3)]).astype(np.uint8)
+    for loc in (SINGLE_MESSAGE, NO_FILTER_MESSAGE):
+        by_byte = rx.transmit_byte(pls, CARRIER, message_location=loc)
+        by_bit = rx.transmit_bit(bits, CARRIER, message_location=loc)
+        assert np.array_equal(by_bit, by_byte), (cfg, loc)
+        assert np.array_equal(by_bit[1], orc.transmit_byte(pls[1].astype(np.int32), message_location=loc)), (cfg, loc)
+    rx.close()
+
+
 @pytest.mark.parametrize("cfg", [c for c in MG.TX_CFGS if c < 100])
 def test_library_pre_equalization_channel_matches_the_reference_fixture(cfg):
     """cl_telecom_system::get_pre_equalization_channel (telecom_system.cc:3108-3145): the library computes the table on the host
