@@ -219,6 +219,11 @@ int mgpu_ldpc_encode_batch(mgpu_ctx* ctx, const uint8_t* bits, int F, uint8_t* e
 /* ---- device-buffer entry points (asynchronous on `stream`, a hipStream_t) ------------ */
 int mgpu_rx_batch_dev(mgpu_ctx* ctx, const void* d_baseband_c128, int F, void* d_payload,
                       void* d_stats, void* d_llr_opt, void* stream);
+/* The two halves of mgpu_rx_batch_dev on their own: the front-end leaves float LLRs [F][1600] and the float variance that scaled them [F];
+ * the decoder half takes any LLRs. Bits, iteration counts, payload bytes, crc / all_zeros / message_decoded / variance of the stats records
+ * equal the fused call's. stats.snr_db of the decoder half is 10 log10(1 / d_variance_f) (-99.9 without a variance or a decoded message):
+ * the fused call alone knows the PSK modes' variance before amplitude restoration and the zero-forcing modes' re-encoded symbols
+ * (telecom_system.cc:1343-1396), so use it when receive_stats.SNR matters. */
 int mgpu_frontend_dev(mgpu_ctx* ctx, const void* d_baseband_c128, int F, void* d_llr, void* d_variance_f,
                       void* stream);
 int mgpu_ldpc_batch_dev(mgpu_ctx* ctx, const void* d_llr, int F, void* d_bits_opt, void* d_iters,

@@ -758,6 +758,36 @@ def test_host_path_in_several_chunks_equals_one_piece(pinned, monkeypatch):
     rx.close()
 
 
+@pytest.mark.parametrize("cfg", [2, 8, 16])
+def test_front_end_and_decoder_halves_equal_the_fused_call(cfg):
+    """mgpu_frontend_dev + mgpu_ldpc_batch_dev (device buffers, a caller's stream) = mgpu_rx_batch_dev: payload bytes, the stats records up to
+    the variance and the LLRs in between, bit for bit; the launch timers (mgpu_enable_timing / kernel_ms_avg) report both kernels."""
+    import torch
+    rx = _rx(cfg, max_batch=96, agc=0 if cfg >= 15 else 1, variance_source=0 if cfg >= 15 else 1)
+    F = 96
+    dev = torch.device("cuda")
+    bb = torch.empty((F, rx.frame_samples, 2), dtype=torch.float64, device=dev)
+    rx.txgen_dev(SEED, 0, F, float(noise_amp_for(OPERATING_ESN0[cfg] + 0.5)), bb.data_ptr(), None)
+    pay = [torch.zeros((F, rx.payload_stride), dtype=torch.uint8, device=dev) for _ in range(2)]
+    st = [torch.zeros((F, 6), dtype=torch.int32, device=dev) for _ in range(2)]
+    llr = [torch.zeros((F, 1600), dtype=torch.float32, device=dev) for _ in range(2)]
+    var = torch.zeros((F,), dtype=torch.float32, device=dev)
+    s = torch.cuda.Stream()
+    rx.enable_timing(True)
+    rx.receive_dev(bb.data_ptr(), F, pay[0].data_ptr(), st[0].data_ptr(), llr[0].data_ptr(), stream=s.cuda_stream)
+    rx.frontend_dev(bb.data_ptr(), F, llr[1].data_ptr(), var.data_ptr(), stream=s.cuda_stream)
+    rx.ldpc_decode_dev(llr[1].data_ptr(), F, d_payload=pay[1].data_ptr(), d_stats=st[1].data_ptr(), d_variance=var.data_ptr(), stream=s.cuda_stream)
+    s.synchronize()
+    assert torch.equal(llr[0].view(torch.int32), llr[1].view(torch.int32))
+    assert torch.equal(pay[0], pay[1]) and torch.equal(st[0][:, :5], st[1][:, :5])       # all but snr_db (mercury_gpu.h: only the fused call
+    if cfg == 16 or cfg == 8:                                                              # has the PSK / ZF modes' SNR inputs)
+        assert not torch.equal(st[0][:, 5], st[1][:, 5])
+    assert int((st[0][:, 3] == 1).sum()) > F * 0.9            # message_decoded
+    fe_ms, dec_ms, launches = rx.kernel_ms_avg()
+    assert 0 < fe_ms < 50 and 0 < dec_ms < 500 and launches >= 1
+    rx.close()
+
+
 def test_descrambler_crc_and_stats_fields():
     """bit_energy_dispersal / bit_to_byte / CRC16 / all_zeros / SNR against the oracle for decoded, failed and
     all-zero outcomes (telecom_system.cc:1313-1372)."""
