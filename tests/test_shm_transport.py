@@ -108,6 +108,25 @@ def test_wraparound_and_full_state(lib):
     lib.mgpu_shm_destroy(ring)
 
 
+def test_clear_empties_a_wrapped_or_full_ring_for_every_handle(lib):
+    """mgpu_shm_clear = clear_buffer / circular_buf_reset (ring_buffer_posix.h:75,79; ring_buffer_posix.cc:284-330): after it the ring is empty for every handle on the
+    objects, whatever state it was in (wrapped, full), and carries traffic again from position 0."""
+    name = _name()
+    ring = _create(lib, name, 48)
+    other = C.c_void_p()
+    assert lib.mgpu_shm_connect(name, 48, C.byref(other)) == 0
+    buf = C.create_string_buffer(48)
+    for fill in (10, 48, 31):
+        assert lib.mgpu_shm_write(ring, b"z" * 30, 30) == 0 and lib.mgpu_shm_read(other, buf, 30) == 0      # head and tail away from 0
+        assert lib.mgpu_shm_write(ring, bytes(range(fill)), fill) == 0                                          # wraps; 48 = full
+        assert lib.mgpu_shm_used(other) == fill
+        lib.mgpu_shm_clear(other)
+        assert (lib.mgpu_shm_used(ring), lib.mgpu_shm_free(ring), lib.mgpu_shm_used(other)) == (0, 48, 0)
+        assert lib.mgpu_shm_write(ring, b"abcdefg", 7) == 0 and lib.mgpu_shm_read_all(other, buf) == 7 and buf.raw[:7] == b"abcdefg"
+    lib.mgpu_shm_close(other)
+    lib.mgpu_shm_destroy(ring)
+
+
 def test_blocking_reader_and_writer(lib):
     ring = _create(lib, _name(), 32)
     out = []
