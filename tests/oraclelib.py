@@ -441,3 +441,50 @@ def _sync_methods(cls):
 
 
 _sync_methods(_Base)
+
+
+# ---- the reference's own cl_telecom_system (oracle/ref_ts_harness.cc; oracle/_ref/libmercury_ref_ts.so) -----------------------------
+REF_TS_SO = os.path.join(ROOT, "oracle", "_ref", "libmercury_ref_ts.so")
+TS_INFO_FIELDS = ("M K P N Nsymb Nc Nfft Ngi Nofdm nData nBits nPilots nVirtual nReal bit_blk tf_blk preamble_nsymb estimator amp_restore "
+                  "ls_window buffer_nsymb payload_bytes").split()
+
+
+class RefTelecomSystem:
+    """cl_telecom_system as the reference compiles it, driven as main.cc drives it for RX_SHM: load_configuration(cfg), then receive_byte
+    per capture window (telecom_system.cc:646-1503). Only where /root/reference was present at build time (the .so travels)."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_TS_SO)
+
+    def __init__(self, cfg):
+        self.lib = C.CDLL(REF_TS_SO, mode=1)          # RTLD_LAZY: the GUI / ARQ / audio-driver functions the units mention stay unbound
+        self.lib.mrefts_create.restype = C.c_void_p
+        self.h = C.c_void_p(self.lib.mrefts_create(C.c_int(cfg)))
+        assert self.h.value
+        o = (C.c_int * 32)()
+        n = self.lib.mrefts_info(self.h, o)
+        assert n == len(TS_INFO_FIELDS)
+        self.info = dict(zip(TS_INFO_FIELDS, list(o)[:n]))
+        self.payload_bytes = self.info["payload_bytes"]
+
+    def buffer_samples(self):
+        return int(self.lib.mrefts_buffer_samples(self.h))
+
+    def receive_byte(self, passband, carrier=None, trials_max=2, use_last_time=1, use_last_freq=1, state=None, coarse_freq_sync=0):
+        x = np.ascontiguousarray(passband, np.float64)
+        assert x.size == self.buffer_samples()
+        out = np.zeros(1600, np.int32)
+        rs = ReceiveStats()
+        st = state if state is not None else LinkState(-1, 0.0, 0)
+        self.lib.mrefts_receive_byte(self.h, _p(x), C.c_double(CARRIER if carrier is None else carrier), C.c_int(trials_max), C.c_int(use_last_time),
+                                     C.c_int(use_last_freq), C.c_int(coarse_freq_sync), C.byref(st), _p(out), C.byref(rs))
+        res = {k: getattr(rs, k) for k, _ in ReceiveStats._fields_}
+        res["payload"] = out[: self.payload_bytes].astype(np.uint8)
+        res["state"] = st
+        return res
+
+    def close(self):
+        if self.h:
+            self.lib.mrefts_destroy(self.h)
+            self.h = None
