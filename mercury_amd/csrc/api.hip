@@ -399,13 +399,14 @@ int mfsk_sync_from_energies(const mgpu::ModeTables& t, const double* E, int nslo
     return best * sym_period;
 }
 
-void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s, int frame0) {
+void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s, int frame0, double* d_var_out) {
     const auto& t = c->tab;
     if (t.estimator != MGPU_EST_ZF || !d_payload || !d_stats) return;
     for (int off = 0; off < F; off += kMaxFramesPerLaunch) {
         const int n = F - off < kMaxFramesPerLaunch ? F - off : kMaxFramesPerLaunch;
         hipLaunchKernelGGL(mgpu_zf_snr_kernel, dim3(n), dim3(256), mgpu_zfsnr_lds_bytes(t.nData), s, c->dev,
-                           d_payload + size_t(off) * t.payload_stride, c->d_eqdata + (size_t(frame0) + off) * t.nData * 2, n, d_stats + off);
+                           d_payload + size_t(off) * t.payload_stride, c->d_eqdata + (size_t(frame0) + off) * t.nData * 2, n, d_stats + off,
+                           d_var_out ? d_var_out + off : nullptr);
         HIPCK(hipGetLastError());
     }
 }

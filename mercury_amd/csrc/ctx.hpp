@@ -30,7 +30,7 @@ extern "C" __global__ void mgpu_mfsk_frontend_kernel_m16x2(MgpuDev, const double
 extern "C" int mgpu_mfsk_syms_per_block();
 extern "C" __global__ void mgpu_slot_energy_kernel(const double*, int, int, int, const double*, double*);
 extern "C" __global__ void mgpu_mfsk_sync_kernel(const double*, int, int, MgpuMfskSync, const int*, int*);
-extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*);
+extern "C" __global__ void mgpu_zf_snr_kernel(MgpuDev, const uint8_t*, const double*, int, MgpuStatsDev*, double*);
 extern "C" size_t mgpu_zfsnr_lds_bytes(int nData);
 extern "C" __global__ void mgpu_p2b_kernel(const double*, int, const double*, const int*, int, int, int, const double*, int, double, double, double*, const int*, const double*, const int*, int);
 extern "C" __global__ void mgpu_p2b_slide_d1_kernel(const double*, int, const double*, const int*, int, int, const double*, double, double, double*, const int*, const double*, const int*, int);
@@ -175,7 +175,7 @@ template <typename T> T* at(T* p, size_t off) { return p ? p + off : nullptr; }
 // frame0: index of the call's first frame inside the context's max_batch-sized workspaces (the ZF modes keep their equalised symbols there)
 void launch_frontend(mgpu_ctx* c, const double* d_bb, int F, float* d_llr, float* d_var, float* d_snrvar, const MgpuTapsDev& taps,
                      hipStream_t s, int frame_stride = 0, int frame0 = 0);
-void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s, int frame0 = 0);
+void launch_zf_snr(mgpu_ctx* c, int F, const uint8_t* d_payload, MgpuStatsDev* d_stats, hipStream_t s, int frame0 = 0, double* d_var_out = nullptr);
 void launch_decoder(mgpu_ctx* c, const float* d_llr, int F, uint8_t* d_bits, int* d_iters, uint8_t* d_payload, MgpuStatsDev* d_stats,
                     const float* d_var, const float* d_snrvar, hipStream_t s);
 

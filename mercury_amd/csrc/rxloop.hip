@@ -51,7 +51,7 @@ struct Win {                       // one capture window's walk through receive_
 // Device workspace for W windows; allocated on the first call and kept in the context (hipMalloc / hipFree of several GB
 // per call cost more than the kernels)
 struct Workspace {
-    DevBuf d_pass, d_bbi, d_frames, d_carrier, d_ia, d_ib, d_ic, d_vals, d_sum, d_cnt, d_freq, d_meanh, d_stats_k, d_payload_k;
+    DevBuf d_pass, d_bbi, d_frames, d_carrier, d_ia, d_ib, d_ic, d_vals, d_sum, d_cnt, d_freq, d_meanh, d_stats_k, d_payload_k, d_snr_k;
     size_t vals_per_window;
     double* h_vals = nullptr;        // page-locked landing area for the synchroniser metrics (tens of MB per call)
     // page-locked arena for the small index / result arrays of the control rounds: a copy from or to pageable memory holds the calling
@@ -92,7 +92,7 @@ struct Workspace {
         : d_pass(size_t(W) * buf * 8), d_bbi(size_t(W) * buf * 16), d_frames(size_t(W) * frame_n * 16), d_carrier(size_t(W) * 8),
           d_ia(size_t(W) * 128 * 4), d_ib(size_t(W) * 128 * 4), d_ic(size_t(W) * 4), d_vals(size_t(W) * vals_per_window * 8),
           d_sum(size_t(W) * 128 * 8), d_cnt(size_t(W) * 128 * 4), d_freq(size_t(W) * 16), d_meanh(size_t(W) * 8),
-          d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * payload_stride), vals_per_window(vals_per_window) {
+          d_stats_k(size_t(W) * sizeof(MgpuStatsDev)), d_payload_k(size_t(W) * payload_stride), d_snr_k(size_t(W) * 8), vals_per_window(vals_per_window) {
         HIPCK(host_alloc_on_node(reinterpret_cast<void**>(&h_vals), size_t(W) * vals_per_window * 8, numa_node));      // control rounds' results: on the GPU's NUMA node
         pin_cap = std::max<size_t>(size_t(1) << 20, size_t(W) * 128 * 8 * 6);             // a few rounds of the largest index / result arrays
         HIPCK(host_alloc_on_node(reinterpret_cast<void**>(&h_pin), pin_cap, numa_node));
@@ -163,14 +163,15 @@ struct Loop {
         HIPCK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, s));
     }
     // device -> host without waiting: the bytes are in h after the next down() / settle()
-    void down_async(void* h, DevBuf& d, size_t bytes) {
+    void down_async(void* h, const void* d_src, size_t bytes) {
         if (void* p = ws.pin_take(bytes)) {
-            HIPCK(hipMemcpyAsync(p, d.p, bytes, hipMemcpyDeviceToHost, s));
+            HIPCK(hipMemcpyAsync(p, d_src, bytes, hipMemcpyDeviceToHost, s));
             ws.pending.push_back({h, p, bytes});
         } else {
-            HIPCK(hipMemcpyAsync(h, d.p, bytes, hipMemcpyDeviceToHost, s));
+            HIPCK(hipMemcpyAsync(h, d_src, bytes, hipMemcpyDeviceToHost, s));
         }
     }
+    void down_async(void* h, DevBuf& d, size_t bytes) { down_async(h, static_cast<const void*>(d.p), bytes); }
     void settle() {
         HIPCK(hipStreamSynchronize(s));
         for (const auto& q : ws.pending) std::memcpy(q.dst, q.src, q.bytes);
@@ -705,7 +706,15 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             if (!lp.mfsk) taps.mean_H = lp.d_meanh.as<double>();
             launch_frontend(c, lp.d_frames.as<double>() + size_t(lp.pre) * t.Nofdm * 2, n, c->d_llr, c->d_variance, c->d_snrvar, taps, s, lp.frame_n);
             launch_decoder(c, c->d_llr, n, nullptr, nullptr, d_payload_k.as<uint8_t>(), d_stats_k.as<MgpuStatsDev>(), c->d_variance, c->d_snrvar, s);
-            launch_zf_snr(c, n, d_payload_k.as<uint8_t>(), d_stats_k.as<MgpuStatsDev>(), s);
+            // receive_stats.SNR is a double (telecom_system.cc:1343-1396): 10 log10(1 / variance) of the float variance (LS modes), -10 log10 of
+            // the re-encoded symbols' error power (ZF modes). The kernels' records carry it as a float (the mgpu_frame_stats ABI); here the
+            // argument of the logarithm comes back and the host takes it with the libm the reference calls: the double equals the reference's.
+            const bool zf = c->tab.estimator == MGPU_EST_ZF;
+            launch_zf_snr(c, n, d_payload_k.as<uint8_t>(), d_stats_k.as<MgpuStatsDev>(), s, 0, zf ? lp.ws.d_snr_k.as<double>() : nullptr);
+            std::vector<double> zf_var(zf ? n : 0, 1.0);
+            std::vector<float> snr_var(!zf && !lp.mfsk ? n : 0, 1.0f);
+            if (zf) lp.down_async(zf_var.data(), lp.ws.d_snr_k, size_t(n) * 8);
+            else if (!lp.mfsk) lp.down_async(snr_var.data(), static_cast<const void*>(c->d_snrvar), size_t(n) * 4);
             std::vector<double> mh(n, 1.0);
             if (!lp.mfsk) lp.down_async(mh.data(), lp.d_meanh, size_t(n) * 8);
             lp.down_async(st_k.data(), d_stats_k, size_t(n) * sizeof(MgpuStatsDev));
@@ -727,7 +736,9 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
                     r.snr_db = -99.9; r.message_decoded = 0;
                     ++x.sync_trials;
                 } else {                                             // :1361-1430
-                    r.snr_db = double(d.snr_db); r.message_decoded = 1;
+                    r.snr_db = double(d.snr_db); r.message_decoded = 1;                       // MFSK: 0.0 (:1362-1367)
+                    if (zf) r.snr_db = -10.0 * std::log10(zf_var[k]);                              // ofdm.cc:1622-1635
+                    else if (!lp.mfsk) r.snr_db = 10.0 * std::log10(1.0 / double(snr_var[k]));        // :1369-1376
                     x.decoded = true; x.in_loop = false;
                     if (!lp.mfsk) { r.freq_offset = x.freq; if (state) state[w].freq_offset_of_last_decoded_message = x.freq; }
                     if (state) state[w].delay_of_last_decoded_message = x.delay;

@@ -17,7 +17,7 @@ extern "C" size_t mgpu_zfsnr_lds_bytes(int nData) { return 4 * 1600 + size_t(8) 
 
 extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_zf_snr_kernel(
     MgpuDev T, const uint8_t* __restrict__ payload, const double* __restrict__ eqdata, int F,
-    MgpuStatsDev* __restrict__ stats) {
+    MgpuStatsDev* __restrict__ stats, double* __restrict__ var_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint8_t* bits = smem;               // K data bits (re-scrambled, virtual copy)
     uint8_t* enc = bits + 1600;         // N encoded bits
@@ -85,6 +85,7 @@ extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_zf_snr_kernel(
         for (int i = 0; i < T.nData; ++i) var += term[i];
         var /= T.nData;
         stats[f].snr_db = float(-10.0 * log10(var));
+        if (var_out) var_out[f] = var;             // receive_byte's double SNR takes the logarithm on the host (the reference's libm)
     }
 }
 

@@ -211,6 +211,53 @@ def test_gpu_receive_byte_randomised_windows_match_oracle(cfg, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 8, 11, 16, 101])
+def test_gpu_receive_byte_equals_the_reference_cl_telecom_system(cfg):
+    """The GPU's batched receive_byte against the reference's OWN cl_telecom_system::receive_byte (oracle/_ref/libmercury_ref_ts.so: the
+    reference's telecom_system.cc compiled unmodified, oracle/ref_ts_harness.cc) on the randomised windows of
+    tests/test_receive_byte_vs_reference.py, with link state carried in: integers, payload and state equal, the doubles (SNR, frequency
+    offset, Schmidl-Cox metric, signal level) bit for bit where the host's libm is the one the device restates (else to 1e-9)."""
+    from mercury_amd import RxPhy
+    from mercury_amd.physical_layer import LINK_STATE_DTYPE
+    from oraclelib import LinkState, RefTelecomSystem
+    if not RefTelecomSystem.available():
+        pytest.skip("oracle/_ref/libmercury_ref_ts.so not built")
+    from test_receive_byte_vs_reference import windows
+    orc, ref = Oracle(cfg), RefTelecomSystem(cfg)
+    rng = np.random.default_rng(8100 + cfg)
+    W = 24
+    ws = list(windows(orc, rng, W))
+    call = dict(trials_max=2, use_last_time=1, use_last_freq=1, coarse_freq_sync=0)
+    df = 2.5
+    st = np.zeros(W, LINK_STATE_DTYPE)
+    for w, (_, _, _, s, _) in enumerate(ws):
+        st[w] = s
+    rx = RxPhy(cfg, max_batch=W)
+    out = rx.receive_byte(np.stack([x for _, x, _, _, _ in ws]), CARRIER + df, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1,
+                          state=st.copy(), coarse_freq_sync=0)
+    ndec = 0
+    inexact = []
+    for w, (kind, x, _, s, _) in enumerate(ws):
+        sb = LinkState(*s)
+        b = ref.receive_byte(x, carrier=CARRIER + df, state=sb, **call)
+        g = out["stats"][w]
+        for k in ("iterations_done", "crc", "all_zeros", "message_decoded", "delay", "sync_trials", "frame_overflow_symbols"):
+            assert g[k] == b[k], (cfg, w, kind, k, g[k], b[k])
+        assert g["snr_db"] == b["snr_db"], (cfg, w, kind, g["snr_db"], b["snr_db"])        # the double the reference reports (host libm on the device's variance)
+        for k in ("freq_offset", "coarse_metric", "signal_strength_dbm"):
+            inexact.append(k) if g[k] != b[k] else None
+            assert g[k] == b[k] or abs(g[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (cfg, w, kind, k, g[k], b[k])
+        assert np.array_equal(out["payload"][w][: orc.payload_bytes], b["payload"]), (cfg, w, kind)
+        for k in ("delay_of_last_decoded_message", "freq_offset_of_last_decoded_message", "mfsk_search_start", "fixed_delay_plus_one"):
+            assert out["state"][w][k] == getattr(sb, k) or (k.startswith("freq") and abs(out["state"][w][k] - getattr(sb, k)) <= 1e-9), (cfg, w, kind, k)
+        ndec += int(b["message_decoded"])
+    assert ndec >= 4
+    print("doubles not bit-identical to the reference:", sorted(set(inexact)) or "none")
+    rx.close()
+    ref.close()
+
+
+@pytest.mark.gpu
 def test_gpu_receive_byte_mfsk_control_frames_overflow_and_search_start():
     """MFSK specifics of receive_byte: short control frames (set_mfsk_ctrl_mode), the anti-re-decode search start
     (telecom_system.cc:683-686) and the frame-overflow report when the frame runs past the capture window (:702-718)."""
