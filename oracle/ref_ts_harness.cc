@@ -130,4 +130,53 @@ void mrefts_receive_byte(void* h, const double* passband, double carrier_hz, int
     }
 }
 
+// ---- the transmit side and the small members the C-ABI mirrors -------------------------------------------------------------------
+double mrefts_carrier(void* h) { return static_cast<cl_telecom_system*>(h)->carrier_frequency; }
+
+// void cl_telecom_system::transmit_byte(int* data, int nBytes, double* out, int message_location) (telecom_system.cc:343-383 -> transmit_bit
+// :384-634) with the members load_configuration left (output power, PAPR cuts, the measured pre-equalisation table) and the mixer phase at
+// start_sample (ofdm.passband_start_sample, ofdm.cc:2311-2313). Returns total_frame_size.
+int mrefts_transmit_byte(void* h, const int* data, int nbytes, int message_location, unsigned long start_sample, double* out) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    Silence s;
+    t->ofdm.passband_start_sample = start_sample;
+    t->transmit_byte(const_cast<int*>(data), nbytes, out, message_location);
+    return t->data_container.total_frame_size;
+}
+
+// pre_equalization_channel as get_pre_equalization_channel (telecom_system.cc:3108-3145) measured it during load_configuration: [Nc] complex
+int mrefts_pre_equalization_channel(void* h, double* out) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    for (int j = 0; j < t->data_container.Nc; j++) { out[2 * j] = t->pre_equalization_channel[j].value.real(); out[2 * j + 1] = t->pre_equalization_channel[j].value.imag(); }
+    return t->data_container.Nc;
+}
+
+// generate_ack_pattern_passband (:1589-1630) / generate_break_pattern_passband; returns the samples written
+int mrefts_generate_pattern(void* h, int which, unsigned long start_sample, double* out) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    Silence s;
+    t->ofdm.passband_start_sample = start_sample;
+    return which == 2 ? t->generate_break_pattern_passband(out) : t->generate_ack_pattern_passband(out);
+}
+// detect_ack_pattern_from_passband (:1633-1680) / detect_break_pattern_from_passband on `size` passband samples
+double mrefts_detect_pattern(void* h, int which, const double* data, int size, int* matched) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    Silence s;
+    return which == 2 ? t->detect_break_pattern_from_passband(const_cast<double*>(data), size, matched)
+                      : t->detect_ack_pattern_from_passband(const_cast<double*>(data), size, matched);
+}
+// measure_signal_only (:1520-1541) on one capture window
+double mrefts_measure_signal_only(void* h, const double* passband) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    Silence s;
+    return t->measure_signal_only(const_cast<double*>(passband));
+}
+// load_configuration(cfg) / return_to_last_configuration() on the live object; out = {current_configuration, last_configuration, Nsymb, nBits - P}
+void mrefts_load_configuration(void* h, int cfg, int* out) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    Silence s;
+    if (cfg == -1) t->return_to_last_configuration(); else t->load_configuration(cfg);
+    out[0] = t->current_configuration; out[1] = t->last_configuration; out[2] = t->data_container.Nsymb; out[3] = t->data_container.nBits - t->ldpc.P;
+}
+
 }  // extern "C"

@@ -484,6 +484,47 @@ class RefTelecomSystem:
         res["state"] = st
         return res
 
+    def carrier(self):
+        self.lib.mrefts_carrier.restype = C.c_double
+        return float(self.lib.mrefts_carrier(self.h))
+
+    def transmit_byte(self, payload, message_location=SINGLE_MESSAGE, start_sample=0):
+        """cl_telecom_system::transmit_byte with what load_configuration left in the object (carrier, 0.1 W, PAPR cuts, pre-equalisation)."""
+        pl = np.ascontiguousarray(payload, np.int32)
+        out = np.zeros((self.info["preamble_nsymb"] + self.info["Nsymb"]) * self.info["Nofdm"] * 4)
+        n = self.lib.mrefts_transmit_byte(self.h, _p(pl), C.c_int(pl.size), C.c_int(message_location), C.c_ulong(start_sample), _p(out))
+        assert n == out.size, (n, out.size)
+        return out
+
+    def pre_equalization_channel(self):
+        out = np.zeros(self.info["Nc"], np.complex128)
+        assert self.lib.mrefts_pre_equalization_channel(self.h, _p(out)) == self.info["Nc"]
+        return out
+
+    def generate_pattern(self, which=1, start_sample=0):
+        out = np.zeros(16 * self.info["Nofdm"] * 4)
+        n = self.lib.mrefts_generate_pattern(self.h, C.c_int(which), C.c_ulong(start_sample), _p(out))
+        return out[:n]
+
+    def detect_pattern(self, passband, which=1):
+        x = np.ascontiguousarray(passband, np.float64)
+        m = C.c_int(0)
+        self.lib.mrefts_detect_pattern.restype = C.c_double
+        v = self.lib.mrefts_detect_pattern(self.h, C.c_int(which), _p(x), C.c_int(x.size), C.byref(m))
+        return float(v), int(m.value)
+
+    def measure_signal_only(self, passband):
+        x = np.ascontiguousarray(passband, np.float64)
+        assert x.size == self.buffer_samples()
+        self.lib.mrefts_measure_signal_only.restype = C.c_double
+        return float(self.lib.mrefts_measure_signal_only(self.h, _p(x)))
+
+    def load_configuration(self, cfg):
+        """load_configuration(cfg), or return_to_last_configuration() for cfg = -1 -> (current_configuration, last_configuration, Nsymb, nReal)"""
+        o = (C.c_int * 4)()
+        self.lib.mrefts_load_configuration(self.h, C.c_int(cfg), o)
+        return tuple(o)
+
     def close(self):
         if self.h:
             self.lib.mrefts_destroy(self.h)

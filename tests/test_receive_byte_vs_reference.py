@@ -126,3 +126,60 @@ def test_consecutive_windows_with_the_state_carried_over():
         for k in STATE_FIELDS:
             assert getattr(sa, k) == getattr(sb, k), (w, kind, k)
     ref.close()
+
+
+# ---- the other members of cl_telecom_system the C-ABI mirrors, against the real object ------------------------------------------------
+@pytest.mark.parametrize("cfg", [0, 3, 8, 11, 13, 16, 100, 102])
+def test_transmit_byte_pre_equalization_and_patterns_equal_the_reference(cfg):
+    """cl_telecom_system::transmit_byte (telecom_system.cc:343-634) on the object load_configuration left (carrier, 0.1 W, PAPR cuts, the
+    pre-equalisation table it measured, the mixer phase at a start sample): filtered and unfiltered audio bit for bit; the table itself
+    (get_pre_equalization_channel :3108-3145); generate_ack / break_pattern_passband (:1589-1630)."""
+    orc, ref = Oracle(cfg), RefTelecomSystem(cfg)
+    assert ref.carrier() == oraclelib.CARRIER
+    rng = np.random.default_rng(300 + cfg)
+    for loc, start in ((oraclelib.SINGLE_MESSAGE, 0), (oraclelib.NO_FILTER_MESSAGE, 12345), (oraclelib.SINGLE_MESSAGE, 2 ** 33 + 7)):
+        msg = rng.integers(0, 256, orc.payload_bytes).astype(np.int32)
+        want = ref.transmit_byte(msg, message_location=loc, start_sample=start)
+        got = orc.transmit_byte(msg, message_location=loc, start_sample=start, pre_equalize=cfg < 100)
+        assert np.array_equal(got, want), (cfg, loc, start, float(np.abs(got - want).max()))
+    if cfg < 100:
+        assert np.array_equal(orc.get_pre_equalization_channel(), ref.pre_equalization_channel()), cfg
+    for which in (1, 2):
+        want = ref.generate_pattern(which, start_sample=777)
+        got = orc.generate_ack_pattern_passband(which, start_sample=777)
+        assert want.size == got.size and np.array_equal(got, want), (cfg, which)
+    ref.close()
+
+
+@pytest.mark.parametrize("cfg", [8, 100])
+def test_pattern_detection_and_signal_level_equal_the_reference(cfg):
+    """detect_ack / break_pattern_from_passband (telecom_system.cc:1633-1680: FIR_rx_data baseband -> cl_ofdm::detect_ack_pattern) and
+    measure_signal_only (:1520-1541) on noisy audio holding a pattern: metric, matched tones and the level in dBm, as doubles."""
+    orc, ref = Oracle(cfg), RefTelecomSystem(cfg)
+    rng = np.random.default_rng(400 + cfg)
+    n = ref.buffer_samples()
+    for which, noise in ((1, 0.01), (2, 0.05), (1, 0.3), (2, 1e-4)):
+        x = rng.standard_normal(n) * noise
+        pat = ref.generate_pattern(which, start_sample=0)
+        d = int(rng.integers(0, n - pat.size))
+        x[d: d + pat.size] += pat
+        for probe in (1, 2):
+            bbi = orc.passband_to_baseband(x, oraclelib.CARRIER, 1, 1)
+            assert orc.detect_ack_pattern(bbi, probe) == ref.detect_pattern(x, probe), (cfg, which, probe)
+        lvl = ref.measure_signal_only(x)
+        a = orc.receive_byte(x)                                              # signal_stregth_dbm is the same measurement (:678)
+        assert a["signal_strength_dbm"] == lvl, (cfg, which, a["signal_strength_dbm"], lvl)
+    ref.close()
+
+
+def test_configuration_bookkeeping_of_the_reference_object():
+    """What load_configuration / return_to_last_configuration (telecom_system.cc:2487-2492, :3027-3034) leave in current_configuration and
+    last_configuration - the state include/mercury_gpu.hpp's mirror reproduces: after return_to_last_configuration() the two
+    members read as BEFORE the call while the mode actually loaded is the former last_configuration."""
+    ref = RefTelecomSystem(8)
+    assert ref.load_configuration(3) == (3, 8, 48, 400)
+    assert ref.load_configuration(-1) == (3, 8, 24, 600)                   # mode 8 is loaded again; the members still say 3 / 8
+    assert ref.load_configuration(-1) == (3, 8, 24, 600)
+    assert ref.load_configuration(3) == (3, 8, 24, 600)                    # "already current" by the members (:2489-2492): nothing is loaded
+    assert ref.load_configuration(16)[:2] == (16, 3)
+    ref.close()
