@@ -7,10 +7,12 @@
  * independent windows at once; each window behaves as a fresh call whose cross-call memory (last good delay /
  * frequency offset) is passed in and out through mgpu_link_state.
  *
- * PARITY of the control flow is UNPINNED: telecom_system.cc cannot be compiled in the build image (it needs the audio
- * and GUI subsystems), so the gates, recoveries and the retry loop are restated from the source and checked against
- * the repository's own CPU restatement (oracle/mercury_oracle.c:morc_receive_byte). Every DSP block underneath is
- * checked against the compiled reference.
+ * PARITY of the control flow (gates, recoveries, the retry loop — restated from the source) is pinned since round 4 against the
+ * reference's own cl_telecom_system::receive_byte: telecom_system.cc compiles unmodified with the reference's own include directories
+ * (oracle/ref_ts_harness.cc -> oracle/_ref/libmercury_ref_ts.so), and on randomised capture windows of all 20 modes every field of
+ * st_receive_stats (the doubles bit for bit), the payload and the cross-call state equal the CPU restatement's
+ * (oracle/mercury_oracle.c:morc_receive_byte, tests/test_receive_byte_vs_reference.py) and this library's
+ * (tests/test_receive_byte.py). Every DSP block underneath is checked against the compiled reference on its own as well.
  */
 #ifndef MERCURY_RXLOOP_H
 #define MERCURY_RXLOOP_H

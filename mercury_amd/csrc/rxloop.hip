@@ -5,9 +5,10 @@
 // its k-th-best-peak and last-good fallbacks — is host logic that advances all windows of the batch in lock-step
 // rounds, each round one batched kernel call per DSP step over the windows that still need it.
 //
-// Parity: every block is checked against the oracle / the compiled reference on its own; the orchestration is
-// checked against oracle/mercury_oracle.c:morc_receive_byte, whose own parity with telecom_system.cc is UNPINNED
-// (that file cannot be built in this image) — see DESIGN.md.
+// Parity: every block is checked against the oracle / the compiled reference on its own; the orchestration is checked window for window
+// against oracle/mercury_oracle.c:morc_receive_byte and, since round 4, against the reference's own cl_telecom_system::receive_byte
+// (telecom_system.cc compiled unmodified: oracle/ref_ts_harness.cc; tests/test_receive_byte_vs_reference.py pins the oracle,
+// tests/test_receive_byte.py::test_gpu_receive_byte_equals_the_reference_cl_telecom_system the GPU) — see DESIGN.md section 7.
 #include <algorithm>
 #include <chrono>
 #include <cmath>

@@ -10,8 +10,9 @@
  * objects compiled from /root/reference (oracle/Makefile), and tests/test_oracle_vs_ref.py, tests/test_sync_blocks.py
  * + the committed fixtures in tests/golden/ (golden_rx, golden_mfsk, golden_sync; generated from that build by
  * tests/golden/make_golden.py) require bit-identical outputs for every stage.
- * UNPINNED: morc_receive_byte, the restatement of receive_byte's control flow (telecom_system.cc cannot be built in
- * this image); it calls only pinned blocks — see the comment at its declaration below.
+ * morc_receive_byte, the restatement of receive_byte's control flow, and morc_get_info's mode table are pinned since round 4 against
+ * the reference's own cl_telecom_system (telecom_system.cc compiled unmodified: oracle/_ref/libmercury_ref_ts.so, oracle/ref_ts_harness.cc,
+ * tests/test_receive_byte_vs_reference.py) — see the comment at its declaration below.
  *
  * The struct layouts deliberately match oracle/ref_harness.cc (mref_*) so one test body can
  * drive either library.
@@ -141,8 +142,8 @@ int morc_time_sync_mfsk(morc*, const double* in_c128, int size, int interpolatio
 double morc_detect_ack_pattern(morc*, const double* in_c128, int size, int interpolation_rate, int which, int* matched);
 
 /* ---- the whole of cl_telecom_system::receive_byte (telecom_system.cc:646-1503): one passband capture window of
- * morc_buffer_nsymb()*Nofdm*4 samples in, payload + receive_stats out. PARITY UNPINNED for the orchestration (the DSP
- * blocks it calls are pinned): telecom_system.cc cannot be built here. See the comment at the definition. ---- */
+ * morc_buffer_nsymb()*Nofdm*4 samples in, payload + receive_stats out. PARITY PINNED (round 4) against the reference's own
+ * cl_telecom_system::receive_byte, window for window: tests/test_receive_byte_vs_reference.py. See the comment at the definition. ---- */
 typedef struct morc_link_state {          /* the cross-call members of st_receive_stats the loop consults */
     int delay_of_last_decoded_message;    /* -1 = none yet (telecom_system.cc:1972) */
     double freq_offset_of_last_decoded_message;

@@ -234,7 +234,7 @@ class ReceiveStats(C.Structure):
 
 
 def _receive_byte(self, passband, carrier=None, trials_max=2, use_last_time=1, use_last_freq=1, state=None, coarse_freq_sync=0):
-    """The whole cl_telecom_system::receive_byte on one capture window (oracle only; orchestration parity unpinned)."""
+    """The whole cl_telecom_system::receive_byte on one capture window (pinned against the reference's own: RefTelecomSystem.receive_byte below)."""
     x = np.ascontiguousarray(passband, np.float64)
     assert x.size == self.buffer_samples()
     out = np.zeros(1600, np.int32)

@@ -1,9 +1,9 @@
 """The whole of cl_telecom_system::receive_byte on capture windows: the batched GPU
 implementation (csrc/rxloop.hip) against the oracle's restatement (morc_receive_byte) on the same passband windows.
-The orchestration's parity with telecom_system.cc is UNPINNED (see include/mercury_rxloop.h); what these tests pin
-is that the two independent restatements — sequential C on the CPU, lock-step rounds over batched kernels on the
-GPU — take the same decisions window by window, and that real frames buried in noise at unknown delay and carrier
-offset come back decoded."""
+The oracle's restatement is itself pinned against the reference's own cl_telecom_system::receive_byte
+(tests/test_receive_byte_vs_reference.py: telecom_system.cc compiled unmodified); these tests pin that the lock-step rounds over batched
+kernels on the GPU take the same decisions window by window as the sequential CPU code, that real frames buried in noise at unknown delay
+and carrier offset come back decoded, and (one test) that the GPU equals the reference's own object directly."""
 import numpy as np
 import pytest
 
