@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak: the batched GPU receive_byte against the CPU restatement on randomised capture windows (random delay, noise level,
 carrier offset, frame / noise-only / two frames), every mode. Prints one line per mode and any window whose integer fields differ.
-usage: python tests/tools/soak_receive_byte.py [windows_per_mode] [seed]"""
+With a third argument "ref" the checker is the reference's OWN cl_telecom_system::receive_byte (oracle/_ref/libmercury_ref_ts.so,
+oracle/ref_ts_harness.cc) instead of the restatement, and the doubles (SNR, frequency offset, metric) must be bit-identical as well.
+usage: python tests/tools/soak_receive_byte.py [windows_per_mode] [seed] [ref]"""
 import os
 import sys
 
@@ -20,9 +22,11 @@ INT_FIELDS = ("iterations_done", "crc", "all_zeros", "message_decoded", "delay",
 def main():
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    use_ref = len(sys.argv) > 3 and sys.argv[3] == "ref"
     bad = 0
     for cfg in list(range(17)) + [100, 101, 102]:
         orc = oraclelib.Oracle(cfg)
+        checker = oraclelib.RefTelecomSystem(cfg) if use_ref else orc
         rng = np.random.default_rng(seed * 1000 + cfg)
         n = orc.buffer_samples()
         wins, dfs = [], []
@@ -49,19 +53,24 @@ def main():
         out = rx.receive_byte(wins, oraclelib.CARRIER + df)
         nbad = 0
         for w in range(W):
-            ref = orc.receive_byte(wins[w], carrier=oraclelib.CARRIER + df)
+            ref = checker.receive_byte(wins[w], carrier=oraclelib.CARRIER + df)
             st = out["stats"][w]
             diff = [k for k in INT_FIELDS if st[k] != ref[k]]
             if st["coarse_metric"] != ref["coarse_metric"] or st["freq_offset"] != ref["freq_offset"]:
                 diff.append("float")
+            if use_ref and (st["snr_db"] != ref["snr_db"] or st["signal_strength_dbm"] != ref["signal_strength_dbm"]):
+                diff.append("snr/level")
             if not np.array_equal(out["payload"][w][: orc.payload_bytes], ref["payload"]):
                 diff.append("payload")
             if diff:
                 nbad += 1
                 print("  cfg %d window %d differs in %s: gpu %s  cpu %s" % (cfg, w, diff, [st[k] for k in INT_FIELDS], [ref[k] for k in INT_FIELDS]))
         bad += nbad
-        print("cfg %3d: %d windows, %d decoded, %d differ" % (cfg, W, int(out["stats"]["message_decoded"].sum()), nbad), flush=True)
+        print("cfg %3d: %d windows, %d decoded, %d differ%s" % (cfg, W, int(out["stats"]["message_decoded"].sum()), nbad,
+                                                                  " (checker: the reference's cl_telecom_system)" if use_ref else ""), flush=True)
         rx.close()
+        if use_ref:
+            checker.close()
     print("TOTAL differing windows:", bad)
     return 1 if bad else 0
 
