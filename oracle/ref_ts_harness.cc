@@ -179,4 +179,11 @@ void mrefts_load_configuration(void* h, int cfg, int* out) {
     out[0] = t->current_configuration; out[1] = t->last_configuration; out[2] = t->data_container.Nsymb; out[3] = t->data_container.nBits - t->ldpc.P;
 }
 
+// set_mfsk_ctrl_mode (telecom_system.cc:1572-1585): the MFSK modes' short control frames; returns get_active_nsymb()
+int mrefts_set_mfsk_ctrl_mode(void* h, int enable) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    t->set_mfsk_ctrl_mode(enable != 0);
+    return t->get_active_nsymb();
+}
+
 }  // extern "C"

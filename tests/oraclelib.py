@@ -519,6 +519,9 @@ class RefTelecomSystem:
         self.lib.mrefts_measure_signal_only.restype = C.c_double
         return float(self.lib.mrefts_measure_signal_only(self.h, _p(x)))
 
+    def set_ctrl_mode(self, enable):
+        return int(self.lib.mrefts_set_mfsk_ctrl_mode(self.h, C.c_int(1 if enable else 0)))
+
     def load_configuration(self, cfg):
         """load_configuration(cfg), or return_to_last_configuration() for cfg = -1 -> (current_configuration, last_configuration, Nsymb, nReal)"""
         o = (C.c_int * 4)()

@@ -183,3 +183,29 @@ def test_configuration_bookkeeping_of_the_reference_object():
     assert ref.load_configuration(3) == (3, 8, 24, 600)                    # "already current" by the members (:2489-2492): nothing is loaded
     assert ref.load_configuration(16)[:2] == (16, 3)
     ref.close()
+
+
+@pytest.mark.parametrize("cfg", [100, 101, 102])
+def test_mfsk_control_frames_equal_the_reference(cfg):
+    """set_mfsk_ctrl_mode (telecom_system.cc:1572-1585): the short control frames of the ROBUST modes through transmit_byte and receive_byte
+    on both sides - the audio bit for bit, and every receive_byte output on windows that hold such a frame, noise, or a frame whose tail lies
+    beyond the capture window (frame_overflow_symbols)."""
+    orc, ref = Oracle(cfg), RefTelecomSystem(cfg)
+    orc.set_ctrl_mode(True)
+    assert ref.set_ctrl_mode(True) == orc.active_nsymb
+    rng = np.random.default_rng(500 + cfg)
+    msg = rng.integers(0, 256, orc.payload_bytes).astype(np.int32)
+    # A control frame fills only (preamble + ctrl_nsymb) symbols of passband_data_tx; the reference filters and returns total_frame_size
+    # samples all the same, so what lies behind the frame is whatever the buffer held before - the previous full frame, or for a new object
+    # whatever `new double[]` handed out (zeros in a fresh process, a freed buffer's content in this one). The ARQ layer plays only the
+    # control frame's samples; the comparison covers them up to the reach of the two 97-tap transmit filters in front of that tail.
+    used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4 - 2 * 96
+    want = ref.transmit_byte(msg, message_location=oraclelib.SINGLE_MESSAGE)
+    assert np.array_equal(orc.transmit_byte(msg, message_location=oraclelib.SINGLE_MESSAGE)[:used], want[:used])
+    decoded = 0
+    for w, (kind, x, call, state, carrier) in enumerate(windows(orc, rng, 10)):
+        diff, a, b = compare_one(orc, ref, x, carrier, call, state)
+        assert not diff, (cfg, w, kind, call, state, diff, [a.get(k) for k in diff if k in a], [b.get(k) for k in diff if k in b])
+        decoded += b["message_decoded"]
+    assert decoded >= 1
+    ref.close()
