@@ -179,6 +179,16 @@ void mrefts_load_configuration(void* h, int cfg, int* out) {
     out[0] = t->current_configuration; out[1] = t->last_configuration; out[2] = t->data_container.Nsymb; out[3] = t->data_container.nBits - t->ldpc.P;
 }
 
+// data_container.passband_data_tx_buffer (3 * total_frame_size doubles), the memory of the FIRST / MIDDLE / FLUSH_MESSAGE calls (:559-596):
+// set != 0 writes buf into it, else reads it out. Returns its length.
+int mrefts_transmit_buffer(void* h, double* buf, int set) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    const int n = 3 * t->data_container.total_frame_size;
+    if (set) memcpy(t->data_container.passband_data_tx_buffer, buf, size_t(n) * sizeof(double));
+    else memcpy(buf, t->data_container.passband_data_tx_buffer, size_t(n) * sizeof(double));
+    return n;
+}
+
 // set_mfsk_ctrl_mode (telecom_system.cc:1572-1585): the MFSK modes' short control frames; returns get_active_nsymb()
 int mrefts_set_mfsk_ctrl_mode(void* h, int enable) {
     cl_telecom_system* t = static_cast<cl_telecom_system*>(h);

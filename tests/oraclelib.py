@@ -519,6 +519,16 @@ class RefTelecomSystem:
         self.lib.mrefts_measure_signal_only.restype = C.c_double
         return float(self.lib.mrefts_measure_signal_only(self.h, _p(x)))
 
+    def transmit_buffer(self, buffer=None):
+        """passband_data_tx_buffer of the FIRST / MIDDLE / FLUSH_MESSAGE calls: read it (buffer=None) or replace it."""
+        n = 3 * (self.info["preamble_nsymb"] + self.info["Nsymb"]) * self.info["Nofdm"] * 4
+        if buffer is None:
+            out = np.zeros(n)
+            assert self.lib.mrefts_transmit_buffer(self.h, _p(out), C.c_int(0)) == n
+            return out
+        b = np.ascontiguousarray(buffer, np.float64)
+        assert b.size == n and self.lib.mrefts_transmit_buffer(self.h, _p(b), C.c_int(1)) == n
+
     def set_ctrl_mode(self, enable):
         return int(self.lib.mrefts_set_mfsk_ctrl_mode(self.h, C.c_int(1 if enable else 0)))
 

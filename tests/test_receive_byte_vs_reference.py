@@ -209,3 +209,25 @@ def test_mfsk_control_frames_equal_the_reference(cfg):
         decoded += b["message_decoded"]
     assert decoded >= 1
     ref.close()
+
+
+@pytest.mark.parametrize("cfg", [100, 102])
+def test_overlap_save_message_locations_equal_the_reference(cfg):
+    """transmit_byte's FIRST / MIDDLE / FLUSH_MESSAGE (telecom_system.cc:559-596: the frame goes into a three-frame buffer, two frames around
+    its middle are filtered, the buffer shifts left) on the real object, call by call, against the restatement's transmit_stream: the audio of
+    every call and the buffer it leaves. The MFSK modes: the stream form of the restatement applies no pre-equalisation, like the reference's
+    MFSK path (:475)."""
+    orc, ref = Oracle(cfg), RefTelecomSystem(cfg)
+    rng = np.random.default_rng(600 + cfg)
+    total = (orc.preamble_nsymb + orc.Nsymb) * orc.Nofdm * 4
+    buf = rng.standard_normal(3 * total) * 0.01                      # whatever the buffer held: both sides start from the same content
+    ref.transmit_buffer(buf)
+    start = 99
+    for loc in (oraclelib.FIRST_MESSAGE, oraclelib.MIDDLE_MESSAGE, oraclelib.MIDDLE_MESSAGE, oraclelib.FLUSH_MESSAGE, oraclelib.FIRST_MESSAGE):
+        msg = rng.integers(0, 256, (1, orc.payload_bytes)).astype(np.int32)
+        got, buf = orc.transmit_stream(msg, loc, buffer=buf, start_sample=start)
+        want = ref.transmit_byte(msg[0], message_location=loc, start_sample=start)
+        assert np.array_equal(got[0], want), (cfg, loc)
+        assert np.array_equal(buf, ref.transmit_buffer()), (cfg, loc)
+        start += total
+    ref.close()
