@@ -189,6 +189,9 @@ int mrefts_transmit_buffer(void* h, double* buf, int set) {
     return n;
 }
 
+// char cl_telecom_system::get_configuration(double SNR) (telecom_system.cc:3036-3106)
+int mrefts_get_configuration(void* h, double snr) { return static_cast<cl_telecom_system*>(h)->get_configuration(snr); }
+
 // set_mfsk_ctrl_mode (telecom_system.cc:1572-1585): the MFSK modes' short control frames; returns get_active_nsymb()
 int mrefts_set_mfsk_ctrl_mode(void* h, int enable) {
     cl_telecom_system* t = static_cast<cl_telecom_system*>(h);

@@ -231,3 +231,24 @@ def test_overlap_save_message_locations_equal_the_reference(cfg):
         assert np.array_equal(buf, ref.transmit_buffer()), (cfg, loc)
         start += total
     ref.close()
+
+
+def test_get_configuration_thresholds_of_the_mirror_are_the_reference_function():
+    """char cl_telecom_system::get_configuration(double SNR) (telecom_system.cc:3036-3106) on a fine SNR grid against the threshold table of
+    include/mercury_gpu.hpp's mirror (the gear-shift rule a drop-in caller relies on)."""
+    import re
+    hpp = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mercury_gpu.hpp")).read()
+    above = [float(v) for v in re.search(r"static const double above\[15\] = \{([^}]*)\}", hpp).group(1).split(",")]
+    assert len(above) == 15
+
+    def mirror(snr):
+        for i, th in enumerate(above):
+            if snr > th:
+                return 15 - i
+        return 0
+
+    ref = RefTelecomSystem(0)
+    ref.lib.mrefts_get_configuration.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_double]
+    for snr in list(np.arange(-12.0, 16.0, 0.125)) + above + [v + 1e-9 for v in above] + [v - 1e-9 for v in above]:
+        assert ref.lib.mrefts_get_configuration(ref.h, float(snr)) == mirror(float(snr)), snr
+    ref.close()
