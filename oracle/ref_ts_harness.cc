@@ -189,6 +189,28 @@ int mrefts_transmit_buffer(void* h, double* buf, int set) {
     return n;
 }
 
+// One frame of the reference's own BER loop, cl_telecom_system::baseband_test_EsN0(EsN0, 1) (telecom_system.cc:95-229: random data -> encode ->
+// map -> frame -> IFFT -> cl_awgn -> the RX chain without AGC, variance from the un-equalised pilots -> cl_ldpc::decode), and what it left in
+// data_container: the noisy baseband frame it received and every stage's output, so that the same samples can go through the restatement.
+// err = {Bits_total, Error_bits_total, Frames_total, Error_frames_total}. (One frame per call: the loop plots every tenth.)
+void mrefts_baseband_test_one_frame(void* h, float esn0, double* baseband, double* grid, double* eq, double* syms, float* llr_demod,
+                                    float* llr_ldpc, int* data_bits, int* decoded_bits, double* err) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    Silence s;
+    const cl_error_rate e = t->baseband_test_EsN0(esn0, 1);
+    const cl_data_container& d = t->data_container;
+    const int nReal = d.nBits - t->ldpc.P, G = d.Nsymb * d.Nc;
+    memcpy(baseband, d.baseband_data, size_t(d.Nofdm) * d.Nsymb * 16);
+    memcpy(grid, d.ofdm_symbol_demodulated_data, size_t(G) * 16);
+    memcpy(eq, d.equalized_data, size_t(G) * 16);
+    memcpy(syms, d.ofdm_time_freq_deinterleaved_data, size_t(d.nData) * 16);
+    memcpy(llr_demod, d.demodulated_data, size_t(d.nBits) * 4);
+    memcpy(llr_ldpc, d.deinterleaved_data, size_t(t->ldpc.N) * 4);
+    memcpy(data_bits, d.data_bit, size_t(nReal) * 4);
+    memcpy(decoded_bits, d.hd_decoded_data_bit, size_t(nReal) * 4);
+    err[0] = e.Bits_total; err[1] = e.Error_bits_total; err[2] = e.Frames_total; err[3] = e.Error_frames_total;
+}
+
 // char cl_telecom_system::get_configuration(double SNR) (telecom_system.cc:3036-3106)
 int mrefts_get_configuration(void* h, double snr) { return static_cast<cl_telecom_system*>(h)->get_configuration(snr); }
 

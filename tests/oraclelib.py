@@ -529,6 +529,18 @@ class RefTelecomSystem:
         b = np.ascontiguousarray(buffer, np.float64)
         assert b.size == n and self.lib.mrefts_transmit_buffer(self.h, _p(b), C.c_int(1)) == n
 
+    def baseband_test_one_frame(self, esn0):
+        """baseband_test_EsN0(esn0, 1) and what it left in data_container -> dict(baseband, grid, eq, syms, llr_demod, llr_ldpc, data_bits,
+        decoded_bits, err = [Bits_total, Error_bits_total, Frames_total, Error_frames_total])."""
+        i = self.info
+        G, nReal = i["Nsymb"] * i["Nc"], i["nReal"]
+        r = dict(baseband=np.zeros(i["Nofdm"] * i["Nsymb"], np.complex128), grid=np.zeros(G, np.complex128), eq=np.zeros(G, np.complex128),
+                 syms=np.zeros(i["nData"], np.complex128), llr_demod=np.zeros(i["nBits"], np.float32), llr_ldpc=np.zeros(i["N"], np.float32),
+                 data_bits=np.zeros(nReal, np.int32), decoded_bits=np.zeros(nReal, np.int32), err=np.zeros(4))
+        self.lib.mrefts_baseband_test_one_frame(self.h, C.c_float(esn0), *[_p(r[k]) for k in ("baseband", "grid", "eq", "syms", "llr_demod", "llr_ldpc",
+                                                                                           "data_bits", "decoded_bits", "err")])
+        return r
+
     def set_ctrl_mode(self, enable):
         return int(self.lib.mrefts_set_mfsk_ctrl_mode(self.h, C.c_int(1 if enable else 0)))
 

@@ -788,6 +788,38 @@ def test_front_end_and_decoder_halves_equal_the_fused_call(cfg):
     rx.close()
 
 
+@pytest.mark.parametrize("cfg", list(range(17)))
+def test_fused_path_equals_the_reference_ber_loop_directly(cfg):
+    """The frames the reference's OWN cl_telecom_system::baseband_test_EsN0 received (telecom_system.cc:95-229, compiled unmodified:
+    oracle/ref_ts_harness.cc) through mgpu_rx_batch in that variant (agc = 0, variance from the un-equalised pilots): carrier grid,
+    equalised grid, de-interleaved symbols, demapper LLRs and decoder-input LLRs against what the REAL run left in data_container - no
+    restatement in between - bit for bit (the LLRs to 1e-5 where the host's libm is not the one the device restates), and the hard
+    decisions of the real decoder through the payload bytes."""
+    from oraclelib import RefTelecomSystem
+    if not RefTelecomSystem.available():
+        pytest.skip("oracle/_ref/libmercury_ref_ts.so not built")
+    orc, ref = Oracle(cfg), RefTelecomSystem(cfg)
+    op = OPERATING_ESN0[cfg]
+    runs = [ref.baseband_test_one_frame(e) for e in (op, op + 1.0, op + 2.0, op - 3.0)]
+    rx = _rx(cfg, max_iters=50, agc=0, variance_source=0, max_batch=len(runs))
+    out = rx.receive(np.stack([r["baseband"] for r in runs]), taps=True)
+    for f, r in enumerate(runs):
+        for k in ("grid", "eq", "syms"):
+            assert np.array_equal(out[k][f].view(np.uint64), r[k].view(np.uint64)), (cfg, f, k)
+        for k in ("llr_demod", "llr_ldpc"):
+            if EXACT_TRIG:
+                assert np.array_equal(out[k][f].view(np.uint32), r[k].view(np.uint32)), (cfg, f, k)
+            else:
+                assert _llr_close(out[k][f], r[k]).all(), (cfg, f, k)
+        # the real decoder's hard decisions = the data bits before de-scrambling; the library's payload is de-scrambled and packed: compare through the oracle's packing
+        want = orc.rx(r["baseband"], FLAGS_BASEBAND_TEST)
+        assert np.array_equal(want["bits"][: orc.nReal], r["decoded_bits"])
+        assert np.array_equal(out["payload"][f], want["bytes"].astype(np.uint8)), (cfg, f)
+        assert out["stats"]["iterations_done"][f] == want["iterations"], (cfg, f)
+    rx.close()
+    ref.close()
+
+
 def test_descrambler_crc_and_stats_fields():
     """bit_energy_dispersal / bit_to_byte / CRC16 / all_zeros / SNR against the oracle for decoded, failed and
     all-zero outcomes (telecom_system.cc:1313-1372)."""

@@ -252,3 +252,29 @@ def test_get_configuration_thresholds_of_the_mirror_are_the_reference_function()
     for snr in list(np.arange(-12.0, 16.0, 0.125)) + above + [v + 1e-9 for v in above] + [v - 1e-9 for v in above]:
         assert ref.lib.mrefts_get_configuration(ref.h, float(snr)) == mirror(float(snr)), snr
     ref.close()
+
+
+# ---- rows a1-a19 through the reference's own BER loop ------------------------------------------------------------------------------------
+STAGES = ("grid", "eq", "syms", "llr_demod", "llr_ldpc")
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+@pytest.mark.parametrize("cfg", list(range(17)))
+def test_hot_path_stages_equal_the_reference_ber_loop(cfg):
+    """cl_telecom_system::baseband_test_EsN0 (telecom_system.cc:95-229), the reference's own driver of the hot path (SURVEY.md section 3.2): one
+    frame per call, and the noisy samples it received go through the restatement (FLAGS_BASEBAND_TEST: no AGC, variance from the un-equalised
+    pilots). Every stage the real run left in data_container - carrier grid, equalised grid, de-interleaved symbols, demapper LLRs, decoder-input
+    LLRs - is bit-identical, and so are the decoder's hard decisions, at the operating point and in the noise (frames that never converge)."""
+    from conftest import OPERATING_ESN0
+    orc, ref = Oracle(cfg), RefTelecomSystem(cfg)
+    for esn0 in (OPERATING_ESN0[cfg], OPERATING_ESN0[cfg] + 1.0, OPERATING_ESN0[cfg] - 3.0):
+        r = ref.baseband_test_one_frame(esn0)
+        o = orc.rx(r["baseband"], oraclelib.FLAGS_BASEBAND_TEST)
+        for k in STAGES:
+            assert _same_bits(o[k], r[k]), (cfg, esn0, k)
+        assert np.array_equal(o["bits"][: orc.nReal], r["decoded_bits"]), (cfg, esn0, o["iterations"])
+        assert r["err"][0] == orc.nReal and r["err"][1] == int((r["data_bits"] != r["decoded_bits"]).sum()), (cfg, esn0, r["err"])
+    ref.close()
