@@ -54,14 +54,23 @@ def windows(orc, rng, W):
     used = (orc.preamble_nsymb + orc.active_nsymb) * orc.Nofdm * 4
     for w in range(W):
         noise = float(10 ** rng.uniform(-3, -0.3))
-        kind = str(rng.choice(["frame", "frame", "frame", "noise", "two", "edge"]))
+        kind = str(rng.choice(["frame", "frame", "frame", "noise", "two", "edge", "silence", "tone", "clipped", "far"]))
         if w == 0:
             noise, kind = 1e-3, "frame"                                 # one window every mode decodes
+        if kind == "silence":
+            noise = float(10 ** rng.uniform(-12, -8))                   # below the reference's 0.001 norm threshold: every metric is forced to 0
         x = rng.standard_normal(n) * noise
+        if kind == "tone":                                              # a carrier-like interferer over the frame
+            x += float(rng.uniform(0.05, 1.0)) * np.sin(2 * np.pi * float(rng.uniform(300, 2700)) * np.arange(n) / 48000.0)
         pl = rng.integers(0, 256, orc.payload_bytes)
         pb = orc.transmit_byte(pl.astype(np.int32), message_location=int(rng.choice([3, 4]))) * float(rng.uniform(0.8, 4.0))
         d = -1
-        if kind in ("frame", "two"):
+        if kind == "far":                                               # the frame mixed up by an oscillator error far beyond the fine search
+            t = np.arange(pb.size) / 48000.0
+            pb = pb * np.cos(2 * np.pi * float(rng.choice([-25.0, 18.0, 40.0])) * t)
+        if kind == "clipped":
+            pb = np.clip(pb, -0.3 * np.abs(pb).max(), 0.3 * np.abs(pb).max())
+        if kind in ("frame", "two", "tone", "clipped", "far"):
             d = int(rng.integers(0, n - used))
             x[d: d + used] += pb[:used]
         if kind == "two" and n > 2 * used + 5000:
