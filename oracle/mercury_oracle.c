@@ -1399,7 +1399,7 @@ double morc_detect_ack_pattern(morc* o, const double* in_c128, int size, int int
  * PARITY: PINNED since round 4 against the reference's own cl_telecom_system::receive_byte (telecom_system.cc compiled
  * unmodified into oracle/_ref/libmercury_ref_ts.so, oracle/ref_ts_harness.cc): tests/test_receive_byte_vs_reference.py and
  * tests/tools/soak_receive_byte_vs_reference.py run both on randomised capture windows of all 20 modes and require every
- * integer and double of st_receive_stats, the payload and the cross-call state to be equal (4000-window soak: 0 differ).
+ * integer and double of st_receive_stats, the payload and the cross-call state to be equal (13,000 windows in three soaks: 0 differ).
  * Rounds 1-3 had believed telecom_system.cc unbuildable here and checked this restatement (telecom_system.cc:646-1503,
  * block by block, each cited) only by reading. g_gui_state.coarse_freq_sync_enabled (false by default in the reference)
  * is a parameter here. Not restated: prints. */
