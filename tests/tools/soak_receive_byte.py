@@ -48,12 +48,21 @@ def main():
                 x[d:] += pb[: n - d]
             wins.append(x)
         wins = np.stack(wins)
+        states = None
+        if use_ref:      # the harsher generator of tests/test_receive_byte_vs_reference.py (silence, interferers, clipped and far-off-frequency frames) with link states carried in
+            from test_receive_byte_vs_reference import windows as ref_windows
+            from mercury_amd.physical_layer import LINK_STATE_DTYPE
+            gen = list(ref_windows(orc, rng, W))
+            wins = np.stack([g[1] for g in gen])
+            states = np.zeros(W, LINK_STATE_DTYPE)
+            for w, g in enumerate(gen):
+                states[w] = g[3]
         df = float(rng.choice([0.0, 0.0, 2.5, -7.0]))
         rx = RxPhy(cfg, max_batch=W)
-        out = rx.receive_byte(wins, oraclelib.CARRIER + df)
+        out = rx.receive_byte(wins, oraclelib.CARRIER + df, state=None if states is None else states.copy())
         nbad = 0
         for w in range(W):
-            ref = checker.receive_byte(wins[w], carrier=oraclelib.CARRIER + df)
+            ref = checker.receive_byte(wins[w], carrier=oraclelib.CARRIER + df, state=None if states is None else oraclelib.LinkState(*states[w].tolist()))
             st = out["stats"][w]
             diff = [k for k in INT_FIELDS if st[k] != ref[k]]
             if st["coarse_metric"] != ref["coarse_metric"] or st["freq_offset"] != ref["freq_offset"]:
