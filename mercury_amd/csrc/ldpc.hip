@@ -594,41 +594,41 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
             // normalised min-sum: R = alpha * (smallest |Q| among the check's other edges) with the sign parity of the others. The two
             // smallest magnitudes (m1 <= m2) and the sign parity of the whole check by the same all-reduce; the own edge is taken out
             // afterwards: min over the others = (|own| == m1) ? m2 : m1 (a tie leaves m2 == m1).
-            const float a = valid ? __builtin_fabsf(q) : __builtin_inff();
-            float m1 = a, m2 = __builtin_inff();
+            // Magnitudes are non-negative floats, so their bit patterns order like unsigned integers: the (m1, m2) merge runs on integer
+            // minima / maxima - no NaN-quieting instruction in front of every float minimum, the rows' representatives merge on the scalar unit.
+            const uint32_t a = valid ? __float_as_uint(q) & 0x7fffffffu : 0x7f800000u;
+            uint32_t m1 = a, m2 = 0x7f800000u;
             uint32_t sg = valid ? __float_as_uint(q) & 0x80000000u : 0u;
-            auto join = [&](float p1, float p2, uint32_t ps) {
-                const float hi = fmaxf(m1, p1);
-                m1 = fminf(m1, p1);
-                m2 = fminf(hi, fminf(m2, p2));
-                sg ^= ps;
-            };
+            auto umin = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+            auto umax = [](uint32_t x, uint32_t y) { return x > y ? x : y; };
+            auto dppu = [](auto ctrl, uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), decltype(ctrl)::value, 0xf, 0xf, false)); };
             auto step = [&](auto ctrl) {
-                constexpr int C = decltype(ctrl)::value;
-                join(spag_dpp<C>(m1), spag_dpp<C>(m2), uint32_t(__builtin_amdgcn_update_dpp(0, int(sg), C, 0xf, 0xf, false)));
+                const uint32_t p1 = dppu(ctrl, m1), p2 = dppu(ctrl, m2), ps = dppu(ctrl, sg);
+                const uint32_t hi = umax(m1, p1);
+                m1 = umin(m1, p1);
+                m2 = umin(hi, umin(m2, p2));
+                sg ^= ps;
             };
             step(std::integral_constant<int, 0xB1>());
             if (kind >= 2) step(std::integral_constant<int, 0x4E>());
             if (kind >= 3) step(std::integral_constant<int, 0x141>());
             if (kind >= 4) step(std::integral_constant<int, 0x140>());
             if (kind >= 5) {
-                auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
                 auto rs = [](uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); };
-                // rows 0|1 and 2|3 (and, for 64 lanes, both pairs): the same join on the rows' representatives
-                const float a1 = rl(m1, 0), a2 = rl(m2, 0), b1 = rl(m1, 16), b2 = rl(m2, 16), c1 = rl(m1, 32), c2 = rl(m2, 32), d1 = rl(m1, 48), d2 = rl(m2, 48);
+                const uint32_t a1 = rs(m1, 0), a2 = rs(m2, 0), b1 = rs(m1, 16), b2 = rs(m2, 16), c1 = rs(m1, 32), c2 = rs(m2, 32), d1 = rs(m1, 48), d2 = rs(m2, 48);
                 const uint32_t sa = rs(sg, 0) ^ rs(sg, 16), sc = rs(sg, 32) ^ rs(sg, 48);
-                auto join2 = [](float x1, float x2, float y1, float y2, float& o1, float& o2) {
-                    o1 = fminf(x1, y1);
-                    o2 = fminf(fmaxf(x1, y1), fminf(x2, y2));
-                };
-                float ab1, ab2, cd1, cd2;
-                join2(a1, a2, b1, b2, ab1, ab2);
-                join2(c1, c2, d1, d2, cd1, cd2);
-                if (kind == 6) { join2(ab1, ab2, cd1, cd2, m1, m2); sg = sa ^ sc; }
+                const uint32_t ab1 = umin(a1, b1), ab2 = umin(umax(a1, b1), umin(a2, b2)), cd1 = umin(c1, d1), cd2 = umin(umax(c1, d1), umin(c2, d2));
+                if (kind == 6) { m1 = umin(ab1, cd1); m2 = umin(umax(ab1, cd1), umin(ab2, cd2)); sg = sa ^ sc; }
                 else { m1 = lane < 32 ? ab1 : cd1; m2 = lane < 32 ? ab2 : cd2; sg = lane < 32 ? sa : sc; }
             }
-            const float mag = (a == m1) ? m2 : m1;
-            if (valid) M[slot] = __uint_as_float(__float_as_uint(mag * T.minsum_alpha) | ((sg ^ __float_as_uint(q)) & 0x80000000u));
+            float mag = __uint_as_float((a == m1) ? m2 : m1);
+            // Messages saturate at 2^12 (round 4). The rate-1/16 graph has a check of degree 1, whose min-sum message is alpha * min over NO
+            // other edge = +Inf; the Inf walked down the degree-2 checks of the accumulator chain and the next Q = Inf - Inf was a NaN that the
+            // float minima then ignored. With the cap the posteriors stay finite ((x + 2^12) - 2^12 keeps x to 2^-12), the rate-1/16 modes decode
+            // more frames in fewer iterations (mode 0 at -7.5 dB: 1817 -> 1867 of 2048; every other rate: identical results), and the float and
+            // the integer form of the merge agree bit for bit.
+            mag = fminf(mag * T.minsum_alpha, 4096.0f);
+            if (valid) M[slot] = __uint_as_float(__float_as_uint(mag) | ((sg ^ __float_as_uint(q)) & 0x80000000u));
             }
             k = kn;
         }
