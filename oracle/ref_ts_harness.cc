@@ -130,6 +130,53 @@ void mrefts_receive_byte(void* h, const double* passband, double carrier_hz, int
     }
 }
 
+// The two random sources of the reference's self-simulations: libc rand() (cl_awgn, awgn.cc:41-95) and the reference's own generator
+// (__random, os_interop.cc:192-283: the data bits of baseband_test_EsN0 / passband_test_EsN0), so that two objects can be given the same frames.
+void mrefts_seed(unsigned libc_seed, unsigned reference_seed) {
+    srand(libc_seed);
+    __srandom(reference_seed);
+}
+
+// receive_byte WITHOUT any reset of the object's members between calls: consecutive capture windows through one cl_telecom_system as
+// RX_SHM_process_main runs them (telecom_system.cc:2266-2390), so that what a call leaves UNWRITTEN in receive_stats on the paths that do not
+// reach the decoder (:646-1131) is visible. Only the receiver's settings are (re)stated; nUnder_processing_events / mfsk_fixed_delay are the
+// caller's to set (mrefts_set_loop_members). returned / held: {iterations_done delay delay_of_last_decoded_message sync_trials
+// message_decoded crc all_zeros mfsk_search_raw frame_overflow_symbols} + {freq_offset freq_offset_of_last_decoded_message SNR
+// signal_stregth_dbm coarse_metric} of the struct receive_byte returned and of the member afterwards.
+void mrefts_receive_byte_raw(void* h, const double* passband, double carrier_hz, int time_sync_trials_max, int use_last_good_time_sync,
+                             int use_last_good_freq_offset, int coarse_freq_sync_enabled, int* out_bytes, int* returned_ints,
+                             double* returned_doubles, int* held_ints, double* held_doubles) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    Silence s;
+    t->carrier_frequency = carrier_hz;
+    t->time_sync_trials_max = time_sync_trials_max;
+    t->use_last_good_time_sync = use_last_good_time_sync;
+    t->use_last_good_freq_offset = use_last_good_freq_offset;
+    g_gui_state.coarse_freq_sync_enabled.store(coarse_freq_sync_enabled != 0);
+    const int n = mrefts_buffer_samples(h);
+    memcpy(t->data_container.ready_to_process_passband_delayed_data, passband, size_t(n) * sizeof(double));
+    const st_receive_stats r = t->receive_byte(t->data_container.ready_to_process_passband_delayed_data, out_bytes);
+    const st_receive_stats* both[2] = {&r, &t->receive_stats};
+    int* ints[2] = {returned_ints, held_ints};
+    double* dbl[2] = {returned_doubles, held_doubles};
+    for (int k = 0; k < 2; k++) {
+        const st_receive_stats& q = *both[k];
+        int* o = ints[k]; double* d = dbl[k];
+        o[0] = q.iterations_done; o[1] = q.delay; o[2] = q.delay_of_last_decoded_message; o[3] = q.sync_trials; o[4] = q.message_decoded;
+        o[5] = q.crc; o[6] = q.all_zeros; o[7] = q.mfsk_search_raw; o[8] = q.frame_overflow_symbols;
+        d[0] = q.freq_offset; d[1] = q.freq_offset_of_last_decoded_message; d[2] = q.SNR; d[3] = q.signal_stregth_dbm; d[4] = q.coarse_metric;
+    }
+}
+// the loop's own members around receive_byte: data_container.nUnder_processing_events (:683, reset by the process loops :2158), the one-shot
+// mfsk_fixed_delay (:663-672), receive_stats.mfsk_search_raw (ARQ sets it). A value of INT_MIN leaves the member alone.
+void mrefts_set_loop_members(void* h, int nUnder_processing_events, int mfsk_fixed_delay, int mfsk_search_raw) {
+    cl_telecom_system* t = static_cast<cl_telecom_system*>(h);
+    const int keep = -2147483647 - 1;
+    if (nUnder_processing_events != keep) t->data_container.nUnder_processing_events = nUnder_processing_events;
+    if (mfsk_fixed_delay != keep) t->mfsk_fixed_delay = mfsk_fixed_delay;
+    if (mfsk_search_raw != keep) t->receive_stats.mfsk_search_raw = mfsk_search_raw;
+}
+
 // ---- the transmit side and the small members the C-ABI mirrors -------------------------------------------------------------------
 double mrefts_carrier(void* h) { return static_cast<cl_telecom_system*>(h)->carrier_frequency; }
 

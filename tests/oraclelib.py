@@ -457,11 +457,17 @@ class RefTelecomSystem:
     def available():
         return os.path.exists(REF_TS_SO)
 
-    def __init__(self, cfg):
-        self.lib = C.CDLL(REF_TS_SO, mode=1)          # RTLD_LAZY: the GUI / ARQ / audio-driver functions the units mention stay unbound
+    SO = REF_TS_SO
+
+    def _create(self, cfg):
         self.lib.mrefts_create.restype = C.c_void_p
-        self.h = C.c_void_p(self.lib.mrefts_create(C.c_int(cfg)))
-        assert self.h.value
+        return self.lib.mrefts_create(C.c_int(cfg))
+
+    def __init__(self, cfg):
+        self.lib = C.CDLL(self.SO, mode=1)            # RTLD_LAZY: the GUI / ARQ / audio-driver functions the units mention stay unbound
+        self.cfg = cfg
+        self.h = C.c_void_p(self._create(cfg))
+        assert self.h.value, "could not create the reference object for cfg %d" % cfg
         o = (C.c_int * 32)()
         n = self.lib.mrefts_info(self.h, o)
         assert n == len(TS_INFO_FIELDS)
@@ -550,7 +556,96 @@ class RefTelecomSystem:
         self.lib.mrefts_load_configuration(self.h, C.c_int(cfg), o)
         return tuple(o)
 
+    def seed(self, libc_seed, reference_seed=None):
+        """srand() (cl_awgn's noise) and __srandom() (the self-simulations' data bits) of this library's copy of the reference"""
+        self.lib.mrefts_seed(C.c_uint(libc_seed), C.c_uint(libc_seed if reference_seed is None else reference_seed))
+
+    RAW_INTS = "iterations_done delay delay_of_last_decoded_message sync_trials message_decoded crc all_zeros mfsk_search_raw frame_overflow_symbols".split()
+    RAW_DOUBLES = "freq_offset freq_offset_of_last_decoded_message SNR signal_stregth_dbm coarse_metric".split()
+
+    def receive_byte_raw(self, passband, carrier=None, trials_max=2, use_last_time=1, use_last_freq=1, coarse_freq_sync=0):
+        """receive_byte on the object AS IT IS (no member is reset): -> (returned, held, out) where returned / held are dicts of the
+        st_receive_stats the call returned / the object holds afterwards and out the int array receive_byte wrote into (a caller's
+        buffer that is NOT cleared between calls: kept on the wrapper)."""
+        x = np.ascontiguousarray(passband, np.float64)
+        assert x.size == self.buffer_samples()
+        if not hasattr(self, "_raw_out"):
+            self._raw_out = np.full(1600, -1, np.int32)
+        ri, hi = (C.c_int * 9)(), (C.c_int * 9)()
+        rd, hd = (C.c_double * 5)(), (C.c_double * 5)()
+        self.lib.mrefts_receive_byte_raw(self.h, _p(x), C.c_double(CARRIER if carrier is None else carrier), C.c_int(trials_max), C.c_int(use_last_time),
+                                         C.c_int(use_last_freq), C.c_int(coarse_freq_sync), _p(self._raw_out), ri, rd, hi, hd)
+        ret = dict(zip(self.RAW_INTS, list(ri)), **dict(zip(self.RAW_DOUBLES, list(rd))))
+        held = dict(zip(self.RAW_INTS, list(hi)), **dict(zip(self.RAW_DOUBLES, list(hd))))
+        return ret, held, self._raw_out.copy()
+
+    KEEP = -2147483648
+
+    def set_loop_members(self, n_under=KEEP, fixed_delay=KEEP, search_raw=KEEP):
+        self.lib.mrefts_set_loop_members(self.h, C.c_int(n_under), C.c_int(fixed_delay), C.c_int(search_raw))
+
     def close(self):
         if self.h:
             self.lib.mrefts_destroy(self.h)
+            self.h = None
+
+
+# ---- the same reference objects with the section-8b methods re-bound to libmercury_gpu.so (oracle/ref_ts_gpu_harness.cc) -------------
+REF_TS_GPU_SO = os.path.join(ROOT, "oracle", "_ref", "libmercury_ref_ts_gpu.so")
+GPU_METHODS = ("symbol_demod automatic_gain_control channel_estimator restore_channel_amplitude channel_equalizer "
+               "channel_equalizer_without_amplitude_restoration measure_variance deframer deinterleaver_c128 deinterleaver_f32 psk_demod ldpc_decode "
+               "bit_energy_dispersal bit_to_byte crc16 receive_byte").split()
+MODE_REFERENCE, MODE_STAGES, MODE_SHADOW, MODE_WHOLE = 0, 1, 2, 4
+
+
+class RefTelecomSystemGpu(RefTelecomSystem):
+    """The reference's cl_telecom_system (unmodified object code) whose cl_ofdm / cl_psk / cl_ldpc methods, free functions and - with
+    MODE_WHOLE - receive_byte are served by libmercury_gpu.so: the drop-in as the reference's own callers see it. mode 0 = everything falls
+    through to the original machine code (works without a GPU)."""
+    SO = REF_TS_GPU_SO
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_TS_GPU_SO)
+
+    def __init__(self, cfg, mode, max_iters=50):
+        self.mode, self.max_iters = mode, max_iters
+        super().__init__(cfg)
+
+    def _create(self, cfg):
+        self.lib.mreftsgpu_create.restype = C.c_void_p
+        return self.lib.mreftsgpu_create(C.c_int(cfg), C.c_int(self.mode), C.c_int(self.max_iters))
+
+    def set_mode(self, mode):
+        self.mode = mode
+        return int(self.lib.mreftsgpu_set_mode(self.h, C.c_int(mode)))
+
+    def counters(self, reset=False):
+        """{method: (calls, served by the GPU, differed from the original machine code under MODE_SHADOW)}"""
+        o = (C.c_long * (3 * 32))()
+        n = self.lib.mreftsgpu_counters(self.h, o, C.c_int(1 if reset else 0))
+        assert n == len(GPU_METHODS), n
+        return {m: (int(o[3 * i]), int(o[3 * i + 1]), int(o[3 * i + 2])) for i, m in enumerate(GPU_METHODS)}
+
+    def error(self):
+        self.lib.mreftsgpu_error.restype = C.c_char_p
+        return self.lib.mreftsgpu_error(self.h).decode()
+
+    def rx_rand_process_main(self, passband, frames_to_read=0):
+        """cl_telecom_system::RX_RAND_process_main on one capture window -> (what it printed, frames_to_read afterwards)"""
+        x = np.ascontiguousarray(passband, np.float64)
+        assert x.size == self.buffer_samples()
+        buf = C.create_string_buffer(1 << 16)
+        ftr = C.c_int(frames_to_read)
+        n = self.lib.mreftsgpu_rx_rand_process_main(self.h, _p(x), C.byref(ftr), buf, C.c_int(len(buf)))
+        return buf.raw[:n].decode(errors="replace"), int(ftr.value)
+
+    def held_receive_stats(self):
+        i, d = (C.c_int * 9)(), (C.c_double * 5)()
+        self.lib.mreftsgpu_receive_stats(self.h, i, d)
+        return dict(zip(self.RAW_INTS, list(i)), **dict(zip(self.RAW_DOUBLES, list(d))))
+
+    def close(self):
+        if self.h:
+            self.lib.mreftsgpu_destroy(self.h)
             self.h = None
