@@ -52,6 +52,7 @@ struct st_receive_stats {
     double freq_offset = 0;
     double freq_offset_of_last_decoded_message = 0;
     double coarse_metric = 0;
+    double signal_stregth_dbm = -999;   // (the reference's spelling) 10 log10 of the time-sync baseband's mean power in mW, telecom_system.cc:678
     int frame_overflow_symbols = 0;
     int mfsk_search_raw = 0;      // telecom_system.h:79: MFSK anti-re-decode base search position (symbols); the ARQ layer sets it
 };
@@ -69,6 +70,27 @@ inline st_receive_stats convert(const mgpu_frame_stats& s) {
     r.all_zeros = s.all_zeros ? YES : NO;
     r.variance = s.variance;
     return r;
+}
+// What ONE receive_byte call writes into the receive_stats member it returns, path by path (telecom_system.cc:646-1503) - everything else
+// keeps the previous call's value, which is what the caller of the reference reads too (pinned against the real object run window after
+// window without resets: tests/test_receive_byte_stale_fields.py):
+//   message_decoded, frame_overflow_symbols, sync_trials          every call (:653-655, :710-712)
+//   delay, signal_stregth_dbm                                      every call (:668-692)
+//   coarse_metric                                                  every call in the OFDM modes (:693), never in the MFSK modes
+//   iterations_done, all_zeros, crc, SNR                           only when a trial reached the decoder (:1310-1347, :1362-1398)
+//   freq_offset                                                    only on a decoded OFDM frame (:1421-1425)
+//   delay_of_last_decoded_message, freq_offset_of_last_...         through mgpu_link_state (:1423-1427)
+// r.iterations_done == -1 <=> no trial reached the decoder (the decoder itself returns 0 .. nIteration_max + 1).
+inline void apply_receive_byte(st_receive_stats& q, const mgpu_receive_stats& r, const mgpu_link_state& ls, bool mfsk) {
+    q.message_decoded = r.message_decoded ? YES : NO; q.frame_overflow_symbols = r.frame_overflow_symbols; q.sync_trials = r.sync_trials;
+    q.delay = r.delay; q.signal_stregth_dbm = r.signal_strength_dbm;
+    if (!mfsk) q.coarse_metric = r.coarse_metric;
+    if (r.iterations_done != -1 || r.message_decoded) {
+        q.iterations_done = r.iterations_done; q.crc = r.crc; q.all_zeros = r.all_zeros; q.SNR = r.snr_db;
+    }
+    if (r.message_decoded && !mfsk) q.freq_offset = r.freq_offset;
+    q.delay_of_last_decoded_message = ls.delay_of_last_decoded_message;
+    q.freq_offset_of_last_decoded_message = ls.freq_offset_of_last_decoded_message;
 }
 }  // namespace detail
 
@@ -168,6 +190,10 @@ public:
                 detail::check(mgpu_set_pre_equalization_channel(ctx_, reinterpret_cast<const double*>(pre_equalization_channel.data())), ctx_,
                               "load_configuration");
             else { get_pre_equalization_channel(); pre_eq_key_ = key; }
+        } else {
+            // An MFSK mode changes the modulation, which sets the reference's sticky reinit flag (telecom_system.cc:2682-2691); init() only
+            // measures and clears it in an OFDM mode (:1954-1958), so the next OFDM load re-measures whatever its modulation: drop the key.
+            pre_eq_key_ = PreEqKey{};
         }
     }
     // void cl_telecom_system::return_to_last_configuration() — telecom_system.cc:3027-3034, statement for statement. Note what the reference's
@@ -245,15 +271,7 @@ public:
         detail::check(mgpu_receive_byte_batch(ctx_, data, 1, &rc, &ls, bytes.data(), &r), ctx_, "receive_byte");
         if (r.iterations_done != -1)                               // no decode attempted: the reference leaves out[] as it was
             for (int i = 0; i < info.payload_bytes; ++i) out[i] = bytes[i];
-        if (r.iterations_done != -1 || r.message_decoded) {       // a decode was attempted: these members were written
-            receive_stats.iterations_done = r.iterations_done; receive_stats.crc = r.crc; receive_stats.all_zeros = r.all_zeros;
-        }
-        receive_stats.message_decoded = r.message_decoded; receive_stats.SNR = r.snr_db;
-        receive_stats.delay = r.delay; receive_stats.sync_trials = r.sync_trials; receive_stats.coarse_metric = r.coarse_metric;
-        receive_stats.frame_overflow_symbols = r.frame_overflow_symbols;
-        if (r.message_decoded) receive_stats.freq_offset = r.freq_offset;
-        receive_stats.delay_of_last_decoded_message = ls.delay_of_last_decoded_message;
-        receive_stats.freq_offset_of_last_decoded_message = ls.freq_offset_of_last_decoded_message;
+        detail::apply_receive_byte(receive_stats, r, ls, info.mfsk_M > 0);
         return receive_stats;
     }
 
@@ -305,15 +323,7 @@ public:
         if (r.iterations_done != -1)
             for (int i = 0; i < info.nReal / 8; ++i)
                 for (int j = 0; j < 8; ++j) out[i * 8 + j] = (bytes[i] >> j) & 1;
-        if (r.iterations_done != -1 || r.message_decoded) {
-            receive_stats.iterations_done = r.iterations_done; receive_stats.crc = r.crc; receive_stats.all_zeros = r.all_zeros;
-        }
-        receive_stats.message_decoded = r.message_decoded; receive_stats.SNR = r.snr_db;
-        receive_stats.delay = r.delay; receive_stats.sync_trials = r.sync_trials; receive_stats.coarse_metric = r.coarse_metric;
-        receive_stats.frame_overflow_symbols = r.frame_overflow_symbols;
-        if (r.message_decoded) receive_stats.freq_offset = r.freq_offset;
-        receive_stats.delay_of_last_decoded_message = ls.delay_of_last_decoded_message;
-        receive_stats.freq_offset_of_last_decoded_message = ls.freq_offset_of_last_decoded_message;
+        detail::apply_receive_byte(receive_stats, r, ls, info.mfsk_M > 0);
         return receive_stats;
     }
 

@@ -16,6 +16,8 @@
 //   bit 1 (2)  SHADOW   with STAGES: the original machine code runs as well, on copies, and every output is compared bit for bit
 //                       (counters per method: calls, calls on the GPU, calls whose outputs differed)
 //   bit 2 (4)  WHOLE    cl_telecom_system::receive_byte as a whole is mgpu_receive_byte_batch (mercury_rxloop.h) with W = 1
+//   bit 3 (8)  MIRROR   cl_telecom_system::receive_byte as a whole is mgpu::cl_rx_phy::receive_byte (include/mercury_gpu.hpp, the product's C++
+//                       mirror, through oracle/ref_ts_gpu_mirror.cc) running on its OWN receive_stats from call to call
 //   0                   everything falls through to the original code: the object behaves as libmercury_ref_ts.so's
 // A method called on an object that has no binding (another cl_psk inside cl_ofdm, a second cl_telecom_system) runs the original.
 // The product never links this file; it links the product.
@@ -58,15 +60,29 @@ uint16_t mref_orig_crc16(int*, int);
 void mref_orig_ts_receive_byte(st_receive_stats*, cl_telecom_system*, double*, int*);
 }
 
+// oracle/ref_ts_gpu_mirror.cc
+extern "C" {
+struct mmirror_stats {
+    int iterations_done, delay, delay_of_last_decoded_message, sync_trials, message_decoded, crc, all_zeros, mfsk_search_raw, frame_overflow_symbols;
+    double freq_offset, freq_offset_of_last_decoded_message, SNR, signal_stregth_dbm, coarse_metric;
+};
+void* mmirror_create(int cfg, int max_iters);
+void mmirror_destroy(void* h);
+int mmirror_receive_byte(void* h, const double* data, int* out, double carrier_hz, int time_sync_trials_max, int use_last_good_time_sync,
+                         int use_last_good_freq_offset, int coarse_freq_sync_enabled, int ctrl_mode, int nUnder_processing_events, int* mfsk_fixed_delay,
+                         int delay_of_last_decoded_message, double freq_offset_of_last_decoded_message, int mfsk_search_raw, mmirror_stats* held);
+}
+
 namespace {
 
 enum Method { M_SYMBOL_DEMOD, M_AGC, M_ESTIMATOR, M_RESTORE_AMPLITUDE, M_EQUALIZER, M_EQUALIZER_WAR, M_VARIANCE, M_DEFRAMER, M_DEINT_C128,
               M_DEINT_F32, M_PSK_DEMOD, M_LDPC_DECODE, M_DISPERSAL, M_BIT_TO_BYTE, M_CRC16, M_RECEIVE_BYTE, N_METHODS };
-enum { STAGES = 1, SHADOW = 2, WHOLE = 4 };
+enum { STAGES = 1, SHADOW = 2, WHOLE = 4, MIRROR = 8 };
 
 struct Binding {
     cl_telecom_system* ts = nullptr;
     mgpu_ctx* ctx = nullptr;        // the mode's context (receive_byte semantics: agc = 1, variance on the equalised grid)
+    void* mirror = nullptr;         // mode MIRROR: an mgpu::cl_rx_phy (ref_ts_gpu_mirror.cc)
     mgpu_ctx* ctx_ctrl = nullptr;   // ROBUST_0 / ROBUST_1: the short control frames' context (set_mfsk_ctrl_mode), made on first use
     mgpu_info info{};
     int cfg = -1, mode = 0;
@@ -348,6 +364,26 @@ int cl_ldpc::decode(const float* data, int* decoded_data) {
 st_receive_stats cl_telecom_system::receive_byte(double* data, int* out) {
     Binding* b = binding_of(this, 0);
     if (b) b->calls[M_RECEIVE_BYTE]++;
+    if (b && (b->mode & MIRROR) && b->mirror) {
+        b->gpu[M_RECEIVE_BYTE]++;
+        mmirror_stats q{};
+        int fixed = mfsk_fixed_delay;
+        if (mmirror_receive_byte(b->mirror, data, out, carrier_frequency, time_sync_trials_max, use_last_good_time_sync, use_last_good_freq_offset,
+                                 g_gui_state.coarse_freq_sync_enabled.load() ? 1 : 0, (mfsk_ctrl_mode && M == MOD_MFSK && ctrl_nsymb > 0) ? 1 : 0,
+                                 data_container.nUnder_processing_events, &fixed, receive_stats.delay_of_last_decoded_message,
+                                 receive_stats.freq_offset_of_last_decoded_message, receive_stats.mfsk_search_raw, &q) != 0) {
+            snprintf(b->error, sizeof b->error, "mirror receive_byte failed");
+            return receive_stats;
+        }
+        mfsk_fixed_delay = fixed;
+        receive_stats.iterations_done = q.iterations_done; receive_stats.delay = q.delay;
+        receive_stats.delay_of_last_decoded_message = q.delay_of_last_decoded_message; receive_stats.sync_trials = q.sync_trials;
+        receive_stats.message_decoded = q.message_decoded; receive_stats.crc = q.crc; receive_stats.all_zeros = q.all_zeros;
+        receive_stats.frame_overflow_symbols = q.frame_overflow_symbols; receive_stats.freq_offset = q.freq_offset;
+        receive_stats.freq_offset_of_last_decoded_message = q.freq_offset_of_last_decoded_message; receive_stats.SNR = q.SNR;
+        receive_stats.signal_stregth_dbm = q.signal_stregth_dbm; receive_stats.coarse_metric = q.coarse_metric;
+        return receive_stats;
+    }
     if (!b || !(b->mode & WHOLE) || !b->ctx) {
         st_receive_stats r;
         mref_orig_ts_receive_byte(&r, this, data, out);
@@ -368,8 +404,9 @@ st_receive_stats cl_telecom_system::receive_byte(double* data, int* out) {
                            g_gui_state.coarse_freq_sync_enabled.load() ? 1 : 0};
     int search_start = receive_stats.mfsk_search_raw - data_container.nUnder_processing_events;      // :683-685
     if (search_start < 0) search_start = 0;
+    const bool mfsk_mode = M == MOD_MFSK;
     mgpu_link_state ls{receive_stats.delay_of_last_decoded_message, receive_stats.freq_offset_of_last_decoded_message, search_start,
-                       (M == MOD_MFSK && mfsk_fixed_delay >= 0) ? mfsk_fixed_delay + 1 : 0};
+                       (mfsk_mode && mfsk_fixed_delay >= 0) ? mfsk_fixed_delay + 1 : 0};
     mgpu_receive_stats r{};
     mgpu_info info{};
     mgpu_get_info(ctx, &info);
@@ -380,18 +417,20 @@ st_receive_stats cl_telecom_system::receive_byte(double* data, int* out) {
         fprintf(stderr, "[ref_ts_gpu] %s\n", b->error);
         return receive_stats;
     }
-    if (M == MOD_MFSK) mfsk_fixed_delay = -1;                                 // used once (:663-672)
-    // the members receive_byte writes, on the paths that write them (see tests/test_receive_byte_stale_fields.py)
+    if (mfsk_mode) mfsk_fixed_delay = -1;                                     // used once (:663-672)
+    // the members receive_byte writes, on the paths that write them (the same table as mgpu::detail::apply_receive_byte;
+    // pinned by tests/test_receive_byte_stale_fields.py)
     if (r.iterations_done != -1)
-        for (int i = 0; i < info.payload_bytes; i++) out[i] = bytes[i];
-    if (r.iterations_done != -1 || r.message_decoded) {
-        receive_stats.iterations_done = r.iterations_done; receive_stats.crc = r.crc; receive_stats.all_zeros = r.all_zeros;
+        for (int i = 0; i < info.payload_bytes; i++) out[i] = bytes[i];                                              // :1329-1332
+    receive_stats.message_decoded = r.message_decoded; receive_stats.frame_overflow_symbols = r.frame_overflow_symbols;   // :653-655, :710-712
+    receive_stats.sync_trials = r.sync_trials;
+    receive_stats.delay = r.delay; receive_stats.signal_stregth_dbm = r.signal_strength_dbm;                          // :668-692
+    if (!mfsk_mode) receive_stats.coarse_metric = r.coarse_metric;                                                    // :693
+    if (r.iterations_done != -1 || r.message_decoded) {                                                               // a trial reached the decoder
+        receive_stats.iterations_done = r.iterations_done; receive_stats.crc = r.crc; receive_stats.all_zeros = r.all_zeros;   // :1310-1341
+        receive_stats.SNR = r.snr_db;                                                                                 // :1347, :1362-1398
     }
-    receive_stats.message_decoded = r.message_decoded; receive_stats.SNR = r.snr_db;
-    receive_stats.delay = r.delay; receive_stats.sync_trials = r.sync_trials; receive_stats.coarse_metric = r.coarse_metric;
-    receive_stats.frame_overflow_symbols = r.frame_overflow_symbols;
-    receive_stats.signal_stregth_dbm = r.signal_strength_dbm;
-    if (r.message_decoded) receive_stats.freq_offset = r.freq_offset;
+    if (r.message_decoded && !mfsk_mode) receive_stats.freq_offset = r.freq_offset;                                   // :1421-1425
     receive_stats.delay_of_last_decoded_message = ls.delay_of_last_decoded_message;
     receive_stats.freq_offset_of_last_decoded_message = ls.freq_offset_of_last_decoded_message;
     return receive_stats;
@@ -422,6 +461,10 @@ void* mreftsgpu_create(int cfg, int mode, int max_iters) {
             return nullptr;
         }
         mgpu_get_info(b->ctx, &b->info);
+        if (mode & MIRROR) {
+            b->mirror = mmirror_create(cfg, max_iters);
+            if (!b->mirror) { mgpu_destroy(b->ctx); delete b; delete t; return nullptr; }
+        }
     }
     g_bindings.push_back(b);
     t->operation_mode = RX_SHM;                      // main.cc:505
@@ -437,6 +480,7 @@ void mreftsgpu_destroy(void* h) {
             if (g_current == b) g_current = nullptr;
             if (b->ctx) mgpu_destroy(b->ctx);
             if (b->ctx_ctrl) mgpu_destroy(b->ctx_ctrl);
+            if (b->mirror) mmirror_destroy(b->mirror);
             g_bindings.erase(g_bindings.begin() + i);
             delete b;
             break;

@@ -211,7 +211,7 @@ def test_gpu_receive_byte_randomised_windows_match_oracle(cfg, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [0, 8, 11, 16, 101])
+@pytest.mark.parametrize("cfg", list(range(17)) + [100, 101, 102])
 def test_gpu_receive_byte_equals_the_reference_cl_telecom_system(cfg):
     """The GPU's batched receive_byte against the reference's OWN cl_telecom_system::receive_byte (oracle/_ref/libmercury_ref_ts.so: the
     reference's telecom_system.cc compiled unmodified, oracle/ref_ts_harness.cc) on the randomised windows of
@@ -225,7 +225,7 @@ def test_gpu_receive_byte_equals_the_reference_cl_telecom_system(cfg):
     from test_receive_byte_vs_reference import windows
     orc, ref = Oracle(cfg), RefTelecomSystem(cfg)
     rng = np.random.default_rng(8100 + cfg)
-    W = 24
+    W = 16
     ws = list(windows(orc, rng, W))
     call = dict(trials_max=2, use_last_time=1, use_last_freq=1, coarse_freq_sync=0)
     df = 2.5
@@ -251,7 +251,7 @@ def test_gpu_receive_byte_equals_the_reference_cl_telecom_system(cfg):
         for k in ("delay_of_last_decoded_message", "freq_offset_of_last_decoded_message", "mfsk_search_start", "fixed_delay_plus_one"):
             assert out["state"][w][k] == getattr(sb, k) or (k.startswith("freq") and abs(out["state"][w][k] - getattr(sb, k)) <= 1e-9), (cfg, w, kind, k)
         ndec += int(b["message_decoded"])
-    assert ndec >= 4
+    assert ndec >= 1
     print("doubles not bit-identical to the reference:", sorted(set(inexact)) or "none")
     rx.close()
     ref.close()

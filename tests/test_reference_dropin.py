@@ -177,7 +177,7 @@ def test_reference_rx_rand_loop_decodes_what_the_reference_sent(cfg, mode):
     start = base + n // 2 + 3 * symbol + 77
     stream[start: start + pb.size] += pb
     fa = fb = 0
-    decoded = 0
+    decoded, attempted = 0, False
     for step in range(14):                                                # the capture window slides over the frame, as the capture thread would move it
         off = base + n // 2 - (7 - step) * slide
         x = stream[off: off + n]
@@ -191,7 +191,10 @@ def test_reference_rx_rand_loop_decodes_what_the_reference_sent(cfg, mode):
             assert da[1] == list(sent), (cfg, step)
             decoded += 1
         ha, hb = a.held_receive_stats(), b.held_receive_stats()
-        for k in a.RAW_INTS:
+        attempted = attempted or ha["iterations_done"] != -1              # crc / all_zeros: not set by the constructor (telecom_system.cc:38-51),
+        for k in a.RAW_INTS:                                              # first written by the first trial that reaches the decoder (:1319-1341)
+            if k in ("crc", "all_zeros") and not attempted:
+                continue
             assert ha[k] == hb[k], (cfg, step, k, ha[k], hb[k])
         fa = fb = 0                                                       # the capture thread counts frames_to_read down to 0 before the next call
     assert decoded >= 2, (cfg, decoded)
