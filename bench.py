@@ -557,7 +557,7 @@ def main():
     if collective:
         dist.barrier()
     machine = machine_of(local_rank)
-    sampler = ClockSampler(machine["pci_bus_id"]) if rank == 0 else None
+    sampler = ClockSampler(machine["pci_bus_id"])          # every rank watches its own board: a clock sag under N boards' power must be visible
     if sampler:
         sampler.start()
     rx.enable_timing(True)
@@ -578,9 +578,16 @@ def main():
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     sums = torch.stack([iters_acc, decoded_acc]).to(torch.float64).to(rdev)
+    # per rank, next to roofline.frac in the N > 1 line: the engine clock its board held and the power it drew while timed, its own
+    # kernel times and wall time (-1 = no hwmon file for that board)
+    mine = torch.tensor([(sclk or {}).get("median", -1.0), (sclk or {}).get("min", -1.0), (sclk or {}).get("power_w_median", -1.0), dec_ms, fe_ms, dt * 1e3],
+                        dtype=torch.float64, device=rdev)
+    per_rank = [mine]
     if collective:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
     dt = float(tmax.item())
     iters_total = float(sums[0].item())
     decoded_total = float(sums[1].item())
@@ -616,6 +623,8 @@ def main():
             "decoded_fraction": decoded_total / frames_total,
             "kernel_ms": {"frontend": fe_ms, "ldpc": dec_ms, "launches_averaged": nl},
             "sclk_mhz_during_run": sclk,
+            "per_rank": [{"rank": r, "sclk_mhz_median": float(v[0]), "sclk_mhz_min": float(v[1]), "power_w_median": float(v[2]),
+                          "ldpc_kernel_ms": float(v[3]), "frontend_kernel_ms": float(v[4]), "wall_ms": float(v[5])} for r, v in enumerate(per_rank)],
             "machine": machine,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": mix_src,

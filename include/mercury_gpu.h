@@ -212,6 +212,21 @@ int mgpu_host_mode_info(int cfg, int mfsk_ctrl_mode, mgpu_info* info);
  * group (1.0 = conflict-free) of the check pass's posterior reads and the variable update's message reads; out[2] bins; out[3] occupancy */
 int mgpu_host_layout_stats(int cfg, double out[4]);
 
+/* mgpu_host_libm_selfcheck (host-only, no GPU): the device code restates the libm of the reference platform the parity was pinned on -
+ * x86-64 glibc 2.35: tanh / atanh of the sum-product decoder (ldpc_decoder_SPA.cc:145,156), atan / sincos of restore_channel_amplitude and the
+ * receive mixer (misc.cc:34-71, ofdm.cc:2331-2332). This evaluates the HOST's libm and the same restatement compiled for the host on the
+ * branch-boundary sets of tests/test_spa_math.py / tests/test_glibc_trig.py plus a fixed pseudo-random sample and reports, per function
+ * (index 0 tanh(0.5 q), 1 2 atanh(x), 2 atan, 3 sincos), how many arguments were evaluated and how many results differed in any bit.
+ * Returns the number of functions that differ (0: a reference built on this host computes what the device computes). The result is
+ * cached; mgpu_create runs it once per process and writes one line to stderr if anything differs (MERCURY_GPU_LIBM_CHECK=0 disables that). */
+typedef struct mgpu_libm_report {
+    long long evaluated[4], differed[4];
+    double first_differing_argument[4];
+    int differing;
+    char libc_version[32];
+} mgpu_libm_report;
+int mgpu_host_libm_selfcheck(mgpu_libm_report* out /* may be NULL */);
+
 /* void cl_ldpc::encode(const int* data, int* encoded_data) (ldpc.h:82, ldpc.cc:111-132) for F words: bits [F][K], one byte per bit
  * -> encoded [F][N] = the data followed by the P parity bits. */
 int mgpu_ldpc_encode_batch(mgpu_ctx* ctx, const uint8_t* bits, int F, uint8_t* encoded);

@@ -66,7 +66,7 @@ int mgpu_host_pre_equalization_channel(int cfg, double carrier_hz, double* chann
  * continue the PRNG stream the pilot seed started) */
 int mgpu_context_pre_equalization_channel(mgpu_ctx* ctx, double carrier_hz, double* channel_c128);
 /* installs the table transmit_bit multiplies the carrier grids with (telecom_system.cc:474-494) in this context, [Nc] complex128;
- * NULL removes it (all ones). Synchronises the context's stream. The MFSK modes have none (telecom_system.cc:474). */
+ * NULL removes it (all ones). Waits for the whole device (hipDeviceSynchronize: the table is read by kernels on every stream of the context). The MFSK modes have none (telecom_system.cc:474). */
 int mgpu_set_pre_equalization_channel(mgpu_ctx* ctx, const double* channel_c128);
 
 /* total_frame_size = Nofdm * (Nsymb + preamble_nSymb) * 4 (data_container.cc:159): samples written per message */

@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libmercury_gpu.so")
 TABLES = os.path.join(HERE, "data", "mercury_ldpc_tables.bin")
 
 HIP_SOURCES = ["api.hip", "rxloop.hip", "stages_api.hip", "stages.hip", "frontend.hip", "mfsk.hip", "ldpc.hip", "txgen.hip", "tx.hip", "stats.hip", "sync.hip"]
-CXX_SOURCES = ["tables.cpp", "shm_transport.cpp", "pool.cpp", "numa.cpp"]
+CXX_SOURCES = ["tables.cpp", "shm_transport.cpp", "pool.cpp", "numa.cpp", "libm_check.cpp"]
 HEADERS = ["device_tables.h", "tables.hpp", "numa.hpp", "spa_math.h", "fft256.h", "fe_math.h", "glibc_trig.h", "glibc_trig_tables.h", "ctx.hpp", os.path.join(ROOT, "include", "mercury_gpu.h"),
            os.path.join(ROOT, "include", "mercury_shm.h"), os.path.join(ROOT, "include", "mercury_rxloop.h"), os.path.join(ROOT, "include", "mercury_stages.h"),
            os.path.join(ROOT, "include", "mercury_tx.h"), os.path.join(ROOT, "include", "mercury_pool.h")]
@@ -87,6 +87,8 @@ def build(force=False, verbose=False):
         cmd = [hipcc] + HIPCC_FLAGS + ["-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-c", os.path.join(CSRC, src), "-o", obj]
+            if src == "libm_check.cpp":      # the host's libm must be CALLED, not folded (fma() stays a libm call too: correct on any x86-64)
+                cmd[1:1] = ["-fno-builtin"]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

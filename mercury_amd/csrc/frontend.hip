@@ -89,12 +89,15 @@ __host__ __device__ inline FeCarve fe_carve(int G, int nPilots, int nBits, int F
     // LDS is handed out in blocks of 1280 bytes (measured: three workgroups of 53,504 bytes run side by side on a compute unit, three of
     // 54,016 do not — the runtime's occupancy calculator says 3 for both), so a workgroup's share is a whole number of blocks
     const size_t block = 1280;
-    size_t wgs = lds_cu / ((minimal + block - 1) / block * block);  // workgroups per compute unit by LDS with the fewest FFT work areas
+    // ... less 256 bytes: round 4 measured three workgroups of 53,504 bytes resident and three of 53,760 (42 blocks exactly) not. The same
+    // budget (bytes + 256, rounded up to blocks) counts the workgroups AND sizes the FFT work areas.
+    const size_t overhead = 256;
+    size_t wgs = lds_cu / ((minimal + overhead + block - 1) / block * block);  // workgroups per compute unit by LDS with the fewest FFT work areas
     const size_t cap = size_t(24 / FE_WAVES) > 0 ? size_t(24 / FE_WAVES) : 1;    // 80 registers per lane: 24 wavefronts per compute unit
     if (wgs > cap) wgs = cap;
     if (wgs < 1) wgs = 1;
-    // ... less 256 bytes: round 4 measured three workgroups of 53,504 bytes resident and three of 53,760 (42 blocks exactly) not
-    size_t w = (lds_cu / wgs / block * block - 256 - fixed) / per_wave;
+    const size_t share = lds_cu / wgs / block * block;
+    size_t w = share > fixed + overhead ? (share - overhead - fixed) / per_wave : 0;
     c.fft_waves = int(w < 4 ? 4 : (w > size_t(FE_WAVES) ? size_t(FE_WAVES) : w));
     c.work = need > c.fft_waves * per_wave ? need : c.fft_waves * per_wave;
     c.total = fixed + c.work;

@@ -518,7 +518,9 @@ __device__ __forceinline__ void spa_fast_decode(const LdpcDev& T, const float* _
         // sum-product: before the first iteration Q is the channel LLR on every edge of a variable, so T = tanh(Q/2) is computed here once per
         // variable and the first check pass takes it from the posterior array (same expression, same value; the sign - all the syndrome and
         // the hard decisions read - is the LLR's)
-        if (i < N) Lt[i] = RULE == 0 ? spaf_tanh_half(li[k]) : li[k];
+        // (an LLR of -0.0 decides bit 0 in the reference and in the fp64 kernel, `LLR < 0` being false; the clamp inside spaf_tanh_half would
+        // hand copysign its sign and decide 1: zero enters as +0.0)
+        if (i < N) Lt[i] = RULE == 0 ? spaf_tanh_half(li[k] == 0.0f ? 0.0f : li[k]) : li[k];
     }
     const uint32_t* __restrict__ gdesc = T.gdesc;
     // the group sizes of the wavefront's bins, 3 bits per round, in one scalar register pair (a scalar load per round put its latency

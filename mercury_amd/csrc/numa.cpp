@@ -73,19 +73,37 @@ bool bind_thread_to_node(int node) {
 }
 
 // set_mempolicy(2) for the calling thread: MPOL_PREFERRED on `node` while the scope lives (pages first touched — and page-locked — inside
-// it come from that node when it has room), MPOL_DEFAULT afterwards
-static long set_policy(int mode, int node) {
+// it come from that node when it has room); afterwards the policy the thread HAD (a process started under numactl --interleave /
+// --membind, or one that set its own, keeps it: the constructor reads it with get_mempolicy and the destructor puts it back)
+static const unsigned long kMaskBits = 1024;                    // nodes 0..1023: the kernel's MAX_NUMNODES on x86-64 distributions
+static long set_policy(int mode, const unsigned long* mask) {
 #ifdef SYS_set_mempolicy
-    unsigned long mask[16] = {0};
-    if (node >= 0 && node < int(sizeof(mask) * 8)) mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-    return syscall(SYS_set_mempolicy, mode, node >= 0 ? mask : nullptr, node >= 0 ? sizeof(mask) * 8 : 0);
+    return syscall(SYS_set_mempolicy, mode, mask, mask ? kMaskBits + 1 : 0);
 #else
-    (void)mode; (void)node;
+    (void)mode; (void)mask;
     return -1;
 #endif
 }
-PreferNode::PreferNode(int node) : active_(node >= 0 && set_policy(1 /* MPOL_PREFERRED */, node) == 0) {}
-PreferNode::~PreferNode() { if (active_) set_policy(0 /* MPOL_DEFAULT */, -1); }
+PreferNode::PreferNode(int node) : active_(false), saved_mode_(0) {
+    for (unsigned long& w : saved_mask_) w = 0;
+#if defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+    if (node < 0 || node >= int(kMaskBits)) return;
+    int mode = 0;
+    if (syscall(SYS_get_mempolicy, &mode, saved_mask_, kMaskBits + 1, nullptr, 0) != 0) return;     // cannot restore -> do not change
+    saved_mode_ = mode;
+    unsigned long mask[kMaskBits / (8 * sizeof(unsigned long))] = {0};
+    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+    active_ = set_policy(1 /* MPOL_PREFERRED */, mask) == 0;
+#else
+    (void)node;
+#endif
+}
+PreferNode::~PreferNode() {
+    if (!active_) return;
+    bool any = false;
+    for (unsigned long w : saved_mask_) any = any || w != 0;
+    set_policy(saved_mode_, any ? saved_mask_ : nullptr);
+}
 
 }  // namespace mgpu_numa
 

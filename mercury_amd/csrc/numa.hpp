@@ -17,5 +17,7 @@ public:
     bool active() const { return active_; }
 private:
     bool active_;
+    int saved_mode_;
+    unsigned long saved_mask_[1024 / (8 * sizeof(unsigned long)) + 1];   // the policy the thread had, put back by the destructor
 };
 }  // namespace mgpu_numa

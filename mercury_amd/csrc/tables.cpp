@@ -5,7 +5,9 @@
 #include <complex>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 
@@ -439,15 +441,33 @@ static LdpcGraph load_graph_uncached(int K, const uint8_t* blob, size_t size) {
 
 // The layouts are functions of the blob alone and take a few hundred milliseconds to place (the bank-aware descent above): contexts of one
 // process share them (a gear-shifting caller re-creates contexts of the same eight codes over and over).
+// The lock covers the map only: the placement of a code runs outside it (one std::shared_future per (blob, K), so concurrent mgpu_create
+// calls for DIFFERENT codes - pool creation, multi-threaded gear shifting - place in parallel and calls for the SAME code wait for one
+// placement), and a hit copies the graph outside the lock from a shared_ptr<const LdpcGraph>.
 LdpcGraph load_graph(int K, const uint8_t* blob, size_t size) {
+    typedef std::shared_ptr<const LdpcGraph> Ptr;
     static std::mutex m;
-    static std::map<std::pair<uint64_t, int>, LdpcGraph> cache;
+    static std::map<std::pair<uint64_t, int>, std::shared_future<Ptr>> cache;
     uint64_t h = 1469598103934665603ull;                         // FNV-1a of the blob: a file-supplied table set (MERCURY_LDPC_TABLES) gets its own entries
     for (size_t i = 0; i < size; ++i) { h ^= blob[i]; h *= 1099511628211ull; }
-    std::lock_guard<std::mutex> lk(m);
-    auto it = cache.find({h ^ size, K});
-    if (it == cache.end()) it = cache.emplace(std::make_pair(h ^ size, K), load_graph_uncached(K, blob, size)).first;
-    return it->second;
+    const std::pair<uint64_t, int> key(h ^ size, K);
+    std::shared_future<Ptr> fut;
+    std::promise<Ptr> mine;
+    bool build = false;
+    {
+        std::lock_guard<std::mutex> lk(m);
+        auto it = cache.find(key);
+        if (it == cache.end()) { fut = mine.get_future().share(); cache.emplace(key, fut); build = true; }
+        else fut = it->second;
+    }
+    if (build) {
+        try { mine.set_value(std::make_shared<const LdpcGraph>(load_graph_uncached(K, blob, size))); }
+        catch (...) {
+            { std::lock_guard<std::mutex> lk(m); cache.erase(key); }        // a corrupt blob is not remembered: the next call reports it again
+            mine.set_exception(std::current_exception());
+        }
+    }
+    return *fut.get();
 }
 
 }  // namespace

@@ -106,7 +106,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "mgpu_alloc_host", "mgpu_free_host", "mgpu_create", "mgpu_destroy", "mgpu_last_error", "mgpu_get_info", "mgpu_rx_batch", "mgpu_rx_batch_taps",
-    "mgpu_host_select_peak", "mgpu_host_fir_taps", "mgpu_host_preamble_carriers", "mgpu_host_mode_info", "mgpu_host_layout_stats",
+    "mgpu_host_libm_selfcheck", "mgpu_host_select_peak", "mgpu_host_fir_taps", "mgpu_host_preamble_carriers", "mgpu_host_mode_info", "mgpu_host_layout_stats",
     "mgpu_device_props_get", "mgpu_alloc_host_near", "mgpu_host_numa_node_of_pci", "mgpu_host_numa_cpus", "mgpu_pool_device_numa_node",
     "mgpu_ldpc_batch", "mgpu_ldpc_encode_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_host_path_last", "mgpu_device_malloc", "mgpu_device_free", "mgpu_context_stream", "mgpu_synchronize", "mgpu_copy_to_host", "mgpu_copy_to_device",

@@ -95,3 +95,23 @@ def test_corrupt_table_blob_is_reported(tmp_path, monkeypatch):
     rc = lib.mgpu_create(C.byref(Config(8, 50, 1, 1, 1, 0, 4, 0.0)), C.byref(h))
     assert rc == 3 and not h.value
     assert b"LDPC" in lib.mgpu_last_error(None)
+
+
+def test_host_libm_selfcheck_reports_the_pinned_platform():
+    """mgpu_host_libm_selfcheck (host-only): this image is the platform the device restates (x86-64 glibc 2.35), so the host's tanh / atanh /
+    atan / sincos and the restatement compiled for the host agree on every checked argument; the report says what was evaluated."""
+    import ctypes as C
+    import platform
+
+    class Report(C.Structure):
+        _fields_ = [("evaluated", C.c_longlong * 4), ("differed", C.c_longlong * 4), ("first", C.c_double * 4), ("differing", C.c_int),
+                    ("libc_version", C.c_char * 32)]
+    from mercury_amd import load_library
+    lib = load_library()
+    r = Report()
+    n = lib.mgpu_host_libm_selfcheck(C.byref(r))
+    assert n == r.differing and all(e > 100000 for e in r.evaluated), (n, list(r.evaluated))
+    assert r.libc_version.decode() == "glibc " + platform.libc_ver()[1]
+    if platform.libc_ver() == ("glibc", "2.35") and platform.machine() == "x86_64":
+        assert n == 0 and list(r.differed) == [0, 0, 0, 0], list(r.differed)
+    assert lib.mgpu_host_libm_selfcheck(None) == n                      # cached, NULL allowed

@@ -372,6 +372,22 @@ def test_fp32_decoders_track_the_fp64_posteriors_iteration_by_iteration(cfg):
                 assert both.sum() >= open_frames.sum() - 2, (cfg, k, dec)       # and it leaves (almost) the same frames open
 
 
+def test_negative_zero_llr_decides_bit_zero_in_every_decoder():
+    """An LLR of -0.0: `LLR < 0` is false in the reference (ldpc_decoder_SPA.cc:211-214), so the hard decision is 0. A codeword of the
+    all-zero word whose LLRs are +1 with -0.0 sprinkled in is therefore already a codeword (iterations 0, all bits 0) - in the fp64 kernel and
+    in the fp32 decoders alike (round 4's fp32 sum-product took the sign bit of the clamped tanh and decided 1)."""
+    from mercury_amd import DEC_MINSUM, DEC_SPA, DEC_SPA_FAST
+    rng = np.random.default_rng(5)
+    llr = np.ones((8, 1600), np.float32)
+    for f in range(8):
+        llr[f, rng.choice(1600, 40 * f, replace=False)] = -0.0
+    assert np.signbit(llr).sum() == 40 * 28
+    for cfg in (0, 8, 16):
+        for dec in (DEC_SPA, DEC_SPA_FAST, DEC_MINSUM):
+            bits, it = _rx(cfg, decoder=dec, max_batch=8).ldpc_decode(llr)
+            assert not bits.any() and not it.any(), (cfg, dec, int(bits.sum()), it)
+
+
 @pytest.mark.parametrize("max_iters", [1, 2, 5, 50])
 def test_fast_decoders_keep_the_iteration_count_convention(max_iters):
     """cl_ldpc::decode's return value (ldpc_decoder_SPA.cc:25-218): 0 = the input already was a codeword, k = converged after k iterations,
@@ -620,6 +636,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert j["decoded_fraction"] > 0.97            # both ranks' frames decode (disjoint frame ranges, same seed)
     assert abs(j["value"] - 2 * 256 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-6 * j["value"]
     assert "roofline" in j and "cpu_baseline" not in j
+    assert [r["rank"] for r in j["per_rank"]] == [0, 1] and all(r["ldpc_kernel_ms"] > 0 and r["wall_ms"] > 0 for r in j["per_rank"])   # clock / power / kernel time of every rank
 
 
 def test_bench_collective_path_over_rccl_and_two_ranks_share_one_gpu_fairly():
