@@ -333,8 +333,13 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp, machine):
             return sorted(ts)[len(ts) // 2], r
         t_dev, r = med(lambda: rb.receive_byte_dev(dwin.data_ptr(), W, 1500.0))
         t_host, _ = med(lambda: rb.receive_byte(wins, 1500.0))
+        # the audio device's own samples (the reference captures INT32, audioio.c:744, and widens on the host): half the bytes over PCIe
+        w32 = np.rint(np.clip(wins, -1.0, 1.0) * 2147483647.0).astype(np.int32)
+        t_i32, r32 = med(lambda: rb.receive_byte(w32, 1500.0))
         out["receive_byte_capture_windows"] = {"windows": W, "samples_per_window": int(wins.shape[1]), "decoded": int(r["stats"]["message_decoded"].sum()),
-                                               "windows_per_s_device_resident": W / t_dev, "windows_per_s_host_buffers": W / t_host}
+                                               "windows_per_s_device_resident": W / t_dev, "windows_per_s_host_buffers": W / t_host,
+                                               "windows_per_s_host_buffers_int32_samples": W / t_i32,
+                                               "decoded_int32_samples": int(r32["stats"]["message_decoded"].sum())}
         rb.close()
     except Exception as e:                                          # a secondary measurement must never cost the bench line
         out["receive_byte_capture_windows"] = {"error": str(e)[:200]}

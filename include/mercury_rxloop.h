@@ -66,6 +66,19 @@ int mgpu_receive_buffer_nsymb(mgpu_ctx* ctx);
 int mgpu_receive_byte_batch(mgpu_ctx* ctx, const double* passband, int W, const mgpu_receive_config* config,
                             mgpu_link_state* state, uint8_t* payload, mgpu_receive_stats* stats);
 
+/* The same on the samples as the audio device delivers them. The reference captures INT32 (radio_capture_thread, audioio.c:744) and its
+ * capture thread widens every sample to the double receive_byte works on (audioio.c:893-936): INT32 / INT_MAX (:909), INT16 / 32768.0 (:907),
+ * FLOAT32 widened (:905). Here that widening runs on the device - int -> double is exact and the division is the correctly rounded IEEE one
+ * on both sides, so the doubles (hence every result) are bit for bit those of mgpu_receive_byte_batch given the widened window - and 4 (2)
+ * bytes per sample cross PCIe instead of 8: a mode-8 window is 361 KB instead of 722 KB. capture: [W][buffer_Nsymb*Nofdm*4] samples of
+ * sample_format, host or device memory (detected). MGPU_SAMPLES_F64 is mgpu_receive_byte_batch itself. */
+#define MGPU_SAMPLES_F64 0
+#define MGPU_SAMPLES_INT32 1
+#define MGPU_SAMPLES_INT16 2
+#define MGPU_SAMPLES_F32 3
+int mgpu_receive_byte_batch_samples(mgpu_ctx* ctx, const void* capture, int sample_format, int W, const mgpu_receive_config* config,
+                                    mgpu_link_state* state, uint8_t* payload, mgpu_receive_stats* stats);
+
 /* double cl_telecom_system::measure_signal_only(double* data) (telecom_system.cc:1520-1541): the capture window through the
  * time-sync filter and its mean power in dBm (receive_stats.signal_stregth_dbm), without looking for a frame. passband as above
  * (host or device), signal_strength_dbm: [W] host. */

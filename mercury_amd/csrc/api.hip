@@ -515,6 +515,7 @@ void mgpu_destroy(mgpu_ctx* c) {
     (void)hipFree(c->d_payload); (void)hipFree(c->d_stats); (void)hipFree(c->d_bits); (void)hipFree(c->d_iters); (void)hipFree(c->d_eqdata);
     if (c->rxloop_ws && c->rxloop_ws_free) c->rxloop_ws_free(c->rxloop_ws);
     (void)hipFree(c->rb_stage);
+    (void)hipFree(c->rb_compact);
     if (c->rb_stream) (void)hipStreamDestroy(c->rb_stream);
     if (c->tx_state && c->tx_state_free) c->tx_state_free(c->tx_state);
     (void)hipFree(c->d_mix_cs);

@@ -128,6 +128,8 @@ struct mgpu_ctx {
     void (*rxloop_ws_free)(void*) = nullptr;
     void* rb_stage = nullptr;       // mgpu_receive_byte_batch from host memory: landing area of the whole call's windows (uploaded by a helper thread)
     size_t rb_stage_cap = 0;
+    void* rb_compact = nullptr;     // mgpu_receive_byte_batch_samples: the windows as INT32 / INT16 / FLOAT32 samples, before the widening kernel
+    size_t rb_compact_cap = 0;
     hipStream_t rb_stream = nullptr;
     double* d_mix_cs = nullptr;     // receive mixer: cos / sin of the carrier phase per sample index (host libm) for mix_carrier
     double mix_carrier = -1;

@@ -32,6 +32,8 @@ __device__ __forceinline__ int brev8(int p) { return int(__brev(unsigned(p)) >> 
 // In:  r_k = x[lane + 64 k]  (natural order).
 // Out: r_k = X[brev8(4 lane + k)]  (unscaled).
 // tw:  128 twiddles in LDS: exp(-2 pi i j / 256) for the forward transform, their conjugates for the inverse.
+// kCarriersOnly: stop after the last LDS round (r_k = position 4 lane + k BEFORE stages 7 and 8) - wave_fft256_carriers below finishes it
+template <bool kCarriersOnly = false>
 __device__ __forceinline__ void wave_fft256(c2& r0, c2& r1, c2& r2, c2& r3, c2* __restrict__ v, const c2* __restrict__ tw, int lane) {
     auto bfly_w = [](c2& lo, c2& hi, const c2& w) {
         const c2 t = cmul(w, hi);
@@ -70,9 +72,55 @@ __device__ __forceinline__ void wave_fft256(c2& r0, c2& r1, c2& r2, c2& r3, c2* 
     // stages 7, 8: positions 4*lane + k
     const int pd = 4 * lane;
     r0 = v[padded(pd)]; r1 = v[padded(pd + 1)]; r2 = v[padded(pd + 2)]; r3 = v[padded(pd + 3)];
-    bfly(r0, r2, pd, 7); bfly(r1, r3, pd + 1, 7);
-    bfly(r0, r1, pd, 8); bfly(r2, r3, pd + 2, 8);
+    if constexpr (!kCarriersOnly) {
+        bfly(r0, r2, pd, 7); bfly(r1, r3, pd + 1, 7);
+        bfly(r0, r1, pd, 8); bfly(r2, r3, pd + 2, 8);
+    }
     __builtin_amdgcn_wave_barrier();
+}
+
+// The receive side keeps 50 of the 256 bins (zero_depadder, ofdm.cc:401-411: bins 231..255 and 1..25). After the last LDS round a lane
+// holds positions 4 lane + k, i.e. bins b + {0, 128, 64, 192} for k = 0..3 with b = brev6(lane): bins 64..191 are never kept, and of b and
+// b + 192 at most one is (b in 1..25, or b in 39..63; the 14 lanes with b = 0 or 26..38 keep nothing). The last two stages therefore
+// compute ONE output per lane instead of four:
+//     bin b       = (r0 + w7 r2) + w8a (r1 + w7 r3)         bin b + 192 = (r0 - w7 r2) - w8b (r1 - w7 r3)
+// (w7 = twiddle 2b for both stage-7 butterflies, w8a = twiddle b, w8b = twiddle b + 64) - 3 complex multiplications and 3 additions
+// instead of 4 and 8. Every surviving value goes through the reference's own butterfly chain - the same operands, the same operations in
+// the same order; a lane's choice between "u + t" and "u - t" is made by flipping t's sign bit (an XOR on the high word) in front of one
+// written addition - so the bits are those of _fft_fast (ofdm.cc:310-340). What is constant per lane - b, which of the two bins, its
+// carrier column, the twiddle slots, the sign mask - is computed once per kernel (fft256_carrier_lane), not per symbol.
+struct Fft256CarrierLane {
+    int col;             // carrier column 0..49 of the lane's live bin, -1: the lane keeps nothing
+    uint32_t sign;       // 0x80000000 for the b + 192 form, 0 for the b form
+    int slot7, slot8;    // LDS twiddle slots of w7 and w8a / w8b
+};
+__device__ __forceinline__ int carrier_of_bin(int bin);
+__device__ __forceinline__ Fft256CarrierLane fft256_carrier_lane(int lane) {
+    const int b = int(__brev(unsigned(lane)) >> 26);
+    const bool upper = b >= 32;
+    Fft256CarrierLane c;
+    c.col = carrier_of_bin(upper ? b + 192 : b);
+    c.sign = upper ? 0x80000000u : 0u;
+    c.slot7 = fft256_tw_slot(2 * b);
+    c.slot8 = fft256_tw_slot(upper ? b + 64 : b);
+    return c;
+}
+// In: as wave_fft256. Returns the lane's live bin, unscaled (garbage-free but meaningless where c.col < 0).
+__device__ __forceinline__ c2 wave_fft256_carriers(c2 r0, c2 r1, c2 r2, c2 r3, c2* __restrict__ v, const c2* __restrict__ tw, int lane,
+                                                   const Fft256CarrierLane& c) {
+    wave_fft256<true>(r0, r1, r2, r3, v, tw, lane);
+    auto flip = [&](double x) { return __hiloint2double(int(uint32_t(__double2hiint(x)) ^ c.sign), __double2loint(x)); };
+    const c2 w7 = tw[c.slot7], w8 = tw[c.slot8];
+    c2 t = cmul(w7, r2), u = cmul(w7, r3);
+    // a - t is a + (-t) in IEEE arithmetic (signed zeros included), so flipping the subtrahend's sign turns the one written addition into
+    // the butterfly's "lo" (bin b) or "hi" (bin b + 192) output per lane: three flips of complex values, six XORs
+    t = {flip(t.re), flip(t.im)};
+    u = {flip(u.re), flip(u.im)};
+    const c2 x = {r0.re + t.re, r0.im + t.im};                     // stage 7, butterfly (r0, r2): r0 +- w7 r2
+    const c2 y = {r1.re + u.re, r1.im + u.im};                     // stage 7, butterfly (r1, r3): r1 +- w7 r3
+    c2 z = cmul(w8, y);                                            // stage 8: x +- w8 y
+    z = {flip(z.re), flip(z.im)};
+    return {x.re + z.re, x.im + z.im};
 }
 
 // zero_depadder (ofdm.cc:401-411) for Nc = 50, start_shift = 1: carrier column of FFT bin `bin`, or -1

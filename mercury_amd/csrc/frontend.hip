@@ -137,6 +137,7 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
 
     // ---- symbol_demod: one wave per symbol (fft256.h), next symbol's samples requested before the butterflies ----
     c2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
+    const Fft256CarrierLane fcl = fft256_carrier_lane(lane);
     const int nfw = carve.fft_waves;                                // waves that own an FFT work area
     if (wave < nfw && wave < Ns) {
         const c2* in = bb + size_t(wave) * 272 + 16;                // gi_remover
@@ -148,13 +149,9 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
             const c2* in = bb + size_t(s + nfw) * 272 + 16;
             n0 = in[lane]; n1 = in[lane + 64]; n2 = in[lane + 128]; n3 = in[lane + 192];
         }
-        wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
-        // 1/Nfft scale + zero_depadder: position p holds bin brev8(p)
-        auto emit = [&](const c2& x, int p) {
-            const int col = carrier_of_bin(brev8(p));
-            if (col >= 0) grid[s * Nc + col] = {x.re / 256.0, x.im / 256.0};
-        };
-        emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
+        // 1/Nfft scale + zero_depadder: a lane ends with the one bin it keeps, if any (fft256.h: 50 of the 256 bins are carriers)
+        const c2 x = wave_fft256_carriers(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane, fcl);
+        if (fcl.col >= 0) grid[s * Nc + fcl.col] = {x.re / 256.0, x.im / 256.0};
     }
     __syncthreads();
     for (int i = tid; i < G; i += FE_THREADS) type[i] = T.cell_type[i] ? (T.pilot_val[i] < 0 ? int8_t(-1) : int8_t(1)) : int8_t(0);

@@ -81,6 +81,7 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
     const int st = hl >= M ? 1 : 0, m = hl & (M - 1);
     const int gray_m = m ^ (m >> 1);
     const int tone_off = kBandStart + st * M;
+    const Fft256CarrierLane fcl = fft256_carrier_lane(lane);    // the one FFT bin this lane keeps (fft256.h)
     double* E = en[wave] + half * 64;                            // |carrier|^2 of this half's symbol, carrier order
 
     for (int sa = s0 + wave; sa < s1; sa += 2 * MF_WAVES) {
@@ -97,18 +98,17 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
             // four), and five workgroups hide the load latency better than the prefetch did (ROBUST_1: 0.73 -> 0.68 ms per 4096 frames)
             const c2* in = bb + size_t(s) * 272 + 16;                // gi_remover
             c2 r0 = in[lane], r1 = in[lane + 64], r2 = in[lane + 128], r3 = in[lane + 192];
-            wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
-            auto emit = [&](const c2& x, int p) {                    // 1/Nfft scale + zero_depadder + energy
-                const int col = carrier_of_bin(brev8(p));
-                if (col < 0) return;
-                const double re = x.re / 256.0, im = x.im / 256.0;
-                Eo[col] = re * re + im * im;
-                if (taps.grid) {
-                    double* g = taps.grid + (size_t(f) * T.G + size_t(s) * Nc + col) * 2;
-                    g[0] = re; g[1] = im;
+            {                                                        // 1/Nfft scale + zero_depadder + energy: the lane's one kept bin (fft256.h)
+                const c2 x = wave_fft256_carriers(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane, fcl);
+                if (fcl.col >= 0) {
+                    const double re = x.re / 256.0, im = x.im / 256.0;
+                    Eo[fcl.col] = re * re + im * im;
+                    if (taps.grid) {
+                        double* g = taps.grid + (size_t(f) * T.G + size_t(s) * Nc + fcl.col) * 2;
+                        g[0] = re; g[1] = im;
+                    }
                 }
-            };
-            emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         const int s = half ? sb : sa;
@@ -212,15 +212,13 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_slot_energy_kernel
     const c2* in = reinterpret_cast<const c2*>(baseband_interp) + size_t(w) * size + offset;
     c2 r0 = in[size_t(lane) * interp], r1 = in[size_t(lane + 64) * interp];
     c2 r2 = in[size_t(lane + 128) * interp], r3 = in[size_t(lane + 192) * interp];
-    wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
+    const Fft256CarrierLane fcl = fft256_carrier_lane(lane);
+    const c2 x = wave_fft256_carriers(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane, fcl);
     double* E = energy + (size_t(w) * nslots + s) * 50;
-    auto emit = [&](const c2& x, int p) {
-        const int col = carrier_of_bin(brev8(p));
-        if (col < 0) return;
+    if (fcl.col >= 0) {
         const double re = x.re / 256.0, im = x.im / 256.0;
-        E[col] = re * re + im * im;
-    };
-    emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
+        E[fcl.col] = re * re + im * im;
+    }
 }
 
 // The other half of cl_ofdm::time_sync_mfsk (ofdm.cc:2026-2061) where the energies lie: for every start slot s the metric

@@ -759,79 +759,145 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
 }
 }  // namespace
 
+// The capture thread's widening of the audio device's samples to the doubles receive_byte works on (radio_capture_thread,
+// audioio.c:893-936), on the device: INT32 / INT_MAX (:909), INT16 / 32768.0 (:907), FLOAT32 widened (:905). int -> double is exact and the
+// division is the IEEE-754 correctly rounded one on both sides, so the doubles are the CPU's bit for bit; what crosses PCIe is 4 (2) bytes
+// per sample instead of 8.
+template <typename T>
+__global__ __launch_bounds__(256) void mgpu_widen_capture_kernel(const T* __restrict__ in, size_t n, double divisor, double* __restrict__ out) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const double x = double(in[i]);
+        out[i] = divisor == 1.0 ? x : x / divisor;
+    }
+}
+namespace {
+size_t sample_bytes(int fmt) { return fmt == MGPU_SAMPLES_F64 ? 8 : fmt == MGPU_SAMPLES_INT16 ? 2 : 4; }
+void launch_widen(const void* d_in, int fmt, size_t n, double* d_out, hipStream_t s) {
+    const dim3 grid(unsigned(std::min<size_t>((n + 255) / 256, 65535u * 4))), block(256);
+    if (fmt == MGPU_SAMPLES_INT32) hipLaunchKernelGGL(mgpu_widen_capture_kernel<int32_t>, grid, block, 0, s, static_cast<const int32_t*>(d_in), n, 2147483647.0, d_out);
+    else if (fmt == MGPU_SAMPLES_INT16) hipLaunchKernelGGL(mgpu_widen_capture_kernel<int16_t>, grid, block, 0, s, static_cast<const int16_t*>(d_in), n, 32768.0, d_out);
+    else hipLaunchKernelGGL(mgpu_widen_capture_kernel<float>, grid, block, 0, s, static_cast<const float*>(d_in), n, 1.0, d_out);
+    HIPCK(hipGetLastError());
+}
+void ensure_stage(mgpu_ctx* c, size_t bytes) {
+    if (c->rb_stage_cap >= bytes) return;
+    (void)hipFree(c->rb_stage);
+    c->rb_stage = nullptr; c->rb_stage_cap = 0;
+    HIPCK(hipMalloc(&c->rb_stage, bytes));
+    c->rb_stage_cap = bytes;
+}
+void ensure_compact(mgpu_ctx* c, size_t bytes) {
+    if (c->rb_compact_cap >= bytes) return;
+    (void)hipFree(c->rb_compact);
+    c->rb_compact = nullptr; c->rb_compact_cap = 0;
+    HIPCK(hipMalloc(&c->rb_compact, bytes));
+    c->rb_compact_cap = bytes;
+}
+
+// mgpu_receive_byte_batch / _samples: fmt = the sample format of `capture`
+void receive_byte_any(mgpu_ctx* c, const void* capture, int fmt, int W, const mgpu_receive_config* rcp, mgpu_link_state* state, uint8_t* payload,
+                      mgpu_receive_stats* stats) {
+    need(capture && rcp && payload && stats && W > 0 && W <= c->max_batch, "bad argument (W must be 1..max_batch)");
+    need(fmt == MGPU_SAMPLES_F64 || fmt == MGPU_SAMPLES_INT32 || fmt == MGPU_SAMPLES_INT16 || fmt == MGPU_SAMPLES_F32, "unknown sample format");
+    need(rcp->time_sync_trials_max >= 1 && rcp->time_sync_trials_max < 64,
+         "time_sync_trials_max must be 1..63 (0 makes the reference index its peak table at -1)");
+    // every argument is judged before the first copy or kernel is queued: an error return leaves nothing in flight and no state[] entry touched
+    if (state && c->tab.mfsk_M == 0) for (int w = 0; w < W; ++w) need(state[w].fixed_delay_plus_one <= 0, "fixed_delay_plus_one: MFSK modes only");
+    // Windows in host memory: bringing 1024 mode-8 windows over PCIe takes 13.5 ms as doubles (half that as INT32 / FLOAT32 samples, a quarter
+    // as INT16) and the synchroniser + decoder another 17 ms. The windows are independent, so the call is cut into sub-batches: a helper
+    // thread uploads them one after another into a staging buffer (a copy from pageable memory holds its calling thread; compact samples are
+    // widened there by a kernel on the upload stream), this thread runs the whole receive_byte on each sub-batch as soon as it has landed.
+    // The call then lasts the upload plus the receive_byte of the last sub-batch, so small sub-batches win until the fixed cost of the
+    // control rounds takes over: 1024 windows in 19.0 ms with sub-batches of 512, 17.1 ms with 256, 19.4 ms with 128 (doubles, end of round
+    // 2; the upload alone is 13.5 ms). MERCURY_RB_SUB overrides, MERCURY_NO_PIPELINE=1 disables it.
+    static const bool no_pipe = getenv("MERCURY_NO_PIPELINE") != nullptr;
+    hipPointerAttribute_t pattr{};
+    const bool on_device = hipPointerGetAttributes(&pattr, capture) == hipSuccess && pattr.type == hipMemoryTypeDevice;
+    if (!on_device) (void)hipGetLastError();
+    const auto& t = c->tab;
+    const size_t buf = size_t(t.Nofdm) * mgpu_receive_buffer_nsymb(c) * kInterp;
+    const size_t sb = sample_bytes(fmt);
+    const char* src = static_cast<const char*>(capture);
+    if (!c->rb_stream) HIPCK(hipStreamCreateWithFlags(&c->rb_stream, hipStreamNonBlocking));
+    const int kMinSub = 256;
+    if (on_device || no_pipe || W < 2 * kMinSub) {
+        if (fmt == MGPU_SAMPLES_F64) { receive_byte_impl(c, static_cast<const double*>(capture), W, rcp, state, payload, stats); return; }
+        // compact samples, one piece: (upload,) widen into the staging buffer, then the doubles path on device memory
+        ensure_stage(c, size_t(W) * buf * 8);
+        const void* d_in = capture;
+        if (!on_device) {
+            ensure_compact(c, size_t(W) * buf * sb);
+            HIPCK(hipMemcpyAsync(c->rb_compact, capture, size_t(W) * buf * sb, hipMemcpyHostToDevice, c->rb_stream));
+            d_in = c->rb_compact;
+        }
+        launch_widen(d_in, fmt, size_t(W) * buf, static_cast<double*>(c->rb_stage), c->rb_stream);
+        HIPCK(hipStreamSynchronize(c->rb_stream));
+        receive_byte_impl(c, static_cast<const double*>(c->rb_stage), W, rcp, state, payload, stats);
+        return;
+    }
+    static const int sub_env = getenv("MERCURY_RB_SUB") ? atoi(getenv("MERCURY_RB_SUB")) : 0;
+    const int sub = sub_env >= 64 ? std::min(sub_env, W) : 256;
+    const int nsub = (W + sub - 1) / sub;
+    ensure_stage(c, size_t(W) * buf * 8);
+    if (fmt != MGPU_SAMPLES_F64) ensure_compact(c, size_t(W) * buf * sb);
+    double* stage = static_cast<double*>(c->rb_stage);
+    std::mutex m;
+    std::condition_variable cv;
+    int landed = 0;
+    hipError_t failed = hipSuccess;
+    std::thread uploader([&] {
+        hipError_t e = hipSetDevice(c->cfg.device);
+        for (int j = 0; j < nsub; ++j) {
+            const int off = j * sub, n = std::min(sub, W - off);
+            if (fmt == MGPU_SAMPLES_F64) {
+                if (e == hipSuccess) e = hipMemcpyAsync(stage + size_t(off) * buf, src + size_t(off) * buf * 8, size_t(n) * buf * 8, hipMemcpyHostToDevice, c->rb_stream);
+            } else {
+                char* d_c = static_cast<char*>(c->rb_compact) + size_t(off) * buf * sb;
+                if (e == hipSuccess) e = hipMemcpyAsync(d_c, src + size_t(off) * buf * sb, size_t(n) * buf * sb, hipMemcpyHostToDevice, c->rb_stream);
+                if (e == hipSuccess) {
+                    try { launch_widen(d_c, fmt, size_t(n) * buf, stage + size_t(off) * buf, c->rb_stream); }
+                    catch (...) { e = hipErrorLaunchFailure; }
+                }
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->rb_stream);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                failed = e;
+                landed = j + 1;
+            }
+            cv.notify_all();
+            if (e != hipSuccess) break;
+        }
+    });
+    try {
+        for (int j = 0; j < nsub; ++j) {
+            const int off = j * sub, n = std::min(sub, W - off);
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return landed > j || failed != hipSuccess; });
+                if (failed != hipSuccess) break;
+            }
+            receive_byte_impl(c, stage + size_t(off) * buf, n, rcp, state ? state + off : nullptr, payload + size_t(off) * t.payload_stride, stats + off);
+        }
+    } catch (...) {
+        uploader.join();
+        throw;
+    }
+    uploader.join();
+    if (failed != hipSuccess) throw std::runtime_error(std::string("upload of the capture windows: ") + hipGetErrorString(failed));
+}
+}  // namespace
+
 extern "C" int mgpu_receive_byte_batch(mgpu_ctx* c, const double* passband, int W, const mgpu_receive_config* rcp, mgpu_link_state* state,
                                        uint8_t* payload, mgpu_receive_stats* stats) {
     if (!c) return MGPU_ERR_ARG;
-    return guard(c, [&] {
-        need(passband && rcp && payload && stats && W > 0 && W <= c->max_batch, "bad argument (W must be 1..max_batch)");
-        need(rcp->time_sync_trials_max >= 1 && rcp->time_sync_trials_max < 64,
-             "time_sync_trials_max must be 1..63 (0 makes the reference index its peak table at -1)");
-        // every argument is judged before the first copy or kernel is queued: an error return leaves nothing in flight and no state[] entry touched
-        if (state && c->tab.mfsk_M == 0) for (int w = 0; w < W; ++w) need(state[w].fixed_delay_plus_one <= 0, "fixed_delay_plus_one: MFSK modes only");
-        // Windows in host memory: bringing 1024 mode-8 windows over PCIe takes 13.5 ms and the synchroniser + decoder another 17 ms.
-        // The windows are independent, so the call is cut into sub-batches: a helper thread uploads them one after another into a
-        // staging buffer (a copy from pageable memory holds its calling thread), this thread runs the whole receive_byte on each
-        // sub-batch as soon as it has landed. The call then lasts the upload plus the receive_byte of the last sub-batch, so small sub-batches
-        // win until the fixed cost of the control rounds takes over: 1024 windows in 19.0 ms with sub-batches of 512, 17.1 ms with 256,
-        // 19.4 ms with 128 (end of round 2; the upload alone is 13.5 ms). MERCURY_RB_SUB overrides, MERCURY_NO_PIPELINE=1 disables it.
-        static const bool no_pipe = getenv("MERCURY_NO_PIPELINE") != nullptr;
-        hipPointerAttribute_t pattr{};
-        const bool on_device = hipPointerGetAttributes(&pattr, passband) == hipSuccess && pattr.type == hipMemoryTypeDevice;
-        if (!on_device) (void)hipGetLastError();
-        const int kMinSub = 256;
-        if (on_device || no_pipe || W < 2 * kMinSub) {
-            receive_byte_impl(c, passband, W, rcp, state, payload, stats);
-            return;
-        }
-        const auto& t = c->tab;
-        const size_t buf = size_t(t.Nofdm) * mgpu_receive_buffer_nsymb(c) * kInterp;
-        static const int sub_env = getenv("MERCURY_RB_SUB") ? atoi(getenv("MERCURY_RB_SUB")) : 0;
-        const int sub = sub_env >= 64 ? std::min(sub_env, W) : 256;
-        const int nsub = (W + sub - 1) / sub;
-        if (c->rb_stage_cap < size_t(W) * buf * 8) {
-            (void)hipFree(c->rb_stage);
-            c->rb_stage = nullptr; c->rb_stage_cap = 0;
-            HIPCK(hipMalloc(&c->rb_stage, size_t(W) * buf * 8));
-            c->rb_stage_cap = size_t(W) * buf * 8;
-        }
-        if (!c->rb_stream) HIPCK(hipStreamCreateWithFlags(&c->rb_stream, hipStreamNonBlocking));
-        double* stage = static_cast<double*>(c->rb_stage);
-        std::mutex m;
-        std::condition_variable cv;
-        int landed = 0;
-        hipError_t failed = hipSuccess;
-        std::thread uploader([&] {
-            hipError_t e = hipSetDevice(c->cfg.device);
-            for (int j = 0; j < nsub; ++j) {
-                const int off = j * sub, n = std::min(sub, W - off);
-                if (e == hipSuccess) e = hipMemcpyAsync(stage + size_t(off) * buf, passband + size_t(off) * buf, size_t(n) * buf * 8, hipMemcpyHostToDevice, c->rb_stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(c->rb_stream);
-                {
-                    std::lock_guard<std::mutex> lk(m);
-                    failed = e;
-                    landed = j + 1;
-                }
-                cv.notify_all();
-                if (e != hipSuccess) break;
-            }
-        });
-        try {
-            for (int j = 0; j < nsub; ++j) {
-                const int off = j * sub, n = std::min(sub, W - off);
-                {
-                    std::unique_lock<std::mutex> lk(m);
-                    cv.wait(lk, [&] { return landed > j || failed != hipSuccess; });
-                    if (failed != hipSuccess) break;
-                }
-                receive_byte_impl(c, stage + size_t(off) * buf, n, rcp, state ? state + off : nullptr, payload + size_t(off) * t.payload_stride, stats + off);
-            }
-        } catch (...) {
-            uploader.join();
-            throw;
-        }
-        uploader.join();
-        if (failed != hipSuccess) throw std::runtime_error(std::string("upload of the capture windows: ") + hipGetErrorString(failed));
-    });
+    return guard(c, [&] { receive_byte_any(c, passband, MGPU_SAMPLES_F64, W, rcp, state, payload, stats); });
+}
+
+extern "C" int mgpu_receive_byte_batch_samples(mgpu_ctx* c, const void* capture, int sample_format, int W, const mgpu_receive_config* rcp,
+                                               mgpu_link_state* state, uint8_t* payload, mgpu_receive_stats* stats) {
+    if (!c) return MGPU_ERR_ARG;
+    return guard(c, [&] { receive_byte_any(c, capture, sample_format, W, rcp, state, payload, stats); });
 }
 
 // cl_telecom_system::passband_test_EsN0 (telecom_system.cc:231-330) per Es/N0 point, batched: random payloads -> transmit_byte

@@ -31,13 +31,10 @@ extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_symbol_demod
     if (s >= n) return;
     const c2* x = reinterpret_cast<const c2*>(in) + size_t(s) * 272 + 16;                  // gi_remover
     c2 r0 = x[lane], r1 = x[lane + 64], r2 = x[lane + 128], r3 = x[lane + 192];
-    wave_fft256(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane);
+    const Fft256CarrierLane fcl = fft256_carrier_lane(lane);
+    const c2 v = wave_fft256_carriers(r0, r1, r2, r3, fftb + wave * FFT256_STRIDE, tw, lane, fcl);
     c2* y = reinterpret_cast<c2*>(out) + size_t(s) * 50;
-    auto emit = [&](const c2& v, int p) {
-        const int col = carrier_of_bin(brev8(p));
-        if (col >= 0) y[col] = {v.re / 256.0, v.im / 256.0};
-    };
-    emit(r0, 4 * lane); emit(r1, 4 * lane + 1); emit(r2, 4 * lane + 2); emit(r3, 4 * lane + 3);
+    if (fcl.col >= 0) y[fcl.col] = {v.re / 256.0, v.im / 256.0};
 }
 
 // in place: gain = boost / mean_{pilots} |Y| (sum in pilot order), Y *= gain

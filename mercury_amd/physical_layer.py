@@ -113,7 +113,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_pool_rx_batch_dev", "mgpu_pool_ldpc_batch_dev", "mgpu_pool_txgen_dev",
     "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_debug_glibc_trig", "mgpu_debug_tsync_metric", "mgpu_debug_occupancy", "mgpu_debug_select_peak", "mgpu_debug_span_energy", "mgpu_debug_p2b_variant", "mgpu_debug_mfsk_sync", "mgpu_baseband_test_esn0", "mgpu_passband_test_esn0", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
-    "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_measure_signal_only",
+    "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_receive_byte_batch_samples", "mgpu_measure_signal_only",
     "mgpu_host_pre_equalization_channel", "mgpu_context_pre_equalization_channel", "mgpu_set_pre_equalization_channel", "mgpu_transmit_bit_batch", "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_transmit_buffer", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
     "mgpu_symbol_demod", "mgpu_automatic_gain_control", "mgpu_channel_estimator", "mgpu_restore_channel_amplitude", "mgpu_channel_equalizer",
     "mgpu_measure_variance", "mgpu_deframer", "mgpu_deinterleaver_c128", "mgpu_deinterleaver_f32", "mgpu_psk_demod",
@@ -414,8 +414,11 @@ class RxPhy:
 
     def receive_byte(self, passband, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1, state=None,
                      coarse_freq_sync=0):
-        """passband: float64 [W, buffer samples]. Returns dict(payload [W, stride], stats [W] (RECEIVE_STATS_DTYPE), state)."""
-        x = np.ascontiguousarray(passband, np.float64)
+        """passband: [W, buffer samples] float64 - or the audio device's own samples, int32 (x / INT_MAX), int16 (x / 32768) or float32, which
+        are widened on the device as the reference's capture thread widens them (audioio.c:893-936): same results, half / a quarter of the bytes
+        over PCIe. Returns dict(payload [W, stride], stats [W] (RECEIVE_STATS_DTYPE), state)."""
+        fmt = {np.dtype(np.int32): 1, np.dtype(np.int16): 2, np.dtype(np.float32): 3}.get(np.asarray(passband).dtype, 0)
+        x = np.ascontiguousarray(passband, np.asarray(passband).dtype if fmt else np.float64)
         x = x.reshape(1, -1) if x.ndim == 1 else x
         W, n = x.shape
         if n != self.receive_buffer_samples():
@@ -426,7 +429,10 @@ class RxPhy:
             st["delay_of_last_decoded_message"] = -1
         payload = np.zeros((W, self.payload_stride), np.uint8)
         stats = np.zeros(W, RECEIVE_STATS_DTYPE)
-        self._ck(self.lib.mgpu_receive_byte_batch(self.h, _ptr(x), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
+        if fmt:
+            self._ck(self.lib.mgpu_receive_byte_batch_samples(self.h, _ptr(x), C.c_int(fmt), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
+        else:
+            self._ck(self.lib.mgpu_receive_byte_batch(self.h, _ptr(x), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
         return {"payload": payload, "stats": stats, "state": st}
 
     def transmit_frame_samples(self):
@@ -526,6 +532,19 @@ class RxPhy:
         payload = np.zeros((W, self.payload_stride), np.uint8)
         stats = np.zeros(W, RECEIVE_STATS_DTYPE)
         self._ck(self.lib.mgpu_receive_byte_batch(self.h, C.c_void_p(d_passband), C.c_int(W), C.byref(cfg), _ptr(st), _ptr(payload), _ptr(stats)))
+        return {"payload": payload, "stats": stats, "state": st}
+
+    def receive_byte_samples_dev(self, d_capture, sample_format, W, carrier_hz, trials_max=2, use_last_good_time_sync=1, use_last_good_freq_offset=1,
+                                 state=None, coarse_freq_sync=0):
+        """receive_byte on W capture windows of INT32 (1) / INT16 (2) / FLOAT32 (3) samples in device memory (raw pointer)."""
+        cfg = ReceiveConfig(carrier_hz, trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync)
+        st = np.zeros(W, LINK_STATE_DTYPE) if state is None else np.ascontiguousarray(state, LINK_STATE_DTYPE)
+        if state is None:
+            st["delay_of_last_decoded_message"] = -1
+        payload = np.zeros((W, self.payload_stride), np.uint8)
+        stats = np.zeros(W, RECEIVE_STATS_DTYPE)
+        self._ck(self.lib.mgpu_receive_byte_batch_samples(self.h, C.c_void_p(d_capture), C.c_int(sample_format), C.c_int(W), C.byref(cfg), _ptr(st),
+                                                          _ptr(payload), _ptr(stats)))
         return {"payload": payload, "stats": stats, "state": st}
 
     def last_sync_kernel_ms(self):

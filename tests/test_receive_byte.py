@@ -396,3 +396,37 @@ def _find_delay(window, audio):
     n = 1 << int(np.ceil(np.log2(window.size + audio.size)))
     c = np.fft.irfft(np.fft.rfft(window, n) * np.conj(np.fft.rfft(audio, n)), n)
     return int(np.argmax(c[: window.size - audio.size + 1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 16, 101])
+def test_gpu_receive_byte_takes_the_audio_devices_own_samples(cfg):
+    """mgpu_receive_byte_batch_samples: capture windows as INT32 / INT16 / FLOAT32 samples - what the audio device delivers and the reference's
+    capture thread widens to double (audioio.c:893-936: x / INT_MAX, x / 32768.0, (double) x) - are widened on the device. The results must be
+    byte for byte those of the double entry point given the same widening done on the host (numpy's int -> float64 conversion and division
+    are the C ones), in one piece (W < 512) and through the pipelined sub-batch path (W >= 512), from host and from device memory."""
+    import torch
+    from mercury_amd import RxPhy
+    orc = Oracle(cfg)
+    wins, _ = make_windows(orc, SPECS, seed=300 + cfg)
+    wins = np.clip(wins, -1.0, 1.0)            # full scale of the integer formats (receive_byte's gates are amplitude-dependent: no rescaling)
+    forms = {
+        "int32": (np.rint(wins * 2147483647.0).astype(np.int32), lambda q: q.astype(np.float64) / 2147483647.0),
+        "int16": (np.rint(wins * 32767.0).astype(np.int16), lambda q: q.astype(np.float64) / 32768.0),
+        "float32": (wins.astype(np.float32), lambda q: q.astype(np.float64)),
+    }
+    rx = RxPhy(cfg, max_batch=520)
+    for name, (q, widen) in forms.items():
+        for reps in (1, 52):                                   # 10 and 520 windows
+            qq, ref_in = np.tile(q, (reps, 1)), np.tile(widen(q), (reps, 1))
+            a = rx.receive_byte(ref_in, CARRIER + 1.5)
+            b = rx.receive_byte(qq, CARRIER + 1.5)
+            assert a["stats"].tobytes() == b["stats"].tobytes(), (cfg, name, reps)
+            assert np.array_equal(a["payload"], b["payload"]) and a["state"].tobytes() == b["state"].tobytes(), (cfg, name, reps)
+            if reps == 1:
+                assert int(a["stats"]["message_decoded"].sum()) >= (2 if cfg == 16 else 3), (cfg, name)
+                d = torch.from_numpy(qq).cuda()
+                fmt = {"int32": 1, "int16": 2, "float32": 3}[name]
+                c = rx.receive_byte_samples_dev(d.data_ptr(), fmt, qq.shape[0], CARRIER + 1.5)
+                assert a["stats"].tobytes() == c["stats"].tobytes() and np.array_equal(a["payload"], c["payload"]), (cfg, name, "device")
+    rx.close()
