@@ -755,6 +755,12 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             }
         }
         for (int w = 0; w < W; ++w) { stats[w].delay = win[w].delay; stats[w].coarse_metric = win[w].metric; stats[w].sync_trials = win[w].sync_trials; }
+        // The call is blocking, to the last kernel: the final round's lp.p2b(again, 1) above is still in flight here and reads its window list
+        // and carriers IN the page-locked staging ring (up()'s zero-copy views) when it executes. A caller that comes straight back - the
+        // pipelined host path below runs sub-batch after sub-batch without a pause - resets the ring and overwrites those slots: the kernel
+        // then indexes the capture buffer with whatever the next call put there (round 5: a GPU memory fault on modes 13 / 15 / 16 with
+        // sub-batches of 256 / 512 windows; any mode could have hit it). Nothing of this call may outlive it.
+        HIPCK(hipStreamSynchronize(s));
     }
 }
 }  // namespace
