@@ -7,7 +7,7 @@
 #                                        receive_byte chain, host-buffer path, transmit chain
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-R=${R:-r04}
+R=${R:-r05}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
