@@ -218,3 +218,32 @@ def test_cpp_per_method_sequence_matches_oracle(tmp_path, cfg):
         packed[i // 8] |= int(want[i]) << (i % 8)
     assert np.array_equal(by, packed)
     assert crc == orc.crc16(packed[: nreal // 8])
+
+
+def _build_b2b(tmp_path):
+    exe = tmp_path / "back_to_back_test"
+    lib = os.path.join(ROOT, "mercury_amd")
+    subprocess.run(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "back_to_back_test.cpp"),
+                    "-o", str(exe), "-L", lib, "-lmercury_gpu", "-Wl,-rpath," + lib, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_back_to_back_test_compiles(tmp_path):
+    assert _build_b2b(tmp_path).exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [8, 13, 16, 101])
+def test_calls_straight_after_one_another_return_the_same_bytes(tmp_path, cfg):
+    """A C++ host calls mgpu_receive_byte_batch (device windows of alternating large / tiny batch sizes, host windows through the one-piece
+    and the pipelined path) and mgpu_measure_signal_only with no pause between the calls: every repetition must return the bytes of the
+    paused single-window reference. Round 5's use-after-return (a call left its last kernel in flight; NOTES R5.4) made the tiny call after a
+    large one fault or differ; the Python tests cannot see this class of defect because the interpreter always pauses long enough."""
+    from test_receive_byte import SPECS, make_windows
+    exe = _build_b2b(tmp_path)
+    orc = oraclelib.Oracle(cfg)
+    wins, _ = make_windows(orc, SPECS, seed=500 + cfg)
+    (tmp_path / "w.bin").write_bytes(np.ascontiguousarray(wins).tobytes())
+    r = subprocess.run([str(exe), str(cfg), str(tmp_path / "w.bin"), str(len(SPECS))], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    assert "0 differing windows" in r.stdout, r.stdout
