@@ -46,6 +46,28 @@ void ctx_alloc(mgpu_ctx* c) {
     c->d_fir[1] = c->keep(upload(t.fir_data));
     d.tf_inv = c->keep(upload(t.tf_inv));
     d.data_cell = c->keep(upload(t.data_cell));
+    d.cell_lerp = nullptr;
+    if (t.mfsk_M == 0) {
+        // The two pilot rows a data cell (i, j) interpolates between and their pilots' indices, tabulated: column j has its pilots in the rows
+        // == j (mod 3) (checked below: the lattice is refused otherwise), rows above the first / below the last pilot extrapolate from the
+        // nearest two (interpolator.cc:163-254). The kernel used to derive all of this per cell from divisions by 50 and 3.
+        std::vector<int> pilot_of_cell(size_t(t.Nsymb) * t.Nc, -1);
+        for (size_t p = 0; p < pilot_cell.size(); ++p) pilot_of_cell[pilot_cell[p]] = int(p);
+        std::vector<uint32_t> tab(size_t(t.nData) * 2, 0u);
+        bool ok = t.Nsymb >= 4 && t.Nsymb * t.Nc < 4096 && pilot_cell.size() < 1024 && t.Nsymb < 256;
+        for (int k = 0; k < t.nData && ok; ++k) {
+            const int cell = t.data_cell[k], i = cell / t.Nc, j = cell - i * t.Nc;
+            const int m = ((i - j) % 3 + 3) % 3;
+            int a = i - m, b = i + 3 - m;
+            if (a < 0) { a = b; b = a + 3; }
+            else if (b >= t.Nsymb) { b = a; a = b - 3; }
+            if (a < 0 || b >= t.Nsymb || pilot_of_cell[size_t(a) * t.Nc + j] < 0 || pilot_of_cell[size_t(b) * t.Nc + j] < 0) { ok = false; break; }
+            tab[2 * size_t(k)] = uint32_t(cell) | uint32_t(pilot_of_cell[size_t(a) * t.Nc + j]) << 12 | uint32_t(pilot_of_cell[size_t(b) * t.Nc + j]) << 22;
+            tab[2 * size_t(k) + 1] = uint32_t(a) | uint32_t(b) << 8 | uint32_t(i) << 16;
+        }
+        if (!ok) throw std::runtime_error("pilot lattice / frame geometry outside what the front-end kernel's interpolation table covers");
+        d.cell_lerp = c->keep(upload(tab));
+    }
     d.cptr = c->keep(upload(t.graph.cptr));
     d.cvar = c->keep(upload(t.graph.cvar));
     d.S = t.graph.S;

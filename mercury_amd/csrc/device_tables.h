@@ -20,6 +20,9 @@ struct MgpuDev {
     const uint16_t* bit_il;        // [nBits]
     const uint16_t* tf_inv;        // [nData] modulated-symbol index landing at de-framed position i
     const uint16_t* data_cell;     // [nData] grid cell of de-framed position i
+    const uint32_t* cell_lerp;     // [nData][2] per data cell, built on the host from the pilot lattice (interpolate_linear_col, interpolator.cc:163-254):
+                                   // word 0 = cell | pilot index of the upper row << 12 | of the lower row << 22 (pilot order, both in the cell's
+                                   // column); word 1 = upper row | lower row << 8 | the cell's row << 16. OFDM modes; NULL otherwise
     // LDPC graph
     const uint32_t* cptr;          // [P+1] check-major edge list in the reference's row order
     const uint16_t* cvar;          // [E]   variable of edge e

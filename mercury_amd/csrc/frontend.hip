@@ -306,14 +306,13 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
     // = lerp of the two pilot estimates (interpolator.cc:163-254), made a unit phasor in the PSK modes (ofdm.cc:1453-1466), divides the
     // received cell (ofdm.cc:1637-1647); the equalised value replaces the received one in the grid. Same operations per cell as the
     // reference's three passes over a full channel grid.
-    auto first_pilot = [](int k) { const int m = k % 3; return 50 * (k / 3) + (m == 0 ? 0 : m == 1 ? 17 : 34); };
+    const uint2* __restrict__ cell_lerp = reinterpret_cast<const uint2*>(T.cell_lerp);
     auto equalise_data = [&](int idx) {
-        const int c = T.data_cell[idx], i = c / Nc, j = c - i * Nc;
-        const int m = (i - j + 3 * Nc) % 3;                          // 1 or 2 for a data cell
-        int a = i - m, b = i + 3 - m;
-        if (a < 0) { a = b; b = a + 3; }                             // above the first pilot: extrapolate from the first two
-        else if (b >= Ns) { b = a; a = b - 3; }                      // below the last pilot: extrapolate from the last two
-        c2 h = lerp(Hp[first_pilot(a) + j / 3], double(a), Hp[first_pilot(b) + j / 3], double(b), double(i));
+        // the cell, the pilot rows a / b it interpolates between and their pilots' indices in its column: tabulated on the host (api.hip)
+        const uint2 q = cell_lerp[idx];
+        const int c = int(q.x & 0xfffu), pa = int((q.x >> 12) & 0x3ffu), pb = int(q.x >> 22);
+        const int a = int(q.y & 0xffu), b = int((q.y >> 8) & 0xffu), i = int(q.y >> 16);
+        c2 h = lerp(Hp[pa], double(a), Hp[pb], double(b), double(i));
         if (T.amp_restore) h = unit_phasor(h);
         if (taps.H) { taps.H[(size_t(f) * G + c) * 2] = h.re; taps.H[(size_t(f) * G + c) * 2 + 1] = h.im; }
         grid[c] = cdiv(grid[c], h);
