@@ -11,7 +11,7 @@
 // (:2102-2190), receive_bit (:636-644) - are NOT touched and NOT recompiled differently: their object code calls the symbol, the linker
 // binds it here. No reference text is stored in this repository and no reference source is patched.
 //
-// Per cl_telecom_system object a binding chooses what the replaced methods do (mreftsgpu_bind):
+// Per cl_telecom_system object a binding chooses what the replaced methods do (mreftsgpu_create / mreftsgpu_set_mode):
 //   bit 0 (1)  STAGES   the per-method entry points run on the GPU (mercury_stages.h, mgpu_ldpc_batch)
 //   bit 1 (2)  SHADOW   with STAGES: the original machine code runs as well, on copies, and every output is compared bit for bit
 //                       (counters per method: calls, calls on the GPU, calls whose outputs differed)
