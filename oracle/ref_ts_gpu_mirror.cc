@@ -54,4 +54,16 @@ int mmirror_receive_byte(void* h, const double* data, int* out, double carrier_h
     }
 }
 
+// gear shifts on the mirror: load_configuration(cfg) (cl_rx_phy keeps the pre-equalisation table it measured for a (modulation, preamble,
+// carrier, seeds) key and re-installs it; an MFSK load drops the key as the reference's sticky reinit flag does) and the table it holds
+int mmirror_load_configuration(void* h, int cfg) {
+    try { static_cast<mgpu::cl_rx_phy*>(h)->load_configuration(cfg); return 0; }
+    catch (const std::exception& e) { fprintf(stderr, "[ref_ts_gpu mirror] %s\n", e.what()); return 1; }
+}
+int mmirror_pre_equalization_channel(void* h, double* out) {
+    mgpu::cl_rx_phy* p = static_cast<mgpu::cl_rx_phy*>(h);
+    for (size_t j = 0; j < p->pre_equalization_channel.size(); ++j) { out[2 * j] = p->pre_equalization_channel[j].real(); out[2 * j + 1] = p->pre_equalization_channel[j].imag(); }
+    return int(p->pre_equalization_channel.size());
+}
+
 }  // extern "C"

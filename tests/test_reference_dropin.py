@@ -199,3 +199,27 @@ def test_reference_rx_rand_loop_decodes_what_the_reference_sent(cfg, mode):
         fa = fb = 0                                                       # the capture thread counts frames_to_read down to 0 before the next call
     assert decoded >= 2, (cfg, decoded)
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq", [(8, 100, 9), (7, 101, 12, 8), (13, 102, 15, 16, 100, 13), (0, 100, 6, 10)])
+def test_gear_shifts_through_an_mfsk_mode_leave_the_reference_pre_equalisation_table(seq):
+    """load_configuration OFDM(A) -> MFSK -> OFDM(B). The reference re-measures pre_equalization_channel on the last hop whatever
+    B's modulation (the MFSK load sets the sticky reinit flag, telecom_system.cc:2682-2691; init() measures and clears it only in an OFDM mode,
+    :1954-1958); the C++ mirror (mgpu::cl_rx_phy, include/mercury_gpu.hpp) caches the table per (modulation, preamble, carrier, seeds) and must
+    drop that key on the MFSK load. The real object and the mirror go through the same sequence; after every OFDM load the tables are equal."""
+    import ctypes as C
+    ref = RefTelecomSystem(seq[0])
+    lib = C.CDLL(oraclelib.REF_TS_GPU_SO, mode=1)
+    lib.mmirror_create.restype = C.c_void_p
+    m = C.c_void_p(lib.mmirror_create(C.c_int(seq[0]), C.c_int(50)))
+    assert m.value
+    for cfg in seq[1:] + (seq[0],):
+        ref.load_configuration(cfg)
+        assert lib.mmirror_load_configuration(m, C.c_int(cfg)) == 0
+        if cfg < 100:
+            out = np.zeros(50, np.complex128)
+            assert lib.mmirror_pre_equalization_channel(m, out.ctypes.data_as(C.c_void_p)) == 50
+            assert np.array_equal(out, ref.pre_equalization_channel()), (seq, cfg)
+    lib.mmirror_destroy(m)
+    ref.close()
