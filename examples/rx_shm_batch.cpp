@@ -10,10 +10,15 @@
 // Each window slot keeps its own link state (last good delay / frequency offset) from one step to the next, the way
 // the reference keeps it in receive_stats between calls — think of B radios, or B channels of one wide-band capture.
 //
-//   usage: rx_shm_batch <cfg> <windows.f64> <batch> [carrier_hz] [ring_name]
+// The capture file holds the windows as doubles (.f64) or as the audio device delivers them - INT32 (.i32: what the reference's capture
+// thread asks for, audioio.c:744), INT16 (.i16) or FLOAT32 (.f32) - in which case they are widened on the device as audioio.c:893-936 widens
+// them on the host (mgpu_receive_byte_batch_samples): same results, half or a quarter of the bytes over PCIe.
+//
+//   usage: rx_shm_batch <cfg> <windows.f64|.i32|.i16|.f32> <batch> [carrier_hz] [ring_name]
 //   build: g++ -O2 -std=c++14 -I include examples/rx_shm_batch.cpp -L mercury_amd -lmercury_gpu -Wl,-rpath,$PWD/mercury_amd -o rx_shm_batch
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "mercury_gpu.h"
@@ -41,7 +46,11 @@ int main(int argc, char** argv) {
 
     FILE* f = fopen(argv[2], "rb");
     if (!f) { perror(argv[2]); return 1; }
-    double* windows = static_cast<double*>(mgpu_alloc_host(window * batch * sizeof(double)));      // page-locked capture buffer
+    const char* ext = strrchr(argv[2], '.');
+    const int fmt = ext && !strcmp(ext, ".i32") ? MGPU_SAMPLES_INT32 : ext && !strcmp(ext, ".i16") ? MGPU_SAMPLES_INT16 :
+                    ext && !strcmp(ext, ".f32") ? MGPU_SAMPLES_F32 : MGPU_SAMPLES_F64;
+    const size_t sample = fmt == MGPU_SAMPLES_F64 ? 8 : fmt == MGPU_SAMPLES_INT16 ? 2 : 4;
+    void* windows = mgpu_alloc_host(window * batch * sample);                                     // page-locked capture buffer
     std::vector<uint8_t> payload(size_t(batch) * info.payload_stride);
     std::vector<mgpu_receive_stats> stats(batch);
     std::vector<mgpu_frame_stats> fstats(batch);
@@ -51,10 +60,10 @@ int main(int argc, char** argv) {
 
     long total = 0, decoded = 0, lost = 0;
     for (int step = 0;; ++step) {
-        const size_t got = fread(windows, sizeof(double) * window, batch, f);
+        const size_t got = fread(windows, sample * window, batch, f);
         if (got == 0) break;
         const int W = int(got);
-        if (mgpu_receive_byte_batch(rx, windows, W, &rc, link.data(), payload.data(), stats.data()) != MGPU_OK) {
+        if (mgpu_receive_byte_batch_samples(rx, windows, fmt, W, &rc, link.data(), payload.data(), stats.data()) != MGPU_OK) {
             fprintf(stderr, "receive_byte_batch: %s\n", mgpu_last_error(rx));
             return 1;
         }

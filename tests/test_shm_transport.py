@@ -296,6 +296,15 @@ def test_batched_rx_shm_loop_feeds_the_unmodified_reference_client(tmp_path):
         while time.time() < deadline and (not outfile.exists() or outfile.stat().st_size < len(want)):
             time.sleep(0.05)
         assert outfile.read_bytes() == want
+        # the same capture as the audio device's INT32 samples (what the reference's capture thread receives, audioio.c:744): the loop
+        # decodes the same windows and prints the same status lines as for the doubles these samples widen to
+        i32 = np.rint(np.clip(wins, -1.0, 1.0) * 2147483647.0).astype(np.int32)
+        (tmp_path / "windows.i32").write_bytes(i32.tobytes())
+        (tmp_path / "widened.f64").write_bytes((i32.astype(np.float64) / 2147483647.0).tobytes())
+        ra = subprocess.run([str(exe), str(cfg), str(tmp_path / "windows.i32"), "3"], capture_output=True, text=True, timeout=120)
+        rb = subprocess.run([str(exe), str(cfg), str(tmp_path / "widened.f64"), "3"], capture_output=True, text=True, timeout=120)
+        assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr, rb.stderr)
+        assert ra.stdout == rb.stdout and "7 windows, 5 decoded" in ra.stdout, (ra.stdout, rb.stdout)
     finally:
         client.kill()
         client.wait()
