@@ -258,7 +258,13 @@ public:
     // st_receive_stats cl_telecom_system::receive_byte(double* data, int* out) — telecom_system.h:142, .cc:646-1503:
     // one passband capture window in, get_frame_size_bytes() ints out, statistics returned and kept in
     // receive_stats; the last good delay / frequency offset carry over to the next call as in the reference.
-    st_receive_stats receive_byte(const double* data, int* out) {
+    st_receive_stats receive_byte(const double* data, int* out) { return receive_byte_samples(data, MGPU_SAMPLES_F64, out); }
+    // The same on the capture as the audio device delivers it (the reference asks for INT32, audioio.c:744; its capture thread widens to double,
+    // :893-936): widened on the device instead, same results (mgpu_receive_byte_batch_samples)
+    st_receive_stats receive_byte(const int32_t* data, int* out) { return receive_byte_samples(data, MGPU_SAMPLES_INT32, out); }
+    st_receive_stats receive_byte(const int16_t* data, int* out) { return receive_byte_samples(data, MGPU_SAMPLES_INT16, out); }
+    st_receive_stats receive_byte(const float* data, int* out) { return receive_byte_samples(data, MGPU_SAMPLES_F32, out); }
+    st_receive_stats receive_byte_samples(const void* data, int sample_format, int* out) {
         mgpu_receive_config rc{carrier_frequency, time_sync_trials_max, use_last_good_time_sync, use_last_good_freq_offset, coarse_freq_sync_enabled};
         // the MFSK anti-re-decode offset (telecom_system.cc:683-685) and the one-shot known delay (:663-672)
         int search_start = receive_stats.mfsk_search_raw - nUnder_processing_events;
@@ -268,7 +274,7 @@ public:
         mfsk_fixed_delay = -1;
         mgpu_receive_stats r{};
         std::vector<uint8_t> bytes(info.payload_stride);
-        detail::check(mgpu_receive_byte_batch(ctx_, data, 1, &rc, &ls, bytes.data(), &r), ctx_, "receive_byte");
+        detail::check(mgpu_receive_byte_batch_samples(ctx_, data, sample_format, 1, &rc, &ls, bytes.data(), &r), ctx_, "receive_byte");
         if (r.iterations_done != -1)                               // no decode attempted: the reference leaves out[] as it was
             for (int i = 0; i < info.payload_bytes; ++i) out[i] = bytes[i];
         detail::apply_receive_byte(receive_stats, r, ls, info.mfsk_M > 0);
