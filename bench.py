@@ -65,6 +65,52 @@ def machine_of(device_index):
             "clock_hz": 1e3 * p["clock_khz"], "pci_bus_id": p["pci_bus_id"], "numa_node": p["numa_node"]}
 
 
+def live_hbm_traffic(args):
+    """HBM bytes per launch of the two kernels of THIS workload on THIS box: (2 x FETCH_SIZE + WRITE_SIZE) KB - FETCH_SIZE doubled as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads - from two rocprofv3 counter passes (one counter per
+    pass, --kernel-trace only: the guide's recipe, never combined with other trace domains) of a two-step run of this same command. A regression
+    in real HBM traffic then shows in the line of the run that has it, not only in a committed profile. Returns {kernel: bytes} or None
+    (no rocprofv3, a pass failed or timed out: the committed profile's figure is quoted instead)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    work = tempfile.mkdtemp(prefix="mgpu_pmc_", dir="/tmp")
+    raw = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-live-pmc", "--cfg", str(args.cfg), "--frames", str(args.frames),
+                   "--iters", str(args.iters), "--esn0", str(args.esn0), "--decoder", args.decoder, "--variant", args.variant, "--channel", str(args.channel)]
+            if args.ldpc_only:
+                cmd.append("--ldpc-only")
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if r.returncode != 0:
+                return None
+            acc = {}
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == ctr:
+                        acc.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+            raw[ctr] = {k: sum(v) / len(v) for k, v in acc.items()}
+        res = {}
+        for k in raw["FETCH_SIZE"]:
+            if k in raw["WRITE_SIZE"] and ("ldpc" in k or "frontend" in k):
+                res[k] = (2.0 * raw["FETCH_SIZE"][k] + raw["WRITE_SIZE"][k]) * 1024.0
+        return res or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def profile_mix(key, workload_ok=True):
     """The committed PMC passes of one kernel launch (tools/collect_pmc_mix.sh; key "spa" / "spa_fast" / "minsum" = the decoder on the
     headline workload, "<decoder>_op" = on the operating-point workload, "frontend"), or None when they were taken from another build of
@@ -475,6 +521,9 @@ def main():
     ap.add_argument("--ldpc-only", action="store_true",
                     help="BASELINE.json configs[4]: decoder-only soak on noise-only LLRs (every codeword runs --iters iterations)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary per-GPU measurements (min-sum, operating point)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not take the two rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload for roofline.traffic (N = 1 only; quoted from the "
+                         "committed profile instead)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--force-dist", action="store_true",
@@ -607,6 +656,15 @@ def main():
         # gfx950's wide coalesced reads. Quoted only when the profile's stamp matches the decoder build being timed.
         mix, mix_src = profile_mix(args.decoder, headline_workload(args, F) and abs(iters_per_launch - 50.0 * F) <= 1e-6 * F)
         traffic = (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None
+        traffic_src, traffic_profile, fe_traffic = mix_src, traffic, None
+        if world == 1 and not args.no_extras and not args.no_live_pmc:
+            live = live_hbm_traffic(args)
+            if live:
+                for k, v in live.items():
+                    if "ldpc" in k:
+                        traffic, traffic_src = v, "this run, this box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one counter per pass, --kernel-trace only) of a 2-step run of this workload, kernel %s; (2 x FETCH_SIZE + WRITE_SIZE) KB" % k
+                    elif "frontend" in k:
+                        fe_traffic = v
         issue = issue_view(mix, mix_src, dec_ms, machine, sclk)
         line = {
             "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (rx.K, args.iters)) if args.ldpc_only else
@@ -632,7 +690,8 @@ def main():
                           "ldpc_kernel_ms": float(v[3]), "frontend_kernel_ms": float(v[4]), "wall_ms": float(v[5])} for r, v in enumerate(per_rank)],
             "machine": machine,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": mix_src,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_committed_profile": traffic_profile, "traffic_frontend_kernel": fe_traffic,
                          "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
                          "secondary": issue,
                          "bytes_per_codeword_iteration": b_iter,
