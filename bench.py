@@ -78,6 +78,9 @@ def live_hbm_traffic(args):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    # this process is itself being profiled (rocprofv3 -- python bench.py ...): no profiler inside a profiler
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     work = tempfile.mkdtemp(prefix="mgpu_pmc_", dir="/tmp")
     raw = {}
     try:
@@ -91,7 +94,7 @@ def live_hbm_traffic(args):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=90, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             if r.returncode != 0:
                 return None
             acc = {}
