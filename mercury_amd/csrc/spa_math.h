@@ -42,11 +42,21 @@
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define SPA_FN __device__ __forceinline__
+#ifndef SPA_CP_EARLY
+#define SPA_CP_EARLY 1
+#endif
+#if SPA_CP_EARLY
+#define SPA_CP_KEEP(x) asm volatile("" : "+v"(x))
+#else
+#define SPA_CP_KEEP(x) (void)(x)
+#endif
 #define SPA_BITS_HI(x) uint32_t(__double2hiint(x))
 #define SPA_MAKE(hi, lo) __hiloint2double(int(hi), int(lo))
 #define SPA_LO(x) uint32_t(__double2loint(x))
 #define SPA_KEEP(x) asm volatile("" : "+v"(x))
 #define SPA_UNDEF(x) asm volatile("" : "=v"(x))      /* a definition without an instruction */
+#define SPA_ONE_COMPARE(b) (b) = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(b))   /* a lane condition used by a select AND a branch: compared once, kept as a lane mask */
+#define SPA_SGPR(x) asm volatile("" : "+s"(x))       /* a constant that is not an inline operand, kept in scalar registers (an fma's addend would otherwise be moved into vector registers) */
 SPA_FN double spa_recip(double d) {          // 1/d to within an ulp, d normal
     const double r = __builtin_amdgcn_rcp(d);
     const double e = __builtin_fma(-d, r, 1.0);
@@ -61,6 +71,7 @@ SPA_FN double spa_div_r(double n, double d, double r) {   // correctly rounded n
 #else
 #include <string.h>
 #define SPA_FN static inline
+#define SPA_CP_KEEP(x) (void)(x)
 static inline uint32_t spa_bits_hi_(double x) { uint64_t u; memcpy(&u, &x, 8); return uint32_t(u >> 32); }
 static inline uint32_t spa_bits_lo_(double x) { uint64_t u; memcpy(&u, &x, 8); return uint32_t(u); }
 static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_t(hi) << 32) | lo; double x; memcpy(&x, &u, 8); return x; }
@@ -69,6 +80,8 @@ static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_
 #define SPA_MAKE(hi, lo) spa_make_(hi, lo)
 #define SPA_KEEP(x) (void)(x)
 #define SPA_UNDEF(x) (x) = 0
+#define SPA_SGPR(x) (void)(x)
+#define SPA_ONE_COMPARE(b) (void)(b)
 SPA_FN double spa_recip(double d) { return d; }
 SPA_FN double spa_div_r(double n, double d, double) { return n / d; }
 #endif
@@ -80,6 +93,26 @@ SPA_FN double spa_fabs(double x) { return SPA_MAKE(SPA_BITS_HI(x) & 0x7fffffffu,
 #endif
 SPA_FN double spa_div(double n, double d) { return spa_div_r(n, d, spa_recip(d)); }
 
+// 1 - 2/d given rr = spa_recip(d). On the device the quotient sequence for the numerator 2 is 2 * (that for the numerator 1): q = 2 rr,
+// rem = fma(-d, q, 2) = 2 fma(-d, rr, 1), fma(rem, rr, q) = 2 fma(rem/2, rr, rr) - doubling commutes with every rounding - and 1 - 2X is
+// one fma (the product is exact): three instructions for four, the same bits.
+#if defined(__HIPCC__) || defined(__HIP__)
+SPA_FN double spa_one_minus_2_over(double d, double rr) {
+    const double x = __builtin_fma(__builtin_fma(-d, rr, 1.0), rr, rr);
+    return __builtin_fma(-2.0, x, 1.0);
+}
+#else
+SPA_FN double spa_one_minus_2_over(double d, double) { return 1.0 - 2.0 / d; }
+#endif
+
+// Round 5: both routines carry some of fdlibm's intermediate values SCALED BY A POWER OF TWO (r*r = 2 hxs instead of hxs, y/2, f/2, s/2, z/4 ...)
+// and put the scale back inside an fma whose product is exact (2 * a, 0.5 * a, k * ln2_hi with its 32-bit mantissa), or inside the
+// polynomial's constants. Scaling by a power of two commutes with every IEEE rounding away from the denormal range - fl(2a * b) = 2 fl(a * b),
+// fl(2a + 2b) = 2 fl(a + b) - so every value below is fdlibm's own, times the stated power of two, and every result has fdlibm's bits; what
+// goes is the instructions that only doubled or halved (hfx = 0.5 r, t2 = x + x, 0.5 f) and the separate multiplications in front of
+// additions whose product is exact. (The arguments for which an intermediate would be denormal are the ones both routines answer
+// from their tiny-argument branch.) tests/test_spa_math.py runs this very code on the host against the host's libm.
+
 // tanh(0.5 * q)
 SPA_FN double spa_tanh_half(double q) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
@@ -89,33 +122,36 @@ SPA_FN double spa_tanh_half(double q) {
                  Q5 = -2.01099218183624371326e-07;
     const uint32_t jq = SPA_BITS_HI(q), iq = jq & 0x7fffffffu;
     const double A = spa_fabs(q);                            // = 2|x| (exact for |x| >= 2^-55)
-    const bool big = iq >= 0x40000000u;                      // |x| >= 1
+    bool big = iq >= 0x40000000u;                            // |x| >= 1
+    SPA_ONE_COMPARE(big);
     int32_t kk = int32_t(invln2 * A + 0.5);
     kk = (iq <= 0x3fd62e42u) ? 0 : kk;
     const double tk = double(kk);
-    const double hi = A - tk * ln2_hi;
+    const double hi = __builtin_fma(-tk, ln2_hi, A);         // A - tk*ln2_hi: the product is exact (|k| < 2^10, ln2_hi has 32 mantissa bits)
     const double lo = tk * ln2_lo;
-    const double rp = hi - lo;
-    const double cp = (hi - rp) - lo;
+    double rp = hi - lo;
+    double cp = (hi - rp) - lo;                              // (only the k != 0 endings use it; formed here, rp's last use, so that r takes rp's registers)
+    SPA_CP_KEEP(cp);
     const uint32_t sm = big ? 0u : 0x80000000u;
     const double r = SPA_MAKE(SPA_BITS_HI(rp) ^ sm, SPA_LO(rp));
-    const double c = SPA_MAKE(SPA_BITS_HI(cp) ^ sm, SPA_LO(cp));
-    const double hfx = 0.5 * r;
-    const double hxs = r * hfx;
-    const double R1 = 1.0 + hxs * Q1, h2 = hxs * hxs;
-    const double R2 = Q2 + hxs * Q3, h4 = h2 * h2;
-    const double R3 = Q4 + hxs * Q5;
-    const double r1 = R1 + h2 * R2 + h4 * R3;
-    const double tt = 3.0 - r1 * hfx;
+    const double x2 = r * r;                                 // 2 hxs
+    const double R1 = 1.0 + x2 * (0.5 * Q1), g2 = x2 * x2;   // g2 = 4 hxs^2
+    const double R2 = 0.25 * Q2 + x2 * (0.125 * Q3), g4 = g2 * g2;      // R2 / 4, 16 hxs^4
+    const double R3 = 0.0625 * Q4 + x2 * (0.03125 * Q5);     // R3 / 16
+    const double r1 = R1 + g2 * R2 + g4 * R3;
+    double three = 3.0;
+    SPA_SGPR(three);
+    const double tt = __builtin_fma(-0.5, r1 * r, three);    // 3 - r1*hfx
     const double den = 6.0 - r * tt;
-    const double e0 = hxs * spa_div_r(r1 - tt, den, spa_recip(den));
+    const double e2 = x2 * spa_div_r(r1 - tt, den, spa_recip(den));     // 2 e
     double t;
     if (kk == 0) {
-        t = r - (r * e0 - hxs);
+        t = __builtin_fma(-0.5, r * e2 - x2, r);             // r - (r*e - hxs)
         SPA_KEEP(t);
     } else {
-        double e = (r * (e0 - c) - c);
-        e -= hxs;
+        const double c = SPA_MAKE(SPA_BITS_HI(cp) ^ sm, SPA_LO(cp));
+        double e = r * __builtin_fma(0.5, e2, -c) - c;       // r*(e - c) - c
+        e = __builtin_fma(-0.5, x2, e);                      // e -= hxs
         if (big) {
             if (kk < 20) {
                 const double tb = SPA_MAKE(0x3ff00000u - (0x200000u >> uint32_t(kk)), 0u);
@@ -143,16 +179,18 @@ SPA_FN double spa_tanh_half(double q) {
     const double rr = spa_recip(d2);
     double z;
     if (big) {
-        z = 1.0 - spa_div_r(2.0, d2, rr);
+        z = spa_one_minus_2_over(d2, rr);
         SPA_KEEP(z);
     } else {
         z = spa_div_r(-t, d2, rr);
         SPA_KEEP(z);
     }
     double res = SPA_MAKE((SPA_BITS_HI(z) & 0x7fffffffu) | (jq & 0x80000000u), SPA_LO(z));     // z >= 0: one bit-field insert
-    if (__builtin_expect(iq < 0x3c900000u || iq >= 0x40460000u, 0)) {
-        const double one = SPA_MAKE(0x3ff00000u | (jq & 0x80000000u), 0u);
-        res = (iq >= 0x40460000u) ? one : 0.5 * q;
+    // s_tanh.c answers |x| < 2^-55 with x*(1 + x) = x. No branch for it here: down there k = 0, r = -A, r*r and everything multiplied by it
+    // vanish against r, t = r, t + 2 = 2 and the quotient -t/2 IS 0.5*q, rounded once like the reference's own 0.5*Q when Q is denormal
+    // (the host test sweeps every binade down to the smallest denormal).
+    if (__builtin_expect(iq >= 0x40460000u, 0)) {
+        res = SPA_MAKE(0x3ff00000u | (jq & 0x80000000u), 0u);
         if (q != q) res = q;                                 // s_tanh.c: one/x + one for a NaN is that NaN (the posterior array holds T before the first pass: a NaN must stay one)
     }
     return res;
@@ -170,61 +208,65 @@ SPA_FN double spa_atanh_x2(double x) {
     SPA_KEEP(x);                       // the clamp rewrites x itself; |x| below stays a source modifier, never a register pair of its own
     const uint32_t jx = SPA_BITS_HI(x);
     const double xa = spa_fabs(x);
-    const double t2 = xa + xa;
     const double d1 = 1.0 - xa;
     const double r1 = spa_recip(d1);
-    double y;
+    double yh;                         // y / 2, y = 2x/(1-x) resp. 2x + 2x*x/(1-x)
     if (xa < 0.5) {
-        y = t2 + spa_div_r(t2 * xa, d1, r1);
-        SPA_KEEP(y);
+        yh = xa + spa_div_r(xa * xa, d1, r1);
+        SPA_KEEP(yh);
     } else {
-        y = spa_div_r(t2, d1, r1);
-        SPA_KEEP(y);
+        yh = spa_div_r(xa, d1, r1);
+        SPA_KEEP(yh);
     }
     // log1p(y)
-    double f, l;
-    const bool direct = int32_t(SPA_BITS_HI(y)) < 0x3FDA827A;
-    const double u = 1.0 + y;
-    // s_log1p.c normalises u = 1 + y to [sqrt(2)/2, sqrt(2)): k = exponent, + 1 when the top 20 mantissa bits are >= 0x6a09e.
-    // Adding 0x100000 - 0x6a09e to the high word carries into the exponent field in exactly that case, so one addition
-    // gives k ((hadd >> 20) - 1023), the normalised high word ((hadd & 0xfffff) + 0x3fe6a09e = hu | 0x3ff00000 resp.
-    // hu | 0x3fe00000) and the |f| < 2^-20 test (hu == 0 resp. (0x100000 - hu) >> 2 == 0 <=> (hadd & 0xfffff) in 0x95f5f..0x95f62)
-    const uint32_t hadd = SPA_BITS_HI(u) + 0x95f62u, hm = hadd & 0x000fffffu;
+    double fh, l;                      // fh = f / 2
+    const bool direct = int32_t(SPA_BITS_HI(yh)) < 0x3FDA827A - 0x00100000;      // y's high word < 0x3FDA827A
     // The normalised lanes finish with y first (the correction term c = (1 + y - u)/u, exactly as s_log1p.c forms it) and
-    // then turn it into f in place; the direct lanes' f is y itself - no lane copies a register pair.
+    // then turn it into f in place; the direct lanes' f is y itself - no lane copies a register pair. Everything only the
+    // normalised lanes need (u = 1 + y and what is cut out of its high word) is computed under their branch: a wavefront whose
+    // checks are all weak (every y below 0.41421 - the rule far from convergence) skips it.
     double c;
-    SPA_UNDEF(c);
-    f = y;
+    uint32_t hadd, hm;
+    SPA_UNDEF(c); SPA_UNDEF(hadd); SPA_UNDEF(hm);
+    fh = yh;
     if (!direct) {
+        const double u = __builtin_fma(2.0, yh, 1.0);        // 1 + y
+        // s_log1p.c normalises u = 1 + y to [sqrt(2)/2, sqrt(2)): k = exponent, + 1 when the top 20 mantissa bits are >= 0x6a09e.
+        // Adding 0x100000 - 0x6a09e to the high word carries into the exponent field in exactly that case, so one addition
+        // gives k ((hadd >> 20) - 1023), the normalised high word ((hadd & 0xfffff) + 0x3fe6a09e = hu | 0x3ff00000 resp.
+        // hu | 0x3fe00000) and the |f| < 2^-20 test (hu == 0 resp. (0x100000 - hu) >> 2 == 0 <=> (hadd & 0xfffff) in 0x95f5f..0x95f62)
+        hadd = SPA_BITS_HI(u) + 0x95f62u;
+        hm = hadd & 0x000fffffu;
         // not direct => y >= 0.41421 => u >= 1.41421: the unadjusted exponent is > 0 exactly when u >= 2
         if (u >= 2.0) {
-            c = 1.0 - (u - y);
+            c = 1.0 - __builtin_fma(-2.0, yh, u);            // 1 - (u - y)
             SPA_KEEP(c);
         } else {
-            c = y - (u - 1.0);
+            c = __builtin_fma(2.0, yh, -(u - 1.0));          // y - (u - 1)
             SPA_KEEP(c);
         }
         c = spa_div_r(c, u, spa_recip(u));
-        f = SPA_MAKE(hm + 0x3fe6a09eu, SPA_LO(u)) - 1.0;
-        SPA_KEEP(f);
+        fh = SPA_MAKE(hm + 0x3fd6a09eu, SPA_LO(u)) - 0.5;    // (normalised u)/2 - 1/2
+        SPA_KEEP(fh);
         SPA_KEEP(c);
     }
-    const double hfsq = 0.5 * f * f;
-    const double d3 = 2.0 + f;
-    const double s = spa_div_r(f, d3, spa_recip(d3));
-    const double z = s * s;
-    const double R1 = z * Lp1, z2 = z * z;
-    const double R2 = Lp2 + z * Lp3, z4 = z2 * z2;
-    const double R3 = Lp4 + z * Lp5, z6 = z4 * z2;
-    const double R4 = Lp6 + z * Lp7;
-    const double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
-    const double sr = s * (hfsq + R);
+    const double hfsqh = fh * fh;                            // hfsq / 2  (hfsq = 0.5 f f)
+    const double d3 = __builtin_fma(2.0, fh, 2.0);           // 2 + f
+    const double sh = spa_div_r(fh, d3, spa_recip(d3));      // s / 2
+    const double zq = sh * sh;                               // z / 4
+    const double R1 = zq * (8 * Lp1), z2 = zq * zq;                      // 2 z Lp1 ; z^2 / 16
+    const double R2 = 32 * Lp2 + zq * (128 * Lp3), z4 = z2 * z2;         // 32 (Lp2 + z Lp3) ; z^4 / 256
+    const double R3 = 512 * Lp4 + zq * (2048 * Lp5), z6 = z4 * z2;       // 512 (Lp4 + z Lp5) ; z^6 / 4096
+    const double R4 = 8192 * Lp6 + zq * (32768 * Lp7);                   // 8192 (Lp6 + z Lp7)
+    const double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;                   // 2 R
+    const double sr = sh * __builtin_fma(4.0, hfsqh, R);     // s * (hfsq + R)
     if (direct) {
-        l = f - (hfsq - sr);
+        l = __builtin_fma(2.0, fh, -__builtin_fma(2.0, hfsqh, -sr));     // f - (hfsq - s*(hfsq + R))
         SPA_KEEP(l);
     } else {
         const double dk = double(int32_t(hadd >> 20) - 1023);
         if (__builtin_expect(hm - 0x95f5fu < 4u, 0)) {
+            const double f = fh + fh, hfsq = hfsqh + hfsqh;
             if (f == 0.0) {
                 l = dk * ln2_hi + (c + dk * ln2_lo);
             } else {
@@ -232,7 +274,8 @@ SPA_FN double spa_atanh_x2(double x) {
                 l = dk * ln2_hi - ((Rz - (dk * ln2_lo + c)) - f);
             }
         } else {
-            l = dk * ln2_hi - ((hfsq - (sr + (dk * ln2_lo + c))) - f);
+            const double w = __builtin_fma(2.0, hfsqh, -(sr + (dk * ln2_lo + c)));   // hfsq - (s*(hfsq + R) + (k*ln2_lo + c))
+            l = __builtin_fma(dk, ln2_hi, -__builtin_fma(-2.0, fh, w));              // k*ln2_hi - (w - f): k*ln2_hi is exact
         }
         SPA_KEEP(l);
     }

@@ -606,6 +606,13 @@ def test_spa_math_on_device_matches_host_libm():
         sign * np.exp(-rng.uniform(0, 40, n)),
         np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.9999999, -0.9999999, 22.0, -22.0, 21.999999, 2.0 ** -55, 2.0 ** -54,
                   2.0 ** -28, 2.0 ** -29, 0.34657359027997264, 1.0397207708399179, 19.061547465398498, 38.0, 44.0, 1e300]),
+        # round 5: the routines carry power-of-two multiples of fdlibm's intermediates and tanh lost its tiny-argument branch - every binade
+        # down to the smallest denormal (the device's own division sequences and denormal handling are what this checks beyond the host test),
+        # the smallest denormals themselves, and atanh around log1p's direct / normalised switch (x = 0.17157...) and its u = 2^k steps
+        np.concatenate([s * np.ldexp(1.0 + rng.random(64), e) for e in range(-1074, -19) for s in (1.0, -1.0)]),
+        np.arange(0, 4096, dtype=np.uint64).view(np.float64), -np.arange(0, 4096, dtype=np.uint64).view(np.float64),
+        0.17157287525380990 * (1.0 + (rng.random(n >> 3) - 0.5) * 1e-6),
+        np.concatenate([(2.0 ** k - 1) / (2.0 ** k + 1) * (1.0 + (rng.random(4096) - 0.5) * 1e-7) for k in range(1, 26)]),
     ])
     t, a = rx.debug_spa_math(xs)
     ref_t, ref_a = Oracle(8).libm_tanh_atanh(xs)      # the host libm, called from C exactly as the reference does

@@ -81,6 +81,14 @@ SRC = textwrap.dedent(r'''
             const double y1 = std::ldexp(1.0, k + 1) - 1, x1 = y1 / (2 + y1);
             for (int v = 0; v < 20000; ++v) { const double x = x1 * (1.0 + (U(rng) - 0.5) * 4e-7); if (x < 1) { A2(x); A2(-x); } }
         }
+        // tiny arguments: every binade from the smallest denormal up to 2^-20 (tanh has no branch of its own for them; atanh's is |x| < 2^-28)
+        for (int e = -1074; e <= -20; ++e)
+            for (int v = 0; v < 64; ++v) {
+                const double m = v == 0 ? 1.0 : v == 1 ? 2.0 - 0x1p-52 : 1.0 + U(rng);
+                const double x = std::ldexp(m, e);
+                T(x); T(-x); TH(x); TH(-x); A2(x); A2(-x); A(x); A(-x);
+            }
+        for (uint64_t b = 0; b < 4096; ++b) { double x; memcpy(&x, &b, 8); TH(x); TH(-x); T(x); A2(x); A2(-x); }   // the smallest denormals
         printf("n=%ld bad=%ld\n", n, bad);
         return bad != 0;
     }
