@@ -23,6 +23,20 @@
 #include <stdint.h>
 
 #include "device_tables.h"
+// Profiling aid (variant builds only: tools/build_variants.sh census:"-DSPA_CENSUS_ON=1"): every case branch of spa_math.h counts the
+// wavefronts that enter it (first active lane) and the lanes they enter it with; tools/spa_census.py reads the counters back through
+// mgpu_debug_spa_census and prints what a wavefront of the launch actually executes. The product build carries none of it.
+#ifdef SPA_CENSUS_ON
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_spa_census[64];
+#define SPA_CENSUS(i) do { const unsigned long long em_ = __builtin_amdgcn_ballot_w64(true); \
+    if (int(threadIdx.x & 63) == __builtin_ctzll(em_)) { atomicAdd(&g_spa_census[i], 1ull); atomicAdd(&g_spa_census[32 + (i)], (unsigned long long)__builtin_popcountll(em_)); } } while (0)
+extern "C" int mgpu_debug_spa_census(unsigned long long* out, int clear) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spa_census), sizeof(g_spa_census)) != hipSuccess) return -1;
+    if (clear) { static unsigned long long z[64]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_spa_census), z, sizeof(z)) != hipSuccess) return -1; }
+    return 64;
+}
+#endif
 #include "spa_math.h"
 
 #define LDPC_THREADS 1024

@@ -39,6 +39,9 @@
 // Build note: the including TU must be compiled with -ffp-contract=off.
 #pragma once
 #include <stdint.h>
+#ifndef SPA_CENSUS
+#define SPA_CENSUS(i) do {} while (0)      /* ldpc.hip's branch census (variant builds) */
+#endif
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define SPA_FN __device__ __forceinline__
@@ -122,6 +125,7 @@ SPA_FN double spa_tanh_half(double q) {
                  Q5 = -2.01099218183624371326e-07;
     const uint32_t jq = SPA_BITS_HI(q), iq = jq & 0x7fffffffu;
     const double A = spa_fabs(q);                            // = 2|x| (exact for |x| >= 2^-55)
+    SPA_CENSUS(0);
     bool big = iq >= 0x40000000u;                            // |x| >= 1
     SPA_ONE_COMPARE(big);
     int32_t kk = int32_t(invln2 * A + 0.5);
@@ -144,34 +148,40 @@ SPA_FN double spa_tanh_half(double q) {
     const double tt = __builtin_fma(-0.5, r1 * r, three);    // 3 - r1*hfx
     const double den = 6.0 - r * tt;
     const double e2 = x2 * spa_div_r(r1 - tt, den, spa_recip(den));     // 2 e
+    // s_expm1.c's k == 0 ending, x - (x*e - hxs), needs no branch of its own: with k = 0 the correction term c is +-0, so the general
+    // e = (x*(e - c) - c) - hxs IS x*e - hxs bit for bit, and the ending is the difference r - e that the k = -1 and k <= -2 endings start from.
+    const double c = SPA_MAKE(SPA_BITS_HI(cp) ^ sm, SPA_LO(cp));
+    SPA_CENSUS(2);
+    double e = r * __builtin_fma(0.5, e2, -c) - c;           // r*(e - c) - c
+    e = __builtin_fma(-0.5, x2, e);                          // e -= hxs
     double t;
-    if (kk == 0) {
-        t = __builtin_fma(-0.5, r * e2 - x2, r);             // r - (r*e - hxs)
-        SPA_KEEP(t);
-    } else {
-        const double c = SPA_MAKE(SPA_BITS_HI(cp) ^ sm, SPA_LO(cp));
-        double e = r * __builtin_fma(0.5, e2, -c) - c;       // r*(e - c) - c
-        e = __builtin_fma(-0.5, x2, e);                      // e -= hxs
-        if (big) {
-            if (kk < 20) {
-                const double tb = SPA_MAKE(0x3ff00000u - (0x200000u >> uint32_t(kk)), 0u);
-                const double y = tb - (e - r);
-                t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y));
-            } else if (kk <= 56) {
-                const double tc = SPA_MAKE(uint32_t(0x3ff - kk) << 20, 0u);
-                const double y = (r - (e + tc)) + 1.0;
-                t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y));
-            } else {
-                const double y = 1.0 - (e - r);
-                t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y)) - 1.0;
-            }
-            SPA_KEEP(t);
-        } else if (kk == 1) {
-            t = 0.5 * (r - e) - 0.5;
-            SPA_KEEP(t);
+    if (big) {
+        if (kk < 20) {
+            SPA_CENSUS(4);
+            const double tb = SPA_MAKE(0x3ff00000u - (0x200000u >> uint32_t(kk)), 0u);
+            const double y = tb - (e - r);
+            t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y));
+        } else if (kk <= 56) {
+            SPA_CENSUS(5);
+            const double tc = SPA_MAKE(uint32_t(0x3ff - kk) << 20, 0u);
+            const double y = (r - (e + tc)) + 1.0;
+            t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y));
         } else {
             const double y = 1.0 - (e - r);
+            t = SPA_MAKE(SPA_BITS_HI(y) + (uint32_t(kk) << 20), SPA_LO(y)) - 1.0;
+        }
+        SPA_KEEP(t);
+    } else {
+        t = r - e;                                           // k == 0: the result
+        SPA_KEEP(t);
+        if (kk == 1) {
+            SPA_CENSUS(7);
+            t = 0.5 * t - 0.5;
+            SPA_KEEP(t);
+        } else if (kk >= 2) {
+            const double y = 1.0 + t;                        // 1 - (e - r)
             t = SPA_MAKE(SPA_BITS_HI(y) - (uint32_t(kk) << 20), SPA_LO(y)) - 1.0;
+            SPA_CENSUS(8);
             SPA_KEEP(t);
         }
     }
@@ -180,9 +190,11 @@ SPA_FN double spa_tanh_half(double q) {
     double z;
     if (big) {
         z = spa_one_minus_2_over(d2, rr);
+        SPA_CENSUS(9);
         SPA_KEEP(z);
     } else {
         z = spa_div_r(-t, d2, rr);
+        SPA_CENSUS(10);
         SPA_KEEP(z);
     }
     double res = SPA_MAKE((SPA_BITS_HI(z) & 0x7fffffffu) | (jq & 0x80000000u), SPA_LO(z));     // z >= 0: one bit-field insert
@@ -191,6 +203,7 @@ SPA_FN double spa_tanh_half(double q) {
     // (the host test sweeps every binade down to the smallest denormal).
     if (__builtin_expect(iq >= 0x40460000u, 0)) {
         res = SPA_MAKE(0x3ff00000u | (jq & 0x80000000u), 0u);
+        SPA_CENSUS(11);
         if (q != q) res = q;                                 // s_tanh.c: one/x + one for a NaN is that NaN (the posterior array holds T before the first pass: a NaN must stay one)
     }
     return res;
@@ -204,18 +217,22 @@ SPA_FN double spa_atanh_x2(double x) {
                  Lp7 = 1.479819860511658591e-01;
     if (__builtin_expect(spa_fabs(x) == 1.0, 0)) {
         x = SPA_MAKE((SPA_BITS_HI(x) & 0x80000000u) | 0x3fefffffu, 0xca501acbu);      // +-0.9999999
+        SPA_CENSUS(13);
     }
     SPA_KEEP(x);                       // the clamp rewrites x itself; |x| below stays a source modifier, never a register pair of its own
     const uint32_t jx = SPA_BITS_HI(x);
     const double xa = spa_fabs(x);
+    SPA_CENSUS(12);
     const double d1 = 1.0 - xa;
     const double r1 = spa_recip(d1);
     double yh;                         // y / 2, y = 2x/(1-x) resp. 2x + 2x*x/(1-x)
     if (xa < 0.5) {
         yh = xa + spa_div_r(xa * xa, d1, r1);
+        SPA_CENSUS(14);
         SPA_KEEP(yh);
     } else {
         yh = spa_div_r(xa, d1, r1);
+        SPA_CENSUS(15);
         SPA_KEEP(yh);
     }
     // log1p(y)
@@ -231,6 +248,7 @@ SPA_FN double spa_atanh_x2(double x) {
     fh = yh;
     if (!direct) {
         const double u = __builtin_fma(2.0, yh, 1.0);        // 1 + y
+        SPA_CENSUS(16);
         // s_log1p.c normalises u = 1 + y to [sqrt(2)/2, sqrt(2)): k = exponent, + 1 when the top 20 mantissa bits are >= 0x6a09e.
         // Adding 0x100000 - 0x6a09e to the high word carries into the exponent field in exactly that case, so one addition
         // gives k ((hadd >> 20) - 1023), the normalised high word ((hadd & 0xfffff) + 0x3fe6a09e = hu | 0x3ff00000 resp.
@@ -240,9 +258,11 @@ SPA_FN double spa_atanh_x2(double x) {
         // not direct => y >= 0.41421 => u >= 1.41421: the unadjusted exponent is > 0 exactly when u >= 2
         if (u >= 2.0) {
             c = 1.0 - __builtin_fma(-2.0, yh, u);            // 1 - (u - y)
+            SPA_CENSUS(17);
             SPA_KEEP(c);
         } else {
             c = __builtin_fma(2.0, yh, -(u - 1.0));          // y - (u - 1)
+            SPA_CENSUS(18);
             SPA_KEEP(c);
         }
         c = spa_div_r(c, u, spa_recip(u));
@@ -262,11 +282,14 @@ SPA_FN double spa_atanh_x2(double x) {
     const double sr = sh * __builtin_fma(4.0, hfsqh, R);     // s * (hfsq + R)
     if (direct) {
         l = __builtin_fma(2.0, fh, -__builtin_fma(2.0, hfsqh, -sr));     // f - (hfsq - s*(hfsq + R))
+        SPA_CENSUS(19);
         SPA_KEEP(l);
     } else {
         const double dk = double(int32_t(hadd >> 20) - 1023);
+        SPA_CENSUS(20);
         if (__builtin_expect(hm - 0x95f5fu < 4u, 0)) {
             const double f = fh + fh, hfsq = hfsqh + hfsqh;
+            SPA_CENSUS(21);
             if (f == 0.0) {
                 l = dk * ln2_hi + (c + dk * ln2_lo);
             } else {
@@ -280,7 +303,7 @@ SPA_FN double spa_atanh_x2(double x) {
         SPA_KEEP(l);
     }
     double res = SPA_MAKE((SPA_BITS_HI(l) & 0x7fffffffu) | (jx & 0x80000000u), SPA_LO(l));     // l > 0: 2 * (+-0.5 * l) is one bit-field insert
-    if (__builtin_expect(xa < 0x1.0p-28, 0)) res = x + x;
+    if (__builtin_expect(xa < 0x1.0p-28, 0)) { res = x + x; SPA_CENSUS(22); }
     return res;
 }
 
