@@ -176,7 +176,7 @@ SPA_FN double spa_tanh_half(double q) {
         SPA_KEEP(t);
         if (kk == 1) {
             SPA_CENSUS(7);
-            t = 0.5 * t - 0.5;
+            t = __builtin_fma(0.5, t, -0.5);                 // 0.5*(r - e) - 0.5: the product is exact
             SPA_KEEP(t);
         } else if (kk >= 2) {
             const double y = 1.0 + t;                        // 1 - (e - r)
