@@ -10,7 +10,8 @@
 // They are plain IEEE-754 double arithmetic with no FMA, so restating the published algorithm
 // (Sun Microsystems 1993, "Developed at SunPro ... Permission to use, copy, modify, and distribute
 // this software is freely granted, provided that this notice is preserved.") with FMA contraction
-// disabled gives identical bits on any IEEE machine. tests/test_spa_math.py checks this header
+// disabled gives identical bits on any IEEE machine (the fmas written out below are the ones whose
+// product is exact, i.e. that round once like the reference's multiply-then-add: see "Round 5"). tests/test_spa_math.py checks this header
 // (compiled for the host) against the host libm on millions of arguments, including every branch
 // boundary, and tests/test_gpu_parity.py::test_spa_math_on_device does the same for the device build.
 //
@@ -24,7 +25,7 @@
 //    k = 0 regions; only the sliver between 0.5*ln2 and the high-word threshold 0x3fd62e42ffffffff
 //    needs the k = 0 override (checked exhaustively around the thresholds by the host test).
 //  * Where fdlibm's branches compute DIFFERENT things from the shared intermediate values (expm1's
-//    k = 0 / -1 / <= -2 / 2..19 / 20..56 / > 56 endings, log1p's direct / normalised forms) each class is
+//    k = -1 / <= -2 / 2..19 / 20..56 / > 56 endings, log1p's direct / normalised forms) each class is
 //    a real divergent branch: a lane executes exactly its own class's operations and writes its result
 //    under the execution mask, which costs scalar instructions only, instead of every lane computing
 //    every ending and choosing with 64-bit selects. Classes no lane of the wavefront is in are skipped.
@@ -45,14 +46,6 @@
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define SPA_FN __device__ __forceinline__
-#ifndef SPA_CP_EARLY
-#define SPA_CP_EARLY 1
-#endif
-#if SPA_CP_EARLY
-#define SPA_CP_KEEP(x) asm volatile("" : "+v"(x))
-#else
-#define SPA_CP_KEEP(x) (void)(x)
-#endif
 #define SPA_BITS_HI(x) uint32_t(__double2hiint(x))
 #define SPA_MAKE(hi, lo) __hiloint2double(int(hi), int(lo))
 #define SPA_LO(x) uint32_t(__double2loint(x))
@@ -74,7 +67,6 @@ SPA_FN double spa_div_r(double n, double d, double r) {   // correctly rounded n
 #else
 #include <string.h>
 #define SPA_FN static inline
-#define SPA_CP_KEEP(x) (void)(x)
 static inline uint32_t spa_bits_hi_(double x) { uint64_t u; memcpy(&u, &x, 8); return uint32_t(u >> 32); }
 static inline uint32_t spa_bits_lo_(double x) { uint64_t u; memcpy(&u, &x, 8); return uint32_t(u); }
 static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_t(hi) << 32) | lo; double x; memcpy(&x, &u, 8); return x; }
@@ -135,7 +127,7 @@ SPA_FN double spa_tanh_half(double q) {
     const double lo = tk * ln2_lo;
     double rp = hi - lo;
     double cp = (hi - rp) - lo;                              // (only the k != 0 endings use it; formed here, rp's last use, so that r takes rp's registers)
-    SPA_CP_KEEP(cp);
+    SPA_KEEP(cp);
     const uint32_t sm = big ? 0u : 0x80000000u;
     const double r = SPA_MAKE(SPA_BITS_HI(rp) ^ sm, SPA_LO(rp));
     const double x2 = r * r;                                 // 2 hxs
