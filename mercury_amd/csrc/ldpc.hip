@@ -226,6 +226,14 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     const int tid = threadIdx.x, f = blockIdx.x;
     if (f >= F) return;
     if (uint32_t(uintptr_t(smem)) != 0) __builtin_trap();
+    // Rate 14/16 (the only code with checks of degree 46; the only one the zero-forcing modes 15 / 16 use): its wavefronts meet the regimes in
+    // which a whole wavefront gets one of tanh's / atanh's immediate answers (spa_math.h: spa_tanh_half_wave, spa_atanh_x2_wave) - round 5:
+    // 10.97 -> 8.50 ms per 4096 x 50 on mode 16's hard (+-Inf) LLRs, 10.04 -> 9.22 on mode 14 in noise. The other kernels keep the plain calls:
+    // with the shortcuts' extra paths the register allocator spills the resident variable record (+6 % on the headline, measured).
+    // Here the lane's first variable record is fetched per iteration like the second one (below), which frees the registers the
+    // shortcuts need.
+    constexpr bool kWaveShortcuts = NE == 8;
+    constexpr bool kVaResident = !kWaveShortcuts;
     SPA_STAMP_DECL(F);
     SPA_STAMP(1);                                   // 1: start
     // Before the first iteration every R is zero, so Q = posterior - R is the channel LLR on every edge of a variable and T = tanh(Q/2) is
@@ -233,11 +241,21 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     // and the first check pass takes it from the posterior array instead of evaluating tanh (x - 0.0 == x exactly, so the value is the
     // one the pass would have computed; tanh keeps the sign, so the syndrome of the channel LLRs reads the same hard decisions). The
     // messages are never zeroed: nothing reads them before the first pass has written them. Round 4: -6 % at a mode's operating point.
+    // A HARD frame - every |LLR| >= 200, no NaN - is decided before the first iteration. tanh(Q/2) is +-1 exactly from |Q| = 44 on
+    // (s_tanh.c), every product of +-1 is clamped to +-0.9999999 (ldpc_decoder_SPA.cc:150-156) and R = 2 atanh(..) = +-16.81; a variable
+    // has at most nine edges, so |Q| = |LLR + sum of the other R| >= 200 - 9 x 16.82 = 48.6 in every iteration: T = sign(LLR) for ever,
+    // the posteriors keep their signs and the syndrome of the first look is the syndrome of every later one. Such a frame either leaves at
+    // iteration 0 or runs all its iterations without changing a bit: the iterations are skipped, bits and iteration count are those the loop
+    // would deliver. This is what the zero-forcing modes (15, 16) hand the decoder behind RX_SHM at ANY signal-to-noise ratio: their pilots
+    // equalise onto themselves, the measured variance is ~1e-33 and the LLRs are +-1e30 .. +-Inf (telecom_system.cc:1289-1295,
+    // ofdm.cc:1500-1521) - a frame of theirs with one wrong bit cost the reference's 50 iterations and changed nothing.
     const float* lin = llr_in + size_t(f) * N;
+    int hard_lane = 1;
     for (int v = tid; v < N; v += LDPC_THREADS) {
         const float l = lin[v];
         Li[v] = l;
         Lt[v] = spa_tanh_half(double(l));
+        hard_lane &= int(__builtin_fabsf(l) >= 200.0f);          // false for a NaN
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };
@@ -286,7 +304,12 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         Lt[v] = s;
     };
     if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = LDPC_THREADS / 64; flag[3] = LDPC_THREADS / 64; }
+    // (no __syncthreads_and: it brings static LDS, and this kernel's byte-offset addressing needs the dynamic block at address 0) one word per
+    // wavefront in the epilogue's scratch bytes, nothing to initialise
+    int* hard_w = reinterpret_cast<int*>(bytes);
+    if ((tid & 63) == 0) hard_w[tid >> 6] = __builtin_amdgcn_ballot_w64(hard_lane == 0) == 0;
     __syncthreads();
+    const bool hard_frame = __builtin_amdgcn_ballot_w64((tid & 63) < LDPC_THREADS / 64 && hard_w[tid & 15] == 0) == 0;
 
     auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
         m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
@@ -364,6 +387,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             if (valid) {
                 double t;
                 if constexpr (first) t = lt;                           // the posterior array holds T itself (see the top of the kernel)
+                else if constexpr (kWaveShortcuts) t = spa_tanh_half_wave(lt - *ldsd(own));
                 else t = spa_tanh_half(lt - *ldsd(own));
                 *ldsd(own) = t;
             }
@@ -381,7 +405,10 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, lane8, nb * 512, 0);
             vm = bh0[size_t(nb) * 4]; en = bh0[size_t(nb) * 4 + 1];
             double rr;
-            if (valid) rr = spa_atanh_x2(temp);
+            if (valid) {
+                if constexpr (kWaveShortcuts) rr = spa_atanh_x2_wave(temp);
+                else rr = spa_atanh_x2(temp);
+            }
             __builtin_amdgcn_wave_barrier();
             if (valid) *ldsd(own) = rr;
             b = nxt;
@@ -389,9 +416,12 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
     };
 #if SPA_VR_RESIDENT
-    // the lane's two variable records stay in registers (6 + 3): loaded per iteration, their L2 round trip sat behind the barrier
-    const VarRec va = load_var(tid);
-    const spa_u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(vrec, (tid + LDPC_THREADS) * 32, 0, 0);
+    // the record of the lane's first variable stays in registers (6); the second one (3 words, rows from 1024 on) is requested every iteration
+    // in front of the check pass's barrier, where its L2 round trip costs nothing (round 5, same-box: 5.585 vs 5.587 ms on the headline) - the
+    // four registers are the allocator's slack: at 63 of 64 every small change of the loop spilled something (+6 % when it was this record)
+    VarRec va;
+    if constexpr (kVaResident) va = load_var(tid);
+    spa_u32x4 vb;
 #endif
     constexpr int kSpecStart = SPA_SPEC_START;
     int iteration = 0;
@@ -400,7 +430,8 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     SPA_STAMP(3);                                   // 3: syndrome pass done (before its barrier)
     __syncthreads();
     SPA_STAMP(4);                                   // 4: behind the barrier
-    if (flag[0]) {
+    if (flag[0] && hard_frame) iteration = T.max_iters + 1;
+    else if (flag[0]) {
         for (int it = 1;; ++it) {
             const bool spec = it - 1 >= kSpecStart;
             if (it == 1) cn_pass(spec, 0, std::true_type());
@@ -408,6 +439,9 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             else syndrome_pass(it - 1);
 #if !SPA_VR_RESIDENT
             const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
+#else
+            if constexpr (!kVaResident) va = load_var(tid);
+            vb = __builtin_amdgcn_raw_buffer_load_b128(vrec, (tid + LDPC_THREADS) * 32, 0, 0);
 #endif
             SPA_STAMP(5);                           // 5: check pass done
             __syncthreads();

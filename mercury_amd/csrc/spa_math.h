@@ -52,6 +52,7 @@
 #define SPA_KEEP(x) asm volatile("" : "+v"(x))
 #define SPA_UNDEF(x) asm volatile("" : "=v"(x))      /* a definition without an instruction */
 #define SPA_ONE_COMPARE(b) (b) = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(b))   /* a lane condition used by a select AND a branch: compared once, kept as a lane mask */
+#define SPA_ALL(c) (__builtin_amdgcn_ballot_w64(!(c)) == 0)      /* true for every active lane of the wavefront: a scalar branch */
 #define SPA_SGPR(x) asm volatile("" : "+s"(x))       /* a constant that is not an inline operand, kept in scalar registers (an fma's addend would otherwise be moved into vector registers) */
 SPA_FN double spa_recip(double d) {          // 1/d to within an ulp, d normal
     const double r = __builtin_amdgcn_rcp(d);
@@ -76,6 +77,7 @@ static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_
 #define SPA_KEEP(x) (void)(x)
 #define SPA_UNDEF(x) (x) = 0
 #define SPA_SGPR(x) (void)(x)
+#define SPA_ALL(c) (c)
 #define SPA_ONE_COMPARE(b) (void)(b)
 SPA_FN double spa_recip(double d) { return d; }
 SPA_FN double spa_div_r(double n, double d, double) { return n / d; }
@@ -297,6 +299,28 @@ SPA_FN double spa_atanh_x2(double x) {
     double res = SPA_MAKE((SPA_BITS_HI(l) & 0x7fffffffu) | (jx & 0x80000000u), SPA_LO(l));     // l > 0: 2 * (+-0.5 * l) is one bit-field insert
     if (__builtin_expect(xa < 0x1.0p-28, 0)) { res = x + x; SPA_CENSUS(22); }
     return res;
+}
+
+// The decoder's calls (ldpc.hip). Three of the two routines' answers need none of their arithmetic, and a wavefront whose lanes ALL get one
+// of them skips the evaluation - like the reference's libm, which returns at once:
+//  * tanh, |x| >= 22 -> +-1 (s_tanh.c). The zero-forcing modes hand the decoder +-Inf (their pilots equalise onto themselves, the measured
+//    variance is exactly 0 and every LLR is (d1 - d0)/0): every wavefront of theirs, in every iteration of a frame that does not pass its parity
+//    checks at once. (NaN lanes make the wavefront take the evaluation.)
+//  * atanh, the decoder's clamp of +-1 (ldpc_decoder_SPA.cc:150-156): 2 atanh(+-0.9999999) is ONE constant, 0x1.0cfad9b61ff69p+4 (what
+//    spa_atanh_x2 returns for it: tests/test_spa_math.py). Hard inputs make every product of every wavefront +-1.
+//  * atanh, |x| < 2^-28 -> x (e_atanh.c). A check of high degree far from convergence multiplies several dozen small tanh values: every
+//    product of the wavefront is down there (rate 14/16, noise only: all of them; profiles/r05_spa_branch_census.txt).
+SPA_FN double spa_tanh_half_wave(double q) {
+    if (SPA_ALL(spa_fabs(q) >= 44.0)) { SPA_CENSUS(24); return SPA_MAKE(0x3ff00000u | (SPA_BITS_HI(q) & 0x80000000u), 0u); }
+    return spa_tanh_half(q);
+}
+SPA_FN double spa_atanh_x2_wave(double x) {
+    const bool unit = spa_fabs(x) == 1.0, tiny = spa_fabs(x) < 0x1.0p-28;
+    if (SPA_ALL(unit || tiny)) {
+        SPA_CENSUS(25);
+        return unit ? SPA_MAKE((SPA_BITS_HI(x) & 0x80000000u) | 0x4030cfadu, 0x9b61ff69u) : x + x;
+    }
+    return spa_atanh_x2(x);
 }
 
 // the plain forms (tests, probes): tanh(x) = tanh(0.5 * 2x), atanh(x) = 0.5 * (2 atanh(x)); both scalings are exact

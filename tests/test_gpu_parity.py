@@ -236,7 +236,7 @@ def test_ldpc_spa_special_value_llrs_decode_like_the_reference(cfg):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     from fuzz_special_values import salted_words
     orc = Oracle(cfg, 50)
-    words = salted_words(np.random.default_rng(1000 + cfg), 12, orc.K, orc.N)
+    words = salted_words(np.random.default_rng(1000 + cfg), 32, orc.K, orc.N)
     rx = _rx(cfg, max_iters=50, max_batch=len(words))
     with np.errstate(all="ignore"):
         bits, iters = rx.ldpc_decode(words)

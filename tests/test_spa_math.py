@@ -50,6 +50,20 @@ SRC = textwrap.dedent(r'''
             A2(std::tanh((u * 2 - 1) * 3) * std::tanh(U(rng) * 3) * std::tanh(U(rng) * 3));
         }
         A2(1.0); A2(-1.0);
+        // the decoder's entry points with their wavefront-wide shortcuts (on the host a wavefront is one lane)
+        auto THW = [&](double q) { if (bits(tanh(0.5 * q)) != bits(spa_tanh_half_wave(q))) { if (bad < 5) printf("tanh_half_wave %a\n", q); ++bad; } ++n; };
+        auto A2W = [&](double x) {
+            double c = x; if (c == 1) c = 0.9999999; if (c == -1) c = -0.9999999;
+            if (bits(2 * atanh(c)) != bits(spa_atanh_x2_wave(x))) { if (bad < 5) printf("atanh_x2_wave %a\n", x); ++bad; } ++n; };
+        for (long i = 0; i < 200000; ++i) {
+            double u = U(rng), s = (i & 1) ? -1.0 : 1.0;
+            THW(s * std::exp((U(rng) * 62 - 46) * 0.6931471805599453)); THW((u * 2 - 1) * 100); THW(s * (44.0 + (u - 0.5) * 1e-9));
+            A2W(u * 2 - 1); A2W(s * std::exp(-U(rng) * 40)); A2W(s * 0x1p-28 * (1 + (u - 0.5) * 1e-9));
+        }
+        for (double q : {44.0, 43.99999999999999, 44.00000000000001, 1e300, 1e-300}) { THW(q); THW(-q); }
+        THW(INFINITY); THW(-INFINITY);
+        A2W(1.0); A2W(-1.0); A2W(0.0); A2W(-0.0); A2W(0x1p-28); A2W(-0x1p-28); A2W(0x1p-29);
+        if (bits(spa_tanh_half_wave(NAN)) != bits(spa_tanh_half(NAN))) { printf("tanh_half_wave NaN\n"); ++bad; }
         // every high-word threshold of the two routines, swept through the words around it with extreme and random low words
         const uint32_t th_q[] = {0x3c900000u, 0x3c800000u, 0x3fd62e42u, 0x3fd62e43u, 0x3ff0a2b2u, 0x3ff00000u, 0x40000000u, 0x40038000u,
                                  0x402b0000u, 0x402bb9d3u, 0x402bb9d4u, 0x40434e00u, 0x40436800u, 0x40460000u, 0x40450000u, 0x3fe62e42u};

@@ -29,7 +29,7 @@ def salted_words(rng, n, K, N):
     for w in range(n):
         scale = [0.3, 1.0, 3.0, 8.0][w % 4]
         l = (rng.standard_normal(N) * scale + scale * 0.8).astype(np.float32)       # mostly-positive word (all-zero codeword) with errors
-        kind = w % 6
+        kind = w % 8
         if kind == 0:       # a handful of specials
             idx = rng.choice(N, 12, replace=False)
             l[idx] = rng.choice(specials, 12)
@@ -42,6 +42,15 @@ def salted_words(rng, n, K, N):
             l = np.round(l).astype(np.float32)
         elif kind == 4:     # everything huge
             l = (l * np.float32(1e37)).astype(np.float32)
+        elif kind == 6:     # hard words (what the zero-forcing modes hand over): every |LLR| at or above the decoder's whole-frame threshold of 200, sign errors left in
+            mag = [np.float32(200.0), np.float32(np.inf), np.float32(1e32), np.float32(250.0)][(w // 8) % 4]
+            l = np.where(l < 0, -mag, mag).astype(np.float32)
+        elif kind == 7:     # just not hard: one value below the threshold (still saturating tanh), or every value just below it
+            if (w // 8) % 2 == 0:
+                l = np.where(l < 0, np.float32(-1e30), np.float32(1e30)).astype(np.float32)
+                l[rng.integers(N)] = np.float32([199.99, -60.0, 44.0, 150.0][(w // 16) % 4])
+            else:
+                l = np.where(l < 0, np.float32(-199.99), np.float32(199.99)).astype(np.float32)
         # kind 5: plain
         out.append(l)
     return np.stack(out)

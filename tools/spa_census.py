@@ -21,7 +21,7 @@ from mercury_amd import DEC_SPA, RxPhy
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 es = float(sys.argv[3]) if len(sys.argv) > 3 else -15.0
-agc, vs = (1, 1) if (sys.argv[4] if len(sys.argv) > 4 else "baseband") == "receive_byte" else (0, 0)      # bench.py's default is the baseband_test_EsN0 variant
+agc, vs = (1, 1) if (sys.argv[4] if len(sys.argv) > 4 else "receive_byte") == "receive_byte" else (0, 0)      # bench.py's default variant
 rx = RxPhy(cfg, max_iters=50, decoder=DEC_SPA, agc=agc, variance_source=vs, max_batch=F)
 if not hasattr(rx.lib, "mgpu_debug_spa_census"):
     sys.exit("this library was built without -DSPA_CENSUS_ON=1")
@@ -38,7 +38,7 @@ rx.lib.mgpu_debug_spa_census(C.c_void_p(buf.ctypes.data), C.c_int(0))
 w, l = buf[:32].astype(float), buf[32:].astype(float)
 names = {0: "tanh: calls", 1: "  k == 0 ending", 2: "  k != 0: c, e", 4: "    |x| >= 1, k < 20", 5: "    |x| >= 1, k 20..56", 7: "    |x| < 1, k == 1", 8: "    |x| < 1, k >= 2",
          9: "  1 - 2/(t+2)  (|x| >= 1)", 10: "  -t/(t+2)  (|x| < 1)", 11: "  |x| >= 22 / NaN", 12: "atanh: calls", 13: "  clamp of +-1", 14: "  |x| < 0.5", 15: "  |x| >= 0.5",
-         16: "  normalised (y >= 0.41421): u, c, f", 17: "    u >= 2", 18: "    u < 2", 19: "  direct tail", 20: "  normalised tail", 21: "    |f| < 2^-20", 22: "  |x| < 2^-28"}
+         16: "  normalised (y >= 0.41421): u, c, f", 17: "    u >= 2", 18: "    u < 2", 19: "  direct tail", 20: "  normalised tail", 21: "    |f| < 2^-20", 22: "  |x| < 2^-28 (some lanes)", 23: "  every lane +-1 or < 2^-28: evaluation skipped"}
 print("cfg %d, %d frames at %.1f dB, mean iterations %.2f" % (cfg, F, es, stats[:, 0].float().mean().item()))
 for i, n in names.items():
     base = 0 if i < 12 else 12
