@@ -311,6 +311,7 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp, machine):
         phy.enable_timing(True)
         sampler = ClockSampler(machine["pci_bus_id"], period=0.002)
         sampler.start()
+        hard0 = phy.decoder_hard_frames()
         t0 = time.perf_counter()
         for i in range(steps):
             phy.receive_dev(inputs[i % len(inputs)].data_ptr(), F, payload.data_ptr(), stats.data_ptr(), stream=stream)
@@ -319,10 +320,11 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp, machine):
         sclk = sampler.summary()
         fe, dec, _ = phy.kernel_ms_avg()
         phy.enable_timing(False)
-        it = float(stats[:, 0].clamp(max=args.iters).sum().item()) / F
+        hard = (phy.decoder_hard_frames() - hard0) / steps          # frames per step decided without iterating (reported: max + 1 iterations)
+        it = (float(stats[:, 0].clamp(max=args.iters).sum().item()) - hard * args.iters) / F      # iterations EXECUTED per frame
         ok = float(stats[:, 3].sum().item()) / F
         return {"frames_per_s": F * steps / dt, "ms_per_step": dt / steps * 1e3, "frontend_ms": fe, "ldpc_ms": dec, "avg_iters": it, "decoded_fraction": ok,
-                "sclk_mhz": sclk}
+                "hard_frames_per_step": hard, "sclk_mhz": sclk}
 
     agc, vs = (1, 1) if args.variant == "receive_byte" else (0, 0)
     profiled = headline_workload(args, F)
@@ -441,6 +443,7 @@ def run_pool(args):
     for i in range(max(args.warmup, 0)):
         step(i)
     pool.enable_timing(True)
+    hard0 = pool.decoder_hard_frames()
     iters_total = decoded_total = 0
     dev_ms = np.zeros(N)
     for g in range(N):
@@ -456,6 +459,8 @@ def run_pool(args):
     dt = time.perf_counter() - t0
     fe_ms, dec_ms, nl = pool.kernel_ms(0)
     pool.enable_timing(False)
+    hard_total = pool.decoder_hard_frames() - hard0        # frames decided without iterating: reported with max + 1 iterations, none executed
+    iters_total -= hard_total * args.iters
     frames_total = F * N * args.steps
     iters_per_launch = iters_total / (args.steps * N)
     ldpc_bytes, _, b_iter = algorithmic_bytes(one, iters_per_launch, F)
@@ -620,6 +625,7 @@ def main():
     rx.enable_timing(True)
     iters_acc.zero_()
     decoded_acc.zero_()
+    hard0 = rx.decoder_hard_frames()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -632,6 +638,10 @@ def main():
     sclk = sampler.summary() if sampler else None
     fe_ms, dec_ms, nl = rx.kernel_ms_avg()
     rx.enable_timing(False)
+    # HARD frames (every |LLR| >= 200 and an odd parity check: the fp64 decoder decides them without iterating and reports max + 1 iterations,
+    # as the reference's loop would after changing nothing) count with the iterations they EXECUTED: none
+    hard_frames = rx.decoder_hard_frames() - hard0
+    iters_acc.sub_(hard_frames * args.iters)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     sums = torch.stack([iters_acc, decoded_acc]).to(torch.float64).to(rdev)
@@ -687,6 +697,7 @@ def main():
             "ldpc_iters_per_s": iters_total / dt,
             "avg_iters_per_frame": iters_total / frames_total,
             "decoded_fraction": decoded_total / frames_total,
+            "hard_frames_per_step_rank0": hard_frames / args.steps,
             "kernel_ms": {"frontend": fe_ms, "ldpc": dec_ms, "launches_averaged": nl},
             "sclk_mhz_during_run": sclk,
             "per_rank": [{"rank": r, "sclk_mhz_median": float(v[0]), "sclk_mhz_min": float(v[1]), "power_w_median": float(v[2]),

@@ -316,6 +316,12 @@ int mgpu_last_sync_kernel_ms(mgpu_ctx* ctx, float* ms);
  * [1]=LDPC decoder kernel (incl. fused tail). Synchronises on the recorded events. */
 int mgpu_enable_timing(mgpu_ctx* ctx, int on);
 int mgpu_kernel_ms_avg(mgpu_ctx* ctx, float ms[2], int* n_launches);
+/* Frames the fp64 decoder of this context has decided WITHOUT iterating, since the context was created: every |LLR| >= 200 (no NaN) and
+ * a parity check that fails. tanh of such inputs is +-1 for ever, the iterations of cl_ldpc::decode (ldpc_decoder_SPA.cc:127-210) change no
+ * bit of such a frame, and its iteration count is reported as max_iterations + 1 exactly as the loop would. The zero-forcing modes hand the
+ * decoder nothing else behind RX_SHM. For throughput accounting: reported iterations - (max_iterations + 1) x this = iterations executed.
+ * Synchronises the context's stream. */
+int mgpu_decoder_hard_frames(mgpu_ctx* ctx, long long* frames);
 /* Profile of the most recent mgpu_rx_batch call that went through the chunked host-buffer pipeline (F > 1): frames per chunk,
  * number of chunks, and from device events: fill = the first chunk's host-to-device copy (nothing can compute before it has
  * landed), drain = from the last input byte landing to the last result copied back, total = first copy start to that point. */

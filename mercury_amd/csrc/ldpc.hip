@@ -307,7 +307,8 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     // (no __syncthreads_and: it brings static LDS, and this kernel's byte-offset addressing needs the dynamic block at address 0) one word per
     // wavefront in the epilogue's scratch bytes, nothing to initialise
     int* hard_w = reinterpret_cast<int*>(bytes);
-    if ((tid & 63) == 0) hard_w[tid >> 6] = __builtin_amdgcn_ballot_w64(hard_lane == 0) == 0;
+    const int hard_wave = __builtin_amdgcn_ballot_w64(hard_lane == 0) == 0;       // (the whole wavefront votes: not under the lane-0 branch)
+    if ((tid & 63) == 0) hard_w[tid >> 6] = hard_wave;
     __syncthreads();
     const bool hard_frame = __builtin_amdgcn_ballot_w64((tid & 63) < LDPC_THREADS / 64 && hard_w[tid & 15] == 0) == 0;
 
@@ -430,7 +431,10 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     SPA_STAMP(3);                                   // 3: syndrome pass done (before its barrier)
     __syncthreads();
     SPA_STAMP(4);                                   // 4: behind the barrier
-    if (flag[0] && hard_frame) iteration = T.max_iters + 1;
+    if (flag[0] && hard_frame) {
+        iteration = T.max_iters + 1;
+        if (tid == 0 && T.hard_frames) atomicAdd(T.hard_frames, 1ull);      // so that a benchmark can tell reported from executed iterations
+    }
     else if (flag[0]) {
         for (int it = 1;; ++it) {
             const bool spec = it - 1 >= kSpecStart;

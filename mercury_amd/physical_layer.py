@@ -111,7 +111,7 @@ EXPORTED_SYMBOLS = [
     "mgpu_ldpc_batch", "mgpu_ldpc_encode_batch", "mgpu_rx_batch_dev", "mgpu_frontend_dev", "mgpu_ldpc_batch_dev", "mgpu_txgen_dev",
     "mgpu_host_path_last", "mgpu_device_malloc", "mgpu_device_free", "mgpu_context_stream", "mgpu_synchronize", "mgpu_copy_to_host", "mgpu_copy_to_device",
     "mgpu_pool_rx_batch_dev", "mgpu_pool_ldpc_batch_dev", "mgpu_pool_txgen_dev",
-    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_debug_glibc_trig", "mgpu_debug_tsync_metric", "mgpu_debug_occupancy", "mgpu_debug_select_peak", "mgpu_debug_span_energy", "mgpu_debug_p2b_variant", "mgpu_debug_mfsk_sync", "mgpu_baseband_test_esn0", "mgpu_passband_test_esn0", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
+    "mgpu_last_kernel_ms", "mgpu_kernel_ms_avg", "mgpu_decoder_hard_frames", "mgpu_enable_timing", "mgpu_debug_spa_math", "mgpu_debug_glibc_trig", "mgpu_debug_tsync_metric", "mgpu_debug_occupancy", "mgpu_debug_select_peak", "mgpu_debug_span_energy", "mgpu_debug_p2b_variant", "mgpu_debug_mfsk_sync", "mgpu_baseband_test_esn0", "mgpu_passband_test_esn0", "mgpu_passband_to_baseband", "mgpu_time_sync_preamble", "mgpu_freq_sync", "mgpu_last_sync_kernel_ms",
     "mgpu_time_sync_mfsk", "mgpu_detect_ack_pattern", "mgpu_detect_ack_pattern_from_passband",
     "mgpu_receive_buffer_nsymb", "mgpu_receive_byte_batch", "mgpu_receive_byte_batch_samples", "mgpu_measure_signal_only",
     "mgpu_host_pre_equalization_channel", "mgpu_context_pre_equalization_channel", "mgpu_set_pre_equalization_channel", "mgpu_transmit_bit_batch", "mgpu_transmit_frame_samples", "mgpu_transmit_byte_batch", "mgpu_transmit_byte_batch_dev", "mgpu_transmit_buffer", "mgpu_symbol_mod", "mgpu_generate_ack_pattern_passband",
@@ -577,6 +577,12 @@ class RxPhy:
         self._ck(self.lib.mgpu_host_path_last(self.h, C.byref(a), C.byref(b), C.byref(f), C.byref(d), C.byref(t)))
         return {"chunk_frames": a.value, "n_chunks": b.value, "fill_ms": f.value, "drain_ms": d.value, "total_ms": t.value}
 
+    def decoder_hard_frames(self):
+        """Frames the fp64 decoder has decided without iterating since this context was created (every |LLR| >= 200 and an odd parity check)."""
+        n = C.c_longlong(0)
+        self._ck(self.lib.mgpu_decoder_hard_frames(self.h, C.byref(n)))
+        return int(n.value)
+
     def kernel_ms_avg(self):
         """(front-end ms, decoder ms, launches) averaged over the launches since enable_timing()."""
         ms = (C.c_float * 2)()
@@ -735,6 +741,15 @@ class RxPool:
     def enable_timing(self, on=True):
         for g in range(self.n_devices):
             self.lib.mgpu_enable_timing(C.c_void_p(self.lib.mgpu_pool_context(self.h, g)), C.c_int(1 if on else 0))
+
+    def decoder_hard_frames(self):
+        """Frames the pool's fp64 decoders have decided without iterating since the pool was created (sum over its devices)."""
+        total = 0
+        for g in range(self.n_devices):
+            n = C.c_longlong(0)
+            self.lib.mgpu_decoder_hard_frames(C.c_void_p(self.lib.mgpu_pool_context(self.h, g)), C.byref(n))
+            total += int(n.value)
+        return total
 
     def kernel_ms(self, g):
         """(front-end ms, decoder ms, launches) averaged since enable_timing on pool device g."""

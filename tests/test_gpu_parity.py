@@ -247,6 +247,31 @@ def test_ldpc_spa_special_value_llrs_decode_like_the_reference(cfg):
     rx.close()
 
 
+@pytest.mark.parametrize("cfg", [0, 8, 16])
+def test_hard_frames_are_decided_without_iterating_and_counted(cfg):
+    """Every |LLR| >= 200 (what the zero-forcing modes hand over behind RX_SHM): tanh is +-1 for ever and the reference's iterations change no
+    bit. The kernel skips them; bits and iteration counts stay the CPU's (which does iterate), and mgpu_decoder_hard_frames counts exactly the
+    frames that were skipped - a clean hard word leaves at iteration 0 like any clean word and is not one of them."""
+    orc = Oracle(cfg, 50)
+    rng = np.random.default_rng(4200 + cfg)
+    words = np.where(rng.random((10, orc.N)) < 0.03, -1.0, 1.0).astype(np.float32) * np.float32(1e30)       # the all-zero codeword with sign errors
+    words[3] = np.float32(250.0) * np.sign(words[3])
+    words[4] = np.where(words[4] < 0, -np.inf, np.inf).astype(np.float32)
+    words[8] = np.float32(1e30)                                           # clean: parity holds at the first look
+    words[9] = np.float32(np.inf)
+    words[7, orc.N - 3] = np.float32(150.0)                               # not hard: iterates (and still cannot change a bit)
+    words[6, rng.integers(0, orc.N, 40)] = np.float32(0.5)                # not hard either, and these bits CAN change
+    rx = _rx(cfg, max_iters=50, max_batch=len(words))
+    before = rx.decoder_hard_frames()
+    bits, iters = rx.ldpc_decode(words)
+    assert rx.decoder_hard_frames() - before == 6
+    for w in range(len(words)):
+        rb, ri = orc.ldpc_decode(words[w])
+        assert iters[w] == ri and np.array_equal(bits[w], rb.astype(np.uint8)), (cfg, w, iters[w], ri)
+    assert list(iters[[8, 9]]) == [0, 0] and all(i == 51 for i in iters[[0, 1, 2, 3, 4, 5, 7]])
+    rx.close()
+
+
 @pytest.mark.parametrize("cfg", [15, 16])
 def test_zf_modes_in_the_receive_byte_variant_match_the_reference(cfg):
     """What RX_SHM feeds the decoder in the zero-forcing modes: the equalised pilots equal the pilots, the measured variance is ~1e-33 and
