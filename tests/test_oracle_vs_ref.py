@@ -43,6 +43,23 @@ def test_ldpc_decode_identical(cfg):
         assert i1 == i2 and np.array_equal(b1, b2)
 
 
+@pytest.mark.parametrize("cfg", [0, 8, 16])
+def test_the_reference_decoder_changes_no_bit_of_a_hard_word(cfg):
+    """What the GPU decoder's hard-frame shortcut rests on (ldpc.hip, NOTES R5.8), shown on the reference's own cl_ldpc::decode: a word whose
+    LLRs are all >= 200 in magnitude (what the zero-forcing modes hand over behind RX_SHM) comes back with the signs it went in with, after 0
+    iterations when its parity checks hold and after all of them (max + 1) when they do not - the worst case included: every magnitude AT the
+    threshold and a fifth of the signs wrong, so that the checks push against the channel values as hard as they can."""
+    orc, ref = oraclelib.Oracle(cfg, 50), oraclelib.RefLib(cfg, 50)
+    rng = np.random.default_rng(77 + cfg)
+    for mag, wrong in ((200.0, 0.2), (200.0, 0.02), (1e30, 0.05), (np.inf, 0.05), (250.0, 0.0)):
+        signs = np.where(rng.random(1600) < wrong, -1.0, 1.0)
+        llr = (signs * mag).astype(np.float32)                      # the all-zero codeword with sign errors
+        for dec in (orc, ref):
+            bits, it = dec.ldpc_decode(llr)
+            assert it == (0 if wrong == 0.0 else 51), (cfg, mag, wrong, it)
+            assert np.array_equal(np.asarray(bits[: dec.K]) != 0, signs[: dec.K] < 0), (cfg, mag, wrong)
+
+
 @pytest.mark.parametrize("cfg", [100, 101, 102])
 def test_mfsk_modes_identical(cfg):
     """ROBUST_0..2: cl_mfsk::mod / demod (mfsk.cc:232-390) and the MFSK branch of receive_byte, full and control frames."""

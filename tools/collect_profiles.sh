@@ -19,7 +19,7 @@ cp "$OUT/${R}_valu_cycles.json" "$ROOT/profiles/${R}_valu_cycles.json"       # w
 for d in spa spa_fast minsum; do
   "$ROOT/tools/collect_pmc_mix.sh" $d "$OUT/pmc_mix_$d.json" > /dev/null 2> "$OUT/pmc_mix_$d.err" || true
 done
-"$ROOT/tools/collect_pmc_mix.sh" spa "$OUT/pmc_mix_spa_cfg16.json" --cfg 16 > /dev/null 2> "$OUT/pmc_mix_spa_cfg16.err" || true
+"$ROOT/tools/collect_pmc_mix.sh" spa "$OUT/pmc_mix_spa_cfg16.json" --cfg 16 --variant baseband_test > /dev/null 2> "$OUT/pmc_mix_spa_cfg16.err" || true
 # the operating-point launch (mode 8 at Es/N0 3.5 dB, 3.75 iterations per frame: SURVEY.md 8d C2's second point) gets PMC passes of its own
 OPES=${OPES:-3.5}
 for d in spa spa_fast minsum; do
