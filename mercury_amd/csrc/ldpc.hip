@@ -188,7 +188,7 @@ __device__ __forceinline__ void spa_walk(double& temp, uint32_t achk, spa_cptr64
     if (m0 == 0) return;
     uint64_t n0 = 0, n1 = 0;
     if constexpr (C + 1 < CMAX) { n0 = bm[2 * C + 2]; n1 = bm[2 * C + 3]; }
-    const lds_f64* chk = reinterpret_cast<const lds_f64*>(achk);
+    const volatile lds_f64* chk = reinterpret_cast<const volatile lds_f64*>(achk);      // volatile: see spa_walk4
     const double a0 = chk[2 * C], a1 = chk[2 * C + 1];
     spa_masked_mul2(temp, a0, a1, m0, m1);
     if constexpr (C + 1 < CMAX) spa_walk<C + 1, CMAX>(temp, achk, bm, n0, n1);
@@ -200,7 +200,10 @@ __device__ __forceinline__ void spa_walk4(double& temp, uint32_t achk, spa_cptr6
     if (m0 == 0) return;
     uint64_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     if constexpr (C + 1 < CMAX) { n0 = bm[4 * C + 4]; n1 = bm[4 * C + 5]; n2 = bm[4 * C + 6]; n3 = bm[4 * C + 7]; }
-    const lds_f64* chk = reinterpret_cast<const lds_f64*>(achk);
+    // volatile keeps these four reads four ds_read_b64: left alone the compiler pairs them into ds_read2_b64, and the LDS pipeline takes 8 cycles
+    // for one of those against 2.2 for a ds_read_b64 (4.0 for a ds_read_b128, which would need every check to start on an even slot) -
+    // tools/ubench/lds_mask.hip, profiles/r05_lds_mask.json. The walk's reads were what kept the LDS pipeline of the rate-14/16 kernel 86 % busy.
+    const volatile lds_f64* chk = reinterpret_cast<const volatile lds_f64*>(achk);
     const double a0 = chk[4 * C], a1 = chk[4 * C + 1], a2 = chk[4 * C + 2], a3 = chk[4 * C + 3];
     spa_masked_mul2(temp, a0, a1, m0, m1);
     if (m2 != 0) spa_masked_mul2(temp, a2, a3, m2, m3);
