@@ -127,7 +127,7 @@ void ctx_alloc(mgpu_ctx* c) {
     l.DM = t.graph.DM;
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
-    l.hard_frames = reinterpret_cast<unsigned long long*>(c->keep(upload(std::vector<uint64_t>(1, 0))));
+    l.hard_frames = reinterpret_cast<unsigned long long*>(c->keep(upload(std::vector<uint64_t>(64, 0))));
     HIPCK(hipStreamCreate(&c->stream));
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));
     for (auto& e : c->sync_ev) HIPCK(hipEventCreate(&e));
@@ -667,9 +667,11 @@ int mgpu_decoder_hard_frames(mgpu_ctx* c, long long* frames) {
     if (!c || !frames) return MGPU_ERR_ARG;
     return guard(c, [&] {
         HIPCK(hipStreamSynchronize(c->stream));
-        unsigned long long v = 0;
-        HIPCK(hipMemcpy(&v, c->ldev.hard_frames, sizeof(v), hipMemcpyDeviceToHost));
-        *frames = (long long)v;
+        unsigned long long v[64];
+        HIPCK(hipMemcpy(v, c->ldev.hard_frames, sizeof(v), hipMemcpyDeviceToHost));
+        long long sum = 0;
+        for (unsigned long long x : v) sum += (long long)x;
+        *frames = sum;
     });
 }
 

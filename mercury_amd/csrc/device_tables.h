@@ -61,7 +61,7 @@ struct LdpcDev {
     int DM;
     int S, N, P, K, E, nReal, payload_stride, max_iters;
     float minsum_alpha;
-    unsigned long long* hard_frames;   // fp64 decoder: +1 per frame decided before its first iteration (every |LLR| >= 200 and an odd parity check), mgpu_decoder_hard_frames
+    unsigned long long* hard_frames;   // [64] fp64 decoder: +1 (in counter frame % 64) per frame decided before its first iteration (every |LLR| >= 200 and an odd parity check), mgpu_decoder_hard_frames
 };
 
 struct MgpuTapsDev {

@@ -21,6 +21,13 @@
 struct c2 { double re, im; };
 
 __device__ __forceinline__ c2 cmul(c2 a, c2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// A twiddle from the LDS table, which every caller keeps on a 16-byte boundary: one ds_read_b128 (4 LDS-pipeline cycles). Read as a c2 (alignment
+// 8) through a lane's precomputed address it becomes a ds_read2_b64, which takes 8 (tools/ubench/lds_mask.hip).
+__device__ __forceinline__ c2 fft256_twiddle(const c2* __restrict__ tw, int slot) {
+    typedef double fft_v2d __attribute__((ext_vector_type(2)));
+    const fft_v2d w = *reinterpret_cast<const fft_v2d*>(tw + slot);
+    return {w.x, w.y};
+}
 
 #define FFT256_STRIDE 256   // c2 entries of wave-private LDS work space
 
@@ -43,14 +50,14 @@ __device__ __forceinline__ void wave_fft256(c2& r0, c2& r1, c2& r2, c2& r3, c2* 
     };
     auto bfly = [&](c2& lo, c2& hi, int p0, int st) {
         const int j = brev8(p0) & ((1 << (st - 1)) - 1);
-        bfly_w(lo, hi, tw[fft256_tw_slot(j << (8 - st))]);
+        bfly_w(lo, hi, fft256_twiddle(tw, fft256_tw_slot(j << (8 - st))));
     };
     auto padded = [](int p) {       // the entry of position p (see the header of this file)
         const int h = p >> 4;
         return (p & ~15) | ((p & 15) ^ ((h & 1 ? 4 : 0) ^ (h & 2 ? 1 : 0) ^ (h & 4 ? 14 : 0)));
     };
     // stages 1, 2: positions lane + 64k; their twiddle indices are wave-uniform (0, 0, 0 and 64)
-    const c2 w0 = tw[0], w64 = tw[fft256_tw_slot(64)];
+    const c2 w0 = fft256_twiddle(tw, 0), w64 = fft256_twiddle(tw, fft256_tw_slot(64));
     bfly_w(r0, r2, w0); bfly_w(r1, r3, w0);
     bfly_w(r0, r1, w0); bfly_w(r2, r3, w64);
     v[padded(lane)] = r0; v[padded(lane + 64)] = r1; v[padded(lane + 128)] = r2; v[padded(lane + 192)] = r3;
@@ -110,7 +117,7 @@ __device__ __forceinline__ c2 wave_fft256_carriers(c2 r0, c2 r1, c2 r2, c2 r3, c
                                                    const Fft256CarrierLane& c) {
     wave_fft256<true>(r0, r1, r2, r3, v, tw, lane);
     auto flip = [&](double x) { return __hiloint2double(int(uint32_t(__double2hiint(x)) ^ c.sign), __double2loint(x)); };
-    const c2 w7 = tw[c.slot7], w8 = tw[c.slot8];
+    const c2 w7 = fft256_twiddle(tw, c.slot7), w8 = fft256_twiddle(tw, c.slot8);
     c2 t = cmul(w7, r2), u = cmul(w7, r3);
     // a - t is a + (-t) in IEEE arithmetic (signed zeros included), so flipping the subtrahend's sign turns the one written addition into
     // the butterfly's "lo" (bin b) or "hi" (bin b + 192) output per lane: three flips of complex values, six XORs

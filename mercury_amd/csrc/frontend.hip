@@ -116,10 +116,11 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
     c2* grid = reinterpret_cast<c2*>(smem);
     c2* Hp = grid + G;                                              // channel estimate at the pilots, pilot order; Hp and red are the FFT work area first
     c2* fftb = Hp;
-    double* red = reinterpret_cast<double*>(Hp + T.nPilots);        // nPilots doubles
+    double* red = reinterpret_cast<double*>(__builtin_assume_aligned(Hp + T.nPilots, 16));        // nPilots doubles
     float* llr = reinterpret_cast<float*>(red);                     // demapper output reuses the reduction area
     c2* yp = reinterpret_cast<c2*>(red);                            // pilots in row-major pilot order, multiplied by their sign
-    c2* tw = reinterpret_cast<c2*>(reinterpret_cast<unsigned char*>(Hp) + carve.work);
+    // (every piece of the carve is a multiple of 16 bytes; said so, a c2 is one ds_read_b128 - 4 LDS-pipeline cycles - instead of a ds_read2_b64 - 8: tools/ubench/lds_mask.hip)
+    c2* tw = reinterpret_cast<c2*>(__builtin_assume_aligned(reinterpret_cast<unsigned char*>(Hp) + carve.work, 16));
     int8_t* type = reinterpret_cast<int8_t*>(tw);                   // 0 data, +1 / -1 pilot with that sign; takes the twiddles' place after the FFTs
     double* scal = reinterpret_cast<double*>(type + ((G + 15) & ~15));
 
@@ -322,7 +323,7 @@ __device__ __forceinline__ void fe_frame(const MgpuDev& T, const double* __restr
     // baseband_test_EsN0 variant). Both variances are sums of nPilots terms in pilot order — dependent chains for one lane — so
     // wavefront 0 adds them while the other wavefronts equalise the data cells, handed out in runs of 64 from a counter in LDS;
     // wavefront 0 joins when its sums are done.
-    double* red2 = red + T.nPilots;                                  // second term array (the signed pilots are no longer needed)
+    double* red2 = reinterpret_cast<double*>(__builtin_assume_aligned(red + ((T.nPilots + 1) & ~1), 16));   // second term array (the signed pilots are no longer needed), on a 16-byte boundary
     int* queue = reinterpret_cast<int*>(scal + 3);
     if (tid == 0) *queue = 0;
     for (int p = tid; p < T.nPilots; p += FE_THREADS) {

@@ -46,7 +46,7 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
                                               float* __restrict__ snr_variance_out, const MgpuTapsDev& taps) {
     constexpr int NB = M == 32 ? 5 : 4, BPS = NB * NS, HOP = M == 32 ? 13 : 7;   // mfsk.cc:56-66
     static_assert(M * NS == kBandEnd - kBandStart, "tone band");
-    __shared__ c2 tw[128];
+    __shared__ __attribute__((aligned(16))) c2 tw[128];      // 16-byte aligned: fft256_twiddle reads it as ds_read_b128
     __shared__ c2 fftb[MF_WAVES * FFT256_STRIDE];
     __shared__ double en[MF_WAVES][128];         // |carrier|^2 of the wave's current pair of symbols, carrier order, 64 per symbol
 
@@ -200,7 +200,7 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_mfsk_frontend_kern
 extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_slot_energy_kernel(
     const double* __restrict__ baseband_interp, int size, int nslots, int interp, const double* __restrict__ twiddle,
     double* __restrict__ energy /*[W][nslots][50]*/) {
-    __shared__ c2 tw[128];
+    __shared__ __attribute__((aligned(16))) c2 tw[128];      // 16-byte aligned: fft256_twiddle reads it as ds_read_b128
     __shared__ c2 fftb[MF_WAVES * FFT256_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w = blockIdx.y, s = blockIdx.x * MF_WAVES + wave;

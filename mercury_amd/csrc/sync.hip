@@ -692,7 +692,7 @@ extern "C" __global__ __launch_bounds__(64 * TfGeom<8>::WAVES) void mgpu_tsync_m
 extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(
     const double* __restrict__ bb, int stride, int pre_half, const double* __restrict__ twiddle, double* __restrict__ freq_out) {
     __shared__ c2 v[4][256];
-    __shared__ c2 tw[128];
+    __shared__ __attribute__((aligned(16))) c2 tw[128];      // 16-byte aligned: fft256_twiddle reads it as ds_read_b128
     __shared__ c2 dep[8][50];
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const c2* in = reinterpret_cast<const c2*>(bb) + size_t(w) * stride;
