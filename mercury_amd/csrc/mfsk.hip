@@ -47,7 +47,7 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
     constexpr int NB = M == 32 ? 5 : 4, BPS = NB * NS, HOP = M == 32 ? 13 : 7;   // mfsk.cc:56-66
     static_assert(M * NS == kBandEnd - kBandStart, "tone band");
     __shared__ __attribute__((aligned(16))) c2 tw[128];      // 16-byte aligned: fft256_twiddle reads it as ds_read_b128
-    __shared__ c2 fftb[MF_WAVES * FFT256_STRIDE];
+    __shared__ __attribute__((aligned(16))) c2 fftb[MF_WAVES * FFT256_STRIDE];
     __shared__ double en[MF_WAVES][128];         // |carrier|^2 of the wave's current pair of symbols, carrier order, 64 per symbol
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,7 +82,8 @@ __device__ __forceinline__ void mfsk_frontend(const MgpuDev& T, const double* __
     const int gray_m = m ^ (m >> 1);
     const int tone_off = kBandStart + st * M;
     const Fft256CarrierLane fcl = fft256_carrier_lane(lane);    // the one FFT bin this lane keeps (fft256.h)
-    double* E = en[wave] + half * 64;                            // |carrier|^2 of this half's symbol, carrier order
+    // (volatile: the 18 / 32 consecutive reads below stay ds_read_b64 - 2.2 LDS-pipeline cycles each; paired into ds_read2_b64 they take 8: tools/ubench/lds_mask.hip)
+    const volatile double* E = en[wave] + half * 64;             // |carrier|^2 of this half's symbol, carrier order
 
     for (int sa = s0 + wave; sa < s1; sa += 2 * MF_WAVES) {
         const int sb = sa + MF_WAVES;                                // the pair's second symbol (may lie past the run's end)
@@ -201,7 +202,7 @@ extern "C" __global__ __launch_bounds__(MF_THREADS) void mgpu_slot_energy_kernel
     const double* __restrict__ baseband_interp, int size, int nslots, int interp, const double* __restrict__ twiddle,
     double* __restrict__ energy /*[W][nslots][50]*/) {
     __shared__ __attribute__((aligned(16))) c2 tw[128];      // 16-byte aligned: fft256_twiddle reads it as ds_read_b128
-    __shared__ c2 fftb[MF_WAVES * FFT256_STRIDE];
+    __shared__ __attribute__((aligned(16))) c2 fftb[MF_WAVES * FFT256_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w = blockIdx.y, s = blockIdx.x * MF_WAVES + wave;
     for (int i = tid; i < 128; i += MF_THREADS) tw[fft256_tw_slot(i)] = {twiddle[2 * i], twiddle[2 * i + 1]};

@@ -23,7 +23,7 @@
 extern "C" __global__ __launch_bounds__(ST_THREADS) void mgpu_stage_symbol_demod_kernel(
     const double* __restrict__ in, int n, const double* __restrict__ twiddle, double* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) c2 tw[128];      // 16-byte aligned: fft256_twiddle reads it as ds_read_b128
-    __shared__ c2 fftb[(ST_THREADS / 64) * FFT256_STRIDE];
+    __shared__ __attribute__((aligned(16))) c2 fftb[(ST_THREADS / 64) * FFT256_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 128; i += ST_THREADS) tw[fft256_tw_slot(i)] = {twiddle[2 * i], twiddle[2 * i + 1]};
     __syncthreads();

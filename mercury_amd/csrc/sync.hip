@@ -264,7 +264,7 @@ extern "C" __global__ __launch_bounds__(64 * TS_WAVES) void mgpu_tsync_metric_ke
     const int ncand = ncand_w ? ncand_w[blockIdx.x] : ncand_max;
     const int size = stride - wstart;
     // requires ngi_i % TS_CH == 0 and (nfft_i / 2) % TS_CH == 0 (the host checks; 64 and 512 in the reference's calls)
-    __shared__ c2 tile[TS_WAVES][2][64][TS_CH + 1];
+    __shared__ __attribute__((aligned(16))) c2 tile[TS_WAVES][2][64][TS_CH + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cand0 = (blockIdx.y * TS_WAVES + wave) * 64;
     if (cand0 >= ncand) return;
@@ -497,7 +497,7 @@ extern "C" __global__ __launch_bounds__(64 * TS_DWAVES) void mgpu_tsync_metric_d
     const int wstart = start ? start[blockIdx.y] : 0;
     const int ncand = ncand_w ? ncand_w[blockIdx.y] : ncand_max;
     const int size = stride - wstart;
-    __shared__ c2 span[TS_DWAVES][2][TS_DSPAN];
+    __shared__ __attribute__((aligned(16))) c2 span[TS_DWAVES][2][TS_DSPAN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cand0 = (blockIdx.x * TS_DWAVES + wave) * 64;
     if (cand0 >= ncand) return;
@@ -691,9 +691,9 @@ extern "C" __global__ __launch_bounds__(64 * TfGeom<8>::WAVES) void mgpu_tsync_m
 // half symbol repeated twice; the four wavefronts take two symbols per round.
 extern "C" __global__ __launch_bounds__(256) void mgpu_fsync_kernel(
     const double* __restrict__ bb, int stride, int pre_half, const double* __restrict__ twiddle, double* __restrict__ freq_out) {
-    __shared__ c2 v[4][256];
+    __shared__ __attribute__((aligned(16))) c2 v[4][256];
     __shared__ __attribute__((aligned(16))) c2 tw[128];      // 16-byte aligned: fft256_twiddle reads it as ds_read_b128
-    __shared__ c2 dep[8][50];
+    __shared__ __attribute__((aligned(16))) c2 dep[8][50];
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const c2* in = reinterpret_cast<const c2*>(bb) + size_t(w) * stride;
     if (tid < 128) tw[tid] = {twiddle[2 * tid], twiddle[2 * tid + 1]};

@@ -19,7 +19,7 @@
 // cl_ofdm::symbol_mod (ofdm.cc:855-860), one wavefront per symbol
 extern "C" __global__ __launch_bounds__(256) void mgpu_symbol_mod_kernel(const double* __restrict__ twiddle, const double* __restrict__ carriers,
                                                                        int n, double* __restrict__ out) {
-    __shared__ c2 fftb[4 * FFT256_STRIDE];
+    __shared__ __attribute__((aligned(16))) c2 fftb[4 * FFT256_STRIDE];
     __shared__ __attribute__((aligned(16))) c2 tw[128];      // 16-byte aligned: fft256_twiddle reads it as ds_read_b128
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 128; i += 256) tw[fft256_tw_slot(i)] = {twiddle[2 * i], -twiddle[2 * i + 1]};       // conjugated: IFFT (ofdm.cc:365)
