@@ -157,9 +157,12 @@ def issue_view(mix, src, kernel_ms, machine, sclk=None):
         # the engine clock the device actually held while this kernel was timed (hwmon samples) when there are any; else the runtime's maximum
         clock_hz = 1e6 * sclk["median"] if sclk and sclk.get("median") else machine["clock_hz"]
         avail = machine["simds"] * clock_hz * kernel_ms * 1e-3
+        # "frac" is the counters' own, clock-free reading where the profile has it (valu_busy_pmc below); the two priced readings bracket it and can
+        # exceed 1 by the few per cent the sampled clock and the micro-benchmarked costs are off by
+        busy = 4.0 * mix["SQ_ACTIVE_INST_VALU"] / (mix["GRBM_GUI_ACTIVE"] / 8.0 * machine["simds"]) if mix.get("GRBM_GUI_ACTIVE") and fp32 == 0 else None
         return {"bound": "valu_issue", "unit": "SIMD issue cycles per launch", "available": avail,
                 "needed_isolated_costs": isolated, "frac_isolated": isolated / avail,
-                "needed_4cycle_slots": slots, "frac_slots": slots / avail, "frac": slots / avail,
+                "needed_4cycle_slots": slots, "frac_slots": slots / avail, "frac": busy if busy is not None else slots / avail,
                 "clock_hz_used": clock_hz, "clock_source": "hwmon freq1_input, median over the timed region" if clock_hz != machine["clock_hz"] else "hipDeviceProp clockRate (maximum)",
                 "valu_instructions_per_launch": mix["SQ_INSTS_VALU"],
                 # PMC only, clock-free: SQ_ACTIVE_INST_VALU counts issue quanta; x4 turns them into SIMD cycles for fp64 streams (an over-estimate for 32-bit
@@ -294,7 +297,7 @@ def operating_point_roofline(rx, decoder, m, F, machine, profiled, sclk=None):
                          "frac": ldpc_bytes / (m["ldpc_ms"] * 1e-3) / HBM_PEAK, "bytes_per_codeword_iteration": b_iter},
            "traffic": (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None, "traffic_source": src}
     if "frac" in dec["secondary"]:
-        dec["frac"] = dec["secondary"]["frac_isolated"] if decoder != "spa" else dec["secondary"]["frac_slots"]
+        dec["frac"] = dec["secondary"]["frac_isolated"] if decoder != "spa" else dec["secondary"]["frac"]
     return {"frontend": fe, "decoder": dec}
 
 
