@@ -16,6 +16,8 @@ cd /tmp && export TMPDIR=/tmp
 cp "$OUT/${R}_valu_cycles.json" "$ROOT/profiles/${R}_valu_cycles.json"       # where bench.py looks for the opcode costs
 [ -x "$ROOT/tools/ubench/dep_chain" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/dep_chain" "$ROOT/tools/ubench/dep_chain.hip" 2>/dev/null
 "$ROOT/tools/ubench/dep_chain" > "$OUT/${R}_dep_chain.json"
+[ -x "$ROOT/tools/ubench/lds_mask" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/lds_mask" "$ROOT/tools/ubench/lds_mask.hip" 2>/dev/null
+"$ROOT/tools/ubench/lds_mask" > "$OUT/${R}_lds_mask.json"            # LDS-pipeline cycles per instruction kind / execution mask / address pattern (NOTES R5.9)
 for d in spa spa_fast minsum; do
   "$ROOT/tools/collect_pmc_mix.sh" $d "$OUT/pmc_mix_$d.json" > /dev/null 2> "$OUT/pmc_mix_$d.err" || true
 done
@@ -102,5 +104,10 @@ if [ "$1" = "sweep" ]; then
   for dec in spa spa_fast minsum; do for it in 5 20 50; do
     python bench.py --ldpc-only --cfg 13 --iters $it --decoder $dec --no-cpu-baseline --no-extras --steps 20 2>/dev/null | tail -1 >> "$OUT/${R}_bench_ldpc_only_rate8.jsonl"
   done; done
+fi
+# which of fdlibm's case branches the decoder's wavefronts enter (variant build: tools/build_variants.sh census:"-DSPA_CENSUS_ON=1")
+if [ -f "$ROOT/mercury_amd/_variants/lib_census.so" ]; then
+  ( cd "$ROOT"; for a in "8 1024 -15" "8 1024 3.5" "16 512 -15" "16 512 -15 baseband" "14 512 -15" "16 512 13 baseband" "0 512 -15" "11 512 -15"; do
+      MERCURY_GPU_LIB=$ROOT/mercury_amd/_variants/lib_census.so python tools/spa_census.py $a 2>/dev/null | tail -25; done > "$OUT/${R}_spa_branch_census.txt" )
 fi
 ls -la "$OUT"
