@@ -436,9 +436,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     SPA_STAMP(4);                                   // 4: behind the barrier
     if (flag[0] && hard_frame) {
         iteration = T.max_iters + 1;
-#ifndef SPA_NO_HARD_COUNT
-        if (tid == 0 && T.hard_frames) atomicAdd(T.hard_frames + (f & 63), 1ull);      // so that a benchmark can tell reported from executed iterations (64 counters: one address serialised a launch of hard frames for 0.3 ms)
-#endif
+        if (tid == 0 && T.hard_frames) atomicAdd(T.hard_frames + (f & 63), 1ull);      // so that a benchmark can tell reported from executed iterations (64 counters: a launch of hard frames does not queue on one address)
     }
     else if (flag[0]) {
         for (int it = 1;; ++it) {
