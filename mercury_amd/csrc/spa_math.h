@@ -107,8 +107,9 @@ SPA_FN double spa_one_minus_2_over(double d, double) { return 1.0 - 2.0 / d; }
 // polynomial's constants. Scaling by a power of two commutes with every IEEE rounding away from the denormal range - fl(2a * b) = 2 fl(a * b),
 // fl(2a + 2b) = 2 fl(a + b) - so every value below is fdlibm's own, times the stated power of two, and every result has fdlibm's bits; what
 // goes is the instructions that only doubled or halved (hfx = 0.5 r, t2 = x + x, 0.5 f) and the separate multiplications in front of
-// additions whose product is exact. (The arguments for which an intermediate would be denormal are the ones both routines answer
-// from their tiny-argument branch.) tests/test_spa_math.py runs this very code on the host against the host's libm.
+// additions whose product is exact. (Where an intermediate can be denormal - arguments below 2^-500 or so - the host test checks the results
+// binade by binade down to the smallest denormal: atanh answers those from its |x| < 2^-28 branch, tanh's general path yields 0.5*q there.)
+// tests/test_spa_math.py runs this very code on the host against the host's libm.
 
 // tanh(0.5 * q)
 SPA_FN double spa_tanh_half(double q) {
@@ -128,7 +129,7 @@ SPA_FN double spa_tanh_half(double q) {
     const double hi = __builtin_fma(-tk, ln2_hi, A);         // A - tk*ln2_hi: the product is exact (|k| < 2^10, ln2_hi has 32 mantissa bits)
     const double lo = tk * ln2_lo;
     double rp = hi - lo;
-    double cp = (hi - rp) - lo;                              // (only the k != 0 endings use it; formed here, rp's last use, so that r takes rp's registers)
+    double cp = (hi - rp) - lo;                              // (+0 when k = 0; formed here, rp's last use, so that r takes rp's registers)
     SPA_KEEP(cp);
     const uint32_t sm = big ? 0u : 0x80000000u;
     const double r = SPA_MAKE(SPA_BITS_HI(rp) ^ sm, SPA_LO(rp));
