@@ -14,10 +14,15 @@ AWGN. Default Es/N0 = -15 dB so that every frame executes all 50 iterations ("mo
 --esn0 2.5 gives the operating point with early termination. Decoder = sum-product in double (the
 reference's algorithm, results identical to the CPU path); --decoder minsum selects the fp32 variant.
 
-Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (the LDPC decoder) with SURVEY.md
-§8d's algorithmic bytes (16*E + 4*N per codeword-iteration + LLRs in + payload out) against 8 TB/s;
-`cpu_baseline` times the CPU checker (the plain-C port of the reference, bit-identical to it) on a
-bounded sample of the very same frames on the host cores, and cross-checks the GPU results on them.
+Output (rank 0): the LAST stdout line is the contract record - one JSON object of at most 4096 bytes (compact_line(): metric .. config,
+kernel_ms, roofline, cpu_baseline, and the same workload's two other points: operating_point = threshold + 3 dB with early termination,
+waterfall_point = just below the threshold, where every frame runs all the iterations on LLRs of real magnitude). The full record (other
+decoders, opcode classes, per-rank detail, PCIe pipeline, receive_byte, machine) is written to bench_extras.json beside this script and
+printed as an EARLIER stdout line (--line compact|full|both). `roofline` prices the dominant kernel (the LDPC decoder) with SURVEY.md
+§8d's algorithmic bytes (16*E + 4*N per codeword-iteration + LLRs in + payload out) against 8 TB/s; EVERY `frac` of the record is that
+model fraction (an effective bandwidth: the messages are LDS-resident, `traffic` is what the PMC counters saw); the bound the kernels
+really hit, vector-instruction issue, is `roofline.secondary.frac`. `cpu_baseline` times the CPU checker (the plain-C port of the
+reference, bit-identical to it) on a bounded sample of the very same frames on the host cores, and cross-checks the GPU results on them.
 """
 import argparse
 import json
@@ -40,6 +45,7 @@ DECODERS = {"spa": DEC_SPA, "minsum": DEC_MINSUM, "gbf": DEC_GBF, "spa_fast": DE
 from mercury_amd.sharding import frame_range
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+WATERFALL_BELOW_THRESHOLD_DB = 1.5     # waterfall_point: Es/N0 = the mode's threshold (tests/conftest.py OPERATING_ESN0 - 2 dB) minus this
 SEED = 0x4D455243
 
 
@@ -225,6 +231,113 @@ def usable_cores():
     return max(1, n)
 
 
+COMPACT_LIMIT = 4096          # bytes: the contract line is the LAST stdout line and must survive a driver that keeps a stdout tail
+
+
+def _sig(x, n=6):
+    """Numbers of the compact line carry n significant digits (ints, bools, None and strings pass through)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (n, float(x)))
+    except (TypeError, ValueError):
+        return x
+
+
+def _pick(d, keys, n=6):
+    return {k: _sig(d[k], n) for k in keys if isinstance(d, dict) and k in d}
+
+
+def _roofline_compact(r):
+    """bound / achieved / peak / unit / frac / traffic / kernel of one kernel's roofline; `frac` is ALWAYS the SURVEY.md §8d HBM-model fraction
+    (algorithmic bytes / kernel time / 8 TB/s), the issue-bound reading lives in secondary.frac only."""
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_codeword_iteration", "bytes_per_frame"))
+    sec = r.get("secondary")
+    if isinstance(sec, dict) and "frac" in sec:
+        out["secondary"] = _pick(sec, ("bound", "frac"), 4)
+    return out
+
+
+def _point_compact(p):
+    """One secondary operating record (operating_point / waterfall_point) of the compact line."""
+    if not isinstance(p, dict):
+        return None
+    out = _pick(p, ("value", "unit", "ms_per_step", "esn0_db", "avg_iters_per_frame", "frames_running_all_iters", "decoded_fraction", "ldpc_iters_per_s"))
+    if "kernel_ms" in p:
+        out["kernel_ms"] = _pick(p["kernel_ms"], ("frontend", "ldpc"), 5)
+    rf = p.get("roofline") or {}
+    if "decoder" in rf:
+        out["roofline"] = _roofline_compact(rf["decoder"])
+        fe = _roofline_compact(rf.get("frontend"))
+        if fe:
+            out["roofline_frontend"] = _pick(fe, ("frac", "traffic", "secondary"))
+    return out
+
+
+def compact_line(full):
+    """The contract record: what the driver parses (metric .. config, roofline, cpu_baseline) plus the two other first-class points of the same
+    workload (operating_point: threshold + 1 dB with early termination; waterfall_point: the Es/N0 at which >= 90 % of the frames run all the
+    iterations on LLRs of real magnitude), at most COMPACT_LIMIT bytes whatever the full record holds. Everything else (other decoders, opcode
+    classes, per-rank detail, PCIe pipeline, machine) stays in the full record: bench_extras.json beside this script and an EARLIER stdout line."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: _sig(full[k], 7) for k in keep if k in full}
+    cfg = full.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("workload", "frames_per_step_per_gpu", "cfg", "esn0_db", "decoder", "parallelism") if k in cfg}
+    out.update(_pick(full, ("ldpc_iters_per_s", "avg_iters_per_frame", "decoded_fraction", "hard_frames_per_step")))
+    if "kernel_ms" in full:
+        out["kernel_ms"] = _pick(full["kernel_ms"], ("frontend", "ldpc", "launches_averaged"), 5)
+    out["roofline"] = _roofline_compact(full.get("roofline"))
+    if isinstance(out["roofline"], dict) and isinstance(full.get("roofline"), dict):
+        out["roofline"]["note"] = "sec. 8d model bytes; messages are LDS-resident (traffic = PMC HBM bytes); bound is vector issue: secondary"
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "ldpc_iters_per_s", "gpu_vs_cpu_mismatches", "reference_1core_frames_per_s", "gpu_over_cpu"))
+    for name in ("operating_point", "waterfall_point"):
+        pt = _point_compact(full.get(name))
+        if pt:
+            out[name] = pt
+    ex = full.get("extras_per_gpu") or {}
+    rb = ex.get("receive_byte_capture_windows")
+    if isinstance(rb, dict) and "error" not in rb:
+        out["receive_byte"] = _pick(rb, ("windows", "decoded", "windows_per_s_device_resident", "windows_per_s_host_buffers", "windows_per_s_host_buffers_int32_samples"), 5)
+    for k in ("pcie_inclusive_frames_per_s", "pcie_inclusive_pinned_frames_per_s"):
+        if k in full:
+            out[k] = _sig(full[k], 5)
+    pd = full.get("per_device") or full.get("per_rank")
+    if isinstance(pd, list) and len(pd) > 1:          # N > 1: the clock every board held, its power and its own kernel / wall times
+        out["per_device"] = [[_sig(r.get(k), 4) for k in ("sclk_mhz_median", "sclk_mhz_min", "power_w_median", "ldpc_kernel_ms", "frontend_kernel_ms", "wall_ms")] for r in pd]
+        out["per_device_columns"] = "sclk_mhz_median, sclk_mhz_min, power_w_median, ldpc_kernel_ms, frontend_kernel_ms, wall_ms"
+    clk = full.get("sclk_mhz_during_run")
+    if isinstance(clk, dict):
+        out["sclk_mhz"] = _pick(clk, ("min", "median", "max", "power_w_median"), 4)
+    out["full_record"] = "bench_extras.json + the stdout line before this one"
+    # a guard, not a plan: should the record ever outgrow the limit, drop the least important blocks until it fits
+    for victim in ("per_device", "receive_byte", "pcie_inclusive_pinned_frames_per_s", "sclk_mhz", "waterfall_point", "operating_point"):
+        if len(json.dumps(out)) <= COMPACT_LIMIT:
+            break
+        out.pop(victim, None)
+        out.pop(victim + "_columns", None)
+    return out
+
+
+def emit(full, args):
+    """Full record -> bench_extras.json beside the script (best effort) and, unless --line compact, an earlier stdout line; the compact contract
+    record is the LAST stdout line."""
+    compact = compact_line(full)
+    assert len(json.dumps(compact)) <= COMPACT_LIMIT
+    try:
+        with open(os.path.join(ROOT, "bench_extras.json"), "w") as fh:
+            json.dump(full, fh)
+    except OSError:
+        pass
+    if args.line in ("full", "both"):
+        print(json.dumps(dict({"bench_full_record": True}, **full)), flush=True)
+    if args.line in ("compact", "both"):
+        print(json.dumps(compact), flush=True)
+
+
 def cpu_baseline(cfg, max_iters, bb_sample, flags, gpu_payload, gpu_stats):
     """Time the CPU checker on a bounded sample of the same frames; also cross-check the GPU output."""
     import oraclelib
@@ -278,7 +391,7 @@ def headline_workload(args, F):
     return (not args.ldpc_only) and args.cfg == 8 and F == 4096 and args.iters == 50 and args.variant == "receive_byte" and args.channel == 0
 
 
-def operating_point_roofline(rx, decoder, m, F, machine, profiled, sclk=None):
+def operating_point_roofline(rx, decoder, m, F, machine, profiled, sclk=None, mix_suffix="_op"):
     """Rooflines of the two kernels of one operating-point step (SURVEY.md §8d C2's second point): the front-end is a streaming kernel
     - its input samples against HBM - and also priced against vector issue from its PMC mix; the decoder (LDS-resident messages) against
     vector issue from a PMC pass of THIS launch (profiles/<round>_instruction_mix.json["<decoder>_op"]), with the §8d HBM-model figure
@@ -291,13 +404,13 @@ def operating_point_roofline(rx, decoder, m, F, machine, profiled, sclk=None):
     fe["traffic"] = (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None
     fe["secondary"] = issue_view(mix, src, m["frontend_ms"], machine, sclk)
     ldpc_bytes, _, b_iter = algorithmic_bytes(rx, m["avg_iters"] * F, F)
-    mix, src = profile_mix(decoder + "_op", profiled)
-    dec = {"kernel": "mgpu_ldpc_%s_kernel" % decoder, "bound": "valu_issue", "secondary": issue_view(mix, src, m["ldpc_ms"], machine, sclk),
-           "hbm_model": {"achieved": ldpc_bytes / (m["ldpc_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ldpc_bytes / (m["ldpc_ms"] * 1e-3) / HBM_PEAK, "bytes_per_codeword_iteration": b_iter},
-           "traffic": (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None, "traffic_source": src}
-    if "frac" in dec["secondary"]:
-        dec["frac"] = dec["secondary"]["frac_isolated"] if decoder != "spa" else dec["secondary"]["frac"]
+    mix, src = profile_mix(decoder + mix_suffix, profiled)
+    # `frac` is the §8d HBM-model fraction here as everywhere in the line (an EFFECTIVE bandwidth: the messages are LDS-resident); the bound these
+    # launches actually hit - vector-instruction issue - is secondary.frac (the counters' VALU-busy reading where the profile has this launch)
+    ach = ldpc_bytes / (m["ldpc_ms"] * 1e-3)
+    dec = {"kernel": "mgpu_ldpc_%s_kernel" % decoder, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+           "bytes_per_codeword_iteration": b_iter, "traffic": (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None, "traffic_source": src,
+           "secondary": issue_view(mix, src, m["ldpc_ms"], machine, sclk)}
     return {"frontend": fe, "decoder": dec}
 
 
@@ -339,9 +452,10 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp, machine):
         # modes). What bounds them is vector-instruction issue: the fraction of the SIMDs' issue cycles their PMC opcode mix needs.
         mix, src = profile_mix(other, profiled and abs(m["avg_iters"] - 50.0) < 1e-6)
         sec = issue_view(mix, src, m["ldpc_ms"], machine, m["sclk_mhz"])
+        lb, _, _ = algorithmic_bytes(rx, m["avg_iters"] * F, F)
+        m["roofline_frac"] = lb / (m["ldpc_ms"] * 1e-3) / HBM_PEAK       # §8d model, like every `frac` of the line (not a ceiling for LDS-resident fp32 messages: can exceed 1)
         if sec and "frac" in sec:
-            m["roofline_frac"] = sec["frac_isolated"]
-            m["roofline_bound"] = "valu_issue (isolated opcode costs; %s)" % sec["source"]
+            m["roofline_secondary"] = {"bound": "valu_issue", "frac": sec["frac_isolated"], "source": "isolated opcode costs; %s" % sec["source"]}
         out["same_inputs_decoder_" + other] = m
         others[other] = rx2
     op = OPERATING_ESN0[args.cfg] + 1.0
@@ -354,6 +468,18 @@ def extras(args, rx, bufs, payload, stats, stream, dev, F, noise_amp, machine):
         r["esn0_db"] = op
         r["roofline"] = operating_point_roofline(rx, name, r, F, machine, profiled, r["sclk_mhz"])
         out["operating_point_decoder_" + name] = r
+    # the waterfall: the Es/N0 just below the mode's threshold, where (nearly) every frame runs ALL the iterations on LLRs of real magnitude (the
+    # lanes spread over all of fdlibm's cases, unlike the noise-only headline input) - where the reference spends its "~35 ms per trial"
+    wf = args.waterfall_esn0 if args.waterfall_esn0 is not None else OPERATING_ESN0[args.cfg] - 2.0 - WATERFALL_BELOW_THRESHOLD_DB
+    bw = torch.empty_like(bb)
+    rx.txgen_dev(SEED, 1 << 41, F, float(10.0 ** (-wf / 20.0) / np.sqrt(2.0)), bw.data_ptr(), None, channel=args.channel, stream=stream)
+    torch.cuda.synchronize()
+    r = timed(rx, [bw], steps=10)
+    r["esn0_db"] = wf
+    r["frames_running_all_iters"] = float((stats[:, 0] >= args.iters).sum().item()) / F
+    r["roofline"] = operating_point_roofline(rx, args.decoder, r, F, machine, profiled and r["frames_running_all_iters"] > 0.9, r["sclk_mhz"], mix_suffix="_wf")
+    out["waterfall_point_decoder_" + args.decoder] = r
+    del bw
     # one frame per call through the blocking host-buffer entry point (mgpu_rx_batch, F = 1): what a receive_byte
     # patched as in INTEGRATION.md §1.2 waits for, PCIe copies and launch overheads included
     for name, src in (("worst_case", bufs[0]), ("operating_point", bb)):
@@ -447,6 +573,10 @@ def run_pool(args):
         step(i)
     pool.enable_timing(True)
     hard0 = pool.decoder_hard_frames()
+    machines = [machine_of(d) for d in devices]
+    samplers = [ClockSampler(m["pci_bus_id"]) for m in machines] if not args.share_device else [ClockSampler(machines[0]["pci_bus_id"])]
+    for sm in samplers:              # one watcher per board: a clock sag under N boards' power must show next to roofline.frac
+        sm.start()
     iters_total = decoded_total = 0
     dev_ms = np.zeros(N)
     for g in range(N):
@@ -460,7 +590,14 @@ def run_pool(args):
     for g in range(N):
         torch.cuda.synchronize(devices[g])
     dt = time.perf_counter() - t0
+    clocks = [sm.summary() for sm in samplers]
     fe_ms, dec_ms, nl = pool.kernel_ms(0)
+    per_device = []
+    for g in range(N):
+        fe_g, dec_g, _ = pool.kernel_ms(g)
+        ck = clocks[0 if args.share_device else g] or {}
+        per_device.append({"device": devices[g], "sclk_mhz_median": ck.get("median", -1.0), "sclk_mhz_min": ck.get("min", -1.0), "power_w_median": ck.get("power_w_median", -1.0),
+                           "ldpc_kernel_ms": dec_g, "frontend_kernel_ms": fe_g, "wall_ms": float(dev_ms[g])})
     pool.enable_timing(False)
     hard_total = pool.decoder_hard_frames() - hard0        # frames decided without iterating: reported with max + 1 iterations, none executed
     iters_total -= hard_total * args.iters
@@ -468,7 +605,7 @@ def run_pool(args):
     iters_per_launch = iters_total / (args.steps * N)
     ldpc_bytes, _, b_iter = algorithmic_bytes(one, iters_per_launch, F)
     achieved = ldpc_bytes / (dec_ms * 1e-3)
-    machine = machine_of(devices[0])
+    machine = machines[0]
     mix, mix_src = profile_mix(args.decoder, headline_workload(args, F) and abs(iters_per_launch - 50.0 * F) <= 1e-6 * F)
     line = {
         "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (pool.K, args.iters)) if args.ldpc_only else
@@ -486,12 +623,14 @@ def run_pool(args):
                                   "shards, no collectives%s" % (N, " [all contexts on GPU 0: --share-device]" if args.share_device else "")},
         "ldpc_iters_per_s": iters_total / dt, "avg_iters_per_frame": iters_total / frames_total,
         "decoded_fraction": decoded_total / frames_total,
+        "hard_frames_per_step": hard_total / (args.steps * N),
         "kernel_ms": {"frontend": fe_ms, "ldpc": dec_ms, "launches_averaged": nl, "device": 0},
         "pool_device_ms_per_step": [float(x) / args.steps for x in dev_ms],
+        "per_device": per_device, "sclk_mhz_during_run": clocks[0], "machine": machine,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      "traffic": (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None, "traffic_source": mix_src,
                      "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
-                     "secondary": issue_view(mix, mix_src, dec_ms, machine),
+                     "secondary": issue_view(mix, mix_src, dec_ms, machine, clocks[0]),
                      "bytes_per_codeword_iteration": b_iter,
                      "note": "device 0's decoder launch; algorithmic bytes (SURVEY.md 8d: 16E+4N per codeword-iteration); messages are "
                              "LDS-resident so real HBM traffic is far lower; the decoders are bound by vector-instruction issue"},
@@ -509,7 +648,7 @@ def run_pool(args):
         line["cpu_baseline"] = cpu_baseline(args.cfg, args.iters, bb_h, flags, pay, st6)
         line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
     line["placement"] = {"devices": devices, "numa_nodes": pool.numa_nodes(), "worker_threads": "bound to their device's NUMA node (MERCURY_POOL_AFFINITY=0 to disable)"}
-    print(json.dumps(line), flush=True)
+    emit(line, args)
     pool.close()
     one.close()
 
@@ -532,9 +671,15 @@ def main():
     ap.add_argument("--ldpc-only", action="store_true",
                     help="BASELINE.json configs[4]: decoder-only soak on noise-only LLRs (every codeword runs --iters iterations)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary per-GPU measurements (min-sum, operating point)")
-    ap.add_argument("--no-live-pmc", action="store_true",
-                    help="do not take the two rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload for roofline.traffic (N = 1 only; quoted from the "
-                         "committed profile instead)")
+    ap.add_argument("--live-pmc", action="store_true",
+                    help="N = 1 only: take two rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload (child processes, ~5 s) and report them as "
+                         "roofline.traffic_live beside roofline.traffic (always the committed, stamped profile's figure)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="accepted for older command lines; the live passes are off unless --live-pmc")
+    ap.add_argument("--waterfall-esn0", type=float, default=None,
+                    help="Es/N0 of the waterfall_point record (default: the mode's threshold - %.1f dB)" % WATERFALL_BELOW_THRESHOLD_DB)
+    ap.add_argument("--line", choices=["compact", "full", "both"], default="both",
+                    help="stdout: 'both' (default) = the full record as one line, then the compact contract record (<= 4 KB) as the LAST line; "
+                         "'compact' / 'full' = only that one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--force-dist", action="store_true",
@@ -672,15 +817,11 @@ def main():
         # gfx950's wide coalesced reads. Quoted only when the profile's stamp matches the decoder build being timed.
         mix, mix_src = profile_mix(args.decoder, headline_workload(args, F) and abs(iters_per_launch - 50.0 * F) <= 1e-6 * F)
         traffic = (2.0 * mix["FETCH_SIZE"] + mix["WRITE_SIZE"]) * 1024.0 if mix else None
-        traffic_src, traffic_profile, fe_traffic = mix_src, traffic, None
-        if world == 1 and not args.no_extras and not args.no_live_pmc:
-            live = live_hbm_traffic(args)
-            if live:
-                for k, v in live.items():
-                    if "ldpc" in k:
-                        traffic, traffic_src = v, "this run, this box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one counter per pass, --kernel-trace only) of a 2-step run of this workload, kernel %s; (2 x FETCH_SIZE + WRITE_SIZE) KB" % k
-                    elif "frontend" in k:
-                        fe_traffic = v
+        traffic_live = None
+        if world == 1 and args.live_pmc:
+            traffic_live = live_hbm_traffic(args)              # {kernel name: HBM bytes per launch} or None (no rocprofv3, a pass failed / timed out)
+            if traffic_live is None:
+                print("bench.py: --live-pmc: the rocprofv3 counter passes did not complete; roofline.traffic_live is null", file=sys.stderr, flush=True)
         issue = issue_view(mix, mix_src, dec_ms, machine, sclk)
         line = {
             "metric": ("LDPC codewords/s (rate %d/1600, max %d iters)" % (rx.K, args.iters)) if args.ldpc_only else
@@ -700,15 +841,14 @@ def main():
             "ldpc_iters_per_s": iters_total / dt,
             "avg_iters_per_frame": iters_total / frames_total,
             "decoded_fraction": decoded_total / frames_total,
-            "hard_frames_per_step_rank0": hard_frames / args.steps,
+            "hard_frames_per_step": hard_frames / args.steps,
             "kernel_ms": {"frontend": fe_ms, "ldpc": dec_ms, "launches_averaged": nl},
             "sclk_mhz_during_run": sclk,
             "per_rank": [{"rank": r, "sclk_mhz_median": float(v[0]), "sclk_mhz_min": float(v[1]), "power_w_median": float(v[2]),
                           "ldpc_kernel_ms": float(v[3]), "frontend_kernel_ms": float(v[4]), "wall_ms": float(v[5])} for r, v in enumerate(per_rank)],
             "machine": machine,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_committed_profile": traffic_profile, "traffic_frontend_kernel": fe_traffic,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": mix_src, "traffic_live": traffic_live,
                          "kernel": "mgpu_ldpc_%s_kernel" % args.decoder,
                          "secondary": issue,
                          "bytes_per_codeword_iteration": b_iter,
@@ -729,6 +869,14 @@ def main():
                                            "avg_iters_per_frame": opr["avg_iters"], "ldpc_iters_per_s": opr["avg_iters"] * opr["frames_per_s"],
                                            "decoded_fraction": opr["decoded_fraction"], "kernel_ms": {"frontend": opr["frontend_ms"], "ldpc": opr["ldpc_ms"]},
                                            "decoder": args.decoder, "roofline": opr["roofline"]}
+            wfr = line["extras_per_gpu"].get("waterfall_point_decoder_" + args.decoder)
+            if wfr:
+                line["waterfall_point"] = {"metric": "RX frames/s (mode %d at Es/N0 %+.1f dB: just below the threshold, %.0f %% of the frames run all %d iterations)"
+                                                     % (args.cfg, wfr["esn0_db"], 100.0 * wfr["frames_running_all_iters"], args.iters),
+                                           "value": wfr["frames_per_s"], "unit": "frames/s", "ms_per_step": wfr["ms_per_step"], "esn0_db": wfr["esn0_db"],
+                                           "avg_iters_per_frame": wfr["avg_iters"], "frames_running_all_iters": wfr["frames_running_all_iters"],
+                                           "ldpc_iters_per_s": wfr["avg_iters"] * wfr["frames_per_s"], "decoded_fraction": wfr["decoded_fraction"],
+                                           "kernel_ms": {"frontend": wfr["frontend_ms"], "ldpc": wfr["ldpc_ms"]}, "decoder": args.decoder, "roofline": wfr["roofline"]}
         if world == 1 and not args.no_cpu_baseline and not args.ldpc_only:
             cores = usable_cores()
             S = min(F, args.cpu_sample_per_core * cores)
@@ -762,7 +910,7 @@ def main():
             pin[...] = bb_all
             line["pcie_inclusive_pinned_frames_per_s"], _ = median_rate(pin)
             line["pcie_bound_frames_per_s_at_55GBps"] = 55e9 / (rx.frame_samples * 16)
-        print(json.dumps(line), flush=True)
+        emit(line, args)
     if collective:
         dist.destroy_process_group()
 

@@ -662,8 +662,12 @@ def test_bench_two_ranks_on_one_gpu():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    j = json.loads(lines[0])
+    assert len(lines) == 2, r.stdout                # the full record, then the compact contract record as the LAST line
+    j, c = json.loads(lines[0]), json.loads(lines[1])
+    assert j["bench_full_record"] and r.stdout.rstrip().endswith(lines[1]) and len(lines[1]) <= 4096
+    assert c["n_gpus"] == 2 and c["scaling"] == "weak" and c["unit"] == "frames/s" and c["steps"] == 2 and c["warmup"] == 1
+    assert abs(c["value"] / j["value"] - 1) < 1e-5 and c["roofline"]["bound"] == "hbm" and 0 < c["roofline"]["frac"] < 1
+    assert len(c["per_device"]) == 2 and all(row[3] > 0 and row[5] > 0 for row in c["per_device"])      # clock / power / kernel ms / wall ms of every rank
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["unit"] == "frames/s"
     assert j["decoded_fraction"] > 0.97            # both ranks' frames decode (disjoint frame ranges, same seed)
     assert abs(j["value"] - 2 * 256 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-6 * j["value"]
@@ -691,6 +695,8 @@ def test_bench_collective_path_over_rccl_and_two_ranks_share_one_gpu_fairly():
         assert len(ls) == 1, r.stdout
         return json.loads(ls[0])
 
+    common += ["--line", "full"]
+
     one = line([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl"] + common,
                env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
     assert one["n_gpus"] == 1 and one["avg_iters_per_frame"] == 50.0 and one["machine"]["compute_units"] == 256
@@ -715,8 +721,10 @@ def test_bench_pool_two_contexts_on_one_gpu():
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        assert len(lines) == 1, r.stdout
-        j = json.loads(lines[0])
+        assert len(lines) == 2, r.stdout                 # full record, then the compact contract record (the last line)
+        j, c = json.loads(lines[0]), json.loads(lines[1])
+        assert len(lines[1]) <= 4096 and abs(c["value"] / j["value"] - 1) < 1e-5 and c["n_gpus"] == 2 and len(c["per_device"]) == 2
+        assert "hard_frames_per_step" in c and all(row[3] > 0 for row in c["per_device"])
         assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["unit"] == "frames/s" and j["config"]["parallelism"].startswith("pool x2")
         assert abs(j["value"] - 2 * 256 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-6 * j["value"]
         assert "roofline" in j and len(j["pool_device_ms_per_step"]) == 2
@@ -729,8 +737,8 @@ def test_bench_pool_two_contexts_on_one_gpu():
            "--esn0", "2.5", "--cpu-sample-per-core", "4"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert j["cpu_baseline"]["gpu_vs_cpu_mismatches"] == 0 and j["n_gpus"] == 1
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])        # the compact record carries the CPU leg
+    assert j["cpu_baseline"]["gpu_vs_cpu_mismatches"] == 0 and j["n_gpus"] == 1 and j["cpu_baseline"]["kind"] == "port"
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 12])

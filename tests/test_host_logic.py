@@ -1,5 +1,6 @@
 """CPU tests of the host logic around the kernels: frame sharding (single process and a 2-rank gloo
 world), the byte model used by bench.py, and the build recipe."""
+import json
 import os
 import sys
 
@@ -74,6 +75,46 @@ def test_algorithmic_byte_model_matches_survey():
     rx8 = types.SimpleNamespace(Nsymb=24, Nofdm=272, E=6049, N=1600, payload_stride=100)
     assert bench.algorithmic_bytes(rx8, 50, 1)[2] == 103184  # rate 8/16
     assert bench.usable_cores() >= 1
+
+
+def test_bench_contract_line_is_compact_whatever_the_full_record_holds(capsys):
+    """round 5's 20 KB bench line was cut by the driver's stdout tail (BENCH_r05.parsed = null). The contract record is
+    now built from the full record by bench.compact_line and is the LAST stdout line: at most 4096 bytes, valid JSON, with every contract
+    key, `roofline` and `cpu_baseline` - from canned inputs: round 5's committed 20 KB line, the same with an 8-rank block, and with every
+    optional block blown up."""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import copy
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_spa_cfg8.json")))
+    assert len(json.dumps(full)) > 16000                     # the record that broke the driver's parse
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+    big = copy.deepcopy(full)
+    big["n_gpus"] = 8
+    big["per_rank"] = [dict(full["per_rank"][0], rank=r) for r in range(8)]
+    big["waterfall_point"] = copy.deepcopy(full["operating_point"])
+    huge = copy.deepcopy(big)
+    huge["config"]["workload"] *= 3
+    huge["cpu_baseline"]["sample"] *= 8
+    huge["extras_per_gpu"]["junk"] = ["x" * 100] * 1000
+    for rec in (full, big, huge):
+        c = bench.compact_line(rec)
+        text = json.dumps(c)
+        assert len(text) <= bench.COMPACT_LIMIT == 4096, len(text)
+        back = json.loads(text)
+        assert all(k in back for k in contract) and back["config"]["workload"]
+        assert abs(back["value"] / rec["value"] - 1) < 1e-6 and back["steps"] == rec["steps"] and back["warmup"] == rec["warmup"] and back["n_gpus"] == rec["n_gpus"]
+        rf = back["roofline"]
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 and "traffic" in rf
+        assert rf["secondary"]["bound"] == "valu_issue" and set(rf["secondary"]) == {"bound", "frac"}      # the issue-bound reading lives only there
+        cb = back["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["gpu_vs_cpu_mismatches"] == 0 and cb["reference_1core_frames_per_s"] > 0
+    c = bench.compact_line(big)
+    assert len(c["per_device"]) == 8 and c["operating_point"]["kernel_ms"]["ldpc"] > 0 and c["waterfall_point"]["value"] > 0
+    # emit(): the compact record is the last line on stdout, the full one comes before it
+    bench.emit(full, argparse.Namespace(line="both"))
+    out = [l for l in capsys.readouterr().out.splitlines() if l]
+    assert len(out) == 2 and json.loads(out[0])["bench_full_record"] and json.loads(out[1]) == bench.compact_line(full) and len(out[1]) <= 4096
 
 
 def test_table_blob_is_wellformed():

@@ -7,10 +7,12 @@
 #                                        receive_byte chain, host-buffer path, transmit chain
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-R=${R:-r05}
+R=${R:-r06}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# bench.py prints the full record and then the compact contract record (the last line): <name>_full.json and <name>.json
+bench_pair() { local name=$1; shift; python "$ROOT/bench.py" "$@" 2>/dev/null > "$OUT/.pair"; head -1 "$OUT/.pair" > "$OUT/${name}_full.json"; tail -1 "$OUT/.pair" > "$OUT/${name}.json"; rm -f "$OUT/.pair"; }
 [ -x "$ROOT/tools/ubench/valu_cycles" ] || hipcc --offload-arch=gfx950 -O2 -o "$ROOT/tools/ubench/valu_cycles" "$ROOT/tools/ubench/valu_cycles.hip"
 "$ROOT/tools/ubench/valu_cycles" > "$OUT/${R}_valu_cycles.json"
 cp "$OUT/${R}_valu_cycles.json" "$ROOT/profiles/${R}_valu_cycles.json"       # where bench.py looks for the opcode costs
@@ -27,6 +29,10 @@ OPES=${OPES:-3.5}
 for d in spa spa_fast minsum; do
   "$ROOT/tools/collect_pmc_mix.sh" $d "$OUT/pmc_mix_${d}_op.json" --esn0 $OPES > /dev/null 2> "$OUT/pmc_mix_${d}_op.err" || true
 done
+# the waterfall launch (mode 8 just below its threshold: every frame runs all 50 iterations on LLRs of real magnitude) too
+WFES=${WFES:--1.0}
+"$ROOT/tools/collect_pmc_mix.sh" spa "$OUT/pmc_mix_spa_wf.json" --esn0 $WFES > /dev/null 2> "$OUT/pmc_mix_spa_wf.err" || true
+"$ROOT/tools/collect_pmc_mix.sh" spa "$OUT/pmc_mix_spa_cfg16_13db.json" --cfg 16 --variant baseband_test --esn0 13 > /dev/null 2> "$OUT/pmc_mix_spa_cfg16_13db.err" || true
 python - "$OUT" "$ROOT" "$R" <<'PY'
 import json, sys, os
 out, root, R = sys.argv[1:4]
@@ -51,16 +57,20 @@ for d in ("spa", "spa_fast", "minsum"):
                 mix[d + "_op"] = dict(v, kernel=k, workload="mode 8 at Es/N0 3.5 dB (operating point)")
             elif "frontend" in k:
                 mix["frontend_op"] = dict(v, kernel=k)
-f = os.path.join(out, "pmc_mix_spa_cfg16.json")
-if os.path.exists(f):
-    for k, v in json.load(open(f)).items():
-        if "ldpc" in k:
-            mix["spa_cfg16"] = dict(v, kernel=k)
+for key, name, wl in (("spa_cfg16", "pmc_mix_spa_cfg16.json", "mode 16 baseband_test at -15 dB"), ("spa_cfg16_13db", "pmc_mix_spa_cfg16_13db.json", "mode 16 baseband_test at 13 dB"),
+                      ("spa_wf", "pmc_mix_spa_wf.json", "mode 8 just below its threshold (waterfall_point)")):
+    f = os.path.join(out, name)
+    if os.path.exists(f):
+        for k, v in json.load(open(f)).items():
+            if "ldpc" in k:
+                mix[key] = dict(v, kernel=k, workload=wl)
+            elif "frontend" in k and key == "spa_wf":
+                mix["frontend_wf"] = dict(v, kernel=k)
 json.dump(mix, open(os.path.join(out, "%s_instruction_mix.json" % R), "w"), indent=1)
 json.dump(mix, open(os.path.join(root, "profiles", "%s_instruction_mix.json" % R), "w"), indent=1)     # where bench.py looks for it
 PY
 for d in spa spa_fast minsum; do
-  python "$ROOT/bench.py" --decoder $d > "$OUT/${R}_bench_${d}_cfg8.json" 2>/dev/null
+  bench_pair ${R}_bench_${d}_cfg8 --decoder $d
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$d" -- python "$ROOT/bench.py" --decoder $d --no-cpu-baseline --no-extras > /dev/null 2>&1
   cp "$(find "$OUT/prof_$d" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_bench_${d}_cfg8_kernel_stats.csv"
   rm -rf "$OUT/prof_$d"
@@ -74,13 +84,19 @@ cp "$(find "$OUT/prof_op" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_op_sp
       MERCURY_GPU_LIB=$ROOT/mercury_amd/_variants/lib_stamps.so python tools/spa_stamps.py $1 8 4096 $2 2>/dev/null | grep -v "^{" > "$OUT/${R}_decoder_phases_${1}_es${2}.txt"
     done
   fi )
-# the high-degree graph (rate 14/16: modes 12, 14, 15, 16; BASELINE.json configs[3])
-python "$ROOT/bench.py" --cfg 16 --variant baseband_test --no-extras > "$OUT/${R}_bench_spa_cfg16.json" 2>/dev/null
+# the waterfall point: kernel stats of the launch bench.py reports as `waterfall_point`
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_wf" -- python "$ROOT/bench.py" --esn0 $WFES --no-cpu-baseline --no-extras --steps 30 > /dev/null 2>&1
+cp "$(find "$OUT/prof_wf" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_wf_spa_cfg8_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/prof_wf"
+# the high-degree graph (rate 14/16: modes 12, 14, 15, 16; BASELINE.json configs[3]), in noise and at 13 dB (50 iterations both, LLRs of real magnitude at 13 dB)
+python "$ROOT/bench.py" --cfg 16 --variant baseband_test --no-extras --line compact > "$OUT/${R}_bench_spa_cfg16.json" 2>/dev/null
+python "$ROOT/bench.py" --cfg 16 --variant baseband_test --esn0 13 --no-extras --no-cpu-baseline --line compact > "$OUT/${R}_bench_spa_cfg16_13db.json" 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_16b" -- python "$ROOT/bench.py" --cfg 16 --variant baseband_test --esn0 13 --no-cpu-baseline --no-extras > /dev/null 2>&1
+cp "$(find "$OUT/prof_16b" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_bench_spa_cfg16_13db_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/prof_16b"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_16" -- python "$ROOT/bench.py" --cfg 16 --variant baseband_test --no-cpu-baseline --no-extras > /dev/null 2>&1
 cp "$(find "$OUT/prof_16" -name '*kernel_stats.csv' | head -1)" "$OUT/${R}_bench_spa_cfg16_kernel_stats.csv"
 rm -rf "$OUT/prof_16"
-python "$ROOT/bench.py" --cfg 16 --variant baseband_test --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_fast_cfg16.json" 2>/dev/null
-python "$ROOT/bench.py" --gpus 1 --pool --no-extras > "$OUT/${R}_bench_spa_cfg8_pool.json" 2>/dev/null
+python "$ROOT/bench.py" --cfg 16 --variant baseband_test --decoder spa_fast --no-cpu-baseline --no-extras --line compact > "$OUT/${R}_bench_spa_fast_cfg16.json" 2>/dev/null
+python "$ROOT/bench.py" --gpus 1 --pool --no-extras --line compact > "$OUT/${R}_bench_spa_cfg8_pool.json" 2>/dev/null
 if [ "$1" = "sweep" ]; then
   cd "$ROOT"
   python tools/compare_decoders.py 4096 > "$OUT/${R}_compare_decoders.json" 2> "$OUT/${R}_compare_decoders.txt"
@@ -96,9 +112,9 @@ if [ "$1" = "sweep" ]; then
   tools/pmc_any.sh p2b_slide_d1_kernel "$OUT/${R}_pmc_p2b.json" -- python tools/bench_sync.py > /dev/null 2>&1 || true
   tools/pmc_any.sh tsync_metric_stream "$OUT/${R}_pmc_tsync_stream.json" -- python tools/bench_tsync_variants.py 1024 > /dev/null 2>&1 || true
   tools/pmc_any.sh mfsk_frontend "$OUT/${R}_pmc_mfsk_frontend.json" -- python bench.py --cfg 100 --decoder spa_fast --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frames 2048 > /dev/null 2>&1 || true
-  python bench.py --cfg 100 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_fast_cfg100.json" 2>/dev/null
-  python bench.py --cfg 0 --decoder spa_fast --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_fast_cfg0.json" 2>/dev/null
-  python bench.py --cfg 0 --decoder spa --no-cpu-baseline --no-extras > "$OUT/${R}_bench_spa_cfg0.json" 2>/dev/null
+  python bench.py --cfg 100 --decoder spa_fast --no-cpu-baseline --no-extras --line compact > "$OUT/${R}_bench_spa_fast_cfg100.json" 2>/dev/null
+  python bench.py --cfg 0 --decoder spa_fast --no-cpu-baseline --no-extras --line compact > "$OUT/${R}_bench_spa_fast_cfg0.json" 2>/dev/null
+  python bench.py --cfg 0 --decoder spa --no-cpu-baseline --no-extras --line compact > "$OUT/${R}_bench_spa_cfg0.json" 2>/dev/null
   # BASELINE.json configs[4] on one GPU: decoder-only, rate 8/16 (mode 13's code), noise-only LLRs so that every codeword runs all its iterations
   : > "$OUT/${R}_bench_ldpc_only_rate8.jsonl"
   for dec in spa spa_fast minsum; do for it in 5 20 50; do
@@ -107,7 +123,7 @@ if [ "$1" = "sweep" ]; then
 fi
 # which of fdlibm's case branches the decoder's wavefronts enter (variant build: tools/build_variants.sh census:"-DSPA_CENSUS_ON=1")
 if [ -f "$ROOT/mercury_amd/_variants/lib_census.so" ]; then
-  ( cd "$ROOT"; for a in "8 1024 -15" "8 1024 3.5" "16 512 -15" "16 512 -15 baseband" "14 512 -15" "16 512 13 baseband" "0 512 -15" "11 512 -15"; do
+  ( cd "$ROOT"; for a in "8 1024 -15" "8 1024 -1" "8 1024 3.5" "16 512 -15" "16 512 -15 baseband" "14 512 -15" "16 512 13 baseband" "0 512 -15" "11 512 -15"; do
       MERCURY_GPU_LIB=$ROOT/mercury_amd/_variants/lib_census.so python tools/spa_census.py $a 2>/dev/null | tail -25; done > "$OUT/${R}_spa_branch_census.txt" )
 fi
 ls -la "$OUT"

@@ -33,7 +33,14 @@ def main():
         for dec in ("spa", "spa_fast", "minsum"):
             m[dec + "_50iters"] = run(cfg, dec, -25.0 if cfg >= 100 else -15.0, frames)
             m[dec + "_operating"] = run(cfg, dec, OPERATING_ESN0[cfg] + 1.0, frames)
+        # just below the mode's threshold (bench.py's waterfall_point: threshold - 1.5 dB; mode 16: the 13 dB VERDICT r05 quotes): all 50 iterations on LLRs
+        # of real magnitude - the lanes spread over all of fdlibm's cases, which the noise-only -15 dB point does not show
+        if cfg < 100:
+            m["spa_waterfall"] = run(cfg, "spa", 13.0 if cfg == 16 else OPERATING_ESN0[cfg] - 3.5, frames)
         res["modes"][str(cfg)] = m
+        if "spa_waterfall" in m:
+            w = m["spa_waterfall"]
+            print("cfg %3d  spa@waterfall %9.0f f/s  ldpc %.3f ms  %.2f it  roofline.frac %.3f" % (cfg, w["frames_per_s"], w["ldpc_ms"], w["avg_iters"], w["roofline_frac"]), file=sys.stderr)
         print("cfg %3d  spa@50 %9.0f f/s (%.3f)  spa_fast@50 %9.0f f/s (%.3f)  minsum@50 %9.0f f/s  spa@op %9.0f f/s (%.1f it, %.3f ok)  spa_fast@op %9.0f f/s (%.3f ok)  minsum@op %9.0f f/s (%.3f ok)" % (
             cfg, m["spa_50iters"]["frames_per_s"], m["spa_50iters"]["roofline_frac"], m["spa_fast_50iters"]["frames_per_s"], m["spa_fast_50iters"]["roofline_frac"],
             m["minsum_50iters"]["frames_per_s"], m["spa_operating"]["frames_per_s"],
