@@ -35,6 +35,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("MERCURY_GOLDEN_OUT", HERE)     # tests/test_oracle_golden.py regenerates into a scratch directory and compares with the committed files
 sys.path.insert(0, os.path.dirname(HERE))
 import oraclelib  # noqa: E402
 from conftest import OPERATING_ESN0, SEED  # noqa: E402
@@ -86,8 +87,8 @@ def main():
         m["frames"] = frames
         meta["modes"][str(cfg)] = m
         print("cfg", cfg, "done")
-    np.savez_compressed(os.path.join(HERE, "golden_rx.npz"), **arrays)
-    with open(os.path.join(HERE, "golden_rx.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "golden_rx.npz"), **arrays)
+    with open(os.path.join(OUT, "golden_rx.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote golden_rx.npz (%d arrays), golden_rx.json" % len(arrays))
 
@@ -127,8 +128,8 @@ def main_mfsk():
         m["frames"] = frames
         meta["modes"][str(cfg)] = m
         print("cfg", cfg, "done")
-    np.savez_compressed(os.path.join(HERE, "golden_mfsk.npz"), **arrays)
-    with open(os.path.join(HERE, "golden_mfsk.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "golden_mfsk.npz"), **arrays)
+    with open(os.path.join(OUT, "golden_mfsk.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote golden_mfsk.npz (%d arrays), golden_mfsk.json" % len(arrays))
 
@@ -225,7 +226,7 @@ def tx_case(lib, cfg):
 def main_tx():
     assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
     meta = {str(cfg): tx_case(oraclelib.RefLib(cfg), cfg) for cfg in TX_CFGS}
-    with open(os.path.join(HERE, "golden_tx.json"), "w") as f:
+    with open(os.path.join(OUT, "golden_tx.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote golden_tx.json")
 
@@ -233,7 +234,7 @@ def main_tx():
 def main_sync():
     assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
     meta = {str(cfg): sync_case(oraclelib.RefLib(cfg), cfg) for cfg in (8, 10, 16, 100, 101)}
-    with open(os.path.join(HERE, "golden_sync.json"), "w") as f:
+    with open(os.path.join(OUT, "golden_sync.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote golden_sync.json")
 
@@ -274,7 +275,7 @@ def explicit_case(lib, cfg, x, idx):
 def main_explicit():
     assert oraclelib.RefLib.available(), "build oracle/_ref first (make -C oracle ref)"
     out = [explicit_case(oraclelib.RefLib, cfg, x, i) for i, (cfg, x) in enumerate(EXPLICIT_CASES)]
-    with open(os.path.join(HERE, "golden_explicit.json"), "w") as f:
+    with open(os.path.join(OUT, "golden_explicit.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote golden_explicit.json")
 

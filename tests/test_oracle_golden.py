@@ -182,3 +182,28 @@ def test_explicit_parameter_sets_match_reference_vectors():
     for i, (cfg, x) in enumerate(mg.EXPLICIT_CASES):
         got = json.loads(json.dumps(mg.explicit_case(oraclelib.Oracle, cfg, x, i), sort_keys=True))
         assert got == want[i], (cfg, [k for k in got if got[k] != want[i].get(k)])
+
+
+@pytest.mark.skipif(not oraclelib.RefLib.available(), reason="needs oracle/_ref (the compiled reference: build container only)")
+def test_committed_fixtures_are_what_the_generator_writes_today(tmp_path):
+    """VERDICT r05 housekeeping: tests/golden/make_golden.py, run against the compiled reference, must reproduce every committed fixture - the
+    JSON documents key for key, the .npz archives array for array (dtype and bits) - so that the script and the files cannot drift apart
+    (round 5's golden_rx.json lacked four info keys the script had learned to write). Runs where oracle/_ref exists; ~20 s."""
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    env = dict(os.environ, MERCURY_GOLDEN_OUT=str(tmp_path))
+    for flag in ([], ["--mfsk"], ["--tx"], ["--sync"], ["--explicit"]):
+        r = subprocess.run([sys.executable, os.path.join(here, "make_golden.py")] + flag, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    made = sorted(os.listdir(tmp_path))
+    assert made == ["golden_explicit.json", "golden_mfsk.json", "golden_mfsk.npz", "golden_rx.json", "golden_rx.npz", "golden_sync.json", "golden_tx.json"]
+    for name in made:
+        new, old = os.path.join(tmp_path, name), os.path.join(here, name)
+        if name.endswith(".json"):
+            assert json.load(open(new)) == json.load(open(old)), name
+        else:
+            a, b = np.load(new), np.load(old)
+            assert sorted(a.files) == sorted(b.files), name
+            for k in a.files:
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), (name, k)
