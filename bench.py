@@ -132,6 +132,8 @@ def profile_mix(key, workload_ok=True):
         prof = json.load(open(os.path.join(ROOT, name)))
         if prof.get("decoder_digest") != decoder_digest():
             return None, "%s was taken from another build of the decoder kernels (stamp %s, library %s)" % (name, prof.get("decoder_digest"), decoder_digest())
+        if key not in prof:
+            return None, "%s holds no PMC passes of this workload (%s)" % (name, key)
         return prof[key], "%s[%s] (PMC, same workload, same decoder build %s)" % (name, key, prof["decoder_digest"])
     except Exception as e:
         return None, "profile unreadable: %r" % (e,)

@@ -218,7 +218,8 @@ int mgpu_host_layout_stats(int cfg, double out[4]);
  * branch-boundary sets of tests/test_spa_math.py / tests/test_glibc_trig.py plus a fixed pseudo-random sample and reports, per function
  * (index 0 tanh(0.5 q), 1 2 atanh(x), 2 atan, 3 sincos), how many arguments were evaluated and how many results differed in any bit.
  * Returns the number of functions that differ (0: a reference built on this host computes what the device computes). The result is
- * cached; mgpu_create runs it once per process and writes one line to stderr if anything differs (MERCURY_GPU_LIBM_CHECK=0 disables that). */
+ * cached (the first call takes 60-90 ms: about a million libm calls). Opt-in at create time: with MERCURY_GPU_LIBM_CHECK=1 in the environment the
+ * process's first mgpu_create runs it and writes one line to stderr if anything differs; by default mgpu_create does not run it. */
 typedef struct mgpu_libm_report {
     long long evaluated[4], differed[4];
     double first_differing_argument[4];

@@ -468,7 +468,7 @@ extern "C" void mgpu_internal_libm_notice();     // libm_check.cpp
 int mgpu_create_explicit(const mgpu_config* cfg, const mgpu_explicit_params* xp_in, mgpu_ctx** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return MGPU_ERR_ARG; }
     *out = nullptr;
-    mgpu_internal_libm_notice();                 // once per process: is the host's libm the one the device restates? (stderr only if not)
+    mgpu_internal_libm_notice();                 // only with MERCURY_GPU_LIBM_CHECK=1: is the host's libm the one the device restates? (once per process; stderr only if not)
     mgpu::ExplicitParams xp;
     if (xp_in) {
         // the kernels are specialised for the reference's carrier geometry and pilot lattice: those fields only confirm it

@@ -43,6 +43,19 @@ struct MgpuDev {
     double mfsk_amp;
 };
 
+// The fp64 decoder's hard-frame shortcut (ldpc.hip: every |LLR| >= kSpaHardLlr -> the iterations are skipped) rests on three facts that are set
+// in three places; they are tied together HERE so that changing one without the others does not compile:
+//   * a variable has at most kSpaMaxVarDegree edges (tables.cpp refuses a graph with more: the unrolled variable update handles 9, and so does this);
+//   * |R| <= kSpaClampR: the decoder clamps a product of +-1 to +-0.9999999 (ldpc_decoder_SPA.cc:150-156), 2 atanh(0.9999999) = 16.8114 (spa_math.h);
+//   * tanh(Q/2) is +-1 exactly from |Q| = 44 on (s_tanh.c's |x| >= 22 answer).
+// With them |Q| = |LLR + sum of the other R| >= kSpaHardLlr - kSpaMaxVarDegree * kSpaClampR >= 44 in every iteration: T = sign(LLR) for ever.
+constexpr int kSpaMaxVarDegree = 9;
+constexpr float kSpaHardLlr = 200.0f;
+constexpr double kSpaClampR = 16.82;
+constexpr double kSpaTanhSaturates = 44.0;
+static_assert(double(kSpaHardLlr) - kSpaMaxVarDegree * kSpaClampR >= kSpaTanhSaturates,
+              "hard-frame shortcut: |LLR| >= kSpaHardLlr no longer keeps every Q in tanh's saturated range - raise kSpaHardLlr or lower the degree limit");
+
 // Slim argument block for the decoder kernels: only what they touch, so the kernarg does not
 // inflate the SGPR allocation (occupancy on gfx950 drops below 8 waves/SIMD above 80 SGPRs).
 struct LdpcDev {

@@ -258,7 +258,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         const float l = lin[v];
         Li[v] = l;
         Lt[v] = spa_tanh_half(double(l));
-        hard_lane &= int(__builtin_fabsf(l) >= 200.0f);          // false for a NaN
+        hard_lane &= int(__builtin_fabsf(l) >= kSpaHardLlr);     // false for a NaN (device_tables.h ties the threshold to the degree limit and the clamp)
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     struct VarRec { uint32_t vi, w0, w1, w2, w3, w4; };

@@ -1,5 +1,6 @@
 // Host-side table construction for the Mercury RX kernels — see tables.hpp for the reference map.
 #include "tables.hpp"
+#include "device_tables.h"      // kSpaMaxVarDegree: the degree bound the fp64 decoder is built (and its hard-frame shortcut proved) with
 
 #include <algorithm>
 #include <complex>
@@ -188,7 +189,7 @@ static LdpcGraph load_graph_uncached(int K, const uint8_t* blob, size_t size) {
         g.vinfo.assign(size_t(N) * 8, 0u);   // per variable: v | deg<<11, then 10 u16 slot indices in 5 words; rows of 8 words (16-byte aligned)
         for (uint32_t i = 0; i < N; ++i) {
             const uint32_t v = vorder[i], d = vdeg[v];
-            if (d > 9) throw std::runtime_error("variable degree exceeds the unrolled update");
+            if (d > uint32_t(kSpaMaxVarDegree)) throw std::runtime_error("variable degree exceeds the unrolled update (and the bound the fp64 decoder's hard-frame shortcut is proved with: device_tables.h kSpaMaxVarDegree)");
             if (i >= 1024 && d > 4) g.fp64_limit = "variable degrees exceed the fp64 decoder's register layout (rows from 1024 on: at most 4 edges)";
             g.vinfo[size_t(i) * 8] = v | (d << 11);
             for (uint32_t j = 0; j < d; ++j) {

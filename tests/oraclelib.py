@@ -26,6 +26,25 @@ INFO_FIELDS = ("cfg M bits_per_symbol K P N Nsymb Nc Nfft Ngi Nofdm nData nBits 
                "mfsk_M mfsk_nStreams active_nsymb active_nbits").split()
 
 
+def ldpc_graph(K):
+    """The Tanner graph of the rate-K/1600 code from the committed table blob (mercury_amd/data/mercury_ldpc_tables.bin, written from the
+    compiled reference by oracle/gen_ldpc_tables.py): (checks, variables) = the variables of every check in row order, the checks of every variable."""
+    import struct
+    blob = open(TABLES, "rb").read()
+    _, _, n = struct.unpack_from("<4sII", blob, 0)
+    off = 12
+    for _ in range(n):
+        k, P, N, E, _, _ = struct.unpack_from("<6I", blob, off)
+        off += 24
+        cdeg = np.frombuffer(blob, "u1", P, off); off += P
+        Cf = np.frombuffer(blob, "<u2", E, off); off += 2 * E
+        vdeg = np.frombuffer(blob, "u1", N, off); off += N
+        Vf = np.frombuffer(blob, "<u2", E, off); off += 2 * E
+        if k == K:
+            return np.split(Cf.astype(int), np.cumsum(cdeg)[:-1]), np.split(Vf.astype(int), np.cumsum(vdeg)[:-1])
+    raise KeyError(K)
+
+
 class Info(C.Structure):
     _fields_ = [(n, C.c_int) for n in INFO_FIELDS]
 

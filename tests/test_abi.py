@@ -134,3 +134,11 @@ def test_fp64_decoder_kernels_compile_without_register_spills():
         assert int(re.search(r"; ScratchSize: (\d+)", foot).group(1)) == 0, (kern, "spills")
         assert int(re.search(r"; NumVgprs: (\d+)", foot).group(1)) <= 64, kern
         assert not any("scratch_" in l for l in lines[start:end]), kern
+        # the product walk's LDS reads must stay single ds_read_b64 (the compiler pairs them into ds_read2_b64 unless told not to, and the
+        # LDS pipeline takes 8 cycles for one of those against 2 x 2.2: profiles/r05_lds_mask.json; rate 14/16 9.15 -> 8.19 ms). A toolchain that
+        # starts pairing them again fails HERE rather than silently costing 10 %.
+        body = [l.split()[0] for l in lines[start:end] if l.strip() and not l.strip().startswith((";", ".", "//")) and not l.rstrip().endswith(":")]
+        # (two ds_read2_b64 exist outside the walk, in the start-up / epilogue code; the two copies of the bin loop - first pass, steady state -
+        # carry one read per unrolled walk step each: 2 x 16, at rate 14/16 2 x 48)
+        assert body.count("ds_read2_b64") <= 2 and body.count("ds_read2st64_b64") == 0, (kern, "the walk's LDS reads were paired", body.count("ds_read2_b64"))
+        assert body.count("ds_read_b64") >= 2 * (48 if ne == 8 else 16), (kern, body.count("ds_read_b64"))

@@ -261,10 +261,23 @@ def test_hard_frames_are_decided_without_iterating_and_counted(cfg):
     words[9] = np.float32(np.inf)
     words[7, orc.N - 3] = np.float32(150.0)                               # not hard: iterates (and still cannot change a bit)
     words[6, rng.integers(0, orc.N, 40)] = np.float32(0.5)                # not hard either, and these bits CAN change
+    # The shortcut's bound at its edge: every |LLR| EXACTLY the threshold 200, and the variable of highest degree (9 in these codes:
+    # device_tables.h kSpaMaxVarDegree) attacked on every edge - one sign error among the other members of each of its checks, so all its incoming
+    # messages are -16.81 against its +200: |Q| = 200 - 8 x 16.81 = 65.5 on its edges, still inside tanh's saturated range, no bit may change.
+    checks, variables = oraclelib.ldpc_graph(orc.K)
+    v_star = int(np.argmax([len(c) for c in variables]))
+    assert len(variables[v_star]) == max(len(c) for c in variables) <= 9
+    words[2] = np.float32(200.0)
+    mine, taken = set(int(c) for c in variables[v_star]), set()
+    for c in variables[v_star]:
+        u = next(int(u) for u in checks[c] if u != v_star and u not in taken and not (set(int(x) for x in variables[u]) - {int(c)}) & mine)
+        taken.add(u)
+        words[2, u] = np.float32(-200.0)
     rx = _rx(cfg, max_iters=50, max_batch=len(words))
     before = rx.decoder_hard_frames()
     bits, iters = rx.ldpc_decode(words)
     assert rx.decoder_hard_frames() - before == 6
+    assert bits[2].sum() == sum(u < orc.K for u in taken) and v_star < orc.K and bits[2][v_star] == 0      # the attacked variable and everybody else kept their signs (information positions)
     for w in range(len(words)):
         rb, ri = orc.ldpc_decode(words[w])
         assert iters[w] == ri and np.array_equal(bits[w], rb.astype(np.uint8)), (cfg, w, iters[w], ri)
