@@ -143,6 +143,9 @@ struct Loop {
         ws.pin_off = 0;
         d_ia.view = d_ib.view = d_ic.view = d_carrier.view = nullptr;
     }
+    // Nothing of a call may outlive it: when the call ends - by return or by an exception unwinding it - with slots of the staging ring handed
+    // out and no settle() since, the stream is drained before the ring can be reset by the next call (the error path skipped the wait).
+    ~Loop() { if (unsettled) (void)hipStreamSynchronize(s); }
     const bool zero_copy = []{ const char* e = std::getenv("MERCURY_RB_ZEROCOPY"); return !e || atoi(e) != 0; }();
 
     bool in_bounds(int p) const { return p > lower && p < upper; }
@@ -154,8 +157,12 @@ struct Loop {
     // INVARIANT: a buffer with a view may only be consumed by kernels launched on stream `s` — settle() waits for `s` alone, so a kernel on
     // the side stream reading a view could still be running when its slot is handed out again. The side stream's kernels (signal level,
     // upload slices) take device buffers only; keep it that way or give them their own settle().
+    // true from the first staging slot handed out / copy queued until settle() has waited for the stream: while it is set, kernels in flight may
+    // still read this call's slots of the staging ring, and the call must not return (receive_byte_impl's Drain).
+    bool unsettled = false;
     void up(DevBuf& d, const void* h, size_t bytes) {
         d.view = nullptr;
+        unsettled = true;
         if (void* p = ws.pin_take(bytes)) {
             std::memcpy(p, h, bytes);
             if (zero_copy) { d.view = p; return; }
@@ -165,6 +172,7 @@ struct Loop {
     }
     // device -> host without waiting: the bytes are in h after the next down() / settle()
     void down_async(void* h, const void* d_src, size_t bytes) {
+        unsettled = true;
         if (void* p = ws.pin_take(bytes)) {
             HIPCK(hipMemcpyAsync(p, d_src, bytes, hipMemcpyDeviceToHost, s));
             ws.pending.push_back({h, p, bytes});
@@ -178,6 +186,7 @@ struct Loop {
         for (const auto& q : ws.pending) std::memcpy(q.dst, q.src, q.bytes);
         ws.pending.clear();
         ws.pin_off = 0;
+        unsettled = false;
     }
     void down(void* h, DevBuf& d, size_t bytes) { down_async(h, d, bytes); settle(); }
 
@@ -749,18 +758,22 @@ void receive_byte_impl(mgpu_ctx* c, const double* passband, int W, const mgpu_re
             {   // Windows that go on to another trial: in the reference the baseband buffer now holds the FIR_rx_data output of the whole
                 // capture window (:1083-1105 wrote it) and a later trial may read it before refreshing it. p2b_frames computed only the
                 // samples the RX path reads, so the full buffer is produced here — for the windows that did not decode only.
+                // Only for the windows that WILL run another trial (the test at the top of the loop, :931 / :939-944): a window that has used up
+                // its trials leaves the loop there and nothing reads its baseband again (the SKIP-H recovery mixes afresh, :1458-1463). Round 6:
+                // until then the last round of a call re-mixed every failing window once more for nobody - and that kernel, still in flight when
+                // the call returned, was the use-after-return of round 5 (it read its window list in the staging ring). Now the last kernel a
+                // call launches is always followed by a round's down() / settle().
                 std::vector<int> again;
-                for (int w : act) if (win[w].in_loop) again.push_back(w);
+                for (int w : act) if (win[w].in_loop && !(win[w].sync_trials > T || (lp.mfsk && win[w].sync_trials > 0))) again.push_back(w);
                 lp.p2b(again, 1);
             }
         }
         for (int w = 0; w < W; ++w) { stats[w].delay = win[w].delay; stats[w].coarse_metric = win[w].metric; stats[w].sync_trials = win[w].sync_trials; }
-        // The call is blocking, to the last kernel: the final round's lp.p2b(again, 1) above is still in flight here and reads its window list
-        // and carriers IN the page-locked staging ring (up()'s zero-copy views) when it executes. A caller that comes straight back - the
-        // pipelined host path below runs sub-batch after sub-batch without a pause - resets the ring and overwrites those slots: the kernel
-        // then indexes the capture buffer with whatever the next call put there (round 5: a GPU memory fault on modes 13 / 15 / 16 with
-        // sub-batches of 256 / 512 windows; any mode could have hit it). Nothing of this call may outlive it.
-        HIPCK(hipStreamSynchronize(s));
+        // The call is blocking, to the last kernel (round 5's fault: a kernel still in flight read its window list in the staging ring after the
+        // next call had reset it). Every path above ends on a settle(); should one ever not, the stream is waited for here (and by `drain`
+        // when an exception unwinds the call).
+        if (lp.unsettled) HIPCK(hipStreamSynchronize(s));
+        lp.unsettled = false;
     }
 }
 }  // namespace
