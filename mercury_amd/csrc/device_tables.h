@@ -56,6 +56,11 @@ constexpr double kSpaTanhSaturates = 44.0;
 static_assert(double(kSpaHardLlr) - kSpaMaxVarDegree * kSpaClampR >= kSpaTanhSaturates,
               "hard-frame shortcut: |LLR| >= kSpaHardLlr no longer keeps every Q in tanh's saturated range - raise kSpaHardLlr or lower the degree limit");
 
+// fp64 decoder, LDS layout: the first kSpaOnesBytes bytes of the workgroup's LDS hold 48 doubles 1.0 (at LDS address 0, so that the address is an
+// inline constant of the select that forms a walk step's read address: ldpc.hip spa_walk); the posteriors follow, then the messages. The host's
+// address tables (tables.cpp: sadr) carry absolute LDS byte addresses and are built with the same constant.
+constexpr uint32_t kSpaOnesBytes = 48 * 8;
+
 // Slim argument block for the decoder kernels: only what they touch, so the kernarg does not
 // inflate the SGPR allocation (occupancy on gfx950 drops below 8 waves/SIMD above 80 SGPRs).
 struct LdpcDev {

@@ -126,7 +126,7 @@ __device__ void decode_tail(const LdpcDev& T, int f, const uint8_t* hard, uint8_
 }  // namespace
 
 extern "C" size_t mgpu_spa_lds_bytes(int S, int N) {
-    return size_t(8) * S + size_t(8) * N + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
+    return size_t(kSpaOnesBytes) + size_t(8) * S + size_t(8) * N + size_t(4) * N + ((N + 15) & ~15) + 256 + 64;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -180,8 +180,26 @@ typedef uint32_t spa_u32x2 __attribute__((ext_vector_type(2)));
 // the vector memory path), and the compiler keeps track of the outstanding loads itself.
 typedef const uint64_t __attribute__((address_space(4))) * spa_cptr64;
 
-// Steps 2C and 2C+1 of the product walk and, recursively, the rest (unrolled by construction: every step's LDS offset is an
-// immediate): masks m0 / m1 belong to this pair, the next pair's are fetched behind it; an all-zero mask ends the walk.
+// The product walk. Step j multiplies slot j of the lane's check into the lane's product unless j is the lane's own slot, lies past the
+// check's degree, or the lane is padding: the bin's tabulated lane mask for step j (bmask, a scalar load) says which lanes take the factor.
+// Two ways of applying it:
+//  * as the execution mask of the multiplication (spa_masked_mul2: s_and_saveexec / v_mul / s_and / v_mul / s_mov per step pair) - scalar-unit work;
+//  * on the vector side (spa_walk_factor, round 6): a lane that does not take the factor reads a 1.0 instead - its read address is selected (one
+//    v_cndmask_b32 with the mask as its condition operand) between the check's first message and LDS address 0, where 48 doubles 1.0 stand
+//    (the step's offset 8 j is the read's immediate) - and every lane multiplies: x * 1.0 == x exactly, so a lane's product is the same sequence
+//    of roundings.
+// Which one is cheaper depends on which unit the kernel loads more. Round 6 measured what the scalar unit is worth here (profiles/NOTES.md R6.2:
+// twelve more s_mov_b32 per bin-iteration +4 % on the headline, twelve more v_mov_b32 +1 %, 24 s_nop nothing; the CU's one scalar unit is 67 %
+// busy at rate 6/16 and 84 % at rate 14/16 in noise). The short walks (rates 1/16 .. 8/16: 5-8 steps) stay on the scalar side (the vector form
+// measured +-0 at rate 6/16 in noise, +0.4 % at -1 dB, +1 % on mode 11); the 46-step walk of rate 14/16 splits its steps between the two (spa_walk4).
+// Steps 2C and 2C+1 and, recursively, the rest (unrolled by construction: every step's LDS offset is an immediate): masks m0 / m1 belong to this
+// pair, the next pair's are fetched behind it; an all-zero mask ends the walk.
+__device__ __forceinline__ double spa_walk_factor(uint32_t achk, uint64_t m, int step) {
+    typedef __attribute__((address_space(3))) double lds_f64;
+    uint32_t base = __builtin_amdgcn_inverse_ballot_w64(m) ? achk : 0u;
+    asm volatile("" : "+v"(base));          // the select stays a select of the BASE (the optimiser would push the step's offset into both arms: an addition per step); the offset is the read's immediate
+    return *reinterpret_cast<const lds_f64*>(base + 8u * uint32_t(step));
+}
 template <int C, int CMAX>
 __device__ __forceinline__ void spa_walk(double& temp, uint32_t achk, spa_cptr64 bm, uint64_t m0, uint64_t m1) {
     typedef __attribute__((address_space(3))) double lds_f64;
@@ -200,12 +218,17 @@ __device__ __forceinline__ void spa_walk4(double& temp, uint32_t achk, spa_cptr6
     if (m0 == 0) return;
     uint64_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     if constexpr (C + 1 < CMAX) { n0 = bm[4 * C + 4]; n1 = bm[4 * C + 5]; n2 = bm[4 * C + 6]; n3 = bm[4 * C + 7]; }
-    // volatile keeps these four reads four ds_read_b64: left alone the compiler pairs them into ds_read2_b64, and the LDS pipeline takes 8 cycles
-    // for one of those against 2.2 for a ds_read_b64 (4.0 for a ds_read_b128, which would need every check to start on an even slot) -
-    // tools/ubench/lds_mask.hip, profiles/r05_lds_mask.json. The walk's reads were what kept the LDS pipeline of the rate-14/16 kernel 86 % busy.
+    // Steps 4C, 4C+1 take their mask on the vector side (the selected read address: spa_walk_factor), steps 4C+2, 4C+3 on the scalar side (the
+    // execution mask: spa_masked_mul2) - the walk's cost is split between the two units this kernel loads most. Measured on mode 16
+    // (baseband_test, 4096 x 50, ms): all four under the execution mask 8.09 / 9.94 / 10.50 at -15 / 8 / 13 dB (scalar unit 84 % busy in noise),
+    // all four through selected addresses 7.68 / 9.78 / 10.39 (vector unit 91 % busy at 13 dB), two and two 7.70 / 9.65 / 10.24.
+    // volatile keeps the two plain reads two ds_read_b64: left alone the compiler pairs them into ds_read2_b64, and the LDS pipeline takes 8 cycles
+    // for one of those against 2.2 for a ds_read_b64 - tools/ubench/lds_mask.hip, profiles/r05_lds_mask.json (the selected reads have an address
+    // register each and cannot be paired).
     const volatile lds_f64* chk = reinterpret_cast<const volatile lds_f64*>(achk);
-    const double a0 = chk[4 * C], a1 = chk[4 * C + 1], a2 = chk[4 * C + 2], a3 = chk[4 * C + 3];
-    spa_masked_mul2(temp, a0, a1, m0, m1);
+    const double a0 = spa_walk_factor(achk, m0, 4 * C), a1 = spa_walk_factor(achk, m1, 4 * C + 1), a2 = chk[4 * C + 2], a3 = chk[4 * C + 3];
+    temp *= a0; SPA_KEEP(temp);
+    temp *= a1; SPA_KEEP(temp);
     if (m2 != 0) spa_masked_mul2(temp, a2, a3, m2, m3);
     if constexpr (C + 1 < CMAX) spa_walk4<C + 1, CMAX>(temp, achk, bm, n0, n1, n2, n3);
 }
@@ -218,8 +241,8 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = T.S;
     constexpr int N = kN;
-    constexpr int kMoff = N * 8;                        // LDS byte offset of the message array
-    double* Lt = reinterpret_cast<double*>(smem);       // LLRtmp per variable
+    constexpr int kMoff = kSpaOnesBytes + N * 8;        // LDS byte offset of the message array
+    double* Lt = reinterpret_cast<double*>(smem + kSpaOnesBytes);       // LLRtmp per variable (behind the 48 doubles 1.0 at address 0: spa_walk)
     double* M = Lt + N;                                 // R or T per padded edge slot
     float* Li = reinterpret_cast<float*>(M + S);        // channel LLR
     uint8_t* hard = reinterpret_cast<uint8_t*>(Li + N);
@@ -229,6 +252,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     const int tid = threadIdx.x, f = blockIdx.x;
     if (f >= F) return;
     if (uint32_t(uintptr_t(smem)) != 0) __builtin_trap();
+    if (tid < int(kSpaOnesBytes / 8)) reinterpret_cast<double*>(smem)[tid] = 1.0;       // the walk's neutral factors (published by the barrier in front of the first pass)
     // Rate 14/16 (the only code with checks of degree 46; the only one the zero-forcing modes 15 / 16 use): its wavefronts meet the regimes in
     // which a whole wavefront gets one of tanh's / atanh's immediate answers (spa_math.h: spa_tanh_half_wave, spa_atanh_x2_wave) - round 5:
     // 10.97 -> 8.50 ms per 4096 x 50 on mode 16's hard (+-Inf) LLRs, 10.04 -> 9.22 on mode 14 in noise. The other kernels keep the plain calls:

@@ -220,17 +220,16 @@ SPA_FN double spa_atanh_x2(double x) {
     SPA_CENSUS(12);
     const double d1 = 1.0 - xa;
     const double r1 = spa_recip(d1);
-    // y / 2, y = 2x/(1-x) (|x| >= 0.5) resp. 2x + 2x*x/(1-x) (|x| < 0.5): ONE quotient sequence on the numerator |x| resp. x*x, and the |x| < 0.5
-    // lanes add |x| to it. (Round 6: near a mode's threshold nearly every wavefront holds lanes of both classes - profiles/r06_spa_branch_census.txt:
-    // 99.6 % / 90 % at -1 dB - and executed the quotient sequence twice, once per branch; the operations a lane performs are unchanged.)
-    bool small = xa < 0.5;
-    SPA_ONE_COMPARE(small);
-    double num = xa;
-    SPA_KEEP(num);
-    if (small) { num = xa * xa; SPA_CENSUS(14); SPA_KEEP(num); }
-    double yh = spa_div_r(num, d1, r1);
-    SPA_KEEP(yh);
-    if (small) { yh = xa + yh; SPA_KEEP(yh); } else { SPA_CENSUS(15); }
+    double yh;                         // y / 2, y = 2x/(1-x) resp. 2x + 2x*x/(1-x)
+    if (xa < 0.5) {
+        yh = xa + spa_div_r(xa * xa, d1, r1);
+        SPA_CENSUS(14);
+        SPA_KEEP(yh);
+    } else {
+        yh = spa_div_r(xa, d1, r1);
+        SPA_CENSUS(15);
+        SPA_KEEP(yh);
+    }
     // log1p(y)
     double fh, l;                      // fh = f / 2
     const bool direct = int32_t(SPA_BITS_HI(yh)) < 0x3FDA827A - 0x00100000;      // y's high word < 0x3FDA827A
@@ -251,16 +250,16 @@ SPA_FN double spa_atanh_x2(double x) {
         // hu | 0x3fe00000) and the |f| < 2^-20 test (hu == 0 resp. (0x100000 - hu) >> 2 == 0 <=> (hadd & 0xfffff) in 0x95f5f..0x95f62)
         hadd = SPA_BITS_HI(u) + 0x95f62u;
         hm = hadd & 0x000fffffu;
-        // c = the rounding error (1 + y) - u of u = fl(1 + y). s_log1p.c forms it as 1 - (u - y) when u >= 2 (k > 0) and as y - (u - 1) when
-        // u < 2 (k = 0): Dekker's two error-free forms, each exact where it is used - both therefore yield the SAME number, the exact error
-        // (representable, as the error of a rounded-to-nearest sum always is). Round 6: y - (u - 1) is exact for u >= 2 as well - u - 1 is exact
-        // (for 2 <= u < 2^53 it is a multiple of ulp(u) >= 2^-51 in u's binade or the finer one below), y and u - 1 then differ by that
-        // representable error, and the fma's product 2 * yh is exact - so one form serves every lane: the u >= 2 test, its branch and the
-        // second form go (near a mode's threshold 97 % of the wavefronts held lanes of both classes and executed both). Same bits: the host
-        // test compares with libm on the u ~ 2^k switch points and 10^7 random arguments.
-        c = __builtin_fma(2.0, yh, -(u - 1.0));              // y - (u - 1)
-        SPA_CENSUS(17);
-        SPA_KEEP(c);
+        // not direct => y >= 0.41421 => u >= 1.41421: the unadjusted exponent is > 0 exactly when u >= 2
+        if (u >= 2.0) {
+            c = 1.0 - __builtin_fma(-2.0, yh, u);            // 1 - (u - y)
+            SPA_CENSUS(17);
+            SPA_KEEP(c);
+        } else {
+            c = __builtin_fma(2.0, yh, -(u - 1.0));          // y - (u - 1)
+            SPA_CENSUS(18);
+            SPA_KEEP(c);
+        }
         c = spa_div_r(c, u, spa_recip(u));
         fh = SPA_MAKE(hm + 0x3fd6a09eu, SPA_LO(u)) - 0.5;    // (normalised u)/2 - 1/2
         SPA_KEEP(fh);

@@ -418,8 +418,8 @@ static LdpcGraph load_graph_uncached(int K, const uint8_t* blob, size_t size) {
                     const uint32_t cs = p, d = cdeg[c];
                     for (uint32_t j = 0; j < d; ++j, ++p) {
                         const uint32_t eo = g.cptr[c] + j;
-                        g.sadr[size_t(p) * 2] = g.cvar[eo] * 8u;
-                        g.sadr[size_t(p) * 2 + 1] = 8u * N + cs * 8u;
+                        g.sadr[size_t(p) * 2] = kSpaOnesBytes + g.cvar[eo] * 8u;           // LDS address of the slot's posterior
+                        g.sadr[size_t(p) * 2 + 1] = kSpaOnesBytes + 8u * N + cs * 8u;       // LDS address of the first message of the slot's check
                         g.bhead[b * 4] |= 1ull << (p & 63);
                         if (j + 1 == d) g.bhead[b * 4 + 1] |= 1ull << (p & 63);
                         g.bhead[b * 4 + 2] = std::max<uint64_t>(g.bhead[b * 4 + 2], d);
