@@ -59,7 +59,7 @@ def algorithmic_bytes(rx, iters_exec_sum, frames):
     return ldpc, total, b_iter
 
 
-PROFILE_ROUND = "r05"          # profiles/<round>_instruction_mix.json (PMC passes) and <round>_valu_cycles.json (opcode issue costs)
+PROFILE_ROUND = "r06"          # profiles/<round>_instruction_mix.json (PMC passes) and <round>_valu_cycles.json (opcode issue costs)
 
 
 def machine_of(device_index):
