@@ -19,6 +19,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
+#include <vector>
 
 #include "ctx.hpp"
 #include "../../include/mercury_tx.h"
@@ -855,8 +857,30 @@ void receive_byte_any(mgpu_ctx* c, const void* capture, int fmt, int W, const mg
         return;
     }
     static const int sub_env = getenv("MERCURY_RB_SUB") ? atoi(getenv("MERCURY_RB_SUB")) : 0;
-    const int sub = sub_env >= 64 ? std::min(sub_env, W) : 256;
-    const int nsub = (W + sub - 1) / sub;
+    // The sub-batches: [offset, count). Doubles are upload-bound (the synchroniser of a sub-batch is over before the next one has landed): equal
+    // pieces of 256, so that little is left to do behind the last byte. Compact samples (4 or 2 bytes each) land two to four times faster than
+    // they are processed, and every receive_byte_impl call pays its control rounds' fixed ~1.5 ms whatever its size: a short first piece gets the
+    // device started, then the pieces grow (1/8, 3/8, 1/2 of the call) - fewer calls, each one's upload still hidden behind its predecessor.
+    // MERCURY_RB_SUB=<n> forces equal pieces of n, MERCURY_RB_SCHED=<a,b,c,...> a list of piece sizes (the last one repeats).
+    std::vector<std::pair<int, int>> pieces;
+    {
+        std::vector<int> sched;
+        if (const char* e = getenv("MERCURY_RB_SCHED")) {
+            for (const char* q = e; *q;) { const int v = atoi(q); if (v >= 32) sched.push_back(v); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        }
+        if (sched.empty()) {
+            if (sub_env >= 64) sched.push_back(std::min(sub_env, W));
+            else if (fmt == MGPU_SAMPLES_F64) sched.push_back(256);
+            else { const int a = std::max(128, (W / 8 + 63) & ~63); sched = {a, 3 * a, std::max(256, W - 4 * a)}; }
+        }
+        size_t k = 0;
+        for (int off = 0; off < W;) {
+            const int n = std::min(sched[std::min(k, sched.size() - 1)], W - off);
+            pieces.emplace_back(off, n);
+            off += n; ++k;
+        }
+    }
+    const int nsub = int(pieces.size());
     ensure_stage(c, size_t(W) * buf * 8);
     if (fmt != MGPU_SAMPLES_F64) ensure_compact(c, size_t(W) * buf * sb);
     double* stage = static_cast<double*>(c->rb_stage);
@@ -867,7 +891,7 @@ void receive_byte_any(mgpu_ctx* c, const void* capture, int fmt, int W, const mg
     std::thread uploader([&] {
         hipError_t e = hipSetDevice(c->cfg.device);
         for (int j = 0; j < nsub; ++j) {
-            const int off = j * sub, n = std::min(sub, W - off);
+            const int off = pieces[j].first, n = pieces[j].second;
             if (fmt == MGPU_SAMPLES_F64) {
                 if (e == hipSuccess) e = hipMemcpyAsync(stage + size_t(off) * buf, src + size_t(off) * buf * 8, size_t(n) * buf * 8, hipMemcpyHostToDevice, c->rb_stream);
             } else {
@@ -890,7 +914,7 @@ void receive_byte_any(mgpu_ctx* c, const void* capture, int fmt, int W, const mg
     });
     try {
         for (int j = 0; j < nsub; ++j) {
-            const int off = j * sub, n = std::min(sub, W - off);
+            const int off = pieces[j].first, n = pieces[j].second;
             {
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return landed > j || failed != hipSuccess; });
