@@ -860,7 +860,9 @@ void receive_byte_any(mgpu_ctx* c, const void* capture, int fmt, int W, const mg
     // The sub-batches: [offset, count). Doubles are upload-bound (the synchroniser of a sub-batch is over before the next one has landed): equal
     // pieces of 256, so that little is left to do behind the last byte. Compact samples (4 or 2 bytes each) land two to four times faster than
     // they are processed, and every receive_byte_impl call pays its control rounds' fixed ~1.5 ms whatever its size: a short first piece gets the
-    // device started, then the pieces grow (1/8, 3/8, 1/2 of the call) - fewer calls, each one's upload still hidden behind its predecessor.
+    // device started, then the pieces grow (1/8, 3/8, 1/2 of the call; INT16: 128 windows, then the rest) - fewer calls, each one's upload still
+    // hidden behind its predecessor. Measured on 1024 mode-8 windows (tools/bench_rb_sched.py, profiles/r06_rb_sched.txt), k windows/s, equal pieces of
+    // 256 -> these schedules: INT32 66.7 -> 72.4, INT16 71.7 -> 85.3; doubles stay at equal pieces (60.0; 128,384,512 gives 52.9).
     // MERCURY_RB_SUB=<n> forces equal pieces of n, MERCURY_RB_SCHED=<a,b,c,...> a list of piece sizes (the last one repeats).
     std::vector<std::pair<int, int>> pieces;
     {
@@ -871,6 +873,7 @@ void receive_byte_any(mgpu_ctx* c, const void* capture, int fmt, int W, const mg
         if (sched.empty()) {
             if (sub_env >= 64) sched.push_back(std::min(sub_env, W));
             else if (fmt == MGPU_SAMPLES_F64) sched.push_back(256);
+            else if (sb == 2) sched = {128, std::max(256, W - 128)};          // INT16: the whole call lands in the time one piece is processed
             else { const int a = std::max(128, (W / 8 + 63) & ~63); sched = {a, 3 * a, std::max(256, W - 4 * a)}; }
         }
         size_t k = 0;
