@@ -140,16 +140,27 @@ int mgpu_create(const mgpu_config* cfg, mgpu_ctx** out);
  * row) and, when seeds_set != 0, the three PRNG seeds (ofdm_pilot_configurator_seed 0, bit_energy_dispersal_seed 0,
  * ofdm_preamble_configurator_seed 1; seed 0 means 1 to __srandom, os_interop.cc:251). They act on the RX path, the synthetic
  * generator and the transmit chain alike.
- * FIXED, not parameters: the carrier geometry Nc = 50, Nfft = 256 (Ngi = 16, Nofdm = 272) and the pilot lattice Dx = 1, Dy = 3 —
- * physical_config.cc:35-65 gives all 17 modes these values and the kernels are specialised for them. The four fields exist only so
- * that a caller holding the reference's configuration can have it confirmed: 0 or exactly 50 / 256 / 1 / 3 is accepted, anything
- * else returns MGPU_ERR_UNSUPPORTED before any device work. params == NULL: mgpu_create. */
+ * Frame geometry (round 6): Dy (ofdm_pilot_configurator_Dy, the pilot lattice's row period: 3 for every mode's HIGH_DENSITY default;
+ * the reference's LOW_DENSITY option is 5, telecom_system.cc:1848-1869) and Nsymb (ofdm_Nsymb, OFDM symbols per frame; 0 = what
+ * cl_telecom_system::init selects from the modulation, telecom_system.cc:1810-1826; LOW_DENSITY: 40 BPSK / 20 QPSK / 10 16QAM) are
+ * honoured for the OFDM modes as load_configuration copies them (telecom_system.cc:2775-2778): the pilot lattice
+ * (cl_pilot_configurator::configure, ofdm.cc:976-1064), every size derived from it (data_container.cc:90-99) and the whole RX / TX /
+ * generator path follow. With Dy != 3 the LS estimator takes the kernel's general window walk (slower than the lattice-specialised
+ * one; same sums in the same order). Refused (MGPU_ERR_TABLES): a geometry whose data cells hold more bits than a codeword or fewer than
+ * its parity plus one payload byte, one with a column of fewer than two pilots, one that does not fit the front-end's LDS carve, the
+ * MFSK modes.
+ * FIXED, not parameters: Nc = 50, Nfft = 256 (Ngi = 16, Nofdm = 272) and the pilot lattice's column step Dx = 1 — physical_config.cc:35-65
+ * gives all 17 modes these values and the kernels are specialised for them. The three fields exist only so that a caller holding the
+ * reference's configuration can have it confirmed: 0 or exactly 50 / 256 / 1 is accepted, anything else returns MGPU_ERR_UNSUPPORTED
+ * before any device work. params == NULL: mgpu_create. */
 typedef struct mgpu_explicit_params {
     float pilot_boost;
     int ls_window;
     int seeds_set;
     unsigned pilot_seed, scrambler_seed, preamble_seed;
-    int Nc, Nfft, Dx, Dy;      /* fixed at 50 / 256 / 1 / 3 (0 = unspecified); see above */
+    int Nc, Nfft, Dx;          /* fixed at 50 / 256 / 1 (0 = unspecified); see above */
+    int Dy;                    /* pilot row period; 0 = the reference's 3 */
+    int Nsymb;                 /* OFDM symbols per frame; 0 = the reference's choice for the modulation */
 } mgpu_explicit_params;
 int mgpu_create_explicit(const mgpu_config* cfg, const mgpu_explicit_params* params, mgpu_ctx** out);
 void mgpu_destroy(mgpu_ctx* ctx);

@@ -160,11 +160,14 @@ public:
     mgpu_info info{};
     // cl_telecom_system::default_configurations_telecom_system (cl_configuration_telecom_system, physical_config.cc:30-65): the values
     // load_configuration copies into the DSP objects for every mode (telecom_system.cc:2772-2811). Change them BEFORE load_configuration,
-    // as the reference's callers do. (Nc, Nfft, Dx, Dy are fixed: the kernels are specialised for the reference's geometry.)
+    // as the reference's callers do. ofdm_Nsymb / ofdm_pilot_configurator_Dy: -1 = AUTO_SELLECT (physical_config.cc:38-40; resolved as
+    // cl_telecom_system::init does for HIGH_DENSITY pilots, telecom_system.cc:1810-1869); the reference's LOW_DENSITY option is Dy 5 with
+    // Nsymb 40 / 20 / 10 for BPSK / QPSK / 16QAM. (Nc, Nfft, Dx are fixed: the kernels are specialised for the reference's 50 / 256 / 1.)
     struct {
         float ofdm_pilot_configurator_pilot_boost = 1.33f;
         int ofdm_LS_window_width = 20;            // = ofdm_LS_window_hight
         unsigned ofdm_pilot_configurator_seed = 0, bit_energy_dispersal_seed = 0, ofdm_preamble_configurator_seed = 1;
+        int ofdm_Nsymb = -1, ofdm_pilot_configurator_Dy = -1;
     } default_configurations_telecom_system;
 
     ~cl_rx_phy() { release(); }
@@ -419,6 +422,10 @@ private:
             x.pilot_seed = default_configurations_telecom_system.ofdm_pilot_configurator_seed;
             x.scrambler_seed = default_configurations_telecom_system.bit_energy_dispersal_seed;
             x.preamble_seed = default_configurations_telecom_system.ofdm_preamble_configurator_seed;
+            if (current_configuration < 100) {     // the MFSK modes derive their frame length from the codeword and carry no pilots (telecom_system.cc:1812-1816, :1873-1877)
+                x.Nsymb = default_configurations_telecom_system.ofdm_Nsymb > 0 ? default_configurations_telecom_system.ofdm_Nsymb : 0;
+                x.Dy = default_configurations_telecom_system.ofdm_pilot_configurator_Dy > 0 ? default_configurations_telecom_system.ofdm_pilot_configurator_Dy : 0;
+            }
             detail::check(mgpu_create_explicit(&c, &x, &ctxs_[which]), nullptr, "load_configuration");
         }
         ctx_ = ctxs_[which];

@@ -48,20 +48,29 @@ void ctx_alloc(mgpu_ctx* c) {
     d.data_cell = c->keep(upload(t.data_cell));
     d.cell_lerp = nullptr;
     if (t.mfsk_M == 0) {
-        // The two pilot rows a data cell (i, j) interpolates between and their pilots' indices, tabulated: column j has its pilots in the rows
-        // == j (mod 3) (checked below: the lattice is refused otherwise), rows above the first / below the last pilot extrapolate from the
-        // nearest two (interpolator.cc:163-254). The kernel used to derive all of this per cell from divisions by 50 and 3.
+        // The two pilot rows a data cell (i, j) interpolates between and their pilots' indices, tabulated from the lattice itself the way
+        // interpolate_linear_col walks a column (interpolator.cc:163-254): between two measured rows the nearest one above and the nearest
+        // one below; above the column's first measured row the first two, below its last one the last two (extrapolation). Every column
+        // needs two pilots (a column with fewer is refused: the reference's walk degenerates there). The kernel used to derive all of this
+        // per cell from divisions by 50 and 3.
         std::vector<int> pilot_of_cell(size_t(t.Nsymb) * t.Nc, -1);
         for (size_t p = 0; p < pilot_cell.size(); ++p) pilot_of_cell[pilot_cell[p]] = int(p);
         std::vector<uint32_t> tab(size_t(t.nData) * 2, 0u);
-        bool ok = t.Nsymb >= 4 && t.Nsymb * t.Nc < 4096 && pilot_cell.size() < 1024 && t.Nsymb < 256;
+        bool ok = t.Nsymb >= 2 && t.Nsymb * t.Nc < 4096 && pilot_cell.size() < 1024 && t.Nsymb < 256;
+        std::vector<std::vector<int>> col_rows(size_t(t.Nc));
+        for (int i = 0; i < t.Nsymb; ++i)
+            for (int j = 0; j < t.Nc; ++j) if (pilot_of_cell[size_t(i) * t.Nc + j] >= 0) col_rows[size_t(j)].push_back(i);
         for (int k = 0; k < t.nData && ok; ++k) {
             const int cell = t.data_cell[k], i = cell / t.Nc, j = cell - i * t.Nc;
-            const int m = ((i - j) % 3 + 3) % 3;
-            int a = i - m, b = i + 3 - m;
-            if (a < 0) { a = b; b = a + 3; }
-            else if (b >= t.Nsymb) { b = a; a = b - 3; }
-            if (a < 0 || b >= t.Nsymb || pilot_of_cell[size_t(a) * t.Nc + j] < 0 || pilot_of_cell[size_t(b) * t.Nc + j] < 0) { ok = false; break; }
+            const std::vector<int>& rows = col_rows[size_t(j)];
+            if (rows.size() < 2) { ok = false; break; }
+            int a, b;
+            if (i < rows.front()) { a = rows[0]; b = rows[1]; }
+            else if (i > rows.back()) { a = rows[rows.size() - 2]; b = rows.back(); }
+            else {
+                const size_t hi = size_t(std::upper_bound(rows.begin(), rows.end(), i) - rows.begin());     // a data cell is never a measured row itself
+                a = rows[hi - 1]; b = rows[hi];
+            }
             tab[2 * size_t(k)] = uint32_t(cell) | uint32_t(pilot_of_cell[size_t(a) * t.Nc + j]) << 12 | uint32_t(pilot_of_cell[size_t(b) * t.Nc + j]) << 22;
             tab[2 * size_t(k) + 1] = uint32_t(a) | uint32_t(b) << 8 | uint32_t(i) << 16;
         }
@@ -91,8 +100,9 @@ void ctx_alloc(mgpu_ctx* c) {
     for (int r = 0; r < t.Nsymb; ++r)
         for (int q = 0; q < t.Nc; ++q)
             if ((t.cell_type[size_t(r) * t.Nc + q] != 0) != (((r - q) % 3 + 3) % 3 == 0)) d.regular_lattice = 0;
-    if (t.mfsk_M == 0 && (!d.regular_lattice || t.Nc != 50))
-        throw std::runtime_error("pilot lattice differs from the one the front-end kernel is specialised for (pilots where (row - col) % 3 == 0, 50 carriers)");
+    if (t.mfsk_M == 0 && t.Nc != 50) throw std::runtime_error("the front-end kernel is specialised for 50 carriers");
+    // regular_lattice == 0 (an explicit Dy other than 3: include/mercury_gpu.h mgpu_explicit_params): the estimator takes its general path - the
+    // reference's own walk over the window's cells (frontend.hip) - everything else is table-driven and does not care
     if (d.regular_lattice && std::min(t.lsw / 2 + 1, t.Nc) >= 9) d.regular_lattice = 2;   // and every (clipped) window row holds >= 3 pilots of each column residue
     d.minsum_alpha = c->cfg.minsum_alpha > 0 ? c->cfg.minsum_alpha : 0.8f;
     d.mfsk_M = t.mfsk_M; d.mfsk_nbits = t.mfsk_nbits; d.mfsk_nstreams = t.mfsk_nstreams; d.mfsk_hop = t.mfsk_hop;
@@ -128,6 +138,20 @@ void ctx_alloc(mgpu_ctx* c) {
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
     l.hard_frames = reinterpret_cast<unsigned long long*>(c->keep(upload(std::vector<uint64_t>(64, 0))));
+    {   // fp64 decoder, first iterations: from how many odd checks on (estimated from the 16 bins the kernel samples) an iteration's
+        // posteriors are looked at inside the next check pass instead of by a pass of their own (ldpc.hip: "adaptive"): one weight for the
+        // look at the channel's hard decisions (the first iteration removes far more errors than any later one), one for the later looks.
+        // Results do not depend on them. MERCURY_SPA_SPEC_WEIGHT="first,later" for experiments (0 = always inside the check pass).
+        int w0 = 100, w1 = 45;
+        if (const char* e = getenv("MERCURY_SPA_SPEC_WEIGHT")) { if (sscanf(e, "%d,%d", &w0, &w1) == 1) w1 = w0; }
+        const int nbins = d.S / 64 > 0 ? d.S / 64 : 1;
+        auto sample_min = [&](int weight) {
+            const long long m = (static_cast<long long>(weight) * 16 + nbins - 1) / nbins;
+            return weight <= 0 ? 0 : (m > 0x7fffff ? 0x7fffff : int(m));
+        };
+        l.spec_sample_min0 = sample_min(w0);
+        l.spec_sample_min = sample_min(w1);
+    }
     HIPCK(hipStreamCreate(&c->stream));
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));
     for (auto& e : c->sync_ev) HIPCK(hipEventCreate(&e));
@@ -471,12 +495,14 @@ int mgpu_create_explicit(const mgpu_config* cfg, const mgpu_explicit_params* xp_
     mgpu_internal_libm_notice();                 // only with MERCURY_GPU_LIBM_CHECK=1: is the host's libm the one the device restates? (once per process; stderr only if not)
     mgpu::ExplicitParams xp;
     if (xp_in) {
-        // the kernels are specialised for the reference's carrier geometry and pilot lattice: those fields only confirm it
-        if ((xp_in->Nc != 0 && xp_in->Nc != 50) || (xp_in->Nfft != 0 && xp_in->Nfft != 256) || (xp_in->Dx != 0 && xp_in->Dx != 1) ||
-            (xp_in->Dy != 0 && xp_in->Dy != 3)) {
-            g_create_error = "explicit parameters: Nc / Nfft / Dx / Dy other than 50 / 256 / 1 / 3 are not supported (the kernels are specialised for the reference's geometry)";
+        // the kernels are specialised for the reference's carrier count, transform length and pilot column step: those fields only confirm them
+        if ((xp_in->Nc != 0 && xp_in->Nc != 50) || (xp_in->Nfft != 0 && xp_in->Nfft != 256) || (xp_in->Dx != 0 && xp_in->Dx != 1)) {
+            g_create_error = "explicit parameters: Nc / Nfft / Dx other than 50 / 256 / 1 are not supported (the kernels are specialised for them)";
             return MGPU_ERR_UNSUPPORTED;
         }
+        if (xp_in->Dy < 0 || xp_in->Dy > 255 || xp_in->Nsymb < 0 || xp_in->Nsymb > 255) { g_create_error = "explicit parameters: Dy / Nsymb must be 0 (the reference's default) .. 255"; return MGPU_ERR_ARG; }
+        if (xp_in->Dy != 0) xp.Dy = xp_in->Dy;
+        xp.Nsymb = xp_in->Nsymb;
         if (xp_in->pilot_boost != 0.0f) xp.pilot_boost = xp_in->pilot_boost;
         if (xp_in->ls_window != 0) xp.ls_window = xp_in->ls_window;
         if (xp_in->ls_window < 0 || xp_in->ls_window > 21) { g_create_error = "explicit parameters: ls_window must be 1..21 (0 = the reference's 20)"; return MGPU_ERR_ARG; }

@@ -78,6 +78,7 @@ struct LdpcDev {
     const uint32_t* vinfo2;  // vinfo with LDS byte offsets
     int DM;
     int S, N, P, K, E, nReal, payload_stride, max_iters;
+    int spec_sample_min0, spec_sample_min;   // fp64 decoder: a look that counts at least this many odd checks in bins 0..15 sends the next look into the check pass (ldpc.hip); 0: the look at the channel's hard decisions
     float minsum_alpha;
     unsigned long long* hard_frames;   // [64] fp64 decoder: +1 (in counter frame % 64) per frame decided before its first iteration (every |LLR| >= 200 and an odd parity check), mgpu_decoder_hard_frames
 };

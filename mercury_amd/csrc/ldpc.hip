@@ -261,6 +261,11 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     // shortcuts need.
     constexpr bool kWaveShortcuts = NE == 8;
     constexpr bool kVaResident = !kWaveShortcuts;
+    // The adaptive look policy (below) is built into the kernels of rates 1/16 .. 8/16 only. Rate 14/16 keeps the fixed schedule of rounds 2-5
+    // (judged looks in a frame's first kSpecStart iterations): its bin loop is the one the scalar unit bounds, and the sample count's scalar
+    // registers cost it seven more scalar copies per bin (+2.5 % / +3.3 % on a mode-16 launch at 13 / -15 dB, same-box) against gains of
+    // 0-1 % on modes 12 / 14 at their operating points (profiles/r06_ab_spec.txt).
+    constexpr bool kAdaptive = !kWaveShortcuts;
     SPA_STAMP_DECL(F);
     SPA_STAMP(1);                                   // 1: start
     // Before the first iteration every R is zero, so Q = posterior - R is the channel LLR on every edge of a variable and T = tanh(Q/2) is
@@ -339,9 +344,23 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     __syncthreads();
     const bool hard_frame = __builtin_amdgcn_ballot_w64((tid & 63) < LDPC_THREADS / 64 && hard_w[tid & 15] == 0) == 0;
 
-    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool {
+    // m: the sign bits of a bin's posteriors (lanes in use only). The inclusive prefix parity, taken at the lanes that end a check, is the parity of
+    // all checks up to that one: some check of the bin is odd <=> some prefix is (bin_unsat). HOW MANY are odd (bin_odd_count) takes each
+    // prefix against its predecessor: the predecessor's bit, moved one lane up, stands on the check's first lane; added to the bin's non-end lanes
+    // (all ones below the check's end lane) it ripples up to exactly that end lane and no further.
+    auto bin_prefix = [&](unsigned long long m, unsigned long long ends) -> unsigned long long {
         m ^= m << 1; m ^= m << 2; m ^= m << 4; m ^= m << 8; m ^= m << 16; m ^= m << 32;
-        return (m & ends) != 0;
+        return m & ends;
+    };
+    auto bin_unsat = [&](unsigned long long m, unsigned long long ends) -> bool { return bin_prefix(m, ends) != 0; };
+    auto bin_odd_count = [&](unsigned long long pre, unsigned long long used, unsigned long long ends) -> int {
+        return __builtin_popcountll(pre ^ (((pre << 1) + (used & ~ends)) & ends));
+    };
+    // What a look at the posteriors leaves in flag[p & 1]: 0 = every check satisfied; otherwise the number of wavefronts that saw an odd check
+    // (low byte) + 256 x the number of odd checks in bins 0..15 (every wavefront's first bin: a SAMPLE of the syndrome's weight, 16 of the
+    // code's 56-116 bins). The sample steers only where the next look is taken (below: "adaptive"), never what it sees.
+    auto flag_report = [&](int p, bool unsat, int cnt) {
+        if (unsat && (tid & 63) == 0) __hip_atomic_fetch_add(&flag[p & 1], 1 + (cnt << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // Per-slot addresses come straight from a table (no field extraction): the LDS offset of the slot's posterior and the
     // LDS address of its check's first message, one buffer load per round (lane offset in a register, round offset in a
@@ -375,11 +394,13 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         for (int r = 0; r < NE; ++r) lt[r] = *ldsd(q.alt[r]);              // padding reads variable 0; masked out below
 #pragma unroll
         for (int r = 0; r < NE; ++r) SPA_KEEP(lt[r]);                      // all of them here: the optimiser would sink each load to its (conditional) use
-        bool unsat = false;
+        const unsigned long long pre = bin_prefix(__ballot(lt[0] < 0) & q.vmask[0], q.ends[0]);
+        const int cnt = kAdaptive ? bin_odd_count(pre, q.vmask[0], q.ends[0]) : 0;
+        bool unsat = pre != 0;
 #pragma unroll
-        for (int r = 0; r < NE; ++r)
+        for (int r = 1; r < NE; ++r)
             if (!unsat) unsat = bin_unsat(__ballot(lt[r] < 0) & q.vmask[r], q.ends[r]);
-        if (unsat && (tid & 63) == 0) flag[p & 1] = 1;
+        flag_report(p, unsat, cnt);
     };
     auto syndrome_pass = [&](int p) { SynPre q; syn_fetch(q); syn_judge(q, p); };
     // The check pass. Bins are handed out on demand: wavefront w starts with bin w, every further bin goes to whoever asks first (a counter
@@ -391,6 +412,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         constexpr bool first = decltype(first_tag)::value;      // the first pass is a copy of the loop of its own: the steady-state loop carries no test for it
                                                                 // (measured: the test as a run-time flag costs the headline 1.6 %; a copy per syndrome mode as well costs 0.7 %)
         bool unsat = false;
+        int cnt = -1;                                                  // odd checks in the wavefront's first bin (the sample: flag_report)
         const int nbins = T.S >> 6;
         const uint32_t lane8 = (tid & 63) * 8;
         int b = wave;
@@ -411,7 +433,15 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             if ((tid & 63) == 0) nxt = atomicAdd(ctr, 1);
             // one odd check settles the pass, so the wave's later bins skip the test: the ballot -> prefix-XOR chain is a dependent run of
             // scalar instructions on the bin's critical path (6.27 -> 6.06 ms per 4096 x 50 on the headline, where the first bin settles it)
-            if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vm, en);
+            if constexpr (kAdaptive) {
+                if (with_syndrome && !unsat) {
+                    const unsigned long long pre = bin_prefix(__ballot(lt < 0) & vm, en);
+                    if (cnt < 0) cnt = bin_odd_count(pre, vm, en);
+                    unsat = pre != 0;
+                }
+            } else {
+                if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vm, en);
+            }
             if (valid) {
                 double t;
                 if constexpr (first) t = lt;                           // the posterior array holds T itself (see the top of the kernel)
@@ -441,7 +471,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             if (valid) *ldsd(own) = rr;
             b = nxt;
         }
-        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;
+        if (with_syndrome) flag_report(p, unsat, kAdaptive ? cnt : 0);
     };
 #if SPA_VR_RESIDENT
     // the record of the lane's first variable stays in registers (6); the second one (3 words, rows from 1024 on) is requested every iteration
@@ -458,14 +488,24 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     SPA_STAMP(3);                                   // 3: syndrome pass done (before its barrier)
     __syncthreads();
     SPA_STAMP(4);                                   // 4: behind the barrier
-    if (flag[0] && hard_frame) {
+    int look = flag[0];                             // what the last look at the posteriors reported (flag_report)
+    if (look && hard_frame) {
         iteration = T.max_iters + 1;
         if (tid == 0 && T.hard_frames) atomicAdd(T.hard_frames + (f & 63), 1ull);      // so that a benchmark can tell reported from executed iterations (64 counters: a launch of hard frames does not queue on one address)
     }
-    else if (flag[0]) {
+    else if (look) {
+        // Where the look at an iteration's posteriors is taken - "judged": a syndrome-only pass behind the variable update (one more barrier, but a
+        // frame that has converged leaves at once); "speculative": inside the next iteration's check pass (no pass of its own, but a frame that has
+        // converged has paid a check pass in vain). Rounds 2-5: judged in a frame's first kSpecStart iterations, speculative afterwards. Round 6:
+        // ADAPTIVE in the first kSpecStart iterations - the last look's sample of the syndrome's weight decides: with many odd checks left the
+        // next iteration cannot be the last one in practice (mode 8 at its operating point: 266 -> 64 -> 23 -> 2 -> 0 odd checks of 1000; no frame
+        // of any mode went from more than 41 to 0, tests/tools/unsat_profile.py), so its posteriors are looked at speculatively; below the threshold
+        // (T.spec_sample_min, api.hip) the judged form. Both forms test the same syndrome of the same posteriors: bits and iteration counts do
+        // not depend on the choice (tests/test_gpu_parity.py runs every threshold against the oracle).
+        bool spec = false;                                                   // this iteration's check pass carries the look at the previous iteration's posteriors
+        bool skip = kSpecStart <= 1 || (kAdaptive && (look >> 8) >= T.spec_sample_min0);    // this iteration's posteriors get no judged look
         for (int it = 1;; ++it) {
-            const bool spec = it - 1 >= kSpecStart;
-            if (it == 1) cn_pass(spec, 0, std::true_type());
+            if (it == 1) cn_pass(false, 0, std::true_type());
             else if (it <= T.max_iters) cn_pass(spec, it - 1, std::false_type());
             else syndrome_pass(it - 1);
 #if !SPA_VR_RESIDENT
@@ -478,12 +518,14 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             __syncthreads();
             SPA_STAMP(6);                           // 6: behind its barrier
             if (spec) {
-                if (!flag[(it - 1) & 1]) { iteration = it - 1; break; }
+                look = flag[(it - 1) & 1];
+                if (!look) { iteration = it - 1; break; }
                 if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
+                skip = it >= kSpecStart || (kAdaptive && (look >> 8) >= T.spec_sample_min);
             }
             if (tid == 0) { flag[it & 1] = 0; flag[2 + (it & 1)] = LDPC_THREADS / 64; }
             SynPre pre;
-            if (it < kSpecStart) syn_fetch(pre);
+            if (!skip) syn_fetch(pre);
 #if SPA_VR_RESIDENT
             // the records' fields are unpacked here, every iteration: unpacked once in front of the loop (what the optimiser prefers) they are
             // thirteen more values to keep across the check pass, i.e. spills
@@ -496,17 +538,20 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             var_update(va);
             if (tid + LDPC_THREADS < N) var_update(vb);
 #endif
-            if (it < kSpecStart) syn_pin(pre);
+            if (!skip) syn_pin(pre);
             SPA_STAMP(7);                           // 7: variable update done
             __syncthreads();
             SPA_STAMP(8);                           // 8: behind its barrier
-            if (it < kSpecStart) {
+            spec = skip;
+            if (!skip) {
                 syn_judge(pre, it);
                 SPA_STAMP(3);
                 __syncthreads();
                 SPA_STAMP(4);
-                if (!flag[it & 1]) { iteration = it; break; }
+                look = flag[it & 1];
+                if (!look) { iteration = it; break; }
                 if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
+                skip = it + 1 >= kSpecStart || (kAdaptive && (look >> 8) >= T.spec_sample_min);
             }
         }
     }

@@ -94,10 +94,10 @@ std::vector<Cplx> make_constellation(int M) {
     return c;
 }
 
-// cl_pilot_configurator::configure (ofdm.cc:976-1064) for Dx=1, Dy=3, all edge rows/cols DATA,
+// cl_pilot_configurator::configure (ofdm.cc:976-1064) for Dx=1, all edge rows/cols DATA,
 // last_col AUTO_SELLECT with the COPY_FIRST_COL fallback.
-std::vector<uint8_t> make_pilot_lattice(int Nsymb, int Nc) {
-    const int Dx = 1, Dy = 3;
+std::vector<uint8_t> make_pilot_lattice(int Nsymb, int Nc, int Dy) {
+    const int Dx = 1;
     const int S = Nc > Nsymb ? Nc : Nsymb;
     std::vector<uint8_t> v(size_t(S) * S, 0);
     for (int x = 0, y = 0; x < S && y < S; x += Dx, ++y) {
@@ -673,6 +673,11 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
         case 16: t.Nsymb = 12; t.bps = 4; break;
         default: t.Nsymb = 9; t.bps = 5; break;
     }
+    if (xp.Nsymb != 0 || xp.Dy != 3) {                                        // telecom_system.cc:2775-2778: ofdm_Nsymb / ofdm_pilot_configurator_Dy as load_configuration copies them
+        if (robust) throw std::runtime_error("explicit Nsymb / Dy: the MFSK modes take their frame length from the codeword (telecom_system.cc:1812-1816) and carry no pilots");
+        if (xp.Nsymb < 0 || xp.Nsymb > 255 || xp.Dy < 1 || xp.Dy > 255) throw std::runtime_error("explicit Nsymb / Dy out of range");
+        if (xp.Nsymb > 0) t.Nsymb = xp.Nsymb;
+    }
     if (robust) {                                                            // mfsk.cc:48-78 via telecom_system.cc:2900-2907
         t.mfsk_M = cfg == 100 ? 32 : 16;
         t.mfsk_nstreams = cfg == 100 ? 1 : 2;
@@ -687,7 +692,7 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
         t.ctrl_nsymb = t.ctrl_nbits / t.bps;
     }
     const int G = t.Nsymb * t.Nc;
-    t.cell_type = robust ? std::vector<uint8_t>(G, 0) : make_pilot_lattice(t.Nsymb, t.Nc);   // MFSK frames carry no pilots
+    t.cell_type = robust ? std::vector<uint8_t>(G, 0) : make_pilot_lattice(t.Nsymb, t.Nc, xp.Dy);   // MFSK frames carry no pilots
     t.pilot_boost = static_cast<double>(xp.pilot_boost);                      // physical_config.h:53 (float)
     t.pilot_val.assign(G, 0.0);
     if (!robust) {   // DBPSK pilot sequence, ofdm.cc:940-951
@@ -705,6 +710,8 @@ ModeTables build_mode_tables(int cfg, int mfsk_ctrl_mode, const uint8_t* blob, s
     t.nBits = t.nData * t.bps;                                               // data_container.cc:93
     t.nVirtual = t.N - t.nBits;
     t.nReal = t.nBits - t.P;
+    if (t.nVirtual < 0 || t.nVirtual > t.K || t.nReal < 24)
+        throw std::runtime_error("frame geometry: the data cells hold " + std::to_string(t.nBits) + " bits - more than a codeword, fewer than its parity + a payload byte, or more virtual bits than information bits");
     t.bit_blk = t.nBits / 10;                                                // telecom_system.cc:2910-2911
     t.tf_blk = t.nData / 10;
     t.payload_bytes = (t.nReal - 16) / 8;                                    // telecom_system.cc:332-335

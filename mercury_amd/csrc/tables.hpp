@@ -77,6 +77,8 @@ struct ExplicitParams {
     unsigned pilot_seed = 0;       // ofdm_pilot_configurator_seed
     unsigned scrambler_seed = 0;   // bit_energy_dispersal_seed
     unsigned preamble_seed = 1;    // ofdm_preamble_configurator_seed
+    int Nsymb = 0;                 // ofdm_Nsymb; 0 = what init() selects from the modulation for HIGH_DENSITY pilots (telecom_system.cc:1810-1826)
+    int Dy = 3;                    // ofdm_pilot_configurator_Dy: 3 = HIGH_DENSITY (every mode's default), 5 = the reference's LOW_DENSITY option (telecom_system.cc:1848-1869)
 };
 
 struct ModeTables {

@@ -36,7 +36,7 @@ INFO_FIELDS = ("cfg M bits_per_symbol K P N Nsymb Nc Nfft Ngi Nofdm nData nBits 
 
 class ExplicitParams(C.Structure):    # mgpu_explicit_params
     _fields_ = [("pilot_boost", C.c_float), ("ls_window", C.c_int), ("seeds_set", C.c_int), ("pilot_seed", C.c_uint),
-                ("scrambler_seed", C.c_uint), ("preamble_seed", C.c_uint), ("Nc", C.c_int), ("Nfft", C.c_int), ("Dx", C.c_int), ("Dy", C.c_int)]
+                ("scrambler_seed", C.c_uint), ("preamble_seed", C.c_uint), ("Nc", C.c_int), ("Nfft", C.c_int), ("Dx", C.c_int), ("Dy", C.c_int), ("Nsymb", C.c_int)]
 
 
 class Info(C.Structure):
@@ -186,8 +186,8 @@ class RxPhy:
 
     def __init__(self, cfg, max_iters=50, decoder=DEC_SPA, agc=1, variance_source=1, device=0,
                  max_batch=4096, minsum_alpha=0.0, mfsk_ctrl_mode=False, test_puncture_nbits=0, explicit=None):
-        """explicit: dict with any of pilot_boost, ls_window, pilot_seed, scrambler_seed, preamble_seed (and Nc, Nfft, Dx, Dy, which must
-        be the reference's) -> mgpu_create_explicit (include/mercury_gpu.h); the seeds override the reference's 0 / 0 / 1 together."""
+        """explicit: dict with any of pilot_boost, ls_window, pilot_seed, scrambler_seed, preamble_seed, Dy, Nsymb (and Nc, Nfft, Dx, which
+        must be the reference's) -> mgpu_create_explicit (include/mercury_gpu.h); the seeds override the reference's 0 / 0 / 1 together."""
         self.lib = load_library()
         self.h = C.c_void_p()
         c = Config(cfg, max_iters, decoder, agc, variance_source, device, max_batch, minsum_alpha, 1 if mfsk_ctrl_mode else 0, test_puncture_nbits)
@@ -195,7 +195,8 @@ class RxPhy:
             seeds = any(k in explicit for k in ("pilot_seed", "scrambler_seed", "preamble_seed"))
             xp = ExplicitParams(float(explicit.get("pilot_boost", 0.0)), int(explicit.get("ls_window", 0)), 1 if seeds else 0,
                                 int(explicit.get("pilot_seed", 0)), int(explicit.get("scrambler_seed", 0)), int(explicit.get("preamble_seed", 1)),
-                                int(explicit.get("Nc", 0)), int(explicit.get("Nfft", 0)), int(explicit.get("Dx", 0)), int(explicit.get("Dy", 0)))
+                                int(explicit.get("Nc", 0)), int(explicit.get("Nfft", 0)), int(explicit.get("Dx", 0)), int(explicit.get("Dy", 0)),
+                                int(explicit.get("Nsymb", 0)))
             rc = self.lib.mgpu_create_explicit(C.byref(c), C.byref(xp), C.byref(self.h))
         else:
             rc = self.lib.mgpu_create(C.byref(c), C.byref(self.h))

@@ -77,6 +77,7 @@ struct morc {
     int bit_blk, tf_blk, preamble, estimator, amp_restore, lsw;
     /* physical_config.cc:30-65 values a caller may override (morc_create_explicit); defaults are the reference's */
     float boostf;                                  /* ofdm_pilot_configurator_pilot_boost (a float, physical_config.h:53) */
+    int Dy;                                        /* ofdm_pilot_configurator_Dy: 3 (HIGH_DENSITY, every mode's default), 5 with LOW_DENSITY (telecom_system.cc:1848-1869) */
     unsigned pilot_seed, scrambler_seed, preamble_seed;
     int Cwidth, Vwidth;
     /* MFSK modes (ROBUST_0..2 = cfg 100..102): mfsk.cc:48-162, telecom_system.cc:2968-2989 */
@@ -140,7 +141,7 @@ static void build_constellation(morc* o) {
 
 /* cl_pilot_configurator::configure + init — ofdm.cc:904-952, :976-1064 */
 static void build_pilots(morc* o) {
-    int Nc = o->Nc, Ns = o->Nsymb, Dx = 1, Dy = 3;
+    int Nc = o->Nc, Ns = o->Nsymb, Dx = 1, Dy = o->Dy;
     int Ncm = Nc > Ns ? Nc : Ns;
     int* vc = calloc((size_t)Ncm * Ncm, sizeof(int));
     int x = 0, y = 0;
@@ -299,10 +300,21 @@ morc* morc_create(int cfg, int max_iters, const char* tables_path) {
  * (an even value is incremented, telecom_system.cc:2802-2809), pilot / bit-energy-dispersal / preamble PRNG seeds */
 morc* morc_create_explicit(int cfg, int max_iters, const char* tables_path, float pilot_boost, int ls_window, unsigned pilot_seed,
                            unsigned scrambler_seed, unsigned preamble_seed) {
+    return morc_create_geometry(cfg, max_iters, tables_path, pilot_boost, ls_window, pilot_seed, scrambler_seed, preamble_seed, 0, 0);
+}
+
+/* ... and the frame geometry load_configuration copies from default_configurations_telecom_system (telecom_system.cc:2772-2778): the number
+ * of OFDM symbols per frame (ofdm_Nsymb) and the pilot lattice's row period (ofdm_pilot_configurator_Dy); 0 = what init() selects for the
+ * HIGH_DENSITY default (telecom_system.cc:1810-1869). The reference's LOW_DENSITY option is (40, 5) BPSK, (20, 5) QPSK, (10, 5) 16QAM.
+ * Refused: MFSK modes, and a geometry whose data cells hold more bits than a codeword or leave no payload. */
+morc* morc_create_geometry(int cfg, int max_iters, const char* tables_path, float pilot_boost, int ls_window, unsigned pilot_seed,
+                           unsigned scrambler_seed, unsigned preamble_seed, int Nsymb, int Dy) {
     int robust = cfg >= 100 && cfg <= 102;                       /* common_defines.h:63-65 */
     int eM, erate, epre, eest;
     int is_explicit = explicit_row(cfg, &eM, &erate, &epre, &eest);
     if (!robust && !is_explicit && (cfg < 0 || cfg > 16)) return NULL;
+    if (robust && (Nsymb != 0 || Dy != 0)) return NULL;
+    if (Nsymb < 0 || Nsymb > 255 || Dy < 0 || Dy > 255) return NULL;
     morc* o = calloc(1, sizeof(morc));
     o->cfg = cfg;
     int rate16;
@@ -320,6 +332,8 @@ morc* morc_create_explicit(int cfg, int max_iters, const char* tables_path, floa
     o->P = o->N - o->K;
     o->Nc = 50; o->Nfft = 256; o->Ngi = 16; o->Nofdm = 272;
     o->Nsymb = o->M == 2 ? 48 : o->M == 4 ? 24 : o->M == 8 ? 16 : o->M == 16 ? 12 : 9;
+    if (Nsymb > 0) o->Nsymb = Nsymb;
+    o->Dy = Dy > 0 ? Dy : 3;
     o->bps = o->M == 2 ? 1 : o->M == 4 ? 2 : o->M == 8 ? 3 : o->M == 16 ? 4 : 5;
     o->lsw = ls_window % 2 == 0 ? ls_window + 1 : ls_window;     /* telecom_system.cc:2802-2809 */
     o->boostf = pilot_boost; o->pilot_seed = pilot_seed; o->scrambler_seed = scrambler_seed; o->preamble_seed = preamble_seed;
@@ -342,6 +356,7 @@ morc* morc_create_explicit(int cfg, int max_iters, const char* tables_path, floa
     o->nBits = o->nData * o->bps;
     o->nVirtual = o->N - o->nBits;
     o->nReal = o->nBits - o->P;
+    if (o->nVirtual < 0 || o->nVirtual > o->K || o->nReal < 24) { free(o->type); free(o->pilot_seq); free(o->pilot_grid); free(o); return NULL; }
     o->bit_blk = o->nBits / 10; o->tf_blk = o->nData / 10;       /* telecom_system.cc:2910-2911 */
     o->active_nbits = o->nBits;
     prng_t p; prng_seed(&p, o->scrambler_seed);                  /* telecom_system.cc:1961-1966 */

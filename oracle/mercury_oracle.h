@@ -72,6 +72,9 @@ morc* morc_create(int cfg, int max_iters, const char* tables_path);
 /* with the parameters physical_config.cc:35-65 gives every mode spelled out (morc_create: 1.33f, 20, 0, 0, 1) */
 morc* morc_create_explicit(int cfg, int max_iters, const char* tables_path, float pilot_boost, int ls_window, unsigned pilot_seed,
                            unsigned scrambler_seed, unsigned preamble_seed);
+/* ... and ofdm_Nsymb / ofdm_pilot_configurator_Dy (telecom_system.cc:2772-2778; 0 = the HIGH_DENSITY defaults of init(), :1810-1869) */
+morc* morc_create_geometry(int cfg, int max_iters, const char* tables_path, float pilot_boost, int ls_window, unsigned pilot_seed,
+                           unsigned scrambler_seed, unsigned preamble_seed, int Nsymb, int Dy);
 void morc_destroy(morc*);
 void morc_get_info(morc*, morc_info*);
 void morc_set_ctrl_mode(morc*, int enable);         /* cl_telecom_system::set_mfsk_ctrl_mode, telecom_system.cc:1572 */

@@ -130,14 +130,20 @@ static bool explicit_row(int cfg, ModeRow* row) {
     return true;
 }
 
+void* mref_create_geometry(int cfg, int max_iters, float pilot_boost, int ls_window, unsigned pilot_seed, unsigned scrambler_seed,
+                           unsigned preamble_seed, int Nsymb_in, int Dy_in);
 void* mref_create_explicit(int cfg, int max_iters, float pilot_boost, int ls_window, unsigned pilot_seed, unsigned scrambler_seed,
-                           unsigned preamble_seed);
+                           unsigned preamble_seed) {
+    return mref_create_geometry(cfg, max_iters, pilot_boost, ls_window, pilot_seed, scrambler_seed, preamble_seed, 0, 0);
+}
 void* mref_create(int cfg, int max_iters) { return mref_create_explicit(cfg, max_iters, 1.33f, 20, 0u, 0u, 1u); }
 
 // the same with the values physical_config.cc:35-65 holds for every mode passed in (what load_configuration copies from
 // default_configurations_telecom_system, telecom_system.cc:2772-2811)
-void* mref_create_explicit(int cfg, int max_iters, float pilot_boost, int ls_window, unsigned pilot_seed, unsigned scrambler_seed,
-                           unsigned preamble_seed) {
+// ... and ofdm_Nsymb / ofdm_pilot_configurator_Dy, which load_configuration copies the same way (telecom_system.cc:2775-2778); 0 = what
+// init() selects for the HIGH_DENSITY default (telecom_system.cc:1810-1869)
+void* mref_create_geometry(int cfg, int max_iters, float pilot_boost, int ls_window, unsigned pilot_seed, unsigned scrambler_seed,
+                           unsigned preamble_seed, int Nsymb_in, int Dy_in) {
     const bool robust = cfg >= ROBUST_0 && cfg <= ROBUST_2;   // common_defines.h:63-65
     ModeRow explicit_m = {0, 0, 0, 0};
     const bool is_explicit = explicit_row(cfg, &explicit_m);
@@ -172,9 +178,11 @@ void* mref_create_explicit(int cfg, int max_iters, float pilot_boost, int ls_win
         if (cfg == ROBUST_0) r->mfsk.init(32, 50, 1); else r->mfsk.init(16, 50, 2);
         Nsymb = N_MAX / r->mfsk.bits_per_symbol();
     }
+    if (robust && (Nsymb_in != 0 || Dy_in != 0)) { delete r; return nullptr; }
+    if (Nsymb_in > 0) Nsymb = Nsymb_in;
     r->ofdm.Nsymb = Nsymb;
     r->ofdm.pilot_configurator.Dx = 1;
-    r->ofdm.pilot_configurator.Dy = robust ? Nsymb : 3;     // telecom_system.cc:1873-1877
+    r->ofdm.pilot_configurator.Dy = robust ? Nsymb : Dy_in > 0 ? Dy_in : 3;     // telecom_system.cc:1873-1877
     r->ofdm.pilot_configurator.first_row = DATA;
     r->ofdm.pilot_configurator.last_row = DATA;
     r->ofdm.pilot_configurator.first_col = DATA;

@@ -159,6 +159,32 @@ int main(int argc, char** argv) {
                 const mgpu::st_receive_stats st1 = phy.receive_byte(win.data(), got.data());     // the default receiver must not take it
                 if (st1.message_decoded) return 16;
             }
+            // ofdm_pilot_density = LOW_DENSITY as cl_telecom_system::init resolves it (telecom_system.cc:1828-1836, :1857-1865): Dy 5 and 40 / 20 / 10
+            // symbols for BPSK / QPSK / 16QAM - another frame length and another pilot lattice; the frame comes back through a receiver
+            // configured the same way and not through the default one
+            if (cfg < 100 && argc >= 8 && atoi(argv[7]) > 0 && (phy.info.M == 2 || phy.info.M == 4 || phy.info.M == 16)) {
+                mgpu::cl_rx_phy low;
+                low.default_configurations_telecom_system.ofdm_pilot_configurator_Dy = 5;
+                low.default_configurations_telecom_system.ofdm_Nsymb = phy.info.M == 2 ? 40 : phy.info.M == 4 ? 20 : 10;
+                low.load_configuration(cfg);
+                if (low.info.Nsymb != low.default_configurations_telecom_system.ofdm_Nsymb || low.info.nBits != 1600 || low.info.nPilots * 5 != low.info.Nsymb * 50) return 17;
+                const int lt = low.total_frame_size();
+                if (lt >= total) return 18;                                     // fewer symbols per frame than with HIGH_DENSITY pilots
+                std::vector<double> al(lt);
+                if (!low.transmit_byte(&msgs[0], pb, al.data(), MGPU_SINGLE_MESSAGE)) return 19;
+                const int nw = low.capture_window_samples();
+                std::vector<double> win(nw, 0.0);
+                for (int i = 0; i < lt && 20000 + i < nw; ++i) win[20000 + i] = al[i];
+                std::vector<int> got(pb, -1);
+                const mgpu::st_receive_stats sl = low.receive_byte(win.data(), got.data());
+                if (!sl.message_decoded) return 20;
+                for (int j = 0; j < pb; ++j) if (got[j] != (msgs[j] & 0xff)) return 21;
+                const int nwh = phy.capture_window_samples();
+                std::vector<double> winh(nwh, 0.0);
+                for (int i = 0; i < lt && 20000 + i < nwh; ++i) winh[20000 + i] = al[i];
+                const mgpu::st_receive_stats sh = phy.receive_byte(winh.data(), got.data());
+                if (sh.message_decoded) return 22;
+            }
             // 4c) the signalling calls the ARQ layer makes: ACK pattern out and back in, signal level, control-frame mode
             const int n = phy.capture_window_samples(), na = phy.ack_pattern_passband_samples();
             std::vector<double> buf(n, 0.0), ack(na);

@@ -247,6 +247,13 @@ EXPLICIT_CASES = [
     (13, dict(pilot_boost=1.33, ls_window=14, pilot_seed=0, scrambler_seed=123456, preamble_seed=99)),
     (16, dict(pilot_boost=2.5, ls_window=20, pilot_seed=77, scrambler_seed=1, preamble_seed=2)),      # ZF estimator: the window is unused
     (4, dict(pilot_boost=0.8, ls_window=1, pilot_seed=3, scrambler_seed=9, preamble_seed=4)),          # a window of one cell
+    # frame geometry (round 6): ofdm_Nsymb / ofdm_pilot_configurator_Dy as load_configuration copies them (telecom_system.cc:2775-2778)
+    (8, dict(Nsymb=20, Dy=5)),                                                   # the reference's LOW_DENSITY option, QPSK (telecom_system.cc:1828-1836, :1857-1865)
+    (0, dict(Nsymb=40, Dy=5, ls_window=9, pilot_seed=2)),                        # LOW_DENSITY, BPSK
+    (13, dict(Nsymb=10, Dy=5, pilot_boost=1.5)),                                 # LOW_DENSITY, 16QAM
+    (16, dict(Nsymb=8, Dy=4)),                                                   # 32QAM, zero-forcing estimator, 100 virtual bits
+    (4, dict(Nsymb=45, Dy=3)),                                                   # the default lattice on a shorter frame: 100 virtual bits
+    (8, dict(Nsymb=18, Dy=9, ls_window=21)),                                     # two pilots per column: every data row extrapolates or spans 9 rows
 ]
 
 

@@ -165,22 +165,24 @@ class _Base:
 
 
 # physical_config.cc:35-65: what every mode gets unless a context overrides it (mgpu_create_explicit / morc_create_explicit)
-EXPLICIT_DEFAULTS = dict(pilot_boost=1.33, ls_window=20, pilot_seed=0, scrambler_seed=0, preamble_seed=1)
+EXPLICIT_DEFAULTS = dict(pilot_boost=1.33, ls_window=20, pilot_seed=0, scrambler_seed=0, preamble_seed=1, Nsymb=0, Dy=0)
 
 
 class Oracle(_Base):
     prefix = "morc_"
 
     def __init__(self, cfg, max_iters=50, explicit=None):
-        """explicit: dict(pilot_boost, ls_window, pilot_seed, scrambler_seed, preamble_seed) overriding physical_config.cc:35-65"""
+        """explicit: dict(pilot_boost, ls_window, pilot_seed, scrambler_seed, preamble_seed, Nsymb, Dy) overriding physical_config.cc:35-65
+        (Nsymb / Dy 0 = what init() selects, telecom_system.cc:1810-1869)"""
         if not os.path.exists(ORACLE_SO):
             build_oracle()
         self.lib = C.CDLL(ORACLE_SO)
-        self.lib.morc_create_explicit.restype = C.c_void_p
+        self.lib.morc_create_geometry.restype = C.c_void_p
         x = dict(EXPLICIT_DEFAULTS)
         x.update(explicit or {})
-        h = self.lib.morc_create_explicit(C.c_int(cfg), C.c_int(max_iters), TABLES.encode(), C.c_float(x["pilot_boost"]), C.c_int(x["ls_window"]),
-                                          C.c_uint(x["pilot_seed"]), C.c_uint(x["scrambler_seed"]), C.c_uint(x["preamble_seed"]))
+        h = self.lib.morc_create_geometry(C.c_int(cfg), C.c_int(max_iters), TABLES.encode(), C.c_float(x["pilot_boost"]), C.c_int(x["ls_window"]),
+                                          C.c_uint(x["pilot_seed"]), C.c_uint(x["scrambler_seed"]), C.c_uint(x["preamble_seed"]),
+                                          C.c_int(x["Nsymb"]), C.c_int(x["Dy"]))
         if not h:
             raise RuntimeError("morc_create failed")
         self.h = C.c_void_p(h)
@@ -284,11 +286,14 @@ class RefLib(_Base):
 
     def __init__(self, cfg, max_iters=50, explicit=None):
         self.lib = C.CDLL(REF_SO)
-        self.lib.mref_create_explicit.restype = C.c_void_p
+        self.lib.mref_create_geometry.restype = C.c_void_p
         x = dict(EXPLICIT_DEFAULTS)
         x.update(explicit or {})
-        self.h = C.c_void_p(self.lib.mref_create_explicit(C.c_int(cfg), C.c_int(max_iters), C.c_float(x["pilot_boost"]), C.c_int(x["ls_window"]),
-                                                          C.c_uint(x["pilot_seed"]), C.c_uint(x["scrambler_seed"]), C.c_uint(x["preamble_seed"])))
+        self.h = C.c_void_p(self.lib.mref_create_geometry(C.c_int(cfg), C.c_int(max_iters), C.c_float(x["pilot_boost"]), C.c_int(x["ls_window"]),
+                                                          C.c_uint(x["pilot_seed"]), C.c_uint(x["scrambler_seed"]), C.c_uint(x["preamble_seed"]),
+                                                          C.c_int(x["Nsymb"]), C.c_int(x["Dy"])))
+        if not self.h:
+            raise RuntimeError("mref_create failed")
         self.max_iters = max_iters
         self._init_info()
 

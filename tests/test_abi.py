@@ -37,19 +37,24 @@ def test_struct_layouts_match_header():
     assert C.sizeof(Config) == 40               # 7 ints, 1 float, mfsk_ctrl_mode, test_puncture_nBits
     assert C.sizeof(Info) == 4 * 32
     from mercury_amd.physical_layer import ExplicitParams
-    assert C.sizeof(ExplicitParams) == 40       # float, 2 ints, 3 unsigned, 4 ints (mgpu_explicit_params)
+    assert C.sizeof(ExplicitParams) == 44       # float, 2 ints, 3 unsigned, 5 ints (mgpu_explicit_params)
 
 
 def test_explicit_parameters_are_validated_before_any_device_work():
-    """mgpu_create_explicit: geometry other than the reference's is MGPU_ERR_UNSUPPORTED, bad values MGPU_ERR_ARG - on any machine."""
+    """mgpu_create_explicit: Nc / Nfft / Dx other than the reference's are MGPU_ERR_UNSUPPORTED, bad values MGPU_ERR_ARG, a frame geometry
+    (Dy, Nsymb) whose data cells do not fit a codeword MGPU_ERR_TABLES - on any machine, before any device work."""
     from mercury_amd import load_library
     from mercury_amd.physical_layer import Config, ExplicitParams
     lib = load_library()
     h = C.c_void_p()
     good = Config(8, 50, 1, 1, 1, 0, 16, 0.0)
-    for xp, want in ((ExplicitParams(0.0, 0, 0, 0, 0, 0, 64, 0, 0, 0), 4), (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 512, 0, 0), 4),
-                     (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 0, 2, 0), 4), (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 0, 0, 4), 4),
-                     (ExplicitParams(0.0, 23, 0, 0, 0, 0, 0, 0, 0, 0), 1), (ExplicitParams(-1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0), 1)):
+    for xp, want in ((ExplicitParams(0.0, 0, 0, 0, 0, 0, 64, 0, 0, 0, 0), 4), (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 512, 0, 0, 0), 4),
+                     (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0), 4),
+                     (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 0), 3),        # mode 8's 24 symbols with Dy = 4: 1800 bits in the data cells
+                     (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 0, 0, 5, 24), 3),       # LOW_DENSITY lattice on the HIGH_DENSITY frame length: 1920 bits
+                     (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 6), 3),        # too short: fewer bits than the code's parity
+                     (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 0, 0, -1, 0), 1), (ExplicitParams(0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 256), 1),
+                     (ExplicitParams(0.0, 23, 0, 0, 0, 0, 0, 0, 0, 0, 0), 1), (ExplicitParams(-1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), 1)):
         rc = lib.mgpu_create_explicit(C.byref(good), C.byref(xp), C.byref(h))
         assert rc == want and not h.value, (rc, want)
         assert lib.mgpu_last_error(None)

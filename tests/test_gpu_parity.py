@@ -202,11 +202,16 @@ def test_explicit_parameters_match_oracle(cfg, x):
 
 def test_explicit_parameters_are_checked():
     from mercury_amd.physical_layer import MgpuError
-    for bad in (dict(Nc=64), dict(Nfft=512), dict(Dy=4), dict(ls_window=23), dict(pilot_boost=-1.0)):
+    for bad in (dict(Nc=64), dict(Nfft=512), dict(Dx=2), dict(Dy=4), dict(Dy=5), dict(Nsymb=30), dict(Nsymb=64, Dy=2), dict(ls_window=23), dict(pilot_boost=-1.0)):
         with pytest.raises(MgpuError):
             _rx(8, explicit=bad)
-    rx = _rx(8, explicit=dict(Nc=50, Nfft=256, Dx=1, Dy=3))       # the reference's geometry spelled out = the defaults
-    assert rx.ls_window == 21
+    with pytest.raises(MgpuError):
+        _rx(100, explicit=dict(Nsymb=100))                          # the MFSK modes take their frame length from the codeword
+    rx = _rx(8, explicit=dict(Nc=50, Nfft=256, Dx=1, Dy=3, Nsymb=24))       # the reference's geometry spelled out = the defaults
+    assert rx.ls_window == 21 and rx.Nsymb == 24 and rx.nPilots == 400
+    rx.close()
+    rx = _rx(8, explicit=dict(Nsymb=20, Dy=5))                      # the reference's LOW_DENSITY option for QPSK (telecom_system.cc:1828-1865)
+    assert (rx.Nsymb, rx.nPilots, rx.nData, rx.nBits, rx.frame_samples) == (20, 200, 800, 1600, 20 * 272)
     rx.close()
 
 
@@ -319,6 +324,30 @@ def test_ldpc_iteration_cap(max_iters):
         rb, ri = orc.ldpc_decode(llr[f])
         assert iters[f] == ri and np.array_equal(bits[f], rb.astype(np.uint8))
     assert iters[2] == max_iters + 1
+
+
+@pytest.mark.parametrize("weights", ["100,45", "0", "1000000", "20,5", "1000000,0", "0,1000000"])
+@pytest.mark.parametrize("cfg,max_iters", [(8, 50), (8, 1), (8, 2), (8, 3), (8, 4), (8, 9), (12, 50), (12, 2), (0, 12)])
+def test_ldpc_spa_look_policy_changes_no_bit_and_no_count(cfg, max_iters, weights, monkeypatch):
+    """ldpc.hip "adaptive": in a frame's first iterations the syndrome of an iteration's posteriors is tested either by a pass of its own or
+    inside the next check pass, chosen from a sampled syndrome weight (api.hip: MERCURY_SPA_SPEC_WEIGHT="first look,later looks"). Whatever
+    the thresholds - the defaults, always inside the check pass, never, and mixtures that switch forms from look to look - bits and
+    iteration counts are the reference's (ldpc_decoder_SPA.cc:176-196), at iteration caps that end a frame in either form."""
+    monkeypatch.setenv("MERCURY_SPA_SPEC_WEIGHT", weights)
+    orc = Oracle(cfg, max_iters)
+    op = OPERATING_ESN0[cfg]
+    snrs = [op + 6.0] * 3 + [op + 2.0] * 5 + [op + 0.5] * 5 + [op - 1.0] * 5 + [op - 2.5] * 3 + [-15.0] * 2
+    bb, _ = _frames(orc, snrs, seed=1234)
+    llr = np.stack([orc.rx(b, FLAGS_BASEBAND_TEST | oraclelib.FLAG_NO_LDPC)["llr_ldpc"] for b in bb])
+    rx = _rx(cfg, max_iters=max_iters, max_batch=len(snrs))
+    bits, iters = rx.ldpc_decode(llr)
+    seen = set()
+    for f in range(len(snrs)):
+        rb, ri = orc.ldpc_decode(llr[f])
+        seen.add(ri)
+        assert iters[f] == ri, (cfg, max_iters, weights, f, iters[f], ri)
+        assert np.array_equal(bits[f], rb.astype(np.uint8)), (cfg, max_iters, weights, f, "bits differ", ri)
+    assert max_iters + 1 in seen and len(seen) >= 2        # the batch holds frames that leave early and frames that never do
 
 
 @pytest.mark.parametrize("cfg", [2, 8, 13, 16])
