@@ -138,19 +138,25 @@ void ctx_alloc(mgpu_ctx* c) {
     l.S = d.S; l.N = d.N; l.P = d.P; l.K = d.K; l.E = d.E; l.nReal = d.nReal; l.payload_stride = d.payload_stride;
     l.max_iters = d.max_iters; l.minsum_alpha = d.minsum_alpha;
     l.hard_frames = reinterpret_cast<unsigned long long*>(c->keep(upload(std::vector<uint64_t>(64, 0))));
-    {   // fp64 decoder, first iterations: from how many odd checks on (estimated from the 16 bins the kernel samples) an iteration's
-        // posteriors are looked at inside the next check pass instead of by a pass of their own (ldpc.hip: "adaptive"): one weight for the
-        // look at the channel's hard decisions (the first iteration removes far more errors than any later one), one for the later looks.
-        // Results do not depend on them. MERCURY_SPA_SPEC_WEIGHT="first,later" for experiments (0 = always inside the check pass).
-        int w0 = 100, w1 = 45;
-        if (const char* e = getenv("MERCURY_SPA_SPEC_WEIGHT")) { if (sscanf(e, "%d,%d", &w0, &w1) == 1) w1 = w0; }
+    {   // fp64 decoder, a frame's first iterations (ldpc.hip "adaptive"): from how many odd checks on - estimated from the 16 bins a judged look
+        // samples - the next iteration's posteriors (the next two iterations') are looked at inside the following check pass instead of by a
+        // pass of their own. Two pairs of weights: for the look at the channel's hard decisions (the first iteration removes far more errors
+        // than any later one) and for the later looks; defaults from tests/tools/unsat_profile.py and profiles/r06_ab_spec*.txt. Results do
+        // not depend on them. MERCURY_SPA_SPEC_WEIGHT="first:1,first:2,later:1,later:2" for experiments (0 = always, a huge value = never).
+        int w[4] = {100, 230, 45, 150};
+        if (const char* e = getenv("MERCURY_SPA_SPEC_WEIGHT")) {
+            const int n = sscanf(e, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]);
+            if (n == 1) { w[1] = w[2] = w[3] = w[0]; }
+            else if (n == 2) { w[2] = w[0]; w[3] = w[1]; }
+            else if (n == 3) { w[3] = w[2]; }
+        }
         const int nbins = d.S / 64 > 0 ? d.S / 64 : 1;
         auto sample_min = [&](int weight) {
             const long long m = (static_cast<long long>(weight) * 16 + nbins - 1) / nbins;
             return weight <= 0 ? 0 : (m > 0x7fffff ? 0x7fffff : int(m));
         };
-        l.spec_sample_min0 = sample_min(w0);
-        l.spec_sample_min = sample_min(w1);
+        auto byte = [&](int weight) { const int m = sample_min(weight); return unsigned(m > 255 ? 255 : m); };      // (a wavefront's first bin holds at most 64 checks, 16 wavefronts: "never" is any value above 1024 - 255 stands for it, see ldpc.hip)
+        l.spec_sample_pack = byte(w[0]) | byte(w[1]) << 8 | byte(w[2]) << 16 | byte(w[3]) << 24;
     }
     HIPCK(hipStreamCreate(&c->stream));
     for (auto& q : c->ev) for (auto& e : q) HIPCK(hipEventCreate(&e));

@@ -78,7 +78,11 @@ struct LdpcDev {
     const uint32_t* vinfo2;  // vinfo with LDS byte offsets
     int DM;
     int S, N, P, K, E, nReal, payload_stride, max_iters;
-    int spec_sample_min0, spec_sample_min;   // fp64 decoder: a look that counts at least this many odd checks in bins 0..15 sends the next look into the check pass (ldpc.hip); 0: the look at the channel's hard decisions
+    // fp64 decoder (ldpc.hip "adaptive"): a judged look that counts at least _min (_two) odd checks in bins 0..15 sends the next look (the next two)
+    // into the check pass; ..0: the thresholds of the look at the channel's hard decisions
+    // (one byte each, lowest first: min0, two0, min, two - ONE kernel argument: the compiler keeps every argument the loop uses in a scalar
+    // register from the kernel's first instruction on, and the fp64 decoder's bin loop has none to spare)
+    unsigned spec_sample_pack;
     float minsum_alpha;
     unsigned long long* hard_frames;   // [64] fp64 decoder: +1 (in counter frame % 64) per frame decided before its first iteration (every |LLR| >= 200 and an odd parity check), mgpu_decoder_hard_frames
 };

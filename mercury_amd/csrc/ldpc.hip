@@ -262,10 +262,11 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     constexpr bool kWaveShortcuts = NE == 8;
     constexpr bool kVaResident = !kWaveShortcuts;
     // The adaptive look policy (below) is built into the kernels of rates 1/16 .. 8/16 only. Rate 14/16 keeps the fixed schedule of rounds 2-5
-    // (judged looks in a frame's first kSpecStart iterations): its bin loop is the one the scalar unit bounds, and the sample count's scalar
-    // registers cost it seven more scalar copies per bin (+2.5 % / +3.3 % on a mode-16 launch at 13 / -15 dB, same-box) against gains of
-    // 0-1 % on modes 12 / 14 at their operating points (profiles/r06_ab_spec.txt).
+    // (judged looks in a frame's first kSpecStart iterations): its 200 checks fill 116 bins, so the 16 sampled bins hold some 20 checks - too
+    // few to steer anything - and modes 12 / 14 leave after one or two iterations at their operating points (nothing to skip); measured with the
+    // policy switched on: +1 ... +2 % on mode 12 at 7.5 / 8.5 dB (profiles/r06_ab_spec_sweep.txt).
     constexpr bool kAdaptive = !kWaveShortcuts;
+    constexpr int kSpecStart = SPA_SPEC_START;      // from this iteration on every look at the posteriors is taken inside the next check pass
     SPA_STAMP_DECL(F);
     SPA_STAMP(1);                                   // 1: start
     // Before the first iteration every R is zero, so Q = posterior - R is the channel LLR on every edge of a variable and T = tanh(Q/2) is
@@ -356,9 +357,10 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     auto bin_odd_count = [&](unsigned long long pre, unsigned long long used, unsigned long long ends) -> int {
         return __builtin_popcountll(pre ^ (((pre << 1) + (used & ~ends)) & ends));
     };
-    // What a look at the posteriors leaves in flag[p & 1]: 0 = every check satisfied; otherwise the number of wavefronts that saw an odd check
-    // (low byte) + 256 x the number of odd checks in bins 0..15 (every wavefront's first bin: a SAMPLE of the syndrome's weight, 16 of the
-    // code's 56-116 bins). The sample steers only where the next look is taken (below: "adaptive"), never what it sees.
+    // What a JUDGED look at the posteriors (syn_judge) leaves in flag[p & 1]: 0 = every check satisfied; otherwise the number of wavefronts that
+    // saw an odd check (low byte) + 256 x the number of odd checks in bins 0..15 (every wavefront's first round: a SAMPLE of the syndrome's
+    // weight, 16 of the code's 56-116 bins). The sample steers only where the next looks are taken (below: "adaptive"), never what they see.
+    // A look taken inside a check pass leaves 0 or 1.
     auto flag_report = [&](int p, bool unsat, int cnt) {
         if (unsat && (tid & 63) == 0) __hip_atomic_fetch_add(&flag[p & 1], 1 + (cnt << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
@@ -412,7 +414,6 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         constexpr bool first = decltype(first_tag)::value;      // the first pass is a copy of the loop of its own: the steady-state loop carries no test for it
                                                                 // (measured: the test as a run-time flag costs the headline 1.6 %; a copy per syndrome mode as well costs 0.7 %)
         bool unsat = false;
-        int cnt = -1;                                                  // odd checks in the wavefront's first bin (the sample: flag_report)
         const int nbins = T.S >> 6;
         const uint32_t lane8 = (tid & 63) * 8;
         int b = wave;
@@ -433,15 +434,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             if ((tid & 63) == 0) nxt = atomicAdd(ctr, 1);
             // one odd check settles the pass, so the wave's later bins skip the test: the ballot -> prefix-XOR chain is a dependent run of
             // scalar instructions on the bin's critical path (6.27 -> 6.06 ms per 4096 x 50 on the headline, where the first bin settles it)
-            if constexpr (kAdaptive) {
-                if (with_syndrome && !unsat) {
-                    const unsigned long long pre = bin_prefix(__ballot(lt < 0) & vm, en);
-                    if (cnt < 0) cnt = bin_odd_count(pre, vm, en);
-                    unsat = pre != 0;
-                }
-            } else {
-                if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vm, en);
-            }
+            if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vm, en);
             if (valid) {
                 double t;
                 if constexpr (first) t = lt;                           // the posterior array holds T itself (see the top of the kernel)
@@ -471,7 +464,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             if (valid) *ldsd(own) = rr;
             b = nxt;
         }
-        if (with_syndrome) flag_report(p, unsat, kAdaptive ? cnt : 0);
+        if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;        // (no sample from here: counted inside the bin loop it cost every launch 0.7-2 %, NOTES R6.8)
     };
 #if SPA_VR_RESIDENT
     // the record of the lane's first variable stays in registers (6); the second one (3 words, rows from 1024 on) is requested every iteration
@@ -481,7 +474,6 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     if constexpr (kVaResident) va = load_var(tid);
     spa_u32x4 vb;
 #endif
-    constexpr int kSpecStart = SPA_SPEC_START;
     int iteration = 0;
     SPA_STAMP(2);                                   // 2: inputs in LDS, tables requested
     syndrome_pass(0);
@@ -497,17 +489,36 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         // Where the look at an iteration's posteriors is taken - "judged": a syndrome-only pass behind the variable update (one more barrier, but a
         // frame that has converged leaves at once); "speculative": inside the next iteration's check pass (no pass of its own, but a frame that has
         // converged has paid a check pass in vain). Rounds 2-5: judged in a frame's first kSpecStart iterations, speculative afterwards. Round 6:
-        // ADAPTIVE in the first kSpecStart iterations - the last look's sample of the syndrome's weight decides: with many odd checks left the
-        // next iteration cannot be the last one in practice (mode 8 at its operating point: 266 -> 64 -> 23 -> 2 -> 0 odd checks of 1000; no frame
-        // of any mode went from more than 41 to 0, tests/tools/unsat_profile.py), so its posteriors are looked at speculatively; below the threshold
-        // (T.spec_sample_min, api.hip) the judged form. Both forms test the same syndrome of the same posteriors: bits and iteration counts do
-        // not depend on the choice (tests/test_gpu_parity.py runs every threshold against the oracle).
-        bool spec = false;                                                   // this iteration's check pass carries the look at the previous iteration's posteriors
-        bool skip = kSpecStart <= 1 || (kAdaptive && (look >> 8) >= T.spec_sample_min0);    // this iteration's posteriors get no judged look
-        for (int it = 1;; ++it) {
+        // ADAPTIVE in the first kSpecStart iterations - a judged look also samples the syndrome's weight (syn_judge), and with many odd checks
+        // left the next iteration - or the next two - cannot be the last one in practice (mode 8 at its operating point: 266 -> 64 -> 23 -> 2 -> 0
+        // odd checks of 1000; no frame of any mode went from more than 41 to 0 in one iteration, from more than 66 at the first one:
+        // tests/tools/unsat_profile.py), so those iterations' posteriors are looked at speculatively and the next judged look comes after them.
+        // Both forms test the same syndrome of the same posteriors: bits and iteration counts do not depend on the choice
+        // (tests/test_gpu_parity.py runs seven threshold sets against the oracle at nine iteration caps). Mode 8: -2.8 % at 3.5 dB, -4 % at 6 dB,
+        // -2.3 % at 1.5 dB, the 50-iteration launches unchanged (profiles/r06_ab_spec.txt). What did NOT work, and shaped this form (NOTES R6.8):
+        // a sample taken by the speculative looks as well (inside the bin loop: +0.7 ... +2 % on every launch - the loop has no scalar
+        // register to spare), and separate kernel arguments for the thresholds (each one is a scalar register from the kernel's first
+        // instruction on: +6 literal moves per bin).
+        // thresholds: bytes of T.spec_sample_pack (255 = never)
+        auto run_after = [&](int lk, int shift) -> int {
+            const int n = lk >> 8, one = int(T.spec_sample_pack >> shift) & 255, two = int(T.spec_sample_pack >> (shift + 8)) & 255;
+            return !kAdaptive ? 0 : (n >= two && two != 255) ? 2 : (n >= one && one != 255) ? 1 : 0;
+        };
+        // The loop's whole control state is ONE scalar register across the check pass: the iteration (low 16 bits), "this iteration's check pass
+        // carries the look at the previous iteration's posteriors" (kCtlSpec) and how many of the coming iterations go without a judged look
+        // (from kCtlRun up). Kept as separate variables they are three more scalar registers across the bin loop, and the allocator - at its
+        // limit there - answered by rematerialising three of fdlibm's double constants in every bin (+6 scalar moves, NOTES R6.8).
+        constexpr int kCtlSpec = 1 << 16, kCtlRun = 1 << 20;
+        int ctl = 1 + kCtlRun * run_after(look, 0);
+        for (;; ++ctl) {
+            asm volatile("" : "+s"(ctl));
+            const int it = ctl & 0xffff;
+            const bool spec = (ctl & kCtlSpec) != 0;
+            const bool skip = it >= kSpecStart || ctl >= kCtlRun;            // this iteration's posteriors get no judged look
             if (it == 1) cn_pass(false, 0, std::true_type());
-            else if (it <= T.max_iters) cn_pass(spec, it - 1, std::false_type());
+            else if (it <= T.max_iters) cn_pass((ctl & kCtlSpec) != 0, it - 1, std::false_type());
             else syndrome_pass(it - 1);
+            asm volatile("" : "+s"(ctl));
 #if !SPA_VR_RESIDENT
             const VarRec va = load_var(tid), vb = load_var(tid + LDPC_THREADS);
 #else
@@ -521,7 +532,6 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
                 look = flag[(it - 1) & 1];
                 if (!look) { iteration = it - 1; break; }
                 if (it > T.max_iters) { iteration = T.max_iters + 1; break; }
-                skip = it >= kSpecStart || (kAdaptive && (look >> 8) >= T.spec_sample_min);
             }
             if (tid == 0) { flag[it & 1] = 0; flag[2 + (it & 1)] = LDPC_THREADS / 64; }
             SynPre pre;
@@ -542,7 +552,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             SPA_STAMP(7);                           // 7: variable update done
             __syncthreads();
             SPA_STAMP(8);                           // 8: behind its barrier
-            spec = skip;
+            ctl = skip ? (ctl | kCtlSpec) - (ctl >= kCtlRun ? kCtlRun : 0) : ctl & ~kCtlSpec;
             if (!skip) {
                 syn_judge(pre, it);
                 SPA_STAMP(3);
@@ -551,7 +561,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
                 look = flag[it & 1];
                 if (!look) { iteration = it; break; }
                 if (it == T.max_iters) { iteration = T.max_iters + 1; break; }
-                skip = it + 1 >= kSpecStart || (kAdaptive && (look >> 8) >= T.spec_sample_min);
+                ctl += kCtlRun * run_after(look, 16);
             }
         }
     }

@@ -65,6 +65,18 @@ void* mrefts_create(int cfg) {
     t->load_configuration(cfg);                      // main.cc:824
     return t;
 }
+// The same with the frame geometry set where a caller of the reference sets it: the public members ofdm_Nsymb / ofdm_pilot_configurator_Dy of
+// default_configurations_telecom_system (physical_config.cc:38-40; AUTO_SELLECT unless given), which load_configuration copies into the DSP
+// objects (telecom_system.cc:2775-2778) in front of init() (telecom_system.cc:1806-1869). <= 0: left at AUTO_SELLECT.
+void* mrefts_create_geometry(int cfg, int Nsymb, int Dy) {
+    Silence s;
+    cl_telecom_system* t = new cl_telecom_system();
+    t->operation_mode = RX_SHM;
+    if (Nsymb > 0) t->default_configurations_telecom_system.ofdm_Nsymb = Nsymb;
+    if (Dy > 0) t->default_configurations_telecom_system.ofdm_pilot_configurator_Dy = Dy;
+    t->load_configuration(cfg);
+    return t;
+}
 void mrefts_destroy(void* h) {
     Silence s;
     delete static_cast<cl_telecom_system*>(h);

@@ -484,12 +484,18 @@ class RefTelecomSystem:
     SO = REF_TS_SO
 
     def _create(self, cfg):
+        if self.geometry:
+            self.lib.mrefts_create_geometry.restype = C.c_void_p
+            return self.lib.mrefts_create_geometry(C.c_int(cfg), C.c_int(self.geometry.get("Nsymb", 0)), C.c_int(self.geometry.get("Dy", 0)))
         self.lib.mrefts_create.restype = C.c_void_p
         return self.lib.mrefts_create(C.c_int(cfg))
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, geometry=None):
+        """geometry: dict(Nsymb, Dy) written into default_configurations_telecom_system.ofdm_Nsymb / ofdm_pilot_configurator_Dy in front of
+        load_configuration (physical_config.cc:38-40, telecom_system.cc:2775-2778)"""
         self.lib = C.CDLL(self.SO, mode=1)            # RTLD_LAZY: the GUI / ARQ / audio-driver functions the units mention stay unbound
         self.cfg = cfg
+        self.geometry = geometry
         self.h = C.c_void_p(self._create(cfg))
         assert self.h.value, "could not create the reference object for cfg %d" % cfg
         o = (C.c_int * 32)()

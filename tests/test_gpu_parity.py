@@ -326,13 +326,14 @@ def test_ldpc_iteration_cap(max_iters):
     assert iters[2] == max_iters + 1
 
 
-@pytest.mark.parametrize("weights", ["100,45", "0", "1000000", "20,5", "1000000,0", "0,1000000"])
+@pytest.mark.parametrize("weights", ["100,230,45,150", "0", "1000000", "20,40,5,10", "1000000,1000000,0,0", "0,1000000,1000000,1000000", "60,1000000,0,30"])
 @pytest.mark.parametrize("cfg,max_iters", [(8, 50), (8, 1), (8, 2), (8, 3), (8, 4), (8, 9), (12, 50), (12, 2), (0, 12)])
 def test_ldpc_spa_look_policy_changes_no_bit_and_no_count(cfg, max_iters, weights, monkeypatch):
     """ldpc.hip "adaptive": in a frame's first iterations the syndrome of an iteration's posteriors is tested either by a pass of its own or
-    inside the next check pass, chosen from a sampled syndrome weight (api.hip: MERCURY_SPA_SPEC_WEIGHT="first look,later looks"). Whatever
-    the thresholds - the defaults, always inside the check pass, never, and mixtures that switch forms from look to look - bits and
-    iteration counts are the reference's (ldpc_decoder_SPA.cc:176-196), at iteration caps that end a frame in either form."""
+    inside the next check pass; a judged look's sampled syndrome weight decides how many of the following looks (0, 1 or 2) are taken the
+    second way (api.hip: MERCURY_SPA_SPEC_WEIGHT="first look: one, two; later looks: one, two"). Whatever the thresholds - the defaults,
+    always inside the check pass, never, and mixtures that switch forms from look to look - bits and iteration counts are the reference's
+    (ldpc_decoder_SPA.cc:176-196), at iteration caps that end a frame in either form."""
     monkeypatch.setenv("MERCURY_SPA_SPEC_WEIGHT", weights)
     orc = Oracle(cfg, max_iters)
     op = OPERATING_ESN0[cfg]

@@ -120,6 +120,30 @@ def test_receive_byte_control_flow_equals_the_reference(cfg):
     ref.close()
 
 
+GEOMETRIES = [(8, dict(Nsymb=20, Dy=5)), (0, dict(Nsymb=40, Dy=5)), (13, dict(Nsymb=10, Dy=5)),      # the reference's LOW_DENSITY frames (telecom_system.cc:1828-1865)
+              (4, dict(Nsymb=45, Dy=3)), (16, dict(Nsymb=8, Dy=4)), (8, dict(Nsymb=18, Dy=9))]
+
+
+@pytest.mark.parametrize("cfg,geo", GEOMETRIES)
+def test_explicit_frame_geometry_equals_the_reference(cfg, geo):
+    """ofdm_Nsymb / ofdm_pilot_configurator_Dy set on the reference's own object the way its callers would (the public members of
+    default_configurations_telecom_system, in front of load_configuration): the sizes init() derives and receive_byte on randomised windows
+    against the oracle created with the same two numbers (morc_create_geometry) - the restatement the GPU's explicit geometry is tested against."""
+    orc, ref = Oracle(cfg, explicit=geo), RefTelecomSystem(cfg, geometry=geo)
+    for k in ("K", "P", "N", "Nsymb", "Nc", "Nfft", "Ngi", "Nofdm", "nData", "nBits", "nVirtual", "nReal", "bit_blk", "tf_blk", "preamble_nsymb", "payload_bytes"):
+        assert ref.info[k] == getattr(orc, k), (cfg, geo, k, ref.info[k], getattr(orc, k))
+    assert (ref.info["Nsymb"], ref.info["nPilots"]) == (geo["Nsymb"], orc.nPilots)
+    assert ref.buffer_samples() == orc.buffer_samples()
+    rng = np.random.default_rng(7100 + cfg)
+    decoded = 0
+    for w, (kind, x, call, state, carrier) in enumerate(windows(orc, rng, 6)):
+        diff, a, b = compare_one(orc, ref, x, carrier, call, state)
+        assert not diff, (cfg, geo, w, kind, call, state, diff, [a.get(k) for k in diff if k in a], [b.get(k) for k in diff if k in b])
+        decoded += b["message_decoded"]
+    assert decoded >= 1, (cfg, geo)
+    ref.close()
+
+
 def test_consecutive_windows_with_the_state_carried_over():
     """A short RX_SHM session: the state one call leaves goes into the next (last good delay and frequency offset steer the next sync)."""
     cfg = 8
