@@ -179,6 +179,18 @@ typedef uint32_t spa_u32x2 __attribute__((ext_vector_type(2)));
 // barriers the loop contains (through a global pointer every load behind a workgroup barrier counts as clobbered and takes
 // the vector memory path), and the compiler keeps track of the outstanding loads itself.
 typedef const uint64_t __attribute__((address_space(4))) * spa_cptr64;
+// ... at a 32-bit BYTE offset from a table's base: the scalar load then takes base + offset register + immediate as it stands, where a 64-bit
+// element index is a multiplication in two halves, a shift and an add-with-carry in front of it (SPA_OFF32 0: the round 2-5 form)
+#ifndef SPA_OFF32
+#define SPA_OFF32 1
+#endif
+#ifndef SPA_ALLLANES
+#define SPA_ALLLANES 1
+#endif
+typedef const char __attribute__((address_space(4))) * spa_cptr8;
+__device__ __forceinline__ spa_cptr64 spa_at(const void* base, uint32_t byte_off) {
+    return (spa_cptr64)((spa_cptr8)(base) + byte_off);
+}
 
 // The product walk. Step j multiplies slot j of the lane's check into the lane's product unless j is the lane's own slot, lies past the
 // check's degree, or the lane is padding: the bin's tabulated lane mask for step j (bmask, a scalar load) says which lanes take the factor.
@@ -252,7 +264,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     const int tid = threadIdx.x, f = blockIdx.x;
     if (f >= F) return;
     if (uint32_t(uintptr_t(smem)) != 0) __builtin_trap();
-    if (tid < int(kSpaOnesBytes / 8)) reinterpret_cast<double*>(smem)[tid] = 1.0;       // the walk's neutral factors (published by the barrier in front of the first pass)
+    if (tid < int(kSpaOnesBytes / 8)) reinterpret_cast<double*>(smem)[tid] = SPA_ALLLANES != 0 && NE != 8 ? 0x1p-10 : 1.0;       // the walk's neutral factors (published by the barrier in front of the first pass); kAllLanes: what a padding lane reads as its "posterior"
     // Rate 14/16 (the only code with checks of degree 46; the only one the zero-forcing modes 15 / 16 use): its wavefronts meet the regimes in
     // which a whole wavefront gets one of tanh's / atanh's immediate answers (spa_math.h: spa_tanh_half_wave, spa_atanh_x2_wave) - round 5:
     // 10.97 -> 8.50 ms per 4096 x 50 on mode 16's hard (+-Inf) LLRs, 10.04 -> 9.22 on mode 14 in noise. The other kernels keep the plain calls:
@@ -266,6 +278,13 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     // few to steer anything - and modes 12 / 14 leave after one or two iterations at their operating points (nothing to skip); measured with the
     // policy switched on: +1 ... +2 % on mode 12 at 7.5 / 8.5 dB (profiles/r06_ab_spec_sweep.txt).
     constexpr bool kAdaptive = !kWaveShortcuts;
+    // Rates 1/16 .. 8/16: the 1-2 % of a bin's lanes that are padding are NOT masked out of the tanh / atanh / the two message stores (three
+    // execution-mask regions = nine scalar instructions per bin). They compute on harmless small values instead - their table entries make
+    // them read LDS address 0 as "posterior", where these kernels keep 2^-10, they enter the product walk with 2^-10 and take no factor (the
+    // walk's masks exclude them), so they sit in the routines' cheapest branches (tanh: k = 0; atanh: |x| < 0.5, direct log1p) and drag
+    // their wavefront into no other - and write to their own padding slots of the message array, which no check and no variable reads. The syndrome's ballot is masked as before. (Rate 14/16 keeps the masks: its wavefront-wide shortcuts
+    // must not see padding lanes.)
+    constexpr bool kAllLanes = SPA_ALLLANES != 0 && !kWaveShortcuts;
     constexpr int kSpecStart = SPA_SPEC_START;      // from this iteration on every look at the posteriors is taken inside the next check pass
     SPA_STAMP_DECL(F);
     SPA_STAMP(1);                                   // 1: start
@@ -420,22 +439,26 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
         spa_u32x2 ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, lane8, b * 512, 0);
         int* ctr = &flag[2 + (p & 1)];
         const spa_cptr64 bh0 = (spa_cptr64)(T.bhead);
-        unsigned long long vm = bh0[size_t(b) * 4], en = bh0[size_t(b) * 4 + 1];
+        unsigned long long vm, en;
+        if constexpr (SPA_OFF32 != 0) { const spa_cptr64 h = spa_at(T.bhead, uint32_t(b) * 32u); vm = h[0]; en = h[1]; }
+        else { vm = bh0[size_t(b) * 4]; en = bh0[size_t(b) * 4 + 1]; }
 #pragma unroll 1
         while (b < nbins) {
             const uint32_t alt = ad.x, achk = ad.y;
             const uint32_t own = kMoff + lane8 + uint32_t(b) * 512u;
-            spa_cptr64 bm = (spa_cptr64)(T.bmask) + size_t(b) * T.DM;
+            spa_cptr64 bm;
+            if constexpr (SPA_OFF32 != 0) { bm = spa_at(T.bmask, uint32_t(b) * (uint32_t(T.DM) * 8u)); asm volatile("" : "+s"(bm)); }     // (opaque: the bin's base address is formed ONCE - folded into the walk's loads it is re-added in front of every step pair)
+            else bm = (spa_cptr64)(T.bmask) + size_t(b) * T.DM;
             const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
             double lt;
-            if (valid) lt = *ldsd(alt);
+            if (kAllLanes || valid) lt = *ldsd(alt);                   // (a padding lane's table entries are 0: it reads a 1.0 at LDS address 0)
             int nxt;                                                   // the next bin, asked for behind this bin's first read
             SPA_UNDEF(nxt);                                            // (only lane 0's value is ever looked at)
             if ((tid & 63) == 0) nxt = atomicAdd(ctr, 1);
             // one odd check settles the pass, so the wave's later bins skip the test: the ballot -> prefix-XOR chain is a dependent run of
             // scalar instructions on the bin's critical path (6.27 -> 6.06 ms per 4096 x 50 on the headline, where the first bin settles it)
             if (with_syndrome && !unsat) unsat = bin_unsat(__ballot(lt < 0) & vm, en);
-            if (valid) {
+            if (kAllLanes || valid) {
                 double t;
                 if constexpr (first) t = lt;                           // the posterior array holds T itself (see the top of the kernel)
                 else if constexpr (kWaveShortcuts) t = spa_tanh_half_wave(lt - *ldsd(own));
@@ -448,20 +471,22 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             // tabulated mask for that step (own slot, slots past the check's degree and padding lanes excluded).
             // Uniform control flow: the masks come through scalar loads, padding lanes read slot 0 and never multiply.
             double temp = 1;
+            if constexpr (kAllLanes) temp = SPA_MAKE(valid ? 0x3ff00000u : 0x3f500000u, 0u);          // padding lanes: 2^-10 (they take no factor), see kAllLanes
             if constexpr (DMX > 16) spa_walk4<0, DMX / 4>(temp, achk, bm, bm[0], bm[1], bm[2], bm[3]);
             else spa_walk<0, DMX / 2>(temp, achk, bm, bm[0], bm[1]);
             // the next bin's addresses and lane masks land in the registers this one is done with, behind the atanh (the tables have a spare round)
             nxt = __builtin_amdgcn_readfirstlane(nxt);
             const int nb = nxt < nbins ? nxt : nbins;
             ad = __builtin_amdgcn_raw_buffer_load_b64(sadr, lane8, nb * 512, 0);
-            vm = bh0[size_t(nb) * 4]; en = bh0[size_t(nb) * 4 + 1];
+            if constexpr (SPA_OFF32 != 0) { const spa_cptr64 h = spa_at(T.bhead, uint32_t(nb) * 32u); vm = h[0]; en = h[1]; }
+            else { vm = bh0[size_t(nb) * 4]; en = bh0[size_t(nb) * 4 + 1]; }
             double rr;
-            if (valid) {
+            if (kAllLanes || valid) {
                 if constexpr (kWaveShortcuts) rr = spa_atanh_x2_wave(temp);
                 else rr = spa_atanh_x2(temp);
             }
             __builtin_amdgcn_wave_barrier();
-            if (valid) *ldsd(own) = rr;
+            if (kAllLanes || valid) *ldsd(own) = rr;
             b = nxt;
         }
         if (with_syndrome && unsat && (tid & 63) == 0) flag[p & 1] = 1;        // (no sample from here: counted inside the bin loop it cost every launch 0.7-2 %, NOTES R6.8)

@@ -54,6 +54,14 @@
 #define SPA_ONE_COMPARE(b) (b) = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(b))   /* a lane condition used by a select AND a branch: compared once, kept as a lane mask */
 #define SPA_ALL(c) (__builtin_amdgcn_ballot_w64(!(c)) == 0)      /* true for every active lane of the wavefront: a scalar branch */
 #define SPA_SGPR(x) asm volatile("" : "+s"(x))       /* a constant that is not an inline operand, kept in scalar registers (an fma's addend would otherwise be moved into vector registers) */
+#ifndef SPA_VCONST
+#define SPA_VCONST 575
+#endif
+/* A double constant that is not an inline operand, materialised in a VECTOR register pair right where it is used: two v_mov_b32 with literals
+ * inside volatile asm statements (so that they are neither hoisted out of the bin loop, where they would occupy registers the loop does not
+ * have, nor turned back into the scalar unit's s_mov_b32 pair). HI / LO are the constant's words (checked at compile time). */
+#define SPA_VREG(bit, x, HI, LO) do { static_assert(__builtin_bit_cast(unsigned long long, x) == ((unsigned long long)(HI) << 32 | (LO)), "SPA_VREG: words do not spell the constant"); \
+    if constexpr ((SPA_VCONST & (bit)) != 0) { uint32_t lo_, hi_; asm volatile("v_mov_b32 %0, " #LO : "=v"(lo_)); asm volatile("v_mov_b32 %0, " #HI : "=v"(hi_)); x##_v = SPA_MAKE(hi_, lo_); } } while (0)
 SPA_FN double spa_recip(double d) {          // 1/d to within an ulp, d normal
     const double r = __builtin_amdgcn_rcp(d);
     const double e = __builtin_fma(-d, r, 1.0);
@@ -77,6 +85,9 @@ static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_
 #define SPA_KEEP(x) (void)(x)
 #define SPA_UNDEF(x) (x) = 0
 #define SPA_SGPR(x) (void)(x)
+#define SPA_VREG(bit, x, HI, LO) (void)(x)
+#undef SPA_VCONST
+#define SPA_VCONST 0
 #define SPA_ALL(c) (c)
 #define SPA_ONE_COMPARE(b) (void)(b)
 SPA_FN double spa_recip(double d) { return d; }
@@ -113,17 +124,19 @@ SPA_FN double spa_one_minus_2_over(double d, double) { return 1.0 - 2.0 / d; }
 
 // tanh(0.5 * q)
 SPA_FN double spa_tanh_half(double q) {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                 invln2 = 1.44269504088896338700e+00;
-    const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
-                 Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
-                 Q5 = -2.01099218183624371326e-07;
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                     invln2 = 1.44269504088896338700e+00;
+    constexpr double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
+                     Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
+                     Q5 = -2.01099218183624371326e-07;
     const uint32_t jq = SPA_BITS_HI(q), iq = jq & 0x7fffffffu;
     const double A = spa_fabs(q);                            // = 2|x| (exact for |x| >= 2^-55)
     SPA_CENSUS(0);
     bool big = iq >= 0x40000000u;                            // |x| >= 1
     SPA_ONE_COMPARE(big);
-    int32_t kk = int32_t(invln2 * A + 0.5);
+    double invln2_v = invln2;
+    SPA_VREG(1, invln2, 0x3ff71547, 0x652b82fe);
+    int32_t kk = int32_t(invln2_v * A + 0.5);
     kk = (iq <= 0x3fd62e42u) ? 0 : kk;
     const double tk = double(kk);
     const double hi = __builtin_fma(-tk, ln2_hi, A);         // A - tk*ln2_hi: the product is exact (|k| < 2^10, ln2_hi has 32 mantissa bits)
@@ -134,14 +147,24 @@ SPA_FN double spa_tanh_half(double q) {
     const uint32_t sm = big ? 0u : 0x80000000u;
     const double r = SPA_MAKE(SPA_BITS_HI(rp) ^ sm, SPA_LO(rp));
     const double x2 = r * r;                                 // 2 hxs
-    const double R1 = 1.0 + x2 * (0.5 * Q1), g2 = x2 * x2;   // g2 = 4 hxs^2
-    const double R2 = 0.25 * Q2 + x2 * (0.125 * Q3), g4 = g2 * g2;      // R2 / 4, 16 hxs^4
-    const double R3 = 0.0625 * Q4 + x2 * (0.03125 * Q5);     // R3 / 16
+    constexpr double q1 = 0.5 * Q1, q2 = 0.25 * Q2, q3 = 0.125 * Q3, q4 = 0.0625 * Q4, q5 = 0.03125 * Q5;
+    double q1_v = q1, q2_v = q2, q3_v = q3, q4_v = q4, q5_v = q5;
+    SPA_VREG(2, q1, 0xbf911111, 0x111110f4);
+    const double R1 = 1.0 + x2 * q1_v, g2 = x2 * x2;         // g2 = 4 hxs^2
+    SPA_VREG(4, q3, 0xbee4ce19, 0x9eaadbb7); SPA_VREG(4, q2, 0x3f3a01a0, 0x19fe5585);
+    const double R2 = q2_v + x2 * q3_v, g4 = g2 * g2;        // R2 / 4, 16 hxs^4
+    SPA_VREG(8, q5, 0xbe3afdb7, 0x6e09c32d); SPA_VREG(8, q4, 0x3e90cfca, 0x86e65239);
+    const double R3 = q4_v + x2 * q5_v;                      // R3 / 16
     const double r1 = R1 + g2 * R2 + g4 * R3;
-    double three = 3.0;
-    SPA_SGPR(three);
-    const double tt = __builtin_fma(-0.5, r1 * r, three);    // 3 - r1*hfx
-    const double den = 6.0 - r * tt;
+    constexpr double three = 3.0;
+    double three_v = three;
+    if constexpr ((SPA_VCONST & 512) == 0) SPA_SGPR(three_v);
+    SPA_VREG(512, three, 0x40080000, 0x0);
+    const double tt = __builtin_fma(-0.5, r1 * r, three_v);  // 3 - r1*hfx
+    constexpr double six = 6.0;
+    double six_v = six;
+    SPA_VREG(16, six, 0x40180000, 0x0);
+    const double den = six_v - r * tt;
     const double e2 = x2 * spa_div_r(r1 - tt, den, spa_recip(den));     // 2 e
     // s_expm1.c's k == 0 ending, x - (x*e - hxs), needs no branch of its own: with k = 0 the correction term c is +-0, so the general
     // e = (x*(e - c) - c) - hxs IS x*e - hxs bit for bit, and the ending is the difference r - e that the k = -1 and k <= -2 endings start from.
@@ -206,10 +229,10 @@ SPA_FN double spa_tanh_half(double q) {
 
 // 2 * atanh(x) for |x| <= 1, with the decoder's clamp of +-1 to +-0.9999999 (ldpc_decoder_SPA.cc:150-156)
 SPA_FN double spa_atanh_x2(double x) {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
-                 Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
-                 Lp7 = 1.479819860511658591e-01;
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    constexpr double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+                     Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+                     Lp7 = 1.479819860511658591e-01;
     if (__builtin_expect(spa_fabs(x) == 1.0, 0)) {
         x = SPA_MAKE((SPA_BITS_HI(x) & 0x80000000u) | 0x3fefffffu, 0xca501acbu);      // +-0.9999999
         SPA_CENSUS(13);
@@ -269,10 +292,16 @@ SPA_FN double spa_atanh_x2(double x) {
     const double d3 = __builtin_fma(2.0, fh, 2.0);           // 2 + f
     const double sh = spa_div_r(fh, d3, spa_recip(d3));      // s / 2
     const double zq = sh * sh;                               // z / 4
-    const double R1 = zq * (8 * Lp1), z2 = zq * zq;                      // 2 z Lp1 ; z^2 / 16
-    const double R2 = 32 * Lp2 + zq * (128 * Lp3), z4 = z2 * z2;         // 32 (Lp2 + z Lp3) ; z^4 / 256
-    const double R3 = 512 * Lp4 + zq * (2048 * Lp5), z6 = z4 * z2;       // 512 (Lp4 + z Lp5) ; z^6 / 4096
-    const double R4 = 8192 * Lp6 + zq * (32768 * Lp7);                   // 8192 (Lp6 + z Lp7)
+    constexpr double l1 = 8 * Lp1, l2 = 32 * Lp2, l3 = 128 * Lp3, l4 = 512 * Lp4, l5 = 2048 * Lp5, l6 = 8192 * Lp6, l7 = 32768 * Lp7;
+    double l1_v = l1, l2_v = l2, l3_v = l3, l4_v = l4, l5_v = l5, l6_v = l6, l7_v = l7;
+    SPA_VREG(32, l1, 0x40155555, 0x55555593);
+    const double R1 = zq * l1_v, z2 = zq * zq;                           // 2 z Lp1 ; z^2 / 16
+    SPA_VREG(64, l3, 0x40424924, 0x94229359); SPA_VREG(64, l2, 0x40299999, 0x9997fa04);
+    const double R2 = l2_v + zq * l3_v, z4 = z2 * z2;                    // 32 (Lp2 + z Lp3) ; z^4 / 256
+    SPA_VREG(128, l5, 0x40774664, 0x96cb03de); SPA_VREG(128, l4, 0x405c71c5, 0x1d8e78af);
+    const double R3 = l4_v + zq * l5_v, z6 = z4 * z2;                    // 512 (Lp4 + z Lp5) ; z^6 / 4096
+    SPA_VREG(256, l7, 0x40b2f112, 0xdf3e5244); SPA_VREG(256, l6, 0x40939a09, 0xd078c69f);
+    const double R4 = l6_v + zq * l7_v;                                  // 8192 (Lp6 + z Lp7)
     const double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;                   // 2 R
     const double sr = sh * __builtin_fma(4.0, hfsqh, R);     // s * (hfsq + R)
     if (direct) {
