@@ -187,6 +187,9 @@ typedef const uint64_t __attribute__((address_space(4))) * spa_cptr64;
 #ifndef SPA_ALLLANES
 #define SPA_ALLLANES 1
 #endif
+#ifndef SPA_ALLLANES8
+#define SPA_ALLLANES8 0      /* the same at rate 14/16 (the wavefront-wide shortcuts then look at the bin's real lanes only): bit-exact, 30 scalar instructions fewer per bin, and 0.3 - 1.2 % SLOWER (profiles/r06_ab_al8.txt) - a quarter of that kernel's lanes are padding, and what they compute along drags wavefronts into branches */
+#endif
 typedef const char __attribute__((address_space(4))) * spa_cptr8;
 __device__ __forceinline__ spa_cptr64 spa_at(const void* base, uint32_t byte_off) {
     return (spa_cptr64)((spa_cptr8)(base) + byte_off);
@@ -264,7 +267,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     const int tid = threadIdx.x, f = blockIdx.x;
     if (f >= F) return;
     if (uint32_t(uintptr_t(smem)) != 0) __builtin_trap();
-    if (tid < int(kSpaOnesBytes / 8)) reinterpret_cast<double*>(smem)[tid] = SPA_ALLLANES != 0 && NE != 8 ? 0x1p-10 : 1.0;       // the walk's neutral factors (published by the barrier in front of the first pass); kAllLanes: what a padding lane reads as its "posterior"
+    if (tid < int(kSpaOnesBytes / 8)) reinterpret_cast<double*>(smem)[tid] = SPA_ALLLANES != 0 && NE != 8 ? 0x1p-10 : 1.0;      // (rate 14/16: the walk's own 1.0s - its padding lanes then read 1.0, see kAllLanes)       // the walk's neutral factors (published by the barrier in front of the first pass); kAllLanes: what a padding lane reads as its "posterior"
     // Rate 14/16 (the only code with checks of degree 46; the only one the zero-forcing modes 15 / 16 use): its wavefronts meet the regimes in
     // which a whole wavefront gets one of tanh's / atanh's immediate answers (spa_math.h: spa_tanh_half_wave, spa_atanh_x2_wave) - round 5:
     // 10.97 -> 8.50 ms per 4096 x 50 on mode 16's hard (+-Inf) LLRs, 10.04 -> 9.22 on mode 14 in noise. The other kernels keep the plain calls:
@@ -284,7 +287,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
     // walk's masks exclude them), so they sit in the routines' cheapest branches (tanh: k = 0; atanh: |x| < 0.5, direct log1p) and drag
     // their wavefront into no other - and write to their own padding slots of the message array, which no check and no variable reads. The syndrome's ballot is masked as before. (Rate 14/16 keeps the masks: its wavefront-wide shortcuts
     // must not see padding lanes.)
-    constexpr bool kAllLanes = SPA_ALLLANES != 0 && !kWaveShortcuts;
+    constexpr bool kAllLanes = SPA_ALLLANES != 0 && (!kWaveShortcuts || SPA_ALLLANES8 != 0);
     constexpr int kSpecStart = SPA_SPEC_START;      // from this iteration on every look at the posteriors is taken inside the next check pass
     SPA_STAMP_DECL(F);
     SPA_STAMP(1);                                   // 1: start
@@ -450,6 +453,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             if constexpr (SPA_OFF32 != 0) { bm = spa_at(T.bmask, uint32_t(b) * (uint32_t(T.DM) * 8u)); asm volatile("" : "+s"(bm)); }     // (opaque: the bin's base address is formed ONCE - folded into the walk's loads it is re-added in front of every step pair)
             else bm = (spa_cptr64)(T.bmask) + size_t(b) * T.DM;
             const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
+            const unsigned long long lanes_in_use = vm;                 // (vm is overwritten with the next bin's mask further down)
             double lt;
             if (kAllLanes || valid) lt = *ldsd(alt);                   // (a padding lane's table entries are 0: it reads a 1.0 at LDS address 0)
             int nxt;                                                   // the next bin, asked for behind this bin's first read
@@ -461,7 +465,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             if (kAllLanes || valid) {
                 double t;
                 if constexpr (first) t = lt;                           // the posterior array holds T itself (see the top of the kernel)
-                else if constexpr (kWaveShortcuts) t = spa_tanh_half_wave(lt - *ldsd(own));
+                else if constexpr (kWaveShortcuts) t = spa_tanh_half_wave(lt - *ldsd(own), kAllLanes ? lanes_in_use : ~0ull);
                 else t = spa_tanh_half(lt - *ldsd(own));
                 *ldsd(own) = t;
             }
@@ -482,7 +486,7 @@ __device__ __forceinline__ void spa_decode(const LdpcDev& T, const float* __rest
             else { vm = bh0[size_t(nb) * 4]; en = bh0[size_t(nb) * 4 + 1]; }
             double rr;
             if (kAllLanes || valid) {
-                if constexpr (kWaveShortcuts) rr = spa_atanh_x2_wave(temp);
+                if constexpr (kWaveShortcuts) rr = spa_atanh_x2_wave(temp, kAllLanes ? lanes_in_use : ~0ull);
                 else rr = spa_atanh_x2(temp);
             }
             __builtin_amdgcn_wave_barrier();

@@ -53,6 +53,7 @@
 #define SPA_UNDEF(x) asm volatile("" : "=v"(x))      /* a definition without an instruction */
 #define SPA_ONE_COMPARE(b) (b) = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(b))   /* a lane condition used by a select AND a branch: compared once, kept as a lane mask */
 #define SPA_ALL(c) (__builtin_amdgcn_ballot_w64(!(c)) == 0)      /* true for every active lane of the wavefront: a scalar branch */
+#define SPA_ALL_OF(m, c) ((__builtin_amdgcn_ballot_w64(!(c)) & (m)) == 0)      /* ... for every lane of the mask m */
 #define SPA_SGPR(x) asm volatile("" : "+s"(x))       /* a constant that is not an inline operand, kept in scalar registers (an fma's addend would otherwise be moved into vector registers) */
 #ifndef SPA_VCONST
 #define SPA_VCONST 575
@@ -89,6 +90,7 @@ static inline double spa_make_(uint32_t hi, uint32_t lo) { uint64_t u = (uint64_
 #undef SPA_VCONST
 #define SPA_VCONST 575
 #define SPA_ALL(c) (c)
+#define SPA_ALL_OF(m, c) (c)
 #define SPA_ONE_COMPARE(b) (void)(b)
 SPA_FN double spa_recip(double d) { return d; }
 SPA_FN double spa_div_r(double n, double d, double) { return n / d; }
@@ -338,13 +340,14 @@ SPA_FN double spa_atanh_x2(double x) {
 //    spa_atanh_x2 returns for it: tests/test_spa_math.py). Hard inputs make every product of every wavefront +-1.
 //  * atanh, |x| < 2^-28 -> x (e_atanh.c). A check of high degree far from convergence multiplies several dozen small tanh values: every
 //    product of the wavefront is down there (rate 14/16, noise only: all of them; profiles/r05_spa_branch_census.txt).
-SPA_FN double spa_tanh_half_wave(double q) {
-    if (SPA_ALL(spa_fabs(q) >= 44.0)) { SPA_CENSUS(24); return SPA_MAKE(0x3ff00000u | (SPA_BITS_HI(q) & 0x80000000u), 0u); }
+// (lanes: the wavefront's lanes that count - ldpc.hip's padding lanes compute along on dummy values and must not veto a shortcut)
+SPA_FN double spa_tanh_half_wave(double q, unsigned long long lanes = ~0ull) {
+    if (SPA_ALL_OF(lanes, spa_fabs(q) >= 44.0)) { SPA_CENSUS(24); return SPA_MAKE(0x3ff00000u | (SPA_BITS_HI(q) & 0x80000000u), 0u); }
     return spa_tanh_half(q);
 }
-SPA_FN double spa_atanh_x2_wave(double x) {
+SPA_FN double spa_atanh_x2_wave(double x, unsigned long long lanes = ~0ull) {
     const bool unit = spa_fabs(x) == 1.0, tiny = spa_fabs(x) < 0x1.0p-28;
-    if (SPA_ALL(unit || tiny)) {
+    if (SPA_ALL_OF(lanes, unit || tiny)) {
         SPA_CENSUS(25);
         return unit ? SPA_MAKE((SPA_BITS_HI(x) & 0x80000000u) | 0x4030cfadu, 0x9b61ff69u) : x + x;
     }

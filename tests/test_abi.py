@@ -147,3 +147,34 @@ def test_fp64_decoder_kernels_compile_without_register_spills():
         # carry one read per unrolled walk step each: 2 x 16, at rate 14/16 2 x 48)
         assert body.count("ds_read2_b64") <= 2 and body.count("ds_read2st64_b64") == 0, (kern, "the walk's LDS reads were paired", body.count("ds_read2_b64"))
         assert body.count("ds_read_b64") >= 2 * (48 if ne == 8 else 16), (kern, body.count("ds_read_b64"))
+
+
+def test_fp64_decoder_bin_loop_keeps_its_scalar_unit_savings():
+    """Round 6 (profiles/NOTES.md R6.8, R6.10): a scalar instruction costs the fp64 decoder's bin loop three times a vector one, and the loop has no
+    scalar register to spare - one more value carried across it and the allocator rematerialises fdlibm's double constants as literal pairs in
+    every bin. What that round bought is pinned on the compiler's own assembly (cross-compiled here): the steady-state loop of the headline
+    kernel holds at most 185 scalar instructions (round 5: 232), its polynomial constants are v_mov_b32 literals INSIDE the loop (not hoisted into
+    registers the loop does not have, not turned back into s_mov_b32 pairs), and the kernel uses one kernel argument for the look thresholds."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_count
+    lines = isa_count.assembly("ldpc.hip")
+    kern = "mgpu_ldpc_spa_kernel_ne6"
+    start = next(i for i, l in enumerate(lines) if l.startswith(kern + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+    loops, key = {}, None
+    for l in lines[start:end]:
+        if re.match(r"^\.LBB\d+_\d+:", l) or l.startswith("; %bb."):
+            m = re.search(r"Header=(BB\d+_\d+) Depth=2", l)
+            key = m.group(1) if m else None
+            continue
+        t = l.strip()
+        if key and t and t[0] not in ";.":
+            loops.setdefault(key, []).append(t)
+    steady = max(loops.values(), key=len)                     # the steady-state bin loop (tanh + walk + atanh); the other one is the first pass
+    salu = sum(1 for t in steady if t.startswith("s_") and not t.startswith(("s_waitcnt", "s_nop")))
+    assert salu <= 185, salu
+    lits = [t for t in steady if t.startswith("v_mov_b32") and "0x" in t]
+    assert len(lits) >= 18, len(lits)                         # nine double constants of tanh / atanh as word pairs (SPA_VCONST 575: invln2, Q1..Q5, 3, 6, 8 Lp1)
+    assert sum(1 for t in steady if t.startswith("s_mov_b32") and ", 0x" in t) <= 8, [t for t in steady if t.startswith("s_mov_b32") and ", 0x" in t]
